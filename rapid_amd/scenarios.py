@@ -1,0 +1,217 @@
+"""Seeded synthetic populations and alert streams.
+
+Everything here is host-side tooling: it produces the *inputs* (endpoints, node ids, per-receiver streams of
+packed 20-byte alert records) that are fed, byte for byte, both to the HIP engine and to the CPU oracle.
+It needs the monitoring topology (`subj[n][k]` = subject of n on ring k, i.e. the predecessor table of
+MembershipView.java:308-322) from whoever built the view.
+
+Record layout (include/rapid_mi355x.h, `rapid_alert_record`): int64 cfg_id; uint32 src; uint32 dst;
+uint16 ring_mask; uint8 status (0 = UP, 1 = DOWN); uint8 flags (bit0 = last record of its batch).
+One *batch* = one BatchedAlertMessage (rapid.proto:95-99) = all alerts of one sender.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+ALERT_DTYPE = np.dtype(
+    [("cfg_id", "<i8"), ("src", "<u4"), ("dst", "<u4"), ("ring_mask", "<u2"), ("status", "u1"), ("flags", "u1")]
+)
+FLAG_LAST_IN_BATCH = 1
+UP, DOWN = 0, 1
+SEED_IDS = 0x5241504944  # "RAPID"
+
+_M64 = (1 << 64) - 1
+
+
+def splitmix64(seed, idx):
+    """Stateless splitmix64 of (seed + idx * golden) -- used for NodeIds."""
+    z = (np.uint64(seed) + (np.asarray(idx, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15))
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+@dataclass
+class Population:
+    """N endpoints `10.a.b.c:5000` with splitmix64 NodeIds."""
+
+    n: int
+    hostnames: list = field(default_factory=list)
+    ports: np.ndarray = None
+    id_hi: np.ndarray = None
+    id_lo: np.ndarray = None
+
+    @staticmethod
+    def make(n, seed_ids=SEED_IDS, port=5000):
+        with np.errstate(over="ignore"):
+            i = np.arange(n, dtype=np.uint64)
+            hi = splitmix64(seed_ids, 2 * i).view(np.int64)
+            lo = splitmix64(seed_ids, 2 * i + 1).view(np.int64)
+        hosts = [b"10.%d.%d.%d" % ((j >> 16) & 255, (j >> 8) & 255, j & 255) for j in range(n)]
+        return Population(n, hosts, np.full(n, port, dtype=np.int32), hi.copy(), lo.copy())
+
+    def blob(self):
+        """hostnames as one byte blob + offsets (the C-ABI's rapid_view_build input)."""
+        off = np.zeros(self.n + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(h) for h in self.hostnames])
+        return np.frombuffer(b"".join(self.hostnames), dtype=np.uint8).copy(), off
+
+
+def pick_faulty(n, f, seed):
+    """F distinct nodes by a seeded Fisher-Yates."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return np.sort(rng.permutation(n)[:f]).astype(np.int32)
+
+
+def close_fault_set(faulty, subj, L):
+    """C3b: add every healthy node that has >= L faulty observers until none is left."""
+    n, K = subj.shape
+    is_f = np.zeros(n, dtype=bool)
+    is_f[faulty] = True
+    while True:
+        # spurious reports about s = number of rings k on which s's observer is faulty.  subj[o][k] == s <=> o observes s on k
+        cnt = np.zeros(n, dtype=np.int32)
+        for k in range(K):
+            np.add.at(cnt, subj[is_f, k], 1)
+        add = (~is_f) & (cnt >= L)
+        if not add.any():
+            return np.flatnonzero(is_f).astype(np.int32)
+        is_f |= add
+
+
+@dataclass
+class BatchSet:
+    """The round's global alert set as CSR: batch b = recs[off[b]:off[b+1]], sender[b]."""
+
+    recs: np.ndarray
+    off: np.ndarray
+    sender: np.ndarray
+
+    @property
+    def n_batches(self):
+        return len(self.off) - 1
+
+
+def _merge_reports(obs_idx, subj_idx, ring, cfg_id, status=DOWN):
+    """(observer, subject, ring) triples -> one record per (observer, subject) with a ring mask, grouped into one
+    batch per observer (mirrors addAllRingNumber(getRingNumbers(..)), MembershipService.java:486-492)."""
+    if len(obs_idx) == 0:
+        return BatchSet(np.zeros(0, dtype=ALERT_DTYPE), np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32))
+    key = obs_idx.astype(np.int64) * (1 << 32) + subj_idx.astype(np.int64)
+    order = np.argsort(key, kind="stable")
+    key, ring = key[order], ring[order]
+    uniq, start = np.unique(key, return_index=True)
+    mask = np.bitwise_or.reduceat((1 << ring.astype(np.int64)), start).astype(np.uint16)
+    recs = np.zeros(len(uniq), dtype=ALERT_DTYPE)
+    recs["cfg_id"] = cfg_id
+    recs["src"] = (uniq >> 32).astype(np.uint32)
+    recs["dst"] = (uniq & 0xFFFFFFFF).astype(np.uint32)
+    recs["ring_mask"] = mask
+    recs["status"] = status
+    senders, bstart = np.unique(recs["src"], return_index=True)
+    off = np.concatenate([bstart, [len(recs)]]).astype(np.int64)
+    recs["flags"][off[1:] - 1] = FLAG_LAST_IN_BATCH
+    return BatchSet(recs, off, senders.astype(np.int32))
+
+
+def crash_batches(subj, faulty, cfg_id):
+    """C1/C2/C4 crash faults: every NON-crashed observer o of a crashed s reports s DOWN on the rings where it
+    observes s; crashed observers report nothing (exercises implicit invalidation)."""
+    n, K = subj.shape
+    is_f = np.zeros(n, dtype=bool)
+    is_f[faulty] = True
+    o, k = np.nonzero(is_f[subj] & ~is_f[:, None])  # o healthy, subj[o][k] crashed
+    return _merge_reports(o.astype(np.int32), subj[o, k], k.astype(np.int32), cfg_id)
+
+
+def ingress_loss_batches(subj, faulty, cfg_id):
+    """C3 one-way failures: every observer of a faulty f reports f DOWN, and every faulty f (deaf, but able to
+    send) reports each of its K subjects DOWN."""
+    n, K = subj.shape
+    is_f = np.zeros(n, dtype=bool)
+    is_f[faulty] = True
+    o, k = np.nonzero(is_f[subj] | is_f[:, None])
+    return _merge_reports(o.astype(np.int32), subj[o, k], k.astype(np.int32), cfg_id)
+
+
+def deliver(batches, receivers, seed_delivery, loss=0.0, stale_cfg=None, stale_rate=0.0):
+    """Every receiver gets every batch once, in a receiver-specific seeded order (paper Fig.11 methodology);
+    `loss` drops (receiver, batch) pairs i.i.d.  Returns (records, rec_off[R+1], batches_per_receiver[R]).
+    With `stale_rate`, that fraction of delivered records has its cfg_id replaced by `stale_cfg` (exercises
+    the filter of MembershipService.java:653-657)."""
+    B = batches.n_batches
+    blen = np.diff(batches.off)
+    R = len(receivers)
+    out, rec_off, nb = [], np.zeros(R + 1, dtype=np.int64), np.zeros(R, dtype=np.int32)
+    for i, r in enumerate(receivers):
+        rng = np.random.Generator(np.random.PCG64([int(seed_delivery), int(r)]))
+        perm = rng.permutation(B)
+        if loss > 0:
+            perm = perm[rng.random(B) >= loss]
+        lens = blen[perm]
+        tot = int(lens.sum())
+        # gather indices: for each delivered batch, off[b] + arange(len)
+        starts = np.repeat(batches.off[perm] - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens)
+        idx = starts + np.arange(tot, dtype=np.int64)
+        recs = batches.recs[idx]
+        if stale_rate > 0 and tot:
+            st = rng.random(tot) < stale_rate
+            recs["cfg_id"][st] = stale_cfg
+        out.append(recs)
+        rec_off[i + 1] = rec_off[i] + tot
+        nb[i] = len(perm)
+    records = np.concatenate(out) if out else np.zeros(0, dtype=ALERT_DTYPE)
+    return records, rec_off, nb
+
+
+@dataclass
+class Scenario:
+    name: str
+    n: int
+    K: int
+    H: int
+    L: int
+    faulty: np.ndarray
+    receivers: np.ndarray
+    batches: BatchSet
+    records: np.ndarray = None
+    rec_off: np.ndarray = None
+    n_batches_delivered: np.ndarray = None
+
+
+CONFIGS = {
+    # name: (N, K, H, L, fault fraction / count, kind)
+    "C1": dict(n=50, K=3, H=3, L=1, f=1, kind="crash"),
+    "C2": dict(n=2000, K=10, H=9, L=4, f=20, kind="crash"),
+    "C3a": dict(n=10000, K=10, H=9, L=4, f=500, kind="ingress"),
+    "C3b": dict(n=10000, K=10, H=9, L=4, f=500, kind="ingress_closed"),
+    "C4": dict(n=100000, K=10, H=9, L=4, f=1000, kind="crash"),
+}
+
+
+def build_scenario(name, subj, cfg_id, seed_fault=1, seed_delivery=2, receivers=None, loss=0.0, n=None, f=None,
+                   H=None, L=None, kind=None, materialise=True):
+    """Builds one of the BASELINE.json configurations on the topology `subj` ([N][K] predecessor table)."""
+    c = dict(CONFIGS.get(name, {}))
+    for k_, v in (("n", n), ("f", f), ("H", H), ("L", L), ("kind", kind)):
+        if v is not None:
+            c[k_] = v
+    N, K = subj.shape
+    c.setdefault("n", N)
+    c.setdefault("K", K)
+    assert c["n"] == N, "topology size does not match scenario"
+    faulty = pick_faulty(N, c["f"], seed_fault)
+    if c["kind"] == "ingress_closed":
+        faulty = close_fault_set(faulty, subj, c["L"])
+    if c["kind"] == "crash":
+        bs = crash_batches(subj, faulty, cfg_id)
+    else:
+        bs = ingress_loss_batches(subj, faulty, cfg_id)
+    is_f = np.zeros(N, dtype=bool)
+    is_f[faulty] = True
+    healthy = np.flatnonzero(~is_f).astype(np.int32)
+    rx = healthy if receivers is None else np.asarray(receivers, dtype=np.int32)
+    sc = Scenario(name, N, K, c["H"], c["L"], faulty, rx, bs)
+    if materialise:
+        sc.records, sc.rec_off, sc.n_batches_delivered = deliver(bs, rx, seed_delivery, loss)
+    return sc
