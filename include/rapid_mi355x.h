@@ -1,0 +1,200 @@
+/*
+ * rapid_mi355x.h -- C ABI of the MI355X-native cut-detection / consensus-counting engine.
+ *
+ * This is the drop-in boundary for ONE path of lalithsuresh/rapid: the package-private Java classes
+ * MembershipView, MultiNodeCutDetector and the fast round of FastPaxos, plus the per-batch semantics of
+ * MembershipService.handleMessage(BatchedAlertMessage), replayed for a whole simulated population on the GPU.
+ * Citations are relative to /root/reference/rapid/src/main/java/com/vrg/rapid/ ("R/").
+ *
+ * Conventions:
+ *   - plain C, opaque handles, no C++ types, no exceptions across the boundary;
+ *   - endpoints are dense int32 node indices assigned by the host (members AND known joiners);
+ *   - all inputs are borrowed for the duration of the call; all outputs go to caller-allocated buffers with
+ *     an explicit capacity and an out-count; the library never returns memory it owns;
+ *   - every call returns 0 (RAPID_OK) or a negative code that maps 1:1 onto the Java exception the
+ *     reference would throw; rapid_last_error() returns a human-readable detail;
+ *   - threading: one caller at a time per handle, re-entrant across handles (the reference confines these
+ *     classes to its single "protocol" executor thread, R/SharedResources.java:53); no callbacks into the host.
+ *   - the library fails loudly (RAPID_EDEVICE) when no gfx950 device is usable -- there is no CPU fallback.
+ */
+#ifndef RAPID_MI355X_H
+#define RAPID_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------------------------------------- */
+#define RAPID_OK 0
+#define RAPID_EINVAL (-1)        /* IllegalArgumentException          R/MultiNodeCutDetector.java:52-55      */
+#define RAPID_ENODE_EXISTS (-2)  /* NodeAlreadyInRingException        R/MembershipView.java:133-135, 502-506 */
+#define RAPID_ENODE_MISSING (-3) /* NodeNotInRingException            R/MembershipView.java:172-174, 508-512 */
+#define RAPID_EUUID_SEEN (-4)    /* UUIDAlreadySeenException          R/MembershipView.java:127-129, 514-519 */
+#define RAPID_ECAPACITY (-5)     /* a caller buffer / configured capacity is too small                        */
+#define RAPID_EDEVICE (-6)       /* HIP / RCCL failure, or no gfx950 device                                   */
+#define RAPID_ESTATE (-7)        /* call made in the wrong order (e.g. tally before streams were loaded)      */
+#define RAPID_ECOLLISION (-8)    /* two different proposals shared a fingerprint (verified, never silent)     */
+
+/* ---- JoinStatusCode (rapid/src/main/proto/rapid.proto:84-90) ------------------------------------------ */
+#define RAPID_HOSTNAME_ALREADY_IN_RING 0
+#define RAPID_UUID_ALREADY_IN_RING 1
+#define RAPID_SAFE_TO_JOIN 2
+
+/* ---- EdgeStatus (rapid.proto:114-117) ---------------------------------------------------------------- */
+#define RAPID_EDGE_UP 0
+#define RAPID_EDGE_DOWN 1
+
+/* ---- packed alert record: the device-resident form of AlertMessage (rapid.proto:102-111) ---------------
+ * 20 bytes, 4-byte aligned.  ring_mask bit k <=> ringNumber k (0 <= k < K <= 14); one record = one
+ * AlertMessage whose ringNumber list is the set bits in ascending order (as getRingNumbers produces them,
+ * R/MembershipView.java:397-418).  The joiner's NodeId of an UP alert is the id registered for node `dst`.
+ * flags bit0 marks the last record of its BatchedAlertMessage (rapid.proto:95-99); the end of a receiver's
+ * stream also closes a batch. */
+#pragma pack(push, 1)
+typedef struct rapid_alert_record {
+    int64_t cfg_id;     /* AlertMessage.configurationId */
+    uint32_t src;       /* edgeSrc (stored, never read by the detector -- R/MultiNodeCutDetector.java:101) */
+    uint32_t dst;       /* edgeDst */
+    uint16_t ring_mask; /* ringNumber[] */
+    uint8_t status;     /* RAPID_EDGE_UP / RAPID_EDGE_DOWN */
+    uint8_t flags;      /* RAPID_ALERT_LAST_IN_BATCH */
+} rapid_alert_record;
+#pragma pack(pop)
+#define RAPID_ALERT_LAST_IN_BATCH 1u
+#define RAPID_MAX_K 14
+
+typedef struct rapid_engine rapid_engine; /* one simulated cluster on one GPU */
+typedef struct rapid_cd rapid_cd;         /* one MultiNodeCutDetector instance (device-resident state) */
+typedef struct rapid_fast_round rapid_fast_round; /* one FastPaxos fast-round vote counter */
+
+typedef struct rapid_engine_config {
+    int32_t n_max;     /* capacity in node indices (members + joiners) */
+    int32_t K;         /* rings; 3 <= K <= RAPID_MAX_K        (R/MultiNodeCutDetector.java:39, R/Cluster.java:72) */
+    int32_t H;         /* high watermark, L <= H <= K         (R/Cluster.java:73) */
+    int32_t L;         /* low watermark, 1 <= L               (R/Cluster.java:74) */
+    int32_t device_id; /* HIP device ordinal */
+    int32_t max_cut;   /* capacity of one receiver's proposal list; 0 = default (min(n_max, 4096)) */
+} rapid_engine_config;
+
+/* ---- lifecycle ----------------------------------------------------------------------------------------
+ * rapid_engine_create validates K/H/L exactly like the MultiNodeCutDetector constructor
+ * (R/MultiNodeCutDetector.java:51-55; constructed at R/Cluster.java:265-267 and :458-460). */
+int rapid_engine_create(const rapid_engine_config* cfg, rapid_engine** out);
+void rapid_engine_destroy(rapid_engine* h);
+const char* rapid_last_error(const rapid_engine* h);
+int rapid_device_count(void); /* number of usable gfx950 devices (0 on a CPU-only host) */
+
+/* ---- MembershipView (R/MembershipView.java) -----------------------------------------------------------
+ * rapid_view_build <- MembershipView(int K, Collection<NodeId>, Collection<Endpoint>) (:74-89).  Registers
+ * n_nodes endpoints (hostname bytes as one blob + n_nodes+1 offsets, ports, NodeIds) and makes
+ * members[0..n_members) the current membership; identifiersSeen = the members' NodeIds plus
+ * extra_id_hi/lo[0..n_extra) (ids of departed nodes -- never pruned, :167-201).  Builds on the GPU: the
+ * K ring keys of every endpoint (:579-582), K sorted rings, observer / subject tables, configuration id. */
+int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* host_off, const int32_t* ports,
+                     const int64_t* id_hi, const int64_t* id_lo, int32_t n_nodes, const int32_t* members,
+                     int32_t n_members, const int64_t* extra_id_hi, const int64_t* extra_id_lo, int32_t n_extra);
+int rapid_view_is_safe_to_join(rapid_engine* h, int32_t node, int32_t* status_out);       /* :100-115 */
+int rapid_view_ring_add(rapid_engine* h, int32_t node);                                    /* :123-160 */
+int rapid_view_ring_delete(rapid_engine* h, int32_t node);                                 /* :167-201 */
+int rapid_view_observers(rapid_engine* h, int32_t node, int32_t* out, int32_t cap, int32_t* n_out);  /* :210-224 */
+int rapid_view_subjects(rapid_engine* h, int32_t node, int32_t* out, int32_t cap, int32_t* n_out);   /* :267-282 */
+int rapid_view_expected_observers(rapid_engine* h, int32_t node, int32_t* out, int32_t cap,
+                                  int32_t* n_out);                                         /* :292-303 */
+int rapid_view_ring_numbers(rapid_engine* h, int32_t observer, int32_t subject, int32_t* out, int32_t cap,
+                            int32_t* n_out);                                               /* :397-418 */
+int rapid_view_ring(rapid_engine* h, int32_t k, int32_t* out, int32_t cap, int32_t* n_out); /* :380-388 */
+int rapid_view_ring_key(rapid_engine* h, int32_t k, int32_t node, int64_t* key_out);       /* :579-582 */
+int rapid_view_is_host_present(rapid_engine* h, int32_t node, int32_t* present_out);       /* :330-337 */
+int rapid_view_size(rapid_engine* h, int32_t* n_out);                                      /* :425-432 */
+int rapid_view_config_id(rapid_engine* h, int64_t* id_out);                                /* :360-372, 544-556 */
+/* whole tables, row-major [n_nodes][K] (observers of members = ring successors; rows of non-members hold
+ * their expected observers; subjects rows of non-members are -1) -- what the scenario generators consume */
+int rapid_view_tables(rapid_engine* h, int32_t* observers, int32_t* subjects, uint8_t* member, int32_t n_nodes);
+
+/* ---- MultiNodeCutDetector, one instance (R/MultiNodeCutDetector.java) ---------------------------------
+ * State lives on the GPU; every call runs the exact sequential kernel on one wavefront.
+ * rapid_cd_aggregate <- aggregateForProposal(AlertMessage) (:76-82) applied to n alerts in order;
+ * out_idx receives the concatenated returned proposals, out_counts[i] the size of alert i's return value. */
+int rapid_cd_create(rapid_engine* h, int32_t K, int32_t H, int32_t L, rapid_cd** out);      /* :51-60  */
+void rapid_cd_destroy(rapid_cd* cd);
+int rapid_cd_aggregate(rapid_cd* cd, const rapid_alert_record* alerts, int32_t n, int32_t* out_idx, int32_t cap,
+                       int32_t* out_counts, int32_t* n_out);                               /* :76-128 */
+int rapid_cd_invalidate(rapid_cd* cd, int32_t* out_idx, int32_t cap, int32_t* n_out);       /* :137-164 */
+int rapid_cd_num_proposals(rapid_cd* cd, int32_t* n_out);                                  /* :62-66  */
+int rapid_cd_clear(rapid_cd* cd);                                                          /* :169-178 */
+
+/* ---- whole population: MembershipService.handleMessage(BatchedAlertMessage) at every receiver ---------
+ * (R/MembershipService.java:300-354 with the filter of :644-675).  records = the receivers' delivered
+ * streams back to back, rec_off[r]..rec_off[r+1] (in records) = receiver r; every receiver starts the round
+ * with an empty detector and announcedProposal == false in the engine's current configuration. */
+int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, const int64_t* rec_off,
+                           int32_t n_receivers);
+/* same, records already on this device (borrowed until the next load; `records_bytes` readable bytes, which
+ * must extend at least 16 bytes past the last record); d_rec_off is a device pointer to n_receivers+1 int64 */
+int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64_t records_bytes,
+                                  const int64_t* d_rec_off, int32_t n_receivers);
+/* alert-tally kernel over all loaded receivers (asynchronous on the engine's stream) */
+int rapid_sim_tally(rapid_engine* h);
+/* per-receiver results of the last tally: index of the batch whose processing announced a proposal (-1 if
+ * none), getNumProposals(), proposal size, 64-bit proposal fingerprint (0 if none).  Any pointer may be NULL. */
+int rapid_sim_results(rapid_engine* h, int32_t* emit_batch, int32_t* num_proposals, int32_t* prop_count,
+                      uint64_t* fingerprint, int32_t n_receivers);
+/* receiver r's proposal as handed to FastPaxos.propose: sorted by the ring-0 comparator (:346-348) */
+int rapid_sim_proposal(rapid_engine* h, int32_t receiver, int32_t* out, int32_t cap, int32_t* n_out);
+
+/* ---- fast round over the population (R/FastPaxos.java:125-156) -----------------------------------------
+ * Every receiver that announced a proposal votes for it; identical proposals are counted (fingerprint
+ * histogram, verified element by element), summed over all ranks with one RCCL all-reduce when the engine
+ * has a communicator, and the quorum test N - floor((N-1)/4) is applied with N = current membership size. */
+typedef struct rapid_round_result {
+    int32_t decided;            /* 1 if some proposal reached the fast quorum */
+    int32_t cut_size;           /* size of the decided proposal */
+    int32_t quorum;             /* N - floor((N-1)/4) */
+    int32_t membership_size;    /* N */
+    int64_t votes_total;        /* receivers (all ranks) that proposed */
+    int64_t votes_winner;       /* votes for the most popular proposal */
+    int32_t distinct_local;     /* distinct proposals among this rank's receivers */
+    int32_t reserved;
+    int64_t config_id;          /* configuration the round ran in */
+} rapid_round_result;
+int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out);
+int rapid_sim_decided_cut(rapid_engine* h, int32_t* out, int32_t cap, int32_t* n_out); /* ring-0 order */
+/* tally + vote count (+ apply, if decided and apply != 0): one full round; new_config_id may be NULL */
+int rapid_sim_round(rapid_engine* h, int32_t apply, rapid_round_result* out, int64_t* new_config_id);
+
+/* ---- decideViewChange (R/MembershipService.java:385-430) -----------------------------------------------
+ * members in `cut` are removed (ringDelete), non-members are added (ringAdd with their registered NodeId);
+ * rings, tables and the configuration id are rebuilt on the GPU; detector state of the population is cleared. */
+int rapid_apply_cut(rapid_engine* h, const int32_t* cut, int32_t n, int64_t* new_config_id);
+
+/* ---- FastPaxos fast round, one instance (R/FastPaxos.java:62-68, 125-156): host-side control object ---- */
+int rapid_fast_round_create(int64_t config_id, int32_t membership_size, rapid_fast_round** out);
+void rapid_fast_round_destroy(rapid_fast_round* f);
+/* one FastRoundPhase2bMessage; *decided_out = 1 once a decision exists */
+int rapid_fast_round_vote(rapid_fast_round* f, int32_t sender, int64_t config_id, const int32_t* endpoints,
+                          int32_t n, int32_t* decided_out);
+int rapid_fast_round_decision(rapid_fast_round* f, int32_t* out, int32_t cap, int32_t* n_out);
+
+/* ---- multi-GPU: one engine per rank, receivers sharded, vote histogram all-reduced over RCCL/xGMI ------- */
+#define RAPID_UNIQUE_ID_BYTES 128
+int rapid_comm_unique_id(uint8_t out[RAPID_UNIQUE_ID_BYTES]); /* rank 0 creates, host layer broadcasts */
+int rapid_engine_comm_init(rapid_engine* h, const uint8_t id[RAPID_UNIQUE_ID_BYTES], int32_t rank, int32_t n_ranks);
+
+/* ---- instrumentation -------------------------------------------------------------------------------------
+ * stream: the hipStream_t all engine work is enqueued on (for HIP-event timing on the right stream).
+ * stats[0..7] of the last tally: exact-replayed sub-chunks, fast sub-chunks, full-sweep invalidations,
+ * receiver restarts, implicit reports applied, records consumed, 0, 0. */
+void* rapid_engine_stream(rapid_engine* h);
+int rapid_engine_sync(rapid_engine* h);
+int rapid_sim_stats(rapid_engine* h, uint64_t stats[8]);
+/* average duration (ms) of the tally kernel over `reps` back-to-back launches, HIP events on the engine stream */
+int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg);
+/* testing knob: run every sub-chunk through the exact sequential path (0 = normal) */
+int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAPID_MI355X_H */

@@ -1,0 +1,160 @@
+"""The HIP tally kernels (rapid_amd/csrc/tally_kernel.h), compiled UNMODIFIED with g++ against the SIMT
+emulator in tests/emu/, checked against the CPU oracle.  Lanes are scheduled in random order between wave
+collectives, so order-dependence of the LDS atomics would show up here.  This validates the kernel LOGIC on
+CPU; the same comparisons run on the real device in tests/test_gpu_parity.py (-m gpu)."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+from rapid_amd import scenarios as S
+from tests.emu import pyemu
+from tests.helpers import oracle_view, random_stream
+
+
+def _check(records, rec_off, n_nodes, K, H, L, cfg, obs, subj, member, **kw):
+    fe, fn, fo, fp = O.fast_sim_run(n_nodes, K, H, L, cfg, obs, subj, member, records, rec_off)
+    out = {}
+    for force in (0, 1):
+        emit, nprop, pcount, fpr, props, stats = pyemu.tally(records, rec_off, n_nodes, K, H, L, cfg, obs, subj, member,
+                                                            force_exact=force, **kw)
+        bad = np.flatnonzero(emit != fe)
+        assert len(bad) == 0, (force, bad[:5], emit[bad[:5]], fe[bad[:5]])
+        assert np.array_equal(nprop, fn), force
+        assert np.array_equal(pcount, np.diff(fo)), force
+        for r in range(len(fe)):
+            assert props[r, : pcount[r]].tolist() == fp[fo[r]: fo[r + 1]].tolist(), (force, r)
+        assert np.all((fpr != 0) == (fe >= 0))
+        out[force] = (fpr, stats)
+    assert np.array_equal(out[0][0], out[1][0])  # fingerprints identical on both paths
+    return out[0][1]
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_adversarial_streams(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n_nodes = int(rng.integers(8, 48))
+    K = int(rng.integers(3, 11))
+    H = int(rng.integers(1, K + 1))
+    L = int(rng.integers(1, H + 1))
+    pop = S.Population.make(n_nodes)
+    n_members = int(rng.integers(max(2, n_nodes // 2), n_nodes + 1))
+    members = sorted(rng.permutation(n_nodes)[:n_members].tolist())
+    reg, view = oracle_view(pop, K, members)
+    obs, subj, member = view.tables(n_nodes)
+    cfg = view.getCurrentConfigurationId()
+    recs, off = [], [0]
+    for r in range(24):
+        hot = rng.permutation(n_nodes)[: int(rng.integers(1, min(n_nodes, 12) + 1))]
+        n_rec = int(rng.integers(0, 400))
+        recs.append(random_stream(rng, n_nodes, K, member, cfg, n_rec, hot, p_eob=float(rng.choice([0.02, 0.3, 1.0]))))
+        off.append(off[-1] + n_rec)
+    _check(np.concatenate(recs), np.array(off), n_nodes, K, H, L, cfg, obs, subj, member, seed=seed)
+
+
+@pytest.mark.parametrize("name,n,f,K,H,L", [("C1", 50, 1, 3, 3, 1), ("C2", 300, 12, 10, 9, 4),
+                                            ("C3a", 400, 20, 10, 9, 4), ("C3b", 400, 20, 10, 9, 4),
+                                            ("C2", 200, 20, 10, 8, 2)])
+def test_scenarios(name, n, f, K, H, L):
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K)
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    rx = None if n <= 60 else np.arange(0, n, 7)  # a sample of receivers keeps the emulation fast
+    sc = S.build_scenario(name, subj, cfg, n=n, f=f, H=H, L=L, receivers=rx)
+    is_f = np.zeros(n, dtype=bool)
+    is_f[sc.faulty] = True
+    keep = ~is_f[sc.receivers]
+    stats = _check(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member)
+    if n > 60:
+        assert stats[1] > 0  # the fast path was exercised
+
+
+def test_unaligned_starts_and_empty_receivers():
+    n, K, H, L = 24, 5, 4, 2
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K)
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    rng = np.random.default_rng(3)
+    lens = [0, 1, 3, 0, 205, 7, 64, 65, 63, 128, 0, 409, 2]
+    parts = [random_stream(rng, n, K, member, cfg, m, [1, 2, 3, 4, 5]) for m in lens]
+    off = np.cumsum([0] + lens)
+    _check(np.concatenate(parts), off, n, K, H, L, cfg, obs, subj, member)
+
+
+def test_cd_instance_kernel_kats():
+    """CutDetectionTest.java:42-252 (KAT-1..6) through cd_instance_kernel."""
+    K, H, L = 10, 8, 2
+    n = 16
+    obs = np.full((n, K), -1, dtype=np.int32)
+    subj = np.full((n, K), -1, dtype=np.int32)
+    member = np.zeros(n, dtype=np.uint8)
+
+    def alert(src, dst, ring, status=S.UP):
+        a = np.zeros(1, dtype=S.ALERT_DTYPE)
+        a["src"], a["dst"], a["ring_mask"], a["status"], a["cfg_id"] = src, dst, 1 << ring, status, -1
+        return a
+
+    # KAT-1
+    cd = pyemu.CdInstance(n, K, H, L, obs, subj, member)
+    for i in range(H - 1):
+        ret, _ = cd.aggregate(alert(i + 1, 12, i))
+        assert ret == [] and cd.num_proposals() == 0
+    ret, _ = cd.aggregate(alert(H, 12, H - 1))
+    assert ret == [12] and cd.num_proposals() == 1
+    # KAT-4 (three blockers, duplicate reports past H)
+    cd = pyemu.CdInstance(n, K, H, L, obs, subj, member)
+    for d in (12, 13, 14):
+        for i in range(H - 1):
+            assert cd.aggregate(alert(i + 1, d, i))[0] == []
+    for d in (12, 14):
+        cd.aggregate(alert(H, d, H - 1))
+        assert cd.aggregate(alert(H + 1, d, H - 1))[0] == [] and cd.num_proposals() == 0
+    ret, _ = cd.aggregate(alert(H, 13, H - 1))
+    assert sorted(ret) == [12, 13, 14] and cd.num_proposals() == 1
+    # KAT-5 (below L is noise)
+    cd = pyemu.CdInstance(n, K, H, L, obs, subj, member)
+    for i in range(H - 1):
+        cd.aggregate(alert(i + 1, 12, i))
+    cd.aggregate(alert(1, 13, 0))
+    for i in range(H - 1):
+        cd.aggregate(alert(i + 1, 14, i))
+    assert cd.aggregate(alert(H, 12, H - 1))[0] == []
+    assert sorted(cd.aggregate(alert(H, 14, H - 1))[0]) == [12, 14]
+    # KAT-6 (batch of 3 x 10 rings, one multi-alert call): three separate 1-node emissions
+    cd = pyemu.CdInstance(n, K, H, L, obs, subj, member)
+    batch = np.concatenate([alert(1, d, r) for d in (12, 13, 14) for r in range(K)])
+    ret, counts = cd.aggregate(batch)
+    assert ret == [12, 13, 14] and sum(counts) == 3 and cd.num_proposals() == 3
+
+
+def test_cd_instance_kernel_kat7_link_invalidation():
+    """CutDetectionTest.java:254-301 on the real ring topology of 127.0.0.2:2..31."""
+    K, H, L = 10, 8, 2
+    reg = O.Registry()
+    view = O.MembershipView(reg, K)
+    nodes = [reg.intern("127.0.0.2", 2 + i) for i in range(30)]
+    for i, nd in enumerate(nodes):
+        view.ringAdd(nd, (i + 1, i + 1))
+    obs, subj, member = view.tables(30)
+    cd = pyemu.CdInstance(30, K, H, L, obs, subj, member)
+
+    def alert(src, dst, ring):
+        a = np.zeros(1, dtype=S.ALERT_DTYPE)
+        a["src"], a["dst"], a["ring_mask"], a["status"], a["cfg_id"] = src, dst, 1 << ring, S.DOWN, -1
+        return a
+
+    dst = nodes[0]
+    observers = view.getObserversOf(dst)
+    for i in range(H - 1):
+        assert cd.aggregate(alert(observers[i], dst, i))[0] == []
+    failed = set()
+    for i in range(H - 1, K):
+        oo = view.getObserversOf(observers[i])
+        failed.add(observers[i])
+        for j in range(K):
+            assert cd.aggregate(alert(oo[j], observers[i], j))[0] == []
+            assert cd.num_proposals() == 0
+    ret = cd.invalidate()
+    assert len(ret) == 4 and cd.num_proposals() == 1
+    assert set(ret) == failed | {dst}
