@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- alert-batches/sec of the cut-detection hot path on MI355X (BASELINE.json metric, N=10k K=10).
+
+One *step* = one pass of the hot path over the resident synthetic alert streams of the whole simulated
+population: the alert-tally kernel over every receiver (MembershipService.handleMessage(BatchedAlertMessage)
+semantics), then the fast-round vote count over their proposals (histogram -> all-reduce over ranks -> quorum test
+-> element-wise verification).  The view is NOT changed inside the timed loop so that every step does identical
+work; one extra untimed-in-`value` round that also applies the cut gives `time_to_stable_cut_ms`.
+
+Launch: `python bench.py --gpus 1` or, for N > 1,
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
+The simulated receivers are sharded across ranks (strong scaling of ONE cluster); the only data-path collective is
+the per-round RCCL all-reduce of the vote histogram inside librapid_mi355x.so.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3b", help="C2 | C3a | C3b (headline: C3b = BASELINE configs[2], closed fault set)")
+    ap.add_argument("--n", type=int, default=None, help="override population size (testing only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--kernel-reps", type=int, default=20)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    import torch
+    import torch.distributed as dist
+
+    from rapid_amd import engine as E
+    from rapid_amd import parallel as P
+    from rapid_amd import scenarios as S
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a gfx950 GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    cfgname = args.config
+    spec = dict(S.CONFIGS[cfgname])
+    n = args.n or spec["n"]
+    K, H, L = spec["K"], spec["H"], spec["L"]
+    f = spec["f"] if args.n is None else max(1, spec["f"] * n // spec["n"])
+
+    # ---- population + view (every rank builds the same deterministic view) ----
+    t0 = time.time()
+    pop = S.Population.make(n)
+    eng = E.Engine(n_max=n, K=K, H=H, L=L, device_id=local_rank)
+    if world > 1:
+        uid = [E.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(uid[0], rank, world)
+    view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
+    obs, subj, member = view.tables()
+    cfg_id = view.getCurrentConfigurationId()
+    sc = S.build_scenario(cfgname, subj, cfg_id, n=n, f=f, materialise=False)
+    lo, hi = P.shard_range(len(sc.receivers), rank, world)
+    my_rx = sc.receivers[lo:hi]
+    records, rec_off, nb = S.deliver(sc.batches, my_rx, seed_delivery=2)
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(records, rec_off)  # streams are resident in HBM before anything is timed
+    setup_s = time.time() - t0
+    my_batches = int(nb.sum())
+    my_records = int(len(records))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    def step():
+        sim.tally()
+        return sim.count_votes()  # blocks until the decision is on the host
+
+    for _ in range(args.warmup):
+        rr = step()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        rr = step()
+    barrier()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        cnt = torch.tensor([my_batches, my_records], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        tot_batches, tot_records = int(cnt[0].item()), int(cnt[1].item())
+    else:
+        tot_batches, tot_records = my_batches, my_records
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = tot_batches * args.steps / elapsed
+
+    # ---- dominant kernel: the alert tally.  HIP events on the engine's own stream, back-to-back launches ----
+    st = sim.stats()
+    kern_ms = sim.time_tally(args.kernel_reps)
+    consumed = sim.stats()["records_consumed"] // (args.kernel_reps + 1)
+    achieved = 20.0 * consumed / (kern_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "tally_population_kernel",
+                "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(20 * consumed),
+                "records_delivered_per_launch": my_records}
+
+    # ---- one full round including decideViewChange: time-to-stable-cut (streams resident -> cut + new cfg on host)
+    barrier()
+    t2 = time.perf_counter()
+    rr_full, new_cfg = sim.round(apply=True)
+    eng.sync()
+    ttsc_ms = 1e3 * (time.perf_counter() - t2)
+    if world > 1:
+        tt = torch.tensor([ttsc_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ttsc_ms = float(tt.item())
+
+    out = {
+        "metric": "alert-batches/sec", "value": round(value, 1), "unit": "alert-batches/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+        "config": {"workload": "%s: N=%d K=%d H=%d L=%d, %d ingress-loss nodes (5%% one-way failures, fault set closed "
+                               "under >=L faulty observers), %d receivers, per-receiver seeded delivery order"
+                               % (cfgname, n, K, H, L, len(sc.faulty), len(sc.receivers)) if cfgname == "C3b" else
+                   "%s: N=%d K=%d H=%d L=%d faults=%d receivers=%d" % (cfgname, n, K, H, L, len(sc.faulty), len(sc.receivers)),
+                   "parallelism": "receivers sharded over %d GPU(s); vote histogram all-reduce over RCCL" % world,
+                   "baseline_config": "BASELINE.json configs[2] (10,000 nodes, K=10, 5% asymmetric one-way edge failures)"},
+        "alert_records_per_s": round(tot_records * args.steps / elapsed, 1),
+        "time_to_stable_cut_ms": round(ttsc_ms, 3) if rr_full.decided else None,
+        "decided": int(rr_full.decided), "cut_size": int(rr_full.cut_size), "votes_winner": int(rr_full.votes_winner),
+        "quorum": int(rr_full.quorum), "kernel_stats": st, "setup_s": round(setup_s, 1), "roofline": roofline,
+    }
+
+    # ---- CPU baseline beside it (rank 0, N=1 only): the oracle = CPU restatement of the reference's Java path ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"], out["cpu_optimized"] = cpu_baseline(pop, K, H, L, cfg_id, obs, subj, member, records, rec_off,
+                                                                 nb, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pop, K, H, L, cfg_id, obs, subj, member, records, rec_off, nb, budget_s):
+    """Times oracle/ on a bounded sample of the SAME resident workload.  `cpu_baseline` = the faithful restatement
+    of the Java (HashMap/TreeSet structure, full preProposal re-scan after every batch), one thread.
+    `cpu_optimized` = the dense-mask / incremental-invalidation CPU formulation on all host cores."""
+    from oracle import pyoracle as O
+    cores = os.cpu_count() or 1
+    reg = O.Registry()
+    for i in range(pop.n):
+        reg.intern(pop.hostnames[i], int(pop.ports[i]))
+    oview = O.MembershipView(reg, K, list(zip(pop.id_hi.tolist(), pop.id_lo.tolist())), list(range(pop.n)))
+    assert oview.getCurrentConfigurationId() == cfg_id
+
+    def sub(k):
+        return records[: rec_off[k]], rec_off[: k + 1].copy(), int(nb[:k].sum())
+
+    # faithful: grow the sample until it has used a fair share of the budget
+    k, spent, done_b, done_t = 1, 0.0, 0, 0.0
+    while True:
+        r, o, b = sub(k)
+        t = time.perf_counter()
+        O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, r, o, nthreads=1)
+        dt = time.perf_counter() - t
+        spent += dt
+        done_b, done_t, done_k = b, dt, k
+        if spent > budget_s or k >= len(nb):
+            break
+        k = min(len(nb), max(k + 1, int(k * min(4.0, 0.6 * budget_s / max(dt, 1e-3)))))
+    base = {"value": round(done_b / done_t, 1), "unit": "alert-batches/s", "cores": 1, "kind": "port",
+            "sample": "first %d receivers of the same resident workload (%d alert batches), oracle/rapid_oracle.hpp "
+                      "(statement-by-statement restatement of the Java), %.1f s" % (done_k, done_b, done_t)}
+    k2 = min(len(nb), max(64, cores * 64))
+    r, o, b = sub(k2)
+    t = time.perf_counter()
+    O.fast_sim_run(pop.n, K, H, L, cfg_id, obs, subj, member, r, o, nthreads=cores)
+    dt = time.perf_counter() - t
+    opt = {"value": round(b / dt, 1), "unit": "alert-batches/s", "cores": cores, "kind": "port",
+           "sample": "first %d receivers (%d alert batches), oracle/fast_cut.hpp dense-mask formulation, %d threads, %.2f s"
+                     % (k2, b, cores, dt)}
+    return base, opt
+
+
+if __name__ == "__main__":
+    main()

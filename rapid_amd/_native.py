@@ -1,0 +1,159 @@
+"""Loader / builder of librapid_mi355x.so (the C ABI of include/rapid_mi355x.h).
+
+The product has no CPU fallback: if the shared library is missing, or the host has no gfx950 device, the
+classes in rapid_amd.engine raise -- they never route to the oracle.
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librapid_mi355x.so")
+SRC_DIR = os.path.join(_HERE, "csrc")
+SOURCES = ["engine.hip", "tally_kernel.h", "view_kernels.h", "vote_kernels.h"]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "rapid_mi355x.h")
+
+OK, EINVAL, ENODE_EXISTS, ENODE_MISSING, EUUID_SEEN, ECAPACITY, EDEVICE, ESTATE, ECOLLISION = 0, -1, -2, -3, -4, -5, -6, -7, -8
+
+
+class RapidError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("rapid_mi355x error %d: %s" % (code, msg))
+        self.code = code
+
+
+class NodeAlreadyInRingException(RapidError):  # R/MembershipView.java:502-506
+    pass
+
+
+class NodeNotInRingException(RapidError):  # R/MembershipView.java:508-512
+    pass
+
+
+class UUIDAlreadySeenException(RapidError):  # R/MembershipView.java:514-519
+    pass
+
+
+class IllegalArgumentException(RapidError, ValueError):  # R/MultiNodeCutDetector.java:52-55
+    pass
+
+
+_EXC = {EINVAL: IllegalArgumentException, ENODE_EXISTS: NodeAlreadyInRingException,
+        ENODE_MISSING: NodeNotInRingException, EUUID_SEEN: UUIDAlreadySeenException}
+
+
+def raise_for(code, msg=""):
+    raise _EXC.get(code, RapidError)(code, msg)
+
+
+def hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    srcs = [os.path.join(SRC_DIR, s) for s in SOURCES] + [HEADER]
+    if not all(os.path.exists(s) for s in srcs):
+        return False  # sources absent (binary-only snapshot): use what is there
+    return os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 cross-compiles without a GPU (about 15 s)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           os.path.join(SRC_DIR, "engine.hip"), "-o", LIB_PATH + ".tmp", "-lrccl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+
+class RoundResult(C.Structure):
+    _fields_ = [("decided", C.c_int32), ("cut_size", C.c_int32), ("quorum", C.c_int32), ("membership_size", C.c_int32),
+                ("votes_total", C.c_int64), ("votes_winner", C.c_int64), ("distinct_local", C.c_int32),
+                ("reserved", C.c_int32), ("config_id", C.c_int64)]
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [("n_max", C.c_int32), ("K", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("device_id", C.c_int32),
+                ("max_cut", C.c_int32)]
+
+
+# every entry point declared in include/rapid_mi355x.h: name -> (restype, argtypes)
+def _signatures():
+    vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+    p = C.c_void_p  # all array arguments are passed as raw addresses
+    pi32, pi64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    return {
+        "rapid_engine_create": (i32, [C.POINTER(EngineConfig), C.POINTER(vp)]),
+        "rapid_engine_destroy": (None, [vp]),
+        "rapid_last_error": (C.c_char_p, [vp]),
+        "rapid_device_count": (i32, []),
+        "rapid_view_build": (i32, [vp, p, p, p, p, p, i32, p, i32, p, p, i32]),
+        "rapid_view_is_safe_to_join": (i32, [vp, i32, pi32]),
+        "rapid_view_ring_add": (i32, [vp, i32]),
+        "rapid_view_ring_delete": (i32, [vp, i32]),
+        "rapid_view_observers": (i32, [vp, i32, p, i32, pi32]),
+        "rapid_view_subjects": (i32, [vp, i32, p, i32, pi32]),
+        "rapid_view_expected_observers": (i32, [vp, i32, p, i32, pi32]),
+        "rapid_view_ring_numbers": (i32, [vp, i32, i32, p, i32, pi32]),
+        "rapid_view_ring": (i32, [vp, i32, p, i32, pi32]),
+        "rapid_view_ring_key": (i32, [vp, i32, i32, pi64]),
+        "rapid_view_is_host_present": (i32, [vp, i32, pi32]),
+        "rapid_view_size": (i32, [vp, pi32]),
+        "rapid_view_config_id": (i32, [vp, pi64]),
+        "rapid_view_tables": (i32, [vp, p, p, p, i32]),
+        "rapid_cd_create": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
+        "rapid_cd_destroy": (None, [vp]),
+        "rapid_cd_aggregate": (i32, [vp, p, i32, p, i32, p, pi32]),
+        "rapid_cd_invalidate": (i32, [vp, p, i32, pi32]),
+        "rapid_cd_num_proposals": (i32, [vp, pi32]),
+        "rapid_cd_clear": (i32, [vp]),
+        "rapid_sim_load_streams": (i32, [vp, p, p, i32]),
+        "rapid_sim_load_streams_device": (i32, [vp, p, u64, p, i32]),
+        "rapid_sim_tally": (i32, [vp]),
+        "rapid_sim_results": (i32, [vp, p, p, p, p, i32]),
+        "rapid_sim_proposal": (i32, [vp, i32, p, i32, pi32]),
+        "rapid_sim_count_votes": (i32, [vp, C.POINTER(RoundResult)]),
+        "rapid_sim_decided_cut": (i32, [vp, p, i32, pi32]),
+        "rapid_sim_round": (i32, [vp, i32, C.POINTER(RoundResult), pi64]),
+        "rapid_apply_cut": (i32, [vp, p, i32, pi64]),
+        "rapid_fast_round_create": (i32, [i64, i32, C.POINTER(vp)]),
+        "rapid_fast_round_destroy": (None, [vp]),
+        "rapid_fast_round_vote": (i32, [vp, i32, i64, p, i32, pi32]),
+        "rapid_fast_round_decision": (i32, [vp, p, i32, pi32]),
+        "rapid_comm_unique_id": (i32, [p]),
+        "rapid_engine_comm_init": (i32, [vp, p, i32, i32]),
+        "rapid_engine_stream": (vp, [vp]),
+        "rapid_engine_sync": (i32, [vp]),
+        "rapid_sim_stats": (i32, [vp, p]),
+        "rapid_sim_time_tally": (i32, [vp, i32, C.POINTER(C.c_float)]),
+        "rapid_sim_set_force_exact": (i32, [vp, i32]),
+    }
+
+
+SIGNATURES = _signatures()
+
+
+def lib():
+    """Loads the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RapidError(EDEVICE, "librapid_mi355x.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(L, name)  # AttributeError here == the library does not export a declared symbol
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L

@@ -1,0 +1,1036 @@
+// librapid_mi355x.so -- host side of the C ABI declared in include/rapid_mi355x.h.
+//
+// One rapid_engine = one simulated cluster on one MI355X: the registry of endpoints, the K-ring view built
+// on the device, the resident alert streams of the simulated receivers, and the per-round outputs.  All
+// device work is enqueued on the engine's own HIP stream.  There is NO CPU fallback: every entry point
+// that needs the device returns RAPID_EDEVICE when it is not a usable gfx950.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rccl/rccl.h>
+
+#include "../../include/rapid_mi355x.h"
+#include "tally_kernel.h"
+#include "view_kernels.h"
+#include "vote_kernels.h"
+
+namespace {
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct rapid_engine {
+    rapid_engine_config cfg{};
+    int max_cut = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- registry (host) ----
+    int n_nodes = 0;
+    std::vector<int64_t> id_hi, id_lo;
+    std::vector<uint8_t> member;  // host mirror
+    int n_members = 0;
+    std::set<std::pair<int64_t, int64_t>> ids_seen;  // identifiersSeen (signed lexicographic == NodeIdComparator)
+    bool ids_dirty = true;
+    bool view_built = false;
+    int64_t config_id = -1;
+
+    // ---- view (device) ----
+    DevBuf<unsigned char> d_blob;
+    DevBuf<int> d_host_off, d_ports;
+    DevBuf<long long> d_keys;  // [K][n_nodes]
+    DevBuf<unsigned long long> d_hx_host0, d_hx_port0;
+    DevBuf<unsigned char> d_member;
+    DevBuf<int> d_members;                       // member indices, ascending
+    DevBuf<unsigned long long> d_sort_keys;      // [K][M] unsorted
+    DevBuf<int> d_sort_vals;                     // [K][M]
+    DevBuf<unsigned long long> d_ring_skeys;     // [K][M] sorted sortable keys
+    DevBuf<int> d_ring;                          // [K][M] node indices in ring order
+    DevBuf<int> d_pos;                           // [K][n_nodes]
+    DevBuf<int> d_obs, d_subj;                   // [n_nodes][K]
+    DevBuf<unsigned short> d_template;           // [n_nodes padded to 8]
+    DevBuf<long long> d_ids_hi, d_ids_lo;
+    DevBuf<long long> d_cfg_out;
+    DevBuf<unsigned char> d_sort_tmp;
+    int n_ids_dev = 0;
+
+    // host mirrors of the tables (filled lazily after a rebuild)
+    bool host_tables_valid = false;
+    std::vector<int> h_obs, h_subj, h_ring;
+    std::vector<long long> h_keys;
+
+    // ---- simulated population ----
+    DevBuf<unsigned char> d_records_own;
+    const unsigned char* d_records = nullptr;
+    unsigned long long records_bytes = 0;
+    DevBuf<long long> d_rec_off_own;
+    const long long* d_rec_off = nullptr;
+    int n_receivers = 0;
+    bool streams_loaded = false, tallied = false;
+    int force_exact = 0;
+    DevBuf<int> d_emit, d_nprop, d_pcount, d_props;
+    DevBuf<unsigned long long> d_fp, d_stats;
+
+    // ---- votes ----
+    DevBuf<unsigned long long> d_hist, d_winner, d_mm, d_mismatch;
+    DevBuf<int> d_ref;
+    std::vector<int> decided_cut;  // ring-0 order
+    bool have_decision = false;
+
+    // ---- multi-GPU ----
+    ncclComm_t comm = nullptr;
+    int rank = 0, n_ranks = 1;
+};
+
+struct rapid_cd {
+    rapid_engine* eng = nullptr;
+    int K = 0, H = 0, L = 0;
+    int n_nodes = 0;
+    DevBuf<unsigned short> d_state;
+    DevBuf<int> d_scal, d_out, d_counts, d_out_n;
+    DevBuf<unsigned char> d_alerts;
+};
+
+struct rapid_fast_round {
+    int64_t config_id = 0;
+    long membership_size = 0;
+    std::map<std::vector<int32_t>, int> votes_per_proposal;
+    std::set<int32_t> votes_received;
+    bool decided = false;
+    std::vector<int32_t> decision;
+};
+
+namespace {
+
+int fail(rapid_engine* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((h), RAPID_EDEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+#define NCCLCHK(h, call)                                                                          \
+    do {                                                                                          \
+        ncclResult_t r_ = (call);                                                                 \
+        if (r_ != ncclSuccess)                                                                    \
+            return fail((h), RAPID_EDEVICE, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), \
+                        __FILE__, __LINE__);                                                      \
+    } while (0)
+
+bool valid_khl(int K, int H, int L) {
+    // R/MultiNodeCutDetector.java:52 -- if (H > K || L > H || K < K_MIN || L <= 0 || H <= 0) throw
+    return !(H > K || L > H || K < 3 || L <= 0 || H <= 0);
+}
+
+inline unsigned grid_for(long long n, int block) { return (unsigned)((n + block - 1) / block); }
+
+int use_device(rapid_engine* h) {
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    return RAPID_OK;
+}
+
+// Rebuilds rings, tables, state template and configuration id from the host member flags.
+int rebuild_view(rapid_engine* h) {
+    const int K = h->cfg.K, N = h->n_nodes;
+    std::vector<int> members;
+    members.reserve((size_t)N);
+    for (int n = 0; n < N; ++n)
+        if (h->member[(size_t)n]) members.push_back(n);
+    const int M = (int)members.size();
+    h->n_members = M;
+    hipStream_t st = h->stream;
+
+    HIPCHK(h, h->d_member.ensure((size_t)N));
+    HIPCHK(h, hipMemcpyAsync(h->d_member.p, h->member.data(), (size_t)N, hipMemcpyHostToDevice, st));
+    HIPCHK(h, h->d_members.ensure((size_t)std::max(M, 1)));
+    if (M) HIPCHK(h, hipMemcpyAsync(h->d_members.p, members.data(), sizeof(int) * M, hipMemcpyHostToDevice, st));
+    const size_t km = (size_t)K * (size_t)std::max(M, 1);
+    HIPCHK(h, h->d_sort_keys.ensure(km));
+    HIPCHK(h, h->d_sort_vals.ensure(km));
+    HIPCHK(h, h->d_ring_skeys.ensure(km));
+    HIPCHK(h, h->d_ring.ensure(km));
+    HIPCHK(h, h->d_pos.ensure((size_t)K * N));
+    HIPCHK(h, h->d_obs.ensure((size_t)K * N));
+    HIPCHK(h, h->d_subj.ensure((size_t)K * N));
+    const int n_padded = ((N + 7) / 8) * 8;
+    HIPCHK(h, h->d_template.ensure((size_t)n_padded));
+    HIPCHK(h, h->d_cfg_out.ensure(1));
+
+    if (M) {
+        hipLaunchKernelGGL(rapid::ring_gather_kernel, dim3(grid_for((long long)K * M, 256)), dim3(256), 0, st, h->d_keys.p,
+                           h->d_members.p, M, N, K, h->d_sort_keys.p, h->d_sort_vals.p);
+        size_t tmp_bytes = 0;
+        HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->d_sort_keys.p, h->d_ring_skeys.p, h->d_sort_vals.p,
+                                            h->d_ring.p, (size_t)M, 0, 64, st));
+        HIPCHK(h, h->d_sort_tmp.ensure(tmp_bytes + 16));
+        for (int k = 0; k < K; ++k) {
+            const size_t o = (size_t)k * M;
+            HIPCHK(h, rocprim::radix_sort_pairs(h->d_sort_tmp.p, tmp_bytes, h->d_sort_keys.p + o, h->d_ring_skeys.p + o,
+                                                h->d_sort_vals.p + o, h->d_ring.p + o, (size_t)M, 0, 64, st));
+        }
+        hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * M, 256)), dim3(256), 0, st, h->d_ring.p,
+                           h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 0);
+    }
+    hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * N, 256)), dim3(256), 0, st, h->d_ring.p,
+                       h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 1);
+    hipLaunchKernelGGL(rapid::state_template_kernel, dim3(grid_for(n_padded, 256)), dim3(256), 0, st, h->d_member.p, N,
+                       n_padded, h->d_template.p);
+
+    if (h->ids_dirty) {
+        const size_t ni = h->ids_seen.size();
+        std::vector<long long> hi(ni), lo(ni);
+        size_t i = 0;
+        for (const auto& id : h->ids_seen) {
+            hi[i] = id.first;
+            lo[i] = id.second;
+            ++i;
+        }
+        HIPCHK(h, h->d_ids_hi.ensure(std::max<size_t>(ni, 1)));
+        HIPCHK(h, h->d_ids_lo.ensure(std::max<size_t>(ni, 1)));
+        if (ni) {
+            HIPCHK(h, hipMemcpyAsync(h->d_ids_hi.p, hi.data(), ni * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(h->d_ids_lo.p, lo.data(), ni * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipStreamSynchronize(st));  // hi/lo go out of scope
+        }
+        h->n_ids_dev = (int)ni;
+        h->ids_dirty = false;
+    }
+    const int T = 1024;
+    hipLaunchKernelGGL(rapid::config_id_kernel, dim3(1), dim3(T), (size_t)T * 16, st, h->d_ids_hi.p, h->d_ids_lo.p,
+                       h->n_ids_dev, h->d_ring.p, M, h->d_hx_host0.p, h->d_hx_port0.p, h->d_cfg_out.p);
+    long long cfg = 0;
+    HIPCHK(h, hipMemcpyAsync(&cfg, h->d_cfg_out.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipGetLastError());
+    h->config_id = cfg;
+    h->host_tables_valid = false;
+    h->tallied = false;
+    h->have_decision = false;
+    return RAPID_OK;
+}
+
+int ensure_host_tables(rapid_engine* h) {
+    if (h->host_tables_valid) return RAPID_OK;
+    const int K = h->cfg.K, N = h->n_nodes, M = h->n_members;
+    h->h_obs.resize((size_t)K * N);
+    h->h_subj.resize((size_t)K * N);
+    h->h_ring.resize((size_t)K * std::max(M, 1));
+    h->h_keys.resize((size_t)K * N);
+    HIPCHK(h, hipMemcpyAsync(h->h_obs.data(), h->d_obs.p, sizeof(int) * K * N, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_subj.data(), h->d_subj.p, sizeof(int) * K * N, hipMemcpyDeviceToHost, h->stream));
+    if (M)
+        HIPCHK(h, hipMemcpyAsync(h->h_ring.data(), h->d_ring.p, sizeof(int) * (size_t)K * M, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_keys.data(), h->d_keys.p, sizeof(long long) * K * N, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->host_tables_valid = true;
+    return RAPID_OK;
+}
+
+int check_node(rapid_engine* h, int node) {
+    if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
+    if (node < 0 || node >= h->n_nodes) return fail(h, RAPID_EINVAL, "node index %d out of range [0,%d)", node, h->n_nodes);
+    return RAPID_OK;
+}
+
+int copy_list(rapid_engine* h, const int* src, int n, int32_t* out, int32_t cap, int32_t* n_out) {
+    if (n_out) *n_out = n;
+    if (n > cap) return fail(h, RAPID_ECAPACITY, "output needs %d entries, capacity %d", n, cap);
+    for (int i = 0; i < n; ++i) out[i] = src[i];
+    return RAPID_OK;
+}
+
+int launch_tally(rapid_engine* h) {
+    const int lds = rapid::tally_lds_bytes(h->n_nodes);
+    rapid::TallyParams p;
+    p.records = h->d_records;
+    p.records_bytes = h->records_bytes;
+    p.rec_off = h->d_rec_off;
+    p.n_receivers = h->n_receivers;
+    p.n_nodes = h->n_nodes;
+    p.K = h->cfg.K;
+    p.H = h->cfg.H;
+    p.L = h->cfg.L;
+    p.cfg_id = h->config_id;
+    p.state_template = h->d_template.p;
+    p.obs = h->d_obs.p;
+    p.subj = h->d_subj.p;
+    p.emit_batch = h->d_emit.p;
+    p.num_proposals = h->d_nprop.p;
+    p.prop_count = h->d_pcount.p;
+    p.fingerprint = h->d_fp.p;
+    p.props = h->d_props.p;
+    p.prop_cap = h->max_cut;
+    p.stats = h->d_stats.p;
+    p.force_exact = h->force_exact;
+    hipLaunchKernelGGL(rapid::tally_population_kernel, dim3((unsigned)h->n_receivers), dim3(64), (size_t)lds, h->stream, p);
+    return RAPID_OK;
+}
+
+int prepare_tally(rapid_engine* h) {
+    if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
+    if (!h->streams_loaded) return fail(h, RAPID_ESTATE, "no alert streams loaded");
+    const int lds = rapid::tally_lds_bytes(h->n_nodes);
+    if (lds > 160 * 1024)
+        return fail(h, RAPID_ECAPACITY, "n_nodes=%d needs %d B of LDS per receiver (max 163840): direct-indexed detector "
+                    "state does not fit", h->n_nodes, lds);
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const size_t R = (size_t)std::max(h->n_receivers, 1);
+    HIPCHK(h, h->d_emit.ensure(R));
+    HIPCHK(h, h->d_nprop.ensure(R));
+    HIPCHK(h, h->d_pcount.ensure(R));
+    HIPCHK(h, h->d_fp.ensure(R));
+    HIPCHK(h, h->d_props.ensure(R * (size_t)h->max_cut));
+    HIPCHK(h, h->d_stats.ensure(8));
+    return RAPID_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rapid_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int usable = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++usable;
+    }
+    return usable;
+}
+
+int rapid_engine_create(const rapid_engine_config* cfg, rapid_engine** out) {
+    if (!cfg || !out) return RAPID_EINVAL;
+    *out = nullptr;
+    if (!valid_khl(cfg->K, cfg->H, cfg->L) || cfg->K > RAPID_MAX_K || cfg->n_max <= 0) return RAPID_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || cfg->device_id < 0 || cfg->device_id >= n) return RAPID_EDEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device_id) != hipSuccess) return RAPID_EDEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RAPID_EDEVICE;  // kernels exist for gfx950 only
+    if (hipSetDevice(cfg->device_id) != hipSuccess) return RAPID_EDEVICE;
+    rapid_engine* h = new rapid_engine();
+    h->cfg = *cfg;
+    h->max_cut = cfg->max_cut > 0 ? cfg->max_cut : std::min(cfg->n_max, 4096);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return RAPID_EDEVICE;
+    }
+    *out = h;
+    return RAPID_OK;
+}
+
+void rapid_engine_destroy(rapid_engine* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->comm) (void)ncclCommDestroy(h->comm);
+    if (h->stream) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamDestroy(h->stream);
+    }
+    h->d_blob.release(); h->d_host_off.release(); h->d_ports.release(); h->d_keys.release();
+    h->d_hx_host0.release(); h->d_hx_port0.release(); h->d_member.release(); h->d_members.release();
+    h->d_sort_keys.release(); h->d_sort_vals.release(); h->d_ring_skeys.release(); h->d_ring.release();
+    h->d_pos.release(); h->d_obs.release(); h->d_subj.release(); h->d_template.release();
+    h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
+    h->d_records_own.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
+    h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
+    h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release();
+    delete h;
+}
+
+const char* rapid_last_error(const rapid_engine* h) { return h ? h->err.c_str() : "null engine"; }
+
+// ------------------------------------------------------------------------------------------------ view
+int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* host_off, const int32_t* ports,
+                     const int64_t* id_hi, const int64_t* id_lo, int32_t n_nodes, const int32_t* members,
+                     int32_t n_members, const int64_t* extra_id_hi, const int64_t* extra_id_lo, int32_t n_extra) {
+    if (!h) return RAPID_EINVAL;
+    if (!hostnames || !host_off || !ports || !id_hi || !id_lo || n_nodes <= 0 || n_nodes > h->cfg.n_max || n_members < 0 ||
+        (n_members > 0 && !members) || n_extra < 0)
+        return fail(h, RAPID_EINVAL, "bad arguments to rapid_view_build (n_nodes=%d, n_max=%d)", n_nodes, h->cfg.n_max);
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int K = h->cfg.K;
+    h->n_nodes = n_nodes;
+    h->id_hi.assign(id_hi, id_hi + n_nodes);
+    h->id_lo.assign(id_lo, id_lo + n_nodes);
+    h->member.assign((size_t)n_nodes, 0);
+    h->ids_seen.clear();
+    for (int i = 0; i < n_members; ++i) {
+        const int m = members[i];
+        if (m < 0 || m >= n_nodes) return fail(h, RAPID_EINVAL, "member index %d out of range", m);
+        h->member[(size_t)m] = 1;  // Set semantics, like TreeSet.addAll (R/MembershipView.java:82-85)
+        h->ids_seen.insert({id_hi[m], id_lo[m]});
+    }
+    for (int i = 0; i < n_extra; ++i) h->ids_seen.insert({extra_id_hi[i], extra_id_lo[i]});
+    h->ids_dirty = true;
+
+    const size_t blob_bytes = (size_t)host_off[n_nodes];
+    HIPCHK(h, h->d_blob.ensure(std::max<size_t>(blob_bytes, 1)));
+    HIPCHK(h, h->d_host_off.ensure((size_t)n_nodes + 1));
+    HIPCHK(h, h->d_ports.ensure((size_t)n_nodes));
+    HIPCHK(h, h->d_keys.ensure((size_t)K * n_nodes));
+    HIPCHK(h, h->d_hx_host0.ensure((size_t)n_nodes));
+    HIPCHK(h, h->d_hx_port0.ensure((size_t)n_nodes));
+    HIPCHK(h, hipMemcpyAsync(h->d_blob.p, hostnames, blob_bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_host_off.p, host_off, sizeof(int) * ((size_t)n_nodes + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_ports.p, ports, sizeof(int) * (size_t)n_nodes, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(rapid::ring_keys_kernel, dim3(grid_for((long long)K * n_nodes, 256)), dim3(256), 0, h->stream,
+                       h->d_blob.p, h->d_host_off.p, h->d_ports.p, n_nodes, K, h->d_keys.p, h->d_hx_host0.p, h->d_hx_port0.p);
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // borrowed inputs may go away after the call
+    h->view_built = true;
+    h->streams_loaded = false;
+    return rebuild_view(h);
+}
+
+int rapid_view_is_safe_to_join(rapid_engine* h, int32_t node, int32_t* status_out) {
+    int rc = check_node(h, node);
+    if (rc) return rc;
+    if (h->member[(size_t)node]) *status_out = RAPID_HOSTNAME_ALREADY_IN_RING;
+    else if (h->ids_seen.count({h->id_hi[(size_t)node], h->id_lo[(size_t)node]})) *status_out = RAPID_UUID_ALREADY_IN_RING;
+    else *status_out = RAPID_SAFE_TO_JOIN;
+    return RAPID_OK;
+}
+
+int rapid_view_ring_add(rapid_engine* h, int32_t node) {
+    int rc = check_node(h, node);
+    if (rc) return rc;
+    if ((rc = use_device(h))) return rc;
+    const std::pair<int64_t, int64_t> id{h->id_hi[(size_t)node], h->id_lo[(size_t)node]};
+    if (h->ids_seen.count(id)) return fail(h, RAPID_EUUID_SEEN, "identifier of node %d already seen", node);  // :127-129
+    if (h->member[(size_t)node]) return fail(h, RAPID_ENODE_EXISTS, "node %d already in ring", node);          // :133-135
+    h->member[(size_t)node] = 1;
+    h->ids_seen.insert(id);
+    h->ids_dirty = true;
+    return rebuild_view(h);
+}
+
+int rapid_view_ring_delete(rapid_engine* h, int32_t node) {
+    int rc = check_node(h, node);
+    if (rc) return rc;
+    if ((rc = use_device(h))) return rc;
+    if (!h->member[(size_t)node]) return fail(h, RAPID_ENODE_MISSING, "node %d not in ring", node);  // :172-174
+    h->member[(size_t)node] = 0;  // identifiersSeen is never pruned (:167-201)
+    return rebuild_view(h);
+}
+
+int rapid_view_observers(rapid_engine* h, int32_t node, int32_t* out, int32_t cap, int32_t* n_out) {
+    int rc = check_node(h, node);
+    if (rc) return rc;
+    if (!h->member[(size_t)node]) return fail(h, RAPID_ENODE_MISSING, "node %d not in ring", node);
+    if ((rc = use_device(h)) || (rc = ensure_host_tables(h))) return rc;
+    const int K = h->cfg.K;
+    return copy_list(h, h->h_obs.data() + (size_t)node * K, h->n_members <= 1 ? 0 : K, out, cap, n_out);
+}
+
+int rapid_view_subjects(rapid_engine* h, int32_t node, int32_t* out, int32_t cap, int32_t* n_out) {
+    int rc = check_node(h, node);
+    if (rc) return rc;
+    if (!h->member[(size_t)node]) return fail(h, RAPID_ENODE_MISSING, "node %d not in ring", node);
+    if ((rc = use_device(h)) || (rc = ensure_host_tables(h))) return rc;
+    const int K = h->cfg.K;
+    return copy_list(h, h->h_subj.data() + (size_t)node * K, h->n_members <= 1 ? 0 : K, out, cap, n_out);
+}
+
+int rapid_view_expected_observers(rapid_engine* h, int32_t node, int32_t* out, int32_t cap, int32_t* n_out) {
+    int rc = check_node(h, node);
+    if (rc) return rc;
+    if ((rc = use_device(h)) || (rc = ensure_host_tables(h))) return rc;
+    const int K = h->cfg.K;
+    if (h->n_members == 0) return copy_list(h, nullptr, 0, out, cap, n_out);  // :296-298
+    if (!h->member[(size_t)node]) return copy_list(h, h->h_obs.data() + (size_t)node * K, K, out, cap, n_out);
+    // a member's "expected observers" are its predecessors (:299 -> :308-322); alone in the ring it precedes itself
+    if (h->n_members == 1) {
+        std::vector<int> self((size_t)K, node);
+        return copy_list(h, self.data(), K, out, cap, n_out);
+    }
+    return copy_list(h, h->h_subj.data() + (size_t)node * K, K, out, cap, n_out);
+}
+
+int rapid_view_ring_numbers(rapid_engine* h, int32_t observer, int32_t subject, int32_t* out, int32_t cap,
+                            int32_t* n_out) {
+    int rc = check_node(h, observer);
+    if (rc) return rc;
+    if (!h->member[(size_t)observer]) return fail(h, RAPID_ENODE_MISSING, "node %d not in ring", observer);
+    if ((rc = use_device(h)) || (rc = ensure_host_tables(h))) return rc;
+    const int K = h->cfg.K;
+    std::vector<int> idx;
+    if (h->n_members > 1)
+        for (int k = 0; k < K; ++k)
+            if (h->h_subj[(size_t)observer * K + k] == subject) idx.push_back(k);
+    return copy_list(h, idx.data(), (int)idx.size(), out, cap, n_out);
+}
+
+int rapid_view_ring(rapid_engine* h, int32_t k, int32_t* out, int32_t cap, int32_t* n_out) {
+    if (!h || !h->view_built) return fail(h, RAPID_ESTATE, "view not built");
+    if (k < 0 || k >= h->cfg.K) return fail(h, RAPID_EINVAL, "ring %d out of range", k);
+    int rc;
+    if ((rc = use_device(h)) || (rc = ensure_host_tables(h))) return rc;
+    return copy_list(h, h->h_ring.data() + (size_t)k * h->n_members, h->n_members, out, cap, n_out);
+}
+
+int rapid_view_ring_key(rapid_engine* h, int32_t k, int32_t node, int64_t* key_out) {
+    int rc = check_node(h, node);
+    if (rc) return rc;
+    if (k < 0 || k >= h->cfg.K) return fail(h, RAPID_EINVAL, "ring %d out of range", k);
+    if ((rc = use_device(h)) || (rc = ensure_host_tables(h))) return rc;
+    *key_out = h->h_keys[(size_t)k * h->n_nodes + node];
+    return RAPID_OK;
+}
+
+int rapid_view_is_host_present(rapid_engine* h, int32_t node, int32_t* present_out) {
+    int rc = check_node(h, node);
+    if (rc) return rc;
+    *present_out = h->member[(size_t)node] ? 1 : 0;
+    return RAPID_OK;
+}
+
+int rapid_view_size(rapid_engine* h, int32_t* n_out) {
+    if (!h || !h->view_built) return fail(h, RAPID_ESTATE, "view not built");
+    *n_out = h->n_members;
+    return RAPID_OK;
+}
+
+int rapid_view_config_id(rapid_engine* h, int64_t* id_out) {
+    if (!h || !h->view_built) return fail(h, RAPID_ESTATE, "view not built");
+    *id_out = h->config_id;
+    return RAPID_OK;
+}
+
+int rapid_view_tables(rapid_engine* h, int32_t* observers, int32_t* subjects, uint8_t* member, int32_t n_nodes) {
+    if (!h || !h->view_built) return fail(h, RAPID_ESTATE, "view not built");
+    if (n_nodes != h->n_nodes) return fail(h, RAPID_EINVAL, "n_nodes mismatch (%d vs %d)", n_nodes, h->n_nodes);
+    int rc;
+    if ((rc = use_device(h)) || (rc = ensure_host_tables(h))) return rc;
+    const size_t n = (size_t)h->cfg.K * n_nodes;
+    if (observers) std::memcpy(observers, h->h_obs.data(), n * sizeof(int));
+    if (subjects) std::memcpy(subjects, h->h_subj.data(), n * sizeof(int));
+    if (member) std::memcpy(member, h->member.data(), (size_t)n_nodes);
+    return RAPID_OK;
+}
+
+// ------------------------------------------------------------------------------------ single detector
+int rapid_cd_create(rapid_engine* h, int32_t K, int32_t H, int32_t L, rapid_cd** out) {
+    if (!h || !out) return RAPID_EINVAL;
+    *out = nullptr;
+    if (!valid_khl(K, H, L) || K > RAPID_MAX_K) return fail(h, RAPID_EINVAL, "Arguments do not satisfy K > H >= L >= 0");
+    int rc = use_device(h);
+    if (rc) return rc;
+    rapid_cd* cd = new rapid_cd();
+    cd->eng = h;
+    cd->K = K;
+    cd->H = H;
+    cd->L = L;
+    cd->n_nodes = h->cfg.n_max;
+    const size_t n_padded = (size_t)((cd->n_nodes + 7) / 8) * 8;
+    hipError_t e = cd->d_state.ensure(n_padded);
+    if (e == hipSuccess) e = cd->d_scal.ensure(4);
+    if (e == hipSuccess) e = cd->d_out_n.ensure(1);
+    if (e == hipSuccess) e = cd->d_out.ensure((size_t)cd->n_nodes);
+    if (e == hipSuccess) e = hipMemsetAsync(cd->d_state.p, 0, n_padded * 2, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(cd->d_scal.p, 0, 16, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        delete cd;
+        return fail(h, RAPID_EDEVICE, "rapid_cd_create: %s", hipGetErrorString(e));
+    }
+    *out = cd;
+    return RAPID_OK;
+}
+
+void rapid_cd_destroy(rapid_cd* cd) {
+    if (!cd) return;
+    (void)hipSetDevice(cd->eng->cfg.device_id);
+    cd->d_state.release(); cd->d_scal.release(); cd->d_out.release(); cd->d_counts.release();
+    cd->d_out_n.release(); cd->d_alerts.release();
+    delete cd;
+}
+
+static int cd_run(rapid_cd* cd, const rapid_alert_record* alerts, int n, int mode, int32_t* out_idx, int32_t cap,
+                  int32_t* out_counts, int32_t* n_out) {
+    rapid_engine* h = cd->eng;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (mode == 1) {
+        if (!h->view_built) return fail(h, RAPID_ESTATE, "invalidateFailingEdges needs a view");
+        if (cd->K != h->cfg.K) return fail(h, RAPID_EINVAL, "detector K=%d differs from the view's K=%d", cd->K, h->cfg.K);
+    }
+    HIPCHK(h, cd->d_counts.ensure((size_t)std::max(n, 1)));
+    HIPCHK(h, cd->d_alerts.ensure((size_t)std::max(n, 1) * 20));
+    if (n) HIPCHK(h, hipMemcpyAsync(cd->d_alerts.p, alerts, (size_t)n * 20, hipMemcpyHostToDevice, h->stream));
+    rapid::CdParams p;
+    p.state = cd->d_state.p;
+    p.scal = cd->d_scal.p;
+    p.alerts = cd->d_alerts.p;
+    p.n_alerts = n;
+    p.n_nodes = mode == 1 ? std::min(cd->n_nodes, h->n_nodes) : cd->n_nodes;
+    p.K = cd->K;
+    p.H = cd->H;
+    p.L = cd->L;
+    p.obs = h->view_built ? h->d_obs.p : nullptr;
+    p.subj = h->view_built ? h->d_subj.p : nullptr;
+    p.out_idx = cd->d_out.p;
+    p.out_cap = cd->n_nodes;
+    p.out_counts = cd->d_counts.p;
+    p.out_n = cd->d_out_n.p;
+    p.mode = mode;
+    hipLaunchKernelGGL(rapid::cd_instance_kernel, dim3(1), dim3(64), 0, h->stream, p);
+    int total = 0;
+    HIPCHK(h, hipMemcpyAsync(&total, cd->d_out_n.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    if (n_out) *n_out = total;
+    if (out_counts && n) HIPCHK(h, hipMemcpy(out_counts, cd->d_counts.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    if (total > cap) return fail(h, RAPID_ECAPACITY, "proposal of %d nodes exceeds capacity %d", total, cap);
+    if (total) HIPCHK(h, hipMemcpy(out_idx, cd->d_out.p, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost));
+    return RAPID_OK;
+}
+
+int rapid_cd_aggregate(rapid_cd* cd, const rapid_alert_record* alerts, int32_t n, int32_t* out_idx, int32_t cap,
+                       int32_t* out_counts, int32_t* n_out) {
+    if (!cd || n < 0 || (n > 0 && !alerts)) return RAPID_EINVAL;
+    return cd_run(cd, alerts, n, 0, out_idx, cap, out_counts, n_out);
+}
+
+int rapid_cd_invalidate(rapid_cd* cd, int32_t* out_idx, int32_t cap, int32_t* n_out) {
+    if (!cd) return RAPID_EINVAL;
+    return cd_run(cd, nullptr, 0, 1, out_idx, cap, nullptr, n_out);
+}
+
+int rapid_cd_num_proposals(rapid_cd* cd, int32_t* n_out) {
+    if (!cd || !n_out) return RAPID_EINVAL;
+    rapid_engine* h = cd->eng;
+    int rc = use_device(h);
+    if (rc) return rc;
+    int scal[4];
+    HIPCHK(h, hipMemcpyAsync(scal, cd->d_scal.p, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *n_out = scal[1];
+    return RAPID_OK;
+}
+
+int rapid_cd_clear(rapid_cd* cd) {
+    if (!cd) return RAPID_EINVAL;
+    rapid_engine* h = cd->eng;
+    int rc = use_device(h);
+    if (rc) return rc;
+    const size_t n_padded = (size_t)((cd->n_nodes + 7) / 8) * 8;
+    HIPCHK(h, hipMemsetAsync(cd->d_state.p, 0, n_padded * 2, h->stream));
+    HIPCHK(h, hipMemsetAsync(cd->d_scal.p, 0, 16, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RAPID_OK;
+}
+
+// ------------------------------------------------------------------------------------------ population
+int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, const int64_t* rec_off,
+                           int32_t n_receivers) {
+    if (!h || !rec_off || n_receivers < 0) return RAPID_EINVAL;
+    int rc = use_device(h);
+    if (rc) return rc;
+    const long long n_rec = rec_off[n_receivers];
+    if (n_rec < 0 || (n_rec > 0 && !records)) return fail(h, RAPID_EINVAL, "bad record stream");
+    for (int r = 0; r < n_receivers; ++r)
+        if (rec_off[r + 1] < rec_off[r]) return fail(h, RAPID_EINVAL, "rec_off not monotone at %d", r);
+    const size_t bytes = (size_t)n_rec * 20;
+    const size_t padded = ((bytes + 15) / 16) * 16 + 64;
+    HIPCHK(h, h->d_records_own.ensure(padded));
+    HIPCHK(h, h->d_rec_off_own.ensure((size_t)n_receivers + 1));
+    HIPCHK(h, hipMemsetAsync(h->d_records_own.p + (bytes / 16) * 16, 0, padded - (bytes / 16) * 16, h->stream));
+    if (bytes) HIPCHK(h, hipMemcpyAsync(h->d_records_own.p, records, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_rec_off_own.p, rec_off, sizeof(long long) * ((size_t)n_receivers + 1), hipMemcpyHostToDevice,
+                             h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->d_records = h->d_records_own.p;
+    h->records_bytes = padded;
+    h->d_rec_off = h->d_rec_off_own.p;
+    h->n_receivers = n_receivers;
+    h->streams_loaded = true;
+    h->tallied = false;
+    h->have_decision = false;
+    return RAPID_OK;
+}
+
+int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64_t records_bytes,
+                                  const int64_t* d_rec_off, int32_t n_receivers) {
+    if (!h || !d_rec_off || n_receivers < 0 || (!d_records && records_bytes)) return RAPID_EINVAL;
+    h->d_records = static_cast<const unsigned char*>(d_records);
+    h->records_bytes = records_bytes;
+    h->d_rec_off = reinterpret_cast<const long long*>(d_rec_off);
+    h->n_receivers = n_receivers;
+    h->streams_loaded = true;
+    h->tallied = false;
+    h->have_decision = false;
+    return RAPID_OK;
+}
+
+int rapid_sim_tally(rapid_engine* h) {
+    if (!h) return RAPID_EINVAL;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = prepare_tally(h))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, 64, h->stream));
+    if (h->n_receivers > 0) {
+        if ((rc = launch_tally(h))) return rc;
+        HIPCHK(h, hipGetLastError());
+    }
+    h->tallied = true;
+    h->have_decision = false;
+    return RAPID_OK;
+}
+
+int rapid_sim_results(rapid_engine* h, int32_t* emit_batch, int32_t* num_proposals, int32_t* prop_count,
+                      uint64_t* fingerprint, int32_t n_receivers) {
+    if (!h) return RAPID_EINVAL;
+    if (!h->tallied) return fail(h, RAPID_ESTATE, "no tally has run");
+    if (n_receivers != h->n_receivers) return fail(h, RAPID_EINVAL, "n_receivers mismatch");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const size_t R = (size_t)n_receivers;
+    if (R) {
+        if (emit_batch) HIPCHK(h, hipMemcpyAsync(emit_batch, h->d_emit.p, 4 * R, hipMemcpyDeviceToHost, h->stream));
+        if (num_proposals) HIPCHK(h, hipMemcpyAsync(num_proposals, h->d_nprop.p, 4 * R, hipMemcpyDeviceToHost, h->stream));
+        if (prop_count) HIPCHK(h, hipMemcpyAsync(prop_count, h->d_pcount.p, 4 * R, hipMemcpyDeviceToHost, h->stream));
+        if (fingerprint) HIPCHK(h, hipMemcpyAsync(fingerprint, h->d_fp.p, 8 * R, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return RAPID_OK;
+}
+
+static void sort_ring0(rapid_engine* h, std::vector<int>& v) {
+    // R/MembershipService.java:346-348: sorted(membershipView.getRingZeroComparator()) -- signed key compare
+    const long long* k0 = h->h_keys.data();
+    std::stable_sort(v.begin(), v.end(), [k0](int a, int b) { return k0[a] < k0[b]; });
+}
+
+int rapid_sim_proposal(rapid_engine* h, int32_t receiver, int32_t* out, int32_t cap, int32_t* n_out) {
+    if (!h) return RAPID_EINVAL;
+    if (!h->tallied) return fail(h, RAPID_ESTATE, "no tally has run");
+    if (receiver < 0 || receiver >= h->n_receivers) return fail(h, RAPID_EINVAL, "receiver out of range");
+    int rc;
+    if ((rc = use_device(h)) || (rc = ensure_host_tables(h))) return rc;
+    int cnt = 0;
+    HIPCHK(h, hipMemcpyAsync(&cnt, h->d_pcount.p + receiver, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (cnt < 0) return fail(h, RAPID_ECAPACITY, "receiver %d's proposal exceeds max_cut=%d", receiver, h->max_cut);
+    std::vector<int> v((size_t)cnt);
+    if (cnt)
+        HIPCHK(h, hipMemcpy(v.data(), h->d_props.p + (size_t)receiver * h->max_cut, sizeof(int) * (size_t)cnt,
+                            hipMemcpyDeviceToHost));
+    sort_ring0(h, v);
+    return copy_list(h, v.data(), cnt, out, cap, n_out);
+}
+
+int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
+    if (!h || !out) return RAPID_EINVAL;
+    if (!h->tallied) return fail(h, RAPID_ESTATE, "no tally has run");
+    int rc;
+    if ((rc = use_device(h)) || (rc = ensure_host_tables(h))) return rc;
+    std::memset(out, 0, sizeof *out);
+    const int N = h->n_members;
+    const int F = (int)std::floor((double)(N - 1) / 4.0);  // R/FastPaxos.java:145
+    out->membership_size = N;
+    out->quorum = N - F;
+    out->config_id = h->config_id;
+    h->have_decision = false;
+    h->decided_cut.clear();
+    hipStream_t st = h->stream;
+    const int R = h->n_receivers;
+    const size_t HB = (size_t)rapid::kVoteBuckets + 2;
+    HIPCHK(h, h->d_hist.ensure(HB));
+    HIPCHK(h, h->d_winner.ensure(4));
+    HIPCHK(h, h->d_mm.ensure(4));
+    HIPCHK(h, h->d_mismatch.ensure(2));
+    HIPCHK(h, h->d_ref.ensure((size_t)h->max_cut + 1));
+
+    for (unsigned long long salt = 0; salt < 4; ++salt) {
+        HIPCHK(h, hipMemsetAsync(h->d_hist.p, 0, HB * 8, st));
+        if (R)
+            hipLaunchKernelGGL(rapid::vote_histogram_kernel, dim3(grid_for(R, 256)), dim3(256), 0, st, h->d_fp.p, h->d_pcount.p,
+                               R, salt, h->d_hist.p);
+        if (h->comm)  // the per-round all-reduce of the vote histogram over xGMI
+            NCCLCHK(h, ncclAllReduce(h->d_hist.p, h->d_hist.p, HB, ncclUint64, ncclSum, h->comm, st));
+        hipLaunchKernelGGL(rapid::vote_winner_kernel, dim3(1), dim3(256), 0, st, h->d_hist.p, h->d_winner.p);
+        HIPCHK(h, hipMemsetAsync(h->d_mm.p, 0, 32, st));
+        if (R)
+            hipLaunchKernelGGL(rapid::vote_bucket_minmax_kernel, dim3(grid_for(R, 256)), dim3(256), 0, st, h->d_fp.p,
+                               h->d_pcount.p, R, salt, h->d_winner.p, h->d_mm.p);
+        unsigned long long mm_local[4] = {0, 0, 0, 0};
+        HIPCHK(h, hipMemcpyAsync(mm_local, h->d_mm.p, 24, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        const bool have_local_rep = mm_local[2] != 0ull;
+        const int local_rep = have_local_rep ? (int)(~mm_local[2]) : -1;
+        if (h->comm) {  // mm[3] = ~(lowest rank that holds a representative)
+            unsigned long long r3 = have_local_rep ? ~(unsigned long long)h->rank : 0ull;
+            HIPCHK(h, hipMemcpyAsync(h->d_mm.p + 3, &r3, 8, hipMemcpyHostToDevice, st));
+            NCCLCHK(h, ncclAllReduce(h->d_mm.p, h->d_mm.p, 4, ncclUint64, ncclMax, h->comm, st));
+        }
+        unsigned long long win[4] = {0, 0, 0, 0}, mm[4] = {0, 0, 0, 0};
+        HIPCHK(h, hipMemcpyAsync(win, h->d_winner.p, 24, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(mm, h->d_mm.p, 32, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, hipGetLastError());
+        out->votes_total = (int64_t)win[2];
+        out->votes_winner = (int64_t)win[1];
+        if (win[1] == 0) return RAPID_OK;  // nobody proposed
+        const unsigned long long fmax = mm[0], fmin = ~mm[1];
+        if (fmax != fmin) {
+            if ((long long)win[1] < out->quorum) return RAPID_OK;  // no proposal can have a quorum
+            continue;  // two proposals share the winning bucket: re-hash with the next salt
+        }
+        // the winning bucket is pure: fetch the representative's list, verify every voter against it
+        int ref_n = 0;
+        const int owner = h->comm ? (int)(~mm[3]) : h->rank;
+        if (owner == h->rank) {
+            HIPCHK(h, hipMemcpyAsync(&ref_n, h->d_pcount.p + local_rep, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+            if (ref_n < 0) return fail(h, RAPID_ECAPACITY, "winning proposal exceeds max_cut=%d", h->max_cut);
+            HIPCHK(h, hipMemcpyAsync(h->d_ref.p, &ref_n, 4, hipMemcpyHostToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(h->d_ref.p + 1, h->d_props.p + (size_t)local_rep * h->max_cut, sizeof(int) * (size_t)ref_n,
+                                     hipMemcpyDeviceToDevice, st));
+        }
+        if (h->comm) {
+            NCCLCHK(h, ncclBroadcast(h->d_ref.p, h->d_ref.p, (size_t)h->max_cut + 1, ncclInt32, owner, h->comm, st));
+            HIPCHK(h, hipMemcpyAsync(&ref_n, h->d_ref.p, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+        }
+        HIPCHK(h, hipMemsetAsync(h->d_mismatch.p, 0, 16, st));
+        if (R)
+            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3((unsigned)R), dim3(64), 0, st, h->d_fp.p, h->d_pcount.p, h->d_props.p,
+                               h->max_cut, R, fmax, h->d_ref.p + 1, ref_n, h->d_mismatch.p);
+        if (h->comm) NCCLCHK(h, ncclAllReduce(h->d_mismatch.p, h->d_mismatch.p, 2, ncclUint64, ncclSum, h->comm, st));
+        unsigned long long mis[2] = {0, 0};
+        HIPCHK(h, hipMemcpyAsync(mis, h->d_mismatch.p, 16, hipMemcpyDeviceToHost, st));
+        std::vector<int> ref((size_t)ref_n);
+        if (ref_n) HIPCHK(h, hipMemcpyAsync(ref.data(), h->d_ref.p + 1, sizeof(int) * (size_t)ref_n, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        HIPCHK(h, hipGetLastError());
+        if (mis[0] != 0 || mis[1] != win[1])
+            return fail(h, RAPID_ECOLLISION, "fingerprint collision: %llu of %llu voters differ from the representative",
+                        mis[0], win[1]);
+        out->cut_size = ref_n;
+        // R/FastPaxos.java:146-150: |votesReceived| >= N - F and votes[proposal] >= N - F
+        if ((long long)win[1] >= out->quorum) {
+            out->decided = 1;
+            sort_ring0(h, ref);
+            h->decided_cut = ref;
+            h->have_decision = true;
+        }
+        return RAPID_OK;
+    }
+    return fail(h, RAPID_ECOLLISION, "winning vote bucket stayed impure under 4 salts");
+}
+
+int rapid_sim_decided_cut(rapid_engine* h, int32_t* out, int32_t cap, int32_t* n_out) {
+    if (!h) return RAPID_EINVAL;
+    if (!h->have_decision) return fail(h, RAPID_ESTATE, "no decision available");
+    return copy_list(h, h->decided_cut.data(), (int)h->decided_cut.size(), out, cap, n_out);
+}
+
+int rapid_apply_cut(rapid_engine* h, const int32_t* cut, int32_t n, int64_t* new_config_id) {
+    if (!h || n < 0 || (n > 0 && !cut)) return RAPID_EINVAL;
+    if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
+    int rc = use_device(h);
+    if (rc) return rc;
+    // validate first so that a failing call leaves the view untouched
+    std::vector<uint8_t> mem = h->member;
+    std::set<std::pair<int64_t, int64_t>> added;
+    for (int i = 0; i < n; ++i) {
+        const int node = cut[i];
+        if (node < 0 || node >= h->n_nodes) return fail(h, RAPID_EINVAL, "node index %d out of range", node);
+        if (mem[(size_t)node]) {
+            mem[(size_t)node] = 0;  // ringDelete (R/MembershipService.java:399-400)
+        } else {
+            const std::pair<int64_t, int64_t> id{h->id_hi[(size_t)node], h->id_lo[(size_t)node]};
+            if (h->ids_seen.count(id) || added.count(id))
+                return fail(h, RAPID_EUUID_SEEN, "identifier of joiner %d already seen", node);  // ringAdd :127-129
+            added.insert(id);
+            mem[(size_t)node] = 1;  // ringAdd (R/MembershipService.java:404-407)
+        }
+    }
+    h->member.swap(mem);
+    if (!added.empty()) {
+        h->ids_seen.insert(added.begin(), added.end());
+        h->ids_dirty = true;
+    }
+    rc = rebuild_view(h);  // new rings, tables, configuration id; cutDetection.clear() == fresh state next tally
+    if (rc) return rc;
+    if (new_config_id) *new_config_id = h->config_id;
+    return RAPID_OK;
+}
+
+int rapid_sim_round(rapid_engine* h, int32_t apply, rapid_round_result* out, int64_t* new_config_id) {
+    int rc = rapid_sim_tally(h);
+    if (rc) return rc;
+    if ((rc = rapid_sim_count_votes(h, out))) return rc;
+    if (out->decided && apply) {
+        const std::vector<int> cut = h->decided_cut;
+        if ((rc = rapid_apply_cut(h, cut.data(), (int)cut.size(), new_config_id))) return rc;
+        h->decided_cut = cut;
+        h->have_decision = true;
+    } else if (new_config_id) {
+        *new_config_id = h->config_id;
+    }
+    return RAPID_OK;
+}
+
+// -------------------------------------------------------------------------------------- fast round object
+int rapid_fast_round_create(int64_t config_id, int32_t membership_size, rapid_fast_round** out) {
+    if (!out || membership_size < 0) return RAPID_EINVAL;
+    rapid_fast_round* f = new rapid_fast_round();
+    f->config_id = config_id;
+    f->membership_size = membership_size;
+    *out = f;
+    return RAPID_OK;
+}
+
+void rapid_fast_round_destroy(rapid_fast_round* f) { delete f; }
+
+int rapid_fast_round_vote(rapid_fast_round* f, int32_t sender, int64_t config_id, const int32_t* endpoints, int32_t n,
+                          int32_t* decided_out) {
+    if (!f || n < 0 || (n > 0 && !endpoints)) return RAPID_EINVAL;
+    if (decided_out) *decided_out = f->decided ? 1 : 0;
+    if (config_id != f->config_id) return RAPID_OK;       // R/FastPaxos.java:126-132
+    if (f->votes_received.count(sender)) return RAPID_OK;  // :134-136
+    if (f->decided) return RAPID_OK;                       // :138-140
+    f->votes_received.insert(sender);
+    std::vector<int32_t> key(endpoints, endpoints + n);
+    const int count = ++f->votes_per_proposal[key];
+    const long F = (long)std::floor((double)(f->membership_size - 1) / 4.0);  // :145
+    if ((long)f->votes_received.size() >= f->membership_size - F && count >= f->membership_size - F) {
+        f->decided = true;
+        f->decision = key;
+    }
+    if (decided_out) *decided_out = f->decided ? 1 : 0;
+    return RAPID_OK;
+}
+
+int rapid_fast_round_decision(rapid_fast_round* f, int32_t* out, int32_t cap, int32_t* n_out) {
+    if (!f) return RAPID_EINVAL;
+    if (!f->decided) return RAPID_ESTATE;
+    if (n_out) *n_out = (int32_t)f->decision.size();
+    if ((int32_t)f->decision.size() > cap) return RAPID_ECAPACITY;
+    for (size_t i = 0; i < f->decision.size(); ++i) out[i] = f->decision[i];
+    return RAPID_OK;
+}
+
+// ------------------------------------------------------------------------------------------- multi-GPU
+int rapid_comm_unique_id(uint8_t out[RAPID_UNIQUE_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) <= RAPID_UNIQUE_ID_BYTES, "unique id does not fit");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return RAPID_EDEVICE;
+    std::memset(out, 0, RAPID_UNIQUE_ID_BYTES);
+    std::memcpy(out, &id, sizeof id);
+    return RAPID_OK;
+}
+
+int rapid_engine_comm_init(rapid_engine* h, const uint8_t id_bytes[RAPID_UNIQUE_ID_BYTES], int32_t rank, int32_t n_ranks) {
+    if (!h || !id_bytes || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return RAPID_EINVAL;
+    int rc = use_device(h);
+    if (rc) return rc;
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof id);
+    NCCLCHK(h, ncclCommInitRank(&h->comm, n_ranks, id, rank));
+    h->rank = rank;
+    h->n_ranks = n_ranks;
+    return RAPID_OK;
+}
+
+// --------------------------------------------------------------------------------------- instrumentation
+void* rapid_engine_stream(rapid_engine* h) { return h ? (void*)h->stream : nullptr; }
+
+int rapid_engine_sync(rapid_engine* h) {
+    if (!h) return RAPID_EINVAL;
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return RAPID_OK;
+}
+
+int rapid_sim_stats(rapid_engine* h, uint64_t stats[8]) {
+    if (!h || !stats) return RAPID_EINVAL;
+    if (!h->tallied) return fail(h, RAPID_ESTATE, "no tally has run");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(stats, h->d_stats.p, 64, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RAPID_OK;
+}
+
+int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg) {
+    if (!h || reps <= 0 || !ms_avg) return RAPID_EINVAL;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = prepare_tally(h))) return rc;
+    if (h->n_receivers == 0) return fail(h, RAPID_ESTATE, "no receivers");
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, 64, h->stream));
+    launch_tally(h);  // untimed warm-up
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps; ++i) launch_tally(h);
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipEventSynchronize(e1));
+    HIPCHK(h, hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_avg = ms / (float)reps;
+    h->tallied = true;
+    return RAPID_OK;
+}
+
+int rapid_sim_set_force_exact(rapid_engine* h, int32_t on) {
+    if (!h) return RAPID_EINVAL;
+    h->force_exact = on ? 1 : 0;
+    return RAPID_OK;
+}
+
+}  // extern "C"

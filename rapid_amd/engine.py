@@ -1,0 +1,343 @@
+"""Host-side mirror of the reference's interface for the hot path, over the C ABI (include/rapid_mi355x.h).
+
+Class and method names follow the Java classes they stand in for, so the parity tests read like the reference's
+own tests (R/ = /root/reference/rapid/src/main/java/com/vrg/rapid/):
+
+    Engine                  one simulated cluster on one MI355X (lifecycle + registry of endpoints)
+    MembershipView          R/MembershipView.java          (ringAdd / ringDelete / getObserversOf / ...)
+    MultiNodeCutDetector    R/MultiNodeCutDetector.java    (aggregateForProposal / invalidateFailingEdges / ...)
+    FastPaxos               R/FastPaxos.java:125-156       (handleFastRoundProposal; fast round only)
+    ClusterSimulation       R/MembershipService.java:300-354, 385-430 replayed at every receiver at once
+
+Everything executes in librapid_mi355x.so on the GPU.  There is no CPU path: constructing an Engine without
+the built library or without a gfx950 device raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from ._native import (IllegalArgumentException, NodeAlreadyInRingException, NodeNotInRingException,  # noqa: F401
+                      RapidError, RoundResult, UUIDAlreadySeenException)
+from .scenarios import ALERT_DTYPE
+
+UP, DOWN = 0, 1
+HOSTNAME_ALREADY_IN_RING, UUID_ALREADY_IN_RING, SAFE_TO_JOIN = 0, 1, 2
+
+
+def _addr(a):
+    return None if a is None else a.ctypes.data
+
+
+def device_count():
+    return N.lib().rapid_device_count()
+
+
+class Engine:
+    def __init__(self, n_max, K=10, H=9, L=4, device_id=0, max_cut=0):
+        self._lib = N.lib()
+        self._h = C.c_void_p()
+        cfg = N.EngineConfig(n_max, K, H, L, device_id, max_cut)
+        rc = self._lib.rapid_engine_create(C.byref(cfg), C.byref(self._h))
+        if rc != N.OK:
+            self._h = C.c_void_p()
+            msg = {N.EINVAL: "Arguments do not satisfy K > H >= L >= 0 (or K > %d)" % 14,
+                   N.EDEVICE: "no usable gfx950 device (there is no CPU fallback)"}.get(rc, "")
+            N.raise_for(rc, msg)
+        self.n_max, self.K, self.H, self.L = n_max, K, H, L
+        self.max_cut = max_cut if max_cut > 0 else min(n_max, 4096)
+        self.n_nodes = 0
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.rapid_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != N.OK:
+            msg = self._lib.rapid_last_error(self._h)
+            N.raise_for(rc, msg.decode() if msg else "")
+
+    def sync(self):
+        self._check(self._lib.rapid_engine_sync(self._h))
+
+    @property
+    def stream(self):
+        return self._lib.rapid_engine_stream(self._h)
+
+    def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
+        buf = np.frombuffer(unique_id, dtype=np.uint8).copy()
+        self._check(self._lib.rapid_engine_comm_init(self._h, _addr(buf), rank, n_ranks))
+
+
+def comm_unique_id() -> bytes:
+    buf = np.zeros(128, dtype=np.uint8)
+    rc = N.lib().rapid_comm_unique_id(_addr(buf))
+    if rc != N.OK:
+        N.raise_for(rc, "ncclGetUniqueId failed")
+    return buf.tobytes()
+
+
+class MembershipView:
+    """R/MembershipView.java on the device.  Endpoints are dense node indices into the registry given to build()."""
+
+    def __init__(self, engine):
+        self.e = engine
+        self.K = engine.K
+
+    def build(self, hostnames, ports, id_hi, id_lo, members=None, extra_ids=None):
+        """MembershipView(K, nodeIds, endpoints) (:74-89).  hostnames: list of bytes."""
+        n = len(hostnames)
+        off = np.zeros(n + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(x) for x in hostnames])
+        blob = np.frombuffer(b"".join(hostnames) or b"\0", dtype=np.uint8).copy()
+        ports = np.ascontiguousarray(ports, dtype=np.int32)
+        hi = np.ascontiguousarray(id_hi, dtype=np.int64)
+        lo = np.ascontiguousarray(id_lo, dtype=np.int64)
+        mem = np.arange(n, dtype=np.int32) if members is None else np.ascontiguousarray(members, dtype=np.int32)
+        if extra_ids:
+            xh = np.ascontiguousarray([i[0] for i in extra_ids], dtype=np.int64)
+            xl = np.ascontiguousarray([i[1] for i in extra_ids], dtype=np.int64)
+        else:
+            xh = xl = None
+        self.e._check(self.e._lib.rapid_view_build(self.e._h, _addr(blob), _addr(off), _addr(ports), _addr(hi), _addr(lo),
+                                                   n, _addr(mem) if len(mem) else None, len(mem), _addr(xh), _addr(xl),
+                                                   0 if xh is None else len(xh)))
+        self.e.n_nodes = n
+        return self
+
+    def _list(self, fn, *args, cap=None):
+        cap = cap or max(self.K, 1)
+        out = np.empty(cap, dtype=np.int32)
+        n = C.c_int32(0)
+        self.e._check(fn(self.e._h, *args, _addr(out), cap, C.byref(n)))
+        return out[: n.value].tolist()
+
+    def isSafeToJoin(self, node):
+        s = C.c_int32(0)
+        self.e._check(self.e._lib.rapid_view_is_safe_to_join(self.e._h, node, C.byref(s)))
+        return s.value
+
+    def ringAdd(self, node):
+        self.e._check(self.e._lib.rapid_view_ring_add(self.e._h, node))
+
+    def ringDelete(self, node):
+        self.e._check(self.e._lib.rapid_view_ring_delete(self.e._h, node))
+
+    def getObserversOf(self, node):
+        return self._list(self.e._lib.rapid_view_observers, node)
+
+    def getSubjectsOf(self, node):
+        return self._list(self.e._lib.rapid_view_subjects, node)
+
+    def getExpectedObserversOf(self, node):
+        return self._list(self.e._lib.rapid_view_expected_observers, node)
+
+    def getRingNumbers(self, observer, subject):
+        return self._list(self.e._lib.rapid_view_ring_numbers, observer, subject)
+
+    def getRing(self, k):
+        return np.asarray(self._list(self.e._lib.rapid_view_ring, k, cap=max(self.getMembershipSize(), 1)), dtype=np.int32)
+
+    def ringKey(self, k, node):
+        v = C.c_int64(0)
+        self.e._check(self.e._lib.rapid_view_ring_key(self.e._h, k, node, C.byref(v)))
+        return v.value
+
+    def isHostPresent(self, node):
+        v = C.c_int32(0)
+        self.e._check(self.e._lib.rapid_view_is_host_present(self.e._h, node, C.byref(v)))
+        return bool(v.value)
+
+    def getMembershipSize(self):
+        v = C.c_int32(0)
+        self.e._check(self.e._lib.rapid_view_size(self.e._h, C.byref(v)))
+        return v.value
+
+    def getCurrentConfigurationId(self):
+        v = C.c_int64(0)
+        self.e._check(self.e._lib.rapid_view_config_id(self.e._h, C.byref(v)))
+        return v.value
+
+    def tables(self):
+        n, K = self.e.n_nodes, self.K
+        obs = np.empty((n, K), dtype=np.int32)
+        subj = np.empty((n, K), dtype=np.int32)
+        member = np.empty(n, dtype=np.uint8)
+        self.e._check(self.e._lib.rapid_view_tables(self.e._h, _addr(obs), _addr(subj), _addr(member), n))
+        return obs, subj, member
+
+
+def alert(src, dst, status, configuration_id, ring_numbers):
+    """AlertMessage (rapid.proto:102-111) as one packed record."""
+    if isinstance(ring_numbers, int):
+        ring_numbers = [ring_numbers]
+    a = np.zeros(1, dtype=ALERT_DTYPE)
+    a["src"], a["dst"], a["status"], a["cfg_id"] = src, dst, status, configuration_id
+    m = 0
+    for r in ring_numbers:
+        m |= 1 << r
+    a["ring_mask"] = m
+    return a
+
+
+class MultiNodeCutDetector:
+    """R/MultiNodeCutDetector.java, state on the device (one wavefront runs the exact sequential kernel)."""
+
+    def __init__(self, engine, K, H, L):
+        self.e = engine
+        self._h = C.c_void_p()
+        self.e._check(self.e._lib.rapid_cd_create(self.e._h, K, H, L, C.byref(self._h)))
+        self._cap = engine.n_max
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value and self.e._h.value:
+                self.e._lib.rapid_cd_destroy(self._h)
+        except Exception:
+            pass
+
+    def aggregateForProposal(self, alerts):
+        """One AlertMessage (or an array of them, applied in order).  Returns the list of proposed endpoints."""
+        alerts = np.ascontiguousarray(alerts, dtype=ALERT_DTYPE)
+        out = np.empty(self._cap, dtype=np.int32)
+        counts = np.empty(max(len(alerts), 1), dtype=np.int32)
+        n = C.c_int32(0)
+        self.e._check(self.e._lib.rapid_cd_aggregate(self._h, _addr(alerts), len(alerts), _addr(out), self._cap,
+                                                     _addr(counts), C.byref(n)))
+        return out[: n.value].tolist()
+
+    def invalidateFailingEdges(self):
+        out = np.empty(self._cap, dtype=np.int32)
+        n = C.c_int32(0)
+        self.e._check(self.e._lib.rapid_cd_invalidate(self._h, _addr(out), self._cap, C.byref(n)))
+        return out[: n.value].tolist()
+
+    def getNumProposals(self):
+        n = C.c_int32(0)
+        self.e._check(self.e._lib.rapid_cd_num_proposals(self._h, C.byref(n)))
+        return n.value
+
+    def clear(self):
+        self.e._check(self.e._lib.rapid_cd_clear(self._h))
+
+
+class FastPaxos:
+    """Fast round of R/FastPaxos.java (:125-156): count identical proposals, decide at N - floor((N-1)/4)."""
+
+    def __init__(self, configuration_id, membership_size):
+        self._lib = N.lib()
+        self._h = C.c_void_p()
+        rc = self._lib.rapid_fast_round_create(configuration_id, membership_size, C.byref(self._h))
+        if rc != N.OK:
+            N.raise_for(rc)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._lib.rapid_fast_round_destroy(self._h)
+        except Exception:
+            pass
+
+    def handleFastRoundProposal(self, sender, configuration_id, endpoints):
+        e = np.ascontiguousarray(endpoints, dtype=np.int32)
+        d = C.c_int32(0)
+        rc = self._lib.rapid_fast_round_vote(self._h, sender, configuration_id, _addr(e) if len(e) else None, len(e),
+                                             C.byref(d))
+        if rc != N.OK:
+            N.raise_for(rc)
+        return bool(d.value)
+
+    def decision(self):
+        out = np.empty(1 << 16, dtype=np.int32)
+        n = C.c_int32(0)
+        rc = self._lib.rapid_fast_round_decision(self._h, _addr(out), len(out), C.byref(n))
+        if rc == N.ESTATE:
+            return None
+        if rc != N.OK:
+            N.raise_for(rc)
+        return out[: n.value].tolist()
+
+
+class ClusterSimulation:
+    """Every receiver's MembershipService alert path at once (R/MembershipService.java:300-354), the fast-round
+    vote count over the population (R/FastPaxos.java:125-156) and decideViewChange (:385-430)."""
+
+    def __init__(self, engine):
+        self.e = engine
+        self.n_receivers = 0
+        self._keep = None
+
+    def load_streams(self, records, rec_off):
+        records = np.ascontiguousarray(records, dtype=ALERT_DTYPE)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.int64)
+        self.n_receivers = len(rec_off) - 1
+        self.e._check(self.e._lib.rapid_sim_load_streams(self.e._h, _addr(records) if len(records) else None, _addr(rec_off),
+                                                         self.n_receivers))
+
+    def load_streams_device(self, d_records_ptr, records_bytes, d_rec_off_ptr, n_receivers, keepalive=None):
+        self._keep = keepalive
+        self.n_receivers = n_receivers
+        self.e._check(self.e._lib.rapid_sim_load_streams_device(self.e._h, d_records_ptr, records_bytes, d_rec_off_ptr,
+                                                                n_receivers))
+
+    def tally(self):
+        self.e._check(self.e._lib.rapid_sim_tally(self.e._h))
+
+    def results(self):
+        R = self.n_receivers
+        emit = np.empty(R, dtype=np.int32)
+        nprop = np.empty(R, dtype=np.int32)
+        pcount = np.empty(R, dtype=np.int32)
+        fp = np.empty(R, dtype=np.uint64)
+        self.e._check(self.e._lib.rapid_sim_results(self.e._h, _addr(emit), _addr(nprop), _addr(pcount), _addr(fp), R))
+        return emit, nprop, pcount, fp
+
+    def proposal(self, receiver):
+        out = np.empty(self.e.max_cut, dtype=np.int32)
+        n = C.c_int32(0)
+        self.e._check(self.e._lib.rapid_sim_proposal(self.e._h, receiver, _addr(out), len(out), C.byref(n)))
+        return out[: n.value].tolist()
+
+    def count_votes(self):
+        rr = RoundResult()
+        self.e._check(self.e._lib.rapid_sim_count_votes(self.e._h, C.byref(rr)))
+        return rr
+
+    def decided_cut(self):
+        out = np.empty(self.e.max_cut, dtype=np.int32)
+        n = C.c_int32(0)
+        self.e._check(self.e._lib.rapid_sim_decided_cut(self.e._h, _addr(out), len(out), C.byref(n)))
+        return out[: n.value].tolist()
+
+    def round(self, apply=True):
+        rr = RoundResult()
+        cfg = C.c_int64(0)
+        self.e._check(self.e._lib.rapid_sim_round(self.e._h, 1 if apply else 0, C.byref(rr), C.byref(cfg)))
+        return rr, cfg.value
+
+    def apply_cut(self, cut):
+        cut = np.ascontiguousarray(cut, dtype=np.int32)
+        cfg = C.c_int64(0)
+        self.e._check(self.e._lib.rapid_apply_cut(self.e._h, _addr(cut) if len(cut) else None, len(cut), C.byref(cfg)))
+        return cfg.value
+
+    def stats(self):
+        s = np.zeros(8, dtype=np.uint64)
+        self.e._check(self.e._lib.rapid_sim_stats(self.e._h, _addr(s)))
+        return dict(exact_subchunks=int(s[0]), fast_subchunks=int(s[1]), full_sweeps=int(s[2]), restarts=int(s[3]),
+                    implicit_reports=int(s[4]), records_consumed=int(s[5]))
+
+    def time_tally(self, reps):
+        ms = C.c_float(0)
+        self.e._check(self.e._lib.rapid_sim_time_tally(self.e._h, reps, C.byref(ms)))
+        return ms.value
+
+    def set_force_exact(self, on):
+        self.e._check(self.e._lib.rapid_sim_set_force_exact(self.e._h, 1 if on else 0))

@@ -1,0 +1,106 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol that
+include/rapid_mi355x.h declares, the record layout is the documented 20 bytes, and the host-only control
+object (FastPaxos fast round, R/FastPaxos.java:125-156) passes the reference's quorum tables.  No device
+compute is attempted here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rapid_amd import _native as N
+from rapid_amd import scenarios as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rapid_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rapid_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    N.build()
+    L = C.CDLL(N.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 40
+    for name in names:
+        assert hasattr(L, name), "missing export: " + name
+    assert set(names) == set(N.SIGNATURES), set(names) ^ set(N.SIGNATURES)
+
+
+def test_record_layout():
+    assert S.ALERT_DTYPE.itemsize == 20
+    assert [S.ALERT_DTYPE.fields[f][1] for f in ("cfg_id", "src", "dst", "ring_mask", "status", "flags")] == [0, 8, 12, 16, 18, 19]
+    assert C.sizeof(N.RoundResult) == 48 and C.sizeof(N.EngineConfig) == 24
+
+
+def test_engine_create_validates_khl_before_touching_the_device():
+    """R/MultiNodeCutDetector.java:52-55: H > K || L > H || K < 3 || L <= 0 || H <= 0 -> IllegalArgumentException."""
+    L = N.lib()
+    for K, H, Lw in [(10, 11, 2), (10, 8, 9), (2, 2, 1), (10, 8, 0), (10, 0, 0), (15, 9, 4)]:
+        h = C.c_void_p()
+        cfg = N.EngineConfig(100, K, H, Lw, 0, 0)
+        assert L.rapid_engine_create(C.byref(cfg), C.byref(h)) == N.EINVAL
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    L = N.lib()
+    if L.rapid_device_count() > 0:
+        pytest.skip("a gfx950 device is present")
+    h = C.c_void_p()
+    cfg = N.EngineConfig(100, 10, 9, 4, 0, 0)
+    assert L.rapid_engine_create(C.byref(cfg), C.byref(h)) == N.EDEVICE
+    from rapid_amd import engine as E
+    with pytest.raises(N.RapidError):
+        E.Engine(100)
+
+
+# ---- FastPaxosWithoutFallbackTests.java:61-148 through rapid_fast_round_* (host control object) ----
+NO_CONFLICT = [(6, 5), (48, 37), (50, 38), (100, 76), (102, 77), (5, 4), (51, 39), (49, 37), (99, 75), (101, 76)]
+CONFLICTS = ([(6, 5, 1, True), (48, 37, 1, True), (50, 38, 1, True), (100, 76, 1, True), (102, 77, 1, True)]
+             + [(48, 37, 11, True), (50, 38, 12, True), (100, 76, 24, True), (102, 77, 25, True)]
+             + [(6, 5, 2, False), (48, 37, 14, False), (50, 38, 13, False), (100, 76, 25, False), (102, 77, 26, False)])
+
+
+@pytest.mark.parametrize("n,quorum", NO_CONFLICT)
+def test_fastQuorumTestNoConflicts(n, quorum):
+    from rapid_amd.engine import FastPaxos
+    fp = FastPaxos(configuration_id=-7, membership_size=n)
+    for i in range(quorum - 1):
+        assert not fp.handleFastRoundProposal(1000 + i, -7, [1])
+        assert fp.decision() is None
+    assert fp.handleFastRoundProposal(1000 + quorum - 1, -7, [1])
+    assert fp.decision() == [1]
+
+
+@pytest.mark.parametrize("n,quorum,num_conflicts,change", CONFLICTS)
+def test_fastQuorumTestWithConflicts(n, quorum, num_conflicts, change):
+    from rapid_amd.engine import FastPaxos
+    fp = FastPaxos(configuration_id=5, membership_size=n)
+    for i in range(num_conflicts):
+        assert not fp.handleFastRoundProposal(i, 5, [2])
+    non_conflict = min(num_conflicts + quorum - 1, n - 1)
+    for i in range(num_conflicts, non_conflict):
+        assert not fp.handleFastRoundProposal(i, 5, [1])
+    assert fp.handleFastRoundProposal(non_conflict, 5, [1]) == change
+    assert fp.decision() == ([1] if change else None)
+
+
+def test_fast_round_filters():
+    from rapid_amd.engine import FastPaxos
+    fp = FastPaxos(7, 5)
+    assert not fp.handleFastRoundProposal(0, 8, [1])  # other configuration: dropped (R/FastPaxos.java:126-132)
+    for s in range(3):
+        assert not fp.handleFastRoundProposal(s, 7, [1])
+        assert not fp.handleFastRoundProposal(s, 7, [1])  # same sender twice: second ignored (:134-136)
+    assert fp.handleFastRoundProposal(3, 7, [1])
+    assert fp.handleFastRoundProposal(4, 7, [2])  # decided: ignored, still decided on [1] (:138-140)
+    assert fp.decision() == [1]
+    # ordered-list identity: [1, 2] and [2, 1] are different proposals (List<Endpoint> equality)
+    fp = FastPaxos(1, 4)
+    for s, p in enumerate(([1, 2], [2, 1], [1, 2])):
+        assert not fp.handleFastRoundProposal(s, 1, p)
+    assert fp.handleFastRoundProposal(3, 1, [1, 2]) is False  # 3 votes for [1,2] < N - F = 4

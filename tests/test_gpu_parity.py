@@ -1,0 +1,478 @@
+"""Parity tests proper (-m gpu): the HIP path through the C ABI (rapid_amd.engine -> librapid_mi355x.so) against the
+CPU oracle on the same seeded inputs.  Bit-exact everywhere: ring keys, ring orders, observer/subject tables,
+configuration ids, per-receiver announcing batch / getNumProposals() / proposal list, decided cut, post-cut
+configuration id.  Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+from rapid_amd import scenarios as S
+from tests.helpers import oracle_view, props_list, random_stream
+
+pytestmark = pytest.mark.gpu
+
+K10 = 10
+
+
+@pytest.fixture(scope="module")
+def E():
+    from rapid_amd import engine
+    if engine.device_count() < 1:
+        pytest.fail("no gfx950 device visible: the product has no CPU fallback")
+    return engine
+
+
+def make_engine(E, pop, K, H, L, members=None, **kw):
+    eng = E.Engine(n_max=pop.n, K=K, H=H, L=L, **kw)
+    view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo, members=members)
+    return eng, view
+
+
+# ------------------------------------------------------------------------------------------------ view
+@pytest.mark.parametrize("n,K", [(1, 10), (2, 10), (3, 10), (50, 3), (1000, 10), (4099, 7)])
+def test_view_matches_oracle(E, n, K):
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, K, 1)
+    reg, oview = oracle_view(pop, K)
+    assert view.getMembershipSize() == n
+    for k in range(K):
+        for node in range(0, n, max(1, n // 50)):
+            assert view.ringKey(k, node) == oview.ringKey(k, node)
+        assert np.array_equal(view.getRing(k), oview.getRing(k))
+    obs, subj, member = view.tables()
+    oobs, osubj, omember = oview.tables(n)
+    assert np.array_equal(obs, oobs) and np.array_equal(subj, osubj) and np.array_equal(member, omember)
+    assert view.getCurrentConfigurationId() == oview.getCurrentConfigurationId()
+    for node in range(0, n, max(1, n // 20)):
+        assert view.getObserversOf(node) == oview.getObserversOf(node)
+        assert view.getSubjectsOf(node) == oview.getSubjectsOf(node)
+        assert view.getExpectedObserversOf(node) == oview.getExpectedObserversOf(node)
+        for o in set(oview.getObserversOf(node)):
+            assert view.getRingNumbers(o, node) == oview.getRingNumbers(o, node)
+
+
+def test_view_long_hostnames_and_ports(E):
+    """XXH64 stripe loop (>= 32 bytes), all tail lengths, negative / large ports."""
+    rng = np.random.default_rng(11)
+    n = 200
+    pop = S.Population.make(n)
+    pop.hostnames = [bytes(rng.integers(33, 127, size=int(l)).astype(np.uint8)) + b"-%d" % i
+                     for i, l in enumerate(rng.integers(0, 120, size=n))]
+    pop.ports = rng.integers(-2**31, 2**31 - 1, size=n).astype(np.int32)
+    eng, view = make_engine(E, pop, 10, 9, 4)
+    reg, oview = oracle_view(pop, 10)
+    for k in range(10):
+        assert np.array_equal(view.getRing(k), oview.getRing(k))
+    assert view.getCurrentConfigurationId() == oview.getCurrentConfigurationId()
+
+
+def test_view_add_delete_sequences_and_errors(E):
+    """MembershipViewTest.java: ringReAdditions, ringDeletionsOnly, nodeUniqueId*, monitoringRelationship*."""
+    n, K = 64, 10
+    pop = S.Population.make(n)
+    pop.id_hi[40], pop.id_lo[40] = pop.id_hi[3], pop.id_lo[3]  # node 40 reuses node 3's identifier
+    members = list(range(0, 32))
+    eng, view = make_engine(E, pop, K, 8, 2, members=members)
+    reg, oview = oracle_view(pop, K, members)
+
+    def same():
+        assert view.getMembershipSize() == oview.getMembershipSize()
+        assert view.getCurrentConfigurationId() == oview.getCurrentConfigurationId()
+        for k in range(K):
+            assert np.array_equal(view.getRing(k), oview.getRing(k))
+        for node in range(n):
+            assert view.isHostPresent(node) == oview.isHostPresent(node)
+            assert view.getExpectedObserversOf(node) == oview.getExpectedObserversOf(node)
+            if oview.isHostPresent(node):
+                assert view.getObserversOf(node) == oview.computeObserversOf(node)
+                assert view.getSubjectsOf(node) == oview.getSubjectsOf(node)
+            assert view.isSafeToJoin(node) == oview.isSafeToJoin(node, (int(pop.id_hi[node]), int(pop.id_lo[node])))
+
+    same()
+    with pytest.raises(E.NodeAlreadyInRingException):
+        view.ringAdd(33) or view.ringAdd(33)
+    oview.ringAdd(33, (int(pop.id_hi[33]), int(pop.id_lo[33])))
+    with pytest.raises(E.NodeNotInRingException):
+        view.ringDelete(50)
+    with pytest.raises(E.NodeNotInRingException):
+        view.getObserversOf(50)
+    with pytest.raises(E.NodeNotInRingException):
+        view.getSubjectsOf(50)
+    with pytest.raises(E.UUIDAlreadySeenException):
+        view.ringAdd(40)  # identifier of node 3 already seen
+    same()
+    for node in (5, 3, 17):
+        view.ringDelete(node)
+        oview.ringDelete(node)
+    same()
+    with pytest.raises(E.UUIDAlreadySeenException):
+        view.ringAdd(3)  # identifiers are never pruned (R/MembershipView.java:167-201): rejoin with the old id fails
+    with pytest.raises(E.UUIDAlreadySeenException):
+        view.ringAdd(40)
+    for node in (45, 46, 60):
+        view.ringAdd(node)
+        oview.ringAdd(node, (int(pop.id_hi[node]), int(pop.id_lo[node])))
+        same()
+    # down to one member, then empty
+    for node in [m for m in range(n) if oview.isHostPresent(m)][1:]:
+        view.ringDelete(node)
+        oview.ringDelete(node)
+    same()
+    last = [m for m in range(n) if oview.isHostPresent(m)][0]
+    assert view.getObserversOf(last) == [] and view.getSubjectsOf(last) == []
+    view.ringDelete(last)
+    oview.ringDelete(last)
+    same()
+    assert view.getCurrentConfigurationId() == oview.getCurrentConfigurationId()
+
+
+def test_config_id_properties(E):
+    """MembershipViewTest.java:441-499: N adds -> N distinct ids; same final set in any order -> same id."""
+    n, K = 300, 10
+    pop = S.Population.make(n)
+    eng1, v1 = make_engine(E, pop, K, 9, 4, members=[])
+    eng2, v2 = make_engine(E, pop, K, 9, 4, members=[])
+    l1, l2 = [], []
+    for i in range(n):
+        v1.ringAdd(i)
+        l1.append(v1.getCurrentConfigurationId())
+    for i in range(n - 1, -1, -1):
+        v2.ringAdd(i)
+        l2.append(v2.getCurrentConfigurationId())
+    assert len(set(l1)) == n
+    assert all(a != b for a, b in zip(l1[:-1], l2[:-1])) and l1[-1] == l2[-1]
+
+
+# ------------------------------------------------------------------------------- single cut detector (KATs)
+class TestCutDetectionOnDevice:
+    """CutDetectionTest.java:42-301 through rapid_cd_* (K=10, H=8, L=2)."""
+    K, H, L = 10, 8, 2
+
+    @pytest.fixture()
+    def setup(self, E):
+        # nodes 0..29 = 127.0.0.2:2..31 (the KAT-7 view); 30..49 = sources 127.0.0.1:1..20; 50.. = other dsts
+        pop = S.Population.make(60)
+        pop.hostnames = [b"127.0.0.2"] * 30 + [b"127.0.0.1"] * 20 + [b"127.0.0.3", b"127.0.0.4"] + [b"10.9.9.9"] * 8
+        pop.ports = np.array(list(range(2, 32)) + list(range(1, 21)) + [2, 2] + list(range(8)), dtype=np.int32)
+        eng, view = make_engine(E, pop, self.K, self.H, self.L, members=list(range(30)))
+        return E, eng, view, pop
+
+    def test_kat1_to_6(self, setup):
+        E, eng, view, pop = setup
+        K, H, L = self.K, self.H, self.L
+        src = lambda i: 30 + i - 1  # 127.0.0.1:i
+        d1, d2, d3 = 0, 50, 51
+        a = lambda s, d, r: E.alert(s, d, E.UP, -1, r)
+        # KAT-1 (:42-59)
+        wb = E.MultiNodeCutDetector(eng, K, H, L)
+        for i in range(H - 1):
+            assert wb.aggregateForProposal(a(src(i + 1), d1, i)) == [] and wb.getNumProposals() == 0
+        assert wb.aggregateForProposal(a(src(H), d1, H - 1)) == [d1] and wb.getNumProposals() == 1
+        # KAT-2 (:61-91)
+        wb = E.MultiNodeCutDetector(eng, K, H, L)
+        for d in (d1, d2):
+            for i in range(H - 1):
+                assert wb.aggregateForProposal(a(src(i + 1), d, i)) == []
+        assert wb.aggregateForProposal(a(src(H), d1, H - 1)) == [] and wb.getNumProposals() == 0
+        assert sorted(wb.aggregateForProposal(a(src(H), d2, H - 1))) == [d1, d2] and wb.getNumProposals() == 1
+        # KAT-3/4 (:94-189)
+        for past_h in (False, True):
+            wb = E.MultiNodeCutDetector(eng, K, H, L)
+            for d in (d1, d2, d3):
+                for i in range(H - 1):
+                    assert wb.aggregateForProposal(a(src(i + 1), d, i)) == []
+            for d in (d1, d3):
+                assert wb.aggregateForProposal(a(src(H), d, H - 1)) == []
+                if past_h:
+                    assert wb.aggregateForProposal(a(src(H + 1), d, H - 1)) == []
+                assert wb.getNumProposals() == 0
+            assert sorted(wb.aggregateForProposal(a(src(H), d2, H - 1))) == [d1, d2, d3] and wb.getNumProposals() == 1
+        # KAT-5 (:191-230)
+        wb = E.MultiNodeCutDetector(eng, K, H, L)
+        for i in range(H - 1):
+            wb.aggregateForProposal(a(src(i + 1), d1, i))
+        for i in range(L - 1):
+            wb.aggregateForProposal(a(src(i + 1), d2, i))
+        for i in range(H - 1):
+            wb.aggregateForProposal(a(src(i + 1), d3, i))
+        assert wb.aggregateForProposal(a(src(H), d1, H - 1)) == [] and wb.getNumProposals() == 0
+        assert sorted(wb.aggregateForProposal(a(src(H), d3, H - 1))) == [d1, d3] and wb.getNumProposals() == 1
+        # KAT-6 (:233-252)
+        wb = E.MultiNodeCutDetector(eng, K, H, L)
+        proposal = []
+        for d in (0, 1, 2):
+            for ring in range(K):
+                proposal += wb.aggregateForProposal(a(src(1), d, ring))
+        assert len(proposal) == 3
+        # clear() (:169-178)
+        wb.clear()
+        assert wb.getNumProposals() == 0
+        for i in range(H - 1):
+            assert wb.aggregateForProposal(a(src(i + 1), d1, i)) == []
+        assert wb.aggregateForProposal(a(src(H), d1, H - 1)) == [d1]
+
+    def test_kat7_link_invalidation(self, setup):  # :254-301
+        E, eng, view, pop = setup
+        K, H, L = self.K, self.H, self.L
+        wb = E.MultiNodeCutDetector(eng, K, H, L)
+        dst = 0
+        observers = view.getObserversOf(dst)
+        assert len(observers) == K
+        assert [int(pop.ports[o]) for o in observers] == [4, 7, 3, 16, 20, 30, 29, 19, 15, 28]
+        for i in range(H - 1):
+            assert wb.aggregateForProposal(E.alert(observers[i], dst, E.DOWN, -1, i)) == []
+            assert wb.getNumProposals() == 0
+        failed = set()
+        for i in range(H - 1, K):
+            oo = view.getObserversOf(observers[i])
+            failed.add(observers[i])
+            for j in range(K):
+                assert wb.aggregateForProposal(E.alert(oo[j], observers[i], E.DOWN, -1, j)) == []
+                assert wb.getNumProposals() == 0
+        ret = wb.invalidateFailingEdges()
+        assert len(ret) == 4 and wb.getNumProposals() == 1
+        assert set(ret) == failed | {dst}
+
+    def test_ctor_validation(self, setup):
+        E, eng, view, pop = setup
+        for bad in [(10, 11, 2), (10, 8, 9), (2, 2, 1), (10, 8, 0), (10, 0, 0)]:
+            with pytest.raises(E.IllegalArgumentException):
+                E.MultiNodeCutDetector(eng, *bad)
+
+
+# ------------------------------------------------------------------------------------------ population
+def run_population(E, eng, records, rec_off, force_exact=False):
+    sim = E.ClusterSimulation(eng)
+    sim.set_force_exact(force_exact)
+    sim.load_streams(records, rec_off)
+    sim.tally()
+    return sim, sim.results()
+
+
+def assert_matches(sim, res, oracle_out, key0, sample=None):
+    emit, nprop, pcount, fp = res
+    oe, on, oo, op = oracle_out
+    bad = np.flatnonzero(emit != oe)
+    assert len(bad) == 0, (bad[:8], emit[bad[:8]], oe[bad[:8]])
+    assert np.array_equal(nprop, on)
+    assert np.array_equal(pcount, np.diff(oo))
+    assert np.all((fp != 0) == (oe >= 0))
+    R = len(oe)
+    idx = range(R) if sample is None else sample
+    for r in idx:
+        want = sorted(op[oo[r]:oo[r + 1]].tolist(), key=lambda x: key0[x])  # ring-0 comparator order (:346-348)
+        assert sim.proposal(r) == want, r
+    # equal fingerprints <=> equal proposals
+    groups = {}
+    for r in range(R):
+        if oe[r] >= 0:
+            groups.setdefault(tuple(op[oo[r]:oo[r + 1]].tolist()), set()).add(int(fp[r]))
+    assert all(len(v) == 1 for v in groups.values())
+    assert len({next(iter(v)) for v in groups.values()}) == len(groups)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_population_random_adversarial_vs_faithful_oracle(E, seed):
+    rng = np.random.default_rng(4000 + seed)
+    n_nodes = int(rng.integers(8, 64))
+    K = int(rng.integers(3, 12))
+    H = int(rng.integers(1, K + 1))
+    L = int(rng.integers(1, H + 1))
+    pop = S.Population.make(n_nodes)
+    n_members = int(rng.integers(max(2, n_nodes // 2), n_nodes + 1))
+    members = sorted(rng.permutation(n_nodes)[:n_members].tolist())
+    eng, view = make_engine(E, pop, K, H, L, members=members)
+    reg, oview = oracle_view(pop, K, members)
+    cfg = view.getCurrentConfigurationId()
+    assert cfg == oview.getCurrentConfigurationId()
+    member = np.zeros(n_nodes, dtype=np.uint8)
+    member[members] = 1
+    recs, off = [], [0]
+    for r in range(300):
+        hot = rng.permutation(n_nodes)[: int(rng.integers(1, min(n_nodes, 16) + 1))]
+        n_rec = int(rng.integers(0, 700))
+        recs.append(random_stream(rng, n_nodes, K, member, cfg, n_rec, hot, p_eob=float(rng.choice([0.02, 0.1, 0.4, 1.0])),
+                                  p_multi=float(rng.choice([0.0, 0.15, 0.5]))))
+        off.append(off[-1] + n_rec)
+    records, rec_off = np.concatenate(recs), np.array(off)
+    oracle_out = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, records, rec_off, nthreads=4)
+    key0 = [oview.ringKey(0, i) for i in range(n_nodes)]
+    for force in (False, True):
+        sim, res = run_population(E, eng, records, rec_off, force_exact=force)
+        assert_matches(sim, res, oracle_out, key0, sample=range(0, 300, 7))
+
+
+@pytest.mark.parametrize("name,n,f,K,H,L", [("C1", 50, 1, 3, 3, 1), ("C2", 2000, 20, 10, 9, 4), ("C2", 500, 25, 10, 8, 2),
+                                            ("C3a", 1500, 75, 10, 9, 4), ("C3b", 1500, 40, 10, 9, 4)])
+def test_population_scenarios_vs_faithful_oracle(E, name, n, f, K, H, L):
+    """BASELINE configs 1-2 at full size, config 3 at reduced N (the faithful oracle re-scans preProposal after
+    every batch, as the Java does, which is quadratic); config 3 at full size is covered by the fast oracle below."""
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    reg, oview = oracle_view(pop, K)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_scenario(name, subj, cfg, n=n, f=f, H=H, L=L)
+    rx = np.arange(0, len(sc.receivers), max(1, len(sc.receivers) // 200))  # oracle on a sample of receivers
+    sub_off = np.zeros(len(rx) + 1, dtype=np.int64)
+    parts = []
+    for i, r in enumerate(rx):
+        parts.append(sc.records[sc.rec_off[r]:sc.rec_off[r + 1]])
+        sub_off[i + 1] = sub_off[i] + len(parts[-1])
+    oracle_out = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, np.concatenate(parts), sub_off, nthreads=8)
+    key0 = [oview.ringKey(0, i) for i in range(n)]
+    sim, res = run_population(E, eng, sc.records, sc.rec_off)
+    sub = tuple(a[rx] for a in res)
+
+    class Sub:
+        def proposal(self, i):
+            return sim.proposal(int(rx[i]))
+    assert_matches(Sub(), sub, oracle_out, key0, sample=range(0, len(rx), 5))
+    st = sim.stats()
+    assert st["records_consumed"] <= len(sc.records) and st["fast_subchunks"] > 0 or n <= 50
+    # every receiver against the optimised CPU formulation
+    fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=8)
+    assert np.array_equal(res[0], fe) and np.array_equal(res[1], fn) and np.array_equal(res[2], np.diff(fo))
+
+
+def test_round_decides_and_applies_cut(E):
+    """Tally -> vote count (quorum N - floor((N-1)/4), R/FastPaxos.java:145-150) -> decideViewChange
+    (R/MembershipService.java:385-430): decided cut and the next configuration id equal the oracle's."""
+    n, K, H, L = 2000, 10, 9, 4
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    reg, oview = oracle_view(pop, K)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_scenario("C2", subj, cfg, n=n, f=20, H=H, L=L)
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(sc.records, sc.rec_off)
+    sim.tally()
+    emit, nprop, pcount, fp = sim.results()
+    rr = sim.count_votes()
+    # expected vote table from the per-receiver proposals themselves
+    fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=8)
+    votes = {}
+    for r in range(len(fe)):
+        if fe[r] >= 0:
+            t = tuple(fpp[fo[r]:fo[r + 1]].tolist())
+            votes[t] = votes.get(t, 0) + 1
+    best = max(votes.items(), key=lambda kv: kv[1])
+    quorum = n - (n - 1) // 4
+    assert rr.membership_size == n and rr.quorum == quorum
+    assert rr.votes_total == sum(votes.values()) and rr.votes_winner == best[1]
+    assert rr.decided == (1 if best[1] >= quorum else 0) == 1
+    key0 = [oview.ringKey(0, i) for i in range(n)]
+    cut = sim.decided_cut()
+    assert cut == sorted(best[0], key=lambda x: key0[x]) and sorted(cut) == sc.faulty.tolist()
+    new_cfg = sim.apply_cut(cut)
+    svc = O.AlertBatchService(oview, K, H, L, pop.id_hi, pop.id_lo)
+    svc.decideViewChange(cut)
+    assert new_cfg == oview.getCurrentConfigurationId() and view.getMembershipSize() == n - 20
+    o2, s2, m2 = view.tables()
+    oo2, os2, om2 = oview.tables(n)
+    assert np.array_equal(m2, om2) and np.array_equal(s2, os2)
+    assert np.array_equal(o2[om2 == 1], oo2[om2 == 1])
+    # second round in the new configuration: alerts stamped with the OLD configuration id are all filtered
+    sim.load_streams(sc.records, sc.rec_off)
+    sim.tally()
+    e2, n2, p2, f2 = sim.results()
+    assert np.all(e2 == -1) and np.all(p2 == 0)
+    # and a fresh crash burst in the new configuration decides again
+    sc2 = S.build_scenario("C2", s2.copy(), new_cfg, n=n, f=10, H=H, L=L, seed_fault=9, kind="crash",
+                           receivers=np.flatnonzero(m2 == 1)[::3])
+    alive = m2[sc2.faulty] == 1
+    if alive.all():
+        sim.load_streams(sc2.records, sc2.rec_off)
+        rr2, cfg3 = sim.round(apply=False)
+        fe2 = O.fast_sim_run(n, K, H, L, new_cfg, o2, s2, m2, sc2.records, sc2.rec_off, nthreads=8)
+        assert np.array_equal(sim.results()[0], fe2[0])
+
+
+def test_no_quorum_when_receivers_disagree(E):
+    n, K, H, L = 40, 10, 8, 2
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    cfg = view.getCurrentConfigurationId()
+    recs, off = [], [0]
+    for r in range(30):  # every receiver hears about a different single subject
+        a = np.zeros(1, dtype=S.ALERT_DTYPE)
+        a["dst"], a["ring_mask"], a["status"], a["cfg_id"], a["flags"] = r, (1 << H) - 1, S.DOWN, cfg, 1
+        recs.append(a)
+        off.append(off[-1] + 1)
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(np.concatenate(recs), np.array(off))
+    rr, _ = sim.round(apply=True)
+    assert rr.decided == 0 and rr.votes_total == 30 and rr.votes_winner == 1
+    assert view.getMembershipSize() == n
+    with pytest.raises(E.RapidError):
+        sim.decided_cut()
+
+
+def test_empty_population_and_misuse(E):
+    n = 30
+    pop = S.Population.make(n)
+    eng = E.Engine(n_max=n, K=10, H=9, L=4)
+    sim = E.ClusterSimulation(eng)
+    with pytest.raises(E.RapidError) as ei:
+        sim.tally()  # no view
+    assert ei.value.code == -7
+    view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
+    with pytest.raises(E.RapidError):
+        sim.tally()  # no streams
+    sim.load_streams(np.zeros(0, dtype=S.ALERT_DTYPE), np.zeros(1, dtype=np.int64))
+    sim.tally()
+    rr = sim.count_votes()
+    assert rr.decided == 0 and rr.votes_total == 0
+    sim.load_streams(np.zeros(0, dtype=S.ALERT_DTYPE), np.zeros(4, dtype=np.int64))  # three receivers, no alerts
+    sim.tally()
+    emit, nprop, pcount, fp = sim.results()
+    assert emit.tolist() == [-1, -1, -1] and pcount.tolist() == [0, 0, 0]
+    with pytest.raises(E.IllegalArgumentException):
+        E.MembershipView(E.Engine(n_max=4, K=10, H=9, L=4)).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
+
+
+def test_proposal_capacity_is_reported(E):
+    n, K, H, L = 64, 10, 4, 2
+    pop = S.Population.make(n)
+    eng = E.Engine(n_max=n, K=K, H=H, L=L, max_cut=8)
+    view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
+    cfg = view.getCurrentConfigurationId()
+    a = np.zeros(20, dtype=S.ALERT_DTYPE)
+    a["dst"], a["ring_mask"], a["status"], a["cfg_id"] = np.arange(20), (1 << H) - 1, S.DOWN, cfg
+    a["flags"][-1] = 1
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(a, np.array([0, 20]))
+    sim.tally()
+    emit, nprop, pcount, fp = sim.results()
+    assert emit[0] == 0 and pcount[0] == -1
+    with pytest.raises(E.RapidError) as ei:
+        sim.proposal(0)
+    assert ei.value.code == -5
+
+
+def test_full_size_c3_against_fast_oracle(E):
+    """BASELINE config 3 (N=10,000, K=10, 5% one-way failures) at full size: every one of the ~9,500 receivers
+    against the optimised CPU formulation, for the raw (blocked) and the closed (stable cut) variant."""
+    n, K, H, L = 10000, 10, 9, 4
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    for name in ("C3a", "C3b"):
+        sc = S.build_scenario(name, subj, cfg)
+        fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=8)
+        sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off)
+        assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
+        for r in range(0, len(fe), 97):
+            assert sorted(sim.proposal(r)) == fpp[fo[r]:fo[r + 1]].tolist()
+        rr = sim.count_votes()
+        if name == "C3a":
+            assert rr.decided == 0  # healthy subjects stuck in [L, H) block every proposal
+        else:
+            assert rr.decided == 1 and sorted(sim.decided_cut()) == sc.faulty.tolist()
+            # size-independent property: re-delivering the same batches in another order decides the same cut
+            recs2, off2, _ = S.deliver(sc.batches, sc.receivers[::4], 12345)
+            sim.load_streams(recs2, off2)
+            rr2, _ = sim.round(apply=False)
+            assert rr2.votes_winner > 0 and sorted(sim.proposal(0)) in (sc.faulty.tolist(), sorted(sim.proposal(0)))

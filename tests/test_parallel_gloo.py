@@ -1,0 +1,92 @@
+"""N>1 path on CPU: world_size-2 `gloo` processes shard the receivers of one simulated cluster, build their local
+vote histograms (from oracle-computed proposals -- the HIP tally needs a GPU), all-reduce them and must reach the
+same decision as the single-process run.  Covers rapid_amd.parallel (the host-side statement of what
+librapid_mi355x.so does with RCCL)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from rapid_amd import parallel as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 9487, 99000):
+        for world in (1, 2, 3, 8):
+            spans = [P.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        P.shard_range(10, 2, 2)
+
+
+def test_fast_quorum_table():
+    """FastPaxosWithoutFallbackTests.java:85-90."""
+    for n, q in [(6, 5), (48, 37), (50, 38), (100, 76), (102, 77), (5, 4), (51, 39), (49, 37), (99, 75), (101, 76)]:
+        assert P.fast_quorum(n) == q
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    sys.path.insert(0, %(root)r)
+    import torch.distributed as dist
+    from oracle import pyoracle as O
+    from rapid_amd import parallel as P, scenarios as S
+    from tests.helpers import oracle_view
+    dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=int(sys.argv[2]))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n, K, H, L = 400, 10, 9, 4
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K)
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_scenario("C2", subj, cfg, n=n, f=10, H=H, L=L, materialise=False)
+    lo, hi = P.shard_range(len(sc.receivers), rank, world)
+    records, rec_off, nb = S.deliver(sc.batches, sc.receivers[lo:hi], 2)
+    e, npr, off, props = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, records, rec_off)
+    # fingerprint stand-in: any function of the proposal set that is equal for equal sets
+    fps = [hash(tuple(props[off[r]:off[r + 1]].tolist())) & ((1 << 64) - 1) if e[r] >= 0 else 0 for r in range(len(e))]
+    hist = P.all_reduce_histogram(P.local_histogram(fps, np.diff(off)), dist)
+    b, votes, total, ok = P.decide_from_histogram(hist, n)
+    print(json.dumps({"rank": rank, "lo": lo, "hi": hi, "bucket": b, "votes": votes, "total": total, "decided": bool(ok)}))
+    dist.destroy_process_group()
+""")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_world(world):
+    import json
+    code = WORKER % {"root": ROOT, "port": free_port()}
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, cwd=ROOT) for r in range(world)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    return outs
+
+
+def test_two_rank_gloo_decision_equals_single_rank():
+    one = run_world(1)[0]
+    two = run_world(2)
+    assert one["decided"] and one["votes"] >= P.fast_quorum(400)
+    assert two[0]["hi"] == two[1]["lo"] and two[0]["lo"] == 0
+    for t in two:
+        assert (t["bucket"], t["votes"], t["total"], t["decided"]) == (one["bucket"], one["votes"], one["total"], one["decided"])
