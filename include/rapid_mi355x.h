@@ -95,8 +95,11 @@ int rapid_device_count(void); /* number of usable gfx950 devices (0 on a CPU-onl
 int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* host_off, const int32_t* ports,
                      const int64_t* id_hi, const int64_t* id_lo, int32_t n_nodes, const int32_t* members,
                      int32_t n_members, const int64_t* extra_id_hi, const int64_t* extra_id_lo, int32_t n_extra);
-int rapid_view_is_safe_to_join(rapid_engine* h, int32_t node, int32_t* status_out);       /* :100-115 */
-int rapid_view_ring_add(rapid_engine* h, int32_t node);                                    /* :123-160 */
+/* isSafeToJoin(Endpoint, NodeId) (:100-115) and ringAdd(Endpoint, NodeId) (:123-160): the NodeId is explicit, as in
+ * the Java; a successful ringAdd records it as node's identifier.  Order of checks as in the reference:
+ * identifier already seen -> RAPID_EUUID_SEEN, else already a member -> RAPID_ENODE_EXISTS. */
+int rapid_view_is_safe_to_join(rapid_engine* h, int32_t node, int64_t id_hi, int64_t id_lo, int32_t* status_out);
+int rapid_view_ring_add(rapid_engine* h, int32_t node, int64_t id_hi, int64_t id_lo);
 int rapid_view_ring_delete(rapid_engine* h, int32_t node);                                 /* :167-201 */
 int rapid_view_observers(rapid_engine* h, int32_t node, int32_t* out, int32_t cap, int32_t* n_out);  /* :210-224 */
 int rapid_view_subjects(rapid_engine* h, int32_t node, int32_t* out, int32_t cap, int32_t* n_out);   /* :267-282 */

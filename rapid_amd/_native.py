@@ -98,8 +98,8 @@ def _signatures():
         "rapid_last_error": (C.c_char_p, [vp]),
         "rapid_device_count": (i32, []),
         "rapid_view_build": (i32, [vp, p, p, p, p, p, i32, p, i32, p, p, i32]),
-        "rapid_view_is_safe_to_join": (i32, [vp, i32, pi32]),
-        "rapid_view_ring_add": (i32, [vp, i32]),
+        "rapid_view_is_safe_to_join": (i32, [vp, i32, i64, i64, pi32]),
+        "rapid_view_ring_add": (i32, [vp, i32, i64, i64]),
         "rapid_view_ring_delete": (i32, [vp, i32]),
         "rapid_view_observers": (i32, [vp, i32, p, i32, pi32]),
         "rapid_view_subjects": (i32, [vp, i32, p, i32, pi32]),

@@ -427,23 +427,25 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
     return rebuild_view(h);
 }
 
-int rapid_view_is_safe_to_join(rapid_engine* h, int32_t node, int32_t* status_out) {
+int rapid_view_is_safe_to_join(rapid_engine* h, int32_t node, int64_t id_hi, int64_t id_lo, int32_t* status_out) {
     int rc = check_node(h, node);
     if (rc) return rc;
     if (h->member[(size_t)node]) *status_out = RAPID_HOSTNAME_ALREADY_IN_RING;
-    else if (h->ids_seen.count({h->id_hi[(size_t)node], h->id_lo[(size_t)node]})) *status_out = RAPID_UUID_ALREADY_IN_RING;
+    else if (h->ids_seen.count({id_hi, id_lo})) *status_out = RAPID_UUID_ALREADY_IN_RING;
     else *status_out = RAPID_SAFE_TO_JOIN;
     return RAPID_OK;
 }
 
-int rapid_view_ring_add(rapid_engine* h, int32_t node) {
+int rapid_view_ring_add(rapid_engine* h, int32_t node, int64_t id_hi, int64_t id_lo) {
     int rc = check_node(h, node);
     if (rc) return rc;
     if ((rc = use_device(h))) return rc;
-    const std::pair<int64_t, int64_t> id{h->id_hi[(size_t)node], h->id_lo[(size_t)node]};
+    const std::pair<int64_t, int64_t> id{id_hi, id_lo};
     if (h->ids_seen.count(id)) return fail(h, RAPID_EUUID_SEEN, "identifier of node %d already seen", node);  // :127-129
     if (h->member[(size_t)node]) return fail(h, RAPID_ENODE_EXISTS, "node %d already in ring", node);          // :133-135
     h->member[(size_t)node] = 1;
+    h->id_hi[(size_t)node] = id_hi;
+    h->id_lo[(size_t)node] = id_lo;
     h->ids_seen.insert(id);
     h->ids_dirty = true;
     return rebuild_view(h);

@@ -119,13 +119,14 @@ class MembershipView:
         self.e._check(fn(self.e._h, *args, _addr(out), cap, C.byref(n)))
         return out[: n.value].tolist()
 
-    def isSafeToJoin(self, node):
+    def isSafeToJoin(self, node, node_id):
         s = C.c_int32(0)
-        self.e._check(self.e._lib.rapid_view_is_safe_to_join(self.e._h, node, C.byref(s)))
+        self.e._check(self.e._lib.rapid_view_is_safe_to_join(self.e._h, node, int(node_id[0]), int(node_id[1]), C.byref(s)))
         return s.value
 
-    def ringAdd(self, node):
-        self.e._check(self.e._lib.rapid_view_ring_add(self.e._h, node))
+    def ringAdd(self, node, node_id):
+        """ringAdd(Endpoint, NodeId) (:123-160); node_id = (high, low)."""
+        self.e._check(self.e._lib.rapid_view_ring_add(self.e._h, node, int(node_id[0]), int(node_id[1])))
 
     def ringDelete(self, node):
         self.e._check(self.e._lib.rapid_view_ring_delete(self.e._h, node))

@@ -74,6 +74,7 @@ def test_view_add_delete_sequences_and_errors(E):
     members = list(range(0, 32))
     eng, view = make_engine(E, pop, K, 8, 2, members=members)
     reg, oview = oracle_view(pop, K, members)
+    nid = lambda i: (int(pop.id_hi[i]), int(pop.id_lo[i]))
 
     def same():
         assert view.getMembershipSize() == oview.getMembershipSize()
@@ -86,12 +87,17 @@ def test_view_add_delete_sequences_and_errors(E):
             if oview.isHostPresent(node):
                 assert view.getObserversOf(node) == oview.computeObserversOf(node)
                 assert view.getSubjectsOf(node) == oview.getSubjectsOf(node)
-            assert view.isSafeToJoin(node) == oview.isSafeToJoin(node, (int(pop.id_hi[node]), int(pop.id_lo[node])))
+            assert view.isSafeToJoin(node, nid(node)) == oview.isSafeToJoin(node, nid(node))
 
     same()
+    view.ringAdd(33, nid(33))
+    oview.ringAdd(33, nid(33))
+    with pytest.raises(E.UUIDAlreadySeenException):
+        view.ringAdd(33, nid(33))  # same host, same id (MembershipViewTest.java:360-366)
     with pytest.raises(E.NodeAlreadyInRingException):
-        view.ringAdd(33) or view.ringAdd(33)
-    oview.ringAdd(33, (int(pop.id_hi[33]), int(pop.id_lo[33])))
+        view.ringAdd(33, (123, 456))  # same host, different id (:369-374)
+    with pytest.raises(E.UUIDAlreadySeenException):
+        view.ringAdd(34, nid(33))  # different host, same id (:377-383)
     with pytest.raises(E.NodeNotInRingException):
         view.ringDelete(50)
     with pytest.raises(E.NodeNotInRingException):
@@ -99,19 +105,22 @@ def test_view_add_delete_sequences_and_errors(E):
     with pytest.raises(E.NodeNotInRingException):
         view.getSubjectsOf(50)
     with pytest.raises(E.UUIDAlreadySeenException):
-        view.ringAdd(40)  # identifier of node 3 already seen
+        view.ringAdd(40, nid(40))  # identifier of node 3 already seen
     same()
     for node in (5, 3, 17):
         view.ringDelete(node)
         oview.ringDelete(node)
     same()
     with pytest.raises(E.UUIDAlreadySeenException):
-        view.ringAdd(3)  # identifiers are never pruned (R/MembershipView.java:167-201): rejoin with the old id fails
+        view.ringAdd(3, nid(3))  # identifiers are never pruned (R/MembershipView.java:167-201): rejoin with the old id fails
     with pytest.raises(E.UUIDAlreadySeenException):
-        view.ringAdd(40)
+        view.ringAdd(40, nid(40))
+    view.ringAdd(3, (77, 88))  # re-attempt with a new id succeeds (MembershipViewTest.java:430-433)
+    oview.ringAdd(3, (77, 88))
+    same()
     for node in (45, 46, 60):
-        view.ringAdd(node)
-        oview.ringAdd(node, (int(pop.id_hi[node]), int(pop.id_lo[node])))
+        view.ringAdd(node, nid(node))
+        oview.ringAdd(node, nid(node))
         same()
     # down to one member, then empty
     for node in [m for m in range(n) if oview.isHostPresent(m)][1:]:
@@ -134,10 +143,10 @@ def test_config_id_properties(E):
     eng2, v2 = make_engine(E, pop, K, 9, 4, members=[])
     l1, l2 = [], []
     for i in range(n):
-        v1.ringAdd(i)
+        v1.ringAdd(i, (int(pop.id_hi[i]), int(pop.id_lo[i])))
         l1.append(v1.getCurrentConfigurationId())
     for i in range(n - 1, -1, -1):
-        v2.ringAdd(i)
+        v2.ringAdd(i, (int(pop.id_hi[i]), int(pop.id_lo[i])))
         l2.append(v2.getCurrentConfigurationId())
     assert len(set(l1)) == n
     assert all(a != b for a, b in zip(l1[:-1], l2[:-1])) and l1[-1] == l2[-1]
