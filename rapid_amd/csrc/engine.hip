@@ -21,6 +21,7 @@
 #include <rccl/rccl.h>
 
 #include "../../include/rapid_mi355x.h"
+#include "index_kernels.h"
 #include "tally_kernel.h"
 #include "view_kernels.h"
 #include "vote_kernels.h"
@@ -79,7 +80,6 @@ struct rapid_engine {
     DevBuf<int> d_ring;                          // [K][M] node indices in ring order
     DevBuf<int> d_pos;                           // [K][n_nodes]
     DevBuf<int> d_obs, d_subj;                   // [n_nodes][K]
-    DevBuf<unsigned short> d_template;           // [n_nodes padded to 8]
     DevBuf<long long> d_ids_hi, d_ids_lo;
     DevBuf<long long> d_cfg_out;
     DevBuf<unsigned char> d_sort_tmp;
@@ -101,6 +101,20 @@ struct rapid_engine {
     int force_exact = 0;
     DevBuf<int> d_emit, d_nprop, d_pcount, d_props;
     DevBuf<unsigned long long> d_fp, d_stats;
+    DevBuf<unsigned int> d_next;
+
+    // ---- per-round index over the loaded streams (index_kernels.h) ----
+    bool index_valid = false;
+    long long n_records_total = 0;
+    DevBuf<unsigned int> d_gmask, d_adj;
+    DevBuf<unsigned short> d_dict, d_state_tpl, d_adj_off;
+    DevBuf<int> d_node_of_slot, d_deg, d_cursor, d_info;
+    int n_slots = 0, n_hot = 0, n_adj = 0;
+    float index_ms = 0.f;
+    // launch geometry chosen from the index
+    int waves_per_block = 1, grid_blocks = 1, lds_bytes = 0;
+    bool tables_in_lds = true;
+    int num_cus = 256;
 
     // ---- votes ----
     DevBuf<unsigned long long> d_hist, d_winner, d_mm, d_mismatch;
@@ -194,8 +208,6 @@ int rebuild_view(rapid_engine* h) {
     HIPCHK(h, h->d_pos.ensure((size_t)K * N));
     HIPCHK(h, h->d_obs.ensure((size_t)K * N));
     HIPCHK(h, h->d_subj.ensure((size_t)K * N));
-    const int n_padded = ((N + 7) / 8) * 8;
-    HIPCHK(h, h->d_template.ensure((size_t)n_padded));
     HIPCHK(h, h->d_cfg_out.ensure(1));
 
     if (M) {
@@ -215,8 +227,6 @@ int rebuild_view(rapid_engine* h) {
     }
     hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * N, 256)), dim3(256), 0, st, h->d_ring.p,
                        h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 1);
-    hipLaunchKernelGGL(rapid::state_template_kernel, dim3(grid_for(n_padded, 256)), dim3(256), 0, st, h->d_member.p, N,
-                       n_padded, h->d_template.p);
 
     if (h->ids_dirty) {
         const size_t ni = h->ids_seen.size();
@@ -248,6 +258,7 @@ int rebuild_view(rapid_engine* h) {
     h->host_tables_valid = false;
     h->tallied = false;
     h->have_decision = false;
+    h->index_valid = false;
     return RAPID_OK;
 }
 
@@ -281,8 +292,92 @@ int copy_list(rapid_engine* h, const int* src, int n, int32_t* out, int32_t cap,
     return RAPID_OK;
 }
 
+// Builds the per-round index (touched / hot subjects, slot dictionary, hot adjacency) for the loaded streams under
+// the current view, and picks the launch geometry of the tally kernel.
+int build_round_index(rapid_engine* h) {
+    const int N = h->n_nodes, K = h->cfg.K, L = h->cfg.L;
+    hipStream_t st = h->stream;
+    HIPCHK(h, h->d_gmask.ensure((size_t)N));
+    HIPCHK(h, h->d_dict.ensure((size_t)N));
+    HIPCHK(h, h->d_node_of_slot.ensure((size_t)N));
+    HIPCHK(h, h->d_state_tpl.ensure((size_t)N + 16));
+    HIPCHK(h, h->d_deg.ensure((size_t)N));
+    HIPCHK(h, h->d_cursor.ensure((size_t)N));
+    HIPCHK(h, h->d_adj_off.ensure((size_t)N + 1));
+    HIPCHK(h, h->d_info.ensure(8));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, hipEventRecord(e0, st));
+    HIPCHK(h, hipMemsetAsync(h->d_gmask.p, 0, sizeof(unsigned int) * (size_t)N, st));
+    HIPCHK(h, hipMemsetAsync(h->d_state_tpl.p, 0, sizeof(unsigned short) * ((size_t)N + 16), st));
+    HIPCHK(h, hipMemsetAsync(h->d_deg.p, 0, sizeof(int) * (size_t)N, st));
+    HIPCHK(h, hipMemsetAsync(h->d_cursor.p, 0, sizeof(int) * (size_t)N, st));
+    HIPCHK(h, hipMemsetAsync(h->d_info.p, 0, sizeof(int) * 8, st));
+    if (h->n_records_total > 0)
+        hipLaunchKernelGGL(rapid::index_touch_kernel, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_records, h->n_records_total, N,
+                           (1u << K) - 1u, h->d_gmask.p);
+    hipLaunchKernelGGL(rapid::index_slots_kernel, dim3(1), dim3(1024), 0, st, h->d_gmask.p, h->d_member.p, N, L, h->d_dict.p,
+                       h->d_node_of_slot.p, h->d_state_tpl.p, h->d_info.p);
+    int info[8] = {0};
+    HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof info, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipGetLastError());
+    if (info[2] & 1) return fail(h, RAPID_ECAPACITY, "the round names %d subjects; at most 65534 are supported", info[0]);
+    h->n_slots = info[0];
+    h->n_hot = info[1];
+    h->n_adj = 0;
+    HIPCHK(h, h->d_adj.ensure((size_t)std::max(1, 2 * K * h->n_hot)));
+    if (h->n_hot > 0) {
+        const unsigned g = grid_for((long long)h->n_hot * K, 256);
+        hipLaunchKernelGGL(rapid::index_adj_kernel, dim3(g), dim3(256), 0, st, h->d_obs.p, h->d_dict.p, h->d_node_of_slot.p,
+                           h->n_hot, K, h->d_deg.p, h->d_adj_off.p, h->d_cursor.p, h->d_adj.p, 0);
+        hipLaunchKernelGGL(rapid::index_adj_scan_kernel, dim3(1), dim3(64), 0, st, h->d_deg.p, h->n_hot, h->d_adj_off.p,
+                           h->d_info.p);
+        hipLaunchKernelGGL(rapid::index_adj_kernel, dim3(g), dim3(256), 0, st, h->d_obs.p, h->d_dict.p, h->d_node_of_slot.p,
+                           h->n_hot, K, h->d_deg.p, h->d_adj_off.p, h->d_cursor.p, h->d_adj.p, 1);
+        HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof info, hipMemcpyDeviceToHost, st));
+    } else {
+        HIPCHK(h, hipMemsetAsync(h->d_adj_off.p, 0, sizeof(unsigned short) * 2, st));
+    }
+    HIPCHK(h, hipEventRecord(e1, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventElapsedTime(&h->index_ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (info[2] & 2)
+        return fail(h, RAPID_ECAPACITY, "hot adjacency has %d entries; at most 65535 are supported", info[3]);
+    h->n_adj = h->n_hot > 0 ? info[3] : 0;
+
+    // ---- launch geometry: fill the CU's LDS with as many receiver-waves as possible ----
+    const int lds_max = 160 * 1024;
+    const int per_wave = rapid::tally_wave_bytes(h->n_slots);
+    const int shared = rapid::tally_shared_bytes(N, h->n_hot, h->n_adj);
+    if (per_wave > lds_max)
+        return fail(h, RAPID_ECAPACITY, "%d subjects need %d B of LDS per receiver (max %d)", h->n_slots, per_wave, lds_max);
+    h->tables_in_lds = shared + per_wave <= lds_max;
+    const int sh = h->tables_in_lds ? shared : 0;
+    int best_w = 1, best_total = 0;
+    for (int w = 1; w <= rapid::kMaxWavesPerBlock; ++w) {
+        const int blk = sh + w * per_wave;
+        if (blk > lds_max) break;
+        const int total = std::min(32, (lds_max / blk) * w);
+        if (total >= best_total) {
+            best_total = total;
+            best_w = w;
+        }
+    }
+    h->waves_per_block = best_w;
+    h->lds_bytes = sh + best_w * per_wave;
+    const int blocks_per_cu = std::max(1, std::min(32 / best_w, lds_max / h->lds_bytes));
+    const long long want = ((long long)h->n_receivers + best_w - 1) / best_w;
+    h->grid_blocks = (int)std::max<long long>(1, std::min<long long>(want, (long long)h->num_cus * blocks_per_cu));
+    h->index_valid = true;
+    return RAPID_OK;
+}
+
 int launch_tally(rapid_engine* h) {
-    const int lds = rapid::tally_lds_bytes(h->n_nodes);
     rapid::TallyParams p;
     p.records = h->d_records;
     p.records_bytes = h->records_bytes;
@@ -293,9 +388,14 @@ int launch_tally(rapid_engine* h) {
     p.H = h->cfg.H;
     p.L = h->cfg.L;
     p.cfg_id = h->config_id;
-    p.state_template = h->d_template.p;
-    p.obs = h->d_obs.p;
-    p.subj = h->d_subj.p;
+    p.idx.dict = h->d_dict.p;
+    p.idx.node_of_slot = h->d_node_of_slot.p;
+    p.idx.state_tpl = h->d_state_tpl.p;
+    p.idx.adj_off = h->d_adj_off.p;
+    p.idx.adj = h->d_adj.p;
+    p.idx.n_slots = h->n_slots;
+    p.idx.n_hot = h->n_hot;
+    p.idx.n_adj = h->n_adj;
     p.emit_batch = h->d_emit.p;
     p.num_proposals = h->d_nprop.p;
     p.prop_count = h->d_pcount.p;
@@ -303,20 +403,29 @@ int launch_tally(rapid_engine* h) {
     p.props = h->d_props.p;
     p.prop_cap = h->max_cut;
     p.stats = h->d_stats.p;
-    p.force_exact = h->force_exact;
-    hipLaunchKernelGGL(rapid::tally_population_kernel, dim3((unsigned)h->n_receivers), dim3(64), (size_t)lds, h->stream, p);
+    p.next_receiver = h->d_next.p;
+    p.waves_per_block = h->waves_per_block;
+    p.flags = h->force_exact;
+    HIPCHK(h, hipMemsetAsync(h->d_next.p, 0, sizeof(unsigned int), h->stream));
+    const dim3 grid((unsigned)h->grid_blocks), block((unsigned)h->waves_per_block * 64u);
+    if (h->tables_in_lds)
+        hipLaunchKernelGGL(rapid::tally_population_kernel<true>, grid, block, (size_t)h->lds_bytes, h->stream, p);
+    else
+        hipLaunchKernelGGL(rapid::tally_population_kernel<false>, grid, block, (size_t)h->lds_bytes, h->stream, p);
     return RAPID_OK;
 }
 
 int prepare_tally(rapid_engine* h) {
     if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
     if (!h->streams_loaded) return fail(h, RAPID_ESTATE, "no alert streams loaded");
-    const int lds = rapid::tally_lds_bytes(h->n_nodes);
-    if (lds > 160 * 1024)
-        return fail(h, RAPID_ECAPACITY, "n_nodes=%d needs %d B of LDS per receiver (max 163840): direct-indexed detector "
-                    "state does not fit", h->n_nodes, lds);
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (!h->index_valid) {
+        int rc = build_round_index(h);
+        if (rc) return rc;
+    }
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const size_t R = (size_t)std::max(h->n_receivers, 1);
     HIPCHK(h, h->d_emit.ensure(R));
     HIPCHK(h, h->d_nprop.ensure(R));
@@ -324,6 +433,7 @@ int prepare_tally(rapid_engine* h) {
     HIPCHK(h, h->d_fp.ensure(R));
     HIPCHK(h, h->d_props.ensure(R * (size_t)h->max_cut));
     HIPCHK(h, h->d_stats.ensure(8));
+    HIPCHK(h, h->d_next.ensure(4));
     return RAPID_OK;
 }
 
@@ -355,6 +465,7 @@ int rapid_engine_create(const rapid_engine_config* cfg, rapid_engine** out) {
     rapid_engine* h = new rapid_engine();
     h->cfg = *cfg;
     h->max_cut = cfg->max_cut > 0 ? cfg->max_cut : std::min(cfg->n_max, 4096);
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return RAPID_EDEVICE;
@@ -374,10 +485,12 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_blob.release(); h->d_host_off.release(); h->d_ports.release(); h->d_keys.release();
     h->d_hx_host0.release(); h->d_hx_port0.release(); h->d_member.release(); h->d_members.release();
     h->d_sort_keys.release(); h->d_sort_vals.release(); h->d_ring_skeys.release(); h->d_ring.release();
-    h->d_pos.release(); h->d_obs.release(); h->d_subj.release(); h->d_template.release();
+    h->d_pos.release(); h->d_obs.release(); h->d_subj.release();
     h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
     h->d_records_own.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
+    h->d_next.release(); h->d_gmask.release(); h->d_adj.release(); h->d_dict.release(); h->d_state_tpl.release();
+    h->d_adj_off.release(); h->d_node_of_slot.release(); h->d_deg.release(); h->d_cursor.release(); h->d_info.release();
     h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release();
     delete h;
 }
@@ -614,7 +727,6 @@ static int cd_run(rapid_cd* cd, const rapid_alert_record* alerts, int n, int mod
     p.H = cd->H;
     p.L = cd->L;
     p.obs = h->view_built ? h->d_obs.p : nullptr;
-    p.subj = h->view_built ? h->d_subj.p : nullptr;
     p.out_idx = cd->d_out.p;
     p.out_cap = cd->n_nodes;
     p.out_counts = cd->d_counts.p;
@@ -690,6 +802,8 @@ int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, c
     h->records_bytes = padded;
     h->d_rec_off = h->d_rec_off_own.p;
     h->n_receivers = n_receivers;
+    h->n_records_total = n_rec;
+    h->index_valid = false;
     h->streams_loaded = true;
     h->tallied = false;
     h->have_decision = false;
@@ -699,10 +813,19 @@ int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, c
 int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64_t records_bytes,
                                   const int64_t* d_rec_off, int32_t n_receivers) {
     if (!h || !d_rec_off || n_receivers < 0 || (!d_records && records_bytes)) return RAPID_EINVAL;
+    int rc = use_device(h);
+    if (rc) return rc;
+    long long n_rec = 0;
+    HIPCHK(h, hipMemcpy(&n_rec, reinterpret_cast<const long long*>(d_rec_off) + n_receivers, 8, hipMemcpyDeviceToHost));
+    if (n_rec < 0 || (unsigned long long)n_rec * 20ull + 16ull > records_bytes + 0ull)
+        return fail(h, RAPID_EINVAL, "records_bytes=%llu does not cover %lld records plus 16 bytes of padding",
+                    (unsigned long long)records_bytes, n_rec);
     h->d_records = static_cast<const unsigned char*>(d_records);
-    h->records_bytes = records_bytes;
+    h->records_bytes = records_bytes & ~15ull;
     h->d_rec_off = reinterpret_cast<const long long*>(d_rec_off);
     h->n_receivers = n_receivers;
+    h->n_records_total = n_rec;
+    h->index_valid = false;
     h->streams_loaded = true;
     h->tallied = false;
     h->have_decision = false;
@@ -1031,7 +1154,7 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg) {
 
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on) {
     if (!h) return RAPID_EINVAL;
-    h->force_exact = on ? 1 : 0;
+    h->force_exact = on;  // bit0: exact path only; bits 1-2: profiling ablations (results invalid)
     return RAPID_OK;
 }
 

@@ -1,0 +1,110 @@
+// Per-round index over the loaded alert streams (built once per rapid_sim_load_streams / view change, NOT part of
+// the timed tally): which subjects does this round's alert set name at all, which of them can ever reach the L
+// watermark ("hot"), a dense slot numbering (hot subjects first, ascending node index), and the adjacency among
+// hot subjects along the K-ring monitoring graph -- the only (observer, subject, ring) triples for which
+// MultiNodeCutDetector.invalidateFailingEdges (R/MultiNodeCutDetector.java:137-164) can ever apply an implicit
+// report at any receiver, because both ends need >= L explicit reports (R/MultiNodeCutDetector.java:104-107, 153).
+//
+// The index is a SUPERSET construction: it ignores the per-alert filter (configuration id, UP/DOWN vs membership),
+// so it can only make more subjects "touched"/"hot" than a receiver will see, never fewer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rapid {
+
+// gmask[dst] |= ring_mask over every record of every receiver.  After the first few thousand records nearly every
+// bit is already set, so the (possibly stale, L1-cached) pre-test avoids almost all atomics.
+__global__ void index_touch_kernel(const unsigned char* records, long long n_records, int n_nodes, unsigned int kmask,
+                                   unsigned int* gmask) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
+        const unsigned int* w = reinterpret_cast<const unsigned int*>(records + i * 20);
+        const unsigned int dst = w[3];
+        const unsigned int bits = w[4] & kmask;
+        if (dst < (unsigned)n_nodes && bits != 0u && (bits & ~gmask[dst]) != 0u) atomicOr(&gmask[dst], bits);
+    }
+}
+
+// One block.  Slot numbering: hot subjects (>= L distinct rings named) first, then the other touched subjects,
+// both ascending by node index.  info[0]=n_slots, info[1]=n_hot, info[2]=overflow flag.
+__global__ void index_slots_kernel(const unsigned int* gmask, const unsigned char* member, int n_nodes, int L,
+                                   unsigned short* dict, int* node_of_slot, unsigned short* state_tpl, int* info) {
+    __shared__ int s_hot[1024], s_cold[1024];
+    const int T = (int)blockDim.x, t = (int)threadIdx.x;
+    const int per = (n_nodes + T - 1) / T;
+    const int beg = min(n_nodes, t * per), end = min(n_nodes, beg + per);
+    int nh = 0, nc = 0;
+    for (int n = beg; n < end; ++n) {
+        const unsigned int m = gmask[n];
+        if (m != 0u) {
+            if (__popc(m) >= L) ++nh; else ++nc;
+        }
+    }
+    s_hot[t] = nh;
+    s_cold[t] = nc;
+    __syncthreads();
+    if (t == 0) {  // exclusive scans over 1024 partial counts
+        int ah = 0, ac = 0;
+        for (int i = 0; i < T; ++i) {
+            const int h = s_hot[i], c = s_cold[i];
+            s_hot[i] = ah;
+            s_cold[i] = ac;
+            ah += h;
+            ac += c;
+        }
+        info[0] = ah + ac;
+        info[1] = ah;
+        info[2] = (ah + ac > 65534) ? 1 : 0;
+    }
+    __syncthreads();
+    const int n_hot = info[1];
+    int ph = s_hot[t], pc = n_hot + s_cold[t];
+    for (int n = beg; n < end; ++n) {
+        const unsigned int m = gmask[n];
+        int slot = -1;
+        if (m != 0u) slot = (__popc(m) >= L) ? ph++ : pc++;
+        dict[n] = (slot >= 0 && slot < 65535) ? (unsigned short)slot : (unsigned short)0xFFFF;
+        if (slot >= 0 && slot < 65535) {
+            node_of_slot[slot] = n;
+            state_tpl[slot] = member[n] ? (unsigned short)0x8000 : (unsigned short)0;
+        }
+    }
+}
+
+// phase 0: deg[e] += 1 for both ends of every hot-hot (subject e, ring k, observer o) triple;
+// phase 1: fill adj[] at cursor positions.  One thread per (hot slot, ring).
+__global__ void index_adj_kernel(const int* obs, const unsigned short* dict, const int* node_of_slot, int n_hot, int K,
+                                 int* deg, const unsigned short* adj_off, int* cursor, unsigned int* adj, int phase) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= n_hot * K) return;
+    const int e = t / K, k = t - e * K;
+    const int s_node = node_of_slot[e];
+    const int o_node = obs[s_node * K + k];
+    if (o_node < 0) return;
+    const int eo = (int)dict[o_node];
+    if (eo >= n_hot) return;  // observer not hot (or not touched): can never vouch
+    if (phase == 0) {
+        atomicAdd(&deg[e], 1);
+        atomicAdd(&deg[eo], 1);
+    } else {
+        // role 0: `other` is the observer of e on ring k; role 1: `other` is the subject that eo observes on ring k
+        adj[(int)adj_off[e] + atomicAdd(&cursor[e], 1)] = (unsigned)eo | ((unsigned)k << 16);
+        adj[(int)adj_off[eo] + atomicAdd(&cursor[eo], 1)] = (unsigned)e | ((unsigned)k << 16) | (1u << 20);
+    }
+}
+
+// One block: adj_off = exclusive scan of deg (u16); info[3] = n_adj; info[2] |= 2 on overflow.
+__global__ void index_adj_scan_kernel(const int* deg, int n_hot, unsigned short* adj_off, int* info) {
+    if (threadIdx.x != 0) return;
+    long long acc = 0;
+    for (int i = 0; i < n_hot; ++i) {
+        adj_off[i] = (unsigned short)(acc > 65535 ? 65535 : acc);
+        acc += deg[i];
+    }
+    adj_off[n_hot] = (unsigned short)(acc > 65535 ? 65535 : acc);
+    info[3] = (int)(acc > 0x7FFFFFFF ? 0x7FFFFFFF : acc);
+    if (acc > 65535) info[2] |= 2;
+}
+
+}  // namespace rapid

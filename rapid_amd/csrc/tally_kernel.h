@@ -7,25 +7,28 @@
 //                 + MultiNodeCutDetector.invalidateFailingEdges         R/MultiNodeCutDetector.java:137-164
 //
 // Mapping onto the machine (DESIGN.md "Tally kernel"):
-//   * one wavefront (= one 64-thread workgroup) per simulated receiver; the receiver's whole detector state
-//     is a 16-bit word per node in LDS: bits 0..K-1 = rings reported, bit 14 = already flushed into an
-//     emitted proposal, bit 15 = node is a member of the current view;
-//   * the delivered stream is read ONCE from HBM in 4 KiB tiles with 16 B/lane coalesced loads (next tile in
-//     flight in registers while the current one is consumed), staged through an LDS ring, and consumed in
-//     sub-chunks of up to 64 records (one per lane) that always end at a batch end when they contain one;
-//   * FAST path per 64-record sub-chunk: order-free ds_or_rtn on the masks; the L/H watermark crossings of
-//     the sub-chunk are counted with wave ballots; implicit edge invalidation is applied once per sub-chunk,
-//     only for the nodes that crossed L (incremental form), as of the last batch end in the sub-chunk;
-//   * the reference's detector is a sequential state machine: an emission can only happen on an H crossing
-//     that finds updatesInProgress == 0.  If (updatesInProgress before the sub-chunk) - (H crossings in it)
-//     >= 1, no emission is possible under ANY order and the order-free result is exact; otherwise the
-//     sub-chunk is rolled back (undo = clearing exactly the bits each lane set) and replayed by the EXACT
-//     path, record by record, with the implicit invalidation after every batch end;
+//   * one wavefront per simulated receiver; a workgroup is W such wavefronts (W chosen so the CU's 160 KB LDS is
+//     full) that share read-only per-round tables in LDS and pull receivers from a global counter (persistent);
+//   * the receiver's whole detector state is one 16-bit word per SLOT in LDS -- a slot is a subject named by this
+//     round's alert set (index_kernels.h builds the node->slot dictionary once per loaded stream set): bits
+//     0..K-1 = rings reported, bit 14 = already flushed into an emitted proposal, bit 15 = member of the view;
+//   * the delivered stream is read ONCE from HBM: 2 KiB tiles, 16 B/lane coalesced loads, kPrefetch tiles in
+//     flight in registers per wave; tiles are staged through a small LDS ring and consumed in sub-chunks of up
+//     to 64 records (one per lane) that end at a batch end whenever they contain one.  The tally loop touches
+//     global memory for nothing else (dictionary and adjacency live in LDS), so vmcnt only ever tracks the
+//     prefetch and waits for the oldest tile alone;
+//   * FAST path per sub-chunk: order-free ds_or_rtn on the masks; L/H watermark crossings counted with wave
+//     ballots; implicit edge invalidation applied once per sub-chunk, only for the slots that crossed L
+//     (incremental form) and only along the round's "hot" adjacency (pairs whose both ends can reach L at all);
+//   * the reference's detector is a sequential state machine: an emission can only happen on an H crossing that
+//     finds updatesInProgress == 0.  If (updatesInProgress before the sub-chunk) - (H crossings in it) >= 1, no
+//     emission is possible under ANY order and the order-free result is exact; otherwise the sub-chunk is rolled
+//     back (each lane clears exactly the bits it set) and replayed by the EXACT path, record by record, with the
+//     implicit invalidation after every batch end;
 //   * after the batch that announces a proposal the receiver ignores the rest of its stream
-//     (announcedProposal, R/MembershipService.java:318-319) -- the wave stops reading.
+//     (announcedProposal, R/MembershipService.java:318-319) -- the wave stops reading it.
 //
-// No MFMA: the path is integer scatter/popcount.  No static __shared__: all LDS is carved from the
-// 16-byte aligned dynamic segment.
+// No MFMA: the path is integer scatter/popcount.  All LDS is carved from the 16-byte aligned dynamic segment.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,47 +37,69 @@ namespace rapid {
 
 constexpr int kWave = 64;
 constexpr int kRecBytes = 20;
-constexpr int kTileBytes = 4096;                     // one tile = 4 x (64 lanes x 16 B)
-constexpr int kRingTiles = 2;                        // LDS ring of tiles the sub-chunks are read from
-constexpr int kRingBytes = kTileBytes * kRingTiles;  // power of two
-constexpr int kStageBytes = kRingBytes;
-constexpr int kPendCap = 128;                        // nodes that crossed L and still await invalidation
+constexpr int kTileBytes = 2048;                     // one tile = 2 x (64 lanes x 16 B)
+constexpr int kTileVec = kTileBytes / 1024;          // uint4 per lane per tile
+constexpr int kRingTiles = 2;                        // LDS ring the sub-chunks are decoded from
+constexpr int kRingBytes = kTileBytes * kRingTiles;  // power of two; a sub-chunk (<= 1280 B) spans <= 2 tiles
+constexpr int kPrefetch = 4;                         // tiles in flight in registers per wave (8 KiB)
+constexpr int kPendCap = 128;                        // slots that crossed L and still await invalidation
 constexpr int kUndoCap = 128;                        // implicit bits set inside one sub-chunk
+constexpr int kMaxWavesPerBlock = 16;
 constexpr uint32_t kFlushed = 1u << 14;
 constexpr uint32_t kMember = 1u << 15;
+constexpr unsigned short kNoSlot = 0xFFFF;
+
+// Per-round index over the loaded alert set (built by index_kernels.h; all device pointers).
+// Slots [0, n_hot) are the "hot" subjects -- those named on >= L distinct rings by the round's alert set, the only
+// ones that can ever enter preProposal/proposal at any receiver -- in ascending node order; [n_hot, n_slots) the rest.
+struct RoundIndex {
+    const unsigned short* dict;       // [n_nodes] node -> slot, kNoSlot if the round never names the node
+    const int* node_of_slot;          // [n_slots]
+    const unsigned short* state_tpl;  // [n_slots rounded up to 8] kMember for members
+    const unsigned short* adj_off;    // [n_hot + 1] CSR over hot slots
+    const unsigned int* adj;          // [n_adj] other_slot | ring << 16 | role << 20 (role 1: `other` is the subject)
+    int n_slots, n_hot, n_adj;
+};
 
 struct TallyParams {
-    const unsigned char* records;    // packed rapid_alert_record[]
-    unsigned long long records_bytes;  // readable bytes at `records` (>= 16 past the last record)
-    const long long* rec_off;        // [R+1], in records
+    const unsigned char* records;      // packed rapid_alert_record[]
+    unsigned long long records_bytes;  // readable bytes at `records` (multiple of 16, covering the last record)
+    const long long* rec_off;          // [R+1], in records
     int n_receivers;
     int n_nodes;
     int K, H, L;
     long long cfg_id;
-    const unsigned short* state_template;  // [n_nodes rounded up to 8] kMember set for members
-    const int* obs;                        // [n_nodes][K] observers (expected observers for non-members)
-    const int* subj;                       // [n_nodes][K] subjects (-1 rows for non-members)
-    int* emit_batch;                       // [R]
-    int* num_proposals;                    // [R]
-    int* prop_count;                       // [R]; -1 if the proposal did not fit prop_cap
-    unsigned long long* fingerprint;       // [R]
-    int* props;                            // [R][prop_cap] ascending node index
+    RoundIndex idx;
+    int* emit_batch;                  // [R]
+    int* num_proposals;               // [R]
+    int* prop_count;                  // [R]; -1 if the proposal did not fit prop_cap
+    unsigned long long* fingerprint;  // [R]
+    int* props;                       // [R][prop_cap] ascending node index
     int prop_cap;
-    unsigned long long* stats;             // [8]
-    int force_exact;
+    unsigned long long* stats;        // [8]
+    unsigned int* next_receiver;      // work counter (zeroed before every launch)
+    int waves_per_block;
+    int flags;                        // bit0: exact path only (tests); bits 1-2: profiling ablations
 };
 
-__host__ __device__ inline int tally_state_bytes(int n_nodes) { return ((n_nodes * 2 + 15) / 16) * 16; }
-__host__ __device__ inline int tally_lds_bytes(int n_nodes) {
-    return tally_state_bytes(n_nodes) + kStageBytes + kPendCap * 4 + kUndoCap * 4;
+__host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
+// LDS budget: shared tables (only when they are staged in LDS) + per-wave detector state, ring, lists
+__host__ __device__ inline int tally_shared_bytes(int n_nodes, int n_hot, int n_adj) {
+    return align16(n_nodes * 2) + align16((n_hot + 1) * 2) + align16(n_adj * 4);
+}
+__host__ __device__ inline int tally_wave_bytes(int n_slots) {
+    return align16(n_slots * 2) + kRingBytes + align16(kPendCap * 2) + kUndoCap * 4;
 }
 
-// ---- small wave helpers (block == one wave of 64) ------------------------------------------------------
-__device__ __forceinline__ unsigned long long lanes_lt(int lane) { return (1ull << lane) - 1ull; }
-__device__ __forceinline__ int wave_sum(int v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
+// ---- small wave helpers ---------------------------------------------------------------------------------------
+// A receiver is owned by ONE wavefront; that wave's LDS operations execute in program order, so cross-lane
+// hand-offs through its private LDS region only need the compiler not to reorder or cache them -- no s_barrier
+// and no s_waitcnt vmcnt (which would drain the tile prefetch that is deliberately left in flight).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
+__device__ __forceinline__ unsigned long long lanes_lt(int lane) { return (1ull << lane) - 1ull; }
 __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned lo = __shfl_xor((unsigned)v, off, kWave);
@@ -90,147 +115,89 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // 
     return x ^ (x >> 31);
 }
 
-// Per-receiver detector state.  `st` may point to LDS (population kernel) or to global memory (single
-// MultiNodeCutDetector instance); all accesses go through 16-bit loads/stores and 32-bit atomics.
-struct Detector {
+// ---- detector state accessors ---------------------------------------------------------------------------------
+// LDS flavour (population kernel): indices are slots; sweeps cover the hot slots only.
+struct SlotDetector {
     unsigned short* st16;
     unsigned int* st32;
-    const int* obs;
-    const int* subj;
-    int n_nodes, K, H, L;
+    const unsigned short* adj_off;
+    const unsigned int* adj;
+    int n_scan;  // = n_hot
+    int H, L;
     unsigned int kmask;
-
-    __device__ __forceinline__ unsigned int load(int n) const { return st16[n]; }
+    __device__ __forceinline__ unsigned int load(int i) const { return st16[i]; }
+    __device__ __forceinline__ void store(int i, unsigned int v) const { st16[i] = (unsigned short)v; }
     __device__ __forceinline__ int count(unsigned int m) const { return __popc(m & kmask); }
-    // atomically OR `bits` into node n's mask; returns the previous 16-bit word
-    __device__ __forceinline__ unsigned int or_bits(int n, unsigned int bits) const {
-        const int sh = (n & 1) * 16;
-        const unsigned int old = atomicOr(&st32[n >> 1], bits << sh);
-        return (old >> sh) & 0xFFFFu;
+    __device__ __forceinline__ unsigned int or_bits(int i, unsigned int bits) const {
+        const int sh = (i & 1) * 16;
+        return (atomicOr(&st32[i >> 1], bits << sh) >> sh) & 0xFFFFu;
     }
-    __device__ __forceinline__ void clear_bits(int n, unsigned int bits) const {
-        const int sh = (n & 1) * 16;
-        atomicAnd(&st32[n >> 1], ~(bits << sh));
+    __device__ __forceinline__ void clear_bits(int i, unsigned int bits) const {
+        atomicAnd(&st32[i >> 1], ~(bits << ((i & 1) * 16)));
     }
+    __device__ __forceinline__ void sync() const { wave_lds_fence(); }
 };
 
-// Implicit-edge invalidation (R/MultiNodeCutDetector.java:137-164), incremental form: only the nodes in
-// pend[0..n_elig) -- those that crossed L since the previous pass -- can enable a new (observer, subject)
-// pair.  Each lane handles one (entrant, role, ring) triple.  Returns the number of H crossings caused.
-// If undo != nullptr every bit actually set is appended to undo[] (node | ring << 24); *n_undo counts them
-// even beyond kUndoCap so the caller can detect overflow.
-__device__ inline int invalidate_entrants(const Detector& d, const unsigned int* pend, int n_elig, unsigned int* undo,
-                                          int* n_undo, int lane, int* n_applied) {
-    int nH = 0;
-    const int twoK = 2 * d.K;
-    const int total = n_elig * twoK;
-    for (int q0 = 0; q0 < total; q0 += kWave) {
-        const int q = q0 + lane;
-        const bool active = q < total;
-        int s = -1, o = -1, k = 0;
-        if (active) {
-            const int e = q / twoK;
-            const int j = q - e * twoK;
-            const int n = (int)pend[e];
-            if (j < d.K) {  // entrant as the node in flux: its observers
-                k = j;
-                s = n;
-                o = d.obs[n * d.K + k];
-            } else {  // entrant as an observer: its subjects
-                k = j - d.K;
-                o = n;
-                s = d.subj[n * d.K + k];
-            }
-        }
-        const bool ok = active && s >= 0 && o >= 0;
-        const unsigned int ms = ok ? d.load(s) : 0u;
-        const unsigned int mo = ok ? d.load(o) : 0u;
-        const int cs = d.count(ms), co = d.count(mo);
-        const bool apply = ok && cs >= d.L && cs < d.H && co >= d.L && !(mo & kFlushed) && !(ms & (1u << k));
-        unsigned int old = 0;
-        if (apply) old = d.or_bits(s, 1u << k);
-        const bool isnew = apply && !(old & (1u << k));
-        const bool crossH = isnew && d.count(old) == d.H - 1;
-        nH += __popcll(__ballot(crossH));
-        const unsigned long long mnew = __ballot(isnew);
-        if (undo != nullptr) {
-            const int idx = *n_undo + __popcll(mnew & lanes_lt(lane));
-            if (isnew && idx < kUndoCap) undo[idx] = (unsigned)s | ((unsigned)k << 24);
-            *n_undo += __popcll(mnew);
-        }
-        *n_applied += __popcll(mnew);
-        __syncthreads();
+// Global-memory flavour (one MultiNodeCutDetector instance, rapid_cd_*): indices are node indices, the implicit
+// invalidation walks the view's observer table.  Accesses bypass the per-CU L1 (agent scope) because the atomics
+// execute in L2; ordering points drain the vector memory queue.
+struct TableDetector {
+    unsigned short* st16;
+    unsigned int* st32;
+    const int* obs;  // [n_nodes][K]
+    int n_scan;      // = n_nodes
+    int K, H, L;
+    unsigned int kmask;
+    __device__ __forceinline__ unsigned int load(int i) const {
+        return __hip_atomic_load(&st16[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return nH;
-}
-
-// The reference's literal full pass: every node in preProposal x its K observers.  Used when the pending
-// list overflowed or when joiners are in flux (their expected observers are not in the subjects table).
-__device__ inline int invalidate_full(const Detector& d, unsigned int* undo, int* n_undo, int lane, int* n_applied) {
-    int nH = 0;
-    for (int n0 = 0; n0 < d.n_nodes; n0 += kWave) {
-        const int n = n0 + lane;
-        const unsigned int m = n < d.n_nodes ? d.load(n) : 0u;
-        const int c = d.count(m);
-        const bool inpre = n < d.n_nodes && c >= d.L && c < d.H;
-        if (__ballot(inpre) == 0ull) continue;
-        for (int k = 0; k < d.K; ++k) {
-            const int o = inpre ? d.obs[n * d.K + k] : -1;
-            const unsigned int mo = o >= 0 ? d.load(o) : 0u;
-            const bool apply = o >= 0 && d.count(mo) >= d.L && !(mo & kFlushed) && !(m & (1u << k));
-            unsigned int old = 0;
-            if (apply) old = d.or_bits(n, 1u << k);
-            const bool isnew = apply && !(old & (1u << k));
-            const bool crossH = isnew && d.count(old) == d.H - 1;
-            nH += __popcll(__ballot(crossH));
-            const unsigned long long mnew = __ballot(isnew);
-            if (undo != nullptr) {
-                const int idx = *n_undo + __popcll(mnew & lanes_lt(lane));
-                if (isnew && idx < kUndoCap) undo[idx] = (unsigned)n | ((unsigned)k << 24);
-                *n_undo += __popcll(mnew);
-            }
-            *n_applied += __popcll(mnew);
-        }
-        __syncthreads();
+    __device__ __forceinline__ void store(int i, unsigned int v) const {
+        __hip_atomic_store(&st16[i], (unsigned short)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return nH;
-}
+    __device__ __forceinline__ int count(unsigned int m) const { return __popc(m & kmask); }
+    __device__ __forceinline__ unsigned int or_bits(int i, unsigned int bits) const {
+        const int sh = (i & 1) * 16;
+        return (atomicOr(&st32[i >> 1], bits << sh) >> sh) & 0xFFFFu;
+    }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+};
 
-// An emission (R/MultiNodeCutDetector.java:116-123): every node that crossed H and was not yet returned is
+// Scalars of one receiver / detector (wave-uniform).
+struct RxScalars {
+    int running;         // updatesInProgress
+    int npend;           // entries in pend[]
+    int batch;           // batches fully processed
+    int proposal_count;  // getNumProposals()
+    bool seen_down;      // seenLinkDownEvents
+    bool need_full;      // pend[] overflowed -> use the full pass over all hot slots
+    bool batch_emitted;  // some emission happened in the batch being processed
+};
+
+// An emission (R/MultiNodeCutDetector.java:116-123): every entry that crossed H and was not yet returned is
 // returned now and leaves `proposal`.  Marks them flushed; optionally appends them (ascending) to out[].
-__device__ inline void flush_sweep(const Detector& d, int lane, int* out, int out_cap, int* out_n) {
-    __syncthreads();
-    for (int n0 = 0; n0 < d.n_nodes; n0 += kWave) {
-        const int n = n0 + lane;
-        const unsigned int m = n < d.n_nodes ? d.load(n) : 0u;
-        const bool take = n < d.n_nodes && d.count(m) >= d.H && !(m & kFlushed);
-        if (take) d.st16[n] = (unsigned short)(m | kFlushed);
+template <class D>
+__device__ inline void flush_sweep(const D& d, int lane, int* out, int out_cap, int* out_n) {
+    d.sync();
+    for (int i0 = 0; i0 < d.n_scan; i0 += kWave) {
+        const int i = i0 + lane;
+        const unsigned int m = i < d.n_scan ? d.load(i) : 0u;
+        const bool take = i < d.n_scan && d.count(m) >= d.H && !(m & kFlushed);
+        if (take) d.store(i, m | kFlushed);
         if (out_n != nullptr) {
             const unsigned long long mk = __ballot(take);
             const int idx = *out_n + __popcll(mk & lanes_lt(lane));
-            if (take && out != nullptr && idx < out_cap) out[idx] = n;
+            if (take && out != nullptr && idx < out_cap) out[idx] = i;
             *out_n += __popcll(mk);
         }
     }
-    __syncthreads();
+    d.sync();
 }
 
-// Scalars of one receiver (wave-uniform).
-struct RxScalars {
-    int running;        // updatesInProgress
-    int npend;          // entries in pend[]
-    int batch;          // batches fully processed
-    int proposal_count; // getNumProposals()
-    bool seen_down;     // seenLinkDownEvents
-    bool need_full;     // incremental list no longer complete -> use the literal full pass
-    bool batch_emitted; // some emission happened in the batch being processed
-};
-
 // EXACT application of one alert (all rings, ascending) -- R/MultiNodeCutDetector.java:76-128.  Executed
-// redundantly by all lanes on wave-uniform values; lane 0 performs the stores.  Emissions go to the flush
-// sweep; if emit_out != nullptr the returned nodes are appended there.
-__device__ inline void exact_apply(const Detector& d, RxScalars& s, unsigned int* pend, int dst, unsigned int bits,
-                                   bool down, int lane, int* emit_out, int emit_cap, int* emit_n) {
+// redundantly by all lanes on wave-uniform values; lane 0 performs the stores.
+template <class D>
+__device__ inline void exact_apply(const D& d, RxScalars& s, unsigned short* pend, int dst, unsigned int bits, bool down,
+                                   int lane, int* emit_out, int emit_cap, int* emit_n) {
     if (bits == 0) return;
     if (down) s.seen_down = true;
     unsigned int m = d.load(dst);
@@ -242,11 +209,13 @@ __device__ inline void exact_apply(const Detector& d, RxScalars& s, unsigned int
         const int c = d.count(m);
         if (c == d.L) {
             s.running++;
-            if (s.npend < kPendCap) {
-                if (lane == 0) pend[s.npend] = (unsigned)dst;
-                s.npend++;
-            } else {
-                s.need_full = true;
+            if (pend != nullptr) {
+                if (s.npend < kPendCap) {
+                    if (lane == 0) pend[s.npend] = (unsigned short)dst;
+                    s.npend++;
+                } else {
+                    s.need_full = true;
+                }
             }
         }
         if (c == d.H) {
@@ -254,285 +223,395 @@ __device__ inline void exact_apply(const Detector& d, RxScalars& s, unsigned int
             if (s.running == 0) {
                 s.proposal_count++;
                 s.batch_emitted = true;
-                __syncthreads();
-                if (lane == 0) d.st16[dst] = (unsigned short)m;
+                d.sync();
+                if (lane == 0) d.store(dst, m);
                 flush_sweep(d, lane, emit_out, emit_cap, emit_n);
                 m = d.load(dst);
             }
         }
     }
-    __syncthreads();
-    if (lane == 0) d.st16[dst] = (unsigned short)m;
-    __syncthreads();
+    d.sync();
+    if (lane == 0) d.store(dst, m);
+    d.sync();
 }
 
-// EXACT end-of-batch step: invalidateFailingEdges (R/MultiNodeCutDetector.java:137-164) as invoked at
-// R/MembershipService.java:330.
-__device__ inline void exact_batch_end(const Detector& d, RxScalars& s, unsigned int* pend, int lane, int* emit_out,
-                                       int emit_cap, int* emit_n, int* n_applied, int* n_full) {
-    if (!s.seen_down) return;
-    int nH;
-    if (s.need_full) {
-        nH = invalidate_full(d, nullptr, nullptr, lane, n_applied);
-        (*n_full)++;
-    } else {
-        nH = invalidate_entrants(d, pend, s.npend, nullptr, nullptr, lane, n_applied);
+// Implicit-edge invalidation (R/MultiNodeCutDetector.java:137-164) along the round's hot adjacency.  An implicit
+// report (o -> s, ring k) is applicable iff s is in preProposal and o is in proposal U preProposal; both require
+// >= L explicit reports, so only hot slots take part, and a pair becomes applicable at the first batch end after
+// BOTH ends crossed L -- i.e. when the later of the two is among the entrants since the previous pass.  One lane
+// per entrant walks its adjacency list.  all_hot: the literal full pass (every hot slot), used after pend[]
+// overflowed.  Returns the number of H crossings caused; logs every bit actually set when undo != nullptr.
+__device__ inline int invalidate_adj(const SlotDetector& d, const unsigned short* pend, int n_ent, bool all_hot,
+                                     unsigned int* undo, int* n_undo, int lane, int* n_applied) {
+    int nH = 0;
+    const int total = all_hot ? d.n_scan : n_ent;
+    for (int i0 = 0; i0 < total; i0 += kWave) {
+        const int i = i0 + lane;
+        int e = 0;
+        bool act = i < total;
+        if (act) e = all_hot ? i : (int)pend[i];
+        act = act && e < d.n_scan;
+        int a = act ? (int)d.adj_off[e] : 0;
+        const int end = act ? (int)d.adj_off[e + 1] : 0;
+        while (__ballot(a < end) != 0ull) {
+            const bool on = a < end;
+            const unsigned int ent = on ? d.adj[a] : 0u;
+            const int other = (int)(ent & 0xFFFFu);
+            const int k = (int)((ent >> 16) & 15u);
+            const bool other_is_subject = ((ent >> 20) & 1u) != 0;
+            const int sj = other_is_subject ? other : e;
+            const int ob = other_is_subject ? e : other;
+            const unsigned int ms = on ? d.load(sj) : 0u;
+            const unsigned int mo = on ? d.load(ob) : 0u;
+            const int cs = d.count(ms), co = d.count(mo);
+            const bool apply = on && cs >= d.L && cs < d.H && co >= d.L && !(mo & kFlushed) && !(ms & (1u << k));
+            unsigned int old = 0;
+            if (apply) old = d.or_bits(sj, 1u << k);
+            const bool isnew = apply && !(old & (1u << k));
+            const bool crossH = isnew && d.count(old) == d.H - 1;
+            nH += __popcll(__ballot(crossH));
+            const unsigned long long mnew = __ballot(isnew);
+            if (undo != nullptr) {
+                const int idx = *n_undo + __popcll(mnew & lanes_lt(lane));
+                if (isnew && idx < kUndoCap) undo[idx] = (unsigned)sj | ((unsigned)k << 24);
+                *n_undo += __popcll(mnew);
+            }
+            *n_applied += __popcll(mnew);
+            d.sync();
+            ++a;
+        }
     }
+    return nH;
+}
+
+// The reference's literal pass over the view's observer table (single-detector API): every node in preProposal
+// x its K observers (expected observers for a non-member).
+__device__ inline int invalidate_table(const TableDetector& d, int lane) {
+    int nH = 0;
+    for (int n0 = 0; n0 < d.n_scan; n0 += kWave) {
+        const int n = n0 + lane;
+        const unsigned int m = n < d.n_scan ? d.load(n) : 0u;
+        const int c = d.count(m);
+        const bool inpre = n < d.n_scan && c >= d.L && c < d.H;
+        if (__ballot(inpre) == 0ull) continue;
+        for (int k = 0; k < d.K; ++k) {
+            const int o = inpre ? d.obs[n * d.K + k] : -1;
+            const unsigned int mo = o >= 0 ? d.load(o) : 0u;
+            const bool apply = o >= 0 && d.count(mo) >= d.L && !(mo & kFlushed) && !(m & (1u << k));
+            unsigned int old = 0;
+            if (apply) old = d.or_bits(n, 1u << k);
+            const bool isnew = apply && !(old & (1u << k));
+            const bool crossH = isnew && d.count(old) == d.H - 1;
+            nH += __popcll(__ballot(crossH));
+        }
+        d.sync();
+    }
+    return nH;
+}
+
+// EXACT end-of-batch step of the population kernel: invalidateFailingEdges as invoked at
+// R/MembershipService.java:330.
+__device__ inline void exact_batch_end(const SlotDetector& d, RxScalars& s, const unsigned short* pend, int lane,
+                                       int* n_applied, int* n_full) {
+    if (!s.seen_down) return;
+    if (s.need_full) (*n_full)++;
+    const int nH = invalidate_adj(d, pend, s.npend, s.need_full, nullptr, nullptr, lane, n_applied);
     s.npend = 0;
     s.running -= nH;
     if (nH > 0 && s.running == 0) {
         s.proposal_count++;
         s.batch_emitted = true;
-        flush_sweep(d, lane, emit_out, emit_cap, emit_n);
+        flush_sweep(d, lane, nullptr, 0, nullptr);
     }
 }
 
-// --------------------------------------------------------------------------------------------------------
-// Whole-population tally: grid = receivers, block = 64.
-// --------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void tally_population_kernel(TallyParams p) {
+// --------------------------------------------------------------------------------------------------------------
+// Whole-population tally.  block = waves_per_block x 64; every wave pulls receivers until none is left.
+// kTablesInLds: dictionary + adjacency are staged in LDS once per workgroup (the normal case); otherwise they
+// are read from global memory (populations whose dictionary does not fit next to the per-wave state).
+// --------------------------------------------------------------------------------------------------------------
+template <bool kTablesInLds>
+__global__ __launch_bounds__(1024) void tally_population_kernel(TallyParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = (int)threadIdx.x;
-    const int r = (int)blockIdx.x;
-    if (r >= p.n_receivers) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = (int)(threadIdx.x >> 6);
 
-    const int state_bytes = tally_state_bytes(p.n_nodes);
-    unsigned char* const stage = smem + state_bytes;
-    unsigned int* const pend = reinterpret_cast<unsigned int*>(stage + kStageBytes);
-    unsigned int* const undo = pend + kPendCap;
+    // ---- shared read-only tables ----
+    const unsigned short* dict = p.idx.dict;
+    const unsigned short* adj_off = p.idx.adj_off;
+    const unsigned int* adj = p.idx.adj;
+    int shared_bytes = 0;
+    if (kTablesInLds) {
+        unsigned short* l_dict = reinterpret_cast<unsigned short*>(smem);
+        unsigned short* l_off = reinterpret_cast<unsigned short*>(smem + align16(p.n_nodes * 2));
+        unsigned int* l_adj =
+            reinterpret_cast<unsigned int*>(smem + align16(p.n_nodes * 2) + align16((p.idx.n_hot + 1) * 2));
+        for (int i = (int)threadIdx.x; i < p.n_nodes; i += (int)blockDim.x) l_dict[i] = p.idx.dict[i];
+        for (int i = (int)threadIdx.x; i < p.idx.n_hot + 1; i += (int)blockDim.x) l_off[i] = p.idx.adj_off[i];
+        for (int i = (int)threadIdx.x; i < p.idx.n_adj; i += (int)blockDim.x) l_adj[i] = p.idx.adj[i];
+        dict = l_dict;
+        adj_off = l_off;
+        adj = l_adj;
+        shared_bytes = tally_shared_bytes(p.n_nodes, p.idx.n_hot, p.idx.n_adj);
+    }
+    __syncthreads();
 
-    Detector d;
-    d.st16 = reinterpret_cast<unsigned short*>(smem);
-    d.st32 = reinterpret_cast<unsigned int*>(smem);
-    d.obs = p.obs;
-    d.subj = p.subj;
-    d.n_nodes = p.n_nodes;
-    d.K = p.K;
+    // ---- this wave's private LDS ----
+    const int state_bytes = align16(p.idx.n_slots * 2);
+    unsigned char* const mine = smem + shared_bytes + wave * tally_wave_bytes(p.idx.n_slots);
+    unsigned char* const stage = mine + state_bytes;
+    unsigned short* const pend = reinterpret_cast<unsigned short*>(stage + kRingBytes);
+    unsigned int* const undo = reinterpret_cast<unsigned int*>(stage + kRingBytes + align16(kPendCap * 2));
+    const unsigned int* const ring32 = reinterpret_cast<const unsigned int*>(stage);
+
+    SlotDetector d;
+    d.st16 = reinterpret_cast<unsigned short*>(mine);
+    d.st32 = reinterpret_cast<unsigned int*>(mine);
+    d.adj_off = adj_off;
+    d.adj = adj;
+    d.n_scan = p.idx.n_hot;
     d.H = p.H;
     d.L = p.L;
     d.kmask = (1u << p.K) - 1u;
 
-    const long long rec0 = p.rec_off[r];
-    const int nrec = (int)(p.rec_off[r + 1] - rec0);
-    const unsigned long long b0 = (unsigned long long)rec0 * kRecBytes;
-    const unsigned long long a0 = b0 & ~15ull;  // 16-B aligned start of this receiver's byte range
-    const int delta = (int)(b0 - a0);
-    const int ntiles = (int)(((long long)delta + (long long)nrec * kRecBytes + kTileBytes - 1) / kTileBytes);
     const unsigned int cfg_lo = (unsigned int)(unsigned long long)p.cfg_id;
     const unsigned int cfg_hi = (unsigned int)((unsigned long long)p.cfg_id >> 32);
-    const unsigned int* const ring32 = reinterpret_cast<const unsigned int*>(stage);
-
+    const bool abl_noinv = (p.flags & 2) != 0;  // profiling ablations (results invalid)
+    const bool abl_noapply = (p.flags & 4) != 0;
     unsigned long long n_slow = 0, n_fast = 0, n_restart = 0, n_records = 0;
     int n_applied = 0, n_full = 0;
-    int emit_batch = -1;
-    RxScalars s;
-    bool exact_only = p.force_exact != 0;
 
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        // ---- state init: member bits from the template (L2-resident), everything else zero ----
-        {
-            const uint4* tpl = reinterpret_cast<const uint4*>(p.state_template);
-            uint4* dst = reinterpret_cast<uint4*>(smem);
-            for (int i = lane; i < state_bytes / 16; i += kWave) dst[i] = tpl[i];
-        }
-        s.running = 0;
-        s.npend = 0;
-        s.batch = 0;
-        s.proposal_count = 0;
-        s.seen_down = false;
-        s.need_full = false;
-        s.batch_emitted = false;
-        emit_batch = -1;
-        bool restart = false;
+    for (;;) {
+        int r = 0;
+        if (lane == 0) r = (int)atomicAdd(p.next_receiver, 1u);
+        r = __shfl(r, 0, kWave);
+        if (r >= p.n_receivers) break;
 
-        // ---- tile pipeline: the stream is a ring of kRingTiles x 4 KiB in LDS; the next tile is in flight in
-        // registers (16 B/lane coalesced loads) while sub-chunks are consumed from the ring ----
-        uint4 tile[kTileBytes / 1024];
-        int loaded = 0;  // tiles copied into the ring so far
-        auto issue = [&](int j) {
-            const unsigned long long g = a0 + (unsigned long long)j * kTileBytes;
-#pragma unroll
-            for (int m = 0; m < kTileBytes / 1024; ++m) {
-                const unsigned long long addr = g + 16ull * (unsigned)(lane + kWave * m);
-                tile[m] = (addr + 16 <= p.records_bytes) ? *reinterpret_cast<const uint4*>(p.records + addr)
-                                                         : make_uint4(0, 0, 0, 0);
+        const long long rec0 = p.rec_off[r];
+        const int nrec = (int)(p.rec_off[r + 1] - rec0);
+        const unsigned long long b0 = (unsigned long long)rec0 * kRecBytes;
+        const unsigned long long a0 = b0 & ~15ull;  // 16-B aligned start of this receiver's byte range
+        const int delta = (int)(b0 - a0);
+        const int ntiles = (int)(((long long)delta + (long long)nrec * kRecBytes + kTileBytes - 1) / kTileBytes);
+
+        int emit_batch = -1;
+        RxScalars s;
+        bool exact_only = (p.flags & 1) != 0;
+
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            // ---- state init: member bits from the template (L2-resident), everything else zero ----
+            {
+                const uint4* tpl = reinterpret_cast<const uint4*>(p.idx.state_tpl);
+                uint4* dst = reinterpret_cast<uint4*>(mine);
+                for (int i = lane; i < state_bytes / 16; i += kWave) dst[i] = tpl[i];
             }
-        };
-        if (ntiles > 0) issue(0);
+            s.running = 0;
+            s.npend = 0;
+            s.batch = 0;
+            s.proposal_count = 0;
+            s.seen_down = false;
+            s.need_full = false;
+            s.batch_emitted = false;
+            emit_batch = -1;
+            bool restart = false;
+            int pos = 0;          // next unconsumed record
+            int pos_off = delta;  // (delta + 20 * pos) mod ring size
+            wave_lds_fence();
 
-        int pos = 0;          // next unconsumed record
-        int pos_off = delta;  // (delta + 20 * pos) mod ring size
-        while (pos < nrec && emit_batch < 0 && !restart) {
-            const int navail = min(kWave, nrec - pos);
-            const int need = (delta + kRecBytes * (pos + navail) - 1) / kTileBytes;
-            while (loaded <= need) {
-                __syncthreads();  // nobody still reads the slot being overwritten
-                uint4* slot = reinterpret_cast<uint4*>(stage + (loaded % kRingTiles) * kTileBytes);
-#pragma unroll
-                for (int m = 0; m < kTileBytes / 1024; ++m) slot[lane + kWave * m] = tile[m];
-                ++loaded;
-                if (loaded < ntiles) issue(loaded);
-                __syncthreads();
-            }
+            // ---- one sub-chunk: up to 64 records, one per lane ----
+            auto process = [&]() {
+                const int navail = min(kWave, nrec - pos);
+                const int off = (pos_off + kRecBytes * lane) & (kRingBytes - 1);
+                const unsigned int w0 = ring32[off >> 2];
+                const unsigned int w1 = ring32[((off + 4) & (kRingBytes - 1)) >> 2];
+                const unsigned int w3 = ring32[((off + 12) & (kRingBytes - 1)) >> 2];
+                const unsigned int w4 = ring32[((off + 16) & (kRingBytes - 1)) >> 2];
+                const bool down = ((w4 >> 16) & 0xFFu) != 0;
+                bool eob = lane < navail && ((((w4 >> 24) & 1u) != 0) || pos + lane == nrec - 1);
+                // a sub-chunk ends at its last batch end (if it has one): no record is applied before the batch
+                // end that precedes it has been processed
+                const unsigned long long mE_all = __ballot(eob);
+                const int lastE = mE_all ? 63 - __clzll((long long)mE_all) : -1;
+                const int ncons = lastE >= 0 ? lastE + 1 : navail;
+                const bool valid = lane < ncons;
+                eob = eob && valid;
+                // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot
+                bool pass = valid && w0 == cfg_lo && w1 == cfg_hi && w3 < (unsigned)p.n_nodes;
+                const unsigned int slot_raw = pass ? (unsigned int)dict[w3] : (unsigned int)kNoSlot;
+                pass = pass && slot_raw != kNoSlot;
+                const int dst = pass ? (int)slot_raw : 0;
+                const unsigned int m0 = pass ? d.load(dst) : 0u;
+                pass = pass && (((m0 & kMember) != 0) == down);
+                const unsigned int bits = pass ? (w4 & d.kmask) : 0u;
+                n_records += (unsigned long long)ncons;
 
-            // ---- one record per lane ----
-            const int off = (pos_off + kRecBytes * lane) & (kRingBytes - 1);
-            const unsigned int w0 = ring32[off >> 2];
-            const unsigned int w1 = ring32[((off + 4) & (kRingBytes - 1)) >> 2];
-            const unsigned int w3 = ring32[((off + 12) & (kRingBytes - 1)) >> 2];
-            const unsigned int w4 = ring32[((off + 16) & (kRingBytes - 1)) >> 2];
-            const int dst = (int)w3;
-            const bool down = ((w4 >> 16) & 0xFFu) != 0;
-            bool eob = lane < navail && ((((w4 >> 24) & 1u) != 0) || pos + lane == nrec - 1);
-            // a sub-chunk ends at its last batch end (if it has one): no record is applied before the batch
-            // end that precedes it has been processed
-            const unsigned long long mE_all = __ballot(eob);
-            const int lastE = mE_all ? 63 - __clzll((long long)mE_all) : -1;
-            const int ncons = lastE >= 0 ? lastE + 1 : navail;
-            const bool valid = lane < ncons;
-            eob = eob && valid;
-            // filterAlertMessages (R/MembershipService.java:644-675)
-            bool pass = valid && w0 == cfg_lo && w1 == cfg_hi && (unsigned)dst < (unsigned)p.n_nodes;
-            const unsigned int m0 = pass ? d.load(dst) : 0u;
-            pass = pass && (((m0 & kMember) != 0) == down);
-            const unsigned int bits = pass ? (w4 & d.kmask) : 0u;
-            n_records += (unsigned long long)ncons;
-
-            // once an emission happened inside the current batch, the rest of that batch (whose end announces
-            // the proposal) is processed exactly
-            bool replay = exact_only || s.batch_emitted;
-            if (!replay) {
-                // ---------------- FAST path: order-free, then a safety check ----------------
-                unsigned int old = 0;
-                if (bits) old = d.or_bits(dst, bits);
-                const unsigned int newbits = bits & ~old;
-                const int c0 = d.count(old), c1 = d.count(old | bits);
-                const bool isL = bits != 0 && c0 < d.L && c1 >= d.L;
-                const bool isH = bits != 0 && c0 < d.H && c1 >= d.H;
-                const unsigned long long mL = __ballot(isL), mH = __ballot(isH);
-                const unsigned long long mD = __ballot(bits != 0 && down);
-                const unsigned long long mJ = __ballot(bits != 0 && !down);  // joiner (UP) reports
-                const int nLc = __popcll(mL), nHc = __popcll(mH);
-                const bool seen = s.seen_down || mD != 0ull;
-                bool need_full = s.need_full || mJ != 0ull;
-                // append the nodes that crossed L (lane order)
-                const int posn = s.npend + __popcll(mL & lanes_lt(lane));
-                if (isL && posn < kPendCap) pend[posn] = (unsigned)dst;
-                const int npend_new = s.npend + nLc;
-                if (npend_new > kPendCap) need_full = true;
-                const bool run_inv = lastE >= 0 && seen;
-                __syncthreads();
-                int nHi = 0, n_undo = 0, applied_here = 0;
-                if (run_inv) {
-                    if (need_full) {
-                        nHi = invalidate_full(d, undo, &n_undo, lane, &applied_here);
-                        n_full++;
+                // once an emission happened inside the current batch, the rest of that batch (whose end announces
+                // the proposal) is processed exactly
+                bool replay = exact_only || s.batch_emitted;
+                if (!replay) {
+                    // ---------------- FAST path: order-free, then a safety check ----------------
+                    unsigned int old = 0;
+                    if (bits && !abl_noapply) old = d.or_bits(dst, bits);
+                    const unsigned int newbits = bits & ~old;
+                    const int c0 = d.count(old), c1 = d.count(old | bits);
+                    const bool isL = bits != 0 && c0 < d.L && c1 >= d.L;
+                    const bool isH = bits != 0 && c0 < d.H && c1 >= d.H;
+                    const unsigned long long mL = __ballot(isL), mH = __ballot(isH);
+                    const unsigned long long mD = __ballot(bits != 0 && down);
+                    const int nLc = __popcll(mL), nHc = __popcll(mH);
+                    const bool seen = s.seen_down || mD != 0ull;
+                    bool need_full = s.need_full;
+                    // append the slots that crossed L (lane order)
+                    const int posn = s.npend + __popcll(mL & lanes_lt(lane));
+                    if (isL && posn < kPendCap) pend[posn] = (unsigned short)dst;
+                    const int npend_new = s.npend + nLc;
+                    if (npend_new > kPendCap) need_full = true;
+                    const bool run_inv = lastE >= 0 && seen && !abl_noinv && (npend_new > 0 || need_full);
+                    int nHi = 0, n_undo = 0, applied_here = 0;
+                    if (run_inv) {
+                        wave_lds_fence();
+                        if (need_full) n_full++;
+                        nHi = invalidate_adj(d, pend, npend_new, need_full, undo, &n_undo, lane, &applied_here);
+                    }
+                    const int Htot = nHc + nHi;
+                    // No emission is possible inside this sub-chunk under ANY order if updatesInProgress cannot
+                    // reach 0 at one of its H crossings.
+                    const bool safe = Htot == 0 || s.running - Htot >= 1;
+                    if (safe) {
+                        s.running += nLc - Htot;
+                        s.seen_down = seen;
+                        s.batch += __popcll(mE_all & ((ncons == 64) ? ~0ull : ((1ull << ncons) - 1ull)));
+                        s.need_full = need_full;
+                        s.npend = ((lastE >= 0 && seen) || need_full) ? 0 : npend_new;
+                        n_applied += applied_here;
+                        n_fast++;
+                    } else if (n_undo > kUndoCap) {
+                        restart = true;  // cannot roll back: redo this receiver on the exact path only
                     } else {
-                        nHi = invalidate_entrants(d, pend, npend_new, undo, &n_undo, lane, &applied_here);
-                    }
-                }
-                const int Htot = nHc + nHi;
-                // No emission is possible inside this sub-chunk under ANY order if updatesInProgress cannot
-                // reach 0 at one of its H crossings.
-                const bool safe = Htot == 0 || s.running - Htot >= 1;
-                if (safe) {
-                    s.running += nLc - Htot;
-                    s.seen_down = seen;
-                    s.batch += __popcll(mE_all & ((ncons == 64) ? ~0ull : ((1ull << ncons) - 1ull)));
-                    s.need_full = need_full;
-                    s.npend = (run_inv || need_full) ? 0 : npend_new;
-                    n_applied += applied_here;
-                    n_fast++;
-                } else if (n_undo > kUndoCap) {
-                    restart = true;  // cannot roll back: redo this receiver on the exact path only
-                } else {
-                    // ---------------- roll back, then replay exactly ----------------
-                    __syncthreads();
-                    for (int u = lane; u < n_undo; u += kWave) {
-                        const unsigned int e = undo[u];
-                        d.clear_bits((int)(e & 0xFFFFFFu), 1u << (e >> 24));
-                    }
-                    if (newbits) d.clear_bits(dst, newbits);
-                    __syncthreads();
-                    replay = true;
-                }
-            }
-            if (replay && !restart) {
-                // ---------------- EXACT path: record by record ----------------
-                n_slow++;
-                for (int q = 0; q < ncons; ++q) {
-                    const int qdst = __shfl(dst, q, kWave);
-                    const unsigned int qbits = (unsigned)__shfl((int)bits, q, kWave);
-                    const int qflags = __shfl((int)down | ((int)eob << 1), q, kWave);
-                    if (qbits != 0 && !(qflags & 1)) s.need_full = true;  // joiner report
-                    exact_apply(d, s, pend, qdst, qbits, (qflags & 1) != 0, lane, nullptr, 0, nullptr);
-                    if (qflags & 2) {
-                        exact_batch_end(d, s, pend, lane, nullptr, 0, nullptr, &n_applied, &n_full);
-                        if (s.batch_emitted) {  // R/MembershipService.java:333-335
-                            emit_batch = s.batch;
-                            break;
+                        // ---------------- roll back, then replay exactly ----------------
+                        wave_lds_fence();
+                        for (int u = lane; u < n_undo; u += kWave) {
+                            const unsigned int e = undo[u];
+                            d.clear_bits((int)(e & 0xFFFFFFu), 1u << (e >> 24));
                         }
-                        s.batch++;
+                        if (newbits) d.clear_bits(dst, newbits);
+                        wave_lds_fence();
+                        replay = true;
+                    }
+                }
+                if (replay && !restart) {
+                    // ---------------- EXACT path: record by record ----------------
+                    n_slow++;
+                    for (int q = 0; q < ncons; ++q) {
+                        const int qdst = __shfl(dst, q, kWave);
+                        const unsigned int qbits = (unsigned)__shfl((int)bits, q, kWave);
+                        const int qflags = __shfl((int)down | ((int)eob << 1), q, kWave);
+                        exact_apply(d, s, pend, qdst, qbits, (qflags & 1) != 0, lane, nullptr, 0, nullptr);
+                        if (qflags & 2) {
+                            exact_batch_end(d, s, pend, lane, &n_applied, &n_full);
+                            if (s.batch_emitted) {  // R/MembershipService.java:333-335
+                                emit_batch = s.batch;
+                                break;
+                            }
+                            s.batch++;
+                        }
+                    }
+                }
+                pos += ncons;
+                pos_off = (pos_off + kRecBytes * ncons) & (kRingBytes - 1);
+            };
+
+            // ---- tile pipeline: kPrefetch tiles in flight in registers (static indexing via full unroll);
+            // tile j is copied into the LDS ring once every record that needed the slot it overwrites is consumed
+            uint4 tile[kPrefetch][kTileVec];
+            auto issue = [&](int j, uint4(&t)[kTileVec]) {
+                const unsigned long long g = a0 + (unsigned long long)j * kTileBytes;
+#pragma unroll
+                for (int m = 0; m < kTileVec; ++m) {
+                    const unsigned long long addr = g + 16ull * (unsigned)(lane + kWave * m);
+                    t[m] = (j < ntiles && addr + 16 <= p.records_bytes)
+                               ? *reinterpret_cast<const uint4*>(p.records + addr)
+                               : make_uint4(0, 0, 0, 0);
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < kPrefetch; ++q) issue(q, tile[q]);
+
+            for (int jb = 0; jb < ntiles && emit_batch < 0 && !restart; jb += kPrefetch) {
+#pragma unroll
+                for (int q = 0; q < kPrefetch; ++q) {
+                    const int j = jb + q;
+                    if (j < ntiles && emit_batch < 0 && !restart) {
+                        wave_lds_fence();  // every lane is done decoding from the slot about to be overwritten
+                        uint4* slot = reinterpret_cast<uint4*>(stage + (j % kRingTiles) * kTileBytes);
+#pragma unroll
+                        for (int m = 0; m < kTileVec; ++m) slot[lane + kWave * m] = tile[q][m];
+                        issue(j + kPrefetch, tile[q]);
+                        wave_lds_fence();
+                        // consume every sub-chunk whose records lie entirely in tiles <= j
+                        while (pos < nrec && emit_batch < 0 && !restart &&
+                               (delta + kRecBytes * (pos + min(kWave, nrec - pos)) - 1) / kTileBytes <= j)
+                            process();
                     }
                 }
             }
-            pos += ncons;
-            pos_off = (pos_off + kRecBytes * ncons) & (kRingBytes - 1);
+            if (!restart) break;
+            exact_only = true;
+            n_restart++;
+            wave_lds_fence();
         }
-        if (!restart) break;
-        exact_only = true;
-        n_restart++;
-        __syncthreads();
-    }
 
-    // ---- outputs ----
-    int count = 0;
-    unsigned long long fp = 0;
-    if (emit_batch >= 0) {
-        int* const out = p.props + (long long)r * p.prop_cap;
-        for (int n0 = 0; n0 < p.n_nodes; n0 += kWave) {
-            const int n = n0 + lane;
-            const bool take = n < p.n_nodes && (d.load(n) & kFlushed) != 0;
-            const unsigned long long mk = __ballot(take);
-            const int idx = count + __popcll(mk & lanes_lt(lane));
-            if (take) {
-                if (idx < p.prop_cap) out[idx] = n;
-                fp += mix64((unsigned long long)n);
+        // ---- outputs: the proposal = every flushed (hot) slot, ascending node index ----
+        int count = 0;
+        unsigned long long fp = 0;
+        if (emit_batch >= 0) {
+            wave_lds_fence();
+            int* const out = p.props + (long long)r * p.prop_cap;
+            for (int i0 = 0; i0 < d.n_scan; i0 += kWave) {
+                const int i = i0 + lane;
+                const bool take = i < d.n_scan && (d.load(i) & kFlushed) != 0;
+                const unsigned long long mk = __ballot(take);
+                const int idx = count + __popcll(mk & lanes_lt(lane));
+                if (take) {
+                    const int node = p.idx.node_of_slot[i];
+                    if (idx < p.prop_cap) out[idx] = node;
+                    fp += mix64((unsigned long long)node);
+                }
+                count += __popcll(mk);
             }
-            count += __popcll(mk);
+            fp = wave_sum64(fp) + mix64(0x5EEDull + (unsigned long long)count);
+            if (fp == 0) fp = 1;
         }
-        fp = wave_sum64(fp) + mix64(0x5EEDull + (unsigned long long)count);
-        if (fp == 0) fp = 1;
+        if (lane == 0) {
+            p.emit_batch[r] = emit_batch;
+            p.num_proposals[r] = s.proposal_count;
+            p.prop_count[r] = count > p.prop_cap ? -1 : count;
+            p.fingerprint[r] = fp;
+        }
+        wave_lds_fence();
     }
-    if (lane == 0) {
-        p.emit_batch[r] = emit_batch;
-        p.num_proposals[r] = s.proposal_count;
-        p.prop_count[r] = count > p.prop_cap ? -1 : count;
-        p.fingerprint[r] = fp;
-        if (p.stats != nullptr) {
-            atomicAdd(&p.stats[0], n_slow);
-            atomicAdd(&p.stats[1], n_fast);
-            atomicAdd(&p.stats[2], (unsigned long long)n_full);
-            atomicAdd(&p.stats[3], n_restart);
-            atomicAdd(&p.stats[4], (unsigned long long)n_applied);
-            atomicAdd(&p.stats[5], n_records);
-        }
+    if (lane == 0 && p.stats != nullptr) {
+        atomicAdd(&p.stats[0], n_slow);
+        atomicAdd(&p.stats[1], n_fast);
+        atomicAdd(&p.stats[2], (unsigned long long)n_full);
+        atomicAdd(&p.stats[3], n_restart);
+        atomicAdd(&p.stats[4], (unsigned long long)n_applied);
+        atomicAdd(&p.stats[5], n_records);
     }
 }
 
-// --------------------------------------------------------------------------------------------------------
+// --------------------------------------------------------------------------------------------------------------
 // One MultiNodeCutDetector instance with its state in global memory (parity API rapid_cd_*): exact path only.
 // scal[0]=updatesInProgress [1]=proposalCount [2]=seenLinkDownEvents.  mode 0: apply n alerts (no filter --
 // the class itself has none); mode 1: invalidateFailingEdges (literal full pass); grid = 1, block = 64.
-// --------------------------------------------------------------------------------------------------------
+// --------------------------------------------------------------------------------------------------------------
 struct CdParams {
-    unsigned short* state;  // [n_nodes rounded to even], bit15 = member (refreshed by the host from the view)
-    int* scal;              // [4]
+    unsigned short* state;        // [n_nodes rounded to even] node-indexed masks
+    int* scal;                    // [4]
     const unsigned char* alerts;  // packed records (mode 0)
     int n_alerts;
     int n_nodes, K, H, L;
-    const int* obs;
-    const int* subj;
+    const int* obs;   // view's observer table (mode 1)
     int* out_idx;     // concatenated emissions
     int out_cap;
     int* out_counts;  // [n_alerts] (mode 0) / [1] (mode 1)
@@ -542,12 +621,11 @@ struct CdParams {
 
 __global__ __launch_bounds__(64) void cd_instance_kernel(CdParams p) {
     const int lane = (int)threadIdx.x;
-    Detector d;
+    TableDetector d;
     d.st16 = p.state;
     d.st32 = reinterpret_cast<unsigned int*>(p.state);
     d.obs = p.obs;
-    d.subj = p.subj;
-    d.n_nodes = p.n_nodes;
+    d.n_scan = p.n_nodes;
     d.K = p.K;
     d.H = p.H;
     d.L = p.L;
@@ -558,10 +636,9 @@ __global__ __launch_bounds__(64) void cd_instance_kernel(CdParams p) {
     s.seen_down = p.scal[2] != 0;
     s.npend = 0;
     s.batch = 0;
-    s.need_full = true;  // the instance API always uses the literal full pass
+    s.need_full = true;
     s.batch_emitted = false;
-    unsigned int dummy_pend = 0;
-    int total = 0, n_applied = 0, n_full = 0;
+    int total = 0;
     if (p.mode == 0) {
         for (int a = 0; a < p.n_alerts; ++a) {
             const unsigned int* w = reinterpret_cast<const unsigned int*>(p.alerts + (long long)a * kRecBytes);
@@ -569,16 +646,20 @@ __global__ __launch_bounds__(64) void cd_instance_kernel(CdParams p) {
             const unsigned int w4 = w[4];
             const int before = total;
             if ((unsigned)dst < (unsigned)p.n_nodes)
-                exact_apply(d, s, &dummy_pend, dst, w4 & d.kmask, ((w4 >> 16) & 0xFFu) != 0, lane, p.out_idx, p.out_cap,
+                exact_apply(d, s, nullptr, dst, w4 & d.kmask, ((w4 >> 16) & 0xFFu) != 0, lane, p.out_idx, p.out_cap,
                             &total);
-            s.npend = 0;
             if (lane == 0) p.out_counts[a] = total - before;
         }
-    } else {
-        exact_batch_end(d, s, &dummy_pend, lane, p.out_idx, p.out_cap, &total, &n_applied, &n_full);
-        if (lane == 0) p.out_counts[0] = total;
+    } else if (s.seen_down) {  // R/MultiNodeCutDetector.java:140-142
+        const int nH = invalidate_table(d, lane);
+        s.running -= nH;
+        if (nH > 0 && s.running == 0) {
+            s.proposal_count++;
+            flush_sweep(d, lane, p.out_idx, p.out_cap, &total);
+        }
     }
-    __syncthreads();
+    if (p.mode != 0 && lane == 0) p.out_counts[0] = total;
+    d.sync();
     if (lane == 0) {
         p.scal[0] = s.running;
         p.scal[1] = s.proposal_count;

@@ -167,12 +167,6 @@ __global__ void ring_tables_kernel(const int* ring, const unsigned long long* ri
     subj[t] = s;
 }
 
-__global__ void state_template_kernel(const unsigned char* member, int n_nodes, int n_padded, unsigned short* tpl) {
-    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (t >= n_padded) return;
-    tpl[t] = (t < n_nodes && member[t]) ? (unsigned short)0x8000 : (unsigned short)0;
-}
-
 // ---- configuration id -------------------------------------------------------------------------------------------
 // hash = 1; for id in sorted ids: hash = hash*37 + xx0(high); hash = hash*37 + xx0(low);
 //           for ep in ring 0:     hash = hash*37 + xx0(hostname); hash = hash*37 + xx0(port)

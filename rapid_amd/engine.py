@@ -341,4 +341,4 @@ class ClusterSimulation:
         return ms.value
 
     def set_force_exact(self, on):
-        self.e._check(self.e._lib.rapid_sim_set_force_exact(self.e._h, 1 if on else 0))
+        self.e._check(self.e._lib.rapid_sim_set_force_exact(self.e._h, int(on)))

@@ -1,0 +1,15 @@
+import sys, time, json
+import numpy as np
+sys.path.insert(0, '/root/repo')
+from rapid_amd import engine as E, scenarios as S
+n,K,H,L=10000,10,9,4
+pop=S.Population.make(n)
+eng=E.Engine(n_max=n,K=K,H=H,L=L)
+view=E.MembershipView(eng).build(pop.hostnames,pop.ports,pop.id_hi,pop.id_lo)
+obs,subj,member=view.tables(); cfg=view.getCurrentConfigurationId()
+sc=S.build_scenario("C3b",subj,cfg)
+sim=E.ClusterSimulation(eng); sim.load_streams(sc.records, sc.rec_off)
+for flag,name in [(0,"full"),(2,"no_invalidate"),(6,"no_apply_no_inv")]:
+    sim.set_force_exact(flag)
+    ms=sim.time_tally(10)
+    print(name, round(ms,3),"ms", round(20*len(sc.records)/ms/1e6,1),"GB/s", sim.stats())

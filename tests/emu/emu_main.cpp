@@ -4,74 +4,116 @@
 #include "tally_kernel.h"
 
 namespace emu {
-Wave* g_wave = nullptr;
+Block* g_block = nullptr;
 Dim g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 
 static void trampoline() {
-    Wave* w = g_wave;
-    const int l = w->cur;
+    Block* w = g_block;
+    const int t = w->cur;
     w->body();
-    w->done[l] = true;
-    w->op[l] = OP_NONE;
-    swapcontext(&w->ctx[l], &w->sched);
+    w->done[t] = 1;
+    w->op[t] = OP_NONE;
+    swapcontext(&w->ctx[t], &w->sched);
 }
 
-void run_block(unsigned block, unsigned grid, const std::function<void()>& body, uint64_t seed) {
-    Wave w;
-    g_wave = &w;
+// One workgroup of nthreads (= waves x 64).  Fibers run one at a time in a random order until each is parked at a
+// collective; a wave-level collective resolves when all live lanes of THAT wave are parked at it, __syncthreads
+// when every live fiber of the block is.  Waves therefore progress independently, as on the device.
+void run_block(unsigned block, unsigned grid, unsigned nthreads, const std::function<void()>& body, uint64_t seed) {
+    Block w;
+    g_block = &w;
     w.body = body;
+    w.nthreads = (int)nthreads;
     w.rng = seed * 0x9E3779B97F4A7C15ull + 12345;
     g_blockIdx.x = block;
     g_gridDim.x = grid;
-    g_blockDim.x = Wave::W;
-    for (int l = 0; l < Wave::W; ++l) {
-        w.stacks[l].resize(256 * 1024);
-        w.done[l] = false;
-        w.op[l] = OP_NONE;
-        getcontext(&w.ctx[l]);
-        w.ctx[l].uc_stack.ss_sp = w.stacks[l].data();
-        w.ctx[l].uc_stack.ss_size = w.stacks[l].size();
-        w.ctx[l].uc_link = &w.sched;
-        makecontext(&w.ctx[l], trampoline, 0);
+    g_blockDim.x = nthreads;
+    const int T = (int)nthreads;
+    w.ctx.resize(T);
+    w.stacks.resize(T);
+    w.done.assign(T, 0);
+    w.op.assign(T, OP_NONE);
+    w.arg.assign(T, 0);
+    w.aux.assign(T, 0);
+    w.res.assign(T, 0);
+    for (int t = 0; t < T; ++t) {
+        w.stacks[t].resize(192 * 1024);
+        getcontext(&w.ctx[t]);
+        w.ctx[t].uc_stack.ss_sp = w.stacks[t].data();
+        w.ctx[t].uc_stack.ss_size = w.stacks[t].size();
+        w.ctx[t].uc_link = &w.sched;
+        makecontext(&w.ctx[t], trampoline, 0);
     }
-    int order[Wave::W];
-    for (int l = 0; l < Wave::W; ++l) order[l] = l;
+    std::vector<int> order(T), runnable(T, 1);
+    for (int t = 0; t < T; ++t) order[t] = t;
     for (;;) {
-        // random lane order for this phase
-        for (int i = Wave::W - 1; i > 0; --i) {
+        for (int i = T - 1; i > 0; --i) {
             w.rng = w.rng * 6364136223846793005ull + 1442695040888963407ull;
             std::swap(order[i], order[(w.rng >> 33) % (uint64_t)(i + 1)]);
         }
-        bool any = false;
-        for (int i = 0; i < Wave::W; ++i) {
-            const int l = order[i];
-            if (w.done[l]) continue;
-            any = true;
-            w.cur = l;
-            g_threadIdx.x = (unsigned)l;
-            swapcontext(&w.sched, &w.ctx[l]);
+        bool ran = false;
+        for (int i = 0; i < T; ++i) {
+            const int t = order[i];
+            if (w.done[t] || !runnable[t]) continue;
+            ran = true;
+            w.cur = t;
+            g_threadIdx.x = (unsigned)t;
+            swapcontext(&w.sched, &w.ctx[t]);
+            runnable[t] = 0;  // parked (or finished)
         }
-        if (!any) break;
-        // every live lane is now parked at a collective (or finished): they must all be at the same one
-        int op = OP_NONE;
-        uint64_t ballot = 0;
-        for (int l = 0; l < Wave::W; ++l) {
-            if (w.done[l]) continue;
-            if (op == OP_NONE) op = w.op[l];
-            if (w.op[l] != op) {
-                std::fprintf(stderr, "emu: divergent wave op (lane %d at %d, expected %d)\n", l, w.op[l], op);
+        bool all_done = true;
+        for (int t = 0; t < T; ++t) all_done = all_done && w.done[t];
+        if (all_done) break;
+        // resolve wave-level collectives
+        bool progressed = false;
+        for (int wv = 0; wv < T / W; ++wv) {
+            int op = OP_NONE, live = 0, parked = 0;
+            bool same = true;
+            uint64_t ballot = 0;
+            for (int l = 0; l < W; ++l) {
+                const int t = wv * W + l;
+                if (w.done[t]) continue;
+                ++live;
+                if (runnable[t]) continue;
+                ++parked;
+                if (op == OP_NONE) op = w.op[t];
+                if (w.op[t] != op) same = false;
+                if (w.op[t] == OP_BALLOT && w.arg[t]) ballot |= 1ull << l;
+            }
+            if (live == 0 || parked < live) continue;
+            if (!same) {
+                std::fprintf(stderr, "emu: divergent wave op in wave %d\n", wv);
                 std::abort();
             }
-            if (op == OP_BALLOT && w.arg[l]) ballot |= 1ull << l;
+            if (op == OP_BLOCK_SYNC) continue;  // handled below
+            for (int l = 0; l < W; ++l) {
+                const int t = wv * W + l;
+                if (w.done[t]) continue;
+                if (op == OP_BALLOT) w.res[t] = ballot;
+                else if (op == OP_SHFL) { const int src = wv * W + (int)w.aux[t]; w.res[t] = w.done[src] ? 0 : w.arg[src]; }
+                else w.res[t] = 0;
+                runnable[t] = 1;
+            }
+            progressed = true;
         }
-        for (int l = 0; l < Wave::W; ++l) {
-            if (w.done[l]) continue;
-            if (op == OP_BALLOT) w.res[l] = ballot;
-            else if (op == OP_SHFL) w.res[l] = w.done[w.aux[l]] ? 0 : w.arg[w.aux[l]];
-            else w.res[l] = 0;
+        // block-level barrier: every live fiber parked at it
+        bool all_at_sync = true, any_live = false;
+        for (int t = 0; t < T; ++t) {
+            if (w.done[t]) continue;
+            any_live = true;
+            if (runnable[t] || w.op[t] != OP_BLOCK_SYNC) all_at_sync = false;
+        }
+        if (any_live && all_at_sync) {
+            for (int t = 0; t < T; ++t)
+                if (!w.done[t]) { w.res[t] = 0; runnable[t] = 1; }
+            progressed = true;
+        }
+        if (!progressed && !ran) {
+            std::fprintf(stderr, "emu: deadlock (a wave waits at __syncthreads while another finished a different path?)\n");
+            std::abort();
         }
     }
-    g_wave = nullptr;
+    g_block = nullptr;
 }
 }  // namespace emu
 
@@ -82,15 +124,18 @@ __attribute__((aligned(16))) unsigned char smem[160 * 1024];
 using rapid::smem;
 
 extern "C" {
-int emu_tally_lds_bytes(int n_nodes) { return rapid::tally_lds_bytes(n_nodes); }
+int emu_tally_wave_bytes(int n_slots) { return rapid::tally_wave_bytes(n_slots); }
+int emu_tally_shared_bytes(int n_nodes, int n_hot, int n_adj) { return rapid::tally_shared_bytes(n_nodes, n_hot, n_adj); }
 
-// Runs the population kernel for receivers [r0, r1) one block at a time.
+// Runs the population kernel: `grid` persistent workgroups of `waves` waves, one workgroup at a time.
 int emu_tally_run(const unsigned char* records, unsigned long long records_bytes, const long long* rec_off,
-                  int n_receivers, int n_nodes, int K, int H, int L, long long cfg_id,
-                  const unsigned short* state_template, const int* obs, const int* subj, int* emit_batch,
-                  int* num_proposals, int* prop_count, unsigned long long* fingerprint, int* props, int prop_cap,
-                  unsigned long long* stats, int force_exact, unsigned long long seed) {
-    if (rapid::tally_lds_bytes(n_nodes) > (int)sizeof(smem)) return -5;
+                  int n_receivers, int n_nodes, int K, int H, int L, long long cfg_id, const unsigned short* dict,
+                  const int* node_of_slot, const unsigned short* state_tpl, const unsigned short* adj_off,
+                  const unsigned int* adj, int n_slots, int n_hot, int n_adj, int* emit_batch, int* num_proposals,
+                  int* prop_count, unsigned long long* fingerprint, int* props, int prop_cap, unsigned long long* stats,
+                  int flags, int waves, int grid, int tables_in_lds, unsigned long long seed) {
+    const int lds = (tables_in_lds ? rapid::tally_shared_bytes(n_nodes, n_hot, n_adj) : 0) + waves * rapid::tally_wave_bytes(n_slots);
+    if (lds > (int)sizeof(smem)) return -5;
     rapid::TallyParams p;
     p.records = records;
     p.records_bytes = records_bytes;
@@ -101,9 +146,14 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     p.H = H;
     p.L = L;
     p.cfg_id = cfg_id;
-    p.state_template = state_template;
-    p.obs = obs;
-    p.subj = subj;
+    p.idx.dict = dict;
+    p.idx.node_of_slot = node_of_slot;
+    p.idx.state_tpl = state_tpl;
+    p.idx.adj_off = adj_off;
+    p.idx.adj = adj;
+    p.idx.n_slots = n_slots;
+    p.idx.n_hot = n_hot;
+    p.idx.n_adj = n_adj;
     p.emit_batch = emit_batch;
     p.num_proposals = num_proposals;
     p.prop_count = prop_count;
@@ -111,16 +161,22 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     p.props = props;
     p.prop_cap = prop_cap;
     p.stats = stats;
-    p.force_exact = force_exact;
-    for (int r = 0; r < n_receivers; ++r) {
+    unsigned int next = 0;
+    p.next_receiver = &next;
+    p.waves_per_block = waves;
+    p.flags = flags;
+    for (int b = 0; b < grid; ++b) {
         std::memset(smem, 0xCD, sizeof(smem));  // poison: the kernel must initialise what it reads
-        emu::run_block((unsigned)r, (unsigned)n_receivers, [&] { rapid::tally_population_kernel(p); }, seed + (unsigned)r);
+        if (tables_in_lds)
+            emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { rapid::tally_population_kernel<true>(p); }, seed + (unsigned)b);
+        else
+            emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { rapid::tally_population_kernel<false>(p); }, seed + (unsigned)b);
     }
     return 0;
 }
 
 int emu_cd_run(unsigned short* state, int* scal, const unsigned char* alerts, int n_alerts, int n_nodes, int K, int H,
-               int L, const int* obs, const int* subj, int* out_idx, int out_cap, int* out_counts, int* out_n, int mode,
+               int L, const int* obs, int* out_idx, int out_cap, int* out_counts, int* out_n, int mode,
                unsigned long long seed) {
     rapid::CdParams p;
     p.state = state;
@@ -132,13 +188,12 @@ int emu_cd_run(unsigned short* state, int* scal, const unsigned char* alerts, in
     p.H = H;
     p.L = L;
     p.obs = obs;
-    p.subj = subj;
     p.out_idx = out_idx;
     p.out_cap = out_cap;
     p.out_counts = out_counts;
     p.out_n = out_n;
     p.mode = mode;
-    emu::run_block(0, 1, [&] { rapid::cd_instance_kernel(p); }, seed);
+    emu::run_block(0, 1, 64, [&] { rapid::cd_instance_kernel(p); }, seed);
     return 0;
 }
 }

@@ -32,34 +32,37 @@ namespace emu {
 struct Dim {
     unsigned x = 0, y = 0, z = 0;
 };
-struct Wave {
-    static constexpr int W = 64;
+constexpr int W = 64;          // lanes per wave
+constexpr int MAXT = 16 * 64;  // threads per block
+struct Block {
     ucontext_t sched;
-    ucontext_t ctx[W];
-    std::vector<char> stacks[W];
-    bool done[W];
-    int op[W];           // collective id the lane is parked at (0 = none)
-    uint64_t arg[W];     // deposited operand
-    uint64_t aux[W];     // second operand (shuffle source lane)
-    uint64_t res[W];     // result handed back
+    std::vector<ucontext_t> ctx;
+    std::vector<std::vector<char>> stacks;
+    std::vector<char> done;
+    std::vector<int> op;         // collective the fiber is parked at (0 = none)
+    std::vector<uint64_t> arg;   // deposited operand
+    std::vector<uint64_t> aux;   // second operand (shuffle source lane)
+    std::vector<uint64_t> res;   // result handed back
+    int nthreads = 0;
     int cur = -1;
     uint64_t rng = 0x1234567;
     std::function<void()> body;
 };
-extern Wave* g_wave;
+extern Block* g_block;
 extern Dim g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
-enum { OP_NONE = 0, OP_BALLOT = 1, OP_SHFL = 2, OP_SYNC = 3 };
+enum { OP_NONE = 0, OP_BALLOT = 1, OP_SHFL = 2, OP_WAVE_SYNC = 3, OP_BLOCK_SYNC = 4 };
 
 inline uint64_t park(int op, uint64_t a, uint64_t b) {
-    Wave* w = g_wave;
-    const int l = w->cur;
-    w->op[l] = op;
-    w->arg[l] = a;
-    w->aux[l] = b;
-    swapcontext(&w->ctx[l], &w->sched);
-    return w->res[l];
+    Block* w = g_block;
+    const int t = w->cur;
+    w->op[t] = op;
+    w->arg[t] = a;
+    w->aux[t] = b;
+    swapcontext(&w->ctx[t], &w->sched);
+    return w->res[t];
 }
-void run_block(unsigned block, unsigned grid, const std::function<void()>& body, uint64_t seed);
+inline int cur_lane() { return g_block->cur & 63; }
+void run_block(unsigned block, unsigned grid, unsigned nthreads, const std::function<void()>& body, uint64_t seed);
 }  // namespace emu
 
 #define threadIdx (emu::g_threadIdx)
@@ -71,16 +74,24 @@ inline unsigned long long __ballot(int p) { return emu::park(emu::OP_BALLOT, p ?
 inline int __shfl(int v, int src, int = 64) { return (int)(uint32_t)emu::park(emu::OP_SHFL, (uint32_t)v, (unsigned)src & 63u); }
 inline unsigned __shfl(unsigned v, int src, int = 64) { return (unsigned)emu::park(emu::OP_SHFL, v, (unsigned)src & 63u); }
 inline int __shfl_xor(int v, int m, int = 64) {
-    return (int)(uint32_t)emu::park(emu::OP_SHFL, (uint32_t)v, (unsigned)(emu::g_wave->cur ^ m) & 63u);
+    return (int)(uint32_t)emu::park(emu::OP_SHFL, (uint32_t)v, (unsigned)(emu::cur_lane() ^ m) & 63u);
 }
 inline unsigned __shfl_xor(unsigned v, int m, int = 64) {
-    return (unsigned)emu::park(emu::OP_SHFL, v, (unsigned)(emu::g_wave->cur ^ m) & 63u);
+    return (unsigned)emu::park(emu::OP_SHFL, v, (unsigned)(emu::cur_lane() ^ m) & 63u);
 }
-inline void __syncthreads() { (void)emu::park(emu::OP_SYNC, 0, 0); }
+inline void __syncthreads() { (void)emu::park(emu::OP_BLOCK_SYNC, 0, 0); }
+// wave-local LDS ordering point of the kernels (compiler-only on the device): a rendezvous here, so that the
+// emulator keeps shuffling the lane order around every point where lanes exchange data through LDS
+inline void __builtin_amdgcn_wave_barrier() { (void)emu::park(emu::OP_WAVE_SYNC, 0, 0); }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clzll(long long v) { return v == 0 ? 64 : __builtin_clzll((unsigned long long)v); }
 using std::min;
 using std::max;

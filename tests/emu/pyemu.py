@@ -15,18 +15,47 @@ def lib():
     if _LIB is None:
         subprocess.check_call(["make", "-C", _HERE, "-s"], stderr=subprocess.DEVNULL)
         _LIB = C.CDLL(os.path.join(_HERE, "_build", "libtally_emu.so"))
-        _LIB.emu_tally_lds_bytes.restype = C.c_int
     return _LIB
 
 
-def state_template(member):
-    n = len(member)
-    t = np.zeros(((n + 7) // 8) * 8, dtype=np.uint16)
-    t[:n] = np.where(np.asarray(member) != 0, 0x8000, 0).astype(np.uint16)
-    return t
+def build_round_index(records, n_nodes, K, L, obs, member):
+    """Independent numpy statement of rapid_amd/csrc/index_kernels.h: touched / hot subjects, slot numbering (hot
+    first, ascending node index), state template and the hot-hot adjacency in CSR form."""
+    recs = np.asarray(records)
+    kmask = (1 << K) - 1
+    gmask = np.zeros(n_nodes, dtype=np.int64)
+    ok = recs["dst"] < n_nodes
+    np.bitwise_or.at(gmask, recs["dst"][ok].astype(np.int64), recs["ring_mask"][ok].astype(np.int64) & kmask)
+    pop = np.array([bin(int(x)).count("1") for x in gmask])
+    hot_nodes = np.flatnonzero((gmask != 0) & (pop >= L))
+    cold_nodes = np.flatnonzero((gmask != 0) & (pop < L))
+    node_of_slot = np.concatenate([hot_nodes, cold_nodes]).astype(np.int32)
+    n_hot, n_slots = len(hot_nodes), len(node_of_slot)
+    dict_ = np.full(n_nodes, 0xFFFF, dtype=np.uint16)
+    dict_[node_of_slot] = np.arange(n_slots, dtype=np.uint16)
+    tpl = np.zeros(((n_slots + 7) // 8) * 8 + 8, dtype=np.uint16)
+    tpl[:n_slots] = np.where(np.asarray(member)[node_of_slot] != 0, 0x8000, 0)
+    lists = [[] for _ in range(n_hot)]
+    for e in range(n_hot):
+        s_node = int(node_of_slot[e])
+        for k in range(K):
+            o = int(obs[s_node, k])
+            if o < 0:
+                continue
+            eo = int(dict_[o])
+            if eo >= n_hot:
+                continue
+            lists[e].append(eo | (k << 16))
+            lists[eo].append(e | (k << 16) | (1 << 20))
+    adj_off = np.zeros(n_hot + 1, dtype=np.uint16)
+    adj_off[1:] = np.cumsum([len(x) for x in lists])
+    adj = np.array([x for l in lists for x in l] + [0], dtype=np.uint32)
+    return dict(dict=dict_, node_of_slot=np.concatenate([node_of_slot, [0]]).astype(np.int32), tpl=tpl, adj_off=adj_off,
+                adj=adj, n_slots=n_slots, n_hot=n_hot, n_adj=int(adj_off[-1]))
 
 
-def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_cap=None, force_exact=0, seed=1):
+def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_cap=None, force_exact=0, seed=1, waves=3,
+          grid=2, tables_in_lds=1):
     L_ = lib()
     recs = np.ascontiguousarray(records)
     raw = np.zeros(((recs.nbytes + 15) // 16) * 16 + 32, dtype=np.uint8)
@@ -34,9 +63,7 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     rec_off = np.ascontiguousarray(rec_off, dtype=np.int64)
     R = len(rec_off) - 1
     prop_cap = n_nodes if prop_cap is None else prop_cap
-    tpl = state_template(member)
-    obs = np.ascontiguousarray(obs, dtype=np.int32)
-    subj = np.ascontiguousarray(subj, dtype=np.int32)
+    ix = build_round_index(recs, n_nodes, K, L, np.asarray(obs), member)
     emit = np.full(R, -99, dtype=np.int32)
     nprop = np.full(R, -99, dtype=np.int32)
     pcount = np.full(R, -99, dtype=np.int32)
@@ -44,9 +71,10 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     props = np.full((R, prop_cap), -1, dtype=np.int32)
     stats = np.zeros(8, dtype=np.uint64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    rc = L_.emu_tally_run(p(raw), C.c_ulonglong(raw.nbytes), p(rec_off), R, n_nodes, K, H, L, C.c_longlong(cfg_id),
-                          p(tpl), p(obs), p(subj), p(emit), p(nprop), p(pcount), p(fp), p(props), prop_cap, p(stats),
-                          force_exact, C.c_ulonglong(seed))
+    rc = L_.emu_tally_run(p(raw), C.c_ulonglong((raw.nbytes // 16) * 16), p(rec_off), R, n_nodes, K, H, L, C.c_longlong(cfg_id),
+                          p(ix["dict"]), p(ix["node_of_slot"]), p(ix["tpl"]), p(ix["adj_off"]), p(ix["adj"]), ix["n_slots"],
+                          ix["n_hot"], ix["n_adj"], p(emit), p(nprop), p(pcount), p(fp), p(props), prop_cap, p(stats),
+                          force_exact, waves, grid, tables_in_lds, C.c_ulonglong(seed))
     assert rc == 0, rc
     return emit, nprop, pcount, fp, props, stats
 
@@ -56,7 +84,7 @@ class CdInstance:
 
     def __init__(self, n_nodes, K, H, L, obs, subj, member):
         self.n, self.K, self.H, self.L = n_nodes, K, H, L
-        self.state = state_template(member).copy()
+        self.state = np.zeros(((n_nodes + 7) // 8) * 8, dtype=np.uint16)
         self.scal = np.zeros(4, dtype=np.int32)
         self.obs = np.ascontiguousarray(obs, dtype=np.int32)
         self.subj = np.ascontiguousarray(subj, dtype=np.int32)
@@ -69,7 +97,7 @@ class CdInstance:
         raw = np.ascontiguousarray(alerts).view(np.uint8).reshape(-1) if n else np.zeros(1, dtype=np.uint8)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         lib().emu_cd_run(p(self.state), p(self.scal), p(raw), n, self.n, self.K, self.H, self.L, p(self.obs),
-                         p(self.subj), p(out), len(out), p(counts), p(out_n), mode, C.c_ulonglong(7))
+                         p(out), len(out), p(counts), p(out_n), mode, C.c_ulonglong(7))
         return out[: out_n[0]].tolist(), counts[:n].tolist()
 
     def aggregate(self, alerts):
