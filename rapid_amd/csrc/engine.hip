@@ -107,7 +107,7 @@ struct rapid_engine {
     bool index_valid = false;
     long long n_records_total = 0;
     DevBuf<unsigned int> d_gmask, d_adj;
-    DevBuf<unsigned short> d_dict, d_state_tpl, d_adj_off;
+    DevBuf<unsigned short> d_dict, d_adj_off;
     DevBuf<int> d_node_of_slot, d_deg, d_cursor, d_info;
     int n_slots = 0, n_hot = 0, n_adj = 0;
     float index_ms = 0.f;
@@ -300,7 +300,6 @@ int build_round_index(rapid_engine* h) {
     HIPCHK(h, h->d_gmask.ensure((size_t)N));
     HIPCHK(h, h->d_dict.ensure((size_t)N));
     HIPCHK(h, h->d_node_of_slot.ensure((size_t)N));
-    HIPCHK(h, h->d_state_tpl.ensure((size_t)N + 16));
     HIPCHK(h, h->d_deg.ensure((size_t)N));
     HIPCHK(h, h->d_cursor.ensure((size_t)N));
     HIPCHK(h, h->d_adj_off.ensure((size_t)N + 1));
@@ -310,7 +309,6 @@ int build_round_index(rapid_engine* h) {
     HIPCHK(h, hipEventCreate(&e1));
     HIPCHK(h, hipEventRecord(e0, st));
     HIPCHK(h, hipMemsetAsync(h->d_gmask.p, 0, sizeof(unsigned int) * (size_t)N, st));
-    HIPCHK(h, hipMemsetAsync(h->d_state_tpl.p, 0, sizeof(unsigned short) * ((size_t)N + 16), st));
     HIPCHK(h, hipMemsetAsync(h->d_deg.p, 0, sizeof(int) * (size_t)N, st));
     HIPCHK(h, hipMemsetAsync(h->d_cursor.p, 0, sizeof(int) * (size_t)N, st));
     HIPCHK(h, hipMemsetAsync(h->d_info.p, 0, sizeof(int) * 8, st));
@@ -318,12 +316,12 @@ int build_round_index(rapid_engine* h) {
         hipLaunchKernelGGL(rapid::index_touch_kernel, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_records, h->n_records_total, N,
                            (1u << K) - 1u, h->d_gmask.p);
     hipLaunchKernelGGL(rapid::index_slots_kernel, dim3(1), dim3(1024), 0, st, h->d_gmask.p, h->d_member.p, N, L, h->d_dict.p,
-                       h->d_node_of_slot.p, h->d_state_tpl.p, h->d_info.p);
+                       h->d_node_of_slot.p, h->d_info.p);
     int info[8] = {0};
     HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof info, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
-    if (info[2] & 1) return fail(h, RAPID_ECAPACITY, "the round names %d subjects; at most 65534 are supported", info[0]);
+    if (info[2] & 1) return fail(h, RAPID_ECAPACITY, "the round has %d hot subjects; at most 16382 are supported", info[0]);
     h->n_slots = info[0];
     h->n_hot = info[1];
     h->n_adj = 0;
@@ -336,6 +334,8 @@ int build_round_index(rapid_engine* h) {
                            h->d_info.p);
         hipLaunchKernelGGL(rapid::index_adj_kernel, dim3(g), dim3(256), 0, st, h->d_obs.p, h->d_dict.p, h->d_node_of_slot.p,
                            h->n_hot, K, h->d_deg.p, h->d_adj_off.p, h->d_cursor.p, h->d_adj.p, 1);
+        hipLaunchKernelGGL(rapid::index_adj_flag_kernel, dim3(grid_for(h->n_hot, 256)), dim3(256), 0, st, h->d_deg.p,
+                           h->d_node_of_slot.p, h->n_hot, h->d_dict.p);
         HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof info, hipMemcpyDeviceToHost, st));
     } else {
         HIPCHK(h, hipMemsetAsync(h->d_adj_off.p, 0, sizeof(unsigned short) * 2, st));
@@ -390,10 +390,8 @@ int launch_tally(rapid_engine* h) {
     p.cfg_id = h->config_id;
     p.idx.dict = h->d_dict.p;
     p.idx.node_of_slot = h->d_node_of_slot.p;
-    p.idx.state_tpl = h->d_state_tpl.p;
     p.idx.adj_off = h->d_adj_off.p;
     p.idx.adj = h->d_adj.p;
-    p.idx.n_slots = h->n_slots;
     p.idx.n_hot = h->n_hot;
     p.idx.n_adj = h->n_adj;
     p.emit_batch = h->d_emit.p;
@@ -489,7 +487,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
     h->d_records_own.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
-    h->d_next.release(); h->d_gmask.release(); h->d_adj.release(); h->d_dict.release(); h->d_state_tpl.release();
+    h->d_next.release(); h->d_gmask.release(); h->d_adj.release(); h->d_dict.release();
     h->d_adj_off.release(); h->d_node_of_slot.release(); h->d_deg.release(); h->d_cursor.release(); h->d_info.release();
     h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release();
     delete h;

@@ -26,49 +26,41 @@ __global__ void index_touch_kernel(const unsigned char* records, long long n_rec
     }
 }
 
-// One block.  Slot numbering: hot subjects (>= L distinct rings named) first, then the other touched subjects,
-// both ascending by node index.  info[0]=n_slots, info[1]=n_hot, info[2]=overflow flag.
+// One block.  Slot numbering: the hot subjects (>= L distinct rings named by the round's alert set), ascending by
+// node index.  Every node gets a dictionary entry  member << 15 | has_adjacency << 14 | slot  with slot = 0x3FFF for
+// subjects that are not hot.  info[0] = info[1] = n_hot, info[2] = overflow flag.
 __global__ void index_slots_kernel(const unsigned int* gmask, const unsigned char* member, int n_nodes, int L,
-                                   unsigned short* dict, int* node_of_slot, unsigned short* state_tpl, int* info) {
-    __shared__ int s_hot[1024], s_cold[1024];
+                                   unsigned short* dict, int* node_of_slot, int* info) {
+    __shared__ int s_hot[1024];
     const int T = (int)blockDim.x, t = (int)threadIdx.x;
     const int per = (n_nodes + T - 1) / T;
     const int beg = min(n_nodes, t * per), end = min(n_nodes, beg + per);
-    int nh = 0, nc = 0;
-    for (int n = beg; n < end; ++n) {
-        const unsigned int m = gmask[n];
-        if (m != 0u) {
-            if (__popc(m) >= L) ++nh; else ++nc;
-        }
-    }
+    int nh = 0;
+    for (int n = beg; n < end; ++n)
+        if (__popc(gmask[n]) >= L) ++nh;
     s_hot[t] = nh;
-    s_cold[t] = nc;
     __syncthreads();
-    if (t == 0) {  // exclusive scans over 1024 partial counts
-        int ah = 0, ac = 0;
+    if (t == 0) {  // exclusive scan over 1024 partial counts
+        int ah = 0;
         for (int i = 0; i < T; ++i) {
-            const int h = s_hot[i], c = s_cold[i];
+            const int h = s_hot[i];
             s_hot[i] = ah;
-            s_cold[i] = ac;
             ah += h;
-            ac += c;
         }
-        info[0] = ah + ac;
+        info[0] = ah;
         info[1] = ah;
-        info[2] = (ah + ac > 65534) ? 1 : 0;
+        info[2] = (ah > 16382) ? 1 : 0;
     }
     __syncthreads();
-    const int n_hot = info[1];
-    int ph = s_hot[t], pc = n_hot + s_cold[t];
+    int ph = s_hot[t];
     for (int n = beg; n < end; ++n) {
-        const unsigned int m = gmask[n];
-        int slot = -1;
-        if (m != 0u) slot = (__popc(m) >= L) ? ph++ : pc++;
-        dict[n] = (slot >= 0 && slot < 65535) ? (unsigned short)slot : (unsigned short)0xFFFF;
-        if (slot >= 0 && slot < 65535) {
-            node_of_slot[slot] = n;
-            state_tpl[slot] = member[n] ? (unsigned short)0x8000 : (unsigned short)0;
+        int slot = 0x3FFF;
+        if (__popc(gmask[n]) >= L) {
+            slot = ph < 16383 ? ph : 0x3FFF;
+            if (ph < 16383) node_of_slot[ph] = n;
+            ++ph;
         }
+        dict[n] = (unsigned short)(slot | (member[n] ? 0x8000 : 0));
     }
 }
 
@@ -82,7 +74,7 @@ __global__ void index_adj_kernel(const int* obs, const unsigned short* dict, con
     const int s_node = node_of_slot[e];
     const int o_node = obs[s_node * K + k];
     if (o_node < 0) return;
-    const int eo = (int)dict[o_node];
+    const int eo = (int)(dict[o_node] & 0x3FFF);
     if (eo >= n_hot) return;  // observer not hot (or not touched): can never vouch
     if (phase == 0) {
         atomicAdd(&deg[e], 1);
@@ -105,6 +97,12 @@ __global__ void index_adj_scan_kernel(const int* deg, int n_hot, unsigned short*
     adj_off[n_hot] = (unsigned short)(acc > 65535 ? 65535 : acc);
     info[3] = (int)(acc > 0x7FFFFFFF ? 0x7FFFFFFF : acc);
     if (acc > 65535) info[2] |= 2;
+}
+
+// dict[node] |= has-adjacency flag for every hot slot with at least one adjacency entry
+__global__ void index_adj_flag_kernel(const int* deg, const int* node_of_slot, int n_hot, unsigned short* dict) {
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e < n_hot && deg[e] > 0) dict[node_of_slot[e]] |= (unsigned short)0x4000;
 }
 
 }  // namespace rapid

@@ -9,9 +9,11 @@
 // Mapping onto the machine (DESIGN.md "Tally kernel"):
 //   * one wavefront per simulated receiver; a workgroup is W such wavefronts (W chosen so the CU's 160 KB LDS is
 //     full) that share read-only per-round tables in LDS and pull receivers from a global counter (persistent);
-//   * the receiver's whole detector state is one 16-bit word per SLOT in LDS -- a slot is a subject named by this
-//     round's alert set (index_kernels.h builds the node->slot dictionary once per loaded stream set): bits
-//     0..K-1 = rings reported, bit 14 = already flushed into an emitted proposal, bit 15 = member of the view;
+//   * the receiver's whole detector state is one 16-bit word per SLOT in LDS -- a slot is a "hot" subject: one the
+//     round's alert set names on >= L distinct rings, the only kind that can ever reach the L watermark at any
+//     receiver (index_kernels.h builds the node->slot dictionary once per loaded stream set; reports about other
+//     subjects can never change any receiver's outcome and only contribute to seenLinkDownEvents): bits 0..K-1 =
+//     rings reported, bit 14 = already flushed into an emitted proposal;
 //   * the delivered stream is read ONCE from HBM: 2 KiB tiles, 16 B/lane coalesced loads, kPrefetch tiles in
 //     flight in registers per wave; tiles are staged through a small LDS ring and consumed in sub-chunks of up
 //     to 64 records (one per lane) that end at a batch end whenever they contain one.  The tally loop touches
@@ -41,24 +43,28 @@ constexpr int kTileBytes = 2048;                     // one tile = 2 x (64 lanes
 constexpr int kTileVec = kTileBytes / 1024;          // uint4 per lane per tile
 constexpr int kRingTiles = 2;                        // LDS ring the sub-chunks are decoded from
 constexpr int kRingBytes = kTileBytes * kRingTiles;  // power of two; a sub-chunk (<= 1280 B) spans <= 2 tiles
-constexpr int kPrefetch = 4;                         // tiles in flight in registers per wave (8 KiB)
+constexpr int kMirrorBytes = kWave * kRecBytes;      // head of slot 0 repeated after the ring: decode never wraps
+constexpr int kPrefetch = 4;                         // tiles in flight in registers per wave (8 KiB); multiple of kRingTiles
 constexpr int kPendCap = 128;                        // slots that crossed L and still await invalidation
 constexpr int kUndoCap = 128;                        // implicit bits set inside one sub-chunk
 constexpr int kMaxWavesPerBlock = 16;
 constexpr uint32_t kFlushed = 1u << 14;
 constexpr uint32_t kMember = 1u << 15;
-constexpr unsigned short kNoSlot = 0xFFFF;
+// dictionary entry (16 bit): bit 15 = node is a member, bit 14 = slot has hot adjacency, bits 0..13 = slot
+constexpr unsigned int kDictMember = 1u << 15;
+constexpr unsigned int kDictHasAdj = 1u << 14;
+constexpr unsigned int kSlotMask = 0x3FFFu;
+constexpr unsigned int kNoSlot = 0x3FFFu;            // at most 16382 subjects per round
 
 // Per-round index over the loaded alert set (built by index_kernels.h; all device pointers).
 // Slots [0, n_hot) are the "hot" subjects -- those named on >= L distinct rings by the round's alert set, the only
-// ones that can ever enter preProposal/proposal at any receiver -- in ascending node order; [n_hot, n_slots) the rest.
+// ones that can ever enter preProposal/proposal at any receiver -- in ascending node order.
 struct RoundIndex {
-    const unsigned short* dict;       // [n_nodes] node -> slot, kNoSlot if the round never names the node
-    const int* node_of_slot;          // [n_slots]
-    const unsigned short* state_tpl;  // [n_slots rounded up to 8] kMember for members
-    const unsigned short* adj_off;    // [n_hot + 1] CSR over hot slots
-    const unsigned int* adj;          // [n_adj] other_slot | ring << 16 | role << 20 (role 1: `other` is the subject)
-    int n_slots, n_hot, n_adj;
+    const unsigned short* dict;     // [n_nodes] node -> kDictMember | kDictHasAdj | slot (kNoSlot: not hot)
+    const int* node_of_slot;        // [n_hot]
+    const unsigned short* adj_off;  // [n_hot + 1] CSR over hot slots
+    const unsigned int* adj;        // [n_adj] other_slot | ring << 16 | role << 20 (role 1: `other` is the subject)
+    int n_hot, n_adj;
 };
 
 struct TallyParams {
@@ -79,7 +85,7 @@ struct TallyParams {
     unsigned long long* stats;        // [8]
     unsigned int* next_receiver;      // work counter (zeroed before every launch)
     int waves_per_block;
-    int flags;                        // bit0: exact path only (tests); bits 1-2: profiling ablations
+    int flags;                        // bit0: exact path only, bit3: careful loop only (tests); bits 1-2: ablations
 };
 
 __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
@@ -88,7 +94,7 @@ __host__ __device__ inline int tally_shared_bytes(int n_nodes, int n_hot, int n_
     return align16(n_nodes * 2) + align16((n_hot + 1) * 2) + align16(n_adj * 4);
 }
 __host__ __device__ inline int tally_wave_bytes(int n_slots) {
-    return align16(n_slots * 2) + kRingBytes + align16(kPendCap * 2) + kUndoCap * 4;
+    return align16(n_slots * 2) + kRingBytes + kMirrorBytes + align16(kPendCap * 2) + kUndoCap * 4;
 }
 
 // ---- small wave helpers ---------------------------------------------------------------------------------------
@@ -100,6 +106,11 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ unsigned long long lanes_lt(int lane) { return (1ull << lane) - 1ull; }
+// Values that are the same in every lane are kept provably uniform (SGPRs, scalar branches): everything derived
+// from them -- loop bounds, the detector's counters -- then costs scalar instead of exec-masked vector code.
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned int uniform(unsigned int v) { return (unsigned int)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int lane_value(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
 __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned lo = __shfl_xor((unsigned)v, off, kWave);
@@ -200,7 +211,7 @@ __device__ inline void exact_apply(const D& d, RxScalars& s, unsigned short* pen
                                    int lane, int* emit_out, int emit_cap, int* emit_n) {
     if (bits == 0) return;
     if (down) s.seen_down = true;
-    unsigned int m = d.load(dst);
+    unsigned int m = uniform(d.load(dst));
     unsigned int nb = bits & ~m & d.kmask;
     while (nb) {
         const int k = __ffs((int)nb) - 1;
@@ -226,7 +237,7 @@ __device__ inline void exact_apply(const D& d, RxScalars& s, unsigned short* pen
                 d.sync();
                 if (lane == 0) d.store(dst, m);
                 flush_sweep(d, lane, emit_out, emit_cap, emit_n);
-                m = d.load(dst);
+                m = uniform(d.load(dst));
             }
         }
     }
@@ -331,7 +342,7 @@ __device__ inline void exact_batch_end(const SlotDetector& d, RxScalars& s, cons
 // are read from global memory (populations whose dictionary does not fit next to the per-wave state).
 // --------------------------------------------------------------------------------------------------------------
 template <bool kTablesInLds>
-__global__ __launch_bounds__(1024) void tally_population_kernel(TallyParams p) {
+__global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kernel(TallyParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = (int)(threadIdx.x >> 6);
@@ -357,11 +368,11 @@ __global__ __launch_bounds__(1024) void tally_population_kernel(TallyParams p) {
     __syncthreads();
 
     // ---- this wave's private LDS ----
-    const int state_bytes = align16(p.idx.n_slots * 2);
-    unsigned char* const mine = smem + shared_bytes + wave * tally_wave_bytes(p.idx.n_slots);
+    const int state_bytes = align16(p.idx.n_hot * 2);
+    unsigned char* const mine = smem + shared_bytes + wave * tally_wave_bytes(p.idx.n_hot);
     unsigned char* const stage = mine + state_bytes;
-    unsigned short* const pend = reinterpret_cast<unsigned short*>(stage + kRingBytes);
-    unsigned int* const undo = reinterpret_cast<unsigned int*>(stage + kRingBytes + align16(kPendCap * 2));
+    unsigned short* const pend = reinterpret_cast<unsigned short*>(stage + kRingBytes + kMirrorBytes);
+    unsigned int* const undo = reinterpret_cast<unsigned int*>(stage + kRingBytes + kMirrorBytes + align16(kPendCap * 2));
     const unsigned int* const ring32 = reinterpret_cast<const unsigned int*>(stage);
 
     SlotDetector d;
@@ -379,12 +390,13 @@ __global__ __launch_bounds__(1024) void tally_population_kernel(TallyParams p) {
     const bool abl_noinv = (p.flags & 2) != 0;  // profiling ablations (results invalid)
     const bool abl_noapply = (p.flags & 4) != 0;
     unsigned long long n_slow = 0, n_fast = 0, n_restart = 0, n_records = 0;
-    int n_applied = 0, n_full = 0;
+    int n_applied = 0, n_full = 0, n_fast32 = 0;
+    const int lane20 = lane * kRecBytes;
 
     for (;;) {
         int r = 0;
         if (lane == 0) r = (int)atomicAdd(p.next_receiver, 1u);
-        r = __shfl(r, 0, kWave);
+        r = uniform(r);
         if (r >= p.n_receivers) break;
 
         const long long rec0 = p.rec_off[r];
@@ -393,172 +405,341 @@ __global__ __launch_bounds__(1024) void tally_population_kernel(TallyParams p) {
         const unsigned long long a0 = b0 & ~15ull;  // 16-B aligned start of this receiver's byte range
         const int delta = (int)(b0 - a0);
         const int ntiles = (int)(((long long)delta + (long long)nrec * kRecBytes + kTileBytes - 1) / kTileBytes);
+        const unsigned long long last16 = p.records_bytes - 16ull;
 
         int emit_batch = -1;
         RxScalars s;
+        int pend_pairs = 0;   // upper bound on the H crossings the pending (not yet invalidated) entrants can cause
         bool exact_only = (p.flags & 1) != 0;
+        bool restart = true;  // (re)initialise the detector before the first sub-chunk
+        int pos = 0;          // next unconsumed record
+        int ring_tile0 = 0;   // stream tile that maps to ring slot 0
+        int careful_budget = 0, careful_next = 2;
 
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            // ---- state init: member bits from the template (L2-resident), everything else zero ----
-            {
-                const uint4* tpl = reinterpret_cast<const uint4*>(p.idx.state_tpl);
-                uint4* dst = reinterpret_cast<uint4*>(mine);
-                for (int i = lane; i < state_bytes / 16; i += kWave) dst[i] = tpl[i];
-            }
-            s.running = 0;
+        // per-sub-chunk decode results (one record per lane)
+        int dst = 0, ncons = 0, lastE = -1;
+        unsigned int bits = 0;
+        bool down = false, eob = false, hasadj = false;
+        unsigned long long mE_all = 0ull;
+
+        // ---- decode the sub-chunk starting at `pos` from the LDS ring (the mirror makes it wrap-free) ----
+        auto decode = [&]() {
+            const int navail = min(kWave, nrec - pos);
+            const int base = (delta + kRecBytes * pos - ring_tile0 * kTileBytes) & (kRingBytes - 1);
+            const unsigned int* w = ring32 + ((base + lane20) >> 2);
+            const unsigned int w0 = w[0], w1 = w[1], w3 = w[3], w4 = w[4];
+            down = ((w4 >> 16) & 0xFFu) != 0;
+            eob = lane < navail && ((((w4 >> 24) & 1u) != 0) || pos + lane == nrec - 1);
+            // a sub-chunk ends at its last batch end (if it has one): no record is applied before the batch end
+            // that precedes it has been processed
+            mE_all = __ballot(eob);
+            lastE = mE_all ? 63 - __clzll((long long)mE_all) : -1;
+            ncons = lastE >= 0 ? lastE + 1 : navail;
+            const bool valid = lane < ncons;
+            eob = eob && valid;
+            // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot, branch-free
+            const unsigned int de = (unsigned int)dict[w3 < (unsigned)p.n_nodes ? w3 : 0u];
+            const bool okf = valid & (w0 == cfg_lo) & (w1 == cfg_hi) & (w3 < (unsigned)p.n_nodes) &
+                             (((de & kDictMember) != 0) == down) & ((w4 & d.kmask) != 0u);
+            const bool hot = (de & kSlotMask) != kNoSlot;
+            down = down & okf;  // from here on: "a DOWN report passed the filter" (sets seenLinkDownEvents)
+            dst = (okf & hot) ? (int)(de & kSlotMask) : 0;
+            hasadj = (de & kDictHasAdj) != 0;
+            bits = (okf & hot) ? (w4 & d.kmask) : 0u;
+        };
+
+        // ---- apply the pending implicit invalidation.  Only called while running - pend_pairs >= 1 holds, so it
+        // cannot produce an emission (the H crossings it causes are bounded by pend_pairs). ----
+        auto flush_pending = [&]() {
+            if (s.npend == 0 || !s.seen_down || s.need_full) return;
+            if (s.running - pend_pairs < 1) return;  // an emission cannot be excluded: left to the careful loop
+            wave_lds_fence();
+            int applied = 0;
+            const int nH = invalidate_adj(d, pend, s.npend, false, nullptr, nullptr, lane, &applied);
+            s.running -= nH;
             s.npend = 0;
-            s.batch = 0;
-            s.proposal_count = 0;
-            s.seen_down = false;
-            s.need_full = false;
-            s.batch_emitted = false;
-            emit_batch = -1;
-            bool restart = false;
-            int pos = 0;          // next unconsumed record
-            int pos_off = delta;  // (delta + 20 * pos) mod ring size
-            wave_lds_fence();
+            pend_pairs = 0;
+            n_applied += applied;
+        };
 
-            // ---- one sub-chunk: up to 64 records, one per lane ----
-            auto process = [&]() {
-                const int navail = min(kWave, nrec - pos);
-                const int off = (pos_off + kRecBytes * lane) & (kRingBytes - 1);
-                const unsigned int w0 = ring32[off >> 2];
-                const unsigned int w1 = ring32[((off + 4) & (kRingBytes - 1)) >> 2];
-                const unsigned int w3 = ring32[((off + 12) & (kRingBytes - 1)) >> 2];
-                const unsigned int w4 = ring32[((off + 16) & (kRingBytes - 1)) >> 2];
-                const bool down = ((w4 >> 16) & 0xFFu) != 0;
-                bool eob = lane < navail && ((((w4 >> 24) & 1u) != 0) || pos + lane == nrec - 1);
-                // a sub-chunk ends at its last batch end (if it has one): no record is applied before the batch
-                // end that precedes it has been processed
-                const unsigned long long mE_all = __ballot(eob);
-                const int lastE = mE_all ? 63 - __clzll((long long)mE_all) : -1;
-                const int ncons = lastE >= 0 ? lastE + 1 : navail;
-                const bool valid = lane < ncons;
-                eob = eob && valid;
-                // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot
-                bool pass = valid && w0 == cfg_lo && w1 == cfg_hi && w3 < (unsigned)p.n_nodes;
-                const unsigned int slot_raw = pass ? (unsigned int)dict[w3] : (unsigned int)kNoSlot;
-                pass = pass && slot_raw != kNoSlot;
-                const int dst = pass ? (int)slot_raw : 0;
-                const unsigned int m0 = pass ? d.load(dst) : 0u;
-                pass = pass && (((m0 & kMember) != 0) == down);
-                const unsigned int bits = pass ? (w4 & d.kmask) : 0u;
+        // ---- LEAN path (pipelined loop): decode + order-free application of the sub-chunk starting at `pos`; the
+        // implicit invalidation is deferred to the end of the tile round.  No emission is possible as long as
+        // running - pend_pairs - (H crossings here) >= 1.  Returns false -- with the sub-chunk rolled back and
+        // nothing consumed -- when that cannot be shown.  Written with lane MASKS (scalar registers) rather than
+        // per-lane booleans: predicates cost one v_cmp each and combine with scalar ANDs.
+        auto lean_subchunk = [&]() -> bool {
+            const int navail = min(kWave, nrec - pos);
+            const int base = (delta + kRecBytes * pos - ring_tile0 * kTileBytes) & (kRingBytes - 1);
+            const unsigned int* w = ring32 + ((base + lane20) >> 2);
+            const unsigned int w0 = w[0], w1 = w[1], w3 = w[3], w4 = w[4];
+            const unsigned long long m_in = navail == kWave ? ~0ull : ((1ull << navail) - 1ull);
+            const unsigned long long m_last = (pos + navail == nrec) ? (1ull << (navail - 1)) : 0ull;
+            const unsigned long long mE = (__ballot((w4 & 0x01000000u) != 0u) | m_last) & m_in;
+            // consume up to the last batch end; a batch longer than a sub-chunk (mE == 0) is left to the careful loop
+            // through the common roll-back exit below, which keeps this code straight-line
+            const int nc = mE != 0ull ? kWave - __clzll((long long)mE) : navail;
+            const unsigned long long m_valid = nc == kWave ? ~0ull : ((1ull << nc) - 1ull);
+            // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot
+            const unsigned int node = w3 < (unsigned)p.n_nodes ? w3 : 0u;
+            const unsigned int de = (unsigned int)dict[node];
+            const unsigned int rb = w4 & d.kmask;
+            const unsigned long long m_down = __ballot((w4 & 0x00FF0000u) != 0u);
+            const unsigned long long m_ok = m_valid & __ballot(w0 == cfg_lo) & __ballot(w1 == cfg_hi) &
+                                            __ballot(w3 < (unsigned)p.n_nodes) & __ballot(rb != 0u) &
+                                            ~(m_down ^ __ballot((de & kDictMember) != 0u));
+            const unsigned int slot = de & kSlotMask;
+            const unsigned long long m_app = m_ok & __ballot(slot != kNoSlot);
+            const unsigned long long mD = m_ok & m_down;  // DOWN reports that passed the filter
+            const bool app = ((m_app >> lane) & 1ull) != 0ull;
+            unsigned int old = 0;
+            if (app && !abl_noapply) old = d.or_bits((int)slot, rb);
+            const unsigned int oldk = old & d.kmask;
+            const int c0 = __popc(oldk), c1 = __popc(oldk | rb);
+            const unsigned long long mL = m_app & __ballot(c0 < d.L) & __ballot(c1 >= d.L);
+            const unsigned long long mH = m_app & __ballot(c0 < d.H) & __ballot(c1 >= d.H);
+            const unsigned long long mA = abl_noinv ? 0ull : (mL & __ballot((de & kDictHasAdj) != 0u));
+            const int nLc = __popcll(mL), nHc = __popcll(mH);
+            int add_pairs = 0;
+            if (mA != 0ull) {
+                const bool ent = ((mA >> lane) & 1ull) != 0ull;
+                const int degv = ent ? (int)adj_off[slot + 1] - (int)adj_off[slot] : 0;
+                for (unsigned long long m = mA; m != 0ull; m &= m - 1ull)
+                    add_pairs += lane_value(degv, __ffsll((long long)m) - 1);
+            }
+            const int pairs_new = pend_pairs + add_pairs;
+            const int npend_new = s.npend + __popcll(mA);
+            const bool safe = ((nHc | pairs_new) == 0 || s.running - pairs_new - nHc >= 1) && npend_new <= kPendCap &&
+                              mE != 0ull;
+            if (!safe) {
+                const unsigned int newbits = rb & ~old;
+                if (app && newbits != 0u) d.clear_bits((int)slot, newbits);
+                wave_lds_fence();
+                return false;
+            }
+            if (mA != 0ull) {
+                const int posn = s.npend + __popcll(mA & lanes_lt(lane));
+                if (((mA >> lane) & 1ull) != 0ull) pend[posn] = (unsigned short)slot;
+            }
+            s.running += nLc - nHc;
+            s.seen_down = s.seen_down || mD != 0ull;
+            s.batch += __popcll(mE);
+            s.npend = npend_new;
+            pend_pairs = pairs_new;
+            pos += nc;
+            ++n_fast32;
+            return true;
+        };
+
+        // ---- CAREFUL path (non-pipelined loop), first attempt: order-free application with the implicit
+        // invalidation applied immediately and an EXACT count of the H crossings; rolled back if an emission
+        // cannot be excluded.  Returns false when the sub-chunk must be replayed record by record. ----
+        auto immediate_subchunk = [&]() -> bool {
+            unsigned int old = 0;
+            if (bits) old = d.or_bits(dst, bits);
+            const unsigned int newbits = bits & ~old;
+            const int c0 = d.count(old), c1 = d.count(old | bits);
+            const bool isL = bits != 0 && c0 < d.L && c1 >= d.L;
+            const bool isH = bits != 0 && c0 < d.H && c1 >= d.H;
+            const unsigned long long mL = __ballot(isL), mH = __ballot(isH);
+            const unsigned long long mD = __ballot(down);
+            const int nLc = __popcll(mL), nHc = __popcll(mH);
+            const bool seen = s.seen_down || mD != 0ull;
+            bool need_full = s.need_full;
+            const int posn = s.npend + __popcll(mL & lanes_lt(lane));
+            if (isL && posn < kPendCap) pend[posn] = (unsigned short)dst;
+            const int npend_new = s.npend + nLc;
+            if (npend_new > kPendCap) need_full = true;
+            const bool run_inv = lastE >= 0 && seen && (npend_new > 0 || need_full);
+            int nHi = 0, n_undo = 0, applied_here = 0;
+            if (run_inv) {
+                wave_lds_fence();
+                if (need_full) n_full++;
+                nHi = invalidate_adj(d, pend, npend_new, need_full, undo, &n_undo, lane, &applied_here);
+            }
+            const int Htot = nHc + nHi;
+            if (Htot == 0 || s.running - Htot >= 1) {
+                s.running += nLc - Htot;
+                s.seen_down = seen;
+                s.batch += __popcll(mE_all);
+                s.need_full = need_full;
+                s.npend = ((lastE >= 0 && seen) || need_full) ? 0 : npend_new;
+                n_applied += applied_here;
+                n_fast++;
                 n_records += (unsigned long long)ncons;
-
-                // once an emission happened inside the current batch, the rest of that batch (whose end announces
-                // the proposal) is processed exactly
-                bool replay = exact_only || s.batch_emitted;
-                if (!replay) {
-                    // ---------------- FAST path: order-free, then a safety check ----------------
-                    unsigned int old = 0;
-                    if (bits && !abl_noapply) old = d.or_bits(dst, bits);
-                    const unsigned int newbits = bits & ~old;
-                    const int c0 = d.count(old), c1 = d.count(old | bits);
-                    const bool isL = bits != 0 && c0 < d.L && c1 >= d.L;
-                    const bool isH = bits != 0 && c0 < d.H && c1 >= d.H;
-                    const unsigned long long mL = __ballot(isL), mH = __ballot(isH);
-                    const unsigned long long mD = __ballot(bits != 0 && down);
-                    const int nLc = __popcll(mL), nHc = __popcll(mH);
-                    const bool seen = s.seen_down || mD != 0ull;
-                    bool need_full = s.need_full;
-                    // append the slots that crossed L (lane order)
-                    const int posn = s.npend + __popcll(mL & lanes_lt(lane));
-                    if (isL && posn < kPendCap) pend[posn] = (unsigned short)dst;
-                    const int npend_new = s.npend + nLc;
-                    if (npend_new > kPendCap) need_full = true;
-                    const bool run_inv = lastE >= 0 && seen && !abl_noinv && (npend_new > 0 || need_full);
-                    int nHi = 0, n_undo = 0, applied_here = 0;
-                    if (run_inv) {
-                        wave_lds_fence();
-                        if (need_full) n_full++;
-                        nHi = invalidate_adj(d, pend, npend_new, need_full, undo, &n_undo, lane, &applied_here);
-                    }
-                    const int Htot = nHc + nHi;
-                    // No emission is possible inside this sub-chunk under ANY order if updatesInProgress cannot
-                    // reach 0 at one of its H crossings.
-                    const bool safe = Htot == 0 || s.running - Htot >= 1;
-                    if (safe) {
-                        s.running += nLc - Htot;
-                        s.seen_down = seen;
-                        s.batch += __popcll(mE_all & ((ncons == 64) ? ~0ull : ((1ull << ncons) - 1ull)));
-                        s.need_full = need_full;
-                        s.npend = ((lastE >= 0 && seen) || need_full) ? 0 : npend_new;
-                        n_applied += applied_here;
-                        n_fast++;
-                    } else if (n_undo > kUndoCap) {
-                        restart = true;  // cannot roll back: redo this receiver on the exact path only
-                    } else {
-                        // ---------------- roll back, then replay exactly ----------------
-                        wave_lds_fence();
-                        for (int u = lane; u < n_undo; u += kWave) {
-                            const unsigned int e = undo[u];
-                            d.clear_bits((int)(e & 0xFFFFFFu), 1u << (e >> 24));
-                        }
-                        if (newbits) d.clear_bits(dst, newbits);
-                        wave_lds_fence();
-                        replay = true;
-                    }
-                }
-                if (replay && !restart) {
-                    // ---------------- EXACT path: record by record ----------------
-                    n_slow++;
-                    for (int q = 0; q < ncons; ++q) {
-                        const int qdst = __shfl(dst, q, kWave);
-                        const unsigned int qbits = (unsigned)__shfl((int)bits, q, kWave);
-                        const int qflags = __shfl((int)down | ((int)eob << 1), q, kWave);
-                        exact_apply(d, s, pend, qdst, qbits, (qflags & 1) != 0, lane, nullptr, 0, nullptr);
-                        if (qflags & 2) {
-                            exact_batch_end(d, s, pend, lane, &n_applied, &n_full);
-                            if (s.batch_emitted) {  // R/MembershipService.java:333-335
-                                emit_batch = s.batch;
-                                break;
-                            }
-                            s.batch++;
-                        }
-                    }
-                }
                 pos += ncons;
-                pos_off = (pos_off + kRecBytes * ncons) & (kRingBytes - 1);
-            };
+                return true;
+            }
+            if (n_undo > kUndoCap) {
+                restart = true;  // cannot roll back: redo this receiver on the exact path only
+                exact_only = true;
+                n_restart++;
+                return false;
+            }
+            wave_lds_fence();
+            for (int u = lane; u < n_undo; u += kWave) {
+                const unsigned int e = undo[u];
+                d.clear_bits((int)(e & 0xFFFFFFu), 1u << (e >> 24));
+            }
+            if (newbits) d.clear_bits(dst, newbits);
+            wave_lds_fence();
+            return false;
+        };
 
-            // ---- tile pipeline: kPrefetch tiles in flight in registers (static indexing via full unroll);
-            // tile j is copied into the LDS ring once every record that needed the slot it overwrites is consumed
-            uint4 tile[kPrefetch][kTileVec];
-            auto issue = [&](int j, uint4(&t)[kTileVec]) {
-                const unsigned long long g = a0 + (unsigned long long)j * kTileBytes;
-#pragma unroll
-                for (int m = 0; m < kTileVec; ++m) {
-                    const unsigned long long addr = g + 16ull * (unsigned)(lane + kWave * m);
-                    t[m] = (j < ntiles && addr + 16 <= p.records_bytes)
-                               ? *reinterpret_cast<const uint4*>(p.records + addr)
-                               : make_uint4(0, 0, 0, 0);
-                }
-            };
-#pragma unroll
-            for (int q = 0; q < kPrefetch; ++q) issue(q, tile[q]);
-
-            for (int jb = 0; jb < ntiles && emit_batch < 0 && !restart; jb += kPrefetch) {
-#pragma unroll
-                for (int q = 0; q < kPrefetch; ++q) {
-                    const int j = jb + q;
-                    if (j < ntiles && emit_batch < 0 && !restart) {
-                        wave_lds_fence();  // every lane is done decoding from the slot about to be overwritten
-                        uint4* slot = reinterpret_cast<uint4*>(stage + (j % kRingTiles) * kTileBytes);
-#pragma unroll
-                        for (int m = 0; m < kTileVec; ++m) slot[lane + kWave * m] = tile[q][m];
-                        issue(j + kPrefetch, tile[q]);
-                        wave_lds_fence();
-                        // consume every sub-chunk whose records lie entirely in tiles <= j
-                        while (pos < nrec && emit_batch < 0 && !restart &&
-                               (delta + kRecBytes * (pos + min(kWave, nrec - pos)) - 1) / kTileBytes <= j)
-                            process();
+        // ---- EXACT path for the decoded sub-chunk: record by record ----
+        auto exact_subchunk = [&]() {
+            n_slow++;
+            n_records += (unsigned long long)ncons;
+            for (int q = 0; q < ncons; ++q) {
+                const int qdst = lane_value(dst, q);
+                const unsigned int qbits = (unsigned)lane_value((int)bits, q);
+                const int qflags = lane_value((int)down | ((int)eob << 1), q);
+                if (qflags & 1) s.seen_down = true;  // R/MultiNodeCutDetector.java:89-91, hot subject or not
+                exact_apply(d, s, pend, qdst, qbits, (qflags & 1) != 0, lane, nullptr, 0, nullptr);
+                if (qflags & 2) {
+                    exact_batch_end(d, s, pend, lane, &n_applied, &n_full);
+                    if (s.batch_emitted) {  // R/MembershipService.java:333-335
+                        emit_batch = s.batch;
+                        break;
                     }
+                    s.batch++;
                 }
             }
-            if (!restart) break;
-            exact_only = true;
-            n_restart++;
-            wave_lds_fence();
+            pos += ncons;
+        };
+
+        while (emit_batch < 0 && (restart || pos < nrec)) {
+            if (restart) {
+                // ---- detector state: nothing reported yet ----
+                uint4* st = reinterpret_cast<uint4*>(mine);
+                for (int i = lane; i < state_bytes / 16; i += kWave) st[i] = make_uint4(0, 0, 0, 0);
+                s.running = 0;
+                s.npend = 0;
+                s.batch = 0;
+                s.proposal_count = 0;
+                s.seen_down = false;
+                s.need_full = false;
+                s.batch_emitted = false;
+                pend_pairs = 0;
+                pos = 0;
+                restart = false;
+                careful_budget = 0;
+                wave_lds_fence();
+                continue;
+            }
+            const int t_first = (delta + kRecBytes * pos) / kTileBytes;
+            if (exact_only || s.batch_emitted || s.need_full || careful_budget > 0 || (p.flags & 8) != 0) {
+                // ================= CAREFUL loop: one sub-chunk, tiles loaded synchronously =================
+                ring_tile0 = t_first;
+                wave_lds_fence();
+#pragma unroll
+                for (int tt = 0; tt < kRingTiles; ++tt) {
+                    const unsigned long long g = a0 + (unsigned long long)(t_first + tt) * kTileBytes;
+#pragma unroll
+                    for (int m = 0; m < kTileVec; ++m) {
+                        unsigned long long addr = g + 16ull * (unsigned)(lane + kWave * m);
+                        addr = addr < last16 ? addr : last16;
+                        reinterpret_cast<uint4*>(stage + tt * kTileBytes)[lane + kWave * m] =
+                            *reinterpret_cast<const uint4*>(p.records + addr);
+                    }
+                }
+                wave_lds_fence();
+                decode();
+                if (exact_only || s.batch_emitted || !immediate_subchunk()) {
+                    if (!restart) exact_subchunk();
+                }
+                if (careful_budget > 0) --careful_budget;
+                continue;
+            }
+            // ================= PIPELINED loop: two register sets of kPrefetch tiles =================
+            // Set A (the round being consumed) was issued a whole round earlier; set B (the next round) is issued
+            // while A is consumed.  All vector-memory traffic is unconditional and statically indexed, so every wait
+            // is for the OLDEST outstanding tile only and 8-16 KiB per wave stay in flight.  Tiles past the end of
+            // the stream re-read the first tile (L2-resident) and are never decoded.
+            ring_tile0 = t_first;
+            if (s.npend > 0) {  // entrants carried over from the careful loop: re-establish the bound on their pairs
+                int dsum = 0;
+                for (int i0 = 0; i0 < s.npend; i0 += kWave) {
+                    const int i = i0 + lane;
+                    const int e = i < s.npend ? (int)pend[i] : -1;
+                    int dg = (e >= 0 && e < d.n_scan) ? (int)adj_off[e + 1] - (int)adj_off[e] : 0;
+                    for (int o2 = 32; o2 > 0; o2 >>= 1) dg += __shfl_xor(dg, o2, kWave);
+                    dsum += uniform(dg);
+                }
+                pend_pairs = dsum;
+                if (s.running - pend_pairs < 1) {  // the lean invariant does not hold yet: one more careful sub-chunk
+                    careful_budget = 1;
+                    continue;
+                }
+            } else {
+                pend_pairs = 0;
+            }
+            uint4 a0_, a1_, a2_, a3_, a4_, a5_, a6_, a7_, b0_, b1_, b2_, b3_, b4_, b5_, b6_, b7_;
+#define RAPID_LOAD(jrel, x0, x1)                                                                                \
+    {                                                                                                           \
+        const int jabs_ = t_first + (jrel);                                                                     \
+        const unsigned long long g_ = a0 + (unsigned long long)(jabs_ < ntiles ? jabs_ : t_first) * kTileBytes; \
+        unsigned long long addr0_ = g_ + 16ull * (unsigned)lane;                                               \
+        unsigned long long addr1_ = addr0_ + 1024ull;                                                           \
+        addr0_ = addr0_ < last16 ? addr0_ : last16;                                                             \
+        addr1_ = addr1_ < last16 ? addr1_ : last16;                                                             \
+        x0 = *reinterpret_cast<const uint4*>(p.records + addr0_);                                               \
+        x1 = *reinterpret_cast<const uint4*>(p.records + addr1_);                                               \
+    }
+#define RAPID_STEP(q, x0, x1)                                                                              \
+    {                                                                                                      \
+        const int jrel_ = jb + (q);                                                                        \
+        wave_lds_fence(); /* every lane is done decoding from the slot about to be overwritten */         \
+        uint4* slot_ = reinterpret_cast<uint4*>(stage + ((q) % kRingTiles) * kTileBytes);                  \
+        slot_[lane] = x0;                                                                                  \
+        slot_[lane + kWave] = x1;                                                                          \
+        if (((q) % kRingTiles) == 0) { /* mirror the head of slot 0 behind the ring */                     \
+            slot_[lane + kRingBytes / 16] = x0;                                                            \
+            if (lane < (kMirrorBytes - 1024) / 16) slot_[lane + kWave + kRingBytes / 16] = x1;             \
+        }                                                                                                  \
+        wave_lds_fence();                                                                                  \
+        /* consume every sub-chunk whose records lie entirely in stream tiles <= t_first + jrel_ */        \
+        const int lim_ = min(nrec, ((t_first + jrel_ + 1) * kTileBytes - delta) / kRecBytes);              \
+        while (!stop && pos < nrec && min(pos + kWave, nrec) <= lim_) {                                    \
+            if (!lean_subchunk()) stop = true;                                                             \
+        }                                                                                                  \
+    }
+            static_assert(kPrefetch == 4 && kTileVec == 2 && kRingTiles == 2, "tile pipeline is written for 4 x 2 KiB");
+            static_assert(kMirrorBytes > 1024 && kMirrorBytes <= 2048, "mirror = one full + one partial 16-B store");
+            RAPID_LOAD(0, a0_, a1_)
+            RAPID_LOAD(1, a2_, a3_)
+            RAPID_LOAD(2, a4_, a5_)
+            RAPID_LOAD(3, a6_, a7_)
+            RAPID_LOAD(4, b0_, b1_)
+            RAPID_LOAD(5, b2_, b3_)
+            RAPID_LOAD(6, b4_, b5_)
+            RAPID_LOAD(7, b6_, b7_)
+            bool stop = false;
+            const int pos_in = pos;
+            n_fast32 = 0;
+            const int jend = ((ntiles - t_first + kPrefetch - 1) / kPrefetch) * kPrefetch;
+            for (int jb = 0; jb < jend; jb += kPrefetch) {
+                RAPID_STEP(0, a0_, a1_)
+                RAPID_STEP(1, a2_, a3_)
+                RAPID_STEP(2, a4_, a5_)
+                RAPID_STEP(3, a6_, a7_)
+                flush_pending();  // once per round: the deferred implicit invalidation (cannot emit, see above)
+                if (stop) break;
+                a0_ = b0_; a1_ = b1_; a2_ = b2_; a3_ = b3_; a4_ = b4_; a5_ = b5_; a6_ = b6_; a7_ = b7_;
+                RAPID_LOAD(jb + 8, b0_, b1_)
+                RAPID_LOAD(jb + 9, b2_, b3_)
+                RAPID_LOAD(jb + 10, b4_, b5_)
+                RAPID_LOAD(jb + 11, b6_, b7_)
+            }
+#undef RAPID_STEP
+#undef RAPID_LOAD
+            n_fast += (unsigned long long)n_fast32;
+            n_records += (unsigned long long)(pos - pos_in);
+            if (stop) {
+                // the lean path could not exclude an emission: take the next sub-chunks through the careful loop,
+                // for longer and longer if the pipelined loop keeps giving up immediately
+                careful_next = (pos - pos_in < 4 * kWave) ? min(careful_next * 2, 64) : 2;
+                careful_budget = careful_next;
+            }
         }
 
         // ---- outputs: the proposal = every flushed (hot) slot, ascending node index ----
@@ -642,8 +823,8 @@ __global__ __launch_bounds__(64) void cd_instance_kernel(CdParams p) {
     if (p.mode == 0) {
         for (int a = 0; a < p.n_alerts; ++a) {
             const unsigned int* w = reinterpret_cast<const unsigned int*>(p.alerts + (long long)a * kRecBytes);
-            const int dst = (int)w[3];
-            const unsigned int w4 = w[4];
+            const int dst = uniform((int)w[3]);
+            const unsigned int w4 = uniform(w[4]);
             const int before = total;
             if ((unsigned)dst < (unsigned)p.n_nodes)
                 exact_apply(d, s, nullptr, dst, w4 & d.kmask, ((w4 >> 16) & 0xFFu) != 0, lane, p.out_idx, p.out_cap,

@@ -86,11 +86,15 @@ void run_block(unsigned block, unsigned grid, unsigned nthreads, const std::func
                 std::abort();
             }
             if (op == OP_BLOCK_SYNC) continue;  // handled below
+            int first = -1;
+            for (int l = 0; l < W && first < 0; ++l)
+                if (!w.done[wv * W + l]) first = wv * W + l;
             for (int l = 0; l < W; ++l) {
                 const int t = wv * W + l;
                 if (w.done[t]) continue;
                 if (op == OP_BALLOT) w.res[t] = ballot;
                 else if (op == OP_SHFL) { const int src = wv * W + (int)w.aux[t]; w.res[t] = w.done[src] ? 0 : w.arg[src]; }
+                else if (op == OP_FIRST) w.res[t] = w.arg[first];
                 else w.res[t] = 0;
                 runnable[t] = 1;
             }
@@ -130,11 +134,11 @@ int emu_tally_shared_bytes(int n_nodes, int n_hot, int n_adj) { return rapid::ta
 // Runs the population kernel: `grid` persistent workgroups of `waves` waves, one workgroup at a time.
 int emu_tally_run(const unsigned char* records, unsigned long long records_bytes, const long long* rec_off,
                   int n_receivers, int n_nodes, int K, int H, int L, long long cfg_id, const unsigned short* dict,
-                  const int* node_of_slot, const unsigned short* state_tpl, const unsigned short* adj_off,
-                  const unsigned int* adj, int n_slots, int n_hot, int n_adj, int* emit_batch, int* num_proposals,
+                  const int* node_of_slot, const unsigned short* adj_off,
+                  const unsigned int* adj, int n_hot, int n_adj, int* emit_batch, int* num_proposals,
                   int* prop_count, unsigned long long* fingerprint, int* props, int prop_cap, unsigned long long* stats,
                   int flags, int waves, int grid, int tables_in_lds, unsigned long long seed) {
-    const int lds = (tables_in_lds ? rapid::tally_shared_bytes(n_nodes, n_hot, n_adj) : 0) + waves * rapid::tally_wave_bytes(n_slots);
+    const int lds = (tables_in_lds ? rapid::tally_shared_bytes(n_nodes, n_hot, n_adj) : 0) + waves * rapid::tally_wave_bytes(n_hot);
     if (lds > (int)sizeof(smem)) return -5;
     rapid::TallyParams p;
     p.records = records;
@@ -148,10 +152,8 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     p.cfg_id = cfg_id;
     p.idx.dict = dict;
     p.idx.node_of_slot = node_of_slot;
-    p.idx.state_tpl = state_tpl;
     p.idx.adj_off = adj_off;
     p.idx.adj = adj;
-    p.idx.n_slots = n_slots;
     p.idx.n_hot = n_hot;
     p.idx.n_adj = n_adj;
     p.emit_batch = emit_batch;

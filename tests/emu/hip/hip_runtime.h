@@ -50,7 +50,7 @@ struct Block {
 };
 extern Block* g_block;
 extern Dim g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
-enum { OP_NONE = 0, OP_BALLOT = 1, OP_SHFL = 2, OP_WAVE_SYNC = 3, OP_BLOCK_SYNC = 4 };
+enum { OP_NONE = 0, OP_BALLOT = 1, OP_SHFL = 2, OP_WAVE_SYNC = 3, OP_BLOCK_SYNC = 4, OP_FIRST = 5 };
 
 inline uint64_t park(int op, uint64_t a, uint64_t b) {
     Block* w = g_block;
@@ -79,6 +79,9 @@ inline int __shfl_xor(int v, int m, int = 64) {
 inline unsigned __shfl_xor(unsigned v, int m, int = 64) {
     return (unsigned)emu::park(emu::OP_SHFL, v, (unsigned)(emu::cur_lane() ^ m) & 63u);
 }
+// readlane / readfirstlane: uniform reads (all live lanes of a wave execute them together)
+inline int __builtin_amdgcn_readlane(int v, int src) { return (int)(uint32_t)emu::park(emu::OP_SHFL, (uint32_t)v, (unsigned)src & 63u); }
+inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)emu::park(emu::OP_FIRST, (uint32_t)v, 0); }
 inline void __syncthreads() { (void)emu::park(emu::OP_BLOCK_SYNC, 0, 0); }
 // wave-local LDS ordering point of the kernels (compiler-only on the device): a rendezvous here, so that the
 // emulator keeps shuffling the lane order around every point where lanes exchange data through LDS

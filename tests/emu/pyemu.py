@@ -27,14 +27,12 @@ def build_round_index(records, n_nodes, K, L, obs, member):
     ok = recs["dst"] < n_nodes
     np.bitwise_or.at(gmask, recs["dst"][ok].astype(np.int64), recs["ring_mask"][ok].astype(np.int64) & kmask)
     pop = np.array([bin(int(x)).count("1") for x in gmask])
-    hot_nodes = np.flatnonzero((gmask != 0) & (pop >= L))
-    cold_nodes = np.flatnonzero((gmask != 0) & (pop < L))
-    node_of_slot = np.concatenate([hot_nodes, cold_nodes]).astype(np.int32)
-    n_hot, n_slots = len(hot_nodes), len(node_of_slot)
-    dict_ = np.full(n_nodes, 0xFFFF, dtype=np.uint16)
-    dict_[node_of_slot] = np.arange(n_slots, dtype=np.uint16)
-    tpl = np.zeros(((n_slots + 7) // 8) * 8 + 8, dtype=np.uint16)
-    tpl[:n_slots] = np.where(np.asarray(member)[node_of_slot] != 0, 0x8000, 0)
+    hot_nodes = np.flatnonzero(pop >= L)
+    node_of_slot = hot_nodes.astype(np.int32)
+    n_hot = len(hot_nodes)
+    assert n_hot <= 16382
+    slot_of = np.full(n_nodes, 0x3FFF, dtype=np.int64)
+    slot_of[node_of_slot] = np.arange(n_hot)
     lists = [[] for _ in range(n_hot)]
     for e in range(n_hot):
         s_node = int(node_of_slot[e])
@@ -42,7 +40,7 @@ def build_round_index(records, n_nodes, K, L, obs, member):
             o = int(obs[s_node, k])
             if o < 0:
                 continue
-            eo = int(dict_[o])
+            eo = int(slot_of[o])
             if eo >= n_hot:
                 continue
             lists[e].append(eo | (k << 16))
@@ -50,8 +48,13 @@ def build_round_index(records, n_nodes, K, L, obs, member):
     adj_off = np.zeros(n_hot + 1, dtype=np.uint16)
     adj_off[1:] = np.cumsum([len(x) for x in lists])
     adj = np.array([x for l in lists for x in l] + [0], dtype=np.uint32)
-    return dict(dict=dict_, node_of_slot=np.concatenate([node_of_slot, [0]]).astype(np.int32), tpl=tpl, adj_off=adj_off,
-                adj=adj, n_slots=n_slots, n_hot=n_hot, n_adj=int(adj_off[-1]))
+    dict_ = slot_of | np.where(np.asarray(member) != 0, 0x8000, 0)
+    for e in range(n_hot):
+        if lists[e]:
+            dict_[node_of_slot[e]] |= 0x4000
+    dict_ = dict_.astype(np.uint16)
+    return dict(dict=dict_, node_of_slot=np.concatenate([node_of_slot, [0]]).astype(np.int32), adj_off=adj_off,
+                adj=adj, n_hot=n_hot, n_adj=int(adj_off[-1]))
 
 
 def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_cap=None, force_exact=0, seed=1, waves=3,
@@ -72,7 +75,7 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     stats = np.zeros(8, dtype=np.uint64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     rc = L_.emu_tally_run(p(raw), C.c_ulonglong((raw.nbytes // 16) * 16), p(rec_off), R, n_nodes, K, H, L, C.c_longlong(cfg_id),
-                          p(ix["dict"]), p(ix["node_of_slot"]), p(ix["tpl"]), p(ix["adj_off"]), p(ix["adj"]), ix["n_slots"],
+                          p(ix["dict"]), p(ix["node_of_slot"]), p(ix["adj_off"]), p(ix["adj"]),
                           ix["n_hot"], ix["n_adj"], p(emit), p(nprop), p(pcount), p(fp), p(props), prop_cap, p(stats),
                           force_exact, waves, grid, tables_in_lds, C.c_ulonglong(seed))
     assert rc == 0, rc
