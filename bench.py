@@ -84,6 +84,7 @@ def main():
     records, rec_off, nb = S.deliver(sc.batches, my_rx, seed_delivery=2)
     sim = E.ClusterSimulation(eng)
     sim.load_streams(records, rec_off)  # streams are resident in HBM before anything is timed
+    sim.set_alert_set(sc.batches.recs)   # the round's distinct alerts (the receivers' streams are copies of these)
     setup_s = time.time() - t0
     my_batches = int(nb.sum())
     my_records = int(len(records))

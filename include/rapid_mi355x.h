@@ -138,6 +138,12 @@ int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, c
  * must extend at least 16 bytes past the last record); d_rec_off is a device pointer to n_receivers+1 int64 */
 int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64_t records_bytes,
                                   const int64_t* d_rec_off, int32_t n_receivers);
+/* Optional, after a load: declares the round's DISTINCT alerts (every delivered record is a byte-identical copy of
+ * one of them, flags aside -- one AlertMessage is broadcast to all receivers, R/UnicastToAllBroadcaster.java:46-52).
+ * The per-round index (which subjects can reach the L watermark at all, their adjacency) and the one-time validation
+ * of the alerts against the current view are then computed from these n_alerts records instead of from a pass over
+ * every delivered record.  Without it the library scans the delivered streams. */
+int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, int64_t n_alerts);
 /* alert-tally kernel over all loaded receivers (asynchronous on the engine's stream) */
 int rapid_sim_tally(rapid_engine* h);
 /* per-receiver results of the last tally: index of the batch whose processing announced a proposal (-1 if
@@ -194,6 +200,9 @@ int rapid_engine_sync(rapid_engine* h);
 int rapid_sim_stats(rapid_engine* h, uint64_t stats[8]);
 /* average duration (ms) of the tally kernel over `reps` back-to-back launches, HIP events on the engine stream */
 int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg);
+/* measurement probe (not a product path): stream the loaded records with the tally kernel's access pattern and no
+ * processing.  variant 0: 2 KiB tiles x 8 in flight, 1: 4 KiB x 4, 2: 8 KiB x 2, 3: 2 KiB x 4; waves per block */
+int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, int32_t reps, float* ms_avg);
 /* testing knob: run every sub-chunk through the exact sequential path (0 = normal) */
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);
 

@@ -119,6 +119,7 @@ def _signatures():
         "rapid_cd_clear": (i32, [vp]),
         "rapid_sim_load_streams": (i32, [vp, p, p, i32]),
         "rapid_sim_load_streams_device": (i32, [vp, p, u64, p, i32]),
+        "rapid_sim_set_alert_set": (i32, [vp, p, i64]),
         "rapid_sim_tally": (i32, [vp]),
         "rapid_sim_results": (i32, [vp, p, p, p, p, i32]),
         "rapid_sim_proposal": (i32, [vp, i32, p, i32, pi32]),
@@ -137,6 +138,7 @@ def _signatures():
         "rapid_sim_stats": (i32, [vp, p]),
         "rapid_sim_time_tally": (i32, [vp, i32, C.POINTER(C.c_float)]),
         "rapid_sim_set_force_exact": (i32, [vp, i32]),
+        "rapid_debug_stream_probe": (i32, [vp, i32, i32, i32, C.POINTER(C.c_float)]),
     }
 
 

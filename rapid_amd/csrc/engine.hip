@@ -106,6 +106,9 @@ struct rapid_engine {
     // ---- per-round index over the loaded streams (index_kernels.h) ----
     bool index_valid = false;
     long long n_records_total = 0;
+    DevBuf<unsigned char> d_alert_set;  // the round's distinct alerts, if the host declared them
+    long long n_alert_set = -1;
+    bool trusted = false, all_down = false;
     DevBuf<unsigned int> d_gmask, d_adj;
     DevBuf<unsigned short> d_dict, d_adj_off;
     DevBuf<int> d_node_of_slot, d_deg, d_cursor, d_info;
@@ -312,9 +315,12 @@ int build_round_index(rapid_engine* h) {
     HIPCHK(h, hipMemsetAsync(h->d_deg.p, 0, sizeof(int) * (size_t)N, st));
     HIPCHK(h, hipMemsetAsync(h->d_cursor.p, 0, sizeof(int) * (size_t)N, st));
     HIPCHK(h, hipMemsetAsync(h->d_info.p, 0, sizeof(int) * 8, st));
-    if (h->n_records_total > 0)
-        hipLaunchKernelGGL(rapid::index_touch_kernel, dim3(h->num_cus * 8), dim3(256), 0, st, h->d_records, h->n_records_total, N,
-                           (1u << K) - 1u, h->d_gmask.p);
+    const unsigned char* scan = h->n_alert_set >= 0 ? h->d_alert_set.p : h->d_records;
+    const long long n_scan = h->n_alert_set >= 0 ? h->n_alert_set : h->n_records_total;
+    if (n_scan > 0)
+        hipLaunchKernelGGL(rapid::index_touch_kernel, dim3((unsigned)std::min<long long>(h->num_cus * 8, (n_scan + 255) / 256)),
+                           dim3(256), 0, st, scan, n_scan, N, (1u << K) - 1u, (long long)h->config_id, h->d_member.p, h->d_gmask.p,
+                           reinterpret_cast<unsigned int*>(h->d_info.p + 4));
     hipLaunchKernelGGL(rapid::index_slots_kernel, dim3(1), dim3(1024), 0, st, h->d_gmask.p, h->d_member.p, N, L, h->d_dict.p,
                        h->d_node_of_slot.p, h->d_info.p);
     int info[8] = {0};
@@ -322,6 +328,8 @@ int build_round_index(rapid_engine* h) {
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
     if (info[2] & 1) return fail(h, RAPID_ECAPACITY, "the round has %d hot subjects; at most 16382 are supported", info[0]);
+    h->trusted = (info[4] & 1) == 0;
+    h->all_down = (info[4] & 2) == 0;
     h->n_slots = info[0];
     h->n_hot = info[1];
     h->n_adj = 0;
@@ -403,13 +411,18 @@ int launch_tally(rapid_engine* h) {
     p.stats = h->d_stats.p;
     p.next_receiver = h->d_next.p;
     p.waves_per_block = h->waves_per_block;
-    p.flags = h->force_exact;
+    p.flags = h->force_exact & 9;
     HIPCHK(h, hipMemsetAsync(h->d_next.p, 0, sizeof(unsigned int), h->stream));
     const dim3 grid((unsigned)h->grid_blocks), block((unsigned)h->waves_per_block * 64u);
-    if (h->tables_in_lds)
-        hipLaunchKernelGGL(rapid::tally_population_kernel<true>, grid, block, (size_t)h->lds_bytes, h->stream, p);
+    const bool trusted = h->trusted && (h->force_exact & 64) == 0;  // bit6 of the testing knob: never trust
+    if (h->tables_in_lds && trusted)
+        hipLaunchKernelGGL((rapid::tally_population_kernel<true, true>), grid, block, (size_t)h->lds_bytes, h->stream, p);
+    else if (h->tables_in_lds)
+        hipLaunchKernelGGL((rapid::tally_population_kernel<true, false>), grid, block, (size_t)h->lds_bytes, h->stream, p);
+    else if (trusted)
+        hipLaunchKernelGGL((rapid::tally_population_kernel<false, true>), grid, block, (size_t)h->lds_bytes, h->stream, p);
     else
-        hipLaunchKernelGGL(rapid::tally_population_kernel<false>, grid, block, (size_t)h->lds_bytes, h->stream, p);
+        hipLaunchKernelGGL((rapid::tally_population_kernel<false, false>), grid, block, (size_t)h->lds_bytes, h->stream, p);
     return RAPID_OK;
 }
 
@@ -420,9 +433,13 @@ int prepare_tally(rapid_engine* h) {
         int rc = build_round_index(h);
         if (rc) return rc;
     }
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel<true>),
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel<true, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel<false>),
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel<true, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel<false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel<false, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const size_t R = (size_t)std::max(h->n_receivers, 1);
     HIPCHK(h, h->d_emit.ensure(R));
@@ -487,7 +504,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
     h->d_records_own.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
-    h->d_next.release(); h->d_gmask.release(); h->d_adj.release(); h->d_dict.release();
+    h->d_alert_set.release(); h->d_next.release(); h->d_gmask.release(); h->d_adj.release(); h->d_dict.release();
     h->d_adj_off.release(); h->d_node_of_slot.release(); h->d_deg.release(); h->d_cursor.release(); h->d_info.release();
     h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release();
     delete h;
@@ -801,6 +818,7 @@ int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, c
     h->d_rec_off = h->d_rec_off_own.p;
     h->n_receivers = n_receivers;
     h->n_records_total = n_rec;
+    h->n_alert_set = -1;
     h->index_valid = false;
     h->streams_loaded = true;
     h->tallied = false;
@@ -823,10 +841,25 @@ int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64
     h->d_rec_off = reinterpret_cast<const long long*>(d_rec_off);
     h->n_receivers = n_receivers;
     h->n_records_total = n_rec;
+    h->n_alert_set = -1;
     h->index_valid = false;
     h->streams_loaded = true;
     h->tallied = false;
     h->have_decision = false;
+    return RAPID_OK;
+}
+
+int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, int64_t n_alerts) {
+    if (!h || n_alerts < 0 || (n_alerts > 0 && !alerts)) return RAPID_EINVAL;
+    if (!h->streams_loaded) return fail(h, RAPID_ESTATE, "load the streams first");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, h->d_alert_set.ensure((size_t)std::max<int64_t>(n_alerts, 1) * 20 + 16));
+    if (n_alerts)
+        HIPCHK(h, hipMemcpyAsync(h->d_alert_set.p, alerts, (size_t)n_alerts * 20, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->n_alert_set = n_alerts;
+    h->index_valid = false;
     return RAPID_OK;
 }
 
@@ -1147,6 +1180,41 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg) {
     (void)hipEventDestroy(e1);
     *ms_avg = ms / (float)reps;
     h->tallied = true;
+    return RAPID_OK;
+}
+
+// Measurement probe: streams the loaded records with the tally kernel's access pattern and no processing.
+// variant: 0 = 2 KiB tiles x 8 in flight, 1 = 4 KiB x 4, 2 = 8 KiB x 2, 3 = 2 KiB x 4; waves = waves per block.
+int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, int32_t reps, float* ms_avg) {
+    if (!h || reps <= 0 || !ms_avg || waves <= 0 || waves > 16) return RAPID_EINVAL;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->streams_loaded || h->n_receivers == 0) return fail(h, RAPID_ESTATE, "no alert streams loaded");
+    HIPCHK(h, h->d_next.ensure(4));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    const dim3 grid((unsigned)h->num_cus * (unsigned)std::max(1, 16 / waves)), block((unsigned)waves * 64u);
+    auto launch = [&]() {
+        (void)hipMemsetAsync(h->d_next.p, 0, 4, h->stream);
+        switch (variant) {
+            case 0: hipLaunchKernelGGL((rapid::stream_probe_kernel<2, 8>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
+            case 1: hipLaunchKernelGGL((rapid::stream_probe_kernel<4, 4>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
+            case 2: hipLaunchKernelGGL((rapid::stream_probe_kernel<8, 2>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
+            default: hipLaunchKernelGGL((rapid::stream_probe_kernel<2, 4>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
+        }
+    };
+    launch();
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    for (int i = 0; i < reps; ++i) launch();
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipEventSynchronize(e1));
+    HIPCHK(h, hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_avg = ms / (float)reps;
     return RAPID_OK;
 }
 

@@ -13,17 +13,28 @@
 
 namespace rapid {
 
-// gmask[dst] |= ring_mask over every record of every receiver.  After the first few thousand records nearly every
-// bit is already set, so the (possibly stale, L1-cached) pre-test avoids almost all atomics.
+// gmask[dst] |= ring_mask over every record given (the round's distinct alert set if the host declared one, else
+// every delivered record).  After the first few thousand records nearly every bit is already set, so the (possibly
+// stale, L1-cached) pre-test avoids almost all atomics.  Also validates the records once: vflags bit0 is set if ANY
+// record fails the filter of R/MembershipService.java:644-675 under the current view (or names a node out of range
+// or no ring), bit1 if any record is an UP alert.
 __global__ void index_touch_kernel(const unsigned char* records, long long n_records, int n_nodes, unsigned int kmask,
-                                   unsigned int* gmask) {
+                                   long long cfg_id, const unsigned char* member, unsigned int* gmask,
+                                   unsigned int* vflags) {
     const long long stride = (long long)gridDim.x * blockDim.x;
+    const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
+    unsigned int f = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
         const unsigned int* w = reinterpret_cast<const unsigned int*>(records + i * 20);
         const unsigned int dst = w[3];
         const unsigned int bits = w[4] & kmask;
+        const bool down = (w[4] & 0x00FF0000u) != 0u;
         if (dst < (unsigned)n_nodes && bits != 0u && (bits & ~gmask[dst]) != 0u) atomicOr(&gmask[dst], bits);
+        const bool ok = w[0] == cfg_lo && w[1] == cfg_hi && dst < (unsigned)n_nodes && bits != 0u &&
+                        ((member[dst < (unsigned)n_nodes ? dst : 0u] != 0) == down);
+        f |= (ok ? 0u : 1u) | (down ? 0u : 2u);
     }
+    if (f) atomicOr(vflags, f);
 }
 
 // One block.  Slot numbering: the hot subjects (>= L distinct rings named by the round's alert set), ascending by

@@ -85,7 +85,7 @@ struct TallyParams {
     unsigned long long* stats;        // [8]
     unsigned int* next_receiver;      // work counter (zeroed before every launch)
     int waves_per_block;
-    int flags;                        // bit0: exact path only, bit3: careful loop only (tests); bits 1-2: ablations
+    int flags;                        // bit0: exact path only, bit3: careful loop only (both for tests)
 };
 
 __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
@@ -94,7 +94,7 @@ __host__ __device__ inline int tally_shared_bytes(int n_nodes, int n_hot, int n_
     return align16(n_nodes * 2) + align16((n_hot + 1) * 2) + align16(n_adj * 4);
 }
 __host__ __device__ inline int tally_wave_bytes(int n_slots) {
-    return align16(n_slots * 2) + kRingBytes + kMirrorBytes + align16(kPendCap * 2) + kUndoCap * 4;
+    return align16(n_slots * 4) + kRingBytes + kMirrorBytes + align16(kPendCap * 2) + kUndoCap * 4;
 }
 
 // ---- small wave helpers ---------------------------------------------------------------------------------------
@@ -106,6 +106,8 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ unsigned long long lanes_lt(int lane) { return (1ull << lane) - 1ull; }
+// lane mask of a per-lane predicate, straight from the compare (no bool -> int -> compare round trip)
+__device__ __forceinline__ unsigned long long wave_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 // Values that are the same in every lane are kept provably uniform (SGPRs, scalar branches): everything derived
 // from them -- loop bounds, the detector's counters -- then costs scalar instead of exec-masked vector code.
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -129,23 +131,17 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // 
 // ---- detector state accessors ---------------------------------------------------------------------------------
 // LDS flavour (population kernel): indices are slots; sweeps cover the hot slots only.
 struct SlotDetector {
-    unsigned short* st16;
-    unsigned int* st32;
+    unsigned int* st;  // one 32-bit word per hot slot (low 16 bits used): plain ds_or_rtn_b32, no sub-word shuffling
     const unsigned short* adj_off;
     const unsigned int* adj;
     int n_scan;  // = n_hot
     int H, L;
     unsigned int kmask;
-    __device__ __forceinline__ unsigned int load(int i) const { return st16[i]; }
-    __device__ __forceinline__ void store(int i, unsigned int v) const { st16[i] = (unsigned short)v; }
+    __device__ __forceinline__ unsigned int load(int i) const { return st[i]; }
+    __device__ __forceinline__ void store(int i, unsigned int v) const { st[i] = v; }
     __device__ __forceinline__ int count(unsigned int m) const { return __popc(m & kmask); }
-    __device__ __forceinline__ unsigned int or_bits(int i, unsigned int bits) const {
-        const int sh = (i & 1) * 16;
-        return (atomicOr(&st32[i >> 1], bits << sh) >> sh) & 0xFFFFu;
-    }
-    __device__ __forceinline__ void clear_bits(int i, unsigned int bits) const {
-        atomicAnd(&st32[i >> 1], ~(bits << ((i & 1) * 16)));
-    }
+    __device__ __forceinline__ unsigned int or_bits(int i, unsigned int bits) const { return atomicOr(&st[i], bits); }
+    __device__ __forceinline__ void clear_bits(int i, unsigned int bits) const { atomicAnd(&st[i], ~bits); }
     __device__ __forceinline__ void sync() const { wave_lds_fence(); }
 };
 
@@ -195,7 +191,7 @@ __device__ inline void flush_sweep(const D& d, int lane, int* out, int out_cap, 
         const bool take = i < d.n_scan && d.count(m) >= d.H && !(m & kFlushed);
         if (take) d.store(i, m | kFlushed);
         if (out_n != nullptr) {
-            const unsigned long long mk = __ballot(take);
+            const unsigned long long mk = wave_ballot(take);
             const int idx = *out_n + __popcll(mk & lanes_lt(lane));
             if (take && out != nullptr && idx < out_cap) out[idx] = i;
             *out_n += __popcll(mk);
@@ -264,7 +260,7 @@ __device__ inline int invalidate_adj(const SlotDetector& d, const unsigned short
         act = act && e < d.n_scan;
         int a = act ? (int)d.adj_off[e] : 0;
         const int end = act ? (int)d.adj_off[e + 1] : 0;
-        while (__ballot(a < end) != 0ull) {
+        while (wave_ballot(a < end) != 0ull) {
             const bool on = a < end;
             const unsigned int ent = on ? d.adj[a] : 0u;
             const int other = (int)(ent & 0xFFFFu);
@@ -280,8 +276,8 @@ __device__ inline int invalidate_adj(const SlotDetector& d, const unsigned short
             if (apply) old = d.or_bits(sj, 1u << k);
             const bool isnew = apply && !(old & (1u << k));
             const bool crossH = isnew && d.count(old) == d.H - 1;
-            nH += __popcll(__ballot(crossH));
-            const unsigned long long mnew = __ballot(isnew);
+            nH += __popcll(wave_ballot(crossH));
+            const unsigned long long mnew = wave_ballot(isnew);
             if (undo != nullptr) {
                 const int idx = *n_undo + __popcll(mnew & lanes_lt(lane));
                 if (isnew && idx < kUndoCap) undo[idx] = (unsigned)sj | ((unsigned)k << 24);
@@ -304,7 +300,7 @@ __device__ inline int invalidate_table(const TableDetector& d, int lane) {
         const unsigned int m = n < d.n_scan ? d.load(n) : 0u;
         const int c = d.count(m);
         const bool inpre = n < d.n_scan && c >= d.L && c < d.H;
-        if (__ballot(inpre) == 0ull) continue;
+        if (wave_ballot(inpre) == 0ull) continue;
         for (int k = 0; k < d.K; ++k) {
             const int o = inpre ? d.obs[n * d.K + k] : -1;
             const unsigned int mo = o >= 0 ? d.load(o) : 0u;
@@ -313,7 +309,7 @@ __device__ inline int invalidate_table(const TableDetector& d, int lane) {
             if (apply) old = d.or_bits(n, 1u << k);
             const bool isnew = apply && !(old & (1u << k));
             const bool crossH = isnew && d.count(old) == d.H - 1;
-            nH += __popcll(__ballot(crossH));
+            nH += __popcll(wave_ballot(crossH));
         }
         d.sync();
     }
@@ -341,7 +337,10 @@ __device__ inline void exact_batch_end(const SlotDetector& d, RxScalars& s, cons
 // kTablesInLds: dictionary + adjacency are staged in LDS once per workgroup (the normal case); otherwise they
 // are read from global memory (populations whose dictionary does not fit next to the per-wave state).
 // --------------------------------------------------------------------------------------------------------------
-template <bool kTablesInLds>
+// kTrusted: the engine has verified once, on the round's distinct alert set, that EVERY alert passes the filter of
+// R/MembershipService.java:644-675 under the current view (configuration id, UP/DOWN vs membership, node range,
+// non-empty ring list); the pipelined loop then skips the per-delivery re-check (the careful loop never does).
+template <bool kTablesInLds, bool kTrusted>
 __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kernel(TallyParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = (int)(threadIdx.x & 63u);
@@ -368,7 +367,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     __syncthreads();
 
     // ---- this wave's private LDS ----
-    const int state_bytes = align16(p.idx.n_hot * 2);
+    const int state_bytes = align16(p.idx.n_hot * 4);
     unsigned char* const mine = smem + shared_bytes + wave * tally_wave_bytes(p.idx.n_hot);
     unsigned char* const stage = mine + state_bytes;
     unsigned short* const pend = reinterpret_cast<unsigned short*>(stage + kRingBytes + kMirrorBytes);
@@ -376,8 +375,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     const unsigned int* const ring32 = reinterpret_cast<const unsigned int*>(stage);
 
     SlotDetector d;
-    d.st16 = reinterpret_cast<unsigned short*>(mine);
-    d.st32 = reinterpret_cast<unsigned int*>(mine);
+    d.st = reinterpret_cast<unsigned int*>(mine);
     d.adj_off = adj_off;
     d.adj = adj;
     d.n_scan = p.idx.n_hot;
@@ -387,10 +385,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 
     const unsigned int cfg_lo = (unsigned int)(unsigned long long)p.cfg_id;
     const unsigned int cfg_hi = (unsigned int)((unsigned long long)p.cfg_id >> 32);
-    const bool abl_noinv = (p.flags & 2) != 0;  // profiling ablations (results invalid)
-    const bool abl_noapply = (p.flags & 4) != 0;
     unsigned long long n_slow = 0, n_fast = 0, n_restart = 0, n_records = 0;
-    int n_applied = 0, n_full = 0, n_fast32 = 0;
+    int n_applied = 0, n_full = 0;
     const int lane20 = lane * kRecBytes;
 
     for (;;) {
@@ -432,7 +428,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             eob = lane < navail && ((((w4 >> 24) & 1u) != 0) || pos + lane == nrec - 1);
             // a sub-chunk ends at its last batch end (if it has one): no record is applied before the batch end
             // that precedes it has been processed
-            mE_all = __ballot(eob);
+            mE_all = wave_ballot(eob);
             lastE = mE_all ? 63 - __clzll((long long)mE_all) : -1;
             ncons = lastE >= 0 ? lastE + 1 : navail;
             const bool valid = lane < ncons;
@@ -467,67 +463,75 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // running - pend_pairs - (H crossings here) >= 1.  Returns false -- with the sub-chunk rolled back and
         // nothing consumed -- when that cannot be shown.  Written with lane MASKS (scalar registers) rather than
         // per-lane booleans: predicates cost one v_cmp each and combine with scalar ANDs.
-        auto lean_subchunk = [&]() -> bool {
+        auto lean_subchunk = [&]() -> int {
             const int navail = min(kWave, nrec - pos);
             const int base = (delta + kRecBytes * pos - ring_tile0 * kTileBytes) & (kRingBytes - 1);
             const unsigned int* w = ring32 + ((base + lane20) >> 2);
-            const unsigned int w0 = w[0], w1 = w[1], w3 = w[3], w4 = w[4];
-            const unsigned long long m_in = navail == kWave ? ~0ull : ((1ull << navail) - 1ull);
-            const unsigned long long m_last = (pos + navail == nrec) ? (1ull << (navail - 1)) : 0ull;
-            const unsigned long long mE = (__ballot((w4 & 0x01000000u) != 0u) | m_last) & m_in;
+            const unsigned int w3 = w[3], w4 = w[4];
+            // batch ends among the available records (the last record of the stream always closes a batch)
+            const unsigned long long mE =
+                wave_ballot((lane < navail) & (((w4 & 0x01000000u) != 0u) | (pos + lane == nrec - 1)));
             // consume up to the last batch end; a batch longer than a sub-chunk (mE == 0) is left to the careful loop
             // through the common roll-back exit below, which keeps this code straight-line
             const int nc = mE != 0ull ? kWave - __clzll((long long)mE) : navail;
-            const unsigned long long m_valid = nc == kWave ? ~0ull : ((1ull << nc) - 1ull);
-            // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot
-            const unsigned int node = w3 < (unsigned)p.n_nodes ? w3 : 0u;
-            const unsigned int de = (unsigned int)dict[node];
             const unsigned int rb = w4 & d.kmask;
-            const unsigned long long m_down = __ballot((w4 & 0x00FF0000u) != 0u);
-            const unsigned long long m_ok = m_valid & __ballot(w0 == cfg_lo) & __ballot(w1 == cfg_hi) &
-                                            __ballot(w3 < (unsigned)p.n_nodes) & __ballot(rb != 0u) &
-                                            ~(m_down ^ __ballot((de & kDictMember) != 0u));
-            const unsigned int slot = de & kSlotMask;
-            const unsigned long long m_app = m_ok & __ballot(slot != kNoSlot);
-            const unsigned long long mD = m_ok & m_down;  // DOWN reports that passed the filter
-            const bool app = ((m_app >> lane) & 1ull) != 0ull;
+            const bool seen_before = s.seen_down;
+            unsigned int de, slot;
+            bool app;
+            if (kTrusted) {
+                de = (unsigned int)dict[lane < nc ? w3 : 0u];  // lanes past the consumed records hold stale ring bytes
+                slot = de & kSlotMask;
+                app = (lane < nc) & (slot != kNoSlot);
+                // every consumed alert passed the filter; the first DOWN one sets seenLinkDownEvents
+                if (!s.seen_down) s.seen_down = wave_ballot((lane < nc) & ((w4 & 0x00FF0000u) != 0u)) != 0ull;
+            } else {
+                // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot
+                const unsigned int w0 = w[0], w1 = w[1];
+                const unsigned int node = w3 < (unsigned)p.n_nodes ? w3 : 0u;
+                de = (unsigned int)dict[node];
+                const unsigned int dn = (w4 & 0x00FF0000u) != 0u ? 1u : 0u;
+                // bad == 0 <=> the record is consumed here AND passes the filter
+                const unsigned int bad = (w0 ^ cfg_lo) | (w1 ^ cfg_hi) | (dn ^ (de >> 15)) |
+                                         (w3 >= (unsigned)p.n_nodes ? 1u : 0u) | (rb == 0u ? 1u : 0u) | (lane >= nc ? 1u : 0u);
+                slot = de & kSlotMask;
+                app = (bad | (slot == kNoSlot ? 1u : 0u)) == 0u;
+                if (!s.seen_down) s.seen_down = wave_ballot((bad | (dn ^ 1u)) == 0u) != 0ull;
+            }
             unsigned int old = 0;
-            if (app && !abl_noapply) old = d.or_bits((int)slot, rb);
+            if (app) old = d.or_bits((int)slot, rb);
             const unsigned int oldk = old & d.kmask;
             const int c0 = __popc(oldk), c1 = __popc(oldk | rb);
-            const unsigned long long mL = m_app & __ballot(c0 < d.L) & __ballot(c1 >= d.L);
-            const unsigned long long mH = m_app & __ballot(c0 < d.H) & __ballot(c1 >= d.H);
-            const unsigned long long mA = abl_noinv ? 0ull : (mL & __ballot((de & kDictHasAdj) != 0u));
-            const int nLc = __popcll(mL), nHc = __popcll(mH);
-            int add_pairs = 0;
-            if (mA != 0ull) {
-                const bool ent = ((mA >> lane) & 1ull) != 0ull;
+            const bool isL = app & (c0 < d.L) & (c1 >= d.L);
+            const int nLc = __popcll(wave_ballot(isL));
+            const int nHc = __popcll(wave_ballot(app & (c0 < d.H) & (c1 >= d.H)));
+            const bool ent = isL & ((de & kDictHasAdj) != 0u);
+            const unsigned long long mA = wave_ballot(ent);
+            int pairs_new = pend_pairs, npend_new = s.npend;
+            if (mA != 0ull) {  // entrants with hot adjacency: bound their pairs, queue them (committed below)
                 const int degv = ent ? (int)adj_off[slot + 1] - (int)adj_off[slot] : 0;
                 for (unsigned long long m = mA; m != 0ull; m &= m - 1ull)
-                    add_pairs += lane_value(degv, __ffsll((long long)m) - 1);
+                    pairs_new += lane_value(degv, __ffsll((long long)m) - 1);
+                const int posn = npend_new + __popcll(mA & lanes_lt(lane));
+                if (ent && posn < kPendCap) pend[posn] = (unsigned short)slot;
+                npend_new += __popcll(mA);
+                if (npend_new > kPendCap) pairs_new = 0x3FFFFFFF;  // forces the roll-back exit
             }
-            const int pairs_new = pend_pairs + add_pairs;
-            const int npend_new = s.npend + __popcll(mA);
-            const bool safe = ((nHc | pairs_new) == 0 || s.running - pairs_new - nHc >= 1) && npend_new <= kPendCap &&
-                              mE != 0ull;
-            if (!safe) {
+            // an emission is impossible if no H crossing can bring updatesInProgress to 0: the pending implicit
+            // reports can cause at most pairs_new more crossings than the nHc explicit ones counted here
+            const int hx = nHc + pairs_new;
+            if ((hx != 0 && s.running - hx < 1) || mE == 0ull) {
                 const unsigned int newbits = rb & ~old;
                 if (app && newbits != 0u) d.clear_bits((int)slot, newbits);
+                s.seen_down = seen_before;
                 wave_lds_fence();
-                return false;
-            }
-            if (mA != 0ull) {
-                const int posn = s.npend + __popcll(mA & lanes_lt(lane));
-                if (((mA >> lane) & 1ull) != 0ull) pend[posn] = (unsigned short)slot;
+                return 0;
             }
             s.running += nLc - nHc;
-            s.seen_down = s.seen_down || mD != 0ull;
             s.batch += __popcll(mE);
             s.npend = npend_new;
             pend_pairs = pairs_new;
             pos += nc;
-            ++n_fast32;
-            return true;
+            return 1;
         };
 
         // ---- CAREFUL path (non-pipelined loop), first attempt: order-free application with the implicit
@@ -540,8 +544,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             const int c0 = d.count(old), c1 = d.count(old | bits);
             const bool isL = bits != 0 && c0 < d.L && c1 >= d.L;
             const bool isH = bits != 0 && c0 < d.H && c1 >= d.H;
-            const unsigned long long mL = __ballot(isL), mH = __ballot(isH);
-            const unsigned long long mD = __ballot(down);
+            const unsigned long long mL = wave_ballot(isL), mH = wave_ballot(isH);
+            const unsigned long long mD = wave_ballot(down);
             const int nLc = __popcll(mL), nHc = __popcll(mH);
             const bool seen = s.seen_down || mD != 0ull;
             bool need_full = s.need_full;
@@ -697,10 +701,15 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             if (lane < (kMirrorBytes - 1024) / 16) slot_[lane + kWave + kRingBytes / 16] = x1;             \
         }                                                                                                  \
         wave_lds_fence();                                                                                  \
-        /* consume every sub-chunk whose records lie entirely in stream tiles <= t_first + jrel_ */        \
-        const int lim_ = min(nrec, ((t_first + jrel_ + 1) * kTileBytes - delta) / kRecBytes);              \
-        while (!stop && pos < nrec && min(pos + kWave, nrec) <= lim_) {                                    \
-            if (!lean_subchunk()) stop = true;                                                             \
+        /* consume every sub-chunk whose records lie entirely in stream tiles <= t_first + jrel_: with lim_ = */ \
+        /* records fully loaded, that is  pos + 64 <= lim_  or, once the whole stream is loaded, pos < nrec */ \
+        const int lim_ = ((t_first + jrel_ + 1) * kTileBytes - delta) / kRecBytes;                         \
+        const int lim2_ = stop ? pos : (nrec <= lim_ ? nrec : lim_ - (kWave - 1));                        \
+        while (pos < lim2_) {                                                                              \
+            if (!lean_subchunk()) {                                                                        \
+                stop = 1;                                                                                  \
+                break;                                                                                     \
+            }                                                                                              \
         }                                                                                                  \
     }
             static_assert(kPrefetch == 4 && kTileVec == 2 && kRingTiles == 2, "tile pipeline is written for 4 x 2 KiB");
@@ -713,9 +722,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             RAPID_LOAD(5, b2_, b3_)
             RAPID_LOAD(6, b4_, b5_)
             RAPID_LOAD(7, b6_, b7_)
-            bool stop = false;
+            int stop = 0;
             const int pos_in = pos;
-            n_fast32 = 0;
             const int jend = ((ntiles - t_first + kPrefetch - 1) / kPrefetch) * kPrefetch;
             for (int jb = 0; jb < jend; jb += kPrefetch) {
                 RAPID_STEP(0, a0_, a1_)
@@ -732,7 +740,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             }
 #undef RAPID_STEP
 #undef RAPID_LOAD
-            n_fast += (unsigned long long)n_fast32;
+            n_fast += (unsigned long long)((pos - pos_in + kWave - 1) / kWave);  // lean sub-chunks, to within rounding
             n_records += (unsigned long long)(pos - pos_in);
             if (stop) {
                 // the lean path could not exclude an emission: take the next sub-chunks through the careful loop,
@@ -751,7 +759,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             for (int i0 = 0; i0 < d.n_scan; i0 += kWave) {
                 const int i = i0 + lane;
                 const bool take = i < d.n_scan && (d.load(i) & kFlushed) != 0;
-                const unsigned long long mk = __ballot(take);
+                const unsigned long long mk = wave_ballot(take);
                 const int idx = count + __popcll(mk & lanes_lt(lane));
                 if (take) {
                     const int node = p.idx.node_of_slot[i];
@@ -847,6 +855,53 @@ __global__ __launch_bounds__(64) void cd_instance_kernel(CdParams p) {
         p.scal[2] = s.seen_down ? 1 : 0;
         *p.out_n = total;
     }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// Measurement probe (not part of the product path): the same access pattern as the tally kernel -- one wave per
+// receiver stream, TILE-byte tiles of 16 B/lane loads, DEPTH tiles in flight -- with no processing, to separate
+// what the memory system delivers for this pattern from what the detector logic costs.
+// --------------------------------------------------------------------------------------------------------------
+template <int TILE_VEC, int DEPTH>
+__global__ __launch_bounds__(1024) void stream_probe_kernel(const unsigned char* records, unsigned long long records_bytes,
+                                                            const long long* rec_off, int n_receivers,
+                                                            unsigned int* next_receiver, unsigned int* sink) {
+    const int lane = (int)(threadIdx.x & 63u);
+    unsigned int acc = 0;
+    for (;;) {
+        int r = 0;
+        if (lane == 0) r = (int)atomicAdd(next_receiver, 1u);
+        r = __builtin_amdgcn_readfirstlane(r);
+        if (r >= n_receivers) break;
+        const unsigned long long b0 = (unsigned long long)rec_off[r] * 20ull, b1 = (unsigned long long)rec_off[r + 1] * 20ull;
+        const unsigned long long a0 = b0 & ~15ull;
+        const int tile_bytes = TILE_VEC * 1024;
+        const int ntiles = (int)((b1 - a0 + tile_bytes - 1) / tile_bytes);
+        const unsigned long long last16 = records_bytes - 16ull;
+        uint4 t[DEPTH][TILE_VEC];
+#pragma unroll
+        for (int q = 0; q < DEPTH; ++q)
+#pragma unroll
+            for (int m = 0; m < TILE_VEC; ++m) {
+                unsigned long long addr = a0 + (unsigned long long)q * tile_bytes + 16ull * (unsigned)(lane + 64 * m);
+                addr = addr < last16 ? addr : last16;
+                t[q][m] = *reinterpret_cast<const uint4*>(records + addr);
+            }
+        for (int jb = 0; jb < ntiles; jb += DEPTH) {
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) {
+#pragma unroll
+                for (int m = 0; m < TILE_VEC; ++m) {
+                    acc ^= t[q][m].x ^ t[q][m].y ^ t[q][m].z ^ t[q][m].w;
+                    const int j = jb + q + DEPTH;
+                    unsigned long long addr = a0 + (unsigned long long)(j < ntiles ? j : 0) * tile_bytes + 16ull * (unsigned)(lane + 64 * m);
+                    addr = addr < last16 ? addr : last16;
+                    t[q][m] = *reinterpret_cast<const uint4*>(records + addr);
+                }
+            }
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
 }
 
 }  // namespace rapid

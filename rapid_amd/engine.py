@@ -288,6 +288,11 @@ class ClusterSimulation:
         self.e._check(self.e._lib.rapid_sim_load_streams_device(self.e._h, d_records_ptr, records_bytes, d_rec_off_ptr,
                                                                 n_receivers))
 
+    def set_alert_set(self, alerts):
+        """Declares the round's distinct alerts (see rapid_sim_set_alert_set)."""
+        alerts = np.ascontiguousarray(alerts, dtype=ALERT_DTYPE)
+        self.e._check(self.e._lib.rapid_sim_set_alert_set(self.e._h, _addr(alerts) if len(alerts) else None, len(alerts)))
+
     def tally(self):
         self.e._check(self.e._lib.rapid_sim_tally(self.e._h))
 
@@ -338,6 +343,11 @@ class ClusterSimulation:
     def time_tally(self, reps):
         ms = C.c_float(0)
         self.e._check(self.e._lib.rapid_sim_time_tally(self.e._h, reps, C.byref(ms)))
+        return ms.value
+
+    def stream_probe(self, variant, waves, reps=10):
+        ms = C.c_float(0)
+        self.e._check(self.e._lib.rapid_debug_stream_probe(self.e._h, variant, waves, reps, C.byref(ms)))
         return ms.value
 
     def set_force_exact(self, on):

@@ -8,8 +8,15 @@ eng=E.Engine(n_max=n,K=K,H=H,L=L)
 view=E.MembershipView(eng).build(pop.hostnames,pop.ports,pop.id_hi,pop.id_lo)
 obs,subj,member=view.tables(); cfg=view.getCurrentConfigurationId()
 sc=S.build_scenario("C3b",subj,cfg)
-sim=E.ClusterSimulation(eng); sim.load_streams(sc.records, sc.rec_off)
-for flag,name in [(0,"full"),(2,"no_invalidate"),(6,"no_apply_no_inv")]:
+sim=E.ClusterSimulation(eng); sim.load_streams(sc.records, sc.rec_off); sim.set_alert_set(sc.batches.recs)
+for flag,name in [(0,"full"),(64,"full_untrusted")]:
     sim.set_force_exact(flag)
     ms=sim.time_tally(10)
     print(name, round(ms,3),"ms", round(20*len(sc.records)/ms/1e6,1),"GB/s", sim.stats())
+
+sim.set_force_exact(0)
+gb = 20*len(sc.records)/1e6
+for variant,name in [(0,"2KiBx8"),(3,"2KiBx4"),(1,"4KiBx4"),(2,"8KiBx2")]:
+    for waves in (4, 8, 16):
+        ms = sim.stream_probe(variant, waves, 10)
+        print("probe", name, "waves/block", waves, round(ms,3), "ms", round(gb/ms,1), "GB/s")

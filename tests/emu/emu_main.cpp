@@ -169,10 +169,15 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     p.flags = flags;
     for (int b = 0; b < grid; ++b) {
         std::memset(smem, 0xCD, sizeof(smem));  // poison: the kernel must initialise what it reads
-        if (tables_in_lds)
-            emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { rapid::tally_population_kernel<true>(p); }, seed + (unsigned)b);
+        const bool trusted = (flags & 256) != 0;  // emulator-only selector of the kTrusted instantiation
+        if (tables_in_lds && trusted)
+            emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { rapid::tally_population_kernel<true, true>(p); }, seed + (unsigned)b);
+        else if (tables_in_lds)
+            emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { rapid::tally_population_kernel<true, false>(p); }, seed + (unsigned)b);
+        else if (trusted)
+            emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { rapid::tally_population_kernel<false, true>(p); }, seed + (unsigned)b);
         else
-            emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { rapid::tally_population_kernel<false>(p); }, seed + (unsigned)b);
+            emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { rapid::tally_population_kernel<false, false>(p); }, seed + (unsigned)b);
     }
     return 0;
 }

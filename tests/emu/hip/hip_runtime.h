@@ -71,6 +71,7 @@ void run_block(unsigned block, unsigned grid, unsigned nthreads, const std::func
 #define gridDim (emu::g_gridDim)
 
 inline unsigned long long __ballot(int p) { return emu::park(emu::OP_BALLOT, p ? 1 : 0, 0); }
+inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return emu::park(emu::OP_BALLOT, p ? 1 : 0, 0); }
 inline int __shfl(int v, int src, int = 64) { return (int)(uint32_t)emu::park(emu::OP_SHFL, (uint32_t)v, (unsigned)src & 63u); }
 inline unsigned __shfl(unsigned v, int src, int = 64) { return (unsigned)emu::park(emu::OP_SHFL, v, (unsigned)src & 63u); }
 inline int __shfl_xor(int v, int m, int = 64) {

@@ -57,8 +57,22 @@ def build_round_index(records, n_nodes, K, L, obs, member):
                 adj=adj, n_hot=n_hot, n_adj=int(adj_off[-1]))
 
 
+def validate_alerts(records, n_nodes, K, cfg_id, member):
+    """(every record passes the filter of MembershipService.java:644-675, every record is DOWN) -- what
+    index_touch_kernel computes once per round."""
+    r = np.asarray(records)
+    if len(r) == 0:
+        return True, True
+    dst = r["dst"].astype(np.int64)
+    inr = dst < n_nodes
+    mem = np.asarray(member)[np.where(inr, dst, 0)] != 0
+    down = r["status"] != 0
+    ok = (r["cfg_id"] == cfg_id) & inr & ((r["ring_mask"] & ((1 << K) - 1)) != 0) & (mem == down)
+    return bool(ok.all()), bool(down.all())
+
+
 def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_cap=None, force_exact=0, seed=1, waves=3,
-          grid=2, tables_in_lds=1):
+          grid=2, tables_in_lds=1, trusted=False):
     L_ = lib()
     recs = np.ascontiguousarray(records)
     raw = np.zeros(((recs.nbytes + 15) // 16) * 16 + 32, dtype=np.uint8)
@@ -67,6 +81,10 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     R = len(rec_off) - 1
     prop_cap = n_nodes if prop_cap is None else prop_cap
     ix = build_round_index(recs, n_nodes, K, L, np.asarray(obs), member)
+    if trusted:
+        ok, all_down = validate_alerts(recs, n_nodes, K, cfg_id, member)
+        assert ok, "trusted variant requested for a stream with alerts that fail the filter"
+        force_exact = force_exact | 256
     emit = np.full(R, -99, dtype=np.int32)
     nprop = np.full(R, -99, dtype=np.int32)
     pcount = np.full(R, -99, dtype=np.int32)

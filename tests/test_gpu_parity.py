@@ -250,10 +250,12 @@ class TestCutDetectionOnDevice:
 
 
 # ------------------------------------------------------------------------------------------ population
-def run_population(E, eng, records, rec_off, force_exact=False):
+def run_population(E, eng, records, rec_off, force_exact=False, alert_set=None):
     sim = E.ClusterSimulation(eng)
     sim.set_force_exact(force_exact)
     sim.load_streams(records, rec_off)
+    if alert_set is not None:
+        sim.set_alert_set(alert_set)
     sim.tally()
     return sim, sim.results()
 
@@ -331,6 +333,11 @@ def test_population_scenarios_vs_faithful_oracle(E, name, n, f, K, H, L):
     oracle_out = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, np.concatenate(parts), sub_off, nthreads=8)
     key0 = [oview.ringKey(0, i) for i in range(n)]
     sim, res = run_population(E, eng, sc.records, sc.rec_off)
+    # same round with the distinct alert set declared (index + validation from the set, kTrusted tally) and with the
+    # per-delivery filter forced on (knob 64): identical results
+    for kw in (dict(alert_set=sc.batches.recs), dict(force_exact=64), dict(force_exact=8)):
+        sim2, res2 = run_population(E, eng, sc.records, sc.rec_off, **kw)
+        assert all(np.array_equal(a, b) for a, b in zip(res, res2)), kw
     sub = tuple(a[rx] for a in res)
 
     class Sub:

@@ -14,9 +14,10 @@ from tests.helpers import oracle_view, random_stream
 def _check(records, rec_off, n_nodes, K, H, L, cfg, obs, subj, member, **kw):
     fe, fn, fo, fp = O.fast_sim_run(n_nodes, K, H, L, cfg, obs, subj, member, records, rec_off)
     out = {}
-    for force in (0, 1):
+    valid, _ = pyemu.validate_alerts(records, n_nodes, K, cfg, member)
+    for force in (0, 1, 2) if valid else (0, 1):  # 2: the kTrusted instantiation (only for streams that qualify)
         emit, nprop, pcount, fpr, props, stats = pyemu.tally(records, rec_off, n_nodes, K, H, L, cfg, obs, subj, member,
-                                                            force_exact=force, **kw)
+                                                            force_exact=force & 1, trusted=(force == 2), **kw)
         bad = np.flatnonzero(emit != fe)
         assert len(bad) == 0, (force, bad[:5], emit[bad[:5]], fe[bad[:5]])
         assert np.array_equal(nprop, fn), force
@@ -27,6 +28,32 @@ def _check(records, rec_off, n_nodes, K, H, L, cfg, obs, subj, member, **kw):
         out[force] = (fpr, stats)
     assert np.array_equal(out[0][0], out[1][0])  # fingerprints identical on both paths
     return out[0][1]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_valid_streams_trusted_variant(seed):
+    """Streams in which every alert passes the filter (what the generators produce): exercises kTrusted."""
+    rng = np.random.default_rng(7000 + seed)
+    n_nodes = int(rng.integers(8, 48))
+    K = int(rng.integers(3, 11))
+    H = int(rng.integers(1, K + 1))
+    L = int(rng.integers(1, H + 1))
+    pop = S.Population.make(n_nodes)
+    n_members = int(rng.integers(max(2, n_nodes // 2), n_nodes + 1))
+    members = sorted(rng.permutation(n_nodes)[:n_members].tolist())
+    reg, view = oracle_view(pop, K, members)
+    obs, subj, member = view.tables(n_nodes)
+    cfg = view.getCurrentConfigurationId()
+    recs, off = [], [0]
+    for r in range(16):
+        hot = rng.permutation(n_nodes)[: int(rng.integers(1, min(n_nodes, 12) + 1))]
+        n_rec = int(rng.integers(0, 500))
+        recs.append(random_stream(rng, n_nodes, K, member, cfg, n_rec, hot, p_bad_cfg=0.0, p_bad_status=0.0,
+                                  p_eob=float(rng.choice([0.05, 0.3, 1.0]))))
+        off.append(off[-1] + n_rec)
+    records = np.concatenate(recs)
+    assert pyemu.validate_alerts(records, n_nodes, K, cfg, member)[0]
+    _check(records, np.array(off), n_nodes, K, H, L, cfg, obs, subj, member, seed=seed)
 
 
 @pytest.mark.parametrize("seed", range(10))
