@@ -124,12 +124,19 @@ def main():
     kern_ms = sim.time_tally(args.kernel_reps)
     consumed = sim.stats()["records_consumed"] // (args.kernel_reps + 1)
     achieved = 20.0 * consumed / (kern_ms * 1e-3) / 1e9
+    # what the memory system delivers for the SAME access pattern with no processing (measurement probe)
+    probe_ms = sim.stream_probe(0, 16, 5)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "tally_population_kernel",
-                "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": int(20 * consumed),
-                "records_delivered_per_launch": my_records}
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(cfgname, world),
+                "kernel": "tally_population_kernel", "kernel_ms": round(kern_ms, 4),
+                "algorithmic_bytes_per_launch": int(20 * consumed), "records_delivered_per_launch": my_records,
+                "stream_probe_gbs": round(20.0 * my_records / (probe_ms * 1e-3) / 1e9, 1)}
+    index = sim.index_info()
 
-    # ---- one full round including decideViewChange: time-to-stable-cut (streams resident -> cut + new cfg on host)
+    # ---- one full round including decideViewChange: time-to-stable-cut = streams resident -> decided cut + new
+    # configuration id on the host: per-round index build + tally + vote count + apply cut (rings, tables, config id)
+    sim.load_streams(records, rec_off)  # drops the cached per-round index so that the round below rebuilds it
+    sim.set_alert_set(sc.batches.recs)
     barrier()
     t2 = time.perf_counter()
     rr_full, new_cfg = sim.round(apply=True)
@@ -153,7 +160,8 @@ def main():
         "alert_records_per_s": round(tot_records * args.steps / elapsed, 1),
         "time_to_stable_cut_ms": round(ttsc_ms, 3) if rr_full.decided else None,
         "decided": int(rr_full.decided), "cut_size": int(rr_full.cut_size), "votes_winner": int(rr_full.votes_winner),
-        "quorum": int(rr_full.quorum), "kernel_stats": st, "setup_s": round(setup_s, 1), "roofline": roofline,
+        "quorum": int(rr_full.quorum), "kernel_stats": st, "round_index": index, "setup_s": round(setup_s, 1),
+        "roofline": roofline,
     }
 
     # ---- CPU baseline beside it (rank 0, N=1 only): the oracle = CPU restatement of the reference's Java path ----
@@ -164,6 +172,18 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def traffic_from_profiles(cfgname, world):
+    """HBM bytes per tally launch from the committed rocprofv3 PMC pass (profiles/*_traffic.json, written by
+    scripts/pmc_traffic.py with the FETCH_SIZE correction of MI355X_MICROARCH.md); null if none was recorded."""
+    path = os.path.join(ROOT, "profiles", "tally_traffic_%s.json" % cfgname)
+    if world != 1 or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path)).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def cpu_baseline(pop, K, H, L, cfg_id, obs, subj, member, records, rec_off, nb, budget_s):

@@ -200,6 +200,10 @@ int rapid_engine_sync(rapid_engine* h);
 int rapid_sim_stats(rapid_engine* h, uint64_t stats[8]);
 /* average duration (ms) of the tally kernel over `reps` back-to-back launches, HIP events on the engine stream */
 int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg);
+/* the per-round index of the loaded streams (built on demand): info = {hot subjects, adjacency entries, waves per
+ * workgroup, workgroups, LDS bytes per workgroup, alerts pre-validated (0/1), tables staged in LDS (0/1), alert set
+ * declared (0/1)}; index_ms = device time of the last index build */
+int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms);
 /* measurement probe (not a product path): stream the loaded records with the tally kernel's access pattern and no
  * processing.  variant 0: 2 KiB tiles x 8 in flight, 1: 4 KiB x 4, 2: 8 KiB x 2, 3: 2 KiB x 4; waves per block */
 int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, int32_t reps, float* ms_avg);

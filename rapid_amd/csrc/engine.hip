@@ -1218,6 +1218,23 @@ int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, in
     return RAPID_OK;
 }
 
+int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
+    if (!h || !info) return RAPID_EINVAL;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if ((rc = prepare_tally(h))) return rc;  // builds the index if it is stale
+    info[0] = h->n_hot;
+    info[1] = h->n_adj;
+    info[2] = h->waves_per_block;
+    info[3] = h->grid_blocks;
+    info[4] = h->lds_bytes;
+    info[5] = h->trusted ? 1 : 0;
+    info[6] = h->tables_in_lds ? 1 : 0;
+    info[7] = h->n_alert_set >= 0 ? 1 : 0;
+    if (index_ms) *index_ms = h->index_ms;
+    return RAPID_OK;
+}
+
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on) {
     if (!h) return RAPID_EINVAL;
     h->force_exact = on;  // bit0: exact path only; bits 1-2: profiling ablations (results invalid)

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             const bool ent = isL & ((de & kDictHasAdj) != 0u);
             const unsigned long long mA = wave_ballot(ent);
             int pairs_new = pend_pairs, npend_new = s.npend;
-            if (mA != 0ull) {  // entrants with hot adjacency: bound their pairs, queue them (committed below)
+            if (__builtin_expect(mA != 0ull, 0)) {  // entrants with hot adjacency: bound their pairs, queue them (committed below)
                 const int degv = ent ? (int)adj_off[slot + 1] - (int)adj_off[slot] : 0;
                 for (unsigned long long m = mA; m != 0ull; m &= m - 1ull)
                     pairs_new += lane_value(degv, __ffsll((long long)m) - 1);
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             // an emission is impossible if no H crossing can bring updatesInProgress to 0: the pending implicit
             // reports can cause at most pairs_new more crossings than the nHc explicit ones counted here
             const int hx = nHc + pairs_new;
-            if ((hx != 0 && s.running - hx < 1) || mE == 0ull) {
+            if (__builtin_expect((hx != 0 && s.running - hx < 1) || mE == 0ull, 0)) {
                 const unsigned int newbits = rb & ~old;
                 if (app && newbits != 0u) d.clear_bits((int)slot, newbits);
                 s.seen_down = seen_before;
@@ -593,7 +593,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         auto exact_subchunk = [&]() {
             n_slow++;
             n_records += (unsigned long long)ncons;
-            for (int q = 0; q < ncons; ++q) {
+            // only the records that do something: a report about a hot subject, a DOWN report, or a batch end
+            for (unsigned long long todo = wave_ballot((lane < ncons) & ((bits != 0u) | down | eob)); todo != 0ull;
+                 todo &= todo - 1ull) {
+                const int q = __ffsll((long long)todo) - 1;
                 const int qdst = lane_value(dst, q);
                 const unsigned int qbits = (unsigned)lane_value((int)bits, q);
                 const int qflags = lane_value((int)down | ((int)eob << 1), q);

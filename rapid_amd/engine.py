@@ -345,6 +345,16 @@ class ClusterSimulation:
         self.e._check(self.e._lib.rapid_sim_time_tally(self.e._h, reps, C.byref(ms)))
         return ms.value
 
+    def index_info(self):
+        info = np.zeros(8, dtype=np.int32)
+        ms = C.c_float(0)
+        self.e._check(self.e._lib.rapid_sim_index_info(self.e._h, _addr(info), C.byref(ms)))
+        keys = ("hot_subjects", "adjacency_entries", "waves_per_workgroup", "workgroups", "lds_bytes_per_workgroup",
+                "alerts_prevalidated", "tables_in_lds", "alert_set_declared")
+        out = {k: int(v) for k, v in zip(keys, info)}
+        out["index_build_ms"] = round(ms.value, 4)
+        return out
+
     def stream_probe(self, variant, waves, reps=10):
         ms = C.c_float(0)
         self.e._check(self.e._lib.rapid_debug_stream_probe(self.e._h, variant, waves, reps, C.byref(ms)))
