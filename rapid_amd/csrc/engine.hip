@@ -124,6 +124,8 @@ struct rapid_engine {
     DevBuf<int> d_ref;
     std::vector<int> decided_cut;  // ring-0 order
     bool have_decision = false;
+    unsigned long long* h_pinned = nullptr;  // pinned staging for the vote read-back
+    size_t h_pinned_ref_len = 0;
 
     // ---- multi-GPU ----
     ncclComm_t comm = nullptr;
@@ -493,6 +495,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device_id);
     if (h->comm) (void)ncclCommDestroy(h->comm);
+    if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->stream) {
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamDestroy(h->stream);
@@ -937,81 +940,72 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
     hipStream_t st = h->stream;
     const int R = h->n_receivers;
     const size_t HB = (size_t)rapid::kVoteBuckets + 2;
+    const size_t ref_len = (size_t)h->max_cut + 1;
     HIPCHK(h, h->d_hist.ensure(HB));
     HIPCHK(h, h->d_winner.ensure(4));
-    HIPCHK(h, h->d_mm.ensure(4));
+    HIPCHK(h, h->d_mm.ensure(8));
     HIPCHK(h, h->d_mismatch.ensure(2));
-    HIPCHK(h, h->d_ref.ensure((size_t)h->max_cut + 1));
+    HIPCHK(h, h->d_ref.ensure(ref_len));
+    if (!h->h_pinned) {  // one pinned staging area: {winner[4], mm[8], mismatch[2]} as u64, then the ref list
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned), 16 * 8 + ref_len * sizeof(int), hipHostMallocDefault));
+        h->h_pinned_ref_len = ref_len;
+    }
+    unsigned long long* hw = h->h_pinned;
+    unsigned long long* hmm = h->h_pinned + 4;
+    unsigned long long* hmis = h->h_pinned + 12;
+    int* href = reinterpret_cast<int*>(h->h_pinned + 16);
+    const unsigned long long my_tag = ~(unsigned long long)h->rank;
 
+    // Everything below is enqueued on the engine stream and read back with ONE synchronisation per salt:
+    // histogram -> (all-reduce) -> winner -> min/max of the winning bucket -> (all-reduce) -> representative list
+    // -> (all-reduce) -> element-wise verification -> (all-reduce).
     for (unsigned long long salt = 0; salt < 4; ++salt) {
         HIPCHK(h, hipMemsetAsync(h->d_hist.p, 0, HB * 8, st));
+        HIPCHK(h, hipMemsetAsync(h->d_mm.p, 0, 64, st));
+        HIPCHK(h, hipMemsetAsync(h->d_mismatch.p, 0, 16, st));
         if (R)
             hipLaunchKernelGGL(rapid::vote_histogram_kernel, dim3(grid_for(R, 256)), dim3(256), 0, st, h->d_fp.p, h->d_pcount.p,
                                R, salt, h->d_hist.p);
         if (h->comm)  // the per-round all-reduce of the vote histogram over xGMI
             NCCLCHK(h, ncclAllReduce(h->d_hist.p, h->d_hist.p, HB, ncclUint64, ncclSum, h->comm, st));
         hipLaunchKernelGGL(rapid::vote_winner_kernel, dim3(1), dim3(256), 0, st, h->d_hist.p, h->d_winner.p);
-        HIPCHK(h, hipMemsetAsync(h->d_mm.p, 0, 32, st));
         if (R)
             hipLaunchKernelGGL(rapid::vote_bucket_minmax_kernel, dim3(grid_for(R, 256)), dim3(256), 0, st, h->d_fp.p,
-                               h->d_pcount.p, R, salt, h->d_winner.p, h->d_mm.p);
-        unsigned long long mm_local[4] = {0, 0, 0, 0};
-        HIPCHK(h, hipMemcpyAsync(mm_local, h->d_mm.p, 24, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipStreamSynchronize(st));
-        const bool have_local_rep = mm_local[2] != 0ull;
-        const int local_rep = have_local_rep ? (int)(~mm_local[2]) : -1;
-        if (h->comm) {  // mm[3] = ~(lowest rank that holds a representative)
-            unsigned long long r3 = have_local_rep ? ~(unsigned long long)h->rank : 0ull;
-            HIPCHK(h, hipMemcpyAsync(h->d_mm.p + 3, &r3, 8, hipMemcpyHostToDevice, st));
+                               h->d_pcount.p, R, salt, h->d_winner.p, h->d_mm.p, my_tag);
+        if (h->comm)  // mm[0..3] = {max fp, max ~fp, -, max ~rank of a rank holding a representative}
             NCCLCHK(h, ncclAllReduce(h->d_mm.p, h->d_mm.p, 4, ncclUint64, ncclMax, h->comm, st));
-        }
-        unsigned long long win[4] = {0, 0, 0, 0}, mm[4] = {0, 0, 0, 0};
-        HIPCHK(h, hipMemcpyAsync(win, h->d_winner.p, 24, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipMemcpyAsync(mm, h->d_mm.p, 32, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(rapid::vote_prepare_ref_kernel, dim3(1), dim3(256), 0, st, h->d_mm.p, my_tag, h->comm ? 0 : 1,
+                           h->d_pcount.p, h->d_props.p, h->max_cut, h->d_ref.p);
+        if (h->comm) NCCLCHK(h, ncclAllReduce(h->d_ref.p, h->d_ref.p, ref_len, ncclInt32, ncclMax, h->comm, st));
+        if (R)
+            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(grid_for((long long)R * 64, 256)), dim3(256), 0, st, h->d_fp.p,
+                               h->d_pcount.p, h->d_props.p, h->max_cut, R, h->d_mm.p, h->d_ref.p, h->d_mismatch.p);
+        if (h->comm) NCCLCHK(h, ncclAllReduce(h->d_mismatch.p, h->d_mismatch.p, 2, ncclUint64, ncclSum, h->comm, st));
+        HIPCHK(h, hipMemcpyAsync(hw, h->d_winner.p, 32, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(hmm, h->d_mm.p, 64, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(hmis, h->d_mismatch.p, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(href, h->d_ref.p, ref_len * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
         HIPCHK(h, hipGetLastError());
-        out->votes_total = (int64_t)win[2];
-        out->votes_winner = (int64_t)win[1];
-        if (win[1] == 0) return RAPID_OK;  // nobody proposed
-        const unsigned long long fmax = mm[0], fmin = ~mm[1];
+        out->votes_total = (int64_t)hw[2];
+        out->votes_winner = (int64_t)hw[1];
+        out->distinct_local = (int32_t)hw[3];
+        if (hw[1] == 0) return RAPID_OK;  // nobody proposed
+        const unsigned long long fmax = hmm[0], fmin = ~hmm[1];
         if (fmax != fmin) {
-            if ((long long)win[1] < out->quorum) return RAPID_OK;  // no proposal can have a quorum
+            if ((long long)hw[1] < out->quorum) return RAPID_OK;  // no proposal can have a quorum
             continue;  // two proposals share the winning bucket: re-hash with the next salt
         }
-        // the winning bucket is pure: fetch the representative's list, verify every voter against it
-        int ref_n = 0;
-        const int owner = h->comm ? (int)(~mm[3]) : h->rank;
-        if (owner == h->rank) {
-            HIPCHK(h, hipMemcpyAsync(&ref_n, h->d_pcount.p + local_rep, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(h, hipStreamSynchronize(st));
-            if (ref_n < 0) return fail(h, RAPID_ECAPACITY, "winning proposal exceeds max_cut=%d", h->max_cut);
-            HIPCHK(h, hipMemcpyAsync(h->d_ref.p, &ref_n, 4, hipMemcpyHostToDevice, st));
-            HIPCHK(h, hipMemcpyAsync(h->d_ref.p + 1, h->d_props.p + (size_t)local_rep * h->max_cut, sizeof(int) * (size_t)ref_n,
-                                     hipMemcpyDeviceToDevice, st));
-        }
-        if (h->comm) {
-            NCCLCHK(h, ncclBroadcast(h->d_ref.p, h->d_ref.p, (size_t)h->max_cut + 1, ncclInt32, owner, h->comm, st));
-            HIPCHK(h, hipMemcpyAsync(&ref_n, h->d_ref.p, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(h, hipStreamSynchronize(st));
-        }
-        HIPCHK(h, hipMemsetAsync(h->d_mismatch.p, 0, 16, st));
-        if (R)
-            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3((unsigned)R), dim3(64), 0, st, h->d_fp.p, h->d_pcount.p, h->d_props.p,
-                               h->max_cut, R, fmax, h->d_ref.p + 1, ref_n, h->d_mismatch.p);
-        if (h->comm) NCCLCHK(h, ncclAllReduce(h->d_mismatch.p, h->d_mismatch.p, 2, ncclUint64, ncclSum, h->comm, st));
-        unsigned long long mis[2] = {0, 0};
-        HIPCHK(h, hipMemcpyAsync(mis, h->d_mismatch.p, 16, hipMemcpyDeviceToHost, st));
-        std::vector<int> ref((size_t)ref_n);
-        if (ref_n) HIPCHK(h, hipMemcpyAsync(ref.data(), h->d_ref.p + 1, sizeof(int) * (size_t)ref_n, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipStreamSynchronize(st));
-        HIPCHK(h, hipGetLastError());
-        if (mis[0] != 0 || mis[1] != win[1])
+        const int ref_n = href[0];
+        if (ref_n < 0) return fail(h, RAPID_ECAPACITY, "winning proposal exceeds max_cut=%d", h->max_cut);
+        if (hmis[0] != 0 || hmis[1] != hw[1])
             return fail(h, RAPID_ECOLLISION, "fingerprint collision: %llu of %llu voters differ from the representative",
-                        mis[0], win[1]);
+                        hmis[0], hw[1]);
         out->cut_size = ref_n;
         // R/FastPaxos.java:146-150: |votesReceived| >= N - F and votes[proposal] >= N - F
-        if ((long long)win[1] >= out->quorum) {
+        if ((long long)hw[1] >= out->quorum) {
             out->decided = 1;
+            std::vector<int> ref(href + 1, href + 1 + ref_n);
             sort_ring0(h, ref);
             h->decided_cut = ref;
             h->have_decision = true;

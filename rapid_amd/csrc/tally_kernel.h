@@ -411,6 +411,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         int pos = 0;          // next unconsumed record
         int ring_tile0 = 0;   // stream tile that maps to ring slot 0
         int careful_budget = 0, careful_next = 2;
+        int careful_cap = kWave;  // records the careful loop takes at once; halved while an emission cannot be excluded
 
         // per-sub-chunk decode results (one record per lane)
         int dst = 0, ncons = 0, lastE = -1;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 
         // ---- decode the sub-chunk starting at `pos` from the LDS ring (the mirror makes it wrap-free) ----
         auto decode = [&]() {
-            const int navail = min(kWave, nrec - pos);
+            const int navail = min(careful_cap, nrec - pos);
             const int base = (delta + kRecBytes * pos - ring_tile0 * kTileBytes) & (kRingBytes - 1);
             const unsigned int* w = ring32 + ((base + lane20) >> 2);
             const unsigned int w0 = w[0], w1 = w[1], w3 = w[3], w4 = w[4];
@@ -630,6 +631,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 pos = 0;
                 restart = false;
                 careful_budget = 0;
+                careful_cap = kWave;
                 wave_lds_fence();
                 continue;
             }
@@ -651,8 +653,19 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 }
                 wave_lds_fence();
                 decode();
-                if (exact_only || s.batch_emitted || !immediate_subchunk()) {
-                    if (!restart) exact_subchunk();
+                if (exact_only || s.batch_emitted) {
+                    exact_subchunk();
+                } else if (immediate_subchunk()) {
+                    careful_cap = min(kWave, careful_cap * 2);
+                } else if (!restart) {
+                    // An emission cannot be excluded somewhere in these ncons records.  Narrow the window instead of
+                    // replaying all of them one by one: the record-by-record path only ever runs on a few records.
+                    if (ncons > 4) {
+                        careful_cap = ncons / 2;
+                        continue;  // same position, smaller sub-chunk
+                    }
+                    exact_subchunk();
+                    careful_cap = kWave;
                 }
                 if (careful_budget > 0) --careful_budget;
                 continue;

@@ -29,7 +29,7 @@ __global__ void vote_histogram_kernel(const unsigned long long* fp, const int* p
                                       unsigned long long salt, unsigned long long* hist) {
     const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int lane = (int)(threadIdx.x & 63);
-    const bool votes = r < n_receivers && prop_count[r] > 0;
+    const bool votes = r < n_receivers && prop_count[r] != 0;  // -1 = proposal larger than max_cut: still a vote
     const unsigned int b = votes ? vote_bucket(fp[r], salt) : 0xFFFFFFFFu;
     unsigned long long todo = __ballot(votes);
     const unsigned long long all = todo;
@@ -43,7 +43,7 @@ __global__ void vote_histogram_kernel(const unsigned long long* fp, const int* p
     if (all && lane == __ffsll((long long)all) - 1) atomicAdd(&hist[kVoteBuckets], (unsigned long long)__popcll(all));
 }
 
-// out[0] = bucket with the most votes, out[1] = its count, out[2] = total voters.  One block.
+// out[0] = bucket with the most votes, out[1] = its count, out[2] = total voters, out[3] = non-empty buckets.  One block.
 __global__ void vote_winner_kernel(const unsigned long long* hist, unsigned long long* out) {
     __shared__ unsigned long long best_cnt[256];
     __shared__ unsigned int best_idx[256];
@@ -69,47 +69,80 @@ __global__ void vote_winner_kernel(const unsigned long long* hist, unsigned long
         }
         __syncthreads();
     }
+    __shared__ unsigned int nz[256];
+    unsigned int z = 0;
+    for (int b = t; b < kVoteBuckets; b += (int)blockDim.x) z += hist[b] != 0ull ? 1u : 0u;
+    nz[t] = z;
+    __syncthreads();
+    for (int s2 = (int)blockDim.x / 2; s2 > 0; s2 >>= 1) {
+        if (t < s2) nz[t] += nz[t + s2];
+        __syncthreads();
+    }
     if (t == 0) {
         out[0] = best_idx[0];
         out[1] = best_cnt[0];
         out[2] = hist[kVoteBuckets];
+        out[3] = nz[0];  // non-empty buckets ~ distinct proposals
     }
 }
 
-// For the winning bucket: mm[0] = max fingerprint, mm[1] = max of ~fingerprint (i.e. ~min), mm[2] = max of
-// ~(receiver index) over local voters in the bucket (i.e. ~lowest local representative); all start at 0.
+// For the winning bucket (all slots start at 0): mm[0] = max fingerprint, mm[1] = max of ~fingerprint (i.e. ~min),
+// mm[3] = my_tag if this rank has a voter in the bucket, mm[4] = max of ~(receiver index) over the local voters.
 __global__ void vote_bucket_minmax_kernel(const unsigned long long* fp, const int* prop_count, int n_receivers,
                                           unsigned long long salt, const unsigned long long* winner,
-                                          unsigned long long* mm) {
+                                          unsigned long long* mm, unsigned long long my_tag) {
     const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (r >= n_receivers || prop_count[r] <= 0) return;
-    const unsigned long long f = fp[r];
-    if (vote_bucket(f, salt) != (unsigned int)winner[0]) return;
-    atomicMax(&mm[0], f);
-    atomicMax(&mm[1], ~f);
-    atomicMax(&mm[2], ~(unsigned long long)r);
+    const bool in = r < n_receivers && prop_count[r] != 0 && vote_bucket(fp[r], salt) == (unsigned int)winner[0];
+    const unsigned long long f = in ? fp[r] : 0ull;
+    // wave-level pre-reduction: most voters share one fingerprint, so one lane per wave touches global memory
+    unsigned long long fmx = f, fmn = in ? ~f : 0ull, rr = in ? ~(unsigned long long)r : 0ull;
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(fmx, off, 64), b = __shfl_xor(fmn, off, 64), c = __shfl_xor(rr, off, 64);
+        fmx = a > fmx ? a : fmx;
+        fmn = b > fmn ? b : fmn;
+        rr = c > rr ? c : rr;
+    }
+    if ((threadIdx.x & 63u) == 0 && rr != 0ull) {
+        atomicMax(&mm[0], fmx);
+        atomicMax(&mm[1], fmn);
+        atomicMax(&mm[3], my_tag);  // this rank holds a representative
+        atomicMax(&mm[4], rr);      // ~(lowest local representative) -- never all-reduced
+    }
 }
 
-// Element-wise verification: every local voter whose fingerprint equals `want` must hold exactly the list
-// ref[0..ref_n).  mismatch[0] counts offenders; mismatch[1] counts the verified voters.
+// ref[0] = size, ref[1..cap] = node list of the proposal every voter must equal.  The rank that owns the lowest
+// representative (owner_tag == my_tag, or a single-rank run) copies it from its receiver; every other rank writes
+// zeros, so that a max all-reduce of ref[] hands the list to everybody without a host round trip.
+// mm[4] = ~(local representative receiver), 0 if this rank has no voter in the winning bucket.
+__global__ void vote_prepare_ref_kernel(const unsigned long long* mm, unsigned long long my_tag, int single_rank,
+                                        const int* prop_count, const int* props, int prop_cap, int* ref) {
+    const bool owner = mm[4] != 0ull && (single_rank || mm[3] == my_tag);
+    const int rep = owner ? (int)(~mm[4]) : 0;
+    int n = owner ? prop_count[rep] : 0;
+    if (n < 0) n = -1;  // the representative's proposal overflowed max_cut: reported by the host
+    for (int i = (int)threadIdx.x; i < prop_cap; i += (int)blockDim.x)
+        ref[1 + i] = (owner && i < n) ? props[(long long)rep * prop_cap + i] : 0;
+    if (threadIdx.x == 0) ref[0] = owner ? n : 0;
+}
+
+// Element-wise verification: every local voter whose fingerprint equals mm[0] (== the winning bucket's only
+// fingerprint when it is pure) must hold exactly the list ref[1..ref[0]].  mismatch[0] counts offenders, mismatch[1]
+// the verified voters.  One wavefront per receiver.
 __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop_count, const int* props, int prop_cap,
-                                   int n_receivers, unsigned long long want, const int* ref, int ref_n,
+                                   int n_receivers, const unsigned long long* mm, const int* ref,
                                    unsigned long long* mismatch) {
-    const int r = (int)blockIdx.x;
-    if (r >= n_receivers || prop_count[r] <= 0 || fp[r] != want) return;
-    __shared__ int bad;
-    if (threadIdx.x == 0) bad = 0;
-    __syncthreads();
-    if (prop_count[r] != ref_n) {
-        if (threadIdx.x == 0) bad = 1;
-    } else {
+    const int r = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = (int)(threadIdx.x & 63u);
+    if (r >= n_receivers || prop_count[r] == 0 || fp[r] != mm[0]) return;
+    const int ref_n = ref[0];
+    bool bad = prop_count[r] != ref_n;
+    if (!bad) {
         const int* mine = props + (long long)r * prop_cap;
-        for (int i = (int)threadIdx.x; i < ref_n; i += (int)blockDim.x)
-            if (mine[i] != ref[i]) bad = 1;
+        for (int i = lane; i < ref_n; i += 64) bad |= mine[i] != ref[1 + i];
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (bad) atomicAdd(&mismatch[0], 1ull);
+    const unsigned long long any_bad = __ballot(bad);
+    if (lane == 0) {
+        if (any_bad) atomicAdd(&mismatch[0], 1ull);
         atomicAdd(&mismatch[1], 1ull);
     }
 }
