@@ -128,6 +128,15 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // 
     return x ^ (x >> 31);
 }
 
+// 16 B per lane through a buffer resource descriptor (V#): a 32-bit per-lane offset plus a scalar tile offset, and
+// the hardware bounds check returns zeros past the end of the receiver's stream -- no address clamping in the
+// loop and no memory traffic for tiles beyond the stream.
+using buffer_rsrc_t = decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0));
+__device__ __forceinline__ uint4 buffer_load16(buffer_rsrc_t rsrc, unsigned int lane_off, unsigned int tile_off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, tile_off, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 // ---- detector state accessors ---------------------------------------------------------------------------------
 // LDS flavour (population kernel): indices are slots; sweeps cover the hot slots only.
 struct SlotDetector {
@@ -401,7 +410,12 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         const unsigned long long a0 = b0 & ~15ull;  // 16-B aligned start of this receiver's byte range
         const int delta = (int)(b0 - a0);
         const int ntiles = (int)(((long long)delta + (long long)nrec * kRecBytes + kTileBytes - 1) / kTileBytes);
-        const unsigned long long last16 = p.records_bytes - 16ull;
+        // this receiver's bytes, 16-B aligned start, as a buffer resource (wave-uniform)
+        unsigned long long span = ((unsigned long long)delta + (unsigned long long)nrec * kRecBytes + 15ull) & ~15ull;
+        if (a0 + span > p.records_bytes) span = p.records_bytes > a0 ? p.records_bytes - a0 : 0ull;
+        const buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.records + a0), (short)0, (int)(span > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : span), 0x00020000);
+        const unsigned int lane16 = (unsigned int)lane * 16u;
 
         int emit_batch = -1;
         RxScalars s;
@@ -642,14 +656,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 wave_lds_fence();
 #pragma unroll
                 for (int tt = 0; tt < kRingTiles; ++tt) {
-                    const unsigned long long g = a0 + (unsigned long long)(t_first + tt) * kTileBytes;
 #pragma unroll
-                    for (int m = 0; m < kTileVec; ++m) {
-                        unsigned long long addr = g + 16ull * (unsigned)(lane + kWave * m);
-                        addr = addr < last16 ? addr : last16;
+                    for (int m = 0; m < kTileVec; ++m)
                         reinterpret_cast<uint4*>(stage + tt * kTileBytes)[lane + kWave * m] =
-                            *reinterpret_cast<const uint4*>(p.records + addr);
-                    }
+                            buffer_load16(rsrc, lane16 + 1024u * m, (unsigned int)(t_first + tt) * kTileBytes);
                 }
                 wave_lds_fence();
                 decode();
@@ -674,7 +684,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             // Set A (the round being consumed) was issued a whole round earlier; set B (the next round) is issued
             // while A is consumed.  All vector-memory traffic is unconditional and statically indexed, so every wait
             // is for the OLDEST outstanding tile only and 8-16 KiB per wave stay in flight.  Tiles past the end of
-            // the stream re-read the first tile (L2-resident) and are never decoded.
+            // the stream are out of range of the receiver's buffer resource: they return zeros without touching memory.
             ring_tile0 = t_first;
             if (s.npend > 0) {  // entrants carried over from the careful loop: re-establish the bound on their pairs
                 int dsum = 0;
@@ -694,16 +704,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 pend_pairs = 0;
             }
             uint4 a0_, a1_, a2_, a3_, a4_, a5_, a6_, a7_, b0_, b1_, b2_, b3_, b4_, b5_, b6_, b7_;
-#define RAPID_LOAD(jrel, x0, x1)                                                                                \
-    {                                                                                                           \
-        const int jabs_ = t_first + (jrel);                                                                     \
-        const unsigned long long g_ = a0 + (unsigned long long)(jabs_ < ntiles ? jabs_ : t_first) * kTileBytes; \
-        unsigned long long addr0_ = g_ + 16ull * (unsigned)lane;                                               \
-        unsigned long long addr1_ = addr0_ + 1024ull;                                                           \
-        addr0_ = addr0_ < last16 ? addr0_ : last16;                                                             \
-        addr1_ = addr1_ < last16 ? addr1_ : last16;                                                             \
-        x0 = *reinterpret_cast<const uint4*>(p.records + addr0_);                                               \
-        x1 = *reinterpret_cast<const uint4*>(p.records + addr1_);                                               \
+#define RAPID_LOAD(jrel, x0, x1)                                                        \
+    {                                                                                   \
+        const unsigned int toff_ = (unsigned int)(t_first + (jrel)) * kTileBytes;       \
+        x0 = buffer_load16(rsrc, lane16, toff_);                                        \
+        x1 = buffer_load16(rsrc, lane16 + 1024u, toff_);                                \
     }
 #define RAPID_STEP(q, x0, x1)                                                                              \
     {                                                                                                      \
@@ -734,26 +739,37 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             RAPID_LOAD(1, a2_, a3_)
             RAPID_LOAD(2, a4_, a5_)
             RAPID_LOAD(3, a6_, a7_)
-            RAPID_LOAD(4, b0_, b1_)
-            RAPID_LOAD(5, b2_, b3_)
-            RAPID_LOAD(6, b4_, b5_)
-            RAPID_LOAD(7, b6_, b7_)
             int stop = 0;
             const int pos_in = pos;
-            const int jend = ((ntiles - t_first + kPrefetch - 1) / kPrefetch) * kPrefetch;
-            for (int jb = 0; jb < jend; jb += kPrefetch) {
+            // Two rounds per trip; each register set is reloaded IN PLACE half a trip before it is consumed again, so
+            // no in-flight value is ever copied and every wait is for loads issued a whole round earlier:
+            //   [load B] [consume A] [load A] [consume B]
+            const int jend = ((ntiles - t_first + 2 * kPrefetch - 1) / (2 * kPrefetch)) * (2 * kPrefetch);
+            for (int jb = 0; jb < jend; jb += 2 * kPrefetch) {
+                RAPID_LOAD(jb + 4, b0_, b1_)
+                RAPID_LOAD(jb + 5, b2_, b3_)
+                RAPID_LOAD(jb + 6, b4_, b5_)
+                RAPID_LOAD(jb + 7, b6_, b7_)
                 RAPID_STEP(0, a0_, a1_)
                 RAPID_STEP(1, a2_, a3_)
                 RAPID_STEP(2, a4_, a5_)
                 RAPID_STEP(3, a6_, a7_)
-                flush_pending();  // once per round: the deferred implicit invalidation (cannot emit, see above)
+                // the deferred implicit invalidation (cannot emit, see above): when enough entrants are queued, and
+                // always before the loop is left
+                if (s.npend >= kPendCap / 4 || stop) flush_pending();
                 if (stop) break;
-                a0_ = b0_; a1_ = b1_; a2_ = b2_; a3_ = b3_; a4_ = b4_; a5_ = b5_; a6_ = b6_; a7_ = b7_;
-                RAPID_LOAD(jb + 8, b0_, b1_)
-                RAPID_LOAD(jb + 9, b2_, b3_)
-                RAPID_LOAD(jb + 10, b4_, b5_)
-                RAPID_LOAD(jb + 11, b6_, b7_)
+                RAPID_LOAD(jb + 8, a0_, a1_)
+                RAPID_LOAD(jb + 9, a2_, a3_)
+                RAPID_LOAD(jb + 10, a4_, a5_)
+                RAPID_LOAD(jb + 11, a6_, a7_)
+                RAPID_STEP(4, b0_, b1_)
+                RAPID_STEP(5, b2_, b3_)
+                RAPID_STEP(6, b4_, b5_)
+                RAPID_STEP(7, b6_, b7_)
+                if (s.npend >= kPendCap / 4 || stop) flush_pending();
+                if (stop) break;
             }
+            flush_pending();  // leaves nothing deferred behind (a no-op unless the stream ended inside the loop)
 #undef RAPID_STEP
 #undef RAPID_LOAD
             n_fast += (unsigned long long)((pos - pos_in + kWave - 1) / kWave);  // lean sub-chunks, to within rounding

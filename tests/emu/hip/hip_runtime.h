@@ -65,6 +65,27 @@ inline int cur_lane() { return g_block->cur & 63; }
 void run_block(unsigned block, unsigned grid, unsigned nthreads, const std::function<void()>& body, uint64_t seed);
 }  // namespace emu
 
+// buffer resource descriptor + bounds-checked 16-B load
+namespace emu {
+struct Rsrc {
+    const unsigned char* base;
+    unsigned int num;
+};
+struct U4 {
+    unsigned int v[4];
+    unsigned int operator[](int i) const { return v[i]; }
+};
+}  // namespace emu
+inline emu::Rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num, int) {
+    return emu::Rsrc{static_cast<const unsigned char*>(p), (unsigned int)num};
+}
+inline emu::U4 __builtin_amdgcn_raw_buffer_load_b128(emu::Rsrc r, unsigned int voff, unsigned int soff, int) {
+    emu::U4 out{{0, 0, 0, 0}};
+    const unsigned long long off = (unsigned long long)voff + soff;
+    if (r.base != nullptr && off + 16ull <= r.num) std::memcpy(out.v, r.base + off, 16);
+    return out;
+}
+
 #define threadIdx (emu::g_threadIdx)
 #define blockIdx (emu::g_blockIdx)
 #define blockDim (emu::g_blockDim)
@@ -87,6 +108,7 @@ inline void __syncthreads() { (void)emu::park(emu::OP_BLOCK_SYNC, 0, 0); }
 // wave-local LDS ordering point of the kernels (compiler-only on the device): a rendezvous here, so that the
 // emulator keeps shuffling the lane order around every point where lanes exchange data through LDS
 inline void __builtin_amdgcn_wave_barrier() { (void)emu::park(emu::OP_WAVE_SYNC, 0, 0); }
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
