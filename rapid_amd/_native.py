@@ -9,7 +9,7 @@ import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librapid_mi355x.so")
+LIB_PATH = os.environ.get("RAPID_MI355X_LIB") or os.path.join(_HERE, "librapid_mi355x.so")  # override: profiling builds
 SRC_DIR = os.path.join(_HERE, "csrc")
 SOURCES = ["engine.hip", "tally_kernel.h", "index_kernels.h", "view_kernels.h", "vote_kernels.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rapid_mi355x.h")
@@ -64,7 +64,7 @@ def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 cross-compiles without a GPU (about 15 s)."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + SRC_DIR,
            os.path.join(SRC_DIR, "engine.hip"), "-o", LIB_PATH + ".tmp", "-lrccl"]
     if verbose:
         print(" ".join(cmd))

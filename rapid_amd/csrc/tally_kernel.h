@@ -35,16 +35,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <lds_dma.h>
+
 namespace rapid {
 
 constexpr int kWave = 64;
 constexpr int kRecBytes = 20;
-constexpr int kTileBytes = 2048;                     // one tile = 2 x (64 lanes x 16 B)
-constexpr int kTileVec = kTileBytes / 1024;          // uint4 per lane per tile
-constexpr int kRingTiles = 2;                        // LDS ring the sub-chunks are decoded from
-constexpr int kRingBytes = kTileBytes * kRingTiles;  // power of two; a sub-chunk (<= 1280 B) spans <= 2 tiles
-constexpr int kMirrorBytes = kWave * kRecBytes;      // head of slot 0 repeated after the ring: decode never wraps
-constexpr int kPrefetch = 4;                         // tiles in flight in registers per wave (8 KiB); multiple of kRingTiles
+constexpr int kSlotBytes = 1024;                     // one LDS-DMA wave instruction: 64 lanes x 16 B
+constexpr int kWindowSlots = 4;                      // a 128-record window (2560 B) at any alignment touches <= 4 slots
+constexpr int kDepth = 8;                            // KiB kept in flight per wave
+constexpr int kRingSlots = kWindowSlots + kDepth;    // LDS ring the windows are decoded from
+constexpr int kRingBytes = kSlotBytes * kRingSlots;
+constexpr int kMirrorBytes = kWave * kRecBytes;      // head of slot 0 repeated after the ring: a 64-record read never wraps
 constexpr int kPendCap = 128;                        // slots that crossed L and still await invalidation
 constexpr int kUndoCap = 128;                        // implicit bits set inside one sub-chunk
 constexpr int kMaxWavesPerBlock = 16;
@@ -85,7 +87,7 @@ struct TallyParams {
     unsigned long long* stats;        // [8]
     unsigned int* next_receiver;      // work counter (zeroed before every launch)
     int waves_per_block;
-    int flags;                        // bit0: exact path only, bit3: careful loop only (both for tests)
+    int flags;                        // bit0: exact path only, bit3: careful path only (both for tests); bit5: stream only
 };
 
 __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
@@ -136,6 +138,16 @@ __device__ __forceinline__ uint4 buffer_load16(buffer_rsrc_t rsrc, unsigned int 
     const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, tile_off, 0);
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
+
+// Phase timers of the profiling build (-DRAPID_PHASE_TIMERS, scripts/phase_timers.sh): shader-clock cycles per phase,
+// summed over all waves, reported through the stats array instead of the usual counters.  Never in the product build.
+#ifdef RAPID_PHASE_TIMERS
+#define RAPID_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define RAPID_T1(acc, v) acc += __builtin_amdgcn_s_memtime() - (v)
+#else
+#define RAPID_T0(v)
+#define RAPID_T1(acc, v)
+#endif
 
 // ---- detector state accessors ---------------------------------------------------------------------------------
 // LDS flavour (population kernel): indices are slots; sweeps cover the hot slots only.
@@ -382,6 +394,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     unsigned short* const pend = reinterpret_cast<unsigned short*>(stage + kRingBytes + kMirrorBytes);
     unsigned int* const undo = reinterpret_cast<unsigned int*>(stage + kRingBytes + kMirrorBytes + align16(kPendCap * 2));
     const unsigned int* const ring32 = reinterpret_cast<const unsigned int*>(stage);
+    uint4* const ring16 = reinterpret_cast<uint4*>(stage);
+    const lds_addr_t ring_lds = lds_uniform(lds_address(stage));
 
     SlotDetector d;
     d.st = reinterpret_cast<unsigned int*>(mine);
@@ -394,7 +408,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 
     const unsigned int cfg_lo = (unsigned int)(unsigned long long)p.cfg_id;
     const unsigned int cfg_hi = (unsigned int)((unsigned long long)p.cfg_id >> 32);
-    unsigned long long n_slow = 0, n_fast = 0, n_restart = 0, n_records = 0;
+    unsigned long long n_slow = 0, n_fast = 0, n_restart = 0, n_records = 0, n_pipe = 0, n_careful = 0;
+#ifdef RAPID_PHASE_TIMERS
+    unsigned long long t_total = 0, t_ensure = 0, t_lean = 0, t_careful = 0, t_out = 0, t_flush = 0, t_rx = 0;
+    RAPID_T0(t_kernel0);
+#endif
     int n_applied = 0, n_full = 0;
     const int lane20 = lane * kRecBytes;
 
@@ -409,12 +427,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         const unsigned long long b0 = (unsigned long long)rec0 * kRecBytes;
         const unsigned long long a0 = b0 & ~15ull;  // 16-B aligned start of this receiver's byte range
         const int delta = (int)(b0 - a0);
-        const int ntiles = (int)(((long long)delta + (long long)nrec * kRecBytes + kTileBytes - 1) / kTileBytes);
         // this receiver's bytes, 16-B aligned start, as a buffer resource (wave-uniform)
         unsigned long long span = ((unsigned long long)delta + (unsigned long long)nrec * kRecBytes + 15ull) & ~15ull;
         if (a0 + span > p.records_bytes) span = p.records_bytes > a0 ? p.records_bytes - a0 : 0ull;
-        const buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(p.records + a0), (short)0, (int)(span > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : span), 0x00020000);
+        const dma_rsrc_t rsrc = dma_make_rsrc(p.records + a0, (unsigned int)(span > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : span));
         const unsigned int lane16 = (unsigned int)lane * 16u;
 
         int emit_batch = -1;
@@ -423,7 +439,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         bool exact_only = (p.flags & 1) != 0;
         bool restart = true;  // (re)initialise the detector before the first sub-chunk
         int pos = 0;          // next unconsumed record
-        int ring_tile0 = 0;   // stream tile that maps to ring slot 0
         int careful_budget = 0, careful_next = 2;
         int careful_cap = kWave;  // records the careful loop takes at once; halved while an emission cannot be excluded
 
@@ -436,7 +451,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // ---- decode the sub-chunk starting at `pos` from the LDS ring (the mirror makes it wrap-free) ----
         auto decode = [&]() {
             const int navail = min(careful_cap, nrec - pos);
-            const int base = (delta + kRecBytes * pos - ring_tile0 * kTileBytes) & (kRingBytes - 1);
+            const int base = (int)((unsigned int)(delta + kRecBytes * pos) % (unsigned int)kRingBytes);
             const unsigned int* w = ring32 + ((base + lane20) >> 2);
             const unsigned int w0 = w[0], w1 = w[1], w3 = w[3], w4 = w[4];
             down = ((w4 >> 16) & 0xFFu) != 0;
@@ -480,7 +495,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // per-lane booleans: predicates cost one v_cmp each and combine with scalar ANDs.
         auto lean_subchunk = [&]() -> int {
             const int navail = min(kWave, nrec - pos);
-            const int base = (delta + kRecBytes * pos - ring_tile0 * kTileBytes) & (kRingBytes - 1);
+            const int base = (int)((unsigned int)(delta + kRecBytes * pos) % (unsigned int)kRingBytes);
             const unsigned int* w = ring32 + ((base + lane20) >> 2);
             const unsigned int w3 = w[3], w4 = w[4];
             // batch ends among the available records (the last record of the stream always closes a batch)
@@ -535,6 +550,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             // reports can cause at most pairs_new more crossings than the nHc explicit ones counted here
             const int hx = nHc + pairs_new;
             if (__builtin_expect((hx != 0 && s.running - hx < 1) || mE == 0ull, 0)) {
+#ifdef RAPID_TRACE
+                if (lane == 0) fprintf(stderr, "N-fail r=%d pos=%d run=%d nHc=%d pairs=%d->%d npend=%d noE=%d\n", r, pos, s.running, nHc, pend_pairs, pairs_new, s.npend, (int)(mE == 0ull));
+#endif
                 const unsigned int newbits = rb & ~old;
                 if (app && newbits != 0u) d.clear_bits((int)slot, newbits);
                 s.seen_down = seen_before;
@@ -546,6 +564,104 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             s.npend = npend_new;
             pend_pairs = pairs_new;
             pos += nc;
+            return 1;
+        };
+
+        // ---- WIDE lean path: the same order-free application on TWO records per lane (records pos .. pos+127, all
+        // inside the stream and resident in the ring), so the wave-uniform bookkeeping -- window cut, safety test,
+        // counters -- is paid once per 128 records.  Half A = records pos+lane, half B = records pos+64+lane; each
+        // half is a contiguous 1280-byte read that the mirror keeps wrap-free.  LDS atomics of one wave execute in
+        // program order, so B's ds_or_rtn sees A's bits and every threshold crossing is still counted exactly once.
+        auto lean_wide = [&]() -> int {
+            const int baseA = (int)((unsigned int)(delta + kRecBytes * pos) % (unsigned int)kRingBytes);
+            const int baseB = baseA + kWave * kRecBytes - (baseA + kWave * kRecBytes >= kRingBytes ? kRingBytes : 0);
+            const unsigned int* wa = ring32 + ((baseA + lane20) >> 2);
+            const unsigned int* wb = ring32 + ((baseB + lane20) >> 2);
+            const unsigned int a3 = wa[3], a4 = wa[4], b3 = wb[3], b4 = wb[4];
+            const unsigned long long mEA = wave_ballot((a4 & 0x01000000u) != 0u);
+            const unsigned long long mEB = wave_ballot((b4 & 0x01000000u) != 0u);
+            // consume up to the last batch end of the window
+            const int ncA = mEB != 0ull ? kWave : (mEA != 0ull ? kWave - __clzll((long long)mEA) : 0);
+            const int ncB = mEB != 0ull ? kWave - __clzll((long long)mEB) : 0;
+            const unsigned int rbA = a4 & d.kmask, rbB = b4 & d.kmask;
+            const bool seen_before = s.seen_down;
+            unsigned int deA, deB;
+            unsigned long long mAppA, mAppB;
+            bool appA, appB;
+            if (kTrusted) {
+                // all 128 records are real, validated alerts: the dictionary lookup needs no clamping
+                deA = (unsigned int)dict[a3];
+                deB = (unsigned int)dict[b3];
+                mAppA = wave_ballot(lane < ncA) & wave_ballot((deA & kSlotMask) != kNoSlot);
+                mAppB = wave_ballot(lane < ncB) & wave_ballot((deB & kSlotMask) != kNoSlot);
+                appA = (lane < ncA) & ((deA & kSlotMask) != kNoSlot);
+                appB = (lane < ncB) & ((deB & kSlotMask) != kNoSlot);
+                if (!s.seen_down)
+                    s.seen_down = ((wave_ballot(lane < ncA) & wave_ballot((a4 & 0x00FF0000u) != 0u)) |
+                                   (wave_ballot(lane < ncB) & wave_ballot((b4 & 0x00FF0000u) != 0u))) != 0ull;
+            } else {
+                // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot, per half
+                const unsigned int a0 = wa[0], a1 = wa[1], b0w = wb[0], b1 = wb[1];
+                deA = (unsigned int)dict[a3 < (unsigned)p.n_nodes ? a3 : 0u];
+                deB = (unsigned int)dict[b3 < (unsigned)p.n_nodes ? b3 : 0u];
+                const unsigned int dnA = (a4 & 0x00FF0000u) != 0u ? 1u : 0u, dnB = (b4 & 0x00FF0000u) != 0u ? 1u : 0u;
+                const unsigned int badA = (a0 ^ cfg_lo) | (a1 ^ cfg_hi) | (dnA ^ (deA >> 15)) |
+                                          (a3 >= (unsigned)p.n_nodes ? 1u : 0u) | (rbA == 0u ? 1u : 0u) | (lane >= ncA ? 1u : 0u);
+                const unsigned int badB = (b0w ^ cfg_lo) | (b1 ^ cfg_hi) | (dnB ^ (deB >> 15)) |
+                                          (b3 >= (unsigned)p.n_nodes ? 1u : 0u) | (rbB == 0u ? 1u : 0u) | (lane >= ncB ? 1u : 0u);
+                mAppA = wave_ballot(badA == 0u) & wave_ballot((deA & kSlotMask) != kNoSlot);
+                mAppB = wave_ballot(badB == 0u) & wave_ballot((deB & kSlotMask) != kNoSlot);
+                appA = (badA == 0u) & ((deA & kSlotMask) != kNoSlot);
+                appB = (badB == 0u) & ((deB & kSlotMask) != kNoSlot);
+                if (!s.seen_down) s.seen_down = (wave_ballot((badA | (dnA ^ 1u)) == 0u) | wave_ballot((badB | (dnB ^ 1u)) == 0u)) != 0ull;
+            }
+            const unsigned int slotA = deA & kSlotMask, slotB = deB & kSlotMask;
+            unsigned int oldA = 0, oldB = 0;
+            if (appA) oldA = d.or_bits((int)slotA, rbA);
+            if (appB) oldB = d.or_bits((int)slotB, rbB);
+            const unsigned int okA = oldA & d.kmask, okB = oldB & d.kmask;
+            const int c0A = __popc(okA), c1A = __popc(okA | rbA), c0B = __popc(okB), c1B = __popc(okB | rbB);
+            const unsigned long long mLA = mAppA & wave_ballot(c0A < d.L) & wave_ballot(c1A >= d.L);
+            const unsigned long long mLB = mAppB & wave_ballot(c0B < d.L) & wave_ballot(c1B >= d.L);
+            const unsigned long long mHA = mAppA & wave_ballot(c0A < d.H) & wave_ballot(c1A >= d.H);
+            const unsigned long long mHB = mAppB & wave_ballot(c0B < d.H) & wave_ballot(c1B >= d.H);
+            const int nLc = __popcll(mLA) + __popcll(mLB);
+            const int nHc = __popcll(mHA) + __popcll(mHB);
+            const unsigned long long mXA = mLA & wave_ballot((deA & kDictHasAdj) != 0u);
+            const unsigned long long mXB = mLB & wave_ballot((deB & kDictHasAdj) != 0u);
+            int pairs_new = pend_pairs, npend_new = s.npend;
+            if (__builtin_expect((mXA | mXB) != 0ull, 0)) {  // entrants with hot adjacency: bound their pairs, queue them
+                const bool entA = ((mXA >> lane) & 1ull) != 0ull, entB = ((mXB >> lane) & 1ull) != 0ull;
+                const int degA = entA ? (int)adj_off[slotA + 1] - (int)adj_off[slotA] : 0;
+                const int degB = entB ? (int)adj_off[slotB + 1] - (int)adj_off[slotB] : 0;
+                for (unsigned long long m = mXA; m != 0ull; m &= m - 1ull)
+                    pairs_new += lane_value(degA, __ffsll((long long)m) - 1);
+                for (unsigned long long m = mXB; m != 0ull; m &= m - 1ull)
+                    pairs_new += lane_value(degB, __ffsll((long long)m) - 1);
+                const int posA = npend_new + __popcll(mXA & lanes_lt(lane));
+                const int posB = npend_new + __popcll(mXA) + __popcll(mXB & lanes_lt(lane));
+                if (entA && posA < kPendCap) pend[posA] = (unsigned short)slotA;
+                if (entB && posB < kPendCap) pend[posB] = (unsigned short)slotB;
+                npend_new += __popcll(mXA) + __popcll(mXB);
+                if (npend_new > kPendCap) pairs_new = 0x3FFFFFFF;  // forces the roll-back exit
+            }
+            const int hx = nHc + pairs_new;
+            if (__builtin_expect((hx != 0 && s.running - hx < 1) || (mEA | mEB) == 0ull, 0)) {
+#ifdef RAPID_TRACE
+                if (lane == 0) fprintf(stderr, "W-fail r=%d pos=%d run=%d nHc=%d pairs=%d->%d npend=%d noE=%d\n", r, pos, s.running, nHc, pend_pairs, pairs_new, s.npend, (int)((mEA | mEB) == 0ull));
+#endif
+                const unsigned int newA = rbA & ~oldA, newB = rbB & ~oldB;
+                if (appA && newA != 0u) d.clear_bits((int)slotA, newA);
+                if (appB && newB != 0u) d.clear_bits((int)slotB, newB);
+                s.seen_down = seen_before;
+                wave_lds_fence();
+                return 0;
+            }
+            s.running += nLc - nHc;
+            s.batch += __popcll(mEA) + __popcll(mEB);
+            s.npend = npend_new;
+            pend_pairs = pairs_new;
+            pos += ncA + ncB;
             return 1;
         };
 
@@ -629,6 +745,44 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             pos += ncons;
         };
 
+        // ---- the record stream: LDS-DMA into this wave's ring, kDepth KiB always in flight ----
+        // Stream KiB k (bytes [1024 k, 1024 k + 1024) from the receiver's 16-B aligned start) lives in ring slot
+        // k % kRingSlots.  `landed` KiB have arrived (and, for slots 0/1, been copied to the mirror behind the ring);
+        // KiB landed .. landed + kDepth - 1 are in flight, so one more has landed once at most kDepth - 1 loads are
+        // outstanding.  KiB past the end of the stream are out of range of the buffer resource: they cost no memory
+        // traffic but keep the count of outstanding loads constant, which keeps every wait a compile-time constant.
+        int landed = 0, slot_landed = 0;  // slot_landed = landed % kRingSlots
+        auto stream_start = [&]() {
+            wait_dma<0>();  // nothing issued for an earlier receiver / an abandoned pass is still landing
+            wave_lds_fence();
+            landed = 0;
+            slot_landed = 0;
+#pragma unroll
+            for (int k = 0; k < kDepth; ++k) lds_dma16(rsrc, lane16, (unsigned int)k * kSlotBytes, ring_lds + k * kSlotBytes);
+        };
+        // Makes the records [pos, end_rec) resident.  A slot is recycled only when every record in it has been
+        // consumed: a window of <= 128 records touches <= kWindowSlots slots, so need <= kp + kWindowSlots (kp = the KiB
+        // `pos` lies in) and the KiB issued here, landed + kDepth, reuses the slot of KiB landed + kDepth - kRingSlots < kp.
+        auto stream_ensure = [&](int end_rec) {
+            const int need = (int)((unsigned int)(delta + kRecBytes * end_rec + kSlotBytes - 1) / (unsigned int)kSlotBytes);
+            while (landed < need) {
+                RAPID_T0(te0);
+                wait_dma<kDepth - 1>();
+                RAPID_T1(t_ensure, te0);
+                wave_lds_fence();
+                if (slot_landed == 0) ring16[lane + kRingBytes / 16] = ring16[lane];  // mirror the head of the ring behind it
+                if (slot_landed == 1 && lane < (kMirrorBytes - kSlotBytes) / 16) ring16[lane + kWave + kRingBytes / 16] = ring16[lane + kWave];
+                int slot_issue = slot_landed + kDepth;
+                if (slot_issue >= kRingSlots) slot_issue -= kRingSlots;
+                lds_dma16(rsrc, lane16, (unsigned int)(landed + kDepth) * kSlotBytes, ring_lds + slot_issue * kSlotBytes);
+                ++landed;
+                if (++slot_landed == kRingSlots) slot_landed = 0;
+                wave_lds_fence();
+            }
+        };
+
+        int lean_run = 0;           // records the lean path consumed since it was last entered
+        bool from_careful = false;  // entrants may have been carried over from the careful path
         while (emit_batch < 0 && (restart || pos < nrec)) {
             if (restart) {
                 // ---- detector state: nothing reported yet ----
@@ -646,22 +800,25 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 restart = false;
                 careful_budget = 0;
                 careful_cap = kWave;
-                wave_lds_fence();
+                lean_run = 0;
+                from_careful = false;
+                stream_start();
                 continue;
             }
-            const int t_first = (delta + kRecBytes * pos) / kTileBytes;
+            if ((p.flags & 32) != 0) {  // measurement aid: stream the records through the ring without tallying them
+                stream_ensure(min(pos + 2 * kWave, nrec));
+                pos = min(pos + 2 * kWave, nrec);
+                continue;
+            }
             if (exact_only || s.batch_emitted || s.need_full || careful_budget > 0 || (p.flags & 8) != 0) {
-                // ================= CAREFUL loop: one sub-chunk, tiles loaded synchronously =================
-                ring_tile0 = t_first;
-                wave_lds_fence();
-#pragma unroll
-                for (int tt = 0; tt < kRingTiles; ++tt) {
-#pragma unroll
-                    for (int m = 0; m < kTileVec; ++m)
-                        reinterpret_cast<uint4*>(stage + tt * kTileBytes)[lane + kWave * m] =
-                            buffer_load16(rsrc, lane16 + 1024u * m, (unsigned int)(t_first + tt) * kTileBytes);
-                }
-                wave_lds_fence();
+                // ================= CAREFUL path: one sub-chunk of <= 64 records =================
+                n_careful++;
+#ifdef RAPID_TRACE
+                if (lane == 0) fprintf(stderr, "C r=%d pos=%d run=%d npend=%d cap=%d budget=%d\n", r, pos, s.running, s.npend, careful_cap, careful_budget);
+#endif
+                from_careful = true;
+                stream_ensure(min(pos + kWave, nrec));
+                RAPID_T0(tc0);
                 decode();
                 if (exact_only || s.batch_emitted) {
                     exact_subchunk();
@@ -672,115 +829,80 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     // replaying all of them one by one: the record-by-record path only ever runs on a few records.
                     if (ncons > 4) {
                         careful_cap = ncons / 2;
+                        RAPID_T1(t_careful, tc0);
                         continue;  // same position, smaller sub-chunk
                     }
                     exact_subchunk();
                     careful_cap = kWave;
                 }
                 if (careful_budget > 0) --careful_budget;
+                RAPID_T1(t_careful, tc0);
                 continue;
             }
-            // ================= PIPELINED loop: two register sets of kPrefetch tiles =================
-            // Set A (the round being consumed) was issued a whole round earlier; set B (the next round) is issued
-            // while A is consumed.  All vector-memory traffic is unconditional and statically indexed, so every wait
-            // is for the OLDEST outstanding tile only and 8-16 KiB per wave stay in flight.  Tiles past the end of
-            // the stream are out of range of the receiver's buffer resource: they return zeros without touching memory.
-            ring_tile0 = t_first;
-            if (s.npend > 0) {  // entrants carried over from the careful loop: re-establish the bound on their pairs
-                int dsum = 0;
-                for (int i0 = 0; i0 < s.npend; i0 += kWave) {
-                    const int i = i0 + lane;
-                    const int e = i < s.npend ? (int)pend[i] : -1;
-                    int dg = (e >= 0 && e < d.n_scan) ? (int)adj_off[e + 1] - (int)adj_off[e] : 0;
-                    for (int o2 = 32; o2 > 0; o2 >>= 1) dg += __shfl_xor(dg, o2, kWave);
-                    dsum += uniform(dg);
-                }
-                pend_pairs = dsum;
-                if (s.running - pend_pairs < 1) {  // the lean invariant does not hold yet: one more careful sub-chunk
-                    careful_budget = 1;
-                    continue;
-                }
-            } else {
+            // ================= LEAN path: order-free windows, implicit invalidation deferred =================
+            if (from_careful) {
+                from_careful = false;
+                lean_run = 0;
                 pend_pairs = 0;
+                if (s.npend > 0) {  // entrants carried over from the careful path: re-establish the bound on their pairs
+                    int dsum = 0;
+                    for (int i0 = 0; i0 < s.npend; i0 += kWave) {
+                        const int i = i0 + lane;
+                        const int e = i < s.npend ? (int)pend[i] : -1;
+                        int dg = (e >= 0 && e < d.n_scan) ? (int)adj_off[e + 1] - (int)adj_off[e] : 0;
+                        for (int o2 = 32; o2 > 0; o2 >>= 1) dg += __shfl_xor(dg, o2, kWave);
+                        dsum += uniform(dg);
+                    }
+                    pend_pairs = dsum;
+                    if (s.running - pend_pairs < 1) {  // the lean invariant does not hold yet: one more careful sub-chunk
+                        careful_budget = 1;
+                        continue;
+                    }
+                }
             }
-            uint4 a0_, a1_, a2_, a3_, a4_, a5_, a6_, a7_, b0_, b1_, b2_, b3_, b4_, b5_, b6_, b7_;
-#define RAPID_LOAD(jrel, x0, x1)                                                        \
-    {                                                                                   \
-        const unsigned int toff_ = (unsigned int)(t_first + (jrel)) * kTileBytes;       \
-        x0 = buffer_load16(rsrc, lane16, toff_);                                        \
-        x1 = buffer_load16(rsrc, lane16 + 1024u, toff_);                                \
-    }
-#define RAPID_STEP(q, x0, x1)                                                                              \
-    {                                                                                                      \
-        const int jrel_ = jb + (q);                                                                        \
-        wave_lds_fence(); /* every lane is done decoding from the slot about to be overwritten */         \
-        uint4* slot_ = reinterpret_cast<uint4*>(stage + ((q) % kRingTiles) * kTileBytes);                  \
-        slot_[lane] = x0;                                                                                  \
-        slot_[lane + kWave] = x1;                                                                          \
-        if (((q) % kRingTiles) == 0) { /* mirror the head of slot 0 behind the ring */                     \
-            slot_[lane + kRingBytes / 16] = x0;                                                            \
-            if (lane < (kMirrorBytes - 1024) / 16) slot_[lane + kWave + kRingBytes / 16] = x1;             \
-        }                                                                                                  \
-        wave_lds_fence();                                                                                  \
-        /* consume every sub-chunk whose records lie entirely in stream tiles <= t_first + jrel_: with lim_ = */ \
-        /* records fully loaded, that is  pos + 64 <= lim_  or, once the whole stream is loaded, pos < nrec */ \
-        const int lim_ = ((t_first + jrel_ + 1) * kTileBytes - delta) / kRecBytes;                         \
-        const int lim2_ = stop ? pos : (nrec <= lim_ ? nrec : lim_ - (kWave - 1));                        \
-        while (pos < lim2_) {                                                                              \
-            if (!lean_subchunk()) {                                                                        \
-                stop = 1;                                                                                  \
-                break;                                                                                     \
-            }                                                                                              \
-        }                                                                                                  \
-    }
-            static_assert(kPrefetch == 4 && kTileVec == 2 && kRingTiles == 2, "tile pipeline is written for 4 x 2 KiB");
-            static_assert(kMirrorBytes > 1024 && kMirrorBytes <= 2048, "mirror = one full + one partial 16-B store");
-            RAPID_LOAD(0, a0_, a1_)
-            RAPID_LOAD(1, a2_, a3_)
-            RAPID_LOAD(2, a4_, a5_)
-            RAPID_LOAD(3, a6_, a7_)
-            int stop = 0;
             const int pos_in = pos;
-            // Two rounds per trip; each register set is reloaded IN PLACE half a trip before it is consumed again, so
-            // no in-flight value is ever copied and every wait is for loads issued a whole round earlier:
-            //   [load B] [consume A] [load A] [consume B]
-            const int jend = ((ntiles - t_first + 2 * kPrefetch - 1) / (2 * kPrefetch)) * (2 * kPrefetch);
-            for (int jb = 0; jb < jend; jb += 2 * kPrefetch) {
-                RAPID_LOAD(jb + 4, b0_, b1_)
-                RAPID_LOAD(jb + 5, b2_, b3_)
-                RAPID_LOAD(jb + 6, b4_, b5_)
-                RAPID_LOAD(jb + 7, b6_, b7_)
-                RAPID_STEP(0, a0_, a1_)
-                RAPID_STEP(1, a2_, a3_)
-                RAPID_STEP(2, a4_, a5_)
-                RAPID_STEP(3, a6_, a7_)
-                // the deferred implicit invalidation (cannot emit, see above): when enough entrants are queued, and
-                // always before the loop is left
-                if (s.npend >= kPendCap / 4 || stop) flush_pending();
-                if (stop) break;
-                RAPID_LOAD(jb + 8, a0_, a1_)
-                RAPID_LOAD(jb + 9, a2_, a3_)
-                RAPID_LOAD(jb + 10, a4_, a5_)
-                RAPID_LOAD(jb + 11, a6_, a7_)
-                RAPID_STEP(4, b0_, b1_)
-                RAPID_STEP(5, b2_, b3_)
-                RAPID_STEP(6, b4_, b5_)
-                RAPID_STEP(7, b6_, b7_)
-                if (s.npend >= kPendCap / 4 || stop) flush_pending();
-                if (stop) break;
+            bool gave_up = false;
+            // wide windows while 128 records are left, then the tail in single-record-per-lane sub-chunks
+            while (nrec - pos >= 2 * kWave) {
+                stream_ensure(pos + 2 * kWave);
+                RAPID_T0(tl0);
+                const int ok_ = lean_wide();
+                RAPID_T1(t_lean, tl0);
+                if (!ok_) {
+                    // flush what is pending (when that is allowed) and try once more: the bound on the pending pairs is
+                    // usually what failed, and it is gone after the flush
+                    if (s.npend > 0 && s.seen_down && !s.need_full && s.running - pend_pairs >= 1) {
+                        flush_pending();
+                        if (lean_wide()) continue;
+                    }
+                    gave_up = true;
+                    break;
+                }
+                // the deferred implicit invalidation (cannot emit, see flush_pending) once enough entrants are queued
+                if (s.npend >= kPendCap / 4) {
+                    RAPID_T0(tf0);
+                    flush_pending();
+                    RAPID_T1(t_flush, tf0);
+                }
             }
-            flush_pending();  // leaves nothing deferred behind (a no-op unless the stream ended inside the loop)
-#undef RAPID_STEP
-#undef RAPID_LOAD
-            n_fast += (unsigned long long)((pos - pos_in + kWave - 1) / kWave);  // lean sub-chunks, to within rounding
+            while (!gave_up && pos < nrec) {
+                stream_ensure(nrec);
+                if (!lean_subchunk()) gave_up = true;
+            }
+            n_fast += (unsigned long long)((pos - pos_in + 2 * kWave - 1) / (2 * kWave));
             n_records += (unsigned long long)(pos - pos_in);
-            if (stop) {
-                // the lean path could not exclude an emission: take the next sub-chunks through the careful loop,
-                // for longer and longer if the pipelined loop keeps giving up immediately
-                careful_next = (pos - pos_in < 4 * kWave) ? min(careful_next * 2, 64) : 2;
+            lean_run = pos - pos_in;
+            if (gave_up) {
+                // the lean path could not exclude an emission: take the next sub-chunks through the careful path, for
+                // longer and longer if the lean path keeps giving up immediately
+                n_pipe++;
+                flush_pending();
+                careful_next = (lean_run < 4 * kWave) ? min(careful_next * 2, 16) : 2;
                 careful_budget = careful_next;
             }
         }
+        wait_dma<0>();  // the ring is reused by the next receiver
+        RAPID_T0(to0);
 
         // ---- outputs: the proposal = every flushed (hot) slot, ascending node index ----
         int count = 0;
@@ -810,14 +932,35 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             p.fingerprint[r] = fp;
         }
         wave_lds_fence();
+        RAPID_T1(t_out, to0);
+#ifdef RAPID_PHASE_TIMERS
+        t_rx++;
+#endif
     }
+#ifdef RAPID_PHASE_TIMERS
+    RAPID_T1(t_total, t_kernel0);
     if (lane == 0 && p.stats != nullptr) {
+        atomicAdd(&p.stats[0], t_total);
+        atomicAdd(&p.stats[1], t_ensure);
+        atomicAdd(&p.stats[2], t_lean);
+        atomicAdd(&p.stats[3], t_careful);
+        atomicAdd(&p.stats[4], t_out);
+        atomicAdd(&p.stats[5], t_flush);
+        atomicAdd(&p.stats[6], t_rx);
+        atomicAdd(&p.stats[7], n_fast);
+    }
+    if (false) {
+#else
+    if (lane == 0 && p.stats != nullptr) {
+#endif
         atomicAdd(&p.stats[0], n_slow);
         atomicAdd(&p.stats[1], n_fast);
         atomicAdd(&p.stats[2], (unsigned long long)n_full);
         atomicAdd(&p.stats[3], n_restart);
         atomicAdd(&p.stats[4], (unsigned long long)n_applied);
         atomicAdd(&p.stats[5], n_records);
+        atomicAdd(&p.stats[6], n_pipe);
+        atomicAdd(&p.stats[7], n_careful);
     }
 }
 
