@@ -35,6 +35,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include <lds_dma.h>
 
 namespace rapid {
@@ -43,10 +45,10 @@ constexpr int kWave = 64;
 constexpr int kRecBytes = 20;
 constexpr int kSlotBytes = 1024;                     // one LDS-DMA wave instruction: 64 lanes x 16 B
 constexpr int kWindowSlots = 4;                      // a 128-record window (2560 B) at any alignment touches <= 4 slots
-constexpr int kDepth = 8;                            // KiB kept in flight per wave
+constexpr int kDepth = 6;                            // KiB kept in flight per wave
 constexpr int kRingSlots = kWindowSlots + kDepth;    // LDS ring the windows are decoded from
-constexpr int kRingBytes = kSlotBytes * kRingSlots;
-constexpr int kMirrorBytes = kWave * kRecBytes;      // head of slot 0 repeated after the ring: a 64-record read never wraps
+constexpr int kRingBytes = kSlotBytes * kRingSlots;  // 10 KiB = 512 records exactly: records never straddle the ring's end
+static_assert(kRingBytes % kRecBytes == 0, "the ring must hold a whole number of records");
 constexpr int kPendCap = 128;                        // slots that crossed L and still await invalidation
 constexpr int kUndoCap = 128;                        // implicit bits set inside one sub-chunk
 constexpr int kMaxWavesPerBlock = 16;
@@ -93,10 +95,10 @@ struct TallyParams {
 __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
 // LDS budget: shared tables (only when they are staged in LDS) + per-wave detector state, ring, lists
 __host__ __device__ inline int tally_shared_bytes(int n_nodes, int n_hot, int n_adj) {
-    return align16(n_nodes * 2) + align16((n_hot + 1) * 2) + align16(n_adj * 4);
+    return align16(n_nodes * 2) + align16((n_hot + 1) * 2) + align16(n_adj * 4) + align16(n_hot * 4);
 }
 __host__ __device__ inline int tally_wave_bytes(int n_slots) {
-    return align16(n_slots * 4) + kRingBytes + kMirrorBytes + align16(kPendCap * 2) + kUndoCap * 4;
+    return align16(n_slots * 4) + kRingBytes + align16(kPendCap * 2) + kUndoCap * 4;
 }
 
 // ---- small wave helpers ---------------------------------------------------------------------------------------
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     const unsigned short* dict = p.idx.dict;
     const unsigned short* adj_off = p.idx.adj_off;
     const unsigned int* adj = p.idx.adj;
+    const int* node_of_slot = p.idx.node_of_slot;
     int shared_bytes = 0;
     if (kTablesInLds) {
         unsigned short* l_dict = reinterpret_cast<unsigned short*>(smem);
@@ -380,6 +383,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         for (int i = (int)threadIdx.x; i < p.n_nodes; i += (int)blockDim.x) l_dict[i] = p.idx.dict[i];
         for (int i = (int)threadIdx.x; i < p.idx.n_hot + 1; i += (int)blockDim.x) l_off[i] = p.idx.adj_off[i];
         for (int i = (int)threadIdx.x; i < p.idx.n_adj; i += (int)blockDim.x) l_adj[i] = p.idx.adj[i];
+        int* l_nos = reinterpret_cast<int*>(smem + align16(p.n_nodes * 2) + align16((p.idx.n_hot + 1) * 2) + align16(p.idx.n_adj * 4));
+        for (int i = (int)threadIdx.x; i < p.idx.n_hot; i += (int)blockDim.x) l_nos[i] = p.idx.node_of_slot[i];
+        node_of_slot = l_nos;
         dict = l_dict;
         adj_off = l_off;
         adj = l_adj;
@@ -391,10 +397,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     const int state_bytes = align16(p.idx.n_hot * 4);
     unsigned char* const mine = smem + shared_bytes + wave * tally_wave_bytes(p.idx.n_hot);
     unsigned char* const stage = mine + state_bytes;
-    unsigned short* const pend = reinterpret_cast<unsigned short*>(stage + kRingBytes + kMirrorBytes);
-    unsigned int* const undo = reinterpret_cast<unsigned int*>(stage + kRingBytes + kMirrorBytes + align16(kPendCap * 2));
+    unsigned short* const pend = reinterpret_cast<unsigned short*>(stage + kRingBytes);
+    unsigned int* const undo = reinterpret_cast<unsigned int*>(stage + kRingBytes + align16(kPendCap * 2));
     const unsigned int* const ring32 = reinterpret_cast<const unsigned int*>(stage);
-    uint4* const ring16 = reinterpret_cast<uint4*>(stage);
     const lds_addr_t ring_lds = lds_uniform(lds_address(stage));
 
     SlotDetector d;
@@ -416,29 +421,69 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     int n_applied = 0, n_full = 0;
     const int lane20 = lane * kRecBytes;
 
-    for (;;) {
-        int r = 0;
-        if (lane == 0) r = (int)atomicAdd(p.next_receiver, 1u);
-        r = uniform(r);
-        if (r >= p.n_receivers) break;
-
-        const long long rec0 = p.rec_off[r];
-        const int nrec = (int)(p.rec_off[r + 1] - rec0);
-        const unsigned long long b0 = (unsigned long long)rec0 * kRecBytes;
-        const unsigned long long a0 = b0 & ~15ull;  // 16-B aligned start of this receiver's byte range
-        const int delta = (int)(b0 - a0);
-        // this receiver's bytes, 16-B aligned start, as a buffer resource (wave-uniform)
-        unsigned long long span = ((unsigned long long)delta + (unsigned long long)nrec * kRecBytes + 15ull) & ~15ull;
+    // Receivers are handed out by a global counter, two steps ahead: while receiver r is processed, the index of r''
+    // is on its way (atomic issued at the start of r) and the stream bounds of r' are loaded, so that at the end of r
+    // the stream of r' is started BEFORE r's results are written -- neither the counter, nor the offsets, nor the first
+    // KiB of the next stream are waited for between receivers.
+    const unsigned int lane16 = (unsigned int)lane * 16u;
+    auto fetch_index = [&]() -> int {
+        int v = 0;
+        if (lane == 0) v = (int)atomicAdd(p.next_receiver, 1u);
+        return v;  // lane 0 holds the index; made uniform where it is consumed
+    };
+    // the stream of a receiver as the ring sees it
+    struct Stream {
+        dma_rsrc_t rsrc;
+        int delta, nrec;
+    };
+    // The ring starts 0..3 records BEFORE the receiver's first one, at the 16-B aligned address a0 = b0 - 20 m with
+    // m = rec0 mod 4: stream byte 20 (i + m) holds record i, and since the ring is a whole number of records (512) no
+    // record ever straddles its end.
+    auto make_stream = [&](long long rec0, long long rec1) -> Stream {
+        Stream st;
+        st.nrec = (int)(rec1 - rec0);
+        st.delta = (int)(rec0 & 3) * kRecBytes;
+        const unsigned long long a0 = (unsigned long long)rec0 * kRecBytes - (unsigned long long)st.delta;
+        unsigned long long span = ((unsigned long long)st.delta + (unsigned long long)st.nrec * kRecBytes + 15ull) & ~15ull;
         if (a0 + span > p.records_bytes) span = p.records_bytes > a0 ? p.records_bytes - a0 : 0ull;
-        const dma_rsrc_t rsrc = dma_make_rsrc(p.records + a0, (unsigned int)(span > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : span));
-        const unsigned int lane16 = (unsigned int)lane * 16u;
+        st.rsrc = dma_make_rsrc(p.records + a0, (unsigned int)(span > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : span));
+        return st;
+    };
+    auto uniform64 = [&](long long v) -> long long {
+        return ((long long)uniform((unsigned int)((unsigned long long)v >> 32)) << 32) | (long long)uniform((unsigned int)(unsigned long long)v);
+    };
+    auto issue_head = [&](const Stream& st) {  // the first kDepth KiB of a stream into ring slots 0 .. kDepth - 1
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) lds_dma16(st.rsrc, lane16, (unsigned int)k * kSlotBytes, ring_lds + k * kSlotBytes);
+    };
+
+    int r = uniform(fetch_index());
+    Stream cur = make_stream(0, 0);
+    if (r < p.n_receivers) cur = make_stream(p.rec_off[r], p.rec_off[r + 1]);
+    int r_next_v = fetch_index();
+    bool prestarted = false;  // the head of `cur` is already on its way into the ring
+    while (r < p.n_receivers) {
+        const int r_next = uniform(r_next_v);  // issued a whole receiver ago
+        long long n0_v = 0, n1_v = 0;          // lane 0: stream bounds of r_next, consumed after this receiver's stream
+        if (lane == 0 && r_next < p.n_receivers) {
+            n0_v = p.rec_off[r_next];
+            n1_v = p.rec_off[r_next + 1];
+        }
+        r_next_v = fetch_index();
+        const dma_rsrc_t rsrc = cur.rsrc;
+        const int delta = cur.delta, nrec = cur.nrec;
 
         int emit_batch = -1;
         RxScalars s;
-        int pend_pairs = 0;   // upper bound on the H crossings the pending (not yet invalidated) entrants can cause
         bool exact_only = (p.flags & 1) != 0;
         bool restart = true;  // (re)initialise the detector before the first sub-chunk
         int pos = 0;          // next unconsumed record
+        int ring_pos = delta;  // its byte offset in the ring: (delta + 20 pos) mod kRingBytes
+        auto advance = [&](int n) {  // n <= 128 records consumed
+            pos += n;
+            ring_pos += n * kRecBytes;
+            if (ring_pos >= kRingBytes) ring_pos -= kRingBytes;
+        };
         int careful_budget = 0, careful_next = 2;
         int careful_cap = kWave;  // records the careful loop takes at once; halved while an emission cannot be excluded
 
@@ -448,11 +493,12 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         bool down = false, eob = false, hasadj = false;
         unsigned long long mE_all = 0ull;
 
-        // ---- decode the sub-chunk starting at `pos` from the LDS ring (the mirror makes it wrap-free) ----
+        // ---- decode the sub-chunk starting at `pos` from the LDS ring ----
         auto decode = [&]() {
             const int navail = min(careful_cap, nrec - pos);
-            const int base = (int)((unsigned int)(delta + kRecBytes * pos) % (unsigned int)kRingBytes);
-            const unsigned int* w = ring32 + ((base + lane20) >> 2);
+            unsigned int t = (unsigned int)(ring_pos + lane20);
+            t = min(t, t - (unsigned int)kRingBytes);  // per-lane wrap
+            const unsigned int* w = ring32 + (t >> 2);
             const unsigned int w0 = w[0], w1 = w[1], w3 = w[3], w4 = w[4];
             down = ((w4 >> 16) & 0xFFu) != 0;
             eob = lane < navail && ((((w4 >> 24) & 1u) != 0) || pos + lane == nrec - 1);
@@ -474,181 +520,128 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             bits = (okf & hot) ? (w4 & d.kmask) : 0u;
         };
 
-        // ---- apply the pending implicit invalidation.  Only called while running - pend_pairs >= 1 holds, so it
-        // cannot produce an emission (the H crossings it causes are bounded by pend_pairs). ----
+        // ---- apply the deferred implicit invalidation for the entrants queued by the lean path.  Every report applied
+        // here was applied by the reference at a batch end inside a window already certified emission-free, and the
+        // certificate's witness (see below) takes no implicit reports, so this cannot be where an emission happens.
         auto flush_pending = [&]() {
             if (s.npend == 0 || !s.seen_down || s.need_full) return;
-            if (s.running - pend_pairs < 1) return;  // an emission cannot be excluded: left to the careful loop
             wave_lds_fence();
             int applied = 0;
-            const int nH = invalidate_adj(d, pend, s.npend, false, nullptr, nullptr, lane, &applied);
-            s.running -= nH;
+            (void)invalidate_adj(d, pend, s.npend, false, nullptr, nullptr, lane, &applied);
             s.npend = 0;
-            pend_pairs = 0;
             n_applied += applied;
         };
 
-        // ---- LEAN path (pipelined loop): decode + order-free application of the sub-chunk starting at `pos`; the
-        // implicit invalidation is deferred to the end of the tile round.  No emission is possible as long as
-        // running - pend_pairs - (H crossings here) >= 1.  Returns false -- with the sub-chunk rolled back and
-        // nothing consumed -- when that cannot be shown.  Written with lane MASKS (scalar registers) rather than
-        // per-lane booleans: predicates cost one v_cmp each and combine with scalar ANDs.
-        auto lean_subchunk = [&]() -> int {
-            const int navail = min(kWave, nrec - pos);
-            const int base = (int)((unsigned int)(delta + kRecBytes * pos) % (unsigned int)kRingBytes);
-            const unsigned int* w = ring32 + ((base + lane20) >> 2);
-            const unsigned int w3 = w[3], w4 = w[4];
-            // batch ends among the available records (the last record of the stream always closes a batch)
-            const unsigned long long mE =
-                wave_ballot((lane < navail) & (((w4 & 0x01000000u) != 0u) | (pos + lane == nrec - 1)));
-            // consume up to the last batch end; a batch longer than a sub-chunk (mE == 0) is left to the careful loop
-            // through the common roll-back exit below, which keeps this code straight-line
-            const int nc = mE != 0ull ? kWave - __clzll((long long)mE) : navail;
-            const unsigned int rb = w4 & d.kmask;
-            const bool seen_before = s.seen_down;
-            unsigned int de, slot;
-            bool app;
-            if (kTrusted) {
-                de = (unsigned int)dict[lane < nc ? w3 : 0u];  // lanes past the consumed records hold stale ring bytes
-                slot = de & kSlotMask;
-                app = (lane < nc) & (slot != kNoSlot);
-                // every consumed alert passed the filter; the first DOWN one sets seenLinkDownEvents
-                if (!s.seen_down) s.seen_down = wave_ballot((lane < nc) & ((w4 & 0x00FF0000u) != 0u)) != 0ull;
-            } else {
-                // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot
-                const unsigned int w0 = w[0], w1 = w[1];
-                const unsigned int node = w3 < (unsigned)p.n_nodes ? w3 : 0u;
-                de = (unsigned int)dict[node];
-                const unsigned int dn = (w4 & 0x00FF0000u) != 0u ? 1u : 0u;
-                // bad == 0 <=> the record is consumed here AND passes the filter
-                const unsigned int bad = (w0 ^ cfg_lo) | (w1 ^ cfg_hi) | (dn ^ (de >> 15)) |
-                                         (w3 >= (unsigned)p.n_nodes ? 1u : 0u) | (rb == 0u ? 1u : 0u) | (lane >= nc ? 1u : 0u);
-                slot = de & kSlotMask;
-                app = (bad | (slot == kNoSlot ? 1u : 0u)) == 0u;
-                if (!s.seen_down) s.seen_down = wave_ballot((bad | (dn ^ 1u)) == 0u) != 0ull;
+        // ---- one pass over the hot slots: updatesInProgress (slots with L <= count < H) as the careful path needs it,
+        // and a WITNESS for the lean path -- a slot in [L, H) with no hot adjacency (so it never takes an implicit
+        // report and its count here is the reference's count), the one with the fewest reports.  -1 if there is none.
+        int witness = -1;
+        auto recount = [&]() {
+            wave_lds_fence();
+            int run = 0;
+            unsigned int best = 0xFFFFFFFFu;  // count << 16 | slot
+            for (int i0 = 0; i0 < d.n_scan; i0 += kWave) {
+                const int i = i0 + lane;
+                const unsigned int m = i < d.n_scan ? d.load(i) : 0u;
+                const int c = d.count(m);
+                const bool pre = i < d.n_scan && c >= d.L && c < d.H;
+                run += __popcll(wave_ballot(pre));
+                const bool free_of_adj = pre && adj_off[i + 1] == adj_off[i];
+                const unsigned int key = free_of_adj ? ((unsigned int)c << 16) | (unsigned int)i : 0xFFFFFFFFu;
+                best = min(best, key);
             }
-            unsigned int old = 0;
-            if (app) old = d.or_bits((int)slot, rb);
-            const unsigned int oldk = old & d.kmask;
-            const int c0 = __popc(oldk), c1 = __popc(oldk | rb);
-            const bool isL = app & (c0 < d.L) & (c1 >= d.L);
-            const int nLc = __popcll(wave_ballot(isL));
-            const int nHc = __popcll(wave_ballot(app & (c0 < d.H) & (c1 >= d.H)));
-            const bool ent = isL & ((de & kDictHasAdj) != 0u);
-            const unsigned long long mA = wave_ballot(ent);
-            int pairs_new = pend_pairs, npend_new = s.npend;
-            if (__builtin_expect(mA != 0ull, 0)) {  // entrants with hot adjacency: bound their pairs, queue them (committed below)
-                const int degv = ent ? (int)adj_off[slot + 1] - (int)adj_off[slot] : 0;
-                for (unsigned long long m = mA; m != 0ull; m &= m - 1ull)
-                    pairs_new += lane_value(degv, __ffsll((long long)m) - 1);
-                const int posn = npend_new + __popcll(mA & lanes_lt(lane));
-                if (ent && posn < kPendCap) pend[posn] = (unsigned short)slot;
-                npend_new += __popcll(mA);
-                if (npend_new > kPendCap) pairs_new = 0x3FFFFFFF;  // forces the roll-back exit
-            }
-            // an emission is impossible if no H crossing can bring updatesInProgress to 0: the pending implicit
-            // reports can cause at most pairs_new more crossings than the nHc explicit ones counted here
-            const int hx = nHc + pairs_new;
-            if (__builtin_expect((hx != 0 && s.running - hx < 1) || mE == 0ull, 0)) {
-#ifdef RAPID_TRACE
-                if (lane == 0) fprintf(stderr, "N-fail r=%d pos=%d run=%d nHc=%d pairs=%d->%d npend=%d noE=%d\n", r, pos, s.running, nHc, pend_pairs, pairs_new, s.npend, (int)(mE == 0ull));
-#endif
-                const unsigned int newbits = rb & ~old;
-                if (app && newbits != 0u) d.clear_bits((int)slot, newbits);
-                s.seen_down = seen_before;
-                wave_lds_fence();
-                return 0;
-            }
-            s.running += nLc - nHc;
-            s.batch += __popcll(mE);
-            s.npend = npend_new;
-            pend_pairs = pairs_new;
-            pos += nc;
-            return 1;
+            for (int o2 = 32; o2 > 0; o2 >>= 1) best = min(best, (unsigned int)__shfl_xor((int)best, o2, kWave));
+            best = uniform(best);
+            s.running = run;
+            witness = best == 0xFFFFFFFFu ? -1 : (int)(best & 0xFFFFu);
         };
 
-        // ---- WIDE lean path: the same order-free application on TWO records per lane (records pos .. pos+127, all
-        // inside the stream and resident in the ring), so the wave-uniform bookkeeping -- window cut, safety test,
-        // counters -- is paid once per 128 records.  Half A = records pos+lane, half B = records pos+64+lane; each
-        // half is a contiguous 1280-byte read that the mirror keeps wrap-free.  LDS atomics of one wave execute in
-        // program order, so B's ds_or_rtn sees A's bits and every threshold crossing is still counted exactly once.
-        auto lean_wide = [&]() -> int {
-            const int baseA = (int)((unsigned int)(delta + kRecBytes * pos) % (unsigned int)kRingBytes);
-            const int baseB = baseA + kWave * kRecBytes - (baseA + kWave * kRecBytes >= kRingBytes ? kRingBytes : 0);
-            const unsigned int* wa = ring32 + ((baseA + lane20) >> 2);
-            const unsigned int* wb = ring32 + ((baseB + lane20) >> 2);
+        // ---- LEAN path: order-free application of a window of up to 128 records, TWO per lane (half A = records
+        // pos + lane, half B = records pos + 64 + lane), cut at its last batch end; the implicit invalidation is
+        // deferred (entrants are queued in pend[]).  The window is committed only with a CERTIFICATE that the reference
+        // cannot emit at any point inside it.  An emission needs updatesInProgress to reach 0
+        // (R/MultiNodeCutDetector.java:110-121), so either of these suffices:
+        //   (a) the witness -- in preProposal before the window, never the target of an implicit report -- still has
+        //       fewer than H reports after the window: it was in preProposal throughout, updatesInProgress >= 1;
+        //   (b) no report of the window takes any subject to H, and no implicit report can be generated in it (nothing
+        //       queued, no entrant with hot adjacency): then nothing crosses H at all.
+        // Counts only grow, LDS atomics of one wave execute in program order (B sees A's bits), and every crossing of
+        // L is seen by exactly one lane, whatever the order.  Returns 0 -- window rolled back, nothing consumed -- when
+        // no certificate holds.  kTail: fewer than 128 records are left (the last record closes the last batch).
+        auto lean_window = [&](auto tail_tag) -> int {
+            constexpr bool kTail = decltype(tail_tag)::value;
+            const int navail = kTail ? nrec - pos : 2 * kWave;
+            unsigned int tA = (unsigned int)(ring_pos + lane20), tB = tA + (unsigned int)(kWave * kRecBytes);
+            tA = min(tA, tA - (unsigned int)kRingBytes);  // per-lane wrap (records never straddle the end of the ring)
+            tB = min(tB, tB - (unsigned int)kRingBytes);
+            const unsigned int* wa = ring32 + (tA >> 2);
+            const unsigned int* wb = ring32 + (tB >> 2);
             const unsigned int a3 = wa[3], a4 = wa[4], b3 = wb[3], b4 = wb[4];
-            const unsigned long long mEA = wave_ballot((a4 & 0x01000000u) != 0u);
-            const unsigned long long mEB = wave_ballot((b4 & 0x01000000u) != 0u);
-            // consume up to the last batch end of the window
+            unsigned long long mEA, mEB;
+            if (kTail) {
+                mEA = wave_ballot((lane < navail) & (((a4 & 0x01000000u) != 0u) | (lane == navail - 1)));
+                mEB = wave_ballot((lane + kWave < navail) & (((b4 & 0x01000000u) != 0u) | (lane + kWave == navail - 1)));
+            } else {
+                mEA = wave_ballot((a4 & 0x01000000u) != 0u);
+                mEB = wave_ballot((b4 & 0x01000000u) != 0u);
+            }
+            // consume up to the last batch end of the window (none at all: a batch longer than the window -> careful path)
             const int ncA = mEB != 0ull ? kWave : (mEA != 0ull ? kWave - __clzll((long long)mEA) : 0);
             const int ncB = mEB != 0ull ? kWave - __clzll((long long)mEB) : 0;
             const unsigned int rbA = a4 & d.kmask, rbB = b4 & d.kmask;
             const bool seen_before = s.seen_down;
             unsigned int deA, deB;
-            unsigned long long mAppA, mAppB;
             bool appA, appB;
             if (kTrusted) {
-                // all 128 records are real, validated alerts: the dictionary lookup needs no clamping
-                deA = (unsigned int)dict[a3];
-                deB = (unsigned int)dict[b3];
-                mAppA = wave_ballot(lane < ncA) & wave_ballot((deA & kSlotMask) != kNoSlot);
-                mAppB = wave_ballot(lane < ncB) & wave_ballot((deB & kSlotMask) != kNoSlot);
+                // every consumed record is a validated alert: the dictionary lookup needs no range check
+                deA = (unsigned int)dict[(!kTail || lane < ncA) ? a3 : 0u];
+                deB = (unsigned int)dict[(!kTail || lane < ncB) ? b3 : 0u];
                 appA = (lane < ncA) & ((deA & kSlotMask) != kNoSlot);
                 appB = (lane < ncB) & ((deB & kSlotMask) != kNoSlot);
                 if (!s.seen_down)
-                    s.seen_down = ((wave_ballot(lane < ncA) & wave_ballot((a4 & 0x00FF0000u) != 0u)) |
-                                   (wave_ballot(lane < ncB) & wave_ballot((b4 & 0x00FF0000u) != 0u))) != 0ull;
+                    s.seen_down = (wave_ballot((lane < ncA) & ((a4 & 0x00FF0000u) != 0u)) |
+                                   wave_ballot((lane < ncB) & ((b4 & 0x00FF0000u) != 0u))) != 0ull;
             } else {
                 // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot, per half
-                const unsigned int a0 = wa[0], a1 = wa[1], b0w = wb[0], b1 = wb[1];
+                const unsigned int a0w = wa[0], a1w = wa[1], b0w = wb[0], b1w = wb[1];
                 deA = (unsigned int)dict[a3 < (unsigned)p.n_nodes ? a3 : 0u];
                 deB = (unsigned int)dict[b3 < (unsigned)p.n_nodes ? b3 : 0u];
                 const unsigned int dnA = (a4 & 0x00FF0000u) != 0u ? 1u : 0u, dnB = (b4 & 0x00FF0000u) != 0u ? 1u : 0u;
-                const unsigned int badA = (a0 ^ cfg_lo) | (a1 ^ cfg_hi) | (dnA ^ (deA >> 15)) |
+                const unsigned int badA = (a0w ^ cfg_lo) | (a1w ^ cfg_hi) | (dnA ^ (deA >> 15)) |
                                           (a3 >= (unsigned)p.n_nodes ? 1u : 0u) | (rbA == 0u ? 1u : 0u) | (lane >= ncA ? 1u : 0u);
-                const unsigned int badB = (b0w ^ cfg_lo) | (b1 ^ cfg_hi) | (dnB ^ (deB >> 15)) |
+                const unsigned int badB = (b0w ^ cfg_lo) | (b1w ^ cfg_hi) | (dnB ^ (deB >> 15)) |
                                           (b3 >= (unsigned)p.n_nodes ? 1u : 0u) | (rbB == 0u ? 1u : 0u) | (lane >= ncB ? 1u : 0u);
-                mAppA = wave_ballot(badA == 0u) & wave_ballot((deA & kSlotMask) != kNoSlot);
-                mAppB = wave_ballot(badB == 0u) & wave_ballot((deB & kSlotMask) != kNoSlot);
                 appA = (badA == 0u) & ((deA & kSlotMask) != kNoSlot);
                 appB = (badB == 0u) & ((deB & kSlotMask) != kNoSlot);
                 if (!s.seen_down) s.seen_down = (wave_ballot((badA | (dnA ^ 1u)) == 0u) | wave_ballot((badB | (dnB ^ 1u)) == 0u)) != 0ull;
             }
             const unsigned int slotA = deA & kSlotMask, slotB = deB & kSlotMask;
+            // both lane masks first: the two atomics then go out back to back, one LDS round trip for the pair
+            const unsigned long long mAppA = wave_ballot(appA), mAppB = wave_ballot(appB);
             unsigned int oldA = 0, oldB = 0;
-            if (appA) oldA = d.or_bits((int)slotA, rbA);
-            if (appB) oldB = d.or_bits((int)slotB, rbB);
+            if ((mAppA >> lane) & 1ull) oldA = d.or_bits((int)slotA, rbA);
+            if ((mAppB >> lane) & 1ull) oldB = d.or_bits((int)slotB, rbB);
+            // The witness's reports AFTER the window: a wave's LDS operations are served in program order, so this read
+            // sees every lane's atomic above without waiting for their results (the barrier is not an instruction; it
+            // keeps the compiler -- and the lane-by-lane emulator -- from moving the read ahead of them).
+            __builtin_amdgcn_wave_barrier();
+            const unsigned int wv = uniform(d.load(witness >= 0 ? witness : 0));
             const unsigned int okA = oldA & d.kmask, okB = oldB & d.kmask;
             const int c0A = __popc(okA), c1A = __popc(okA | rbA), c0B = __popc(okB), c1B = __popc(okB | rbB);
-            const unsigned long long mLA = mAppA & wave_ballot(c0A < d.L) & wave_ballot(c1A >= d.L);
-            const unsigned long long mLB = mAppB & wave_ballot(c0B < d.L) & wave_ballot(c1B >= d.L);
-            const unsigned long long mHA = mAppA & wave_ballot(c0A < d.H) & wave_ballot(c1A >= d.H);
-            const unsigned long long mHB = mAppB & wave_ballot(c0B < d.H) & wave_ballot(c1B >= d.H);
-            const int nLc = __popcll(mLA) + __popcll(mLB);
-            const int nHc = __popcll(mHA) + __popcll(mHB);
-            const unsigned long long mXA = mLA & wave_ballot((deA & kDictHasAdj) != 0u);
-            const unsigned long long mXB = mLB & wave_ballot((deB & kDictHasAdj) != 0u);
-            int pairs_new = pend_pairs, npend_new = s.npend;
-            if (__builtin_expect((mXA | mXB) != 0ull, 0)) {  // entrants with hot adjacency: bound their pairs, queue them
-                const bool entA = ((mXA >> lane) & 1ull) != 0ull, entB = ((mXB >> lane) & 1ull) != 0ull;
-                const int degA = entA ? (int)adj_off[slotA + 1] - (int)adj_off[slotA] : 0;
-                const int degB = entB ? (int)adj_off[slotB + 1] - (int)adj_off[slotB] : 0;
-                for (unsigned long long m = mXA; m != 0ull; m &= m - 1ull)
-                    pairs_new += lane_value(degA, __ffsll((long long)m) - 1);
-                for (unsigned long long m = mXB; m != 0ull; m &= m - 1ull)
-                    pairs_new += lane_value(degB, __ffsll((long long)m) - 1);
-                const int posA = npend_new + __popcll(mXA & lanes_lt(lane));
-                const int posB = npend_new + __popcll(mXA) + __popcll(mXB & lanes_lt(lane));
-                if (entA && posA < kPendCap) pend[posA] = (unsigned short)slotA;
-                if (entB && posB < kPendCap) pend[posB] = (unsigned short)slotB;
-                npend_new += __popcll(mXA) + __popcll(mXB);
-                if (npend_new > kPendCap) pairs_new = 0x3FFFFFFF;  // forces the roll-back exit
+            const unsigned long long mLA = wave_ballot(appA & (c0A < d.L) & (c1A >= d.L));
+            const unsigned long long mLB = wave_ballot(appB & (c0B < d.L) & (c1B >= d.L));
+            // entrants with hot adjacency (their implicit reports are owed) / without (witness material)
+            const unsigned long long mJA = wave_ballot((deA & kDictHasAdj) != 0u), mJB = wave_ballot((deB & kDictHasAdj) != 0u);
+            const unsigned long long mXA = mLA & mJA, mXB = mLB & mJB;
+            const int nX = __popcll(mXA) + __popcll(mXB);
+            bool certified = witness >= 0 && __popc(wv & d.kmask) < d.H;
+            if (!certified) {
+                const unsigned long long mH = wave_ballot(appA & (c0A < d.H) & (c1A >= d.H)) | wave_ballot(appB & (c0B < d.H) & (c1B >= d.H));
+                certified = mH == 0ull && s.npend == 0 && nX == 0;
             }
-            const int hx = nHc + pairs_new;
-            if (__builtin_expect((hx != 0 && s.running - hx < 1) || (mEA | mEB) == 0ull, 0)) {
+            if (__builtin_expect(!certified || (mEA | mEB) == 0ull || s.npend + nX > kPendCap, 0)) {
 #ifdef RAPID_TRACE
-                if (lane == 0) fprintf(stderr, "W-fail r=%d pos=%d run=%d nHc=%d pairs=%d->%d npend=%d noE=%d\n", r, pos, s.running, nHc, pend_pairs, pairs_new, s.npend, (int)((mEA | mEB) == 0ull));
+                if (lane == 0) fprintf(stderr, "L-fail r=%d pos=%d witness=%d wcount=%d npend=%d nX=%d noE=%d\n", r, pos, witness, __popc(wv & d.kmask), s.npend, nX, (int)((mEA | mEB) == 0ull));
 #endif
                 const unsigned int newA = rbA & ~oldA, newB = rbB & ~oldB;
                 if (appA && newA != 0u) d.clear_bits((int)slotA, newA);
@@ -657,11 +650,24 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 wave_lds_fence();
                 return 0;
             }
-            s.running += nLc - nHc;
+#ifdef RAPID_TRACE
+            if (lane == 0) fprintf(stderr, "L-ok r=%d pos=%d nc=%d witness=%d wcount=%d npend=%d nX=%d batch=%d\n", r, pos, ncA + ncB, witness, __popc(wv & d.kmask), s.npend, nX, s.batch);
+#endif
+            if (nX != 0) {  // queue the entrants whose implicit reports are owed
+                const int posA = s.npend + __popcll(mXA & lanes_lt(lane));
+                const int posB = s.npend + __popcll(mXA) + __popcll(mXB & lanes_lt(lane));
+                if ((mXA >> lane) & 1ull) pend[posA] = (unsigned short)slotA;
+                if ((mXB >> lane) & 1ull) pend[posB] = (unsigned short)slotB;
+                s.npend += nX;
+            }
+            // a fresh entrant without hot adjacency is the best witness there is: it needs H - L more reports to leave
+            const unsigned long long mNA = mLA & ~mJA, mNB = mLB & ~mJB;
+            if (mNB != 0ull)
+                witness = lane_value((int)slotB, __ffsll((long long)mNB) - 1);
+            else if (mNA != 0ull)
+                witness = lane_value((int)slotA, __ffsll((long long)mNA) - 1);
             s.batch += __popcll(mEA) + __popcll(mEB);
-            s.npend = npend_new;
-            pend_pairs = pairs_new;
-            pos += ncA + ncB;
+            advance(ncA + ncB);
             return 1;
         };
 
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 n_applied += applied_here;
                 n_fast++;
                 n_records += (unsigned long long)ncons;
-                pos += ncons;
+                advance(ncons);
                 return true;
             }
             if (n_undo > kUndoCap) {
@@ -742,23 +748,25 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     s.batch++;
                 }
             }
-            pos += ncons;
+            advance(ncons);
         };
 
         // ---- the record stream: LDS-DMA into this wave's ring, kDepth KiB always in flight ----
-        // Stream KiB k (bytes [1024 k, 1024 k + 1024) from the receiver's 16-B aligned start) lives in ring slot
-        // k % kRingSlots.  `landed` KiB have arrived (and, for slots 0/1, been copied to the mirror behind the ring);
-        // KiB landed .. landed + kDepth - 1 are in flight, so one more has landed once at most kDepth - 1 loads are
-        // outstanding.  KiB past the end of the stream are out of range of the buffer resource: they cost no memory
+        // Stream KiB k (bytes [1024 k, 1024 k + 1024) from a0) lives in ring slot k % kRingSlots.  `landed` KiB have
+        // arrived; KiB landed .. landed + kDepth - 1 are in flight, so one more has landed once at most kDepth - 1 loads
+        // are outstanding.  KiB past the end of the stream are out of range of the buffer resource: they cost no memory
         // traffic but keep the count of outstanding loads constant, which keeps every wait a compile-time constant.
-        int landed = 0, slot_landed = 0;  // slot_landed = landed % kRingSlots
+        int landed = 0, slot_issue = 0;  // slot_issue = (landed + kDepth) % kRingSlots: where the next KiB goes
         auto stream_start = [&]() {
-            wait_dma<0>();  // nothing issued for an earlier receiver / an abandoned pass is still landing
-            wave_lds_fence();
             landed = 0;
-            slot_landed = 0;
-#pragma unroll
-            for (int k = 0; k < kDepth; ++k) lds_dma16(rsrc, lane16, (unsigned int)k * kSlotBytes, ring_lds + k * kSlotBytes);
+            slot_issue = kDepth;
+            if (prestarted) {  // issued at the end of the previous receiver
+                prestarted = false;
+                return;
+            }
+            wait_dma<0>();  // an abandoned pass over this stream may still be landing
+            wave_lds_fence();
+            issue_head(cur);
         };
         // Makes the records [pos, end_rec) resident.  A slot is recycled only when every record in it has been
         // consumed: a window of <= 128 records touches <= kWindowSlots slots, so need <= kp + kWindowSlots (kp = the KiB
@@ -769,20 +777,14 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 RAPID_T0(te0);
                 wait_dma<kDepth - 1>();
                 RAPID_T1(t_ensure, te0);
-                wave_lds_fence();
-                if (slot_landed == 0) ring16[lane + kRingBytes / 16] = ring16[lane];  // mirror the head of the ring behind it
-                if (slot_landed == 1 && lane < (kMirrorBytes - kSlotBytes) / 16) ring16[lane + kWave + kRingBytes / 16] = ring16[lane + kWave];
-                int slot_issue = slot_landed + kDepth;
-                if (slot_issue >= kRingSlots) slot_issue -= kRingSlots;
                 lds_dma16(rsrc, lane16, (unsigned int)(landed + kDepth) * kSlotBytes, ring_lds + slot_issue * kSlotBytes);
                 ++landed;
-                if (++slot_landed == kRingSlots) slot_landed = 0;
-                wave_lds_fence();
+                if (++slot_issue == kRingSlots) slot_issue = 0;
             }
+            wave_lds_fence();
         };
 
-        int lean_run = 0;           // records the lean path consumed since it was last entered
-        bool from_careful = false;  // entrants may have been carried over from the careful path
+        bool from_careful = true;  // the lean path (re)establishes its witness on entry
         while (emit_batch < 0 && (restart || pos < nrec)) {
             if (restart) {
                 // ---- detector state: nothing reported yet ----
@@ -795,19 +797,19 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 s.seen_down = false;
                 s.need_full = false;
                 s.batch_emitted = false;
-                pend_pairs = 0;
                 pos = 0;
+                ring_pos = delta;
+                witness = -1;
                 restart = false;
                 careful_budget = 0;
                 careful_cap = kWave;
-                lean_run = 0;
-                from_careful = false;
+                from_careful = false;  // nothing to recount: no slot has a report yet
                 stream_start();
                 continue;
             }
             if ((p.flags & 32) != 0) {  // measurement aid: stream the records through the ring without tallying them
                 stream_ensure(min(pos + 2 * kWave, nrec));
-                pos = min(pos + 2 * kWave, nrec);
+                advance(min(2 * kWave, nrec - pos));
                 continue;
             }
             if (exact_only || s.batch_emitted || s.need_full || careful_budget > 0 || (p.flags & 8) != 0) {
@@ -839,70 +841,60 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 RAPID_T1(t_careful, tc0);
                 continue;
             }
-            // ================= LEAN path: order-free windows, implicit invalidation deferred =================
-            if (from_careful) {
+            // ================= LEAN path: certified windows, implicit invalidation deferred =================
+            if (from_careful) {  // the careful path keeps updatesInProgress itself; the lean path needs a witness
                 from_careful = false;
-                lean_run = 0;
-                pend_pairs = 0;
-                if (s.npend > 0) {  // entrants carried over from the careful path: re-establish the bound on their pairs
-                    int dsum = 0;
-                    for (int i0 = 0; i0 < s.npend; i0 += kWave) {
-                        const int i = i0 + lane;
-                        const int e = i < s.npend ? (int)pend[i] : -1;
-                        int dg = (e >= 0 && e < d.n_scan) ? (int)adj_off[e + 1] - (int)adj_off[e] : 0;
-                        for (int o2 = 32; o2 > 0; o2 >>= 1) dg += __shfl_xor(dg, o2, kWave);
-                        dsum += uniform(dg);
-                    }
-                    pend_pairs = dsum;
-                    if (s.running - pend_pairs < 1) {  // the lean invariant does not hold yet: one more careful sub-chunk
-                        careful_budget = 1;
-                        continue;
-                    }
-                }
+                recount();
             }
             const int pos_in = pos;
-            bool gave_up = false;
-            // wide windows while 128 records are left, then the tail in single-record-per-lane sub-chunks
+            int gave_up = 0;
             while (nrec - pos >= 2 * kWave) {
                 stream_ensure(pos + 2 * kWave);
                 RAPID_T0(tl0);
-                const int ok_ = lean_wide();
+                const int ok_ = lean_window(std::false_type{});
                 RAPID_T1(t_lean, tl0);
                 if (!ok_) {
-                    // flush what is pending (when that is allowed) and try once more: the bound on the pending pairs is
-                    // usually what failed, and it is gone after the flush
-                    if (s.npend > 0 && s.seen_down && !s.need_full && s.running - pend_pairs >= 1) {
-                        flush_pending();
-                        if (lean_wide()) continue;
-                    }
-                    gave_up = true;
+                    gave_up = 1;
                     break;
                 }
-                // the deferred implicit invalidation (cannot emit, see flush_pending) once enough entrants are queued
-                if (s.npend >= kPendCap / 4) {
+                if (s.npend >= kPendCap / 2) {
                     RAPID_T0(tf0);
                     flush_pending();
                     RAPID_T1(t_flush, tf0);
                 }
             }
-            while (!gave_up && pos < nrec) {
+            if (!gave_up && pos < nrec) {  // the tail: fewer than 128 records, the last one closes the last batch
                 stream_ensure(nrec);
-                if (!lean_subchunk()) gave_up = true;
+                if (!lean_window(std::true_type{})) gave_up = 1;
             }
             n_fast += (unsigned long long)((pos - pos_in + 2 * kWave - 1) / (2 * kWave));
             n_records += (unsigned long long)(pos - pos_in);
-            lean_run = pos - pos_in;
             if (gave_up) {
-                // the lean path could not exclude an emission: take the next sub-chunks through the careful path, for
-                // longer and longer if the lean path keeps giving up immediately
+                // No certificate for the window at `pos`.  If the lean path got anywhere, `pos` is a batch end: apply what
+                // is owed and look for a new witness -- with one, the lean path goes on.  Otherwise the careful path takes
+                // the next sub-chunks (for longer and longer if the lean path keeps giving up at once).
                 n_pipe++;
-                flush_pending();
-                careful_next = (lean_run < 4 * kWave) ? min(careful_next * 2, 16) : 2;
-                careful_budget = careful_next;
+                RAPID_T0(tf1);
+                const int old_witness = witness;
+                if (pos > pos_in) flush_pending();  // never in the middle of a batch: the reference has not done it yet
+                recount();
+                RAPID_T1(t_flush, tf1);
+                if (pos == pos_in || witness < 0 || witness == old_witness) {
+                    careful_next = (pos - pos_in < 4 * kWave) ? min(careful_next * 2, 16) : 2;
+                    careful_budget = careful_next;
+                }
             }
         }
-        wait_dma<0>();  // the ring is reused by the next receiver
+        wait_dma<0>();  // the ring is free: nothing of this stream is still landing
         RAPID_T0(to0);
+        // start the next receiver's stream now; its first KiB land while this receiver's results are written
+        Stream nxt = make_stream(0, 0);
+        if (r_next < p.n_receivers) {
+            nxt = make_stream(uniform64(n0_v), uniform64(n1_v));
+            wave_lds_fence();
+            issue_head(nxt);
+            prestarted = true;
+        }
 
         // ---- outputs: the proposal = every flushed (hot) slot, ascending node index ----
         int count = 0;
@@ -916,7 +908,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 const unsigned long long mk = wave_ballot(take);
                 const int idx = count + __popcll(mk & lanes_lt(lane));
                 if (take) {
-                    const int node = p.idx.node_of_slot[i];
+                    const int node = node_of_slot[i];
                     if (idx < p.prop_cap) out[idx] = node;
                     fp += mix64((unsigned long long)node);
                 }
@@ -932,6 +924,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             p.fingerprint[r] = fp;
         }
         wave_lds_fence();
+        r = r_next;
+        cur = nxt;
         RAPID_T1(t_out, to0);
 #ifdef RAPID_PHASE_TIMERS
         t_rx++;
