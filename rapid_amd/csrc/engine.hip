@@ -369,7 +369,9 @@ int build_round_index(rapid_engine* h) {
     h->tables_in_lds = shared + per_wave <= lds_max;
     const int sh = h->tables_in_lds ? shared : 0;
     int best_w = 1, best_total = 0;
-    for (int w = 1; w <= rapid::kMaxWavesPerBlock; ++w) {
+    int w_cap = rapid::kMaxWavesPerBlock;
+    if (const char* e = getenv("RAPID_TALLY_WAVES")) w_cap = std::max(1, std::min(w_cap, atoi(e)));  // profiling knob
+    for (int w = 1; w <= w_cap; ++w) {
         const int blk = sh + w * per_wave;
         if (blk > lds_max) break;
         const int total = std::min(32, (lds_max / blk) * w);
@@ -413,7 +415,7 @@ int launch_tally(rapid_engine* h) {
     p.stats = h->d_stats.p;
     p.next_receiver = h->d_next.p;
     p.waves_per_block = h->waves_per_block;
-    p.flags = h->force_exact & (1 | 8 | 16 | 32);
+    p.flags = h->force_exact & (1 | 8 | 32);
     HIPCHK(h, hipMemsetAsync(h->d_next.p, 0, sizeof(unsigned int), h->stream));
     const dim3 grid((unsigned)h->grid_blocks), block((unsigned)h->waves_per_block * 64u);
     const bool trusted = h->trusted && (h->force_exact & 64) == 0;  // bit6 of the testing knob: never trust

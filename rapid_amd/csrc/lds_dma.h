@@ -32,7 +32,7 @@ __device__ __forceinline__ lds_addr_t lds_address(const void* p) {
 // Declares an LDS address wave-uniform (it is: every lane computes it from the wave index), so that it lives in an SGPR.
 __device__ __forceinline__ lds_addr_t lds_uniform(lds_addr_t a) { return (lds_addr_t)__builtin_amdgcn_readfirstlane((int)a); }
 
-// One wave instruction: lane i copies the 16 bytes at (rsrc base + lane_off + soff) to LDS address lds_dst + 16 * i.
+// One wave instruction (non-temporal: every byte of the stream is read once): lane i copies the 16 bytes at (rsrc base + lane_off + soff) to LDS address lds_dst + 16 * i.
 // lds_dst and soff must be wave-uniform (SGPRs).  M0 carries the LDS destination and is left modified: hipcc has no
 // use for M0 in these kernels (no LDS-direct, GWS, sendmsg or movrel code) and rewrites it before any use of its own.  s_mov + s_nop 3 give the five wait states that cover both the
 // M0-write -> LDS-DMA hazard and a VALU-written SGPR operand (an SGPR reloaded from a spill lane) -> VMEM hazard.
@@ -40,7 +40,7 @@ __device__ __forceinline__ void lds_dma16(dma_rsrc_t rsrc, unsigned int lane_off
     asm volatile(
         "s_mov_b32 m0, %3\n\t"
         "s_nop 3\n\t"
-        "buffer_load_dwordx4 %0, %1, %2 offen lds"
+        "buffer_load_dwordx4 %0, %1, %2 offen nt lds"
         :
         : "v"(lane_off), "s"(rsrc), "s"(soff), "s"(lds_dst)
         : "memory");

@@ -463,6 +463,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     int r_next_v = fetch_index();
     bool prestarted = false;  // the head of `cur` is already on its way into the ring
     while (r < p.n_receivers) {
+#ifdef RAPID_PHASE_TIMERS
+        const unsigned long long t_rx0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long t_ensure0 = t_ensure, t_lean0 = t_lean, t_careful0 = t_careful;
+#endif
         const int r_next = uniform(r_next_v);  // issued a whole receiver ago
         long long n0_v = 0, n1_v = 0;          // lane 0: stream bounds of r_next, consumed after this receiver's stream
         if (lane == 0 && r_next < p.n_receivers) {
@@ -756,10 +760,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // arrived; KiB landed .. landed + kDepth - 1 are in flight, so one more has landed once at most kDepth - 1 loads
         // are outstanding.  KiB past the end of the stream are out of range of the buffer resource: they cost no memory
         // traffic but keep the count of outstanding loads constant, which keeps every wait a compile-time constant.
-        int landed = 0, slot_issue = 0;  // slot_issue = (landed + kDepth) % kRingSlots: where the next KiB goes
+        int landed = 0, slot_issue = 0;  // KiB landed .. landed + kDepth - 1 are in flight; slot_issue = (landed + kDepth) % kRingSlots
         auto stream_start = [&]() {
             landed = 0;
-            slot_issue = kDepth;
+            slot_issue = kDepth % kRingSlots;
             if (prestarted) {  // issued at the end of the previous receiver
                 prestarted = false;
                 return;
@@ -770,7 +774,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         };
         // Makes the records [pos, end_rec) resident.  A slot is recycled only when every record in it has been
         // consumed: a window of <= 128 records touches <= kWindowSlots slots, so need <= kp + kWindowSlots (kp = the KiB
-        // `pos` lies in) and the KiB issued here, landed + kDepth, reuses the slot of KiB landed + kDepth - kRingSlots < kp.
+        // `pos` lies in) and no KiB up to landed + kDepth can reuse the slot of a KiB >= kp.
         auto stream_ensure = [&](int end_rec) {
             const int need = (int)((unsigned int)(delta + kRecBytes * end_rec + kSlotBytes - 1) / (unsigned int)kSlotBytes);
             while (landed < need) {
@@ -778,8 +782,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 wait_dma<kDepth - 1>();
                 RAPID_T1(t_ensure, te0);
                 lds_dma16(rsrc, lane16, (unsigned int)(landed + kDepth) * kSlotBytes, ring_lds + slot_issue * kSlotBytes);
-                ++landed;
                 if (++slot_issue == kRingSlots) slot_issue = 0;
+                ++landed;
             }
             wave_lds_fence();
         };
@@ -921,7 +925,14 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             p.emit_batch[r] = emit_batch;
             p.num_proposals[r] = s.proposal_count;
             p.prop_count[r] = count > p.prop_cap ? -1 : count;
+#ifdef RAPID_PHASE_TIMERS
+            // profiling build: cycles spent on this receiver, in total and per phase
+            p.fingerprint[r] = ((__builtin_amdgcn_s_memtime() - t_rx0) & 0xFFFFFFFFull) | ((t_ensure - t_ensure0) << 32);
+            p.num_proposals[r] = (int)((t_careful - t_careful0) >> 4);
+            p.prop_count[r] = (int)((t_lean - t_lean0) >> 4);
+#else
             p.fingerprint[r] = fp;
+#endif
         }
         wave_lds_fence();
         r = r_next;
