@@ -368,15 +368,23 @@ int build_round_index(rapid_engine* h) {
         return fail(h, RAPID_ECAPACITY, "%d subjects need %d B of LDS per receiver (max %d)", h->n_slots, per_wave, lds_max);
     h->tables_in_lds = shared + per_wave <= lds_max;
     const int sh = h->tables_in_lds ? shared : 0;
-    int best_w = 1, best_total = 0;
+    // Waves per CU: every receiver costs about the same, so the kernel runs ceil(receivers / resident waves) rounds;
+    // a wave is slowed by roughly 4 % per co-resident wave (measured, profiles/), so among the wave counts that fit
+    // the one minimising rounds x slowdown wins -- e.g. 13 rather than 16 waves for 9,492 receivers on 256 CUs
+    // (3 rounds either way).  One workgroup per CU when the shared tables are staged in LDS.
+    int best_w = 1;
+    double best_cost = 1e300;
     int w_cap = rapid::kMaxWavesPerBlock;
     if (const char* e = getenv("RAPID_TALLY_WAVES")) w_cap = std::max(1, std::min(w_cap, atoi(e)));  // profiling knob
     for (int w = 1; w <= w_cap; ++w) {
         const int blk = sh + w * per_wave;
         if (blk > lds_max) break;
-        const int total = std::min(32, (lds_max / blk) * w);
-        if (total >= best_total) {
-            best_total = total;
+        const int per_cu = std::min(32, (lds_max / blk) * w);
+        const long long resident = (long long)per_cu * h->num_cus;
+        const long long rounds = std::max<long long>(1, (h->n_receivers + resident - 1) / resident);
+        const double cost = (double)rounds * (1.0 + 0.04 * (per_cu - 1));
+        if (cost < best_cost) {
+            best_cost = cost;
             best_w = w;
         }
     }
@@ -1190,13 +1198,18 @@ int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, in
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
-    const dim3 grid((unsigned)h->num_cus * (unsigned)std::max(1, 16 / waves)), block((unsigned)waves * 64u);
+    int per_cu = 16;  // waves per CU
+    if (const char* e = getenv("RAPID_PROBE_WAVES_PER_CU")) per_cu = std::max(1, std::min(32, atoi(e)));
+    const dim3 grid((unsigned)h->num_cus * (unsigned)std::max(1, per_cu / waves)), block((unsigned)waves * 64u);
     auto launch = [&]() {
         (void)hipMemsetAsync(h->d_next.p, 0, 4, h->stream);
         switch (variant) {
             case 0: hipLaunchKernelGGL((rapid::stream_probe_kernel<2, 8>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
             case 1: hipLaunchKernelGGL((rapid::stream_probe_kernel<4, 4>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
             case 2: hipLaunchKernelGGL((rapid::stream_probe_kernel<8, 2>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
+            case 4: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 8>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
+            case 5: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 16>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
+            case 6: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 4>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
             default: hipLaunchKernelGGL((rapid::stream_probe_kernel<2, 4>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
         }
     };

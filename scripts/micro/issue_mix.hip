@@ -18,6 +18,10 @@ __global__ void mix_kernel(int iters, unsigned long long* out) {
             asm volatile(".rept 64\n s_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n .endr" : "+s"(s0), "+v"(v0) : : "scc");
         if (MODE == 3)  // 128 SALU + 64 VALU interleaved 2:1
             asm volatile(".rept 64\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n .endr" : "+s"(s0), "+v"(v0) : : "scc");
+        if (MODE == 5)  // 32 x (s_cmp; TAKEN s_cbranch over one s_nop): cost of a taken branch
+            asm volatile(".rept 32\n s_cmp_eq_u32 %0, %0\n s_cbranch_scc1 1\n s_nop 0\n .endr" : "+s"(s0) : : "scc");
+        if (MODE == 6)  // 32 x (s_cmp; NOT-taken s_cbranch; s_nop)
+            asm volatile(".rept 32\n s_cmp_lg_u32 %0, %0\n s_cbranch_scc1 1\n s_nop 0\n .endr" : "+s"(s0) : : "scc");
         if (MODE == 4)  // 64 x (v_cmp -> s_and on its result -> s_bcnt1): VALU->SALU dependency chain
             asm volatile(".rept 64\n v_cmp_ne_u32 vcc, 0, %1\n s_and_b64 vcc, vcc, exec\n s_bcnt1_i32_b64 %0, vcc\n .endr" : "+s"(s0), "+v"(v0) : : "vcc", "scc");
     }
@@ -52,5 +56,7 @@ int main() {
     run<2>("64 SALU + 64 VALU (1:1)", 128);
     run<3>("128 SALU + 64 VALU (2:1)", 192);
     run<4>("v_cmp -> s_and -> s_bcnt1", 192);
+    run<5>("32 x taken branch (+cmp)", 32);
+    run<6>("32 x not-taken branch (+cmp,nop)", 32);
     return 0;
 }

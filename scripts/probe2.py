@@ -1,0 +1,14 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+from rapid_amd import engine as E, scenarios as S
+n,K,H,L=10000,10,9,4
+pop=S.Population.make(n)
+eng=E.Engine(n_max=n,K=K,H=H,L=L)
+view=E.MembershipView(eng).build(pop.hostnames,pop.ports,pop.id_hi,pop.id_lo)
+obs,subj,member=view.tables(); cfg=view.getCurrentConfigurationId()
+sc=S.build_scenario("C3b",subj,cfg)
+sim=E.ClusterSimulation(eng); sim.load_streams(sc.records, sc.rec_off)
+gb = 20*len(sc.records)/1e6
+for variant,name in [(0,"2KiBx8"),(4,"1KiBx8"),(5,"1KiBx16"),(6,"1KiBx4"),(3,"2KiBx4")]:
+    ms = sim.stream_probe(variant, 4, 5)
+    print("probe", name, "waves/CU", os.environ.get("RAPID_PROBE_WAVES_PER_CU","16"), round(ms,3), "ms", round(gb/ms,1), "GB/s")
