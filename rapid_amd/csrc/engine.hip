@@ -423,7 +423,7 @@ int launch_tally(rapid_engine* h) {
     p.stats = h->d_stats.p;
     p.next_receiver = h->d_next.p;
     p.waves_per_block = h->waves_per_block;
-    p.flags = h->force_exact & (1 | 8 | 32);
+    p.flags = h->force_exact & (1 | 8 | 32 | 64);
     HIPCHK(h, hipMemsetAsync(h->d_next.p, 0, sizeof(unsigned int), h->stream));
     const dim3 grid((unsigned)h->grid_blocks), block((unsigned)h->waves_per_block * 64u);
     const bool trusted = h->trusted && (h->force_exact & 64) == 0;  // bit6 of the testing knob: never trust
@@ -1201,12 +1201,22 @@ int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, in
     int per_cu = 16;  // waves per CU
     if (const char* e = getenv("RAPID_PROBE_WAVES_PER_CU")) per_cu = std::max(1, std::min(32, atoi(e)));
     const dim3 grid((unsigned)h->num_cus * (unsigned)std::max(1, per_cu / waves)), block((unsigned)waves * 64u);
+    size_t lds_pad = 0;
+    if (const char* e = getenv("RAPID_PROBE_LDS_PAD")) lds_pad = (size_t)atoi(e);
+    if (lds_pad > 0)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::dma_probe_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    unsigned int ring_off = 0;
+    if (const char* e = getenv("RAPID_PROBE_RING_OFFSET")) ring_off = (unsigned int)atoi(e);
     auto launch = [&]() {
         (void)hipMemsetAsync(h->d_next.p, 0, 4, h->stream);
+        (void)hipMemcpyAsync(h->d_next.p + 2, &ring_off, 4, hipMemcpyHostToDevice, h->stream);
         switch (variant) {
             case 0: hipLaunchKernelGGL((rapid::stream_probe_kernel<2, 8>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
             case 1: hipLaunchKernelGGL((rapid::stream_probe_kernel<4, 4>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
             case 2: hipLaunchKernelGGL((rapid::stream_probe_kernel<8, 2>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
+            case 9: hipLaunchKernelGGL((rapid::dma_probe_kernel<6>), grid, block, (size_t)waves * 6 * 1024 + lds_pad, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
+            case 7: hipLaunchKernelGGL((rapid::dma_probe_kernel<4>), grid, block, (size_t)waves * 4 * 1024, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
+            case 8: hipLaunchKernelGGL((rapid::dma_probe_kernel<8>), grid, block, (size_t)waves * 8 * 1024, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
             case 4: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 8>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
             case 5: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 16>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
             case 6: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 4>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;

@@ -25,6 +25,16 @@ __device__ __forceinline__ dma_rsrc_t dma_make_rsrc(const void* base, unsigned i
     return r;
 }
 
+// Declares a descriptor wave-uniform again after it travelled through something the compiler does not prove uniform.
+__device__ __forceinline__ dma_rsrc_t dma_uniform(dma_rsrc_t r) {
+    dma_rsrc_t u;
+    u.x = __builtin_amdgcn_readfirstlane(r.x);
+    u.y = __builtin_amdgcn_readfirstlane(r.y);
+    u.z = __builtin_amdgcn_readfirstlane(r.z);
+    u.w = __builtin_amdgcn_readfirstlane(r.w);
+    return u;
+}
+
 __device__ __forceinline__ lds_addr_t lds_address(const void* p) {
     return (lds_addr_t)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
 }

@@ -44,7 +44,9 @@ namespace rapid {
 constexpr int kWave = 64;
 constexpr int kRecBytes = 20;
 constexpr int kSlotBytes = 1024;                     // one LDS-DMA wave instruction: 64 lanes x 16 B
-constexpr int kWindowSlots = 4;                      // a 128-record window (2560 B) at any alignment touches <= 4 slots
+constexpr int kQuarters = 2;                         // records per lane in a lean window (4 measured slower: profiles/)
+constexpr int kLeanWindow = kQuarters * kWave;       // 128 records = 2560 B
+constexpr int kWindowSlots = 4;                      // a 2560-byte window at any alignment touches <= 4 slots
 constexpr int kDepth = 6;                            // KiB kept in flight per wave
 constexpr int kRingSlots = kWindowSlots + kDepth;    // LDS ring the windows are decoded from
 constexpr int kRingBytes = kSlotBytes * kRingSlots;  // 10 KiB = 512 records exactly: records never straddle the ring's end
@@ -421,16 +423,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     int n_applied = 0, n_full = 0;
     const int lane20 = lane * kRecBytes;
 
-    // Receivers are handed out by a global counter, two steps ahead: while receiver r is processed, the index of r''
-    // is on its way (atomic issued at the start of r) and the stream bounds of r' are loaded, so that at the end of r
-    // the stream of r' is started BEFORE r's results are written -- neither the counter, nor the offsets, nor the first
-    // KiB of the next stream are waited for between receivers.
     const unsigned int lane16 = (unsigned int)lane * 16u;
-    auto fetch_index = [&]() -> int {
-        int v = 0;
-        if (lane == 0) v = (int)atomicAdd(p.next_receiver, 1u);
-        return v;  // lane 0 holds the index; made uniform where it is consumed
-    };
     // the stream of a receiver as the ring sees it
     struct Stream {
         dma_rsrc_t rsrc;
@@ -453,29 +446,36 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         return ((long long)uniform((unsigned int)((unsigned long long)v >> 32)) << 32) | (long long)uniform((unsigned int)(unsigned long long)v);
     };
     auto issue_head = [&](const Stream& st) {  // the first kDepth KiB of a stream into ring slots 0 .. kDepth - 1
+        const dma_rsrc_t head_rsrc = dma_uniform(st.rsrc);
 #pragma unroll
-        for (int k = 0; k < kDepth; ++k) lds_dma16(st.rsrc, lane16, (unsigned int)k * kSlotBytes, ring_lds + k * kSlotBytes);
+        for (int k = 0; k < kDepth; ++k) lds_dma16(head_rsrc, lane16, (unsigned int)k * kSlotBytes, ring_lds + k * kSlotBytes);
     };
 
-    int r = uniform(fetch_index());
+    // Receivers are dealt round-robin: wave g of G takes receivers g, g + G, g + 2 G ...  Every receiver of a round costs
+    // about the same (they all see the same alerts), so a shared work counter would balance nothing -- but 2,560 waves
+    // hitting one counter at the same moment queue up behind each other (measured: ~15 us per receiver waiting for the
+    // atomic), and a static deal lets the next stream's bounds be loaded a whole receiver ahead.  Everything the
+    // compiler has to wait for is waited for at ONE point per receiver -- right after the stream of r has drained,
+    // when none of the asm-issued loads is in flight -- because its wait for any of its own loads is a full
+    // s_waitcnt vmcnt(0).
+    const int wave_global = uniform((int)blockIdx.x * (int)(blockDim.x >> 6) + wave), waves_total = (int)gridDim.x * (int)(blockDim.x >> 6);
+    int r = wave_global;
     Stream cur = make_stream(0, 0);
     if (r < p.n_receivers) cur = make_stream(p.rec_off[r], p.rec_off[r + 1]);
-    int r_next_v = fetch_index();
     bool prestarted = false;  // the head of `cur` is already on its way into the ring
     while (r < p.n_receivers) {
 #ifdef RAPID_PHASE_TIMERS
         const unsigned long long t_rx0 = __builtin_amdgcn_s_memtime();
         const unsigned long long t_ensure0 = t_ensure, t_lean0 = t_lean, t_careful0 = t_careful;
 #endif
-        const int r_next = uniform(r_next_v);  // issued a whole receiver ago
-        long long n0_v = 0, n1_v = 0;          // lane 0: stream bounds of r_next, consumed after this receiver's stream
+        const int r_next = uniform(r + waves_total);
+        long long n0_v = 0, n1_v = 0;  // lane 0: stream bounds of r_next, consumed after this receiver's stream
         if (lane == 0 && r_next < p.n_receivers) {
             n0_v = p.rec_off[r_next];
             n1_v = p.rec_off[r_next + 1];
         }
-        r_next_v = fetch_index();
-        const dma_rsrc_t rsrc = cur.rsrc;
-        const int delta = cur.delta, nrec = cur.nrec;
+        const dma_rsrc_t rsrc = dma_uniform(cur.rsrc);
+        const int delta = uniform(cur.delta), nrec = uniform(cur.nrec);
 
         int emit_batch = -1;
         RxScalars s;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         bool restart = true;  // (re)initialise the detector before the first sub-chunk
         int pos = 0;          // next unconsumed record
         int ring_pos = delta;  // its byte offset in the ring: (delta + 20 pos) mod kRingBytes
-        auto advance = [&](int n) {  // n <= 128 records consumed
+        auto advance = [&](int n) {  // n <= 256 records consumed (5120 B < kRingBytes: one wrap at most)
             pos += n;
             ring_pos += n * kRecBytes;
             if (ring_pos >= kRingBytes) ring_pos -= kRingBytes;
@@ -560,118 +560,155 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             witness = best == 0xFFFFFFFFu ? -1 : (int)(best & 0xFFFFu);
         };
 
-        // ---- LEAN path: order-free application of a window of up to 128 records, TWO per lane (half A = records
-        // pos + lane, half B = records pos + 64 + lane), cut at its last batch end; the implicit invalidation is
-        // deferred (entrants are queued in pend[]).  The window is committed only with a CERTIFICATE that the reference
-        // cannot emit at any point inside it.  An emission needs updatesInProgress to reach 0
-        // (R/MultiNodeCutDetector.java:110-121), so either of these suffices:
+        // ---- LEAN path: order-free application of a window of up to 256 records, FOUR per lane (quarter q = records
+        // pos + 64 q + lane), cut at its last batch end; the implicit invalidation is deferred (entrants are queued in
+        // pend[]).  The window is committed only with a CERTIFICATE that the reference cannot emit at any point inside
+        // it.  An emission needs updatesInProgress to reach 0 (R/MultiNodeCutDetector.java:110-121), so either of these
+        // suffices:
         //   (a) the witness -- in preProposal before the window, never the target of an implicit report -- still has
         //       fewer than H reports after the window: it was in preProposal throughout, updatesInProgress >= 1;
         //   (b) no report of the window takes any subject to H, and no implicit report can be generated in it (nothing
         //       queued, no entrant with hot adjacency): then nothing crosses H at all.
-        // Counts only grow, LDS atomics of one wave execute in program order (B sees A's bits), and every crossing of
-        // L is seen by exactly one lane, whatever the order.  Returns 0 -- window rolled back, nothing consumed -- when
-        // no certificate holds.  kTail: fewer than 128 records are left (the last record closes the last batch).
+        // Counts only grow, LDS atomics of one wave execute in program order (a later quarter sees the earlier ones'
+        // bits), and every crossing of L is seen by exactly one lane, whatever the order.  Four independent quarters
+        // also give the wave four independent dependency chains to interleave.  Returns 0 -- window rolled back,
+        // nothing consumed -- when no certificate holds.  kTail: fewer than 256 records are left (the last record
+        // closes the last batch).
         auto lean_window = [&](auto tail_tag) -> int {
             constexpr bool kTail = decltype(tail_tag)::value;
-            const int navail = kTail ? nrec - pos : 2 * kWave;
-            unsigned int tA = (unsigned int)(ring_pos + lane20), tB = tA + (unsigned int)(kWave * kRecBytes);
-            tA = min(tA, tA - (unsigned int)kRingBytes);  // per-lane wrap (records never straddle the end of the ring)
-            tB = min(tB, tB - (unsigned int)kRingBytes);
-            const unsigned int* wa = ring32 + (tA >> 2);
-            const unsigned int* wb = ring32 + (tB >> 2);
-            const unsigned int a3 = wa[3], a4 = wa[4], b3 = wb[3], b4 = wb[4];
-            unsigned long long mEA, mEB;
-            if (kTail) {
-                mEA = wave_ballot((lane < navail) & (((a4 & 0x01000000u) != 0u) | (lane == navail - 1)));
-                mEB = wave_ballot((lane + kWave < navail) & (((b4 & 0x01000000u) != 0u) | (lane + kWave == navail - 1)));
-            } else {
-                mEA = wave_ballot((a4 & 0x01000000u) != 0u);
-                mEB = wave_ballot((b4 & 0x01000000u) != 0u);
+            const int navail = kTail ? nrec - pos : kLeanWindow;
+            unsigned int w3[kQuarters], w4[kQuarters], rb[kQuarters], de[kQuarters], slot[kQuarters], old[kQuarters];
+            unsigned long long mE[kQuarters], mApp[kQuarters], mL[kQuarters], mJ[kQuarters];
+            int nc[kQuarters];
+#pragma unroll
+            for (int q = 0; q < kQuarters; ++q) {
+                unsigned int t = (unsigned int)(ring_pos + lane20 + q * kWave * kRecBytes);
+                t = min(t, t - (unsigned int)kRingBytes);  // per-lane wrap (records never straddle the end of the ring)
+                const unsigned int* w = ring32 + (t >> 2);
+                w3[q] = w[3];
+                w4[q] = w[4];
+            }
+            unsigned long long anyE = 0ull;
+#pragma unroll
+            for (int q = 0; q < kQuarters; ++q) {
+                if (kTail)
+                    mE[q] = wave_ballot((lane + q * kWave < navail) & (((w4[q] & 0x01000000u) != 0u) | (lane + q * kWave == navail - 1)));
+                else
+                    mE[q] = wave_ballot((w4[q] & 0x01000000u) != 0u);
+                anyE |= mE[q];
             }
             // consume up to the last batch end of the window (none at all: a batch longer than the window -> careful path)
-            const int ncA = mEB != 0ull ? kWave : (mEA != 0ull ? kWave - __clzll((long long)mEA) : 0);
-            const int ncB = mEB != 0ull ? kWave - __clzll((long long)mEB) : 0;
-            const unsigned int rbA = a4 & d.kmask, rbB = b4 & d.kmask;
-            const bool seen_before = s.seen_down;
-            unsigned int deA, deB;
-            bool appA, appB;
-            if (kTrusted) {
-                // every consumed record is a validated alert: the dictionary lookup needs no range check
-                deA = (unsigned int)dict[(!kTail || lane < ncA) ? a3 : 0u];
-                deB = (unsigned int)dict[(!kTail || lane < ncB) ? b3 : 0u];
-                appA = (lane < ncA) & ((deA & kSlotMask) != kNoSlot);
-                appB = (lane < ncB) & ((deB & kSlotMask) != kNoSlot);
-                if (!s.seen_down)
-                    s.seen_down = (wave_ballot((lane < ncA) & ((a4 & 0x00FF0000u) != 0u)) |
-                                   wave_ballot((lane < ncB) & ((b4 & 0x00FF0000u) != 0u))) != 0ull;
-            } else {
-                // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot, per half
-                const unsigned int a0w = wa[0], a1w = wa[1], b0w = wb[0], b1w = wb[1];
-                deA = (unsigned int)dict[a3 < (unsigned)p.n_nodes ? a3 : 0u];
-                deB = (unsigned int)dict[b3 < (unsigned)p.n_nodes ? b3 : 0u];
-                const unsigned int dnA = (a4 & 0x00FF0000u) != 0u ? 1u : 0u, dnB = (b4 & 0x00FF0000u) != 0u ? 1u : 0u;
-                const unsigned int badA = (a0w ^ cfg_lo) | (a1w ^ cfg_hi) | (dnA ^ (deA >> 15)) |
-                                          (a3 >= (unsigned)p.n_nodes ? 1u : 0u) | (rbA == 0u ? 1u : 0u) | (lane >= ncA ? 1u : 0u);
-                const unsigned int badB = (b0w ^ cfg_lo) | (b1w ^ cfg_hi) | (dnB ^ (deB >> 15)) |
-                                          (b3 >= (unsigned)p.n_nodes ? 1u : 0u) | (rbB == 0u ? 1u : 0u) | (lane >= ncB ? 1u : 0u);
-                appA = (badA == 0u) & ((deA & kSlotMask) != kNoSlot);
-                appB = (badB == 0u) & ((deB & kSlotMask) != kNoSlot);
-                if (!s.seen_down) s.seen_down = (wave_ballot((badA | (dnA ^ 1u)) == 0u) | wave_ballot((badB | (dnB ^ 1u)) == 0u)) != 0ull;
+            int consumed = 0;
+            {
+                bool later = false;  // a later quarter has a batch end: this one is consumed whole
+#pragma unroll
+                for (int q = kQuarters - 1; q >= 0; --q) {
+                    nc[q] = later ? kWave : (mE[q] != 0ull ? kWave - __clzll((long long)mE[q]) : 0);
+                    later = later || mE[q] != 0ull;
+                    consumed += nc[q];
+                }
             }
-            const unsigned int slotA = deA & kSlotMask, slotB = deB & kSlotMask;
-            // both lane masks first: the two atomics then go out back to back, one LDS round trip for the pair
-            const unsigned long long mAppA = wave_ballot(appA), mAppB = wave_ballot(appB);
-            unsigned int oldA = 0, oldB = 0;
-            if ((mAppA >> lane) & 1ull) oldA = d.or_bits((int)slotA, rbA);
-            if ((mAppB >> lane) & 1ull) oldB = d.or_bits((int)slotB, rbB);
+            const bool seen_before = s.seen_down;
+            unsigned long long mDown = 0ull;
+#pragma unroll
+            for (int q = 0; q < kQuarters; ++q) {
+                rb[q] = w4[q] & d.kmask;
+                bool app;
+                if (kTrusted) {
+                    // every consumed record is a validated alert: the dictionary lookup needs no range check
+                    de[q] = (unsigned int)dict[(!kTail || lane < nc[q]) ? w3[q] : 0u];
+                    app = (lane < nc[q]) & ((de[q] & kSlotMask) != kNoSlot);
+                    if (!seen_before) mDown |= wave_ballot((lane < nc[q]) & ((w4[q] & 0x00FF0000u) != 0u));
+                } else {
+                    // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot
+                    unsigned int t = (unsigned int)(ring_pos + lane20 + q * kWave * kRecBytes);
+                    t = min(t, t - (unsigned int)kRingBytes);
+                    const unsigned int* w = ring32 + (t >> 2);
+                    const unsigned int w0 = w[0], w1 = w[1];
+                    de[q] = (unsigned int)dict[w3[q] < (unsigned)p.n_nodes ? w3[q] : 0u];
+                    const unsigned int dn = (w4[q] & 0x00FF0000u) != 0u ? 1u : 0u;
+                    const unsigned int bad = (w0 ^ cfg_lo) | (w1 ^ cfg_hi) | (dn ^ (de[q] >> 15)) |
+                                             (w3[q] >= (unsigned)p.n_nodes ? 1u : 0u) | (rb[q] == 0u ? 1u : 0u) |
+                                             (lane >= nc[q] ? 1u : 0u);
+                    app = (bad == 0u) & ((de[q] & kSlotMask) != kNoSlot);
+                    if (!seen_before) mDown |= wave_ballot((bad | (dn ^ 1u)) == 0u);
+                }
+                slot[q] = de[q] & kSlotMask;
+                mApp[q] = wave_ballot(app);  // all lane masks first: the atomics then go out back to back
+            }
+            if (!seen_before) s.seen_down = mDown != 0ull;
+#pragma unroll
+            for (int q = 0; q < kQuarters; ++q) {
+                old[q] = 0u;
+                if ((mApp[q] >> lane) & 1ull) old[q] = d.or_bits((int)slot[q], rb[q]);
+            }
             // The witness's reports AFTER the window: a wave's LDS operations are served in program order, so this read
             // sees every lane's atomic above without waiting for their results (the barrier is not an instruction; it
             // keeps the compiler -- and the lane-by-lane emulator -- from moving the read ahead of them).
             __builtin_amdgcn_wave_barrier();
             const unsigned int wv = uniform(d.load(witness >= 0 ? witness : 0));
-            const unsigned int okA = oldA & d.kmask, okB = oldB & d.kmask;
-            const int c0A = __popc(okA), c1A = __popc(okA | rbA), c0B = __popc(okB), c1B = __popc(okB | rbB);
-            const unsigned long long mLA = wave_ballot(appA & (c0A < d.L) & (c1A >= d.L));
-            const unsigned long long mLB = wave_ballot(appB & (c0B < d.L) & (c1B >= d.L));
-            // entrants with hot adjacency (their implicit reports are owed) / without (witness material)
-            const unsigned long long mJA = wave_ballot((deA & kDictHasAdj) != 0u), mJB = wave_ballot((deB & kDictHasAdj) != 0u);
-            const unsigned long long mXA = mLA & mJA, mXB = mLB & mJB;
-            const int nX = __popcll(mXA) + __popcll(mXB);
+            unsigned long long anyX = 0ull, anyN = 0ull;
+            int nX = 0;
+#pragma unroll
+            for (int q = 0; q < kQuarters; ++q) {
+                const unsigned int ok = old[q] & d.kmask;
+                const int c0 = __popc(ok), c1 = __popc(ok | rb[q]);
+                mL[q] = mApp[q] & wave_ballot(c0 < d.L) & wave_ballot(c1 >= d.L);
+                // entrants with hot adjacency (their implicit reports are owed) / without (witness material)
+                mJ[q] = wave_ballot((de[q] & kDictHasAdj) != 0u);
+                anyX |= mL[q] & mJ[q];
+                anyN |= mL[q] & ~mJ[q];
+                nX += __popcll(mL[q] & mJ[q]);
+            }
             bool certified = witness >= 0 && __popc(wv & d.kmask) < d.H;
             if (!certified) {
-                const unsigned long long mH = wave_ballot(appA & (c0A < d.H) & (c1A >= d.H)) | wave_ballot(appB & (c0B < d.H) & (c1B >= d.H));
+                unsigned long long mH = 0ull;
+#pragma unroll
+                for (int q = 0; q < kQuarters; ++q) {
+                    const unsigned int ok = old[q] & d.kmask;
+                    mH |= mApp[q] & wave_ballot(__popc(ok) < d.H) & wave_ballot(__popc(ok | rb[q]) >= d.H);
+                }
                 certified = mH == 0ull && s.npend == 0 && nX == 0;
             }
-            if (__builtin_expect(!certified || (mEA | mEB) == 0ull || s.npend + nX > kPendCap, 0)) {
+            if (__builtin_expect(!certified || anyE == 0ull || s.npend + nX > kPendCap, 0)) {
 #ifdef RAPID_TRACE
-                if (lane == 0) fprintf(stderr, "L-fail r=%d pos=%d witness=%d wcount=%d npend=%d nX=%d noE=%d\n", r, pos, witness, __popc(wv & d.kmask), s.npend, nX, (int)((mEA | mEB) == 0ull));
+                if (lane == 0) fprintf(stderr, "L-fail r=%d pos=%d witness=%d wcount=%d npend=%d nX=%d noE=%d\n", r, pos, witness, __popc(wv & d.kmask), s.npend, nX, (int)(anyE == 0ull));
 #endif
-                const unsigned int newA = rbA & ~oldA, newB = rbB & ~oldB;
-                if (appA && newA != 0u) d.clear_bits((int)slotA, newA);
-                if (appB && newB != 0u) d.clear_bits((int)slotB, newB);
+#pragma unroll
+                for (int q = 0; q < kQuarters; ++q) {
+                    const unsigned int fresh = rb[q] & ~old[q];
+                    if (((mApp[q] >> lane) & 1ull) && fresh != 0u) d.clear_bits((int)slot[q], fresh);
+                }
                 s.seen_down = seen_before;
                 wave_lds_fence();
                 return 0;
             }
 #ifdef RAPID_TRACE
-            if (lane == 0) fprintf(stderr, "L-ok r=%d pos=%d nc=%d witness=%d wcount=%d npend=%d nX=%d batch=%d\n", r, pos, ncA + ncB, witness, __popc(wv & d.kmask), s.npend, nX, s.batch);
+            if (lane == 0) fprintf(stderr, "L-ok r=%d pos=%d nc=%d witness=%d wcount=%d npend=%d nX=%d batch=%d\n", r, pos, consumed, witness, __popc(wv & d.kmask), s.npend, nX, s.batch);
 #endif
-            if (nX != 0) {  // queue the entrants whose implicit reports are owed
-                const int posA = s.npend + __popcll(mXA & lanes_lt(lane));
-                const int posB = s.npend + __popcll(mXA) + __popcll(mXB & lanes_lt(lane));
-                if ((mXA >> lane) & 1ull) pend[posA] = (unsigned short)slotA;
-                if ((mXB >> lane) & 1ull) pend[posB] = (unsigned short)slotB;
-                s.npend += nX;
+            if (anyX != 0ull) {  // queue the entrants whose implicit reports are owed
+                int base = s.npend;
+#pragma unroll
+                for (int q = 0; q < kQuarters; ++q) {
+                    const unsigned long long mX = mL[q] & mJ[q];
+                    if ((mX >> lane) & 1ull) pend[base + __popcll(mX & lanes_lt(lane))] = (unsigned short)slot[q];
+                    base += __popcll(mX);
+                }
+                s.npend = base;
             }
             // a fresh entrant without hot adjacency is the best witness there is: it needs H - L more reports to leave
-            const unsigned long long mNA = mLA & ~mJA, mNB = mLB & ~mJB;
-            if (mNB != 0ull)
-                witness = lane_value((int)slotB, __ffsll((long long)mNB) - 1);
-            else if (mNA != 0ull)
-                witness = lane_value((int)slotA, __ffsll((long long)mNA) - 1);
-            s.batch += __popcll(mEA) + __popcll(mEB);
-            advance(ncA + ncB);
+            if (anyN != 0ull) {
+#pragma unroll
+                for (int q = 0; q < kQuarters; ++q) {
+                    const unsigned long long mN = mL[q] & ~mJ[q];
+                    if (mN != 0ull) witness = lane_value((int)slot[q], __ffsll((long long)mN) - 1);
+                }
+            }
+            int nbatches = 0;
+#pragma unroll
+            for (int q = 0; q < kQuarters; ++q) nbatches += __popcll(mE[q]);
+            s.batch += nbatches;
+            advance(consumed);
             return 1;
         };
 
@@ -773,14 +810,18 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             issue_head(cur);
         };
         // Makes the records [pos, end_rec) resident.  A slot is recycled only when every record in it has been
-        // consumed: a window of <= 128 records touches <= kWindowSlots slots, so need <= kp + kWindowSlots (kp = the KiB
+        // consumed: a window of <= 256 records touches <= kWindowSlots slots, so need <= kp + kWindowSlots (kp = the KiB
         // `pos` lies in) and no KiB up to landed + kDepth can reuse the slot of a KiB >= kp.
         auto stream_ensure = [&](int end_rec) {
             const int need = (int)((unsigned int)(delta + kRecBytes * end_rec + kSlotBytes - 1) / (unsigned int)kSlotBytes);
             while (landed < need) {
+#ifdef RAPID_TIMER_FINE
                 RAPID_T0(te0);
+#endif
                 wait_dma<kDepth - 1>();
+#ifdef RAPID_TIMER_FINE
                 RAPID_T1(t_ensure, te0);
+#endif
                 lds_dma16(rsrc, lane16, (unsigned int)(landed + kDepth) * kSlotBytes, ring_lds + slot_issue * kSlotBytes);
                 if (++slot_issue == kRingSlots) slot_issue = 0;
                 ++landed;
@@ -789,6 +830,20 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         };
 
         bool from_careful = true;  // the lean path (re)establishes its witness on entry
+        if ((p.flags & 64) != 0 && (p.flags & 32) != 0) {  // measurement aid: the stream alone, in the tightest possible loop
+            RAPID_T1(t_flush, t_rx0);  // profiling build: loop top -> here (index/offset hand-over)
+            RAPID_T0(tq0);
+            stream_start();
+            stream_ensure(min(pos + kLeanWindow, nrec));
+            RAPID_T1(t_careful, tq0);  // first window resident
+            RAPID_T0(tq1);
+            while (pos < nrec) {
+                stream_ensure(min(pos + kLeanWindow, nrec));
+                advance(min(kLeanWindow, nrec - pos));
+            }
+            RAPID_T1(t_lean, tq1);  // steady-state streaming
+            restart = false;
+        }
         while (emit_batch < 0 && (restart || pos < nrec)) {
             if (restart) {
                 // ---- detector state: nothing reported yet ----
@@ -812,8 +867,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 continue;
             }
             if ((p.flags & 32) != 0) {  // measurement aid: stream the records through the ring without tallying them
-                stream_ensure(min(pos + 2 * kWave, nrec));
-                advance(min(2 * kWave, nrec - pos));
+                stream_ensure(min(pos + kLeanWindow, nrec));
+                advance(min(kLeanWindow, nrec - pos));
                 continue;
             }
             if (exact_only || s.batch_emitted || s.need_full || careful_budget > 0 || (p.flags & 8) != 0) {
@@ -852,8 +907,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             }
             const int pos_in = pos;
             int gave_up = 0;
-            while (nrec - pos >= 2 * kWave) {
-                stream_ensure(pos + 2 * kWave);
+            while (nrec - pos >= kLeanWindow) {
+                stream_ensure(pos + kLeanWindow);
                 RAPID_T0(tl0);
                 const int ok_ = lean_window(std::false_type{});
                 RAPID_T1(t_lean, tl0);
@@ -867,11 +922,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     RAPID_T1(t_flush, tf0);
                 }
             }
-            if (!gave_up && pos < nrec) {  // the tail: fewer than 128 records, the last one closes the last batch
+            if (!gave_up && pos < nrec) {  // the tail: fewer than 256 records, the last one closes the last batch
                 stream_ensure(nrec);
                 if (!lean_window(std::true_type{})) gave_up = 1;
             }
-            n_fast += (unsigned long long)((pos - pos_in + 2 * kWave - 1) / (2 * kWave));
+            n_fast += (unsigned long long)((pos - pos_in + kLeanWindow - 1) / kLeanWindow);
             n_records += (unsigned long long)(pos - pos_in);
             if (gave_up) {
                 // No certificate for the window at `pos`.  If the lean path got anywhere, `pos` is a batch end: apply what
@@ -884,7 +939,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 recount();
                 RAPID_T1(t_flush, tf1);
                 if (pos == pos_in || witness < 0 || witness == old_witness) {
-                    careful_next = (pos - pos_in < 4 * kWave) ? min(careful_next * 2, 16) : 2;
+                    careful_next = (pos - pos_in < 2 * kLeanWindow) ? min(careful_next * 2, 16) : 2;
                     careful_budget = careful_next;
                 }
             }
@@ -1082,6 +1137,40 @@ __global__ __launch_bounds__(1024) void stream_probe_kernel(const unsigned char*
         }
     }
     if (acc == 0x12345678u) sink[0] = acc;
+}
+
+// The same probe through the LDS-DMA path: kD KiB in flight per wave, landing in a private LDS ring of kD slots.
+template <int kD>
+__global__ __launch_bounds__(1024) void dma_probe_kernel(const unsigned char* records, unsigned long long records_bytes,
+                                                         const long long* rec_off, int n_receivers,
+                                                         unsigned int* next_receiver, unsigned int* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = (int)(threadIdx.x >> 6);
+    // sink[1] = byte offset of the rings inside the workgroup's LDS allocation (measurement knob)
+    const lds_addr_t ring = lds_uniform(lds_address(smem + sink[1] + wave * kD * 1024));
+    const unsigned int lane16 = (unsigned int)lane * 16u;
+    for (;;) {
+        int r = 0;
+        if (lane == 0) r = (int)atomicAdd(next_receiver, 1u);
+        r = __builtin_amdgcn_readfirstlane(r);
+        if (r >= n_receivers) break;
+        const unsigned long long b0 = (unsigned long long)rec_off[r] * 20ull, b1 = (unsigned long long)rec_off[r + 1] * 20ull;
+        const unsigned long long a0 = b0 & ~15ull;
+        const int nk = (int)((b1 - a0 + 1023ull) / 1024ull);
+        const dma_rsrc_t rsrc = dma_make_rsrc(records + a0, (unsigned int)(((b1 - a0) + 15ull) & ~15ull));
+        wait_dma<0>();
+#pragma unroll
+        for (int k = 0; k < kD; ++k) lds_dma16(rsrc, lane16, (unsigned int)k * 1024u, ring + k * 1024);
+        int slot = 0;
+        for (int k = 0; k < nk; ++k) {
+            wait_dma<kD - 1>();
+            lds_dma16(rsrc, lane16, (unsigned int)(k + kD) * 1024u, ring + slot * 1024);
+            if (++slot == kD) slot = 0;
+        }
+    }
+    wait_dma<0>();
+    if (reinterpret_cast<unsigned int*>(smem)[threadIdx.x] == 0x12345678u) sink[0] = 1u;
 }
 
 }  // namespace rapid

@@ -9,6 +9,6 @@ obs,subj,member=view.tables(); cfg=view.getCurrentConfigurationId()
 sc=S.build_scenario("C3b",subj,cfg)
 sim=E.ClusterSimulation(eng); sim.load_streams(sc.records, sc.rec_off)
 gb = 20*len(sc.records)/1e6
-for variant,name in [(0,"2KiBx8"),(6,"1KiBx4"),(7,"LDS-DMA 1KiBx4"),(8,"LDS-DMA 1KiBx8")]:
-    ms = sim.stream_probe(variant, 4, 5)
-    print("probe", name, "waves/CU", os.environ.get("RAPID_PROBE_WAVES_PER_CU","16"), round(ms,3), "ms", round(gb/ms,1), "GB/s")
+w=int(sys.argv[1])
+ms = sim.stream_probe(9, w, 5)
+print("LDS-DMA 1KiBx6, waves/block", w, "waves/CU", os.environ.get("RAPID_PROBE_WAVES_PER_CU","16"), "pad", os.environ.get("RAPID_PROBE_LDS_PAD","0"), round(ms,3), "ms", round(gb/ms,1), "GB/s")

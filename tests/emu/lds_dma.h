@@ -20,6 +20,7 @@ inline dma_rsrc_t dma_make_rsrc(const void* base, unsigned int bytes) {
     return dma_rsrc_t{static_cast<const unsigned char*>(base), bytes};
 }
 inline lds_addr_t lds_uniform(lds_addr_t a) { return a; }
+inline dma_rsrc_t dma_uniform(dma_rsrc_t r) { return r; }
 inline lds_addr_t lds_address(const void* p) { return const_cast<unsigned char*>(static_cast<const unsigned char*>(p)); }
 
 struct EmuDmaCopy {
