@@ -44,10 +44,17 @@ namespace rapid {
 constexpr int kWave = 64;
 constexpr int kRecBytes = 20;
 constexpr int kSlotBytes = 1024;                     // one LDS-DMA wave instruction: 64 lanes x 16 B
-constexpr int kQuarters = 2;                         // records per lane in a lean window (4 measured slower: profiles/)
-constexpr int kLeanWindow = kQuarters * kWave;       // 128 records = 2560 B
-constexpr int kWindowSlots = 4;                      // a 2560-byte window at any alignment touches <= 4 slots
-constexpr int kDepth = 6;                            // KiB kept in flight per wave
+#ifndef RAPID_QUARTERS
+#define RAPID_QUARTERS 3
+#endif
+constexpr int kQuarters = RAPID_QUARTERS;            // records per lane in a lean window
+constexpr int kLeanWindow = kQuarters * kWave;       // 192 records = 3840 B (2 and 4 per lane measured slower: profiles/)
+constexpr int kWindowSlots = (kLeanWindow * kRecBytes + kSlotBytes - 1) / kSlotBytes + 1;  // slots a window can touch at any alignment
+#ifndef RAPID_RING_SLOTS
+#define RAPID_RING_SLOTS 10
+#endif
+constexpr int kDepth = RAPID_RING_SLOTS - kWindowSlots;  // KiB kept in flight per wave (the rest of the ring)
+static_assert(kDepth >= 1, "ring too small for the window");
 constexpr int kRingSlots = kWindowSlots + kDepth;    // LDS ring the windows are decoded from
 constexpr int kRingBytes = kSlotBytes * kRingSlots;  // 10 KiB = 512 records exactly: records never straddle the ring's end
 static_assert(kRingBytes % kRecBytes == 0, "the ring must hold a whole number of records");
@@ -458,7 +465,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // compiler has to wait for is waited for at ONE point per receiver -- right after the stream of r has drained,
     // when none of the asm-issued loads is in flight -- because its wait for any of its own loads is a full
     // s_waitcnt vmcnt(0).
-    const int wave_global = uniform((int)blockIdx.x * (int)(blockDim.x >> 6) + wave), waves_total = (int)gridDim.x * (int)(blockDim.x >> 6);
+    // wave-major numbering: consecutive receivers go to different CUs, so the last, partial round still uses every CU
+    const int wave_global = uniform(wave * (int)gridDim.x + (int)blockIdx.x), waves_total = (int)gridDim.x * (int)(blockDim.x >> 6);
     int r = wave_global;
     Stream cur = make_stream(0, 0);
     if (r < p.n_receivers) cur = make_stream(p.rec_off[r], p.rec_off[r + 1]);
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         bool restart = true;  // (re)initialise the detector before the first sub-chunk
         int pos = 0;          // next unconsumed record
         int ring_pos = delta;  // its byte offset in the ring: (delta + 20 pos) mod kRingBytes
-        auto advance = [&](int n) {  // n <= 256 records consumed (5120 B < kRingBytes: one wrap at most)
+        auto advance = [&](int n) {  // n <= kLeanWindow records consumed (less than the ring: one wrap at most)
             pos += n;
             ring_pos += n * kRecBytes;
             if (ring_pos >= kRingBytes) ring_pos -= kRingBytes;
@@ -560,8 +568,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             witness = best == 0xFFFFFFFFu ? -1 : (int)(best & 0xFFFFu);
         };
 
-        // ---- LEAN path: order-free application of a window of up to 256 records, FOUR per lane (quarter q = records
-        // pos + 64 q + lane), cut at its last batch end; the implicit invalidation is deferred (entrants are queued in
+        // ---- LEAN path: order-free application of a window of up to kLeanWindow records, kQuarters per lane (part q =
+        // records pos + 64 q + lane), cut at its last batch end; the implicit invalidation is deferred (entrants are queued in
         // pend[]).  The window is committed only with a CERTIFICATE that the reference cannot emit at any point inside
         // it.  An emission needs updatesInProgress to reach 0 (R/MultiNodeCutDetector.java:110-121), so either of these
         // suffices:
@@ -570,9 +578,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         //   (b) no report of the window takes any subject to H, and no implicit report can be generated in it (nothing
         //       queued, no entrant with hot adjacency): then nothing crosses H at all.
         // Counts only grow, LDS atomics of one wave execute in program order (a later quarter sees the earlier ones'
-        // bits), and every crossing of L is seen by exactly one lane, whatever the order.  Four independent quarters
-        // also give the wave four independent dependency chains to interleave.  Returns 0 -- window rolled back,
-        // nothing consumed -- when no certificate holds.  kTail: fewer than 256 records are left (the last record
+        // bits), and every crossing of L is seen by exactly one lane, whatever the order.  The parts are independent
+        // dependency chains for the wave to interleave.  Returns 0 -- window rolled back,
+        // nothing consumed -- when no certificate holds.  kTail: fewer than kLeanWindow records are left (the last record
         // closes the last batch).
         auto lean_window = [&](auto tail_tag) -> int {
             constexpr bool kTail = decltype(tail_tag)::value;
@@ -810,7 +818,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             issue_head(cur);
         };
         // Makes the records [pos, end_rec) resident.  A slot is recycled only when every record in it has been
-        // consumed: a window of <= 256 records touches <= kWindowSlots slots, so need <= kp + kWindowSlots (kp = the KiB
+        // consumed: a window of <= kLeanWindow records touches <= kWindowSlots slots, so need <= kp + kWindowSlots (kp = the KiB
         // `pos` lies in) and no KiB up to landed + kDepth can reuse the slot of a KiB >= kp.
         auto stream_ensure = [&](int end_rec) {
             const int need = (int)((unsigned int)(delta + kRecBytes * end_rec + kSlotBytes - 1) / (unsigned int)kSlotBytes);
@@ -830,20 +838,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         };
 
         bool from_careful = true;  // the lean path (re)establishes its witness on entry
-        if ((p.flags & 64) != 0 && (p.flags & 32) != 0) {  // measurement aid: the stream alone, in the tightest possible loop
-            RAPID_T1(t_flush, t_rx0);  // profiling build: loop top -> here (index/offset hand-over)
-            RAPID_T0(tq0);
-            stream_start();
-            stream_ensure(min(pos + kLeanWindow, nrec));
-            RAPID_T1(t_careful, tq0);  // first window resident
-            RAPID_T0(tq1);
-            while (pos < nrec) {
-                stream_ensure(min(pos + kLeanWindow, nrec));
-                advance(min(kLeanWindow, nrec - pos));
-            }
-            RAPID_T1(t_lean, tq1);  // steady-state streaming
-            restart = false;
-        }
         while (emit_batch < 0 && (restart || pos < nrec)) {
             if (restart) {
                 // ---- detector state: nothing reported yet ----
@@ -922,7 +916,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     RAPID_T1(t_flush, tf0);
                 }
             }
-            if (!gave_up && pos < nrec) {  // the tail: fewer than 256 records, the last one closes the last batch
+            if (!gave_up && pos < nrec) {  // the tail: less than a window, the last record closes the last batch
                 stream_ensure(nrec);
                 if (!lean_window(std::true_type{})) gave_up = 1;
             }

@@ -9,7 +9,7 @@ view=E.MembershipView(eng).build(pop.hostnames,pop.ports,pop.id_hi,pop.id_lo)
 obs,subj,member=view.tables(); cfg=view.getCurrentConfigurationId()
 sc=S.build_scenario("C3b",subj,cfg)
 sim=E.ClusterSimulation(eng); sim.load_streams(sc.records, sc.rec_off); sim.set_alert_set(sc.batches.recs)
-for flag,name in [(0,"full"),(32,"stream_only"),(96,"stream_only_tight")]:
+for flag,name in [(0,"full"),(64,"full_untrusted"),(32,"stream_only")]:
     sim.set_force_exact(flag)
     ms=sim.time_tally(10)
     print(name, round(ms,3),"ms", round(20*len(sc.records)/ms/1e6,1),"GB/s", sim.stats())

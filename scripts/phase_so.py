@@ -12,11 +12,11 @@ sc = S.build_scenario("C3b", subj, view.getCurrentConfigurationId())
 sim = E.ClusterSimulation(eng)
 sim.load_streams(sc.records, sc.rec_off)
 sim.set_alert_set(sc.batches.recs)
-sim.set_force_exact(96)
+sim.set_force_exact(32)
 ms = sim.time_tally(3)
 s = np.zeros(8, dtype=np.uint64)
 eng._check(eng._lib.rapid_sim_stats(eng._h, E._addr(s)))
 tot = float(s[0])
 print("stream_only tally_ms", round(ms, 4))
-for i, nm in enumerate(["total", "dma_wait(fine only)", "steady streaming loop", "first window resident", "drain..end of receiver", "loop top..stream start"]):
+for i, nm in enumerate(["total", "dma_wait", "lean_window", "careful", "output+init", "flush"]):
     print("%-12s %6.1f %%   %.0f cycles/receiver" % (nm, 100.0 * float(s[i]) / tot, float(s[i]) / max(1.0, float(s[6]))))

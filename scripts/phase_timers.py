@@ -44,6 +44,6 @@ for name, sel in (("slowest 1%", order[-100:]), ("median 1%", order[4950:5050]),
         name, cyc[sel].mean(), dma[sel].mean(), lean[sel].mean(), careful[sel].mean(),
         (cyc[sel] - dma[sel] - lean[sel] - careful[sel]).mean(), sel.mean()))
 # does the time depend on when (which round) a receiver was processed?
-for lo in range(0, 10000, 1000):
-    sel = np.arange(lo, lo + 1000)
+for lo in range(0, len(cyc), 1000):
+    sel = np.arange(lo, min(lo + 1000, len(cyc)))
     print("receivers %5d.. total %8.0f dma %8.0f lean %8.0f careful %8.0f" % (lo, cyc[sel].mean(), dma[sel].mean(), lean[sel].mean(), careful[sel].mean()))
