@@ -978,7 +978,7 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
                                R, salt, h->d_hist.p);
         if (h->comm)  // the per-round all-reduce of the vote histogram over xGMI
             NCCLCHK(h, ncclAllReduce(h->d_hist.p, h->d_hist.p, HB, ncclUint64, ncclSum, h->comm, st));
-        hipLaunchKernelGGL(rapid::vote_winner_kernel, dim3(1), dim3(256), 0, st, h->d_hist.p, h->d_winner.p);
+        hipLaunchKernelGGL(rapid::vote_winner_kernel, dim3(1), dim3(1024), 0, st, h->d_hist.p, h->d_winner.p);
         if (R)
             hipLaunchKernelGGL(rapid::vote_bucket_minmax_kernel, dim3(grid_for(R, 256)), dim3(256), 0, st, h->d_fp.p,
                                h->d_pcount.p, R, salt, h->d_winner.p, h->d_mm.p, my_tag);
@@ -988,7 +988,7 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
                            h->d_pcount.p, h->d_props.p, h->max_cut, h->d_ref.p);
         if (h->comm) NCCLCHK(h, ncclAllReduce(h->d_ref.p, h->d_ref.p, ref_len, ncclInt32, ncclMax, h->comm, st));
         if (R)
-            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(grid_for((long long)R * 64, 256)), dim3(256), 0, st, h->d_fp.p,
+            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(grid_for((long long)R * 64, 1024)), dim3(1024), 0, st, h->d_fp.p,
                                h->d_pcount.p, h->d_props.p, h->max_cut, R, h->d_mm.p, h->d_ref.p, h->d_mismatch.p);
         if (h->comm) NCCLCHK(h, ncclAllReduce(h->d_mismatch.p, h->d_mismatch.p, 2, ncclUint64, ncclSum, h->comm, st));
         HIPCHK(h, hipMemcpyAsync(hw, h->d_winner.p, 32, hipMemcpyDeviceToHost, st));

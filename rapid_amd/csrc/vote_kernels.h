@@ -45,8 +45,8 @@ __global__ void vote_histogram_kernel(const unsigned long long* fp, const int* p
 
 // out[0] = bucket with the most votes, out[1] = its count, out[2] = total voters, out[3] = non-empty buckets.  One block.
 __global__ void vote_winner_kernel(const unsigned long long* hist, unsigned long long* out) {
-    __shared__ unsigned long long best_cnt[256];
-    __shared__ unsigned int best_idx[256];
+    __shared__ unsigned long long best_cnt[1024];
+    __shared__ unsigned int best_idx[1024];
     const int t = (int)threadIdx.x;
     unsigned long long bc = 0;
     unsigned int bi = 0;
@@ -69,7 +69,7 @@ __global__ void vote_winner_kernel(const unsigned long long* hist, unsigned long
         }
         __syncthreads();
     }
-    __shared__ unsigned int nz[256];
+    __shared__ unsigned int nz[1024];
     unsigned int z = 0;
     for (int b = t; b < kVoteBuckets; b += (int)blockDim.x) z += hist[b] != 0ull ? 1u : 0u;
     nz[t] = z;
@@ -127,23 +127,37 @@ __global__ void vote_prepare_ref_kernel(const unsigned long long* mm, unsigned l
 
 // Element-wise verification: every local voter whose fingerprint equals mm[0] (== the winning bucket's only
 // fingerprint when it is pure) must hold exactly the list ref[1..ref[0]].  mismatch[0] counts offenders, mismatch[1]
-// the verified voters.  One wavefront per receiver.
+// the verified voters.  One wavefront per receiver; the counts are reduced per workgroup first -- thousands of waves
+// adding to the same two words would queue up behind each other for longer than the comparison takes.
 __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop_count, const int* props, int prop_cap,
                                    int n_receivers, const unsigned long long* mm, const int* ref,
                                    unsigned long long* mismatch) {
+    __shared__ unsigned int s_bad, s_seen;
+    if (threadIdx.x == 0) {
+        s_bad = 0u;
+        s_seen = 0u;
+    }
+    __syncthreads();
     const int r = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = (int)(threadIdx.x & 63u);
-    if (r >= n_receivers || prop_count[r] == 0 || fp[r] != mm[0]) return;
-    const int ref_n = ref[0];
-    bool bad = prop_count[r] != ref_n;
-    if (!bad) {
-        const int* mine = props + (long long)r * prop_cap;
-        for (int i = lane; i < ref_n; i += 64) bad |= mine[i] != ref[1 + i];
+    const bool voter = r < n_receivers && prop_count[r] != 0 && fp[r] == mm[0];
+    if (voter) {
+        const int ref_n = ref[0];
+        bool bad = prop_count[r] != ref_n;
+        if (!bad) {
+            const int* mine = props + (long long)r * prop_cap;
+            for (int i = lane; i < ref_n; i += 64) bad |= mine[i] != ref[1 + i];
+        }
+        const unsigned long long any_bad = __ballot(bad);
+        if (lane == 0) {
+            if (any_bad) atomicAdd(&s_bad, 1u);
+            atomicAdd(&s_seen, 1u);
+        }
     }
-    const unsigned long long any_bad = __ballot(bad);
-    if (lane == 0) {
-        if (any_bad) atomicAdd(&mismatch[0], 1ull);
-        atomicAdd(&mismatch[1], 1ull);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_bad) atomicAdd(&mismatch[0], (unsigned long long)s_bad);
+        if (s_seen) atomicAdd(&mismatch[1], (unsigned long long)s_seen);
     }
 }
 
