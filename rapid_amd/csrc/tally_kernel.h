@@ -6,27 +6,26 @@
 //                 + MultiNodeCutDetector.aggregateForProposal           R/MultiNodeCutDetector.java:76-128
 //                 + MultiNodeCutDetector.invalidateFailingEdges         R/MultiNodeCutDetector.java:137-164
 //
-// Mapping onto the machine (DESIGN.md "Tally kernel"):
-//   * one wavefront per simulated receiver; a workgroup is W such wavefronts (W chosen so the CU's 160 KB LDS is
-//     full) that share read-only per-round tables in LDS and pull receivers from a global counter (persistent);
-//   * the receiver's whole detector state is one 16-bit word per SLOT in LDS -- a slot is a "hot" subject: one the
-//     round's alert set names on >= L distinct rings, the only kind that can ever reach the L watermark at any
-//     receiver (index_kernels.h builds the node->slot dictionary once per loaded stream set; reports about other
-//     subjects can never change any receiver's outcome and only contribute to seenLinkDownEvents): bits 0..K-1 =
-//     rings reported, bit 14 = already flushed into an emitted proposal;
-//   * the delivered stream is read ONCE from HBM: 2 KiB tiles, 16 B/lane coalesced loads, kPrefetch tiles in
-//     flight in registers per wave; tiles are staged through a small LDS ring and consumed in sub-chunks of up
-//     to 64 records (one per lane) that end at a batch end whenever they contain one.  The tally loop touches
-//     global memory for nothing else (dictionary and adjacency live in LDS), so vmcnt only ever tracks the
-//     prefetch and waits for the oldest tile alone;
-//   * FAST path per sub-chunk: order-free ds_or_rtn on the masks; L/H watermark crossings counted with wave
-//     ballots; implicit edge invalidation applied once per sub-chunk, only for the slots that crossed L
-//     (incremental form) and only along the round's "hot" adjacency (pairs whose both ends can reach L at all);
-//   * the reference's detector is a sequential state machine: an emission can only happen on an H crossing that
-//     finds updatesInProgress == 0.  If (updatesInProgress before the sub-chunk) - (H crossings in it) >= 1, no
-//     emission is possible under ANY order and the order-free result is exact; otherwise the sub-chunk is rolled
-//     back (each lane clears exactly the bits it set) and replayed by the EXACT path, record by record, with the
-//     implicit invalidation after every batch end;
+// Mapping onto the machine:
+//   * one wavefront per simulated receiver, persistent; receivers are dealt round-robin (wave-major); a workgroup is
+//     W such wavefronts (one workgroup per CU, W chosen by the host) that share read-only per-round tables in LDS;
+//   * the receiver's whole detector state is one word per SLOT in LDS -- a slot is a "hot" subject: one the round's
+//     alert set names on >= L distinct rings, the only kind that can ever reach the L watermark at any receiver
+//     (index_kernels.h builds the node->slot dictionary once per loaded stream set; reports about other subjects can
+//     never change any receiver's outcome and only contribute to seenLinkDownEvents): bits 0..K-1 = rings reported,
+//     bit 14 = already flushed into an emitted proposal;
+//   * the delivered stream is read ONCE from HBM and never passes through registers: LDS-DMA loads (lds_dma.h), 1 KiB
+//     per wave instruction, kDepth of them in flight per wave, land in the wave's own 10 KiB LDS ring; completion is
+//     counted by hand (s_waitcnt vmcnt(kDepth - 1) = the oldest has landed).  The tally loop touches global memory
+//     for nothing else;
+//   * LEAN path per window of up to 192 records (three per lane): order-free ds_or_rtn on the masks, committed under a
+//     certificate that the reference cannot emit inside the window (a witness slot that provably stays in
+//     preProposal; or no possible H crossing; or fewer H crossings than updatesInProgress); the implicit edge
+//     invalidation is deferred, incremental (only the slots that crossed L) and walks only the round's "hot"
+//     adjacency (pairs whose both ends can reach L at all);
+//   * without a certificate the window is rolled back (each lane clears exactly the bits it set) and taken by the
+//     CAREFUL path (<= 64 records, invalidation applied immediately, exact crossing count, halving) and finally by the
+//     EXACT path, record by record;
 //   * after the batch that announces a proposal the receiver ignores the rest of its stream
 //     (announcedProposal, R/MembershipService.java:318-319) -- the wave stops reading it.
 //
@@ -57,7 +56,9 @@ constexpr int kDepth = RAPID_RING_SLOTS - kWindowSlots;  // KiB kept in flight p
 static_assert(kDepth >= 1, "ring too small for the window");
 constexpr int kRingSlots = kWindowSlots + kDepth;    // LDS ring the windows are decoded from
 constexpr int kRingBytes = kSlotBytes * kRingSlots;  // 10 KiB = 512 records exactly: records never straddle the ring's end
-static_assert(kRingBytes % kRecBytes == 0, "the ring must hold a whole number of records");
+// With a ring of a whole number of records (10 KiB = 512) no record straddles its end and one wrap per lane is enough;
+// otherwise every dword of a record is wrapped on its own (a smaller ring, more waves per CU, two more VALU per read).
+constexpr bool kRingRecordAligned = kRingBytes % kRecBytes == 0;
 constexpr int kPendCap = 128;                        // slots that crossed L and still await invalidation
 constexpr int kUndoCap = 128;                        // implicit bits set inside one sub-chunk
 constexpr int kMaxWavesPerBlock = 16;
@@ -104,7 +105,7 @@ struct TallyParams {
 __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
 // LDS budget: shared tables (only when they are staged in LDS) + per-wave detector state, ring, lists
 __host__ __device__ inline int tally_shared_bytes(int n_nodes, int n_hot, int n_adj) {
-    return align16(n_nodes * 2) + align16((n_hot + 1) * 2) + align16(n_adj * 4) + align16(n_hot * 4);
+    return align16(n_nodes * 2) + align16((n_hot + 1) * 2) + align16(n_adj * 4) + align16(n_hot * 4) + align16(n_hot * 2);
 }
 __host__ __device__ inline int tally_wave_bytes(int n_slots) {
     return align16(n_slots * 4) + kRingBytes + align16(kPendCap * 2) + kUndoCap * 4;
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     const unsigned short* adj_off = p.idx.adj_off;
     const unsigned int* adj = p.idx.adj;
     const int* node_of_slot = p.idx.node_of_slot;
+    const unsigned short* subject_mask = nullptr;  // per hot slot, staged in LDS; computed on the fly otherwise
     int shared_bytes = 0;
     if (kTablesInLds) {
         unsigned short* l_dict = reinterpret_cast<unsigned short*>(smem);
@@ -395,6 +397,18 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         int* l_nos = reinterpret_cast<int*>(smem + align16(p.n_nodes * 2) + align16((p.idx.n_hot + 1) * 2) + align16(p.idx.n_adj * 4));
         for (int i = (int)threadIdx.x; i < p.idx.n_hot; i += (int)blockDim.x) l_nos[i] = p.idx.node_of_slot[i];
         node_of_slot = l_nos;
+        // rings on which a hot observer watches each hot slot: the implicit reports that slot can ever receive
+        unsigned short* l_smask = reinterpret_cast<unsigned short*>(smem + align16(p.n_nodes * 2) + align16((p.idx.n_hot + 1) * 2) +
+                                                                     align16(p.idx.n_adj * 4) + align16(p.idx.n_hot * 4));
+        for (int i = (int)threadIdx.x; i < p.idx.n_hot; i += (int)blockDim.x) {
+            unsigned int am = 0u;
+            for (int a = (int)p.idx.adj_off[i]; a < (int)p.idx.adj_off[i + 1]; ++a) {
+                const unsigned int ent = p.idx.adj[a];
+                if (((ent >> 20) & 1u) == 0u) am |= 1u << ((ent >> 16) & 15u);  // role 0: slot i is the subject on that ring
+            }
+            l_smask[i] = (unsigned short)am;
+        }
+        subject_mask = l_smask;
         dict = l_dict;
         adj_off = l_off;
         adj = l_adj;
@@ -496,7 +510,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             ring_pos += n * kRecBytes;
             if (ring_pos >= kRingBytes) ring_pos -= kRingBytes;
         };
-        int careful_budget = 0, careful_next = 2;
+        int careful_budget = 0, careful_next = 1;
         int careful_cap = kWave;  // records the careful loop takes at once; halved while an emission cannot be excluded
 
         // per-sub-chunk decode results (one record per lane)
@@ -505,13 +519,19 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         bool down = false, eob = false, hasadj = false;
         unsigned long long mE_all = 0ull;
 
+        // dword `i` of the record that starts at ring byte offset t (t < 2 * kRingBytes, already wrapped if record-aligned)
+        auto ring_word = [&](unsigned int t, int i) -> unsigned int {
+            if (kRingRecordAligned) return ring32[(t >> 2) + i];
+            unsigned int x = t + 4u * (unsigned int)i;
+            x = min(x, x - (unsigned int)kRingBytes);
+            return ring32[x >> 2];
+        };
         // ---- decode the sub-chunk starting at `pos` from the LDS ring ----
         auto decode = [&]() {
             const int navail = min(careful_cap, nrec - pos);
             unsigned int t = (unsigned int)(ring_pos + lane20);
-            t = min(t, t - (unsigned int)kRingBytes);  // per-lane wrap
-            const unsigned int* w = ring32 + (t >> 2);
-            const unsigned int w0 = w[0], w1 = w[1], w3 = w[3], w4 = w[4];
+            if (kRingRecordAligned) t = min(t, t - (unsigned int)kRingBytes);  // per-lane wrap
+            const unsigned int w0 = ring_word(t, 0), w1 = ring_word(t, 1), w3 = ring_word(t, 3), w4 = ring_word(t, 4);
             down = ((w4 >> 16) & 0xFFu) != 0;
             eob = lane < navail && ((((w4 >> 24) & 1u) != 0) || pos + lane == nrec - 1);
             // a sub-chunk ends at its last batch end (if it has one): no record is applied before the batch end
@@ -545,27 +565,54 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         };
 
         // ---- one pass over the hot slots: updatesInProgress (slots with L <= count < H) as the careful path needs it,
-        // and a WITNESS for the lean path -- a slot in [L, H) with no hot adjacency (so it never takes an implicit
-        // report and its count here is the reference's count), the one with the fewest reports.  -1 if there is none.
+        // and a WITNESS for the lean path: a slot in [L, H) that stays below H even if it is given every implicit report
+        // it can ever get -- popc(state | rings on which a hot observer watches it) < H -- so that a lagging state cannot
+        // hide its departure; the one with the smallest such bound.  -1 if there is none.
         int witness = -1;
+        unsigned int witness_mask = 0u;  // rings on which the witness can receive an implicit report
+        bool running_exact = false;      // s.running is the reference's updatesInProgress (nothing queued, kept up to date)
         auto recount = [&]() {
             wave_lds_fence();
             int run = 0;
-            unsigned int best = 0xFFFFFFFFu;  // count << 16 | slot
+            unsigned int best = 0xFFFFFFFFu, best_mask = 0u;  // bound << 16 | slot
             for (int i0 = 0; i0 < d.n_scan; i0 += kWave) {
                 const int i = i0 + lane;
                 const unsigned int m = i < d.n_scan ? d.load(i) : 0u;
                 const int c = d.count(m);
                 const bool pre = i < d.n_scan && c >= d.L && c < d.H;
                 run += __popcll(wave_ballot(pre));
-                const bool free_of_adj = pre && adj_off[i + 1] == adj_off[i];
-                const unsigned int key = free_of_adj ? ((unsigned int)c << 16) | (unsigned int)i : 0xFFFFFFFFu;
-                best = min(best, key);
+                unsigned int am = 0u;
+                if (kTablesInLds) {
+                    am = pre ? (unsigned int)subject_mask[i] : 0u;
+                } else {
+                    int a = pre ? (int)adj_off[i] : 0;
+                    const int a_end = pre ? (int)adj_off[i + 1] : 0;
+                    while (wave_ballot(a < a_end) != 0ull) {
+                        const unsigned int ent = a < a_end ? adj[a] : (1u << 20);
+                        if (((ent >> 20) & 1u) == 0u) am |= 1u << ((ent >> 16) & 15u);  // role 0: slot i is the subject on that ring
+                        ++a;
+                    }
+                }
+                const int bound = d.count(m | am);
+                const unsigned int key = (pre && bound < d.H) ? ((unsigned int)bound << 16) | (unsigned int)i : 0xFFFFFFFFu;
+                if (key < best) {
+                    best = key;
+                    best_mask = am;
+                }
             }
-            for (int o2 = 32; o2 > 0; o2 >>= 1) best = min(best, (unsigned int)__shfl_xor((int)best, o2, kWave));
-            best = uniform(best);
+            unsigned int all_best = best;
+            for (int o2 = 32; o2 > 0; o2 >>= 1) all_best = min(all_best, (unsigned int)__shfl_xor((int)all_best, o2, kWave));
+            all_best = uniform(all_best);
             s.running = run;
-            witness = best == 0xFFFFFFFFu ? -1 : (int)(best & 0xFFFFu);
+            running_exact = s.npend == 0;  // with nothing queued the state here is the reference's
+            if (all_best == 0xFFFFFFFFu) {
+                witness = -1;
+                witness_mask = 0u;
+            } else {
+                witness = (int)(all_best & 0xFFFFu);
+                const unsigned long long holder = wave_ballot(best == all_best);
+                witness_mask = (unsigned int)lane_value((int)best_mask, __ffsll((long long)holder) - 1);
+            }
         };
 
         // ---- LEAN path: order-free application of a window of up to kLeanWindow records, kQuarters per lane (part q =
@@ -573,10 +620,12 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // pend[]).  The window is committed only with a CERTIFICATE that the reference cannot emit at any point inside
         // it.  An emission needs updatesInProgress to reach 0 (R/MultiNodeCutDetector.java:110-121), so either of these
         // suffices:
-        //   (a) the witness -- in preProposal before the window, never the target of an implicit report -- still has
-        //       fewer than H reports after the window: it was in preProposal throughout, updatesInProgress >= 1;
+        //   (a) the witness -- in preProposal before the window -- stays below H even when credited with every implicit
+        //       report it can ever get, popc(state | witness_mask) < H after the window: it was in preProposal
+        //       throughout, updatesInProgress >= 1 (the bound covers whatever the deferred invalidation still owes it);
         //   (b) no report of the window takes any subject to H, and no implicit report can be generated in it (nothing
-        //       queued, no entrant with hot adjacency): then nothing crosses H at all.
+        //       queued, no entrant with hot adjacency): then nothing crosses H at all;
+        //   (c) as (b), but with fewer H crossings than an exactly known updatesInProgress.
         // Counts only grow, LDS atomics of one wave execute in program order (a later quarter sees the earlier ones'
         // bits), and every crossing of L is seen by exactly one lane, whatever the order.  The parts are independent
         // dependency chains for the wave to interleave.  Returns 0 -- window rolled back,
@@ -591,10 +640,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #pragma unroll
             for (int q = 0; q < kQuarters; ++q) {
                 unsigned int t = (unsigned int)(ring_pos + lane20 + q * kWave * kRecBytes);
-                t = min(t, t - (unsigned int)kRingBytes);  // per-lane wrap (records never straddle the end of the ring)
-                const unsigned int* w = ring32 + (t >> 2);
-                w3[q] = w[3];
-                w4[q] = w[4];
+                if (kRingRecordAligned) t = min(t, t - (unsigned int)kRingBytes);  // per-lane wrap
+                w3[q] = ring_word(t, 3);
+                w4[q] = ring_word(t, 4);
             }
             unsigned long long anyE = 0ull;
 #pragma unroll
@@ -630,9 +678,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 } else {
                     // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot
                     unsigned int t = (unsigned int)(ring_pos + lane20 + q * kWave * kRecBytes);
-                    t = min(t, t - (unsigned int)kRingBytes);
-                    const unsigned int* w = ring32 + (t >> 2);
-                    const unsigned int w0 = w[0], w1 = w[1];
+                    if (kRingRecordAligned) t = min(t, t - (unsigned int)kRingBytes);
+                    const unsigned int w0 = ring_word(t, 0), w1 = ring_word(t, 1);
                     de[q] = (unsigned int)dict[w3[q] < (unsigned)p.n_nodes ? w3[q] : 0u];
                     const unsigned int dn = (w4[q] & 0x00FF0000u) != 0u ? 1u : 0u;
                     const unsigned int bad = (w0 ^ cfg_lo) | (w1 ^ cfg_hi) | (dn ^ (de[q] >> 15)) |
@@ -668,15 +715,23 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 anyN |= mL[q] & ~mJ[q];
                 nX += __popcll(mL[q] & mJ[q]);
             }
-            bool certified = witness >= 0 && __popc(wv & d.kmask) < d.H;
+            bool certified = witness >= 0 && __popc((wv | witness_mask) & d.kmask) < d.H;
+            int nLc = 0, nHc = 0;
+            bool counted = false;
             if (!certified) {
+                // (b)/(c): no implicit report can be generated inside the window (nothing queued, no entrant with hot
+                // adjacency), so only its explicit reports cross H -- none of them, or fewer than updatesInProgress
                 unsigned long long mH = 0ull;
 #pragma unroll
                 for (int q = 0; q < kQuarters; ++q) {
                     const unsigned int ok = old[q] & d.kmask;
-                    mH |= mApp[q] & wave_ballot(__popc(ok) < d.H) & wave_ballot(__popc(ok | rb[q]) >= d.H);
+                    const unsigned long long mHq = mApp[q] & wave_ballot(__popc(ok) < d.H) & wave_ballot(__popc(ok | rb[q]) >= d.H);
+                    mH |= mHq;
+                    nHc += __popcll(mHq);
+                    nLc += __popcll(mL[q]);
                 }
-                certified = mH == 0ull && s.npend == 0 && nX == 0;
+                counted = true;
+                certified = s.npend == 0 && nX == 0 && (mH == 0ull || (running_exact && s.running - nHc >= 1));
             }
             if (__builtin_expect(!certified || anyE == 0ull || s.npend + nX > kPendCap, 0)) {
 #ifdef RAPID_TRACE
@@ -711,7 +766,13 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     const unsigned long long mN = mL[q] & ~mJ[q];
                     if (mN != 0ull) witness = lane_value((int)slot[q], __ffsll((long long)mN) - 1);
                 }
+                witness_mask = 0u;
             }
+            // updatesInProgress stays exact only through windows that counted their crossings
+            if (counted && running_exact)
+                s.running += nLc - nHc;
+            else
+                running_exact = false;
             int nbatches = 0;
 #pragma unroll
             for (int q = 0; q < kQuarters; ++q) nbatches += __popcll(mE[q]);
@@ -933,7 +994,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 recount();
                 RAPID_T1(t_flush, tf1);
                 if (pos == pos_in || witness < 0 || witness == old_witness) {
-                    careful_next = (pos - pos_in < 2 * kLeanWindow) ? min(careful_next * 2, 16) : 2;
+                    careful_next = pos == pos_in ? min(careful_next * 2, 16) : 1;
                     careful_budget = careful_next;
                 }
             }
