@@ -18,6 +18,7 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rccl/rccl.h>
 
 #include "../../include/rapid_mi355x.h"
@@ -83,6 +84,10 @@ struct rapid_engine {
     DevBuf<long long> d_ids_hi, d_ids_lo;
     DevBuf<long long> d_cfg_out;
     DevBuf<unsigned char> d_sort_tmp;
+    DevBuf<int> d_seg_off;                       // [K + 1] ring boundaries inside the [K][M] sort buffers
+    std::vector<int> seg_host;                   // its host copy (lives as long as the async upload needs it)
+    std::vector<uint8_t> ring_member;            // member flags the device rings were built from (empty: no rings yet)
+    int ring_m = 0;                              // their length
     int n_ids_dev = 0;
 
     // host mirrors of the tables (filled lazily after a rebuild)
@@ -215,18 +220,36 @@ int rebuild_view(rapid_engine* h) {
     HIPCHK(h, h->d_subj.ensure((size_t)K * N));
     HIPCHK(h, h->d_cfg_out.ensure(1));
 
-    if (M) {
+    // A view change that only removes members leaves the order of the others untouched: compact the rings instead of
+    // sorting them again (the common case -- a decided cut of crashed nodes).
+    bool removals_only = M > 0 && h->ring_m >= M && h->ring_member.size() == (size_t)N;
+    for (int n = 0; removals_only && n < N; ++n)
+        if (h->member[(size_t)n] && !h->ring_member[(size_t)n]) removals_only = false;
+    if (M && removals_only) {
+        if (h->ring_m != M) {
+            hipLaunchKernelGGL(rapid::ring_compact_kernel, dim3(K), dim3(1024), 0, st, h->d_ring.p, h->d_ring_skeys.p, h->ring_m,
+                               h->d_member.p, h->d_sort_vals.p, h->d_sort_keys.p, M);
+            std::swap(h->d_ring, h->d_sort_vals);
+            std::swap(h->d_ring_skeys, h->d_sort_keys);
+        }
+        hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * M, 256)), dim3(256), 0, st, h->d_ring.p,
+                           h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 0);
+    } else if (M) {
         hipLaunchKernelGGL(rapid::ring_gather_kernel, dim3(grid_for((long long)K * M, 256)), dim3(256), 0, st, h->d_keys.p,
                            h->d_members.p, M, N, K, h->d_sort_keys.p, h->d_sort_vals.p);
+        // all K rings in ONE segmented sort (ring k = segment [k M, (k + 1) M) of the key buffer)
+        h->seg_host.resize((size_t)K + 1);
+        for (int k = 0; k <= K; ++k) h->seg_host[(size_t)k] = k * M;
+        HIPCHK(h, h->d_seg_off.ensure((size_t)K + 1));
+        HIPCHK(h, hipMemcpyAsync(h->d_seg_off.p, h->seg_host.data(), sizeof(int) * ((size_t)K + 1), hipMemcpyHostToDevice, st));
         size_t tmp_bytes = 0;
-        HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->d_sort_keys.p, h->d_ring_skeys.p, h->d_sort_vals.p,
-                                            h->d_ring.p, (size_t)M, 0, 64, st));
+        HIPCHK(h, rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, h->d_sort_keys.p, h->d_ring_skeys.p, h->d_sort_vals.p,
+                                                      h->d_ring.p, (unsigned int)((size_t)K * M), (unsigned int)K, h->d_seg_off.p,
+                                                      h->d_seg_off.p + 1, 0, 64, st));
         HIPCHK(h, h->d_sort_tmp.ensure(tmp_bytes + 16));
-        for (int k = 0; k < K; ++k) {
-            const size_t o = (size_t)k * M;
-            HIPCHK(h, rocprim::radix_sort_pairs(h->d_sort_tmp.p, tmp_bytes, h->d_sort_keys.p + o, h->d_ring_skeys.p + o,
-                                                h->d_sort_vals.p + o, h->d_ring.p + o, (size_t)M, 0, 64, st));
-        }
+        HIPCHK(h, rocprim::segmented_radix_sort_pairs(h->d_sort_tmp.p, tmp_bytes, h->d_sort_keys.p, h->d_ring_skeys.p,
+                                                      h->d_sort_vals.p, h->d_ring.p, (unsigned int)((size_t)K * M), (unsigned int)K,
+                                                      h->d_seg_off.p, h->d_seg_off.p + 1, 0, 64, st));
         hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * M, 256)), dim3(256), 0, st, h->d_ring.p,
                            h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 0);
     }
@@ -260,6 +283,8 @@ int rebuild_view(rapid_engine* h) {
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
     h->config_id = cfg;
+    h->ring_member = h->member;
+    h->ring_m = M;
     h->host_tables_valid = false;
     h->tallied = false;
     h->have_decision = false;
@@ -565,6 +590,8 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
     HIPCHK(h, hipStreamSynchronize(h->stream));  // borrowed inputs may go away after the call
     h->view_built = true;
     h->streams_loaded = false;
+    h->ring_member.clear();  // new endpoints, new ring keys: nothing to compact from
+    h->ring_m = 0;
     return rebuild_view(h);
 }
 

@@ -129,6 +129,41 @@ __global__ void ring_gather_kernel(const long long* keys, const int* members, in
     sort_vals[t] = n;
 }
 
+// Removal-only view change: the ring order of the remaining members does not change, so every ring is its old self
+// minus the deleted nodes (R/MembershipView.java:167-201 removes the endpoint from each TreeSet, nothing moves).
+// One workgroup per ring: stable compaction of the (sortable key, node) pairs by the new member flags.
+__global__ void ring_compact_kernel(const int* ring_in, const unsigned long long* skeys_in, int m_old,
+                                    const unsigned char* member, int* ring_out, unsigned long long* skeys_out, int m_new) {
+    __shared__ int s_count[1024];
+    const int k = (int)blockIdx.x, T = (int)blockDim.x, t = (int)threadIdx.x;
+    const int per = (m_old + T - 1) / T;
+    const int beg = min(m_old, t * per), end = min(m_old, beg + per);
+    const int* rin = ring_in + (long long)k * m_old;
+    const unsigned long long* kin = skeys_in + (long long)k * m_old;
+    int kept = 0;
+    for (int i = beg; i < end; ++i) kept += member[rin[i]] ? 1 : 0;
+    s_count[t] = kept;
+    __syncthreads();
+    // inclusive Hillis-Steele scan over the T partial counts
+    for (int off = 1; off < T; off <<= 1) {
+        const int v = t >= off ? s_count[t - off] : 0;
+        __syncthreads();
+        s_count[t] += v;
+        __syncthreads();
+    }
+    int w = s_count[t] - kept;  // exclusive prefix
+    int* rout = ring_out + (long long)k * m_new;
+    unsigned long long* kout = skeys_out + (long long)k * m_new;
+    for (int i = beg; i < end; ++i) {
+        const int node = rin[i];
+        if (member[node] && w < m_new) {
+            rout[w] = node;
+            kout[w] = kin[i];
+            ++w;
+        }
+    }
+}
+
 // after the K sorts: ring[k][pos] = node, ring_skeys[k][pos] = sortable key.  Members get successor /
 // predecessor rows; non-members get their expected observers (predecessor of their key on every ring).
 __global__ void ring_tables_kernel(const int* ring, const unsigned long long* ring_skeys, const long long* keys,

@@ -135,6 +135,45 @@ def test_view_add_delete_sequences_and_errors(E):
     assert view.getCurrentConfigurationId() == oview.getCurrentConfigurationId()
 
 
+def test_bulk_removal_compacts_rings_like_the_oracle(E):
+    """A decided cut that only removes members takes the ring-compaction path (no re-sort); a later join the sort path.
+    Every ring, table and configuration id must equal the oracle's after each (R/MembershipView.java:123-201)."""
+    n, K = 1500, 10
+    pop = S.Population.make(n)
+    members = list(range(0, n - 20))  # the last 20 endpoints stay outside as future joiners
+    eng, view = make_engine(E, pop, K, 9, 4, members=members)
+    sim = E.ClusterSimulation(eng)  # apply_cut lives on the simulation facade
+    reg, oview = oracle_view(pop, K, members)
+    rng = np.random.default_rng(7)
+
+    def same():
+        assert view.getMembershipSize() == oview.getMembershipSize()
+        for k in range(K):
+            assert np.array_equal(view.getRing(k), oview.getRing(k))
+        obs, subj, member = view.tables()
+        oobs, osubj, omember = oview.tables(n)
+        assert np.array_equal(obs, oobs) and np.array_equal(subj, osubj) and np.array_equal(member, omember)
+        assert view.getCurrentConfigurationId() == oview.getCurrentConfigurationId()
+
+    same()
+    for round_size in (1, 37, 300, 2):
+        alive = np.array([m for m in range(n) if oview.isHostPresent(m)])
+        cut = sorted(rng.choice(alive, size=round_size, replace=False).tolist())
+        sim.apply_cut(cut)
+        for node in cut:
+            oview.ringDelete(node)
+        same()
+    joiner = n - 5
+    view.ringAdd(joiner, (int(pop.id_hi[joiner]), int(pop.id_lo[joiner])))
+    oview.ringAdd(joiner, (int(pop.id_hi[joiner]), int(pop.id_lo[joiner])))
+    same()
+    cut = [int(x) for x in rng.choice(np.array([m for m in range(n) if oview.isHostPresent(m)]), size=50, replace=False)]
+    sim.apply_cut(sorted(cut))
+    for node in sorted(cut):
+        oview.ringDelete(node)
+    same()
+
+
 def test_config_id_properties(E):
     """MembershipViewTest.java:441-499: N adds -> N distinct ids; same final set in any order -> same id."""
     n, K = 300, 10
