@@ -97,17 +97,32 @@ __global__ void index_adj_kernel(const int* obs, const unsigned short* dict, con
     }
 }
 
-// One block: adj_off = exclusive scan of deg (u16); info[3] = n_adj; info[2] |= 2 on overflow.
+// One wavefront: adj_off = exclusive scan of deg (u16); info[3] = n_adj; info[2] |= 2 on overflow.  Lane l owns the
+// consecutive chunk [l * per, (l + 1) * per); the chunk totals are scanned across the wave with shuffles.
 __global__ void index_adj_scan_kernel(const int* deg, int n_hot, unsigned short* adj_off, int* info) {
-    if (threadIdx.x != 0) return;
-    long long acc = 0;
-    for (int i = 0; i < n_hot; ++i) {
+    const int lane = (int)(threadIdx.x & 63u);
+    if (threadIdx.x >= 64u) return;
+    const int per = (n_hot + 63) / 64;
+    const int beg = min(n_hot, lane * per), end = min(n_hot, beg + per);
+    long long mine = 0;
+    for (int i = beg; i < end; ++i) mine += deg[i];
+    long long incl = mine;  // inclusive scan of the chunk totals
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long lo = (long long)(unsigned int)__shfl_up((int)(unsigned int)incl, off, 64);
+        const long long hi = (long long)__shfl_up((int)(incl >> 32), off, 64);
+        if (lane >= off) incl += (hi << 32) | lo;
+    }
+    long long acc = incl - mine;
+    for (int i = beg; i < end; ++i) {
         adj_off[i] = (unsigned short)(acc > 65535 ? 65535 : acc);
         acc += deg[i];
     }
-    adj_off[n_hot] = (unsigned short)(acc > 65535 ? 65535 : acc);
-    info[3] = (int)(acc > 0x7FFFFFFF ? 0x7FFFFFFF : acc);
-    if (acc > 65535) info[2] |= 2;
+    const long long total = ((long long)__shfl((int)(incl >> 32), 63, 64) << 32) | (long long)(unsigned int)__shfl((int)(unsigned int)incl, 63, 64);
+    if (lane == 0) {
+        adj_off[n_hot] = (unsigned short)(total > 65535 ? 65535 : total);
+        info[3] = (int)(total > 0x7FFFFFFF ? 0x7FFFFFFF : total);
+        if (total > 65535) info[2] |= 2;
+    }
 }
 
 // dict[node] |= has-adjacency flag for every hot slot with at least one adjacency entry
