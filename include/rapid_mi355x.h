@@ -197,6 +197,8 @@ int rapid_engine_comm_init(rapid_engine* h, const uint8_t id[RAPID_UNIQUE_ID_BYT
  * receiver restarts, implicit reports applied, records consumed, 0, 0. */
 void* rapid_engine_stream(rapid_engine* h);
 int rapid_engine_sync(rapid_engine* h);
+/* counters of the tally launches since the streams were loaded: {exact sub-chunks, lean windows, full invalidation
+ * sweeps, restarts, implicit reports applied, records consumed, lean-path give-ups, careful sub-chunks} */
 int rapid_sim_stats(rapid_engine* h, uint64_t stats[8]);
 /* average duration (ms) of the tally kernel over `reps` back-to-back launches, HIP events on the engine stream */
 int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg);
@@ -205,9 +207,13 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg);
  * declared (0/1)}; index_ms = device time of the last index build */
 int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms);
 /* measurement probe (not a product path): stream the loaded records with the tally kernel's access pattern and no
- * processing.  variant 0: 2 KiB tiles x 8 in flight, 1: 4 KiB x 4, 2: 8 KiB x 2, 3: 2 KiB x 4; waves per block */
+ * processing.  Register loads: variant 0 = 2 KiB tiles x 8 in flight, 1: 4 KiB x 4, 2: 8 KiB x 2, 3: 2 KiB x 4,
+ * 4: 1 KiB x 8, 5: 1 KiB x 16, 6: 1 KiB x 4; LDS-DMA loads (the tally kernel's path): 7: 1 KiB x 4, 8: 1 KiB x 8,
+ * 9: 1 KiB x 6.  `waves` = waves per workgroup (16 waves per CU unless RAPID_PROBE_WAVES_PER_CU says otherwise) */
 int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, int32_t reps, float* ms_avg);
-/* testing knob: run every sub-chunk through the exact sequential path (0 = normal) */
+/* testing / measurement knob, a bit set (0 = normal): 1 = every sub-chunk through the exact sequential path, 8 = careful
+ * path only (no lean windows), 64 = never trust the pre-validation of the alert set, 32 = measurement only: stream the
+ * records through the LDS ring without tallying them (results are meaningless) */
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);
 
 #ifdef __cplusplus
