@@ -337,8 +337,8 @@ class ClusterSimulation:
     def stats(self):
         s = np.zeros(8, dtype=np.uint64)
         self.e._check(self.e._lib.rapid_sim_stats(self.e._h, _addr(s)))
-        return dict(exact_subchunks=int(s[0]), fast_subchunks=int(s[1]), full_sweeps=int(s[2]), restarts=int(s[3]),
-                    implicit_reports=int(s[4]), records_consumed=int(s[5]), pipelined_entries=int(s[6]),
+        return dict(exact_subchunks=int(s[0]), lean_windows=int(s[1]), full_sweeps=int(s[2]), restarts=int(s[3]),
+                    implicit_reports=int(s[4]), records_consumed=int(s[5]), lean_give_ups=int(s[6]),
                     careful_subchunks=int(s[7]))
 
     def time_tally(self, reps):

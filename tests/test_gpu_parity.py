@@ -384,7 +384,7 @@ def test_population_scenarios_vs_faithful_oracle(E, name, n, f, K, H, L):
             return sim.proposal(int(rx[i]))
     assert_matches(Sub(), sub, oracle_out, key0, sample=range(0, len(rx), 5))
     st = sim.stats()
-    assert st["records_consumed"] <= len(sc.records) and st["fast_subchunks"] > 0 or n <= 50
+    assert st["records_consumed"] <= len(sc.records) and st["lean_windows"] > 0 or n <= 50
     # every receiver against the optimised CPU formulation
     fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=8)
     assert np.array_equal(res[0], fe) and np.array_equal(res[1], fn) and np.array_equal(res[2], np.diff(fo))
