@@ -482,8 +482,13 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // wave-major numbering: consecutive receivers go to different CUs, so the last, partial round still uses every CU
     const int wave_global = uniform(wave * (int)gridDim.x + (int)blockIdx.x), waves_total = (int)gridDim.x * (int)(blockDim.x >> 6);
     int r = wave_global;
+#ifdef RAPID_REVERSE_DEAL  // measurement aid: the same deal over the receivers in reverse order
+#define RAPID_RX(i) (p.n_receivers - 1 - (i))
+#else
+#define RAPID_RX(i) (i)
+#endif
     Stream cur = make_stream(0, 0);
-    if (r < p.n_receivers) cur = make_stream(p.rec_off[r], p.rec_off[r + 1]);
+    if (r < p.n_receivers) cur = make_stream(p.rec_off[RAPID_RX(r)], p.rec_off[RAPID_RX(r) + 1]);
     bool prestarted = false;  // the head of `cur` is already on its way into the ring
     while (r < p.n_receivers) {
 #ifdef RAPID_PHASE_TIMERS
@@ -493,8 +498,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         const int r_next = uniform(r + waves_total);
         long long n0_v = 0, n1_v = 0;  // lane 0: stream bounds of r_next, consumed after this receiver's stream
         if (lane == 0 && r_next < p.n_receivers) {
-            n0_v = p.rec_off[r_next];
-            n1_v = p.rec_off[r_next + 1];
+            n0_v = p.rec_off[RAPID_RX(r_next)];
+            n1_v = p.rec_off[RAPID_RX(r_next) + 1];
         }
         const dma_rsrc_t rsrc = dma_uniform(cur.rsrc);
         const int delta = uniform(cur.delta), nrec = uniform(cur.nrec);
@@ -1015,7 +1020,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         unsigned long long fp = 0;
         if (emit_batch >= 0) {
             wave_lds_fence();
-            int* const out = p.props + (long long)r * p.prop_cap;
+            int* const out = p.props + (long long)RAPID_RX(r) * p.prop_cap;
             for (int i0 = 0; i0 < d.n_scan; i0 += kWave) {
                 const int i = i0 + lane;
                 const bool take = i < d.n_scan && (d.load(i) & kFlushed) != 0;
@@ -1032,16 +1037,16 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             if (fp == 0) fp = 1;
         }
         if (lane == 0) {
-            p.emit_batch[r] = emit_batch;
-            p.num_proposals[r] = s.proposal_count;
-            p.prop_count[r] = count > p.prop_cap ? -1 : count;
+            p.emit_batch[RAPID_RX(r)] = emit_batch;
+            p.num_proposals[RAPID_RX(r)] = s.proposal_count;
+            p.prop_count[RAPID_RX(r)] = count > p.prop_cap ? -1 : count;
 #ifdef RAPID_PHASE_TIMERS
             // profiling build: cycles spent on this receiver, in total and per phase
-            p.fingerprint[r] = ((__builtin_amdgcn_s_memtime() - t_rx0) & 0xFFFFFFFFull) | ((t_ensure - t_ensure0) << 32);
-            p.num_proposals[r] = (int)((t_careful - t_careful0) >> 4);
-            p.prop_count[r] = (int)((t_lean - t_lean0) >> 4);
+            p.fingerprint[RAPID_RX(r)] = ((__builtin_amdgcn_s_memtime() - t_rx0) & 0xFFFFFFFFull) | ((t_ensure - t_ensure0) << 32);
+            p.num_proposals[RAPID_RX(r)] = (int)((t_careful - t_careful0) >> 4);
+            p.prop_count[RAPID_RX(r)] = (int)((t_lean - t_lean0) >> 4);
 #else
-            p.fingerprint[r] = fp;
+            p.fingerprint[RAPID_RX(r)] = fp;
 #endif
         }
         wave_lds_fence();
