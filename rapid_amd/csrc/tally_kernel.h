@@ -63,7 +63,6 @@ constexpr int kPendCap = 128;                        // slots that crossed L and
 constexpr int kUndoCap = 128;                        // implicit bits set inside one sub-chunk
 constexpr int kMaxWavesPerBlock = 16;
 constexpr uint32_t kFlushed = 1u << 14;
-constexpr uint32_t kMember = 1u << 15;
 // dictionary entry (16 bit): bit 15 = node is a member, bit 14 = slot has hot adjacency, bits 0..13 = slot
 constexpr unsigned int kDictMember = 1u << 15;
 constexpr unsigned int kDictHasAdj = 1u << 14;
@@ -140,15 +139,6 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // 
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
-}
-
-// 16 B per lane through a buffer resource descriptor (V#): a 32-bit per-lane offset plus a scalar tile offset, and
-// the hardware bounds check returns zeros past the end of the receiver's stream -- no address clamping in the
-// loop and no memory traffic for tiles beyond the stream.
-using buffer_rsrc_t = decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0));
-__device__ __forceinline__ uint4 buffer_load16(buffer_rsrc_t rsrc, unsigned int lane_off, unsigned int tile_off) {
-    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, tile_off, 0);
-    return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
 // Phase timers of the profiling build (-DRAPID_PHASE_TIMERS, scripts/phase_timers.sh): shader-clock cycles per phase,

@@ -65,27 +65,6 @@ inline int cur_lane() { return g_block->cur & 63; }
 void run_block(unsigned block, unsigned grid, unsigned nthreads, const std::function<void()>& body, uint64_t seed);
 }  // namespace emu
 
-// buffer resource descriptor + bounds-checked 16-B load
-namespace emu {
-struct Rsrc {
-    const unsigned char* base;
-    unsigned int num;
-};
-struct U4 {
-    unsigned int v[4];
-    unsigned int operator[](int i) const { return v[i]; }
-};
-}  // namespace emu
-inline emu::Rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num, int) {
-    return emu::Rsrc{static_cast<const unsigned char*>(p), (unsigned int)num};
-}
-inline emu::U4 __builtin_amdgcn_raw_buffer_load_b128(emu::Rsrc r, unsigned int voff, unsigned int soff, int) {
-    emu::U4 out{{0, 0, 0, 0}};
-    const unsigned long long off = (unsigned long long)voff + soff;
-    if (r.base != nullptr && off + 16ull <= r.num) std::memcpy(out.v, r.base + off, 16);
-    return out;
-}
-
 #define threadIdx (emu::g_threadIdx)
 #define blockIdx (emu::g_blockIdx)
 #define blockDim (emu::g_blockDim)
