@@ -283,9 +283,11 @@ __device__ inline int invalidate_adj(const SlotDetector& d, const unsigned short
         act = act && e < d.n_scan;
         int a = act ? (int)d.adj_off[e] : 0;
         const int end = act ? (int)d.adj_off[e + 1] : 0;
+        unsigned int ent_next = a < end ? d.adj[a] : 0u;  // the (read-only) adjacency entry is fetched one step ahead
         while (wave_ballot(a < end) != 0ull) {
             const bool on = a < end;
-            const unsigned int ent = on ? d.adj[a] : 0u;
+            const unsigned int ent = ent_next;
+            ent_next = a + 1 < end ? d.adj[a + 1] : 0u;
             const int other = (int)(ent & 0xFFFFu);
             const int k = (int)((ent >> 16) & 15u);
             const bool other_is_subject = ((ent >> 20) & 1u) != 0;
