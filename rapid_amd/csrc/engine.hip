@@ -391,7 +391,7 @@ int build_round_index(rapid_engine* h) {
     const int shared = rapid::tally_shared_bytes(N, h->n_hot, h->n_adj);
     if (per_wave > lds_max)
         return fail(h, RAPID_ECAPACITY, "%d subjects need %d B of LDS per receiver (max %d)", h->n_slots, per_wave, lds_max);
-    h->tables_in_lds = shared + per_wave <= lds_max;
+    h->tables_in_lds = shared + per_wave + rapid::kBlockStatsBytes <= lds_max;
     const int sh = h->tables_in_lds ? shared : 0;
     // Waves per CU: every receiver costs about the same, so the kernel runs ceil(receivers / resident waves) rounds;
     // a wave is slowed by roughly 4 % per co-resident wave (measured, profiles/), so among the wave counts that fit
@@ -402,7 +402,7 @@ int build_round_index(rapid_engine* h) {
     int w_cap = rapid::kMaxWavesPerBlock;
     if (const char* e = getenv("RAPID_TALLY_WAVES")) w_cap = std::max(1, std::min(w_cap, atoi(e)));  // profiling knob
     for (int w = 1; w <= w_cap; ++w) {
-        const int blk = sh + w * per_wave;
+        const int blk = sh + w * per_wave + rapid::kBlockStatsBytes;
         if (blk > lds_max) break;
         const int per_cu = std::min(32, (lds_max / blk) * w);
         const long long resident = (long long)per_cu * h->num_cus;
@@ -414,7 +414,7 @@ int build_round_index(rapid_engine* h) {
         }
     }
     h->waves_per_block = best_w;
-    h->lds_bytes = sh + best_w * per_wave;
+    h->lds_bytes = sh + best_w * per_wave + rapid::kBlockStatsBytes;
     const int blocks_per_cu = std::max(1, std::min(32 / best_w, lds_max / h->lds_bytes));
     const long long want = ((long long)h->n_receivers + best_w - 1) / best_w;
     h->grid_blocks = (int)std::max<long long>(1, std::min<long long>(want, (long long)h->num_cus * blocks_per_cu));
@@ -445,7 +445,7 @@ int launch_tally(rapid_engine* h) {
     p.fingerprint = h->d_fp.p;
     p.props = h->d_props.p;
     p.prop_cap = h->max_cut;
-    p.stats = h->d_stats.p;
+    p.stats = h->d_stats.p;  // [grid_blocks][8]
     p.next_receiver = h->d_next.p;
     p.waves_per_block = h->waves_per_block;
     p.flags = h->force_exact & (1 | 8 | 32);
@@ -484,7 +484,7 @@ int prepare_tally(rapid_engine* h) {
     HIPCHK(h, h->d_pcount.ensure(R));
     HIPCHK(h, h->d_fp.ensure(R));
     HIPCHK(h, h->d_props.ensure(R * (size_t)h->max_cut));
-    HIPCHK(h, h->d_stats.ensure(8));
+    HIPCHK(h, h->d_stats.ensure((size_t)8 * (size_t)std::max(h->grid_blocks, 1)));
     HIPCHK(h, h->d_next.ensure(4));
     return RAPID_OK;
 }
@@ -908,7 +908,7 @@ int rapid_sim_tally(rapid_engine* h) {
     int rc = use_device(h);
     if (rc) return rc;
     if ((rc = prepare_tally(h))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, 64, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * (size_t)std::max(h->grid_blocks, 1), h->stream));
     if (h->n_receivers > 0) {
         if ((rc = launch_tally(h))) return rc;
         HIPCHK(h, hipGetLastError());
@@ -1184,8 +1184,14 @@ int rapid_sim_stats(rapid_engine* h, uint64_t stats[8]) {
     if (!h->tallied) return fail(h, RAPID_ESTATE, "no tally has run");
     int rc = use_device(h);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(stats, h->d_stats.p, 64, hipMemcpyDeviceToHost, h->stream));
+    // one row of eight counters per workgroup (no contended atomics in the kernel): summed here
+    const size_t rows = (size_t)std::max(h->grid_blocks, 1);
+    std::vector<uint64_t> per_block(rows * 8);
+    HIPCHK(h, hipMemcpyAsync(per_block.data(), h->d_stats.p, rows * 64, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
+    for (size_t b = 0; b < rows; ++b)
+        for (int i = 0; i < 8; ++i) stats[i] += per_block[b * 8 + (size_t)i];
     return RAPID_OK;
 }
 
@@ -1198,7 +1204,7 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg) {
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0));
     HIPCHK(h, hipEventCreate(&e1));
-    HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, 64, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * (size_t)std::max(h->grid_blocks, 1), h->stream));
     launch_tally(h);  // untimed warm-up
     HIPCHK(h, hipEventRecord(e0, h->stream));
     for (int i = 0; i < reps; ++i) launch_tally(h);

@@ -138,7 +138,8 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
                   const unsigned int* adj, int n_hot, int n_adj, int* emit_batch, int* num_proposals,
                   int* prop_count, unsigned long long* fingerprint, int* props, int prop_cap, unsigned long long* stats,
                   int flags, int waves, int grid, int tables_in_lds, unsigned long long seed) {
-    const int lds = (tables_in_lds ? rapid::tally_shared_bytes(n_nodes, n_hot, n_adj) : 0) + waves * rapid::tally_wave_bytes(n_hot);
+    const int lds = (tables_in_lds ? rapid::tally_shared_bytes(n_nodes, n_hot, n_adj) : 0) + waves * rapid::tally_wave_bytes(n_hot) +
+                    rapid::kBlockStatsBytes;
     if (lds > (int)sizeof(smem)) return -5;
     rapid::TallyParams p;
     p.records = records;

@@ -90,14 +90,14 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     pcount = np.full(R, -99, dtype=np.int32)
     fp = np.zeros(R, dtype=np.uint64)
     props = np.full((R, prop_cap), -1, dtype=np.int32)
-    stats = np.zeros(8, dtype=np.uint64)
+    stats = np.zeros((grid, 8), dtype=np.uint64)  # one row per workgroup, as the kernel writes them
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     rc = L_.emu_tally_run(p(raw), C.c_ulonglong((raw.nbytes // 16) * 16), p(rec_off), R, n_nodes, K, H, L, C.c_longlong(cfg_id),
                           p(ix["dict"]), p(ix["node_of_slot"]), p(ix["adj_off"]), p(ix["adj"]),
                           ix["n_hot"], ix["n_adj"], p(emit), p(nprop), p(pcount), p(fp), p(props), prop_cap, p(stats),
                           force_exact, waves, grid, tables_in_lds, C.c_ulonglong(seed))
     assert rc == 0, rc
-    return emit, nprop, pcount, fp, props, stats
+    return emit, nprop, pcount, fp, props, stats.sum(axis=0)
 
 
 class CdInstance:
