@@ -446,10 +446,8 @@ int launch_tally(rapid_engine* h) {
     p.props = h->d_props.p;
     p.prop_cap = h->max_cut;
     p.stats = h->d_stats.p;  // [grid_blocks][8]
-    p.next_receiver = h->d_next.p;
     p.waves_per_block = h->waves_per_block;
     p.flags = h->force_exact & (1 | 8 | 32);
-    HIPCHK(h, hipMemsetAsync(h->d_next.p, 0, sizeof(unsigned int), h->stream));
     const dim3 grid((unsigned)h->grid_blocks), block((unsigned)h->waves_per_block * 64u);
     const bool trusted = h->trusted && (h->force_exact & 64) == 0;  // bit6 of the testing knob: never trust
     if (h->tables_in_lds && trusted)

@@ -96,7 +96,6 @@ struct TallyParams {
     int* props;                       // [R][prop_cap] ascending node index
     int prop_cap;
     unsigned long long* stats;        // [workgroups][8], accumulated over launches
-    unsigned int* next_receiver;      // work counter (zeroed before every launch)
     int waves_per_block;
     int flags;                        // bit0: exact path only, bit3: careful path only (both for tests); bit5: stream only
 };

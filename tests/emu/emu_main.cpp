@@ -164,8 +164,6 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     p.props = props;
     p.prop_cap = prop_cap;
     p.stats = stats;
-    unsigned int next = 0;
-    p.next_receiver = &next;
     p.waves_per_block = waves;
     p.flags = flags;
     for (int b = 0; b < grid; ++b) {
