@@ -94,12 +94,14 @@ class BatchSet:
 
 def _merge_reports(obs_idx, subj_idx, ring, cfg_id, status=DOWN):
     """(observer, subject, ring) triples -> one record per (observer, subject) with a ring mask, grouped into one
-    batch per observer (mirrors addAllRingNumber(getRingNumbers(..)), MembershipService.java:486-492)."""
+    batch per observer (mirrors addAllRingNumber(getRingNumbers(..)), MembershipService.java:486-492).  `status` is a
+    scalar or one value per triple (all triples of one (observer, subject) pair carry the same status)."""
     if len(obs_idx) == 0:
         return BatchSet(np.zeros(0, dtype=ALERT_DTYPE), np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32))
+    status = np.broadcast_to(np.asarray(status, dtype=np.uint8), (len(obs_idx),))
     key = obs_idx.astype(np.int64) * (1 << 32) + subj_idx.astype(np.int64)
     order = np.argsort(key, kind="stable")
-    key, ring = key[order], ring[order]
+    key, ring, status = key[order], ring[order], status[order]
     uniq, start = np.unique(key, return_index=True)
     mask = np.bitwise_or.reduceat((1 << ring.astype(np.int64)), start).astype(np.uint16)
     recs = np.zeros(len(uniq), dtype=ALERT_DTYPE)
@@ -107,7 +109,7 @@ def _merge_reports(obs_idx, subj_idx, ring, cfg_id, status=DOWN):
     recs["src"] = (uniq >> 32).astype(np.uint32)
     recs["dst"] = (uniq & 0xFFFFFFFF).astype(np.uint32)
     recs["ring_mask"] = mask
-    recs["status"] = status
+    recs["status"] = status[start]
     senders, bstart = np.unique(recs["src"], return_index=True)
     off = np.concatenate([bstart, [len(recs)]]).astype(np.int64)
     recs["flags"][off[1:] - 1] = FLAG_LAST_IN_BATCH
@@ -132,6 +134,59 @@ def ingress_loss_batches(subj, faulty, cfg_id):
     is_f[faulty] = True
     o, k = np.nonzero(is_f[subj] | is_f[:, None])
     return _merge_reports(o.astype(np.int32), subj[o, k], k.astype(np.int32), cfg_id)
+
+
+def churn_batches(obs, member, crashed, joiners, cfg_id):
+    """Churn: members crash and new nodes join in the same configuration.  Every healthy member
+    that observes a crashed member reports it DOWN on the rings where it observes it; every healthy member that is an
+    EXPECTED observer of a joiner (MembershipView.getExpectedObserversOf, R/MembershipView.java:292-322 -- row `joiner`
+    of the observer table for a non-member) reports it UP on those rings, as the gatekeepers of the join protocol do
+    (R/MembershipService.java:231-254).  Crashed observers report nothing: a joiner or a crashed node whose observer
+    crashed too only completes through the implicit invalidation (R/MultiNodeCutDetector.java:137-164).
+    obs: [N][K] observer table of the current view, member: [N] flags."""
+    n, K = obs.shape
+    dead = np.zeros(n, dtype=bool)
+    dead[np.asarray(crashed, dtype=np.int64)] = True
+    is_member = np.asarray(member) != 0
+    assert is_member[np.asarray(crashed, dtype=np.int64)].all() and not is_member[np.asarray(joiners, dtype=np.int64)].any()
+    o_all, s_all, k_all, st_all = [], [], [], []
+    for nodes, status in ((np.asarray(crashed, dtype=np.int64), DOWN), (np.asarray(joiners, dtype=np.int64), UP)):
+        if len(nodes) == 0:
+            continue
+        o = obs[nodes]  # [len][K] observers of each node, ring by ring
+        ok = (o >= 0) & is_member[np.clip(o, 0, n - 1)] & ~dead[np.clip(o, 0, n - 1)]
+        i, k = np.nonzero(ok)
+        o_all.append(o[i, k])
+        s_all.append(nodes[i])
+        k_all.append(k)
+        st_all.append(np.full(len(i), status, dtype=np.uint8))
+    if not o_all:
+        return _merge_reports(np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32), cfg_id)
+    return _merge_reports(np.concatenate(o_all).astype(np.int32), np.concatenate(s_all).astype(np.int32),
+                          np.concatenate(k_all).astype(np.int32), cfg_id, np.concatenate(st_all))
+
+
+def build_churn_scenario(obs, member, cfg_id, n_crash, n_join, H, L, seed_fault=1, seed_delivery=2, receivers=None,
+                         materialise=True):
+    """`n_crash` seeded members crash and `n_join` seeded non-members join; receivers = the surviving members."""
+    n, K = obs.shape
+    is_member = np.asarray(member) != 0
+    rng = np.random.Generator(np.random.PCG64(seed_fault))
+    members = np.flatnonzero(is_member)
+    outsiders = np.flatnonzero(~is_member)
+    assert n_crash <= len(members) and n_join <= len(outsiders)
+    crashed = np.sort(rng.permutation(members)[:n_crash]).astype(np.int32)
+    joiners = np.sort(rng.permutation(outsiders)[:n_join]).astype(np.int32)
+    bs = churn_batches(obs, member, crashed, joiners, cfg_id)
+    dead = np.zeros(n, dtype=bool)
+    dead[crashed] = True
+    survivors = np.flatnonzero(is_member & ~dead).astype(np.int32)
+    rx = survivors if receivers is None else np.asarray(receivers, dtype=np.int32)
+    sc = Scenario("churn", n, K, H, L, np.sort(np.concatenate([crashed, joiners])).astype(np.int32), rx, bs)
+    sc.crashed, sc.joiners = crashed, joiners
+    if materialise:
+        sc.records, sc.rec_off, sc.n_batches_delivered = deliver(bs, rx, seed_delivery)
+    return sc
 
 
 def deliver(batches, receivers, seed_delivery, loss=0.0, stale_cfg=None, stale_rate=0.0):

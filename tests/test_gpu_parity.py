@@ -444,6 +444,55 @@ def test_round_decides_and_applies_cut(E):
         assert np.array_equal(sim.results()[0], fe2[0])
 
 
+def test_churn_round_joins_and_crashes_in_one_cut(E):
+    """UP alerts about joiners (non-members, expected observers) and DOWN alerts about crashed members
+    in the same configuration: every surviving member announces crashed + joiners, the fast round decides, and
+    rapid_apply_cut removes / adds them like decideViewChange (R/MembershipService.java:385-430) -- same rings, tables
+    and configuration id as the oracle."""
+    n, n_out, n_crash, n_join, K, H, L = 1200, 60, 25, 30, 10, 9, 4
+    pop = S.Population.make(n)
+    members = list(range(0, n - n_out))
+    eng, view = make_engine(E, pop, K, H, L, members=members)
+    reg, oview = oracle_view(pop, K, members)
+    obs, subj, member = view.tables()
+    oobs, osubj, omember = oview.tables(n)
+    assert np.array_equal(obs, oobs) and np.array_equal(member, omember)  # incl. expected observers of non-members (Q3)
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_churn_scenario(obs, member, cfg, n_crash, n_join, H, L)
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(sc.records, sc.rec_off)
+    sim.set_alert_set(sc.batches.recs)
+    sim.tally()
+    emit, nprop, pcount, fp = sim.results()
+    fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=8)
+    assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
+    for r in range(0, len(fe), 37):
+        assert sorted(sim.proposal(r)) == sorted(fpp[fo[r]:fo[r + 1]].tolist()) == sc.faulty.tolist()
+    rr = sim.count_votes()
+    assert rr.decided == 1 and rr.membership_size == n - n_out and rr.votes_winner == len(sc.receivers)
+    cut = sim.decided_cut()
+    key0 = [oview.ringKey(0, i) for i in range(n)]
+    assert cut == sorted(sc.faulty.tolist(), key=lambda x: key0[x])
+    new_cfg = sim.apply_cut(cut)
+    # the oracle learns the joiners' NodeIds from the UP alerts of one receiver's stream, then decides
+    svc = O.AlertBatchService(oview, K, H, L, pop.id_hi, pop.id_lo)
+    r0 = sc.records[sc.rec_off[0]:sc.rec_off[1]]
+    beg = 0
+    for e in np.flatnonzero(r0["flags"] & S.FLAG_LAST_IN_BATCH) + 1:
+        svc.handleBatchedAlertMessage(r0[beg:e])
+        beg = int(e)
+    svc.decideViewChange(cut)
+    assert new_cfg == oview.getCurrentConfigurationId()
+    assert view.getMembershipSize() == oview.getMembershipSize() == (n - n_out) - n_crash + n_join
+    for k in range(K):
+        assert np.array_equal(view.getRing(k), oview.getRing(k))
+    o2, s2, m2 = view.tables()
+    oo2, os2, om2 = oview.tables(n)
+    assert np.array_equal(m2, om2) and np.array_equal(s2, os2) and np.array_equal(o2, oo2)
+    for j in sc.joiners[:5]:
+        assert view.isHostPresent(int(j)) and view.getObserversOf(int(j)) == oview.getObserversOf(int(j))
+
+
 def test_no_quorum_when_receivers_disagree(E):
     n, K, H, L = 40, 10, 8, 2
     pop = S.Population.make(n)

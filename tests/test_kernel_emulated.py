@@ -96,6 +96,18 @@ def test_scenarios(name, n, f, K, H, L):
         assert stats[1] > 0  # the fast path was exercised
 
 
+@pytest.mark.parametrize("n,n_out,n_crash,n_join,K,H,L", [(300, 30, 10, 12, 10, 9, 4), (150, 25, 4, 20, 10, 8, 3)])
+def test_churn_scenario(n, n_out, n_crash, n_join, K, H, L):
+    """Joins (UP alerts about non-members, expected observers) and crashes in one configuration, SURVEY 8f rank 1."""
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K, list(range(0, n - n_out)))
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_churn_scenario(obs, member, cfg, n_crash, n_join, H, L)
+    sc = S.build_churn_scenario(obs, member, cfg, n_crash, n_join, H, L, receivers=sc.receivers[::11])
+    _check(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member)
+
+
 def test_unaligned_starts_and_empty_receivers():
     n, K, H, L = 24, 5, 4, 2
     pop = S.Population.make(n)

@@ -89,3 +89,40 @@ def test_empty_and_ragged():
     off = np.cumsum([0] + [len(x) for x in parts])
     e, npr, o, p = _compare(view, pop, K, H, L, np.concatenate(parts), off, n)
     assert e[0] == -1 and e[2] == -1 and npr[0] == 0
+
+
+@pytest.mark.parametrize("n,n_out,n_crash,n_join,K,H,L", [(300, 30, 10, 12, 10, 9, 4), (120, 20, 3, 8, 10, 8, 2),
+                                                           (200, 10, 0, 10, 7, 6, 3)])
+def test_churn_crashes_and_joins_in_one_configuration(n, n_out, n_crash, n_join, K, H, L):
+    """UP alerts from the expected observers of joiners (non-members, Q3) mixed with DOWN alerts about
+    crashed members; a joiner or a crashed node whose observer crashed too completes through the implicit invalidation.
+    Every surviving member must announce exactly crashed + joiners, and decideViewChange must add / remove them
+    (R/MembershipService.java:385-430)."""
+    pop = S.Population.make(n)
+    members = list(range(0, n - n_out))
+    reg, view = oracle_view(pop, K, members)
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_churn_scenario(obs, member, cfg, n_crash, n_join, H, L)
+    rx = sc.receivers[:: max(1, len(sc.receivers) // 25)]
+    sc = S.build_churn_scenario(obs, member, cfg, n_crash, n_join, H, L, receivers=rx)
+    assert set(np.unique(sc.batches.recs["status"]).tolist()) <= {S.UP, S.DOWN}
+    fe, fn, fo, fp = _compare(view, pop, K, H, L, sc.records, sc.rec_off, n, orders=(0, 1))
+    assert np.all(fe >= 0)
+    for r in range(len(fe)):
+        assert sorted(fp[fo[r]:fo[r + 1]].tolist()) == sc.faulty.tolist()
+    # the decided cut applied the way the Java does: members leave, joiners enter with their NodeId
+    svc = O.AlertBatchService(view, K, H, L, pop.id_hi, pop.id_lo)
+    r0 = sc.records[sc.rec_off[0]:sc.rec_off[1]]  # one receiver's stream, batch by batch: records the joiners' NodeIds
+    ends = np.flatnonzero(r0["flags"] & S.FLAG_LAST_IN_BATCH) + 1
+    announced, beg = [], 0
+    for e in ends:
+        announced += svc.handleBatchedAlertMessage(r0[beg:e])
+        beg = int(e)
+    assert sorted(announced) == sc.faulty.tolist() and svc.announcedProposal()
+    svc.decideViewChange(announced)
+    assert view.getMembershipSize() == (n - n_out) - n_crash + n_join
+    for j in sc.joiners:
+        assert view.isHostPresent(int(j))
+    for c in sc.crashed:
+        assert not view.isHostPresent(int(c))
