@@ -186,6 +186,36 @@ int rapid_fast_round_vote(rapid_fast_round* f, int32_t sender, int64_t config_id
                           int32_t n, int32_t* decided_out);
 int rapid_fast_round_decision(rapid_fast_round* f, int32_t* out, int32_t cap, int32_t* n_out);
 
+/* ---- wire ingest (host only, no device needed): serialized protobuf messages of rapid.proto -> packed records, so
+ * that a live MembershipService can pass on the bytes it received (R/MembershipService.java:174-196) from a direct
+ * buffer.  Endpoints inside the messages are resolved through an endpoint map built from the same registry that
+ * rapid_view_build receives (hostname bytes + port -> node index). ---- */
+typedef struct rapid_endpoint_map rapid_endpoint_map;
+int rapid_endpoint_map_create(const uint8_t* hostnames, const int32_t* host_off, const int32_t* ports, int32_t n,
+                              rapid_endpoint_map** out);
+void rapid_endpoint_map_destroy(rapid_endpoint_map* m);
+/* node index of (hostname, port); RAPID_ENODE_MISSING if it is not registered */
+int rapid_endpoint_map_lookup(const rapid_endpoint_map* m, const uint8_t* hostname, int32_t hostname_len, int32_t port,
+                              int32_t* node_out);
+#define RAPID_MSG_OTHER 0
+#define RAPID_MSG_BATCHED_ALERT 3 /* RapidRequest.batchedAlertMessage     (rapid.proto:26) */
+#define RAPID_MSG_FAST_ROUND_2B 5 /* RapidRequest.fastRoundPhase2bMessage (rapid.proto:28) */
+/* which `content` case a serialized RapidRequest carries (its field number; RAPID_MSG_OTHER for an empty request) and
+ * where its payload lies inside msg */
+int rapid_decode_request(const uint8_t* msg, int64_t len, int32_t* kind_out, int64_t* payload_off, int64_t* payload_len);
+/* one remoting.BatchedAlertMessage (rapid.proto:95-99) -> one packed record per AlertMessage (:101-110), in message
+ * order, the last one flagged RAPID_ALERT_LAST_IN_BATCH.  id_hi / id_lo (optional, parallel to out) receive the NodeId
+ * of every alert (the joiner's id in UP alerts, extractJoinerUuidAndMetadata R/MembershipService.java:677-685; zeros
+ * when absent).  RAPID_EINVAL: malformed bytes, ring number >= K; RAPID_ENODE_MISSING: an endpoint that is not in
+ * the map; RAPID_ECAPACITY: more than cap alerts (n_out = the number needed). */
+int rapid_decode_batched_alerts(const rapid_endpoint_map* m, const uint8_t* msg, int64_t len, int32_t K,
+                                rapid_alert_record* out, int64_t* id_hi, int64_t* id_lo, int32_t cap, int32_t* n_out,
+                                int32_t* sender_out);
+/* one remoting.FastRoundPhase2bMessage (rapid.proto:124-129) -> sender, configuration id, the proposed endpoints in
+ * message order (the vote that rapid_fast_round_vote takes) */
+int rapid_decode_fast_round_vote(const rapid_endpoint_map* m, const uint8_t* msg, int64_t len, int32_t* sender_out,
+                                 int64_t* config_id_out, int32_t* endpoints_out, int32_t cap, int32_t* n_out);
+
 /* ---- multi-GPU: one engine per rank, receivers sharded, vote histogram all-reduced over RCCL/xGMI ------- */
 #define RAPID_UNIQUE_ID_BYTES 128
 int rapid_comm_unique_id(uint8_t out[RAPID_UNIQUE_ID_BYTES]); /* rank 0 creates, host layer broadcasts */

@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAPID_MI355X_LIB") or os.path.join(_HERE, "librapid_mi355x.so")  # override: profiling builds
 SRC_DIR = os.path.join(_HERE, "csrc")
-SOURCES = ["engine.hip", "tally_kernel.h", "index_kernels.h", "view_kernels.h", "vote_kernels.h"]
+SOURCES = ["engine.hip", "tally_kernel.h", "lds_dma.h", "index_kernels.h", "view_kernels.h", "vote_kernels.h", "wire.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rapid_mi355x.h")
 
 OK, EINVAL, ENODE_EXISTS, ENODE_MISSING, EUUID_SEEN, ECAPACITY, EDEVICE, ESTATE, ECOLLISION = 0, -1, -2, -3, -4, -5, -6, -7, -8
@@ -132,6 +132,12 @@ def _signatures():
         "rapid_fast_round_vote": (i32, [vp, i32, i64, p, i32, pi32]),
         "rapid_fast_round_decision": (i32, [vp, p, i32, pi32]),
         "rapid_comm_unique_id": (i32, [p]),
+        "rapid_endpoint_map_create": (i32, [p, p, p, i32, C.POINTER(vp)]),
+        "rapid_endpoint_map_destroy": (None, [vp]),
+        "rapid_endpoint_map_lookup": (i32, [vp, p, i32, i32, pi32]),
+        "rapid_decode_request": (i32, [p, i64, pi32, pi64, pi64]),
+        "rapid_decode_batched_alerts": (i32, [vp, p, i64, i32, p, p, p, i32, pi32, pi32]),
+        "rapid_decode_fast_round_vote": (i32, [vp, p, i64, pi32, pi64, p, i32, pi32]),
         "rapid_engine_comm_init": (i32, [vp, p, i32, i32]),
         "rapid_engine_stream": (vp, [vp]),
         "rapid_engine_sync": (i32, [vp]),

@@ -26,6 +26,7 @@
 #include "tally_kernel.h"
 #include "view_kernels.h"
 #include "vote_kernels.h"
+#include "wire.h"
 
 namespace {
 
@@ -1288,6 +1289,127 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on) {
     if (!h) return RAPID_EINVAL;
     h->force_exact = on;  // bit0: exact path only; bits 1-2: profiling ablations (results invalid)
+    return RAPID_OK;
+}
+
+
+// -------------------------------------------------------------------------------------- wire ingest (host only)
+int rapid_endpoint_map_create(const uint8_t* hostnames, const int32_t* host_off, const int32_t* ports, int32_t n,
+                              rapid_endpoint_map** out) {
+    if (!out || n < 0 || (n > 0 && (!hostnames || !host_off || !ports))) return RAPID_EINVAL;
+    rapid_endpoint_map* m = new rapid_endpoint_map();
+    m->index.reserve((size_t)n * 2);
+    for (int32_t i = 0; i < n; ++i) {
+        if (host_off[i + 1] < host_off[i]) {
+            delete m;
+            return RAPID_EINVAL;
+        }
+        // the first registration of an endpoint wins, as in the Java-side Endpoint -> int map of the facade
+        m->index.emplace(rapid_endpoint_map::key(hostnames + host_off[i], (size_t)(host_off[i + 1] - host_off[i]), ports[i]), i);
+    }
+    *out = m;
+    return RAPID_OK;
+}
+
+void rapid_endpoint_map_destroy(rapid_endpoint_map* m) { delete m; }
+
+int rapid_endpoint_map_lookup(const rapid_endpoint_map* m, const uint8_t* hostname, int32_t hostname_len, int32_t port,
+                              int32_t* node_out) {
+    if (!m || !node_out || hostname_len < 0 || (hostname_len > 0 && !hostname)) return RAPID_EINVAL;
+    static const uint8_t empty = 0;
+    const auto it = m->index.find(rapid_endpoint_map::key(hostname ? hostname : &empty, (size_t)hostname_len, port));
+    if (it == m->index.end()) return RAPID_ENODE_MISSING;
+    *node_out = it->second;
+    return RAPID_OK;
+}
+
+int rapid_decode_request(const uint8_t* msg, int64_t len, int32_t* kind_out, int64_t* payload_off, int64_t* payload_len) {
+    if ((!msg && len > 0) || len < 0 || !kind_out) return RAPID_EINVAL;
+    rapid_wire::Reader r(msg, len);
+    int32_t kind = RAPID_MSG_OTHER;
+    int64_t off = 0, plen = 0;
+    while (!r.done()) {  // a oneof: the LAST member on the wire wins, as in every protobuf parser
+        int wt;
+        const uint32_t f = r.tag(&wt);
+        if (f >= 1 && f <= 10 && wt == 2) {
+            rapid_wire::Reader p = r.sub();
+            kind = (int32_t)f;
+            off = (int64_t)(p.p - msg);
+            plen = (int64_t)(p.end - p.p);
+        } else {
+            r.skip(wt);
+        }
+    }
+    if (!r.ok) return RAPID_EINVAL;
+    *kind_out = kind;
+    if (payload_off) *payload_off = off;
+    if (payload_len) *payload_len = plen;
+    return RAPID_OK;
+}
+
+int rapid_decode_batched_alerts(const rapid_endpoint_map* m, const uint8_t* msg, int64_t len, int32_t K,
+                                rapid_alert_record* out, int64_t* id_hi, int64_t* id_lo, int32_t cap, int32_t* n_out,
+                                int32_t* sender_out) {
+    if (!m || (!msg && len > 0) || len < 0 || cap < 0 || (cap > 0 && !out) || !n_out || K < 1 || K > RAPID_MAX_K)
+        return RAPID_EINVAL;
+    rapid_wire::Reader r(msg, len);
+    int32_t n = 0, sender = -1;
+    int rc_first = RAPID_OK;
+    bool ok = true;
+    while (!r.done()) {
+        int wt;
+        const uint32_t f = r.tag(&wt);
+        if (f == 1 && wt == 2) {
+            sender = rapid_wire::read_endpoint(r.sub(), *m, &ok);
+        } else if (f == 3 && wt == 2) {
+            rapid_wire::Reader a = r.sub();
+            if (n < cap) {
+                const int rc = rapid_wire::read_alert(a, *m, K, out + n, id_hi ? id_hi + n : nullptr, id_lo ? id_lo + n : nullptr);
+                if (rc != RAPID_OK && rc_first == RAPID_OK) rc_first = rc;
+            }
+            ++n;
+        } else {
+            r.skip(wt);
+        }
+    }
+    if (!r.ok || !ok) return RAPID_EINVAL;
+    *n_out = n;
+    if (sender_out) *sender_out = sender;
+    if (n > cap) return RAPID_ECAPACITY;
+    if (rc_first != RAPID_OK) return rc_first;
+    if (n > 0) out[n - 1].flags |= RAPID_ALERT_LAST_IN_BATCH;
+    return RAPID_OK;
+}
+
+int rapid_decode_fast_round_vote(const rapid_endpoint_map* m, const uint8_t* msg, int64_t len, int32_t* sender_out,
+                                 int64_t* config_id_out, int32_t* endpoints_out, int32_t cap, int32_t* n_out) {
+    if (!m || (!msg && len > 0) || len < 0 || cap < 0 || (cap > 0 && !endpoints_out) || !n_out) return RAPID_EINVAL;
+    rapid_wire::Reader r(msg, len);
+    int32_t n = 0, sender = -1;
+    int64_t cfg = 0;
+    bool ok = true, missing = false;
+    while (!r.done()) {
+        int wt;
+        const uint32_t f = r.tag(&wt);
+        if (f == 1 && wt == 2) {
+            sender = rapid_wire::read_endpoint(r.sub(), *m, &ok);
+        } else if (f == 2 && wt == 0) {
+            cfg = (int64_t)r.varint();
+        } else if (f == 3 && wt == 2) {
+            const int32_t e = rapid_wire::read_endpoint(r.sub(), *m, &ok);
+            if (e < 0) missing = true;
+            if (n < cap) endpoints_out[n] = e;
+            ++n;
+        } else {
+            r.skip(wt);
+        }
+    }
+    if (!r.ok || !ok) return RAPID_EINVAL;
+    *n_out = n;
+    if (sender_out) *sender_out = sender;
+    if (config_id_out) *config_id_out = cfg;
+    if (n > cap) return RAPID_ECAPACITY;
+    if (missing || sender < 0) return RAPID_ENODE_MISSING;
     return RAPID_OK;
 }
 
