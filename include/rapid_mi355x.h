@@ -216,6 +216,84 @@ int rapid_decode_batched_alerts(const rapid_endpoint_map* m, const uint8_t* msg,
 int rapid_decode_fast_round_vote(const rapid_endpoint_map* m, const uint8_t* msg, int64_t len, int32_t* sender_out,
                                  int64_t* config_id_out, int32_t* endpoints_out, int32_t cap, int32_t* n_out);
 
+/* ---- consensus at one node: fast round + classic-Paxos recovery (R/FastPaxos.java, R/Paxos.java) ------------
+ * Host-side state machine, no device needed.  It replaces the FastPaxos object a MembershipService
+ * creates per configuration (R/MembershipService.java:156-158, :427-429).  The object does no I/O: handlers append what
+ * the Java would have broadcast / sent to an outbox, in the same order; the caller drains it with rapid_consensus_poll
+ * and owns the network and the recovery timer (R/FastPaxos.java:107-109).
+ *
+ * A message is a fixed head plus its endpoint list (the value); `kind` is the RapidRequest.content field number
+ * (rapid.proto:28-32).  rank_index stands in for `myAddr.hashCode()` (R/Paxos.java:102), which is not reproducible
+ * across JVMs; any value that is distinct per node keeps the protocol's ordering of concurrent coordinators. */
+typedef struct rapid_consensus rapid_consensus;
+typedef struct rapid_rank { /* remoting.Rank, rapid.proto:133-137; ordered by round, then node_index (R/Paxos.java:333-339) */
+    int32_t round;
+    int32_t node_index;
+} rapid_rank;
+#define RAPID_MSG_PHASE1A 6 /* RapidRequest.phase1aMessage (rapid.proto:29) */
+#define RAPID_MSG_PHASE1B 7 /* RapidRequest.phase1bMessage (rapid.proto:30) */
+#define RAPID_MSG_PHASE2A 8 /* RapidRequest.phase2aMessage (rapid.proto:31) */
+#define RAPID_MSG_PHASE2B 9 /* RapidRequest.phase2bMessage (rapid.proto:32) */
+#define RAPID_DEST_BROADCAST (-1)
+typedef struct rapid_consensus_msg {
+    int32_t kind;        /* RAPID_MSG_FAST_ROUND_2B, RAPID_MSG_PHASE1A .. RAPID_MSG_PHASE2B */
+    int32_t sender;      /* node index */
+    int64_t config_id;
+    rapid_rank rnd;      /* Phase1a.rank; Phase1b / Phase2a / Phase2b.rnd; zero for a fast-round vote */
+    rapid_rank vrnd;     /* Phase1b.vrnd; zero otherwise */
+    int32_t n_endpoints; /* length of the accompanying list: FastRoundPhase2b / Phase2b.endpoints, Phase1b / Phase2a.vval */
+    int32_t dest;        /* outgoing: the node a Phase1b is sent to, RAPID_DEST_BROADCAST otherwise; ignored on input */
+} rapid_consensus_msg;
+/* membership_size = N of the configuration (R/FastPaxos.java:62-87); RAPID_EINVAL if it is < 1 */
+int rapid_consensus_create(int32_t my_index, int32_t rank_index, int64_t config_id, int32_t membership_size,
+                           rapid_consensus** out);
+void rapid_consensus_destroy(rapid_consensus* c);
+/* FastPaxos.propose (:95-110): registers the node's own fast-round vote with its acceptor (R/Paxos.java:246-259) and
+ * queues the FastRoundPhase2bMessage broadcast.  Scheduling startClassicPaxosRound after the recovery delay is the caller's. */
+int rapid_consensus_propose(rapid_consensus* c, const int32_t* proposal, int32_t n);
+/* FastPaxos.handleMessages (:163-185) for one received message; a message of another configuration is ignored
+ * (RAPID_OK), a kind outside 5..9 is RAPID_EINVAL (IllegalArgumentException, :181) */
+int rapid_consensus_handle(rapid_consensus* c, const rapid_consensus_msg* msg, const int32_t* endpoints);
+int rapid_consensus_start_classic_round(rapid_consensus* c);    /* FastPaxos.startClassicPaxosRound, :190-196 */
+int rapid_consensus_start_phase1a(rapid_consensus* c, int32_t round); /* Paxos.startPhase1a, R/Paxos.java:98-111 */
+/* next queued outgoing message, oldest first: *got = 0 if there is none.  RAPID_ECAPACITY (message kept, n_endpoints
+ * set) if its endpoint list is longer than cap. */
+int rapid_consensus_poll(rapid_consensus* c, rapid_consensus_msg* msg_out, int32_t* endpoints_out, int32_t cap,
+                         int32_t* got);
+/* the decided value (what onDecide receives, R/FastPaxos.java:78-85), in the order it was proposed; RAPID_ESTATE until
+ * there is one.  The first decision stands (the Java asserts that there is only one). */
+int rapid_consensus_decision(rapid_consensus* c, int32_t* out, int32_t cap, int32_t* n_out);
+/* FastPaxos.getRandomDelayMs (:201-204): base + (long)(-1000 ln(1 - u) * N) for u = nextDouble() in [0, 1) */
+int rapid_consensus_fallback_delay_ms(int32_t membership_size, int64_t base_delay_ms, double u, int64_t* delay_out);
+/* Paxos.selectProposalUsingCoordinatorRule (R/Paxos.java:271-328) as a function: n_msgs Phase1b messages in arrival
+ * order, message i carrying vrnd[i] and the value vvals[vval_off[i] .. vval_off[i+1]).  *chosen_out = index of a
+ * message whose value is the one to propose, or -1 if no message carries a value.  RAPID_EINVAL for n_msgs < 1 (:274). */
+int rapid_paxos_select_proposal(int32_t membership_size, const rapid_rank* vrnd, const int32_t* vval_off,
+                                const int32_t* vvals, int32_t n_msgs, int32_t* chosen_out);
+/* One classic round (round 2, one coordinator, no message loss) for a whole population whose fast round did not reach
+ * its quorum -- what rapid_sim_count_votes reports as decided = 0.  Acceptor i (one per live receiver) voted in the fast
+ * round iff voted[i] != 0, for the proposal identified by vote_key[i] (rapid_sim_results' fingerprint: equal keys <=>
+ * equal proposals, which rapid_sim_count_votes has verified); arrival[j] = the acceptor whose Phase1b reaches the
+ * coordinator j-th (NULL = index order).  Equivalent to running n_acceptors rapid_consensus objects message by message
+ * (tests/test_consensus.py does). */
+typedef struct rapid_classic_round_result {
+    int32_t decided;         /* 1 iff more than N/2 acceptors are live and one of them voted */
+    int32_t chosen_acceptor; /* an acceptor whose fast-round vote is the decided value; -1 if none */
+    int32_t promises_used;   /* Phase1b messages received when the coordinator chose */
+    int32_t rule;            /* clause that chose: 1 one distinct value, 2 a value seen more than N/4 times, 3 any value */
+    int64_t messages;        /* messages of the round: Phase1a + Phase1b + Phase2a + Phase2b */
+} rapid_classic_round_result;
+int rapid_classic_round_population(int32_t membership_size, int32_t n_acceptors, const uint64_t* vote_key,
+                                   const uint8_t* voted, const int32_t* arrival, rapid_classic_round_result* out);
+/* wire forms of the five consensus messages (rapid.proto:124-169).  decode: the payload of a RapidRequest whose kind
+ * rapid_decode_request reported; out->dest is set to RAPID_DEST_BROADCAST.  encode: a complete serialized RapidRequest,
+ * byte for byte what protobuf-java emits for the messages R/Paxos.java and R/FastPaxos.java build (fields in number
+ * order, zero scalars omitted, the Rank / Endpoint sub-messages always present). */
+int rapid_decode_consensus_message(const rapid_endpoint_map* m, int32_t kind, const uint8_t* msg, int64_t len,
+                                   rapid_consensus_msg* out, int32_t* endpoints_out, int32_t cap);
+int rapid_encode_consensus_request(const rapid_endpoint_map* m, const rapid_consensus_msg* msg, const int32_t* endpoints,
+                                   uint8_t* out, int64_t cap, int64_t* len_out);
+
 /* ---- multi-GPU: one engine per rank, receivers sharded, vote histogram all-reduced over RCCL/xGMI ------- */
 #define RAPID_UNIQUE_ID_BYTES 128
 int rapid_comm_unique_id(uint8_t out[RAPID_UNIQUE_ID_BYTES]); /* rank 0 creates, host layer broadcasts */

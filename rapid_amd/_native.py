@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAPID_MI355X_LIB") or os.path.join(_HERE, "librapid_mi355x.so")  # override: profiling builds
 SRC_DIR = os.path.join(_HERE, "csrc")
-SOURCES = ["engine.hip", "tally_kernel.h", "lds_dma.h", "index_kernels.h", "view_kernels.h", "vote_kernels.h", "wire.h"]
+SOURCES = ["engine.hip", "tally_kernel.h", "lds_dma.h", "index_kernels.h", "view_kernels.h", "vote_kernels.h", "wire.h", "consensus.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rapid_mi355x.h")
 
 OK, EINVAL, ENODE_EXISTS, ENODE_MISSING, EUUID_SEEN, ECAPACITY, EDEVICE, ESTATE, ECOLLISION = 0, -1, -2, -3, -4, -5, -6, -7, -8
@@ -82,6 +82,20 @@ class RoundResult(C.Structure):
                 ("reserved", C.c_int32), ("config_id", C.c_int64)]
 
 
+class Rank(C.Structure):  # rapid_rank
+    _fields_ = [("round", C.c_int32), ("node_index", C.c_int32)]
+
+
+class ConsensusMsg(C.Structure):  # rapid_consensus_msg
+    _fields_ = [("kind", C.c_int32), ("sender", C.c_int32), ("config_id", C.c_int64), ("rnd", Rank), ("vrnd", Rank),
+                ("n_endpoints", C.c_int32), ("dest", C.c_int32)]
+
+
+class ClassicRoundResult(C.Structure):  # rapid_classic_round_result
+    _fields_ = [("decided", C.c_int32), ("chosen_acceptor", C.c_int32), ("promises_used", C.c_int32), ("rule", C.c_int32),
+                ("messages", C.c_int64)]
+
+
 class EngineConfig(C.Structure):
     _fields_ = [("n_max", C.c_int32), ("K", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("device_id", C.c_int32),
                 ("max_cut", C.c_int32)]
@@ -138,6 +152,19 @@ def _signatures():
         "rapid_decode_request": (i32, [p, i64, pi32, pi64, pi64]),
         "rapid_decode_batched_alerts": (i32, [vp, p, i64, i32, p, p, p, i32, pi32, pi32]),
         "rapid_decode_fast_round_vote": (i32, [vp, p, i64, pi32, pi64, p, i32, pi32]),
+        "rapid_consensus_create": (i32, [i32, i32, i64, i32, C.POINTER(vp)]),
+        "rapid_consensus_destroy": (None, [vp]),
+        "rapid_consensus_propose": (i32, [vp, p, i32]),
+        "rapid_consensus_handle": (i32, [vp, C.POINTER(ConsensusMsg), p]),
+        "rapid_consensus_start_classic_round": (i32, [vp]),
+        "rapid_consensus_start_phase1a": (i32, [vp, i32]),
+        "rapid_consensus_poll": (i32, [vp, C.POINTER(ConsensusMsg), p, i32, pi32]),
+        "rapid_consensus_decision": (i32, [vp, p, i32, pi32]),
+        "rapid_consensus_fallback_delay_ms": (i32, [i32, i64, C.c_double, pi64]),
+        "rapid_paxos_select_proposal": (i32, [i32, p, p, p, i32, pi32]),
+        "rapid_classic_round_population": (i32, [i32, i32, p, p, p, C.POINTER(ClassicRoundResult)]),
+        "rapid_decode_consensus_message": (i32, [vp, i32, p, i64, C.POINTER(ConsensusMsg), p, i32]),
+        "rapid_encode_consensus_request": (i32, [vp, C.POINTER(ConsensusMsg), p, p, i64, pi64]),
         "rapid_engine_comm_init": (i32, [vp, p, i32, i32]),
         "rapid_engine_stream": (vp, [vp]),
         "rapid_engine_sync": (i32, [vp]),

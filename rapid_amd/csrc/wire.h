@@ -19,6 +19,8 @@
 
 struct rapid_endpoint_map {
     std::unordered_map<std::string, int32_t> index;  // hostname bytes + '\0' + 4 port bytes -> node index
+    std::vector<std::string> hostname;               // node index -> hostname bytes (for the encoders)
+    std::vector<int32_t> port;
     static std::string key(const uint8_t* host, size_t host_len, int32_t port) {
         std::string k(reinterpret_cast<const char*>(host), host_len);
         k.push_back('\0');
@@ -174,6 +176,63 @@ inline int read_alert(Reader r, const rapid_endpoint_map& m, int K, rapid_alert_
     if (id_hi) *id_hi = hi;
     if (id_lo) *id_lo = lo;
     return RAPID_OK;
+}
+
+// remoting.Rank { int32 round = 1; int32 nodeIndex = 2; } (rapid.proto:133-137)
+inline rapid_rank read_rank(Reader r, bool* ok) {
+    rapid_rank k{0, 0};
+    while (!r.done()) {
+        int wt;
+        const uint32_t f = r.tag(&wt);
+        if (f == 1 && wt == 0)
+            k.round = (int32_t)r.varint();
+        else if (f == 2 && wt == 0)
+            k.node_index = (int32_t)r.varint();
+        else
+            r.skip(wt);
+    }
+    if (!r.ok) *ok = false;
+    return k;
+}
+
+// Serializer for the handful of message shapes the consensus path sends.  Appends to a byte vector.
+struct Writer {
+    std::vector<uint8_t> b;
+    void varint(uint64_t v) {
+        while (v >= 0x80) {
+            b.push_back((uint8_t)(v | 0x80));
+            v >>= 7;
+        }
+        b.push_back((uint8_t)v);
+    }
+    void tag(uint32_t field, int wire_type) { varint(((uint64_t)field << 3) | (uint64_t)wire_type); }
+    void int_field(uint32_t field, int64_t v) {  // int32 / int64: zero is not written, negatives take ten bytes
+        if (v == 0) return;
+        tag(field, 0);
+        varint((uint64_t)v);
+    }
+    void bytes_field(uint32_t field, const uint8_t* p, size_t n, bool even_if_empty) {
+        if (n == 0 && !even_if_empty) return;
+        tag(field, 2);
+        varint(n);
+        b.insert(b.end(), p, p + n);
+    }
+    void message_field(uint32_t field, const Writer& sub) { bytes_field(field, sub.b.data(), sub.b.size(), true); }
+};
+
+inline Writer write_endpoint(const rapid_endpoint_map& m, int32_t node) {
+    Writer w;
+    const std::string& h = m.hostname[(size_t)node];
+    w.bytes_field(1, reinterpret_cast<const uint8_t*>(h.data()), h.size(), false);
+    w.int_field(2, m.port[(size_t)node]);
+    return w;
+}
+
+inline Writer write_rank(rapid_rank k) {
+    Writer w;
+    w.int_field(1, k.round);
+    w.int_field(2, k.node_index);
+    return w;
 }
 
 }  // namespace rapid_wire

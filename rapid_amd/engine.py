@@ -328,6 +328,22 @@ class ClusterSimulation:
         self.e._check(self.e._lib.rapid_sim_round(self.e._h, 1 if apply else 0, C.byref(rr), C.byref(cfg)))
         return rr, cfg.value
 
+    def classic_round(self, arrival=None, apply=True):
+        """The recovery the reference runs when the fast round finds no quorum (R/FastPaxos.java:107-109, 190-196 ->
+        R/Paxos.java): ONE classic round over the receivers of the last tally, each an acceptor holding its fast-round
+        vote; `arrival` = the order in which their Phase1b messages reach the coordinator (default: receiver order).
+        Single-engine populations only.  -> (result dict of consensus.classic_round_population, decided cut or None,
+        new configuration id or None)."""
+        from . import consensus as CS
+        n = C.c_int32(0)
+        self.e._check(self.e._lib.rapid_view_size(self.e._h, C.byref(n)))
+        emit, _, _, fp = self.results()
+        res, winner = CS.classic_round_from_results(n.value, emit, fp, arrival)
+        if winner is None:
+            return res, None, None
+        cut = self.proposal(winner)
+        return res, cut, (self.apply_cut(cut) if apply else None)
+
     def apply_cut(self, cut):
         cut = np.ascontiguousarray(cut, dtype=np.int32)
         cfg = C.c_int64(0)

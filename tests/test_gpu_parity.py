@@ -580,3 +580,45 @@ def test_full_size_c3_against_fast_oracle(E):
             sim.load_streams(recs2, off2)
             rr2, _ = sim.round(apply=False)
             assert rr2.votes_winner > 0 and sorted(sim.proposal(0)) in (sc.faulty.tolist(), sorted(sim.proposal(0)))
+
+
+def test_classic_round_recovers_a_population_without_fast_quorum(E):
+    """the receivers disagree (no fast quorum), one classic round decides a cut every acceptor voted
+    for under the coordinator rule (R/Paxos.java:271-328), and the view change is applied like the oracle's."""
+    from oracle import paxos_oracle as PX
+    n, K, H, L = 40, 10, 8, 2
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    reg, oview = oracle_view(pop, K)
+    cfg = view.getCurrentConfigurationId()
+    # receivers 0..11 hear about subject 3, 12..19 about subject 5, 20..29 about subject 7: 12 + 8 + 10 votes, quorum is 31
+    subject = [3] * 12 + [5] * 8 + [7] * 10
+    recs, off = [], [0]
+    for r in range(30):
+        a = np.zeros(1, dtype=S.ALERT_DTYPE)
+        a["dst"], a["ring_mask"], a["status"], a["cfg_id"], a["flags"] = subject[r], (1 << H) - 1, S.DOWN, cfg, 1
+        recs.append(a)
+        off.append(off[-1] + 1)
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(np.concatenate(recs), np.array(off))
+    rr, _ = sim.round(apply=True)
+    assert rr.decided == 0 and rr.votes_total == 30 and rr.votes_winner == 12
+    arrival = list(np.random.default_rng(4).permutation(30))
+    # the same round, message by message, on the restated Paxos.java: 30 live acceptors of 40 members
+    net = PX.Network(n, configurationId=cfg, live=list(range(30)), seed=1)
+    for r in range(30):
+        net.nodes[r].propose((subject[r],))
+    net.run()
+    assert not net.decisions
+    net.nodes[0].startClassicPaxosRound()
+    for a in arrival:
+        assert net.deliver_one(int(a)).kind == PX.PHASE1A
+    net.run()
+    want = {v for _, v in net.decisions}
+    assert len(net.decisions) == 30 and len(want) == 1
+    res, cut, new_cfg = sim.classic_round(arrival=arrival, apply=True)
+    assert res["decided"] and tuple(cut) == want.pop()
+    svc = O.AlertBatchService(oview, K, H, L, pop.id_hi, pop.id_lo)
+    svc.decideViewChange(cut)
+    assert new_cfg == oview.getCurrentConfigurationId() == view.getCurrentConfigurationId()
+    assert view.getMembershipSize() == n - 1 and not view.isHostPresent(cut[0])
