@@ -49,6 +49,13 @@ constexpr int kSlotBytes = 1024;                     // one LDS-DMA wave instruc
 constexpr int kQuarters = RAPID_QUARTERS;            // records per lane in a lean window
 constexpr int kLeanWindow = kQuarters * kWave;       // 192 records = 3840 B (2 and 4 per lane measured slower: profiles/)
 constexpr int kWindowSlots = (kLeanWindow * kRecBytes + kSlotBytes - 1) / kSlotBytes + 1;  // slots a window can touch at any alignment
+// RAPID_LEAN_V2 (default 0 = the kernel that was measured in round 1): the same lean window with fewer instructions --
+// specialised on "a DOWN report has been seen" (no per-part test of it), lane masks built from the compares themselves
+// instead of a ballot of their conjunction, the per-lane predicate (not a bit test of the ballot) guarding the atomics.
+// Emulator-verified; to be timed against the default before it replaces it (scripts/build_variant.sh).
+#ifndef RAPID_LEAN_V2
+#define RAPID_LEAN_V2 0
+#endif
 #ifndef RAPID_RING_SLOTS
 #define RAPID_RING_SLOTS 10
 #endif
@@ -120,6 +127,10 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ unsigned long long lanes_lt(int lane) { return (1ull << lane) - 1ull; }
+// number of set bits of m below this lane's own bit (v_mbcnt_lo / v_mbcnt_hi)
+__device__ __forceinline__ int rank_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
 // lane mask of a per-lane predicate, straight from the compare (no bool -> int -> compare round trip)
 __device__ __forceinline__ unsigned long long wave_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 // Values that are the same in every lane are kept provably uniform (SGPRs, scalar branches): everything derived
@@ -638,8 +649,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // dependency chains for the wave to interleave.  Returns 0 -- window rolled back,
         // nothing consumed -- when no certificate holds.  kTail: fewer than kLeanWindow records are left (the last record
         // closes the last batch).
-        auto lean_window = [&](auto tail_tag) -> int {
+        auto lean_window = [&](auto tail_tag, auto seen_tag) -> int {
             constexpr bool kTail = decltype(tail_tag)::value;
+            constexpr bool kSeen = decltype(seen_tag)::value;  // the caller knows that s.seen_down is set already
             const int navail = kTail ? nrec - pos : kLeanWindow;
             unsigned int w3[kQuarters], w4[kQuarters], rb[kQuarters], de[kQuarters], slot[kQuarters], old[kQuarters];
             unsigned long long mE[kQuarters], mApp[kQuarters], mL[kQuarters], mJ[kQuarters];
@@ -671,8 +683,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     consumed += nc[q];
                 }
             }
-            const bool seen_before = s.seen_down;
+            const bool seen_before = kSeen || s.seen_down;
             unsigned long long mDown = 0ull;
+#if RAPID_LEAN_V2
+            bool appl[kQuarters];
+#endif
 #pragma unroll
             for (int q = 0; q < kQuarters; ++q) {
                 rb[q] = w4[q] & d.kmask;
@@ -681,7 +696,12 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     // every consumed record is a validated alert: the dictionary lookup needs no range check
                     de[q] = (unsigned int)dict[(!kTail || lane < nc[q]) ? w3[q] : 0u];
                     app = (lane < nc[q]) & ((de[q] & kSlotMask) != kNoSlot);
+#if RAPID_LEAN_V2
+                    mApp[q] = wave_ballot(lane < nc[q]) & wave_ballot((de[q] & kSlotMask) != kNoSlot);
+                    if (!seen_before) mDown |= wave_ballot(lane < nc[q]) & wave_ballot((w4[q] & 0x00FF0000u) != 0u);
+#else
                     if (!seen_before) mDown |= wave_ballot((lane < nc[q]) & ((w4[q] & 0x00FF0000u) != 0u));
+#endif
                 } else {
                     // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot
                     unsigned int t = (unsigned int)(ring_pos + lane20 + q * kWave * kRecBytes);
@@ -693,16 +713,27 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                                              (w3[q] >= (unsigned)p.n_nodes ? 1u : 0u) | (rb[q] == 0u ? 1u : 0u) |
                                              (lane >= nc[q] ? 1u : 0u);
                     app = (bad == 0u) & ((de[q] & kSlotMask) != kNoSlot);
+#if RAPID_LEAN_V2
+                    mApp[q] = wave_ballot(bad == 0u) & wave_ballot((de[q] & kSlotMask) != kNoSlot);
+#endif
                     if (!seen_before) mDown |= wave_ballot((bad | (dn ^ 1u)) == 0u);
                 }
                 slot[q] = de[q] & kSlotMask;
+#if RAPID_LEAN_V2
+                appl[q] = app;
+#else
                 mApp[q] = wave_ballot(app);  // all lane masks first: the atomics then go out back to back
+#endif
             }
             if (!seen_before) s.seen_down = mDown != 0ull;
 #pragma unroll
             for (int q = 0; q < kQuarters; ++q) {
                 old[q] = 0u;
+#if RAPID_LEAN_V2
+                if (appl[q]) old[q] = d.or_bits((int)slot[q], rb[q]);
+#else
                 if ((mApp[q] >> lane) & 1ull) old[q] = d.or_bits((int)slot[q], rb[q]);
+#endif
             }
             // The witness's reports AFTER the window: a wave's LDS operations are served in program order, so this read
             // sees every lane's atomic above without waiting for their results (the barrier is not an instruction; it
@@ -711,11 +742,17 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             const unsigned int wv = uniform(d.load(witness >= 0 ? witness : 0));
             unsigned long long anyX = 0ull, anyN = 0ull;
             int nX = 0;
+#if RAPID_LEAN_V2
+            bool isX[kQuarters];  // this lane's record is an entrant whose implicit reports are owed
+#endif
 #pragma unroll
             for (int q = 0; q < kQuarters; ++q) {
                 const unsigned int ok = old[q] & d.kmask;
                 const int c0 = __popc(ok), c1 = __popc(ok | rb[q]);
                 mL[q] = mApp[q] & wave_ballot(c0 < d.L) & wave_ballot(c1 >= d.L);
+#if RAPID_LEAN_V2
+                isX[q] = appl[q] & (c0 < d.L) & (c1 >= d.L) & ((de[q] & kDictHasAdj) != 0u);
+#endif
                 // entrants with hot adjacency (their implicit reports are owed) / without (witness material)
                 mJ[q] = wave_ballot((de[q] & kDictHasAdj) != 0u);
                 anyX |= mL[q] & mJ[q];
@@ -761,7 +798,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #pragma unroll
                 for (int q = 0; q < kQuarters; ++q) {
                     const unsigned long long mX = mL[q] & mJ[q];
+#if RAPID_LEAN_V2
+                    if (isX[q]) pend[base + rank_below(mX)] = (unsigned short)slot[q];
+#else
                     if ((mX >> lane) & 1ull) pend[base + __popcll(mX & lanes_lt(lane))] = (unsigned short)slot[q];
+#endif
                     base += __popcll(mX);
                 }
                 s.npend = base;
@@ -972,7 +1013,12 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             while (nrec - pos >= kLeanWindow) {
                 stream_ensure(pos + kLeanWindow);
                 RAPID_T0(tl0);
-                const int ok_ = lean_window(std::false_type{});
+#if RAPID_LEAN_V2
+                const int ok_ = s.seen_down ? lean_window(std::false_type{}, std::true_type{})
+                                            : lean_window(std::false_type{}, std::false_type{});
+#else
+                const int ok_ = lean_window(std::false_type{}, std::false_type{});
+#endif
                 RAPID_T1(t_lean, tl0);
                 if (!ok_) {
                     gave_up = 1;
@@ -986,7 +1032,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             }
             if (!gave_up && pos < nrec) {  // the tail: less than a window, the last record closes the last batch
                 stream_ensure(nrec);
-                if (!lean_window(std::true_type{})) gave_up = 1;
+                if (!lean_window(std::true_type{}, std::false_type{})) gave_up = 1;
             }
             n_fast += (unsigned long long)((pos - pos_in + kLeanWindow - 1) / kLeanWindow);
             n_records += (unsigned long long)(pos - pos_in);

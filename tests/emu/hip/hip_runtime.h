@@ -86,6 +86,14 @@ inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)emu::pa
 inline void __syncthreads() { (void)emu::park(emu::OP_BLOCK_SYNC, 0, 0); }
 // wave-local LDS ordering point of the kernels (compiler-only on the device): a rendezvous here, so that the
 // emulator keeps shuffling the lane order around every point where lanes exchange data through LDS
+inline unsigned int __builtin_amdgcn_mbcnt_lo(unsigned int m, unsigned int add) {
+    const unsigned int l = threadIdx.x & 63u;
+    return add + (unsigned int)__builtin_popcount(m & (l >= 32u ? 0xFFFFFFFFu : (1u << l) - 1u));
+}
+inline unsigned int __builtin_amdgcn_mbcnt_hi(unsigned int m, unsigned int add) {
+    const unsigned int l = threadIdx.x & 63u;
+    return add + (l > 32u ? (unsigned int)__builtin_popcount(m & ((1u << (l - 32u)) - 1u)) : 0u);
+}
 inline void __builtin_amdgcn_wave_barrier() { (void)emu::park(emu::OP_WAVE_SYNC, 0, 0); }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __HIP_MEMORY_SCOPE_AGENT 4

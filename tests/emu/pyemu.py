@@ -13,8 +13,9 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        subprocess.check_call(["make", "-C", _HERE, "-s"], stderr=subprocess.DEVNULL)
-        _LIB = C.CDLL(os.path.join(_HERE, "_build", "libtally_emu.so"))
+        variant = os.environ.get("RAPID_EMU_VARIANT", "")  # "v2": the kernel built with -DRAPID_LEAN_V2=1
+        subprocess.check_call(["make", "-C", _HERE, "-s", "VARIANT=" + variant], stderr=subprocess.DEVNULL)
+        _LIB = C.CDLL(os.path.join(_HERE, "_build", "libtally_emu%s.so" % ("_" + variant if variant else "")))
     return _LIB
 
 
