@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAPID_MI355X_LIB") or os.path.join(_HERE, "librapid_mi355x.so")  # override: profiling builds
 SRC_DIR = os.path.join(_HERE, "csrc")
-SOURCES = ["engine.hip", "tally_kernel.h", "lds_dma.h", "index_kernels.h", "view_kernels.h", "vote_kernels.h", "wire.h", "consensus.h"]
+SOURCES = ["engine.hip", "host_abi.cpp", "tally_kernel.h", "lds_dma.h", "index_kernels.h", "view_kernels.h", "vote_kernels.h", "wire.h", "consensus.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rapid_mi355x.h")
 
 OK, EINVAL, ENODE_EXISTS, ENODE_MISSING, EUUID_SEEN, ECAPACITY, EDEVICE, ESTATE, ECOLLISION = 0, -1, -2, -3, -4, -5, -6, -7, -8
@@ -65,7 +65,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + SRC_DIR,
-           os.path.join(SRC_DIR, "engine.hip"), "-o", LIB_PATH + ".tmp", "-lrccl"]
+           os.path.join(SRC_DIR, "engine.hip"), os.path.join(SRC_DIR, "host_abi.cpp"), "-o", LIB_PATH + ".tmp", "-lrccl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

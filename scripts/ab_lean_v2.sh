@@ -6,7 +6,7 @@ set -u
 cd "$(dirname "$0")/.."
 V2="$PWD/rapid_amd/librapid_mi355x_v2.so"
 if [ "${1:-}" = "build" ] || [ ! -f "$V2" ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DRAPID_LEAN_V2=1 -Irapid_amd/csrc rapid_amd/csrc/engine.hip \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DRAPID_LEAN_V2=1 -Irapid_amd/csrc rapid_amd/csrc/engine.hip rapid_amd/csrc/host_abi.cpp \
         -o "$V2" -lrccl || exit 1
     [ "${1:-}" = "build" ] && exit 0
 fi
