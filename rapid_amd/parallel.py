@@ -64,3 +64,31 @@ def all_reduce_histogram(hist, dist=None):
     t = torch.from_numpy(hist.astype(np.int64))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.numpy().astype(np.uint64)
+
+
+def classic_round_sharded(membership_size, emit_batch, fingerprint, local_proposal, dist=None, arrival=None):
+    """The classic-Paxos recovery round (consensus.classic_round_population) when the receivers are sharded: every rank
+    contributes its receivers' votes (emit_batch >= 0 <=> voted, fingerprint = the vote's identity), all ranks run the
+    same O(N) rule on the gathered arrays -- global receiver order is rank order, shards being contiguous -- and the
+    rank that owns the chosen receiver hands its proposal (local_proposal(local index) -> list of node indices) to the
+    others.  `arrival` indexes the GLOBAL receiver order.  -> (result dict, decided cut or None); identical on all
+    ranks.  Two small collectives (gather of 12 bytes per receiver, broadcast of one proposal), host side."""
+    from . import consensus as CS
+    emit = np.ascontiguousarray(emit_batch, dtype=np.int32)
+    fp = np.ascontiguousarray(fingerprint, dtype=np.uint64)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        res, winner = CS.classic_round_from_results(membership_size, emit, fp, arrival)
+        return res, (list(local_proposal(winner)) if winner is not None else None)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    parts = [None] * world
+    dist.all_gather_object(parts, (emit, fp))
+    sizes = [len(p[0]) for p in parts]
+    res, winner = CS.classic_round_from_results(membership_size, np.concatenate([p[0] for p in parts]),
+                                                np.concatenate([p[1] for p in parts]), arrival)
+    if winner is None:
+        return res, None
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    owner = int(np.searchsorted(starts, winner, side="right") - 1)
+    box = [list(local_proposal(winner - int(starts[owner]))) if rank == owner else None]
+    dist.broadcast_object_list(box, src=owner)
+    return res, box[0]

@@ -90,3 +90,57 @@ def test_two_rank_gloo_decision_equals_single_rank():
     assert two[0]["hi"] == two[1]["lo"] and two[0]["lo"] == 0
     for t in two:
         assert (t["bucket"], t["votes"], t["total"], t["decided"]) == (one["bucket"], one["votes"], one["total"], one["decided"])
+
+
+RECOVERY_WORKER = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    sys.path.insert(0, %(root)r)
+    import torch.distributed as dist
+    from oracle import pyoracle as O
+    from rapid_amd import parallel as P, scenarios as S
+    from tests.helpers import oracle_view
+    dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=int(sys.argv[2]))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n, K, H, L = 400, 10, 9, 4
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K)
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    # one-way failures without closing the fault set: healthy subjects stuck between L and H make the proposals differ
+    sc = S.build_scenario("C3a", subj, cfg, n=n, f=20, H=H, L=L, kind="ingress", materialise=False)
+    lo, hi = P.shard_range(len(sc.receivers), rank, world)
+    records, rec_off, nb = S.deliver(sc.batches, sc.receivers[lo:hi], 2, loss=0.02)
+    e, npr, off, props = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, records, rec_off)
+    fps = np.array([hash(tuple(props[off[r]:off[r + 1]].tolist())) & ((1 << 64) - 1) if e[r] >= 0 else 0 for r in range(len(e))],
+                   dtype=np.uint64)
+    hist = P.all_reduce_histogram(P.local_histogram(fps, np.diff(off)), dist)
+    b, votes, total, ok = P.decide_from_histogram(hist, n)
+    arrival = np.random.default_rng(5).permutation(len(sc.receivers))
+    res, cut = P.classic_round_sharded(n, e, fps, lambda r: props[off[r]:off[r + 1]].tolist(), dist, arrival)
+    print(json.dumps({"rank": rank, "fast": bool(ok), "votes": votes, "total": total, "res": res, "cut": cut}))
+    dist.destroy_process_group()
+""")
+
+
+def run_recovery(world):
+    import json
+    code = RECOVERY_WORKER % {"root": ROOT, "port": free_port()}
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, cwd=ROOT) for r in range(world)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    return outs
+
+
+def test_two_rank_gloo_classic_round_equals_single_rank():
+    """No fast quorum -> the recovery round over the sharded receivers decides the cut the single-process run decides."""
+    one = run_recovery(1)[0]
+    two = run_recovery(2)
+    assert not one["fast"] and one["votes"] < P.fast_quorum(400) and one["total"] > 200  # a majority voted, no fast quorum
+    assert one["res"]["decided"] and one["cut"]
+    for t in two:
+        assert (t["fast"], t["votes"], t["total"], t["res"], t["cut"]) == (one["fast"], one["votes"], one["total"], one["res"], one["cut"])
