@@ -8,7 +8,11 @@ counters that turn "node s crashed at time t" into BatchedAlertMessages on the w
                               :572-581 (enqueueAlertMessage), :472-495 (edgeFailureNotification),
                               :613-637 (AlertBatcher.run), :697-706 (one detector per entry of getSubjectsOf)
 
-restated class by class, field by field, with a heap of timed events in place of the ScheduledExecutorService and
+PARITY UNPINNED: the reference holds no known-answer test for these timers (its detectors are only exercised end to
+end, through ClusterTest with real sleeps) and cannot be run here, so this restatement rests on the cited statements
+and constants alone.
+
+Restated class by class, field by field, with a heap of timed events in place of the ScheduledExecutorService and
 System.currentTimeMillis().  Time is integer milliseconds.  What the Java leaves to chance is fixed here, and in the
 product, as follows: events with the same timestamp run in the order  probe callbacks < detector ticks (ring order
 within a node) < batcher ticks;  a probe to a subject that has crashed by the time it is sent fails `probe_fail_ms`
