@@ -46,6 +46,7 @@ constexpr int kSlotBytes = 1024;                     // one LDS-DMA wave instruc
 #ifndef RAPID_QUARTERS
 #define RAPID_QUARTERS 3
 #endif
+constexpr int kEndGameRunning = 16;                   // RAPID_CAREFUL_HINT: updatesInProgress at which the lean path is left for good
 constexpr int kQuarters = RAPID_QUARTERS;            // records per lane in a lean window
 constexpr int kLeanWindow = kQuarters * kWave;       // 192 records = 3840 B (2 and 4 per lane measured slower: profiles/)
 constexpr int kWindowSlots = (kLeanWindow * kRecBytes + kSlotBytes - 1) / kSlotBytes + 1;  // slots a window can touch at any alignment
@@ -55,6 +56,20 @@ constexpr int kWindowSlots = (kLeanWindow * kRecBytes + kSlotBytes - 1) / kSlotB
 // Emulator-verified; to be timed against the default before it replaces it (scripts/build_variant.sh).
 #ifndef RAPID_LEAN_V2
 #define RAPID_LEAN_V2 0
+#endif
+// RAPID_CAREFUL_HINT (default 0): when the careful path cannot exclude an emission in a sub-chunk, retry with the prefix
+// that holds fewer explicit H crossings than updatesInProgress (read off the crossing mask) instead of halving blindly,
+// and go record by record at once when the first record is the critical one.  Only the size of the next attempt
+// changes: every attempt is certified or replayed exactly as before.
+#ifndef RAPID_CAREFUL_HINT
+#define RAPID_CAREFUL_HINT 0
+#endif
+// RAPID_EARLY_CERT (default 0): a fourth certificate for the lean window while there is no witness yet (the first windows
+// of a receiver): if no subject the window touches can reach H even when credited with every implicit report it can
+// ever get -- popc(state | subject_mask) < H -- and the same held for every subject before the window, nothing crosses H
+// in it, so nothing is emitted; any entrant of such a window is a witness for the next one.  Tables in LDS only.
+#ifndef RAPID_EARLY_CERT
+#define RAPID_EARLY_CERT 0
 #endif
 #ifndef RAPID_RING_SLOTS
 #define RAPID_RING_SLOTS 10
@@ -491,6 +506,18 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // s_waitcnt vmcnt(0).
     // wave-major numbering: consecutive receivers go to different CUs, so the last, partial round still uses every CU
     const int wave_global = uniform(wave * (int)gridDim.x + (int)blockIdx.x), waves_total = (int)gridDim.x * (int)(blockDim.x >> 6);
+#if RAPID_EARLY_CERT
+    // with no report at all, can any hot slot reach H through implicit reports alone?  (constant for the round)
+    bool pot_below_h = kTablesInLds;
+    if (kTablesInLds) {
+        unsigned long long any_high0 = 0ull;
+        for (int i0 = 0; i0 < p.idx.n_hot; i0 += kWave) {
+            const int i = i0 + lane;
+            any_high0 |= wave_ballot(i < p.idx.n_hot && __popc((unsigned int)subject_mask[i < p.idx.n_hot ? i : 0] & ((1u << p.K) - 1u)) >= p.H);
+        }
+        pot_below_h = any_high0 == 0ull;
+    }
+#endif
     int r = wave_global;
 #ifdef RAPID_REVERSE_DEAL  // measurement aid: the same deal over the receivers in reverse order
 #define RAPID_RX(i) (p.n_receivers - 1 - (i))
@@ -530,6 +557,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         };
         int careful_budget = 0, careful_next = 1;
         int careful_cap = kWave;  // records the careful loop takes at once; halved while an emission cannot be excluded
+#if RAPID_CAREFUL_HINT
+        int hint_cap = -1;        // after a failed attempt: records of the sub-chunk before its critical H crossing (-1: unknown)
+        bool exact_next = false;  // the next sub-chunk starts with the critical record: replay it record by record
+#endif
 
         // per-sub-chunk decode results (one record per lane)
         int dst = 0, ncons = 0, lastE = -1;
@@ -588,10 +619,22 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // hide its departure; the one with the smallest such bound.  -1 if there is none.
         int witness = -1;
         unsigned int witness_mask = 0u;  // rings on which the witness can receive an implicit report
+#if RAPID_EARLY_CERT
+        bool below_h = false;  // every slot has popc(state | subject_mask) < H: known exactly, nothing applied unchecked since
+#endif
         bool running_exact = false;      // s.running is the reference's updatesInProgress (nothing queued, kept up to date)
+#if RAPID_CAREFUL_HINT
+        int n_at_h = 0;  // slots that have reached H, as of the last recount
+#endif
         auto recount = [&]() {
             wave_lds_fence();
             int run = 0;
+#if RAPID_EARLY_CERT
+            unsigned long long any_high = 0ull;
+#endif
+#if RAPID_CAREFUL_HINT
+            n_at_h = 0;
+#endif
             unsigned int best = 0xFFFFFFFFu, best_mask = 0u;  // bound << 16 | slot
             for (int i0 = 0; i0 < d.n_scan; i0 += kWave) {
                 const int i = i0 + lane;
@@ -599,6 +642,12 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 const int c = d.count(m);
                 const bool pre = i < d.n_scan && c >= d.L && c < d.H;
                 run += __popcll(wave_ballot(pre));
+#if RAPID_EARLY_CERT
+                if (kTablesInLds) any_high |= wave_ballot(i < d.n_scan && d.count(m | (unsigned int)subject_mask[i < d.n_scan ? i : 0]) >= d.H);
+#endif
+#if RAPID_CAREFUL_HINT
+                n_at_h += __popcll(wave_ballot(i < d.n_scan && c >= d.H));
+#endif
                 unsigned int am = 0u;
                 if (kTablesInLds) {
                     am = pre ? (unsigned int)subject_mask[i] : 0u;
@@ -623,6 +672,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             all_best = uniform(all_best);
             s.running = run;
             running_exact = s.npend == 0;  // with nothing queued the state here is the reference's
+#if RAPID_EARLY_CERT
+            below_h = kTablesInLds && any_high == 0ull;
+#endif
             if (all_best == 0xFFFFFFFFu) {
                 witness = -1;
                 witness_mask = 0u;
@@ -762,6 +814,22 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             bool certified = witness >= 0 && __popc((wv | witness_mask) & d.kmask) < d.H;
             int nLc = 0, nHc = 0;
             bool counted = false;
+#if RAPID_EARLY_CERT
+            bool by_bound = false;
+            unsigned int smq[kQuarters];
+            if (kTablesInLds && witness < 0 && below_h) {
+                unsigned long long mHigh = 0ull;
+#pragma unroll
+                for (int q = 0; q < kQuarters; ++q) {
+                    const bool mine_ = ((mApp[q] >> lane) & 1ull) != 0ull;
+                    smq[q] = mine_ ? (unsigned int)subject_mask[slot[q]] : 0u;
+                    mHigh |= mApp[q] & wave_ballot(__popc((old[q] | rb[q] | smq[q]) & d.kmask) >= d.H);
+                }
+                by_bound = mHigh == 0ull;
+                certified = by_bound;
+                below_h = by_bound;
+            }
+#endif
             if (!certified) {
                 // (b)/(c): no implicit report can be generated inside the window (nothing queued, no entrant with hot
                 // adjacency), so only its explicit reports cross H -- none of them, or fewer than updatesInProgress
@@ -792,6 +860,20 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             }
 #ifdef RAPID_TRACE
             if (lane == 0) fprintf(stderr, "L-ok r=%d pos=%d nc=%d witness=%d wcount=%d npend=%d nX=%d batch=%d\n", r, pos, consumed, witness, __popc(wv & d.kmask), s.npend, nX, s.batch);
+#endif
+#if RAPID_EARLY_CERT
+            if (by_bound) {
+                // an entrant of this window is in preProposal from here on and cannot reach H whatever it is credited with
+#pragma unroll
+                for (int q = 0; q < kQuarters; ++q)
+                    if (mL[q] != 0ull) {
+                        const int src = __ffsll((long long)mL[q]) - 1;
+                        witness = lane_value((int)slot[q], src);
+                        witness_mask = (unsigned int)lane_value((int)smq[q], src);
+                    }
+            } else {
+                below_h = false;  // applied without looking at the bounds
+            }
 #endif
             if (anyX != 0ull) {  // queue the entrants whose implicit reports are owed
                 int base = s.npend;
@@ -868,6 +950,16 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 advance(ncons);
                 return true;
             }
+#if RAPID_CAREFUL_HINT
+            // which record is critical: the one with the running-th explicit H crossing (the records before it hold fewer
+            // crossings than updatesInProgress).  Only a hint for the size of the next attempt.
+            hint_cap = -1;
+            if (nHi == 0 && s.running >= 1 && s.running <= 8 && nHc >= s.running) {
+                unsigned long long m = mH;
+                for (int i = 1; i < s.running; ++i) m &= m - 1ull;
+                hint_cap = __ffsll((long long)m) - 1;
+            }
+#endif
             if (n_undo > kUndoCap) {
                 restart = true;  // cannot roll back: redo this receiver on the exact path only
                 exact_only = true;
@@ -962,6 +1054,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 pos = 0;
                 ring_pos = delta;
                 witness = -1;
+#if RAPID_EARLY_CERT
+                below_h = pot_below_h;
+#endif
                 restart = false;
                 careful_budget = 0;
                 careful_cap = kWave;
@@ -981,14 +1076,37 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 if (lane == 0) fprintf(stderr, "C r=%d pos=%d run=%d npend=%d cap=%d budget=%d\n", r, pos, s.running, s.npend, careful_cap, careful_budget);
 #endif
                 from_careful = true;
+#if RAPID_EARLY_CERT
+                below_h = false;
+#endif
                 stream_ensure(min(pos + kWave, nrec));
                 RAPID_T0(tc0);
                 decode();
+#if RAPID_CAREFUL_HINT
+                if (exact_only || s.batch_emitted || exact_next) {
+                    exact_next = false;
+                    exact_subchunk();
+                    if (!exact_only && !s.batch_emitted) careful_cap = kWave;
+#else
                 if (exact_only || s.batch_emitted) {
                     exact_subchunk();
+#endif
                 } else if (immediate_subchunk()) {
                     careful_cap = min(kWave, careful_cap * 2);
                 } else if (!restart) {
+#if RAPID_CAREFUL_HINT
+                    if (hint_cap >= 1 && hint_cap < ncons) {  // the records before the critical crossing
+                        careful_cap = hint_cap;
+                        RAPID_T1(t_careful, tc0);
+                        continue;
+                    }
+                    if (hint_cap == 0 && ncons > 2) {  // the first record is the critical one
+                        careful_cap = 2;
+                        exact_next = true;
+                        RAPID_T1(t_careful, tc0);
+                        continue;
+                    }
+#endif
                     // An emission cannot be excluded somewhere in these ncons records.  Narrow the window instead of
                     // replaying all of them one by one: the record-by-record path only ever runs on a few records.
                     if (ncons > 4) {
@@ -1050,6 +1168,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     careful_next = pos == pos_in ? min(careful_next * 2, 16) : 1;
                     careful_budget = careful_next;
                 }
+#if RAPID_CAREFUL_HINT
+                // End game: most subjects are through and only a few are still between L and H.  Every witness the lean
+                // path could pick is about to leave; each further attempt costs a rolled-back window and a sweep.
+                if (running_exact && s.running <= kEndGameRunning && 2 * n_at_h >= d.n_scan) careful_budget = 1 << 20;
+#endif
             }
         }
         wait_dma<0>();  // the ring is free: nothing of this stream is still landing

@@ -1,22 +1,31 @@
 #!/bin/bash
-# A/B of the RAPID_LEAN_V2 lean window (tally_kernel.h) against the default kernel, on the GPU box:
-#   parity tests on the variant library, then the tally kernel time of both, interleaved (box noise is ~5 %).
-# Build the variant first (works here or on the box):  bash scripts/ab_lean_v2.sh build
+# A/B of the prepared tally-kernel variants (compile-time switches of csrc/tally_kernel.h) against the default kernel:
+#   v2     -DRAPID_LEAN_V2=1        the lean window with fewer instructions
+#   hint   -DRAPID_CAREFUL_HINT=1   careful path: next attempt sized from the crossing mask, end-game rule
+#   early  -DRAPID_EARLY_CERT=1     lean path: bound certificate while there is no witness yet
+#   all    the three together
+# On the GPU box: parity tests on the `all` library, then the tally kernel time of all five, interleaved (box noise ~5 %).
+# Build the variants first (works here or on the box):  bash scripts/ab_lean_v2.sh build
 set -u
 cd "$(dirname "$0")/.."
-V2="$PWD/rapid_amd/librapid_mi355x_v2.so"
-if [ "${1:-}" = "build" ] || [ ! -f "$V2" ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DRAPID_LEAN_V2=1 -Irapid_amd/csrc rapid_amd/csrc/engine.hip rapid_amd/csrc/host_abi.cpp \
-        -o "$V2" -lrccl || exit 1
-    [ "${1:-}" = "build" ] && exit 0
-fi
+declare -A DEFS=( [v2]="-DRAPID_LEAN_V2=1" [hint]="-DRAPID_CAREFUL_HINT=1" [early]="-DRAPID_EARLY_CERT=1"
+                  [all]="-DRAPID_LEAN_V2=1 -DRAPID_CAREFUL_HINT=1 -DRAPID_EARLY_CERT=1" )
+for v in v2 hint early all; do
+    lib="$PWD/rapid_amd/librapid_mi355x_$v.so"
+    if [ "${1:-}" = "build" ] || [ ! -f "$lib" ]; then
+        /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC ${DEFS[$v]} -Irapid_amd/csrc \
+            rapid_amd/csrc/engine.hip rapid_amd/csrc/host_abi.cpp -o "$lib" -lrccl || exit 1
+    fi
+done
+[ "${1:-}" = "build" ] && exit 0
 mkdir -p gpurun_out
-RAPID_MI355X_LIB="$V2" timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu_v2.log 2>&1; tail -2 gpurun_out/pytest_gpu_v2.log
+RAPID_MI355X_LIB="$PWD/rapid_amd/librapid_mi355x_all.so" timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu_all.log 2>&1
+tail -2 gpurun_out/pytest_gpu_all.log
 for i in 1 2 3; do
-    for lib in default v2; do
-        if [ "$lib" = v2 ]; then export RAPID_MI355X_LIB="$V2"; else unset RAPID_MI355X_LIB; fi
-        echo -n "$lib run $i: "
-        timeout 300 python scripts/prof_tally.py C3b 20 2>&1 | grep -h "^workload\|tally" | tail -1
+    for v in default v2 hint early all; do
+        if [ "$v" = default ]; then unset RAPID_MI355X_LIB; else export RAPID_MI355X_LIB="$PWD/rapid_amd/librapid_mi355x_$v.so"; fi
+        echo -n "$v run $i: "
+        timeout 300 python scripts/prof_tally.py C3b 20 2>&1 | grep -h "^workload" | tail -1 | cut -c1-330
     done
 done
 unset RAPID_MI355X_LIB
