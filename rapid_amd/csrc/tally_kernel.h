@@ -606,6 +606,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // certificate's witness (see below) takes no implicit reports, so this cannot be where an emission happens.
         auto flush_pending = [&]() {
             if (s.npend == 0 || !s.seen_down || s.need_full) return;
+#ifdef RAPID_TRACE
+            if (lane == 0) fprintf(stderr, "F r=%d pos=%d npend=%d\n", r, pos, s.npend);
+#endif
             wave_lds_fence();
             int applied = 0;
             (void)invalidate_adj(d, pend, s.npend, false, nullptr, nullptr, lane, &applied);
