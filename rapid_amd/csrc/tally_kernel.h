@@ -71,6 +71,14 @@ constexpr int kWindowSlots = (kLeanWindow * kRecBytes + kSlotBytes - 1) / kSlotB
 #ifndef RAPID_EARLY_CERT
 #define RAPID_EARLY_CERT 0
 #endif
+// RAPID_FAST_WINDOW (default 0): while a witness exists, full windows are applied WITHOUT looking at what the reports do
+// to their subjects: the bits the window adds to the witness are worked out beforehand (its own state + the window's
+// records about it), the window is applied only if the witness provably stays below H -- so nothing is ever rolled
+// back -- and the atomics return nothing.  Which subjects crossed L meanwhile (their implicit reports are owed) is
+// found by a sweep when the owed reports are applied: a slot with >= L reports that has not been walked yet (kWalked).
+#ifndef RAPID_FAST_WINDOW
+#define RAPID_FAST_WINDOW 0
+#endif
 #ifndef RAPID_RING_SLOTS
 #define RAPID_RING_SLOTS 10
 #endif
@@ -85,6 +93,7 @@ constexpr int kPendCap = 128;                        // slots that crossed L and
 constexpr int kUndoCap = 128;                        // implicit bits set inside one sub-chunk
 constexpr int kMaxWavesPerBlock = 16;
 constexpr uint32_t kFlushed = 1u << 14;
+constexpr uint32_t kWalked = 1u << 15;  // RAPID_FAST_WINDOW: the slot's adjacency has been walked for implicit reports
 // dictionary entry (16 bit): bit 15 = node is a member, bit 14 = slot has hot adjacency, bits 0..13 = slot
 constexpr unsigned int kDictMember = 1u << 15;
 constexpr unsigned int kDictHasAdj = 1u << 14;
@@ -339,6 +348,9 @@ __device__ inline int invalidate_adj(const SlotDetector& d, const unsigned short
             d.sync();
             ++a;
         }
+#if RAPID_FAST_WINDOW
+        if (act) (void)d.or_bits(e, kWalked);
+#endif
     }
     return nH;
 }
@@ -604,7 +616,41 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // ---- apply the deferred implicit invalidation for the entrants queued by the lean path.  Every report applied
         // here was applied by the reference at a batch end inside a window already certified emission-free, and the
         // certificate's witness (see below) takes no implicit reports, so this cannot be where an emission happens.
+#if RAPID_FAST_WINDOW
+        bool owed_sweep = false;  // fast windows were applied since the last flush: entrants are not in pend[] but in the state
+#endif
         auto flush_pending = [&]() {
+#if RAPID_FAST_WINDOW
+            if (!s.seen_down || s.need_full || (s.npend == 0 && !owed_sweep)) return;
+            auto walk = [&]() {
+                wave_lds_fence();
+                int applied = 0;
+                (void)invalidate_adj(d, pend, s.npend, false, nullptr, nullptr, lane, &applied);
+                s.npend = 0;
+                n_applied += applied;
+            };
+#ifdef RAPID_TRACE
+            if (lane == 0) fprintf(stderr, "F r=%d pos=%d npend=%d sweep=%d\n", r, pos, s.npend, (int)owed_sweep);
+#endif
+            if (s.npend > 0) walk();  // what the other paths queued (marks it walked)
+            if (owed_sweep) {
+                owed_sweep = false;
+                wave_lds_fence();
+                for (int i0 = 0; i0 < d.n_scan; i0 += kWave) {
+                    const int i = i0 + lane;
+                    const bool in = i < d.n_scan;
+                    const unsigned int m = in ? d.load(i) : 0u;
+                    const bool ent = in && d.count(m) >= d.L && (m & kWalked) == 0u && adj_off[in ? i + 1 : 0] != adj_off[in ? i : 0];
+                    const unsigned long long mk = wave_ballot(ent);
+                    const int cnt = __popcll(mk);
+                    if (cnt == 0) continue;
+                    if (s.npend + cnt > kPendCap) walk();
+                    if (ent) pend[s.npend + __popcll(mk & lanes_lt(lane))] = (unsigned short)i;
+                    s.npend += cnt;
+                }
+                if (s.npend > 0) walk();
+            }
+#else
             if (s.npend == 0 || !s.seen_down || s.need_full) return;
 #ifdef RAPID_TRACE
             if (lane == 0) fprintf(stderr, "F r=%d pos=%d npend=%d\n", r, pos, s.npend);
@@ -614,6 +660,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             (void)invalidate_adj(d, pend, s.npend, false, nullptr, nullptr, lane, &applied);
             s.npend = 0;
             n_applied += applied;
+#endif
         };
 
         // ---- one pass over the hot slots: updatesInProgress (slots with L <= count < H) as the careful path needs it,
@@ -847,6 +894,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 }
                 counted = true;
                 certified = s.npend == 0 && nX == 0 && (mH == 0ull || (running_exact && s.running - nHc >= 1));
+#if RAPID_FAST_WINDOW
+                certified = certified && !owed_sweep;  // entrants of fast windows are owed their implicit reports too
+#endif
             }
             if (__builtin_expect(!certified || anyE == 0ull || s.npend + nX > kPendCap, 0)) {
 #ifdef RAPID_TRACE
@@ -913,6 +963,92 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             advance(consumed);
             return 1;
         };
+
+#if RAPID_FAST_WINDOW
+        // ---- FAST window: kLeanWindow records, a witness exists, a DOWN report has been seen.  Certificate (a) of the lean
+        // window, evaluated BEFORE anything is applied: the witness's state after the window is its state now plus the
+        // bits of the window's records about it.  Returns 0 with nothing applied when the witness could reach H (or the
+        // window holds no batch end).
+        auto fast_window = [&]() -> int {
+            unsigned int w3[kQuarters], w4[kQuarters], rb[kQuarters], slot[kQuarters];
+            bool app[kQuarters];
+            unsigned long long mE[kQuarters], mApp[kQuarters];
+            int nc[kQuarters];
+#pragma unroll
+            for (int q = 0; q < kQuarters; ++q) {
+                unsigned int t = (unsigned int)(ring_pos + lane20 + q * kWave * kRecBytes);
+                if (kRingRecordAligned) t = min(t, t - (unsigned int)kRingBytes);  // per-lane wrap
+                w3[q] = ring_word(t, 3);
+                w4[q] = ring_word(t, 4);
+            }
+            unsigned long long anyE = 0ull;
+#pragma unroll
+            for (int q = 0; q < kQuarters; ++q) {
+                mE[q] = wave_ballot((w4[q] & 0x01000000u) != 0u);
+                anyE |= mE[q];
+            }
+            if (anyE == 0ull) return 0;  // a batch longer than the window: the careful path takes it
+            int consumed = 0;
+            {
+                bool later = false;
+#pragma unroll
+                for (int q = kQuarters - 1; q >= 0; --q) {
+                    nc[q] = later ? kWave : (mE[q] != 0ull ? kWave - __clzll((long long)mE[q]) : 0);
+                    later = later || mE[q] != 0ull;
+                    consumed += nc[q];
+                }
+            }
+            unsigned int wadd = 0u;  // what the window reports about the witness
+#pragma unroll
+            for (int q = 0; q < kQuarters; ++q) {
+                rb[q] = w4[q] & d.kmask;
+                unsigned int de;
+                if (kTrusted) {
+                    de = (unsigned int)dict[w3[q]];  // every record of a full window is a validated alert
+                    app[q] = (lane < nc[q]) & ((de & kSlotMask) != kNoSlot);
+                    mApp[q] = wave_ballot(lane < nc[q]) & wave_ballot((de & kSlotMask) != kNoSlot);
+                } else {
+                    unsigned int t = (unsigned int)(ring_pos + lane20 + q * kWave * kRecBytes);
+                    if (kRingRecordAligned) t = min(t, t - (unsigned int)kRingBytes);
+                    const unsigned int w0 = ring_word(t, 0), w1 = ring_word(t, 1);
+                    de = (unsigned int)dict[w3[q] < (unsigned)p.n_nodes ? w3[q] : 0u];
+                    const unsigned int dn = (w4[q] & 0x00FF0000u) != 0u ? 1u : 0u;
+                    const unsigned int bad = (w0 ^ cfg_lo) | (w1 ^ cfg_hi) | (dn ^ (de >> 15)) |
+                                             (w3[q] >= (unsigned)p.n_nodes ? 1u : 0u) | (rb[q] == 0u ? 1u : 0u) |
+                                             (lane >= nc[q] ? 1u : 0u);
+                    app[q] = (bad == 0u) & ((de & kSlotMask) != kNoSlot);
+                    mApp[q] = wave_ballot(bad == 0u) & wave_ballot((de & kSlotMask) != kNoSlot);
+                }
+                slot[q] = de & kSlotMask;
+                unsigned long long mW = mApp[q] & wave_ballot(slot[q] == (unsigned int)witness);
+                while (mW != 0ull) {  // rare: the witness receives ten reports in a whole stream
+                    wadd |= (unsigned int)lane_value((int)rb[q], __ffsll((long long)mW) - 1);
+                    mW &= mW - 1ull;
+                }
+            }
+            const unsigned int wv = uniform(d.load(witness));
+            if (__popc((wv | wadd | witness_mask) & d.kmask) >= d.H) {
+#ifdef RAPID_TRACE
+                if (lane == 0) fprintf(stderr, "W-fail r=%d pos=%d witness=%d wcount=%d\n", r, pos, witness, __popc((wv | wadd) & d.kmask));
+#endif
+                return 0;
+            }
+#pragma unroll
+            for (int q = 0; q < kQuarters; ++q)
+                if (app[q]) (void)d.or_bits((int)slot[q], rb[q]);
+            owed_sweep = true;
+            running_exact = false;
+#if RAPID_EARLY_CERT
+            below_h = false;
+#endif
+            int nbatches = 0;
+#pragma unroll
+            for (int q = 0; q < kQuarters; ++q) nbatches += __popcll(mE[q]);
+            s.batch += nbatches;
+            advance(consumed);
+            return 1;
+        };
+#endif
 
         // ---- CAREFUL path (non-pipelined loop), first attempt: order-free application with the implicit
         // invalidation applied immediately and an EXACT count of the H crossings; rolled back if an emission
@@ -1060,6 +1196,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #if RAPID_EARLY_CERT
                 below_h = pot_below_h;
 #endif
+#if RAPID_FAST_WINDOW
+                owed_sweep = false;
+#endif
                 restart = false;
                 careful_budget = 0;
                 careful_cap = kWave;
@@ -1134,7 +1273,17 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             while (nrec - pos >= kLeanWindow) {
                 stream_ensure(pos + kLeanWindow);
                 RAPID_T0(tl0);
+#if RAPID_FAST_WINDOW
+                int ok_;
+                if (witness >= 0 && s.seen_down)
+                    ok_ = fast_window();
+                else
 #if RAPID_LEAN_V2
+                    ok_ = s.seen_down ? lean_window(std::false_type{}, std::true_type{}) : lean_window(std::false_type{}, std::false_type{});
+#else
+                    ok_ = lean_window(std::false_type{}, std::false_type{});
+#endif
+#elif RAPID_LEAN_V2
                 const int ok_ = s.seen_down ? lean_window(std::false_type{}, std::true_type{})
                                             : lean_window(std::false_type{}, std::false_type{});
 #else

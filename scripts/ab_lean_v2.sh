@@ -4,13 +4,17 @@
 #   hint   -DRAPID_CAREFUL_HINT=1   careful path: next attempt sized from the crossing mask, end-game rule
 #   early  -DRAPID_EARLY_CERT=1     lean path: bound certificate while there is no witness yet
 #   all    the three together
-# On the GPU box: parity tests on the `all` library, then the tally kernel time of all five, interleaved (box noise ~5 %).
+#   fast   -DRAPID_FAST_WINDOW=1    windows applied without return values once a witness exists; entrants found by a sweep
+#   all4   the four together
+# On the GPU box: parity tests on the `all` and `all4` libraries, then the tally kernel time of all seven, interleaved
+# (box noise ~5 %).
 # Build the variants first (works here or on the box):  bash scripts/ab_lean_v2.sh build
 set -u
 cd "$(dirname "$0")/.."
 declare -A DEFS=( [v2]="-DRAPID_LEAN_V2=1" [hint]="-DRAPID_CAREFUL_HINT=1" [early]="-DRAPID_EARLY_CERT=1"
-                  [all]="-DRAPID_LEAN_V2=1 -DRAPID_CAREFUL_HINT=1 -DRAPID_EARLY_CERT=1" )
-for v in v2 hint early all; do
+                  [all]="-DRAPID_LEAN_V2=1 -DRAPID_CAREFUL_HINT=1 -DRAPID_EARLY_CERT=1" [fast]="-DRAPID_FAST_WINDOW=1"
+                  [all4]="-DRAPID_LEAN_V2=1 -DRAPID_CAREFUL_HINT=1 -DRAPID_EARLY_CERT=1 -DRAPID_FAST_WINDOW=1" )
+for v in v2 hint early all fast all4; do
     lib="$PWD/rapid_amd/librapid_mi355x_$v.so"
     if [ "${1:-}" = "build" ] || [ ! -f "$lib" ]; then
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC ${DEFS[$v]} -Irapid_amd/csrc \
@@ -19,10 +23,12 @@ for v in v2 hint early all; do
 done
 [ "${1:-}" = "build" ] && exit 0
 mkdir -p gpurun_out
-RAPID_MI355X_LIB="$PWD/rapid_amd/librapid_mi355x_all.so" timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu_all.log 2>&1
-tail -2 gpurun_out/pytest_gpu_all.log
+for v in all all4; do
+    RAPID_MI355X_LIB="$PWD/rapid_amd/librapid_mi355x_$v.so" timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu_$v.log 2>&1
+    echo -n "$v: "; tail -1 gpurun_out/pytest_gpu_$v.log
+done
 for i in 1 2 3; do
-    for v in default v2 hint early all; do
+    for v in default v2 hint early all fast all4; do
         if [ "$v" = default ]; then unset RAPID_MI355X_LIB; else export RAPID_MI355X_LIB="$PWD/rapid_amd/librapid_mi355x_$v.so"; fi
         echo -n "$v run $i: "
         timeout 300 python scripts/prof_tally.py C3b 20 2>&1 | grep -h "^workload" | tail -1 | cut -c1-330
