@@ -46,6 +46,7 @@ constexpr int kSlotBytes = 1024;                     // one LDS-DMA wave instruc
 #ifndef RAPID_QUARTERS
 #define RAPID_QUARTERS 3
 #endif
+constexpr int kRepickAfter = 8 * 192;                // RAPID_FAST_WINDOW: records after which the first witness is reconsidered
 constexpr int kEndGameRunning = 16;                   // RAPID_CAREFUL_HINT: updatesInProgress at which the lean path is left for good
 constexpr int kQuarters = RAPID_QUARTERS;            // records per lane in a lean window
 constexpr int kLeanWindow = kQuarters * kWave;       // 192 records = 3840 B (2 and 4 per lane measured slower: profiles/)
@@ -618,6 +619,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // certificate's witness (see below) takes no implicit reports, so this cannot be where an emission happens.
 #if RAPID_FAST_WINDOW
         bool owed_sweep = false;  // fast windows were applied since the last flush: entrants are not in pend[] but in the state
+        bool repicked = false;    // the early witness has been exchanged for the best one available
 #endif
         auto flush_pending = [&]() {
 #if RAPID_FAST_WINDOW
@@ -722,6 +724,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             all_best = uniform(all_best);
             s.running = run;
             running_exact = s.npend == 0;  // with nothing queued the state here is the reference's
+#if RAPID_FAST_WINDOW
+            running_exact = running_exact && !owed_sweep;
+#endif
 #if RAPID_EARLY_CERT
             below_h = kTablesInLds && any_high == 0ull;
 #endif
@@ -1198,6 +1203,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #endif
 #if RAPID_FAST_WINDOW
                 owed_sweep = false;
+                repicked = false;
 #endif
                 restart = false;
                 careful_budget = 0;
@@ -1275,9 +1281,15 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 RAPID_T0(tl0);
 #if RAPID_FAST_WINDOW
                 int ok_;
-                if (witness >= 0 && s.seen_down)
+                if (witness >= 0 && s.seen_down) {
+                    // The first witness is whichever subject crossed L first; a few windows on there are many to choose
+                    // from: one sweep picks the one with the most head room instead of waiting for the first to fail.
+                    if (!repicked && witness_mask != 0u && pos >= kRepickAfter) {
+                        repicked = true;
+                        recount();
+                    }
                     ok_ = fast_window();
-                else
+                } else
 #if RAPID_LEAN_V2
                     ok_ = s.seen_down ? lean_window(std::false_type{}, std::true_type{}) : lean_window(std::false_type{}, std::false_type{});
 #else
