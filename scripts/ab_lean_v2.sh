@@ -27,11 +27,4 @@ for v in all all4; do
     RAPID_MI355X_LIB="$PWD/rapid_amd/librapid_mi355x_$v.so" timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu_$v.log 2>&1
     echo -n "$v: "; tail -1 gpurun_out/pytest_gpu_$v.log
 done
-for i in 1 2 3; do
-    for v in default v2 hint early all fast all4; do
-        if [ "$v" = default ]; then unset RAPID_MI355X_LIB; else export RAPID_MI355X_LIB="$PWD/rapid_amd/librapid_mi355x_$v.so"; fi
-        echo -n "$v run $i: "
-        timeout 300 python scripts/prof_tally.py C3b 20 2>&1 | grep -h "^workload" | tail -1 | cut -c1-330
-    done
-done
-unset RAPID_MI355X_LIB
+timeout 1200 python scripts/ab_variants.py C3b 3 20 2>&1 | tee gpurun_out/ab_variants.log | tail -40
