@@ -1025,13 +1025,22 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     mApp[q] = wave_ballot(bad == 0u) & wave_ballot((de & kSlotMask) != kNoSlot);
                 }
                 slot[q] = de & kSlotMask;
-                unsigned long long mW = mApp[q] & wave_ballot(slot[q] == (unsigned int)witness);
-                while (mW != 0ull) {  // rare: the witness receives ten reports in a whole stream
-                    wadd |= (unsigned int)lane_value((int)rb[q], __ffsll((long long)mW) - 1);
-                    mW &= mW - 1ull;
-                }
             }
             const unsigned int wv = uniform(d.load(witness));
+            {
+                unsigned long long mW[kQuarters], anyW = 0ull;
+#pragma unroll
+                for (int q = 0; q < kQuarters; ++q) {
+                    mW[q] = mApp[q] & wave_ballot(slot[q] == (unsigned int)witness);
+                    anyW |= mW[q];
+                }
+                if (anyW != 0ull) {  // rare: the witness receives ten reports in a whole stream
+#pragma unroll
+                    for (int q = 0; q < kQuarters; ++q)
+                        for (unsigned long long m = mW[q]; m != 0ull; m &= m - 1ull)
+                            wadd |= (unsigned int)lane_value((int)rb[q], __ffsll((long long)m) - 1);
+                }
+            }
             if (__popc((wv | wadd | witness_mask) & d.kmask) >= d.H) {
 #ifdef RAPID_TRACE
                 if (lane == 0) fprintf(stderr, "W-fail r=%d pos=%d witness=%d wcount=%d\n", r, pos, witness, __popc((wv | wadd) & d.kmask));
@@ -1040,7 +1049,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             }
 #pragma unroll
             for (int q = 0; q < kQuarters; ++q)
-                if (app[q]) (void)d.or_bits((int)slot[q], rb[q]);
+                if (__builtin_expect(app[q], 1)) (void)d.or_bits((int)slot[q], rb[q]);
             owed_sweep = true;
             running_exact = false;
 #if RAPID_EARLY_CERT
