@@ -75,8 +75,9 @@ constexpr int kWindowSlots = (kLeanWindow * kRecBytes + kSlotBytes - 1) / kSlotB
 // RAPID_FAST_WINDOW (default 0): while a witness exists, full windows are applied WITHOUT looking at what the reports do
 // to their subjects: the bits the window adds to the witness are worked out beforehand (its own state + the window's
 // records about it), the window is applied only if the witness provably stays below H -- so nothing is ever rolled
-// back -- and the atomics return nothing.  Which subjects crossed L meanwhile (their implicit reports are owed) is
-// found by a sweep when the owed reports are applied: a slot with >= L reports that has not been walked yet (kWalked).
+// back -- and the atomics return nothing.  Which subjects crossed L meanwhile is not tracked at all: the owed implicit
+// reports are applied by one pass over the round's (subject, observer, ring) pairs among the hot slots -- the
+// reference's literal invalidateFailingEdges -- a few hundred pairs, 64 per step.
 #ifndef RAPID_FAST_WINDOW
 #define RAPID_FAST_WINDOW 0
 #endif
@@ -94,7 +95,7 @@ constexpr int kPendCap = 128;                        // slots that crossed L and
 constexpr int kUndoCap = 128;                        // implicit bits set inside one sub-chunk
 constexpr int kMaxWavesPerBlock = 16;
 constexpr uint32_t kFlushed = 1u << 14;
-constexpr uint32_t kWalked = 1u << 15;  // RAPID_FAST_WINDOW: the slot's adjacency has been walked for implicit reports
+
 // dictionary entry (16 bit): bit 15 = node is a member, bit 14 = slot has hot adjacency, bits 0..13 = slot
 constexpr unsigned int kDictMember = 1u << 15;
 constexpr unsigned int kDictHasAdj = 1u << 14;
@@ -134,8 +135,12 @@ struct TallyParams {
 
 __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
 // LDS budget: shared tables (only when they are staged in LDS) + per-wave detector state, ring, lists
+__host__ __device__ inline int tally_pairs_bytes(int n_adj) {  // RAPID_FAST_WINDOW: [count, (subject, observer, ring) ...]
+    return RAPID_FAST_WINDOW ? align16((n_adj / 2 + 1) * 4) : 0;
+}
 __host__ __device__ inline int tally_shared_bytes(int n_nodes, int n_hot, int n_adj) {
-    return align16(n_nodes * 2) + align16((n_hot + 1) * 2) + align16(n_adj * 4) + align16(n_hot * 4) + align16(n_hot * 2);
+    return align16(n_nodes * 2) + align16((n_hot + 1) * 2) + align16(n_adj * 4) + align16(n_hot * 4) + align16(n_hot * 2) +
+           tally_pairs_bytes(n_adj);
 }
 // per-workgroup statistics accumulator at the very end of the dynamic LDS segment
 constexpr int kBlockStatsBytes = 64;
@@ -349,9 +354,6 @@ __device__ inline int invalidate_adj(const SlotDetector& d, const unsigned short
             d.sync();
             ++a;
         }
-#if RAPID_FAST_WINDOW
-        if (act) (void)d.or_bits(e, kWalked);
-#endif
     }
     return nH;
 }
@@ -417,6 +419,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     const unsigned int* adj = p.idx.adj;
     const int* node_of_slot = p.idx.node_of_slot;
     const unsigned short* subject_mask = nullptr;  // per hot slot, staged in LDS; computed on the fly otherwise
+#if RAPID_FAST_WINDOW
+    const unsigned int* pairs = nullptr;  // [0] = n, then (subject slot | observer slot << 14 | ring << 28); LDS tables only
+#endif
     int shared_bytes = 0;
     if (kTablesInLds) {
         unsigned short* l_dict = reinterpret_cast<unsigned short*>(smem);
@@ -441,6 +446,25 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             l_smask[i] = (unsigned short)am;
         }
         subject_mask = l_smask;
+#if RAPID_FAST_WINDOW
+        // the hot adjacency as a flat list of (subject slot, observer slot, ring): one implicit report each
+        unsigned int* l_pairs = reinterpret_cast<unsigned int*>(smem + align16(p.n_nodes * 2) + align16((p.idx.n_hot + 1) * 2) +
+                                                                align16(p.idx.n_adj * 4) + align16(p.idx.n_hot * 4) + align16(p.idx.n_hot * 2));
+        if (threadIdx.x == 0) l_pairs[0] = 0u;
+        __syncthreads();
+        for (int i = (int)threadIdx.x; i < p.idx.n_hot; i += (int)blockDim.x) {
+            const int a0 = (int)p.idx.adj_off[i], a1 = (int)p.idx.adj_off[i + 1];
+            int c = 0;
+            for (int a = a0; a < a1; ++a) c += ((p.idx.adj[a] >> 20) & 1u) == 0u ? 1 : 0;
+            if (c == 0) continue;
+            unsigned int at = atomicAdd(&l_pairs[0], (unsigned int)c);
+            for (int a = a0; a < a1; ++a) {
+                const unsigned int ent = p.idx.adj[a];
+                if (((ent >> 20) & 1u) == 0u) l_pairs[1 + at++] = (unsigned int)i | ((ent & 0x3FFFu) << 14) | (((ent >> 16) & 15u) << 28);
+            }
+        }
+        pairs = l_pairs;
+#endif
         dict = l_dict;
         adj_off = l_off;
         adj = l_adj;
@@ -624,34 +648,33 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         auto flush_pending = [&]() {
 #if RAPID_FAST_WINDOW
             if (!s.seen_down || s.need_full || (s.npend == 0 && !owed_sweep)) return;
-            auto walk = [&]() {
-                wave_lds_fence();
-                int applied = 0;
-                (void)invalidate_adj(d, pend, s.npend, false, nullptr, nullptr, lane, &applied);
-                s.npend = 0;
-                n_applied += applied;
-            };
 #ifdef RAPID_TRACE
             if (lane == 0) fprintf(stderr, "F r=%d pos=%d npend=%d sweep=%d\n", r, pos, s.npend, (int)owed_sweep);
 #endif
-            if (s.npend > 0) walk();  // what the other paths queued (marks it walked)
-            if (owed_sweep) {
-                owed_sweep = false;
-                wave_lds_fence();
-                for (int i0 = 0; i0 < d.n_scan; i0 += kWave) {
-                    const int i = i0 + lane;
-                    const bool in = i < d.n_scan;
-                    const unsigned int m = in ? d.load(i) : 0u;
-                    const bool ent = in && d.count(m) >= d.L && (m & kWalked) == 0u && adj_off[in ? i + 1 : 0] != adj_off[in ? i : 0];
-                    const unsigned long long mk = wave_ballot(ent);
-                    const int cnt = __popcll(mk);
-                    if (cnt == 0) continue;
-                    if (s.npend + cnt > kPendCap) walk();
-                    if (ent) pend[s.npend + __popcll(mk & lanes_lt(lane))] = (unsigned short)i;
-                    s.npend += cnt;
+            wave_lds_fence();
+            int applied = 0;
+            if (kTablesInLds) {
+                const int np = (int)pairs[0];
+                for (int a0 = 0; a0 < np; a0 += kWave) {
+                    const int a = a0 + lane;
+                    const bool on = a < np;
+                    const unsigned int pr = on ? pairs[1 + a] : 0u;
+                    const int sj = (int)(pr & 0x3FFFu), ob = (int)((pr >> 14) & 0x3FFFu);
+                    const unsigned int bit = 1u << (pr >> 28);
+                    const unsigned int ms = on ? d.load(sj) : 0u, mo = on ? d.load(ob) : 0u;
+                    const int cs = d.count(ms), co = d.count(mo);
+                    // same test as invalidate_adj: s in preProposal, o in proposal U preProposal, report not there yet
+                    const bool apply = on && cs >= d.L && cs < d.H && co >= d.L && !(mo & kFlushed) && !(ms & bit);
+                    if (apply) (void)d.or_bits(sj, bit);
+                    applied += __popcll(wave_ballot(apply));
+                    d.sync();
                 }
-                if (s.npend > 0) walk();
+            } else {
+                (void)invalidate_adj(d, pend, 0, true, nullptr, nullptr, lane, &applied);  // the same pass over the adjacency lists
             }
+            s.npend = 0;
+            owed_sweep = false;
+            n_applied += applied;
 #else
             if (s.npend == 0 || !s.seen_down || s.need_full) return;
 #ifdef RAPID_TRACE

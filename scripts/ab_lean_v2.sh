@@ -4,7 +4,7 @@
 #   hint   -DRAPID_CAREFUL_HINT=1   careful path: next attempt sized from the crossing mask, end-game rule
 #   early  -DRAPID_EARLY_CERT=1     lean path: bound certificate while there is no witness yet
 #   all    the three together
-#   fast   -DRAPID_FAST_WINDOW=1    windows applied without return values once a witness exists; entrants found by a sweep
+#   fast   -DRAPID_FAST_WINDOW=1    windows applied without return values once a witness exists; flat pair pass for the owed reports
 #   all4   the four together
 # On the GPU box: parity tests on the `all` and `all4` libraries, then the tally kernel time of all seven, interleaved
 # (box noise ~5 %).
