@@ -358,6 +358,41 @@ __device__ inline int invalidate_adj(const SlotDetector& d, const unsigned short
     return nH;
 }
 
+#if RAPID_FAST_WINDOW
+// The same invalidation as ONE pass over the round's flat list of (subject slot, observer slot, ring) triples among the
+// hot slots: pairs[0] = n, pairs[1 + a] = subject | observer << 14 | ring << 28.  Every triple is one potential implicit
+// report; the test is invalidate_adj's.  A few hundred triples, 64 per step, whatever the number of entrants.
+__device__ inline int invalidate_pairs(const SlotDetector& d, const unsigned int* pairs, unsigned int* undo, int* n_undo, int lane,
+                                       int* n_applied) {
+    int nH = 0;
+    const int np = (int)pairs[0];
+    for (int a0 = 0; a0 < np; a0 += kWave) {
+        const int a = a0 + lane;
+        const bool on = a < np;
+        const unsigned int pr = on ? pairs[1 + a] : 0u;
+        const int sj = (int)(pr & 0x3FFFu), ob = (int)((pr >> 14) & 0x3FFFu);
+        const int k = (int)(pr >> 28);
+        const unsigned int ms = on ? d.load(sj) : 0u, mo = on ? d.load(ob) : 0u;
+        const int cs = d.count(ms), co = d.count(mo);
+        const bool apply = on && cs >= d.L && cs < d.H && co >= d.L && !(mo & kFlushed) && !(ms & (1u << k));
+        unsigned int old = 0;
+        if (apply) old = d.or_bits(sj, 1u << k);
+        const bool isnew = apply && !(old & (1u << k));
+        const bool crossH = isnew && d.count(old) == d.H - 1;
+        nH += __popcll(wave_ballot(crossH));
+        const unsigned long long mnew = wave_ballot(isnew);
+        if (undo != nullptr) {
+            const int idx = *n_undo + __popcll(mnew & lanes_lt(lane));
+            if (isnew && idx < kUndoCap) undo[idx] = (unsigned)sj | ((unsigned)k << 24);
+            *n_undo += __popcll(mnew);
+        }
+        *n_applied += __popcll(mnew);
+        d.sync();
+    }
+    return nH;
+}
+#endif
+
 // The reference's literal pass over the view's observer table (single-detector API): every node in preProposal
 // x its K observers (expected observers for a non-member).
 __device__ inline int invalidate_table(const TableDetector& d, int lane) {
@@ -654,21 +689,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             wave_lds_fence();
             int applied = 0;
             if (kTablesInLds) {
-                const int np = (int)pairs[0];
-                for (int a0 = 0; a0 < np; a0 += kWave) {
-                    const int a = a0 + lane;
-                    const bool on = a < np;
-                    const unsigned int pr = on ? pairs[1 + a] : 0u;
-                    const int sj = (int)(pr & 0x3FFFu), ob = (int)((pr >> 14) & 0x3FFFu);
-                    const unsigned int bit = 1u << (pr >> 28);
-                    const unsigned int ms = on ? d.load(sj) : 0u, mo = on ? d.load(ob) : 0u;
-                    const int cs = d.count(ms), co = d.count(mo);
-                    // same test as invalidate_adj: s in preProposal, o in proposal U preProposal, report not there yet
-                    const bool apply = on && cs >= d.L && cs < d.H && co >= d.L && !(mo & kFlushed) && !(ms & bit);
-                    if (apply) (void)d.or_bits(sj, bit);
-                    applied += __popcll(wave_ballot(apply));
-                    d.sync();
-                }
+                (void)invalidate_pairs(d, pairs, nullptr, nullptr, lane, &applied);
             } else {
                 (void)invalidate_adj(d, pend, 0, true, nullptr, nullptr, lane, &applied);  // the same pass over the adjacency lists
             }
@@ -1111,7 +1132,12 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             if (run_inv) {
                 wave_lds_fence();
                 if (need_full) n_full++;
-                nHi = invalidate_adj(d, pend, npend_new, need_full, undo, &n_undo, lane, &applied_here);
+#if RAPID_FAST_WINDOW
+                if (kTablesInLds)
+                    nHi = invalidate_pairs(d, pairs, undo, &n_undo, lane, &applied_here);
+                else
+#endif
+                    nHi = invalidate_adj(d, pend, npend_new, need_full, undo, &n_undo, lane, &applied_here);
             }
             const int Htot = nHc + nHi;
             if (Htot == 0 || s.running - Htot >= 1) {
@@ -1258,6 +1284,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 from_careful = true;
 #if RAPID_EARLY_CERT
                 below_h = false;
+#endif
+#if RAPID_FAST_WINDOW && defined(RAPID_TRACE)
+                if (owed_sweep && lane == 0) fprintf(stderr, "BUG r=%d pos=%d: implicit reports owed on entry to the careful path\n", r, pos);
 #endif
                 stream_ensure(min(pos + kWave, nrec));
                 RAPID_T0(tc0);
