@@ -365,7 +365,7 @@ __device__ inline int invalidate_adj(const SlotDetector& d, const unsigned short
 __device__ inline int invalidate_pairs(const SlotDetector& d, const unsigned int* pairs, unsigned int* undo, int* n_undo, int lane,
                                        int* n_applied) {
     int nH = 0;
-    const int np = (int)pairs[0];
+    const int np = uniform((int)pairs[0]);
     for (int a0 = 0; a0 < np; a0 += kWave) {
         const int a = a0 + lane;
         const bool on = a < np;
