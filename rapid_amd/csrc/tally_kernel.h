@@ -81,6 +81,11 @@ constexpr int kWindowSlots = (kLeanWindow * kRecBytes + kSlotBytes - 1) / kSlotB
 #ifndef RAPID_FAST_WINDOW
 #define RAPID_FAST_WINDOW 0
 #endif
+// RAPID_DMA_PAIRS (default 0): the stream is topped up two KiB per loop trip (one wait for two landed KiB, two loads)
+// instead of one -- half the scalar bookkeeping and branches per KiB.
+#ifndef RAPID_DMA_PAIRS
+#define RAPID_DMA_PAIRS 0
+#endif
 #ifndef RAPID_RING_SLOTS
 #define RAPID_RING_SLOTS 10
 #endif
@@ -1209,9 +1214,15 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // are outstanding.  KiB past the end of the stream are out of range of the buffer resource: they cost no memory
         // traffic but keep the count of outstanding loads constant, which keeps every wait a compile-time constant.
         int landed = 0, slot_issue = 0;  // KiB landed .. landed + kDepth - 1 are in flight; slot_issue = (landed + kDepth) % kRingSlots
+#if RAPID_DMA_PAIRS
+        lds_addr_t issue_lds = ring_lds;  // = ring_lds + slot_issue * kSlotBytes, kept as an address (no shift + add per load)
+#endif
         auto stream_start = [&]() {
             landed = 0;
             slot_issue = kDepth % kRingSlots;
+#if RAPID_DMA_PAIRS
+            issue_lds = ring_lds + (kDepth % kRingSlots) * kSlotBytes;
+#endif
             if (prestarted) {  // issued at the end of the previous receiver
                 prestarted = false;
                 return;
@@ -1225,6 +1236,28 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // `pos` lies in) and no KiB up to landed + kDepth can reuse the slot of a KiB >= kp.
         auto stream_ensure = [&](int end_rec) {
             const int need = (int)((unsigned int)(delta + kRecBytes * end_rec + kSlotBytes - 1) / (unsigned int)kSlotBytes);
+#if RAPID_DMA_PAIRS
+            static_assert(kDepth >= 2, "pairs need two KiB in flight");
+            // Two at a time: with at most kDepth - 2 loads outstanding two more KiB have landed.  The second load reuses the
+            // slot of KiB landed - (kRingSlots - kDepth - 1), still older than the KiB `pos` lies in (landed + 1 < need).
+            while (landed + 1 < need) {
+                wait_dma<kDepth - 2>();
+                lds_dma16(rsrc, lane16, (unsigned int)(landed + kDepth) * kSlotBytes, issue_lds);
+                issue_lds += kSlotBytes;
+                if (issue_lds == ring_lds + kRingBytes) issue_lds = ring_lds;
+                lds_dma16(rsrc, lane16, (unsigned int)(landed + kDepth + 1) * kSlotBytes, issue_lds);
+                issue_lds += kSlotBytes;
+                if (issue_lds == ring_lds + kRingBytes) issue_lds = ring_lds;
+                landed += 2;
+            }
+            while (landed < need) {
+                wait_dma<kDepth - 1>();
+                lds_dma16(rsrc, lane16, (unsigned int)(landed + kDepth) * kSlotBytes, issue_lds);
+                issue_lds += kSlotBytes;
+                if (issue_lds == ring_lds + kRingBytes) issue_lds = ring_lds;
+                ++landed;
+            }
+#endif
             while (landed < need) {
 #ifdef RAPID_TIMER_FINE
                 RAPID_T0(te0);

@@ -6,15 +6,18 @@
 #   all    the three together
 #   fast   -DRAPID_FAST_WINDOW=1    windows applied without return values once a witness exists; flat pair pass for the owed reports
 #   all4   the four together
-# On the GPU box: parity tests on the `all` and `all4` libraries, then the tally kernel time of all seven, interleaved
+#   pairs  -DRAPID_DMA_PAIRS=1      stream topped up two KiB per loop trip, running LDS address
+#   all5   the five together
+# On the GPU box: parity tests on the `all`, `all4` and `all5` libraries, then the tally kernel time of all nine, interleaved
 # (box noise ~5 %).
 # Build the variants first (works here or on the box):  bash scripts/ab_lean_v2.sh build
 set -u
 cd "$(dirname "$0")/.."
 declare -A DEFS=( [v2]="-DRAPID_LEAN_V2=1" [hint]="-DRAPID_CAREFUL_HINT=1" [early]="-DRAPID_EARLY_CERT=1"
                   [all]="-DRAPID_LEAN_V2=1 -DRAPID_CAREFUL_HINT=1 -DRAPID_EARLY_CERT=1" [fast]="-DRAPID_FAST_WINDOW=1"
-                  [all4]="-DRAPID_LEAN_V2=1 -DRAPID_CAREFUL_HINT=1 -DRAPID_EARLY_CERT=1 -DRAPID_FAST_WINDOW=1" )
-for v in v2 hint early all fast all4; do
+                  [all4]="-DRAPID_LEAN_V2=1 -DRAPID_CAREFUL_HINT=1 -DRAPID_EARLY_CERT=1 -DRAPID_FAST_WINDOW=1" [pairs]="-DRAPID_DMA_PAIRS=1"
+                  [all5]="-DRAPID_LEAN_V2=1 -DRAPID_CAREFUL_HINT=1 -DRAPID_EARLY_CERT=1 -DRAPID_FAST_WINDOW=1 -DRAPID_DMA_PAIRS=1" )
+for v in v2 hint early all fast all4 pairs all5; do
     lib="$PWD/rapid_amd/librapid_mi355x_$v.so"
     if [ "${1:-}" = "build" ] || [ ! -f "$lib" ]; then
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC ${DEFS[$v]} -Irapid_amd/csrc \
@@ -23,7 +26,7 @@ for v in v2 hint early all fast all4; do
 done
 [ "${1:-}" = "build" ] && exit 0
 mkdir -p gpurun_out
-for v in all all4; do
+for v in all all4 all5; do
     RAPID_MI355X_LIB="$PWD/rapid_amd/librapid_mi355x_$v.so" timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu_$v.log 2>&1
     echo -n "$v: "; tail -1 gpurun_out/pytest_gpu_$v.log
 done
