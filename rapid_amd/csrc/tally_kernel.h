@@ -728,6 +728,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         int n_at_h = 0;  // slots that have reached H, as of the last recount
 #endif
         auto recount = [&]() {
+#ifdef RAPID_TRACE
+            if (lane == 0) fprintf(stderr, "R r=%d pos=%d\n", r, pos);
+#endif
             wave_lds_fence();
             int run = 0;
 #if RAPID_EARLY_CERT
@@ -775,6 +778,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             running_exact = s.npend == 0;  // with nothing queued the state here is the reference's
 #if RAPID_FAST_WINDOW
             running_exact = running_exact && !owed_sweep;
+            repicked = pos >= kRepickAfter;  // this WAS the sweep for the best witness, unless it came too early to count
 #endif
 #if RAPID_EARLY_CERT
             below_h = kTablesInLds && any_high == 0ull;
@@ -1430,6 +1434,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 // End game: most subjects are through and only a few are still between L and H.  Every witness the lean
                 // path could pick is about to leave; each further attempt costs a rolled-back window and a sweep.
                 if (running_exact && s.running <= kEndGameRunning && 2 * n_at_h >= d.n_scan) careful_budget = 1 << 20;
+                // ... or the witness just chosen did not survive a single window while most subjects are through
+                if (pos == pos_in && 2 * n_at_h >= d.n_scan) careful_budget = 1 << 20;
 #endif
             }
         }
