@@ -3,7 +3,9 @@
  *
  * This is the drop-in boundary for ONE path of lalithsuresh/rapid: the package-private Java classes
  * MembershipView, MultiNodeCutDetector and the fast round of FastPaxos, plus the per-batch semantics of
- * MembershipService.handleMessage(BatchedAlertMessage), replayed for a whole simulated population on the GPU.
+ * MembershipService.handleMessage(BatchedAlertMessage), replayed for a whole simulated population on the GPU;
+ * and, host only, what sits either side of that path: the wire forms of its messages and the consensus
+ * instance of one node (FastPaxos + Paxos) for the rounds the fast path does not decide.
  * Citations are relative to /root/reference/rapid/src/main/java/com/vrg/rapid/ ("R/").
  *
  * Conventions:
