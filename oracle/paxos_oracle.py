@@ -294,3 +294,48 @@ class Network:
             self.deliver_one(self.rng.choice(p))
             steps += 1
         raise RuntimeError("no quiescence")
+
+
+class TimedNetwork:
+    """The same classes on a time line: a message sent at time t to node j is handled at t + delay(sender, j); handlers
+    run in time order (ties: lower destination, then send order) and send at the time they run.  For the protocol-time
+    checks of tests/test_timeline.py; delay(sender, receiver) -> integer milliseconds."""
+
+    def __init__(self, membershipSize, live, configurationId, delay, hash_codes=None):
+        import heapq
+        self._heapq = heapq
+        self.live = list(live)
+        self.delay = delay
+        self.now = 0
+        self._events = []
+        self._seq = 0
+        self.decision_ms = {}
+        self.decisions = {}
+        self.nodes = {}
+        for i in self.live:
+            self.nodes[i] = FastPaxos(i, configurationId, membershipSize, (lambda dest, m, i=i: self._post(i, dest, m)),
+                                      (lambda m, i=i: [self._post(i, dest, m) for dest in self.live]),
+                                      (lambda v, i=i: self._decided(i, v)), (hash_codes or {}).get(i, i + 2))
+
+    def _post(self, sender, dest, m):
+        if dest in self.nodes:
+            self._heapq.heappush(self._events, (self.now + int(self.delay(sender, dest)), dest, self._seq, m))
+            self._seq += 1
+
+    def _decided(self, i, v):
+        self.decisions[i] = v
+        self.decision_ms[i] = self.now
+
+    def at(self, t, fn):
+        """run fn() (e.g. a node's propose or startClassicPaxosRound) at time t"""
+        self._heapq.heappush(self._events, (t, -1, self._seq, fn))
+        self._seq += 1
+
+    def run(self):
+        while self._events:
+            t, dest, _, what = self._heapq.heappop(self._events)
+            self.now = t
+            if dest < 0:
+                what()
+            else:
+                self.nodes[dest].handleMessages(what)

@@ -184,3 +184,45 @@ def fast_round_decision_times(proposal_ms, receivers, vote_key, n, latency, chun
         # the vote that brings the winner's count to the quorum also finds the total at or above it (:146-147)
         out[a:a + chunk] = np.partition(arr, quorum - 1, axis=1)[:, quorum - 1]
     return out
+
+
+def classic_round_times(proposal_ms, receivers, vote_key, n, latency, base_delay_ms, u):
+    """The recovery round on the time line, for a population whose fast round found no quorum.  Every node arms its
+    recovery timer when it proposes: proposal time + base delay + an exponential jitter with mean N seconds
+    (R/FastPaxos.java:76,107-109,201-204; u[i] = the node's uniform draw) -- so the FIRST timer of N fires about a second
+    after the proposals.  That node is the coordinator: Phase1a out, Phase1b back (their arrival order at the coordinator
+    is what the coordinator rule sees), Phase2a out, Phase2b all-to-all; a node decides on the arrival of the
+    (floor(N/2)+1)-th Phase2b.  Nodes that never proposed arm no timer (R/MembershipService.java:347-349) but answer.
+    -> dict(coordinator = index into receivers, start_ms, arrival = Phase1b arrival order (indices into receivers),
+            result = consensus.classic_round_population(...), phase2a_ms, decision_ms[R] (NEVER if undecided))"""
+    from . import consensus as CS
+    receivers = np.asarray(receivers)
+    proposal_ms = np.asarray(proposal_ms, dtype=np.int64)
+    R = len(receivers)
+    voted = proposal_ms != NEVER
+    out = dict(coordinator=-1, start_ms=NEVER, arrival=None, result=None, phase2a_ms=NEVER, decision_ms=np.full(R, NEVER, dtype=np.int64))
+    if not voted.any():
+        return out
+    u = np.asarray(u, dtype=np.float64)
+    jitter = (-1000.0 * np.log(1.0 - u) * n).astype(np.int64)  # (long)(-1000 ln(1-u) / (1/N))
+    fire = np.where(voted, proposal_ms + base_delay_ms + jitter, NEVER)
+    c = int(np.lexsort((receivers, fire))[0])
+    t0 = int(fire[c])
+    node_c = np.full(R, receivers[c])
+    t_1a = t0 + latency.delay(node_c, receivers, n)      # Phase1a reaches acceptor i
+    t_1b = t_1a + latency.delay(receivers, node_c, n)    # its Phase1b reaches the coordinator
+    arrival = np.lexsort((receivers, t_1a, t_1b))        # ties: the acceptor that answered first, then the lower index
+    res = CS.classic_round_population(n, vote_key, voted, arrival)
+    out.update(coordinator=c, start_ms=t0, arrival=arrival, result=res)
+    if not res["decided"]:
+        return out
+    t_2a = int(t_1b[arrival[res["promises_used"] - 1]])  # the promise that completes the coordinator's choice
+    t_acc = t_2a + latency.delay(node_c, receivers, n)   # Phase2a reaches acceptor i, which broadcasts its Phase2b at once
+    need = n // 2 + 1
+    dec = np.empty(R, dtype=np.int64)
+    for a in range(0, R, 256):
+        rx = receivers[a:a + 256]
+        arr = t_acc[None, :] + latency.delay(receivers[None, :], rx[:, None], n)
+        dec[a:a + 256] = np.partition(arr, need - 1, axis=1)[:, need - 1]
+    out.update(phase2a_ms=t_2a, decision_ms=dec)
+    return out

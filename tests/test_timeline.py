@@ -165,3 +165,52 @@ def test_timed_streams_through_the_emulated_tally_kernel():
     receivers = np.flatnonzero(crash == T.NEVER).astype(np.int32)[::3]
     records, rec_off, arrival, arr_off = T.deliver_timed(bs, send, receivers, n, T.LatencyModel())
     _check(records, rec_off, n, K, H, L, cfg, obs, subj, member)
+
+
+def test_classic_round_on_the_time_line():
+    """No fast quorum -> the first recovery timer -> one classic round, with the message delays of the latency model:
+    coordinator, Phase1b arrival order, decided value and every node's decision time equal the restated Paxos.java run
+    message by message on the same time line."""
+    rng = np.random.default_rng(8)
+    compared = 0
+    for trial in range(80):
+        n = int(rng.integers(9, 60))
+        n_live = int(rng.integers(n // 2 + 1, n + 1))
+        receivers = np.sort(rng.choice(n, n_live, replace=False)).astype(np.int32)
+        lat = T.LatencyModel(base_ms=int(rng.integers(1, 4)), jitter_ms=int(rng.integers(0, 9)), seed=trial)
+        values = [(1, 2), (3,), (2, 1)]
+        which = rng.integers(0, len(values), n_live)
+        proposal_ms = np.where(rng.random(n_live) < 0.85, rng.integers(10_000, 10_400, n_live), T.NEVER)
+        if (proposal_ms != T.NEVER).sum() == 0:
+            proposal_ms[0] = 10_000
+        vote_key = (which + 100).astype(np.uint64)
+        u = rng.random(n_live)
+        base = 1000
+        got = T.classic_round_times(proposal_ms, receivers, vote_key, n, lat, base, u)
+        # the same on the oracle: proposals at their times (fast-round votes travel too), every proposer's timer armed
+        delay = lambda s, r: int(lat.delay(np.array([s]), np.array([r]), n)[0])  # noqa: E731
+        net = PX.TimedNetwork(n, [int(r) for r in receivers], 7, delay)
+        fire = {}
+        for i in range(n_live):
+            if proposal_ms[i] != T.NEVER:
+                node = net.nodes[int(receivers[i])]
+                net.at(int(proposal_ms[i]), (lambda node=node, v=values[which[i]]: node.propose(v)))
+                fire[i] = int(proposal_ms[i]) + node.getRandomDelayMs(float(u[i]), base)
+        first = min(fire, key=lambda i: (fire[i], int(receivers[i])))
+        assert first == got["coordinator"] and fire[first] == got["start_ms"]
+        if sorted(fire.values())[1:2] and sorted(fire.values())[1] < got["start_ms"] + 200:
+            continue  # a second timer would fire before the round is over: not the single-coordinator case
+        net.at(fire[first], net.nodes[int(receivers[first])].startClassicPaxosRound)
+        net.run()
+        fast_decided = any(t < fire[first] for t in net.decision_ms.values())
+        if fast_decided:
+            continue  # the fast round had a quorum after all: nothing to recover
+        if not got["result"]["decided"]:
+            assert not net.decisions
+            continue
+        assert len(net.decisions) == n_live and len(set(net.decisions.values())) == 1
+        assert values[which[got["result"]["chosen_acceptor"]]] == next(iter(net.decisions.values()))
+        want = np.array([net.decision_ms[int(r)] for r in receivers])
+        assert np.array_equal(got["decision_ms"], want), (trial, got["decision_ms"][:5], want[:5])
+        compared += 1
+    assert compared >= 40
