@@ -682,14 +682,14 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // here was applied by the reference at a batch end inside a window already certified emission-free, and the
         // certificate's witness (see below) takes no implicit reports, so this cannot be where an emission happens.
 #if RAPID_FAST_WINDOW
-        bool owed_sweep = false;  // fast windows were applied since the last flush: entrants are not in pend[] but in the state
+        bool owed_reports = false;  // fast windows were applied since the last flush: the implicit reports they make possible are owed
         bool repicked = false;    // the early witness has been exchanged for the best one available
 #endif
         auto flush_pending = [&]() {
 #if RAPID_FAST_WINDOW
-            if (!s.seen_down || s.need_full || (s.npend == 0 && !owed_sweep)) return;
+            if (!s.seen_down || s.need_full || (s.npend == 0 && !owed_reports)) return;
 #ifdef RAPID_TRACE
-            if (lane == 0) fprintf(stderr, "F r=%d pos=%d npend=%d sweep=%d\n", r, pos, s.npend, (int)owed_sweep);
+            if (lane == 0) fprintf(stderr, "F r=%d pos=%d npend=%d owed=%d\n", r, pos, s.npend, (int)owed_reports);
 #endif
             wave_lds_fence();
             int applied = 0;
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 (void)invalidate_adj(d, pend, 0, true, nullptr, nullptr, lane, &applied);  // the same pass over the adjacency lists
             }
             s.npend = 0;
-            owed_sweep = false;
+            owed_reports = false;
             n_applied += applied;
 #else
             if (s.npend == 0 || !s.seen_down || s.need_full) return;
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             s.running = run;
             running_exact = s.npend == 0;  // with nothing queued the state here is the reference's
 #if RAPID_FAST_WINDOW
-            running_exact = running_exact && !owed_sweep;
+            running_exact = running_exact && !owed_reports;
             repicked = pos >= kRepickAfter;  // this WAS the sweep for the best witness, unless it came too early to count
 #endif
 #if RAPID_EARLY_CERT
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 counted = true;
                 certified = s.npend == 0 && nX == 0 && (mH == 0ull || (running_exact && s.running - nHc >= 1));
 #if RAPID_FAST_WINDOW
-                certified = certified && !owed_sweep;  // entrants of fast windows are owed their implicit reports too
+                certified = certified && !owed_reports;  // entrants of fast windows are owed their implicit reports too
 #endif
             }
             if (__builtin_expect(!certified || anyE == 0ull || s.npend + nX > kPendCap, 0)) {
@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #pragma unroll
             for (int q = 0; q < kQuarters; ++q)
                 if (__builtin_expect(app[q], 1)) (void)d.or_bits((int)slot[q], rb[q]);
-            owed_sweep = true;
+            owed_reports = true;
             running_exact = false;
 #if RAPID_EARLY_CERT
             below_h = false;
@@ -1297,7 +1297,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 below_h = pot_below_h;
 #endif
 #if RAPID_FAST_WINDOW
-                owed_sweep = false;
+                owed_reports = false;
                 repicked = false;
 #endif
                 restart = false;
@@ -1323,7 +1323,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 below_h = false;
 #endif
 #if RAPID_FAST_WINDOW && defined(RAPID_TRACE)
-                if (owed_sweep && lane == 0) fprintf(stderr, "BUG r=%d pos=%d: implicit reports owed on entry to the careful path\n", r, pos);
+                if (owed_reports && lane == 0) fprintf(stderr, "BUG r=%d pos=%d: implicit reports owed on entry to the careful path\n", r, pos);
 #endif
                 stream_ensure(min(pos + kWave, nrec));
                 RAPID_T0(tc0);
