@@ -28,8 +28,9 @@ sc0 = S.build_scenario(name, subj, cfg, materialise=False)
 rx = sc0.receivers[:: max(1, len(sc0.receivers) // nrx)][:nrx]
 sc = S.build_scenario(name, subj, cfg, receivers=rx)
 t = time.time()
+in_lds = 1 if n <= 20000 else 0  # C4: a 200 KB dictionary does not fit the LDS; the kernel then reads its tables from memory
 emit, nprop, pcount, fpr, props, stats = pyemu.tally(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, force_exact=0,
-                                                    trusted=True, waves=2, grid=1)
+                                                    trusted=True, waves=2, grid=1, tables_in_lds=in_lds)
 fe, fn, fo, fp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=4)
 assert np.array_equal(emit, fe) and np.array_equal(pcount, np.diff(fo)), "emulated kernel and oracle disagree"
 keys = ["exact sub-chunks", "lean windows applied", "full sweeps", "restarts", "implicit reports", "records consumed",
