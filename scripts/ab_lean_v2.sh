@@ -16,8 +16,10 @@ cd "$(dirname "$0")/.."
 declare -A DEFS=( [v2]="-DRAPID_LEAN_V2=1" [hint]="-DRAPID_CAREFUL_HINT=1" [early]="-DRAPID_EARLY_CERT=1"
                   [all]="-DRAPID_LEAN_V2=1 -DRAPID_CAREFUL_HINT=1 -DRAPID_EARLY_CERT=1" [fast]="-DRAPID_FAST_WINDOW=1"
                   [all4]="-DRAPID_LEAN_V2=1 -DRAPID_CAREFUL_HINT=1 -DRAPID_EARLY_CERT=1 -DRAPID_FAST_WINDOW=1" [pairs]="-DRAPID_DMA_PAIRS=1"
-                  [all5]="-DRAPID_LEAN_V2=1 -DRAPID_CAREFUL_HINT=1 -DRAPID_EARLY_CERT=1 -DRAPID_FAST_WINDOW=1 -DRAPID_DMA_PAIRS=1" )
-for v in v2 hint early all fast all4 pairs all5; do
+                  [all5]="-DRAPID_LEAN_V2=1 -DRAPID_CAREFUL_HINT=1 -DRAPID_EARLY_CERT=1 -DRAPID_FAST_WINDOW=1 -DRAPID_DMA_PAIRS=1"
+                  # with cheap windows fewer waves are needed: a deeper ring (15 KiB = 768 records: 10 KiB in flight per wave, 7 waves per CU)
+                  [all5r15]="-DRAPID_LEAN_V2=1 -DRAPID_CAREFUL_HINT=1 -DRAPID_EARLY_CERT=1 -DRAPID_FAST_WINDOW=1 -DRAPID_DMA_PAIRS=1 -DRAPID_RING_SLOTS=15" )
+for v in v2 hint early all fast all4 pairs all5 all5r15; do
     lib="$PWD/rapid_amd/librapid_mi355x_$v.so"
     if [ "${1:-}" = "build" ] || [ ! -f "$lib" ]; then
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC ${DEFS[$v]} -Irapid_amd/csrc \
