@@ -321,9 +321,10 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms);
  * 4: 1 KiB x 8, 5: 1 KiB x 16, 6: 1 KiB x 4; LDS-DMA loads (the tally kernel's path): 7: 1 KiB x 4, 8: 1 KiB x 8,
  * 9: 1 KiB x 6.  `waves` = waves per workgroup (16 waves per CU unless RAPID_PROBE_WAVES_PER_CU says otherwise) */
 int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, int32_t reps, float* ms_avg);
-/* testing / measurement knob, a bit set (0 = normal): 1 = every sub-chunk through the exact sequential path, 8 = careful
- * path only (no lean windows), 64 = never trust the pre-validation of the alert set, 32 = measurement only: stream the
- * records through the LDS ring without tallying them (results are meaningless) */
+/* testing / measurement knob, a bit set (0 = normal): 1 = every window through the exact sequential path, 8 = careful
+ * path only (no cold / fast windows), 64 = never trust the pre-validation of the alert set, 128 = leave the node -> slot
+ * dictionary in memory even when it fits the LDS (the mode of populations too large for it), 32 = measurement only:
+ * stream the records through the registers without tallying them (results are meaningless) */
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);
 
 #ifdef __cplusplus

@@ -345,7 +345,7 @@ int build_round_index(rapid_engine* h) {
     HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof info, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
-    if (info[2] & 1) return fail(h, RAPID_ECAPACITY, "the round has %d hot subjects; at most 16382 are supported", info[0]);
+    if (info[2] & 1) return fail(h, RAPID_ECAPACITY, "the round has %d hot subjects; at most 16318 are supported", info[0]);
     h->trusted = (info[4] & 1) == 0;
     h->all_down = (info[4] & 2) == 0;
     h->n_slots = info[0];
@@ -379,15 +379,18 @@ int build_round_index(rapid_engine* h) {
     // ---- launch geometry: fill the CU's LDS with as many receiver-waves as possible ----
     const int lds_max = 160 * 1024;
     const int per_wave = rapid::tally_wave_bytes(h->n_slots);
-    const int shared = rapid::tally_shared_bytes(N, h->n_hot, h->n_adj);
-    if (per_wave > lds_max)
-        return fail(h, RAPID_ECAPACITY, "%d subjects need %d B of LDS per receiver (max %d)", h->n_slots, per_wave, lds_max);
-    h->tables_in_lds = shared + per_wave + rapid::kBlockStatsBytes <= lds_max;
-    const int sh = h->tables_in_lds ? shared : 0;
-    // Waves per CU: every receiver costs about the same, so the kernel runs ceil(receivers / resident waves) rounds;
-    // a wave is slowed by roughly 4 % per co-resident wave (measured, profiles/), so among the wave counts that fit
-    // the one minimising rounds x slowdown wins -- e.g. 13 rather than 16 waves for 9,492 receivers on 256 CUs
-    // (3 rounds either way).  One workgroup per CU when the shared tables are staged in LDS.
+    const int shared = rapid::tally_shared_bytes(N, h->n_hot, h->n_adj);  // with the node -> slot dictionary staged in LDS
+    const int shared_small = rapid::tally_shared_bytes(0, h->n_hot, h->n_adj);  // dictionary left in memory
+    if (shared_small + per_wave + rapid::kBlockStatsBytes > lds_max)
+        return fail(h, RAPID_ECAPACITY, "%d subjects need %d B of LDS per receiver (max %d)", h->n_slots,
+                    shared_small + per_wave + rapid::kBlockStatsBytes, lds_max);
+    // the dictionary goes to LDS when at least four receivers still fit next to it (bit 7 of the testing knob: never)
+    h->tables_in_lds = shared + 4 * per_wave + rapid::kBlockStatsBytes <= lds_max && (h->force_exact & 128) == 0;
+    const int sh = h->tables_in_lds ? shared : shared_small;
+    // Waves per CU: every receiver costs about the same, so the kernel runs ceil(receivers / resident waves) rounds and
+    // a partial last round leaves wave slots idle; the stream loads of ~8 waves per CU already saturate the memory
+    // system, so among the wave counts that fit the one wasting the fewest wave-slot rounds wins (ties: more waves) --
+    // e.g. 13 rather than 16 waves for 9,492 receivers on 256 CUs (3 rounds either way).  One workgroup per CU.
     int best_w = 1;
     double best_cost = 1e300;
     int w_cap = rapid::kMaxWavesPerBlock;
@@ -395,20 +398,18 @@ int build_round_index(rapid_engine* h) {
     for (int w = 1; w <= w_cap; ++w) {
         const int blk = sh + w * per_wave + rapid::kBlockStatsBytes;
         if (blk > lds_max) break;
-        const int per_cu = std::min(32, (lds_max / blk) * w);
-        const long long resident = (long long)per_cu * h->num_cus;
+        const long long resident = (long long)w * h->num_cus;
         const long long rounds = std::max<long long>(1, (h->n_receivers + resident - 1) / resident);
-        const double cost = (double)rounds * (1.0 + 0.04 * (per_cu - 1));
-        if (cost < best_cost) {
+        const double cost = (double)rounds * w * (w < 8 ? 1.0 + 0.1 * (8 - w) : 1.0);
+        if (cost <= best_cost) {
             best_cost = cost;
             best_w = w;
         }
     }
     h->waves_per_block = best_w;
     h->lds_bytes = sh + best_w * per_wave + rapid::kBlockStatsBytes;
-    const int blocks_per_cu = std::max(1, std::min(32 / best_w, lds_max / h->lds_bytes));
     const long long want = ((long long)h->n_receivers + best_w - 1) / best_w;
-    h->grid_blocks = (int)std::max<long long>(1, std::min<long long>(want, (long long)h->num_cus * blocks_per_cu));
+    h->grid_blocks = (int)std::max<long long>(1, std::min<long long>(want, (long long)h->num_cus));
     h->index_valid = true;
     return RAPID_OK;
 }
@@ -1238,7 +1239,8 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
 
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on) {
     if (!h) return RAPID_EINVAL;
-    h->force_exact = on;  // bit0: exact path only; bits 1-2: profiling ablations (results invalid)
+    if (((h->force_exact ^ on) & 128) != 0) h->index_valid = false;  // the launch geometry depends on where the dictionary lives
+    h->force_exact = on;
     return RAPID_OK;
 }
 

@@ -60,7 +60,7 @@ __global__ void index_slots_kernel(const unsigned int* gmask, const unsigned cha
         }
         info[0] = ah;
         info[1] = ah;
-        info[2] = (ah > 16382) ? 1 : 0;
+        info[2] = (ah > 16318) ? 1 : 0;  // 64 slot numbers are kept for the tally kernel's dummy slots
     }
     __syncthreads();
     int ph = s_hot[t];

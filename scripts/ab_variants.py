@@ -22,8 +22,11 @@ n, K, H, L = spec["n"], spec["K"], spec["H"], spec["L"]
 libs = {"default": os.path.join(ROOT, "rapid_amd", "librapid_mi355x.so")}
 for path in sorted(glob.glob(os.path.join(ROOT, "rapid_amd", "librapid_mi355x_*.so"))):
     tag = os.path.basename(path)[len("librapid_mi355x_"):-3]
-    if tag != "timers":
+    if not tag.startswith("timers"):
         libs[tag] = path
+if os.environ.get("RAPID_AB_ONLY"):  # comma-separated subset of the variants
+    keep = os.environ["RAPID_AB_ONLY"].split(",")
+    libs = {k: v for k, v in libs.items() if k in keep}
 
 
 def use(path):

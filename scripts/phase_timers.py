@@ -25,7 +25,7 @@ runs = reps + 1
 tot = float(s[0])
 info = sim.index_info()
 print("tally_ms", round(ms, 4), info)
-names = ["total", "dma_wait", "lean_window", "careful", "output+init", "flush"]
+names = ["total", "(unused)", "cold+fast windows", "slow windows", "output+init", "flush+sweeps"]
 for i, nm in enumerate(names):
     print("%-12s %6.1f %%   %.0f cycles/receiver" % (nm, 100.0 * float(s[i]) / tot, float(s[i]) / max(1.0, float(s[6]))))
 print("receivers", int(s[6]) // runs, "lean windows/receiver", float(s[7]) / max(1.0, float(s[6])))
@@ -33,17 +33,17 @@ print("receivers", int(s[6]) // runs, "lean windows/receiver", float(s[7]) / max
 sim.tally()
 emit, nprop, pcount, fpw = sim.results()
 cyc = (fpw & np.uint64(0xFFFFFFFF)).astype(np.float64)
-dma = (fpw >> np.uint64(32)).astype(np.float64)
+dma = (fpw >> np.uint64(32)).astype(np.float64)  # flush + sweeps
 careful = nprop.astype(np.float64) * 16
 lean = pcount.astype(np.float64) * 16
 order = np.argsort(cyc)
 print("per-receiver cycles: min %.0f  median %.0f  p90 %.0f  p99 %.0f  max %.0f  sum/1e6 %.1f" % (
     cyc.min(), np.median(cyc), np.percentile(cyc, 90), np.percentile(cyc, 99), cyc.max(), cyc.sum() / 1e6))
 for name, sel in (("slowest 1%", order[-100:]), ("median 1%", order[4950:5050]), ("fastest 1%", order[:100])):
-    print("%-11s total %8.0f  dma_wait %8.0f  lean %8.0f  careful %8.0f  other %8.0f   mean receiver index %.0f" % (
+    print("%-11s total %8.0f  flush+sweep %8.0f  windows %8.0f  slow %8.0f  other %8.0f   mean receiver index %.0f" % (
         name, cyc[sel].mean(), dma[sel].mean(), lean[sel].mean(), careful[sel].mean(),
         (cyc[sel] - dma[sel] - lean[sel] - careful[sel]).mean(), sel.mean()))
 # does the time depend on when (which round) a receiver was processed?
 for lo in range(0, len(cyc), 1000):
     sel = np.arange(lo, min(lo + 1000, len(cyc)))
-    print("receivers %5d.. total %8.0f dma %8.0f lean %8.0f careful %8.0f" % (lo, cyc[sel].mean(), dma[sel].mean(), lean[sel].mean(), careful[sel].mean()))
+    print("receivers %5d.. total %8.0f flush+sweep %8.0f windows %8.0f slow %8.0f" % (lo, cyc[sel].mean(), dma[sel].mean(), lean[sel].mean(), careful[sel].mean()))

@@ -128,8 +128,9 @@ __attribute__((aligned(16))) unsigned char smem[160 * 1024];
 using rapid::smem;
 
 extern "C" {
+int emu_window_records() { return rapid::kWin; }
 int emu_tally_wave_bytes(int n_slots) { return rapid::tally_wave_bytes(n_slots); }
-int emu_tally_shared_bytes(int n_nodes, int n_hot, int n_adj) { return rapid::tally_shared_bytes(n_nodes, n_hot, n_adj); }
+int emu_tally_shared_bytes(int n_dict, int n_hot, int n_adj) { return rapid::tally_shared_bytes(n_dict, n_hot, n_adj); }
 
 // Runs the population kernel: `grid` persistent workgroups of `waves` waves, one workgroup at a time.
 int emu_tally_run(const unsigned char* records, unsigned long long records_bytes, const long long* rec_off,
@@ -138,7 +139,7 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
                   const unsigned int* adj, int n_hot, int n_adj, int* emit_batch, int* num_proposals,
                   int* prop_count, unsigned long long* fingerprint, int* props, int prop_cap, unsigned long long* stats,
                   int flags, int waves, int grid, int tables_in_lds, unsigned long long seed) {
-    const int lds = (tables_in_lds ? rapid::tally_shared_bytes(n_nodes, n_hot, n_adj) : 0) + waves * rapid::tally_wave_bytes(n_hot) +
+    const int lds = rapid::tally_shared_bytes(tables_in_lds ? n_nodes : 0, n_hot, n_adj) + waves * rapid::tally_wave_bytes(n_hot) +
                     rapid::kBlockStatsBytes;
     if (lds > (int)sizeof(smem)) return -5;
     rapid::TallyParams p;

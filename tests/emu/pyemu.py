@@ -13,10 +13,15 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        variant = os.environ.get("RAPID_EMU_VARIANT", "")  # "v2": the kernel built with -DRAPID_LEAN_V2=1
+        variant = os.environ.get("RAPID_EMU_VARIANT", "")  # "q1" / "q2": smaller windows; "ubsan": sanitizer build
         subprocess.check_call(["make", "-C", _HERE, "-s", "VARIANT=" + variant], stderr=subprocess.DEVNULL)
         _LIB = C.CDLL(os.path.join(_HERE, "_build", "libtally_emu%s.so" % ("_" + variant if variant else "")))
     return _LIB
+
+
+def window_records():
+    """Records per window of the emulated build (RAPID_QUARTERS x 64)."""
+    return int(lib().emu_window_records())
 
 
 def build_round_index(records, n_nodes, K, L, obs, member):
@@ -31,7 +36,7 @@ def build_round_index(records, n_nodes, K, L, obs, member):
     hot_nodes = np.flatnonzero(pop >= L)
     node_of_slot = hot_nodes.astype(np.int32)
     n_hot = len(hot_nodes)
-    assert n_hot <= 16382
+    assert n_hot <= 16318
     slot_of = np.full(n_nodes, 0x3FFF, dtype=np.int64)
     slot_of[node_of_slot] = np.arange(n_hot)
     lists = [[] for _ in range(n_hot)]

@@ -1,0 +1,26 @@
+// TEST INFRASTRUCTURE ONLY: CPU model of rapid_amd/csrc/stream_load.h for the SIMT emulator -- a bounds-checked read
+// (out of range: zeros, as the buffer resource of the device gives).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rapid {
+
+struct stream_rsrc_t {
+    const unsigned char* base;
+    unsigned int bytes;
+};
+
+inline stream_rsrc_t stream_make_rsrc(const void* base, unsigned int bytes) {
+    return stream_rsrc_t{static_cast<const unsigned char*>(base), bytes};
+}
+
+inline void stream_load2(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int imm, unsigned int& a, unsigned int& b) {
+    const unsigned long long off = (unsigned long long)lane_off + (unsigned long long)imm;
+    a = 0u;
+    b = 0u;
+    // the hardware checks every dword on its own
+    if (rsrc.base != nullptr && off + 4ull <= rsrc.bytes) std::memcpy(&a, rsrc.base + off, 4);
+    if (rsrc.base != nullptr && off + 8ull <= rsrc.bytes) std::memcpy(&b, rsrc.base + off + 4, 4);
+}
+
+}  // namespace rapid

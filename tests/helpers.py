@@ -44,3 +44,36 @@ def random_stream(rng, n_nodes, K, member, cfg_id, n_rec, hot, p_bad_cfg=0.05, p
 
 def props_list(poff, props, r):
     return props[poff[r]: poff[r + 1]].tolist()
+
+
+_M64 = (1 << 64) - 1
+
+
+def _mix64(x):
+    """splitmix64 finaliser, as rapid::mix64 in csrc/tally_kernel.h."""
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def proposal_fingerprints(poff, props, emitted):
+    """The kernel's per-receiver proposal fingerprint restated on the host (sum of mix64(node) + mix64(0x5EED + count),
+    0 reserved for "no proposal"), computed from the ORACLE's proposal lists: comparing the whole array with the
+    device's checks every receiver's proposal contents at full size."""
+    R = len(poff) - 1
+    out = np.zeros(R, dtype=np.uint64)
+    props = np.asarray(props, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = props + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+        csum = np.concatenate([[np.uint64(0)], np.cumsum(x, dtype=np.uint64)])
+        for r in range(R):
+            if not emitted[r]:
+                continue
+            cnt = int(poff[r + 1] - poff[r])
+            v = (int(csum[poff[r + 1]]) - int(csum[poff[r]]) + _mix64(0x5EED + cnt)) & _M64
+            out[r] = v if v != 0 else 1
+    return out

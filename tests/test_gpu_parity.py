@@ -7,7 +7,7 @@ import pytest
 
 from oracle import pyoracle as O
 from rapid_amd import scenarios as S
-from tests.helpers import oracle_view, props_list, random_stream
+from tests.helpers import oracle_view, proposal_fingerprints, props_list, random_stream
 
 pytestmark = pytest.mark.gpu
 
@@ -372,6 +372,10 @@ def test_population_scenarios_vs_faithful_oracle(E, name, n, f, K, H, L):
     oracle_out = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, np.concatenate(parts), sub_off, nthreads=8)
     key0 = [oview.ringKey(0, i) for i in range(n)]
     sim, res = run_population(E, eng, sc.records, sc.rec_off)
+    st = sim.stats()  # the engine's counters: read before the next run on this engine resets them
+    assert st["records_consumed"] <= len(sc.records)
+    if np.diff(sc.rec_off).max() >= 3 * 256:  # streams of several windows: the cold / fast windows were exercised
+        assert st["lean_windows"] > 0
     # same round with the distinct alert set declared (index + validation from the set, kTrusted tally) and with the
     # per-delivery filter forced on (knob 64): identical results
     for kw in (dict(alert_set=sc.batches.recs), dict(force_exact=64), dict(force_exact=8)):
@@ -383,8 +387,6 @@ def test_population_scenarios_vs_faithful_oracle(E, name, n, f, K, H, L):
         def proposal(self, i):
             return sim.proposal(int(rx[i]))
     assert_matches(Sub(), sub, oracle_out, key0, sample=range(0, len(rx), 5))
-    st = sim.stats()
-    assert st["records_consumed"] <= len(sc.records) and st["lean_windows"] > 0 or n <= 50
     # every receiver against the optimised CPU formulation
     fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=8)
     assert np.array_equal(res[0], fe) and np.array_equal(res[1], fn) and np.array_equal(res[2], np.diff(fo))
@@ -568,8 +570,21 @@ def test_full_size_c3_against_fast_oracle(E):
         fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=8)
         sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off)
         assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
+        # the proposal CONTENTS of every receiver: the kernel's fingerprint restated on the host over the oracle's lists
+        assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
         for r in range(0, len(fe), 97):
             assert sorted(sim.proposal(r)) == fpp[fo[r]:fo[r + 1]].tolist()
+        # ... and the faithful restatement of the Java (quadratic: a sample of >= 200 receivers) on the same streams
+        rx = np.arange(0, len(fe), len(fe) // 210)
+        sub_off = np.zeros(len(rx) + 1, dtype=np.int64)
+        parts = []
+        for i, r in enumerate(rx):
+            parts.append(sc.records[sc.rec_off[r]:sc.rec_off[r + 1]])
+            sub_off[i + 1] = sub_off[i] + len(parts[-1])
+        reg, oview = oracle_view(pop, K)
+        oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, np.concatenate(parts), sub_off, nthreads=32)
+        assert len(rx) >= 200 and np.array_equal(emit[rx], oe) and np.array_equal(nprop[rx], on)
+        assert np.array_equal(pcount[rx], np.diff(oo)) and np.array_equal(fp[rx], proposal_fingerprints(oo, op, oe >= 0))
         rr = sim.count_votes()
         if name == "C3a":
             assert rr.decided == 0  # healthy subjects stuck in [L, H) block every proposal
@@ -579,7 +594,11 @@ def test_full_size_c3_against_fast_oracle(E):
             recs2, off2, _ = S.deliver(sc.batches, sc.receivers[::4], 12345)
             sim.load_streams(recs2, off2)
             rr2, _ = sim.round(apply=False)
-            assert rr2.votes_winner > 0 and sorted(sim.proposal(0)) in (sc.faulty.tolist(), sorted(sim.proposal(0)))
+            assert rr2.decided == 1 and sorted(sim.decided_cut()) == sc.faulty.tolist()
+            emit2, nprop2, pcount2, fp2 = sim.results()
+            want_fp = proposal_fingerprints(np.array([0, len(sc.faulty)]), sc.faulty, [True])[0]
+            assert np.all(emit2 >= 0) and np.all(pcount2 == len(sc.faulty)) and np.all(fp2 == want_fp)  # every receiver proposes exactly the fault set
+            assert sorted(sim.proposal(0)) == sc.faulty.tolist() and sorted(sim.proposal(len(emit2) - 1)) == sc.faulty.tolist()
 
 
 def test_classic_round_recovers_a_population_without_fast_quorum(E):

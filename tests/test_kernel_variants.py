@@ -1,6 +1,7 @@
-"""The prepared compile-time variants of the tally kernel (RAPID_LEAN_V2, RAPID_CAREFUL_HINT, RAPID_EARLY_CERT,
-RAPID_FAST_WINDOW, RAPID_DMA_PAIRS; csrc/tally_kernel.h, scripts/ab_lean_v2.sh) must keep producing the oracle's results: the emulated
-kernel tests are re-run on the combined builds in a child process (the emulator library is chosen once per process)."""
+"""The tally kernel's window size is a compile-time constant (RAPID_QUARTERS x 64 records, csrc/tally_kernel.h); the
+small populations of the emulated tests hold only a few hundred records per receiver, so the emulated kernel tests are
+re-run on builds with 64- and 128-record windows (every stream then spans many cold / fast / slow windows and carries) and
+on the sanitizer build, in a child process (the emulator library is chosen once per process)."""
 import os
 import subprocess
 import sys
@@ -10,11 +11,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("variant", ["all", "all5"])
+@pytest.mark.parametrize("variant", ["q1", "q2", "ubsan"])
 def test_emulated_kernel_tests_on_variant(variant):
     env = {**os.environ, "RAPID_EMU_VARIANT": variant}
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernel_emulated.py", "-x", "-q", "-p", "no:cacheprovider",
-                        "-k", "scenarios or churn or unaligned or adversarial"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernel_emulated.py", "-x", "-q", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
