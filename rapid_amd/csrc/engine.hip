@@ -387,21 +387,22 @@ int build_round_index(rapid_engine* h) {
     // the dictionary goes to LDS when at least four receivers still fit next to it (bit 7 of the testing knob: never)
     h->tables_in_lds = shared + 4 * per_wave + rapid::kBlockStatsBytes <= lds_max && (h->force_exact & 128) == 0;
     const int sh = h->tables_in_lds ? shared : shared_small;
-    // Waves per CU: every receiver costs about the same, so the kernel runs ceil(receivers / resident waves) rounds and
-    // a partial last round leaves wave slots idle; the stream loads of ~8 waves per CU already saturate the memory
-    // system, so among the wave counts that fit the one wasting the fewest wave-slot rounds wins (ties: more waves) --
-    // e.g. 13 rather than 16 waves for 9,492 receivers on 256 CUs (3 rounds either way).  One workgroup per CU.
+    // Waves per CU (one workgroup per CU, its receivers claimed by its waves from a counter in LDS).  A CU's share of
+    // the memory system is saturated by the stream loads of ~7 waves; with w waves a CU works through its n receivers in
+    // floor(n / w) full rounds, each as long as w streams sharing the CU's bandwidth, plus a last round of the m
+    // remaining receivers that is never shorter than what ~7 streams would take (fewer waves do not stream faster).
+    // Among the wave counts that fit, the one with the smallest total wins (ties: more waves) -- e.g. 13 rather than 16
+    // waves for 9,492 receivers on 256 CUs (2 x 13 + 11 instead of 2 x 16 + 5 -> 2 x 16 + 7).
     int best_w = 1;
     double best_cost = 1e300;
     int w_cap = rapid::kMaxWavesPerBlock;
     if (const char* e = getenv("RAPID_TALLY_WAVES")) w_cap = std::max(1, std::min(w_cap, atoi(e)));  // profiling knob
+    const double n_per_cu = (double)h->n_receivers / (double)std::max(1, h->num_cus), sat = 7.0;
     for (int w = 1; w <= w_cap; ++w) {
-        const int blk = sh + w * per_wave + rapid::kBlockStatsBytes;
-        if (blk > lds_max) break;
-        const long long resident = (long long)w * h->num_cus;
-        const long long rounds = std::max<long long>(1, (h->n_receivers + resident - 1) / resident);
-        const double cost = (double)rounds * w * (w < 8 ? 1.0 + 0.1 * (8 - w) : 1.0);
-        if (cost <= best_cost) {
+        if (sh + w * per_wave + rapid::kBlockStatsBytes > lds_max) break;
+        const double full = std::floor(n_per_cu / w), rem = n_per_cu - full * w;
+        const double cost = full * std::max((double)w, sat) + (rem > 0.0 ? std::max(rem, sat) : 0.0);
+        if (cost <= best_cost + 1e-9) {
             best_cost = cost;
             best_w = w;
         }
@@ -439,7 +440,7 @@ int launch_tally(rapid_engine* h) {
     p.prop_cap = h->max_cut;
     p.stats = h->d_stats.p;  // [grid_blocks][8]
     p.waves_per_block = h->waves_per_block;
-    p.flags = h->force_exact & (1 | 8 | 32);
+    p.flags = h->force_exact & (1 | 4 | 8 | 16 | 32);
     const dim3 grid((unsigned)h->grid_blocks), block((unsigned)h->waves_per_block * 64u);
     const bool trusted = h->trusted && (h->force_exact & 64) == 0;  // bit6 of the testing knob: never trust
     if (h->tables_in_lds && trusted)

@@ -1,14 +1,26 @@
-// The tally kernel's record stream: bounds-checked buffer loads straight into registers.
+// The tally kernel's record stream: bounds-checked buffer loads straight into registers -- and why the kernel's STORES
+// are issued from inline assembly.
 //
 // A receiver's delivered stream is a raw buffer (base = its first record, size = 20 B x its record count); lane l of
 // "quarter" q of a window reads the dwords it needs of record 64 q + l with ONE wave instruction per quarter
 // (buffer_load_dwordx2 ... offen nt, lane stride 20 B: the 64 lanes cover 1,280 contiguous bytes, so every cache line
 // the instruction touches is used completely by it and its neighbours).  Reads past the end of the stream return
 // zeros without touching memory -- a zero record names no ring, closes no batch and is not a DOWN report, so the
-// tail of the last window needs no special case.  The loads are ordinary compiler-visible loads: the compiler's own
-// s_waitcnt bookkeeping lets a whole window stay in flight while the previous one is tallied.
+// tail of the last window needs no special case.
 //
-// tests/emu/ shadows this header with plain bounds-checked reads.
+// The loads are ordinary compiler-visible loads, so the register allocation around them is the compiler's business and
+// correct by construction; the next window is requested before the current one is tallied, and the compiler's
+// wait-count pass inserts s_waitcnt vmcnt(N) with N = the loads issued since.  That pass only counts precisely while
+// every vector-memory operation it knows to be outstanding is a load: on gfx9-family targets loads and stores share the
+// vmcnt counter, and as soon as a store may be outstanding anywhere around the loop (the per-receiver results) it stops
+// trusting the order of completion and waits with vmcnt(0) -- i.e. for the window it has just requested -- before it
+// touches the previous one (measured: tallying and streaming did not overlap at all, and idle time between receivers
+// was fully additive).  So the results are stored from inline assembly (stream_store*): fire-and-forget instructions the
+// pass does not see.  They only make its waits longer than necessary (the hardware counter includes them), never
+// shorter: loads return in issue order, so "at most N operations outstanding" still means every load older than the N
+// youngest loads has landed.
+//
+// tests/emu/ shadows this header with plain bounds-checked reads and plain stores.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,6 +41,19 @@ __device__ __forceinline__ void stream_load2(stream_rsrc_t rsrc, unsigned int la
     const stream_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_off, (int)imm, 2);
     a = v.x;
     b = v.y;
+}
+
+// A 64-bit word of a read-only table at a wave-uniform address, through the scalar cache (s_load, counted by lgkmcnt):
+// a vector load here would put a long-lived destination register into the window loop, and the wait-count pass then
+// waits for everything before each write of a register that MAY still be the target of that load.
+__device__ __forceinline__ long long stream_scalar_load(const long long* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) long long*>(reinterpret_cast<unsigned long long>(p));
+}
+
+// Stores the wait-count pass does not see (see above).  The address is per lane; inactive lanes store nothing.
+__device__ __forceinline__ void stream_store(int* p, int v) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void stream_store(unsigned long long* p, unsigned long long v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
 }  // namespace rapid

@@ -56,10 +56,11 @@ constexpr int kRecBytes = 20;
 constexpr int kQ = RAPID_QUARTERS;        // quarters (64 records each) per window
 constexpr int kWin = kQ * kWave;          // 256 records = 5 KiB of stream per window
 constexpr int kQuarterBytes = kWave * kRecBytes;
-static_assert(kQ >= 1 && (kQ - 1) * kQuarterBytes + 12 < 4096, "quarter offsets must fit the load's immediate");
+static_assert(kQ >= 1 && kQ <= 16, "window size");
 constexpr int kScratchWords = (kQ + 1) * kWave;  // carried quarter + window, one decoded word per record
 constexpr int kUndoCap = 128;                    // implicit bits set inside one careful sub-chunk
 constexpr int kCand = 4;                         // witness candidates kept from one sweep
+constexpr int kClaimAhead = 3;                   // windows before the end of a stream at which the next receiver is claimed
 constexpr int kDummySlots = 64;                  // slots n_hot .. n_hot + 63: where reports about subjects that are not hot go
 constexpr int kMaxWavesPerBlock = 16;
 constexpr uint32_t kFlushed = 1u << 14;
@@ -115,7 +116,7 @@ __host__ __device__ inline int tally_shared_bytes(int n_dict, int n_hot, int n_a
     return align16(n_dict * 2) + align16((n_adj / 2 + 1) * 4) + align16((n_hot + kDummySlots) * 2) + align16(n_hot * 4);
 }
 // per-workgroup statistics accumulator at the very end of the dynamic LDS segment
-constexpr int kBlockStatsBytes = 64;
+constexpr int kBlockStatsBytes = 80;  // eight counters + the workgroup's claim counter
 __host__ __device__ inline int tally_wave_bytes(int n_slots) {
     return align16((n_slots + kDummySlots) * 4) + kScratchWords * 4 + kUndoCap * 4;
 }
@@ -426,7 +427,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // 0.13 ms of a 0.63 ms kernel, and every stream that crosses that channel waits with them.
     unsigned long long* const block_stats =
         reinterpret_cast<unsigned long long*>(smem + shared_bytes + (int)(blockDim.x >> 6) * tally_wave_bytes(n_hot));
+    unsigned int* const block_claims = reinterpret_cast<unsigned int*>(block_stats + 8);  // receivers claimed by this workgroup
     if (threadIdx.x < 8u) block_stats[threadIdx.x] = 0ull;
+    if (threadIdx.x == 8u) *block_claims = blockDim.x >> 6;  // claims 0 .. waves - 1 are the first deal
     __syncthreads();
 
     // ---- this wave's private LDS ----
@@ -471,15 +474,18 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #pragma unroll
         for (int q = 0; q < kQ; ++q) {
             stream_load2(rsrc, voff, (unsigned int)(q * kQuarterBytes + 12), W.w3[q], W.w4[q]);
-            if (!kTrusted) stream_load2(rsrc, voff, (unsigned int)(q * kQuarterBytes), W.w0[q], W.w1[q]);
+            if (!kTrusted) stream_load2(rsrc, voff, (unsigned int)(q * kQuarterBytes), W.w0[kTrusted ? 0 : q], W.w1[kTrusted ? 0 : q]);
         }
     };
-    auto make_stream = [&](int rr) -> Stream {
-        const long long rec0 = p.rec_off[rr], rec1 = p.rec_off[rr + 1];
+    auto make_stream = [&](long long rec0, long long rec1) -> Stream {
         Stream st;
         st.base = p.records + (unsigned long long)rec0 * kRecBytes;
         st.bytes = (unsigned int)((rec1 - rec0) * kRecBytes);
         return st;
+    };
+    auto uniform64 = [&](long long v) -> long long {  // a vector load of a wave-uniform address: back into SGPRs
+        return (long long)(((unsigned long long)uniform((unsigned int)((unsigned long long)v >> 32)) << 32) |
+                           (unsigned long long)uniform((unsigned int)(unsigned long long)v));
     };
 
     // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot for record (q, lane) of a window, branch-free.
@@ -523,20 +529,28 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         return (hot ? r.bits : 0u) | ((hot ? r.slot : 0u) << 14) | (r.down ? kDecDown : 0u) | (eob ? kDecEob : 0u);
     };
 
-    // Receivers are dealt round-robin: wave g of G takes receivers g, g + G, g + 2 G ...  Every receiver of a round costs
-    // about the same (they all see the same alerts), so a shared work counter would balance nothing -- but thousands of
-    // waves hitting one counter at the same moment queue up behind each other (measured: ~15 us per receiver waiting
-    // for the atomic).  Wave-major numbering: consecutive receivers go to different CUs, so a partial last round still
-    // uses every CU.
-    const int wave_global = uniform(wave * (int)gridDim.x + (int)blockIdx.x), waves_total = (int)gridDim.x * (int)(blockDim.x >> 6);
-    int r = wave_global;
-    Win W;
+    // Receivers are dealt to WORKGROUPS statically (workgroup b of G takes receivers b, b + G, b + 2 G ...: consecutive
+    // receivers go to different CUs) and claimed by the workgroup's waves from a counter in LDS: all receivers of a
+    // round cost the same, but the waves do not run equally fast (a wave's share of the memory system varies by ~ +-15 %),
+    // and a workgroup ends with its slowest wave.  No word of global memory is touched by every wave of the launch: a
+    // global work counter was measured twice (round 1: ~15 us per receiver; round 2, claims spread over time and issued
+    // four windows ahead: kernel 0.353 -> 0.386 ms) -- the claims queue up in one L2 channel, and every stream that
+    // crosses that channel waits with them.
+    const int n_blocks = (int)gridDim.x;
+    int r = uniform(wave * n_blocks + (int)blockIdx.x);  // the first deal: claim number `wave` of this workgroup
+    Win W;  // the window in flight
     Stream rsrc;
     rsrc.base = p.records;
     rsrc.bytes = 0u;
     const unsigned int lane20 = (unsigned int)lane * (unsigned int)kRecBytes;
+    if ((p.flags & 16) != 0 && (wave & 1) != 0) {  // measurement aid: every other wave starts half a receiver late
+        for (int i = 0; i < 15; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    int nrec = 0;
     if (r < p.n_receivers) {
-        rsrc = make_stream(r);
+        const long long rec0 = stream_scalar_load(p.rec_off + r), rec1 = stream_scalar_load(p.rec_off + r + 1);
+        nrec = (int)(rec1 - rec0);
+        rsrc = make_stream(rec0, rec1);
         load_window(rsrc, lane20, W);
     }
     while (r < p.n_receivers) {
@@ -544,9 +558,23 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         const unsigned long long t_rx0 = __builtin_amdgcn_s_memtime();
         const unsigned long long t_lean0 = t_lean, t_careful0 = t_careful, t_flush0 = t_flush;
 #endif
-        const int nrec = uniform((int)(p.rec_off[r + 1] - p.rec_off[r]));  // a vector load of a wave-uniform address: back into an SGPR
         const int nwin = (nrec + kWin - 1) / kWin;
-        const int r_next = r + waves_total;
+        // The next receiver is claimed a few windows before the end of this one's stream, and the bounds of its stream are
+        // loaded right then: both answers arrive with the stream's last windows instead of costing two memory round trips
+        // between two receivers.
+        int r_next = p.n_receivers;
+        long long next0 = 0, next1 = 0;
+        bool claimed = false;
+        auto claim = [&]() {
+            claimed = true;
+            unsigned int v = 0u;
+            if (lane == 0) v = atomicAdd(block_claims, 1u);
+            r_next = (int)uniform(v) * n_blocks + (int)blockIdx.x;
+            if (r_next < p.n_receivers) {  // scalar loads: no vector register waits for them inside the window loop
+                next0 = stream_scalar_load(p.rec_off + r_next);
+                next1 = stream_scalar_load(p.rec_off + r_next + 1);
+            }
+        };
 
         int emit_batch = -1;
         RxScalars s;
@@ -990,6 +1018,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 const Win cur = W;
                 voff += (unsigned int)(kWin * kRecBytes);
                 load_window(rsrc, voff, W);  // the next window is in flight while this one is tallied
+                if (!claimed && w + kClaimAhead >= nwin) claim();
                 if ((p.flags & 32) != 0) {  // measurement aid: stream the records through the registers without tallying them
 #pragma unroll
                     for (int q = 0; q < kQ; ++q) sink ^= cur.w3[q] ^ cur.w4[q] ^ (kTrusted ? 0u : cur.w0[kTrusted ? 0 : q] ^ cur.w1[kTrusted ? 0 : q]);
@@ -1025,9 +1054,16 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             if (!restart) break;
         }
         RAPID_T0(to0);
+        if ((p.flags & 4) != 0) {  // measurement aid: ~35 k idle cycles between two receivers (what C3b's end phase costs)
+            for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+        if (!claimed) claim();
         // start the next receiver's stream now; its first window lands while this receiver's results are written
+        int nrec_next = 0;
         if (r_next < p.n_receivers) {
-            rsrc = make_stream(r_next);
+            const long long rec0 = next0, rec1 = next1;
+            nrec_next = (int)(rec1 - rec0);
+            rsrc = make_stream(rec0, rec1);
             load_window(rsrc, lane20, W);
         }
 
@@ -1044,7 +1080,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 const int idx = count + __popcll(mk & lanes_lt(lane));
                 if (take) {
                     const int node = node_of_slot[i];
-                    if (idx < p.prop_cap) out[idx] = node;
+                    if (idx < p.prop_cap) stream_store(out + idx, node);
                     fp += mix64((unsigned long long)node);
                 }
                 count += __popcll(mk);
@@ -1053,20 +1089,22 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             if (fp == 0) fp = 1;
         }
         if (lane == 0) {
-            p.emit_batch[r] = emit_batch;
-            p.num_proposals[r] = s.proposal_count;
-            p.prop_count[r] = count > p.prop_cap ? -1 : count;
-#ifdef RAPID_PHASE_TIMERS
-            // profiling build: cycles spent on this receiver, in total and per phase
-            p.fingerprint[r] = ((__builtin_amdgcn_s_memtime() - t_rx0) & 0xFFFFFFFFull) | ((t_flush - t_flush0) << 32);
-            p.num_proposals[r] = (int)((t_careful - t_careful0) >> 4);
-            p.prop_count[r] = (int)((t_lean - t_lean0) >> 4);
+#ifndef RAPID_PHASE_TIMERS
+            stream_store(p.emit_batch + r, emit_batch);
+            stream_store(p.num_proposals + r, s.proposal_count);
+            stream_store(p.prop_count + r, count > p.prop_cap ? -1 : count);
+            stream_store(p.fingerprint + r, fp);
 #else
-            p.fingerprint[r] = fp;
+            stream_store(p.emit_batch + r, emit_batch);
+            // profiling build: cycles spent on this receiver, in total and per phase
+            stream_store(p.fingerprint + r, ((__builtin_amdgcn_s_memtime() - t_rx0) & 0xFFFFFFFFull) | ((t_flush - t_flush0) << 32));
+            stream_store(p.num_proposals + r, (int)((t_careful - t_careful0) >> 4));
+            stream_store(p.prop_count + r, (int)((t_lean - t_lean0) >> 4));
 #endif
         }
         wave_lds_fence();
         r = r_next;
+        nrec = nrec_next;
         RAPID_T1(t_out, to0);
 #ifdef RAPID_PHASE_TIMERS
         t_rx++;

@@ -1,6 +1,6 @@
 """Event counts of the tally kernel on the REAL streams of a BASELINE configuration, without a GPU: a sample of receivers
-at full size through the SIMT emulator (tests/emu), checked against the oracle.  What it prints per receiver -- lean
-windows applied / rolled back, careful sub-chunks, exact replays, implicit reports -- is what the kernel does on the
+at full size through the SIMT emulator (tests/emu), checked against the oracle.  What it prints per receiver -- cold / fast
+windows applied, windows that went the slow way, sweeps, careful sub-chunks, exact replays, implicit reports -- is what the kernel does on the
 device for the same streams (the counters of rapid_sim_stats), so changes to the certificates or to the careful path
 can be evaluated before a GPU session.   python scripts/emu_counts.py [config] [receivers]   RAPID_EMU_VARIANT=all ...
 """
@@ -33,8 +33,8 @@ emit, nprop, pcount, fpr, props, stats = pyemu.tally(sc.records, sc.rec_off, n, 
                                                     trusted=True, waves=2, grid=1, tables_in_lds=in_lds)
 fe, fn, fo, fp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=4)
 assert np.array_equal(emit, fe) and np.array_equal(pcount, np.diff(fo)), "emulated kernel and oracle disagree"
-keys = ["exact sub-chunks", "lean windows applied", "full sweeps", "restarts", "implicit reports", "records consumed",
-        "lean windows rolled back", "careful sub-chunks"]
+keys = ["exact sub-chunks", "cold + fast windows", "sweeps of the hot slots", "restarts", "implicit reports", "records consumed",
+        "windows that went slow", "careful sub-chunks"]
 print("%s, variant %r: %d receivers, %d records, emulated in %.1f s, results equal to the oracle" %
       (name, os.environ.get("RAPID_EMU_VARIANT", ""), len(rx), len(sc.records), time.time() - t))
 for k, v in zip(keys, stats):

@@ -28,6 +28,8 @@ for w in waves:
     info = sim.index_info()
     sim.set_force_exact(32)
     so = min(sim.time_tally(reps) for _ in range(2))
+    sim.set_force_exact(16)
+    stag = min(sim.time_tally(reps) for _ in range(2))
     sim.set_force_exact(0)
-    print("waves/workgroup %2d (asked %2d)  tally %.4f ms  %.0f GB/s  %.1f %% of 8 TB/s   stream only %.4f ms %.0f GB/s" % (
-        info["waves_per_workgroup"], w, ms, nbytes / ms / 1e6, 100 * nbytes / ms / 1e6 / 8000, so, nbytes / so / 1e6), flush=True)
+    print("waves/workgroup %2d (asked %2d)  tally %.4f ms  %.0f GB/s  %.1f %% of 8 TB/s   stream only %.4f ms %.0f GB/s  staggered start %.4f ms" % (
+        info["waves_per_workgroup"], w, ms, nbytes / ms / 1e6, 100 * nbytes / ms / 1e6 / 8000, so, nbytes / so / 1e6, stag), flush=True)

@@ -96,6 +96,7 @@ inline unsigned int __builtin_amdgcn_mbcnt_hi(unsigned int m, unsigned int add) 
 }
 inline void __builtin_amdgcn_wave_barrier() { (void)emu::park(emu::OP_WAVE_SYNC, 0, 0); }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))

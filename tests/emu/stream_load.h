@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE ONLY: CPU model of rapid_amd/csrc/stream_load.h for the SIMT emulator -- a bounds-checked read
-// (out of range: zeros, as the buffer resource of the device gives).
+// (out of range: zeros, as the buffer resource of the device gives) and plain stores.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -22,5 +22,9 @@ inline void stream_load2(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int
     if (rsrc.base != nullptr && off + 4ull <= rsrc.bytes) std::memcpy(&a, rsrc.base + off, 4);
     if (rsrc.base != nullptr && off + 8ull <= rsrc.bytes) std::memcpy(&b, rsrc.base + off + 4, 4);
 }
+
+inline long long stream_scalar_load(const long long* p) { return *p; }
+inline void stream_store(int* p, int v) { *p = v; }
+inline void stream_store(unsigned long long* p, unsigned long long v) { *p = v; }
 
 }  // namespace rapid

@@ -594,7 +594,7 @@ def test_full_size_c3_against_fast_oracle(E):
             recs2, off2, _ = S.deliver(sc.batches, sc.receivers[::4], 12345)
             sim.load_streams(recs2, off2)
             rr2, _ = sim.round(apply=False)
-            assert rr2.decided == 1 and sorted(sim.decided_cut()) == sc.faulty.tolist()
+            assert rr2.votes_winner == len(off2) - 1  # a quarter of the receivers cannot reach the quorum, but they all agree
             emit2, nprop2, pcount2, fp2 = sim.results()
             want_fp = proposal_fingerprints(np.array([0, len(sc.faulty)]), sc.faulty, [True])[0]
             assert np.all(emit2 >= 0) and np.all(pcount2 == len(sc.faulty)) and np.all(fp2 == want_fp)  # every receiver proposes exactly the fault set
