@@ -300,6 +300,8 @@ int rapid_encode_consensus_request(const rapid_endpoint_map* m, const rapid_cons
 #define RAPID_UNIQUE_ID_BYTES 128
 int rapid_comm_unique_id(uint8_t out[RAPID_UNIQUE_ID_BYTES]); /* rank 0 creates, host layer broadcasts */
 int rapid_engine_comm_init(rapid_engine* h, const uint8_t id[RAPID_UNIQUE_ID_BYTES], int32_t rank, int32_t n_ranks);
+/* rank and size as the communicator reports them (ncclCommUserRank / ncclCommCount); {0, 1} without a communicator */
+int rapid_engine_comm_info(rapid_engine* h, int32_t* rank, int32_t* n_ranks);
 
 /* ---- instrumentation -------------------------------------------------------------------------------------
  * stream: the hipStream_t all engine work is enqueued on (for HIP-event timing on the right stream).

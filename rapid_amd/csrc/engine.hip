@@ -125,7 +125,7 @@ struct rapid_engine {
     int num_cus = 256;
 
     // ---- votes ----
-    DevBuf<unsigned long long> d_hist, d_winner, d_mm, d_mismatch;
+    DevBuf<unsigned long long> d_hist, d_winner, d_mm, d_mismatch, d_voteback;
     DevBuf<int> d_ref;
     std::vector<int> decided_cut;  // ring-0 order
     bool have_decision = false;
@@ -535,7 +535,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
     h->d_alert_set.release(); h->d_next.release(); h->d_gmask.release(); h->d_adj.release(); h->d_dict.release();
     h->d_adj_off.release(); h->d_node_of_slot.release(); h->d_deg.release(); h->d_cursor.release(); h->d_info.release();
-    h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release();
+    h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release(); h->d_voteback.release();
     delete h;
 }
 
@@ -969,52 +969,75 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
     const int R = h->n_receivers;
     const size_t HB = (size_t)rapid::kVoteBuckets + 2;
     const size_t ref_len = (size_t)h->max_cut + 1;
+    // One device buffer for everything the host reads back: res[8] = {winning bucket, its votes, voters, non-empty buckets,
+    // max fingerprint, max ~fingerprint, mismatching voters, verified voters}, then ref[1 + max_cut]; one pinned copy of it.
+    const size_t res_words = 8;
+    const size_t back_bytes = res_words * 8 + ref_len * sizeof(int);
     HIPCHK(h, h->d_hist.ensure(HB));
     HIPCHK(h, h->d_winner.ensure(4));
     HIPCHK(h, h->d_mm.ensure(8));
-    HIPCHK(h, h->d_mismatch.ensure(2));
-    HIPCHK(h, h->d_ref.ensure(ref_len));
-    if (!h->h_pinned) {  // one pinned staging area: {winner[4], mm[8], mismatch[2]} as u64, then the ref list
-        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned), 16 * 8 + ref_len * sizeof(int), hipHostMallocDefault));
+    HIPCHK(h, h->d_voteback.ensure((back_bytes + 7) / 8));
+    if (!h->h_pinned || h->h_pinned_ref_len != ref_len) {
+        if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+        h->h_pinned = nullptr;
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned), back_bytes, hipHostMallocDefault));
         h->h_pinned_ref_len = ref_len;
     }
-    unsigned long long* hw = h->h_pinned;
-    unsigned long long* hmm = h->h_pinned + 4;
-    unsigned long long* hmis = h->h_pinned + 12;
-    int* href = reinterpret_cast<int*>(h->h_pinned + 16);
+    unsigned long long* const d_res = h->d_voteback.p;
+    unsigned long long* const d_mismatch = d_res + 6;
+    int* const d_ref = reinterpret_cast<int*>(d_res + res_words);
+    unsigned long long* hres = h->h_pinned;
+    int* href = reinterpret_cast<int*>(h->h_pinned + res_words);
     const unsigned long long my_tag = ~(unsigned long long)h->rank;
+    // a population held by one rank is counted by ONE workgroup (histogram in LDS) + the element-wise verification:
+    // two launches, one copy, one synchronisation; larger ones and sharded ones go through the histogram in memory
+    const bool local = !h->comm && R <= 262144;
+    if (local)
+        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::vote_count_local_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, rapid::kVoteBuckets * 4 + 1024));
 
     // Everything below is enqueued on the engine stream and read back with ONE synchronisation per salt:
     // histogram -> (all-reduce) -> winner -> min/max of the winning bucket -> (all-reduce) -> representative list
     // -> (all-reduce) -> element-wise verification -> (all-reduce).
     for (unsigned long long salt = 0; salt < 4; ++salt) {
-        HIPCHK(h, hipMemsetAsync(h->d_hist.p, 0, HB * 8, st));
-        HIPCHK(h, hipMemsetAsync(h->d_mm.p, 0, 64, st));
-        HIPCHK(h, hipMemsetAsync(h->d_mismatch.p, 0, 16, st));
-        if (R)
-            hipLaunchKernelGGL(rapid::vote_histogram_kernel, dim3(grid_for(R, 256)), dim3(256), 0, st, h->d_fp.p, h->d_pcount.p,
-                               R, salt, h->d_hist.p);
-        if (h->comm)  // the per-round all-reduce of the vote histogram over xGMI
-            NCCLCHK(h, ncclAllReduce(h->d_hist.p, h->d_hist.p, HB, ncclUint64, ncclSum, h->comm, st));
-        hipLaunchKernelGGL(rapid::vote_winner_kernel, dim3(1), dim3(1024), 0, st, h->d_hist.p, h->d_winner.p);
-        if (R)
-            hipLaunchKernelGGL(rapid::vote_bucket_minmax_kernel, dim3(grid_for(R, 256)), dim3(256), 0, st, h->d_fp.p,
-                               h->d_pcount.p, R, salt, h->d_winner.p, h->d_mm.p, my_tag);
-        if (h->comm)  // mm[0..3] = {max fp, max ~fp, -, max ~rank of a rank holding a representative}
-            NCCLCHK(h, ncclAllReduce(h->d_mm.p, h->d_mm.p, 4, ncclUint64, ncclMax, h->comm, st));
-        hipLaunchKernelGGL(rapid::vote_prepare_ref_kernel, dim3(1), dim3(256), 0, st, h->d_mm.p, my_tag, h->comm ? 0 : 1,
-                           h->d_pcount.p, h->d_props.p, h->max_cut, h->d_ref.p);
-        if (h->comm) NCCLCHK(h, ncclAllReduce(h->d_ref.p, h->d_ref.p, ref_len, ncclInt32, ncclMax, h->comm, st));
-        if (R)
-            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(grid_for((long long)R * 64, 1024)), dim3(1024), 0, st, h->d_fp.p,
-                               h->d_pcount.p, h->d_props.p, h->max_cut, R, h->d_mm.p, h->d_ref.p, h->d_mismatch.p);
-        if (h->comm) NCCLCHK(h, ncclAllReduce(h->d_mismatch.p, h->d_mismatch.p, 2, ncclUint64, ncclSum, h->comm, st));
-        HIPCHK(h, hipMemcpyAsync(hw, h->d_winner.p, 32, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipMemcpyAsync(hmm, h->d_mm.p, 64, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipMemcpyAsync(hmis, h->d_mismatch.p, 16, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipMemcpyAsync(href, h->d_ref.p, ref_len * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (local) {
+            hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st,
+                               h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, d_res, d_ref);
+            if (R)
+                hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(grid_for((long long)R * 64, 1024)), dim3(1024), 0, st, h->d_fp.p,
+                                   h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch);
+        } else {
+            HIPCHK(h, hipMemsetAsync(h->d_hist.p, 0, HB * 8, st));
+            HIPCHK(h, hipMemsetAsync(h->d_mm.p, 0, 64, st));
+            HIPCHK(h, hipMemsetAsync(d_res, 0, res_words * 8, st));
+            if (R)
+                hipLaunchKernelGGL(rapid::vote_histogram_kernel, dim3(grid_for(R, 256)), dim3(256), 0, st, h->d_fp.p, h->d_pcount.p,
+                                   R, salt, h->d_hist.p);
+            if (h->comm)  // the per-round all-reduce of the vote histogram over xGMI
+                NCCLCHK(h, ncclAllReduce(h->d_hist.p, h->d_hist.p, HB, ncclUint64, ncclSum, h->comm, st));
+            hipLaunchKernelGGL(rapid::vote_winner_kernel, dim3(1), dim3(1024), 0, st, h->d_hist.p, d_res);
+            if (R)
+                hipLaunchKernelGGL(rapid::vote_bucket_minmax_kernel, dim3(grid_for(R, 256)), dim3(256), 0, st, h->d_fp.p,
+                                   h->d_pcount.p, R, salt, d_res, h->d_mm.p, my_tag);
+            if (h->comm)  // mm[0..3] = {max fp, max ~fp, -, max ~rank of a rank holding a representative}
+                NCCLCHK(h, ncclAllReduce(h->d_mm.p, h->d_mm.p, 4, ncclUint64, ncclMax, h->comm, st));
+            // (a representative list too large for max_cut is reported as size INT_MAX, which survives the max-reduce
+            // among the other ranks' zeros)
+            hipLaunchKernelGGL(rapid::vote_prepare_ref_kernel, dim3(1), dim3(256), 0, st, h->d_mm.p, my_tag, h->comm ? 0 : 1,
+                               h->d_pcount.p, h->d_props.p, h->max_cut, d_ref);
+            if (h->comm) NCCLCHK(h, ncclAllReduce(d_ref, d_ref, ref_len, ncclInt32, ncclMax, h->comm, st));
+            if (R)
+                hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(grid_for((long long)R * 64, 1024)), dim3(1024), 0, st, h->d_fp.p,
+                                   h->d_pcount.p, h->d_props.p, h->max_cut, R, h->d_mm.p, d_ref, d_mismatch);
+            if (h->comm) NCCLCHK(h, ncclAllReduce(d_mismatch, d_mismatch, 2, ncclUint64, ncclSum, h->comm, st));
+            HIPCHK(h, hipMemcpyAsync(d_res + 4, h->d_mm.p, 16, hipMemcpyDeviceToDevice, st));
+        }
+        HIPCHK(h, hipMemcpyAsync(hres, d_res, back_bytes, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
         HIPCHK(h, hipGetLastError());
+        const unsigned long long* hw = hres;
+        const unsigned long long* hmm = hres + 4;
+        const unsigned long long* hmis = hres + 6;
         out->votes_total = (int64_t)hw[2];
         out->votes_winner = (int64_t)hw[1];
         out->distinct_local = (int32_t)hw[3];
@@ -1025,7 +1048,7 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
             continue;  // two proposals share the winning bucket: re-hash with the next salt
         }
         const int ref_n = href[0];
-        if (ref_n < 0) return fail(h, RAPID_ECAPACITY, "winning proposal exceeds max_cut=%d", h->max_cut);
+        if (ref_n < 0 || ref_n == 0x7FFFFFFF) return fail(h, RAPID_ECAPACITY, "winning proposal exceeds max_cut=%d", h->max_cut);
         if (hmis[0] != 0 || hmis[1] != hw[1])
             return fail(h, RAPID_ECOLLISION, "fingerprint collision: %llu of %llu voters differ from the representative",
                         hmis[0], hw[1]);
@@ -1115,6 +1138,19 @@ int rapid_engine_comm_init(rapid_engine* h, const uint8_t id_bytes[RAPID_UNIQUE_
     NCCLCHK(h, ncclCommInitRank(&h->comm, n_ranks, id, rank));
     h->rank = rank;
     h->n_ranks = n_ranks;
+    return RAPID_OK;
+}
+
+int rapid_engine_comm_info(rapid_engine* h, int32_t* rank, int32_t* n_ranks) {
+    if (!h || !rank || !n_ranks) return RAPID_EINVAL;
+    *rank = 0;
+    *n_ranks = 1;
+    if (!h->comm) return RAPID_OK;  // no communicator: a population held by one engine
+    int r = 0, n = 0;
+    NCCLCHK(h, ncclCommUserRank(h->comm, &r));
+    NCCLCHK(h, ncclCommCount(h->comm, &n));  // what the communicator itself says, not what the caller asked for
+    *rank = r;
+    *n_ranks = n;
     return RAPID_OK;
 }
 

@@ -38,7 +38,10 @@ __device__ __forceinline__ stream_rsrc_t stream_make_rsrc(const void* base, unsi
 // site); non-temporal (every byte of a stream is read once).
 __device__ __forceinline__ void stream_load2(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int imm, unsigned int& a,
                                              unsigned int& b) {
-    const stream_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_off, (int)imm, 2);
+#ifndef RAPID_STREAM_AUX
+#define RAPID_STREAM_AUX 2
+#endif
+    const stream_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_off, (int)imm, RAPID_STREAM_AUX);
     a = v.x;
     b = v.y;
 }

@@ -110,7 +110,7 @@ __global__ void vote_bucket_minmax_kernel(const unsigned long long* fp, const in
     }
 }
 
-// ref[0] = size, ref[1..cap] = node list of the proposal every voter must equal.  The rank that owns the lowest
+// ref[0] = size (INT_MAX: larger than prop_cap), ref[1..cap] = node list of the proposal every voter must equal.  The rank that owns the lowest
 // representative (owner_tag == my_tag, or a single-rank run) copies it from its receiver; every other rank writes
 // zeros, so that a max all-reduce of ref[] hands the list to everybody without a host round trip.
 // mm[4] = ~(local representative receiver), 0 if this rank has no voter in the winning bucket.
@@ -119,10 +119,12 @@ __global__ void vote_prepare_ref_kernel(const unsigned long long* mm, unsigned l
     const bool owner = mm[4] != 0ull && (single_rank || mm[3] == my_tag);
     const int rep = owner ? (int)(~mm[4]) : 0;
     int n = owner ? prop_count[rep] : 0;
-    if (n < 0) n = -1;  // the representative's proposal overflowed max_cut: reported by the host
+    const bool overflow = n < 0;  // the representative's proposal overflowed max_cut: reported by the host
+    if (overflow) n = 0;
     for (int i = (int)threadIdx.x; i < prop_cap; i += (int)blockDim.x)
         ref[1 + i] = (owner && i < n) ? props[(long long)rep * prop_cap + i] : 0;
-    if (threadIdx.x == 0) ref[0] = owner ? n : 0;
+    // INT_MAX, not -1: the other ranks contribute zeros to the max-reduce of ref[]
+    if (threadIdx.x == 0) ref[0] = owner ? (overflow ? 0x7FFFFFFF : n) : 0;
 }
 
 // Element-wise verification: every local voter whose fingerprint equals mm[0] (== the winning bucket's only
@@ -159,6 +161,129 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
         if (s_bad) atomicAdd(&mismatch[0], (unsigned long long)s_bad);
         if (s_seen) atomicAdd(&mismatch[1], (unsigned long long)s_seen);
     }
+}
+
+
+// The whole count for a population held by ONE rank, in one workgroup: histogram of the fingerprints in LDS (64 KiB),
+// winner, purity of the winning bucket (min == max fingerprint), the representative = the lowest receiver voting for
+// it, its node list.  res[0..3] as vote_winner_kernel's out[], res[4] = max fingerprint of the winning bucket,
+// res[5] = max of ~fingerprint (~min), res[6] = mismatch[0] = 0, res[7] = mismatch[1] = 0 (filled by
+// vote_verify_kernel, which follows on the stream and reads res[4] as its mm[0]); ref[0] = size of the
+// representative's list (-1: larger than prop_cap), ref[1..] = the list.  A few tens of thousands of receivers take a
+// few microseconds; larger populations use the multi-kernel path.
+__global__ __launch_bounds__(1024) void vote_count_local_kernel(const unsigned long long* fp, const int* prop_count, const int* props,
+                                                                int prop_cap, int n_receivers, unsigned long long salt,
+                                                                unsigned long long* res, int* ref) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vote_smem[];
+    unsigned int* const hist = reinterpret_cast<unsigned int*>(vote_smem);                          // [kVoteBuckets]
+    unsigned long long* const red64 = reinterpret_cast<unsigned long long*>(hist + kVoteBuckets);  // [2][16] per-wave partials
+    unsigned int* const red32 = reinterpret_cast<unsigned int*>(red64 + 32);                       // [4][16]
+    __shared__ unsigned int s_win_bucket, s_win_count, s_total, s_nz, s_rep;
+    __shared__ unsigned long long s_fmax, s_fminc;
+    const int t = (int)threadIdx.x, T = (int)blockDim.x, lane = t & 63, wv = t >> 6, nw = T >> 6;
+    for (int b = t; b < kVoteBuckets; b += T) hist[b] = 0u;
+    __syncthreads();
+    unsigned int mine = 0;
+    for (int r = t; r < n_receivers; r += T) {
+        if (prop_count[r] != 0) {  // -1 = proposal larger than max_cut: still a vote
+            atomicAdd(&hist[vote_bucket(fp[r], salt)], 1u);
+            ++mine;
+        }
+    }
+    __syncthreads();
+    // winner: most votes, lowest bucket among equals; number of non-empty buckets; total voters
+    unsigned int bc = 0, bi = 0, nz = 0;
+    for (int b = t; b < kVoteBuckets; b += T) {
+        const unsigned int c = hist[b];
+        nz += c != 0u ? 1u : 0u;
+        if (c > bc) {
+            bc = c;
+            bi = (unsigned int)b;
+        }
+    }
+    unsigned long long key = ((unsigned long long)bc << 32) | (unsigned long long)(0xFFFFFFFFu - bi);  // max key = max count, then min bucket
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(key, off, 64);
+        key = o > key ? o : key;
+        nz += (unsigned int)__shfl_xor((int)nz, off, 64);
+        mine += (unsigned int)__shfl_xor((int)mine, off, 64);
+    }
+    if (lane == 0) {
+        red64[wv] = key;
+        red32[wv] = nz;
+        red32[16 + wv] = mine;
+    }
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long k = 0;
+        unsigned int z = 0, m = 0;
+        for (int i = 0; i < nw; ++i) {
+            k = red64[i] > k ? red64[i] : k;
+            z += red32[i];
+            m += red32[16 + i];
+        }
+        s_win_count = (unsigned int)(k >> 32);
+        s_win_bucket = 0xFFFFFFFFu - (unsigned int)(k & 0xFFFFFFFFull);
+        s_nz = z;
+        s_total = m;
+    }
+    __syncthreads();
+    // the winning bucket: max fingerprint, max ~fingerprint, lowest voter
+    const unsigned int wb = s_win_bucket;
+    unsigned long long fmx = 0ull, fmn = 0ull;
+    unsigned int rep = 0xFFFFFFFFu;
+    if (s_win_count != 0u) {
+        for (int r = t; r < n_receivers; r += T) {
+            if (prop_count[r] != 0) {
+                const unsigned long long f = fp[r];
+                if (vote_bucket(f, salt) == wb) {
+                    fmx = f > fmx ? f : fmx;
+                    fmn = ~f > fmn ? ~f : fmn;
+                    rep = (unsigned int)r < rep ? (unsigned int)r : rep;
+                }
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(fmx, off, 64), b = __shfl_xor(fmn, off, 64);
+        const unsigned int c = (unsigned int)__shfl_xor((int)rep, off, 64);
+        fmx = a > fmx ? a : fmx;
+        fmn = b > fmn ? b : fmn;
+        rep = c < rep ? c : rep;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        red64[wv] = fmx;
+        red64[16 + wv] = fmn;
+        red32[wv] = rep;
+    }
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long a = 0, b = 0;
+        unsigned int c = 0xFFFFFFFFu;
+        for (int i = 0; i < nw; ++i) {
+            a = red64[i] > a ? red64[i] : a;
+            b = red64[16 + i] > b ? red64[16 + i] : b;
+            c = red32[i] < c ? red32[i] : c;
+        }
+        s_fmax = a;
+        s_fminc = b;
+        s_rep = c;
+        res[0] = s_win_bucket;
+        res[1] = s_win_count;
+        res[2] = s_total;
+        res[3] = s_nz;
+        res[4] = a;
+        res[5] = b;
+        res[6] = 0ull;
+        res[7] = 0ull;
+    }
+    __syncthreads();
+    const bool have = s_rep != 0xFFFFFFFFu;
+    int n = have ? prop_count[s_rep] : 0;
+    if (n < 0) n = -1;  // the representative's proposal overflowed max_cut: reported by the host
+    for (int i = t; i < prop_cap; i += T) ref[1 + i] = (have && i < n) ? props[(long long)s_rep * prop_cap + i] : 0;
+    if (t == 0) ref[0] = n;
 }
 
 }  // namespace rapid

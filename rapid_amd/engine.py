@@ -75,6 +75,12 @@ class Engine:
         buf = np.frombuffer(unique_id, dtype=np.uint8).copy()
         self._check(self._lib.rapid_engine_comm_init(self._h, _addr(buf), rank, n_ranks))
 
+    def comm_info(self):
+        """(rank, n_ranks) as the RCCL communicator reports them; (0, 1) without one."""
+        r, n = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.rapid_engine_comm_info(self._h, C.byref(r), C.byref(n)))
+        return int(r.value), int(n.value)
+
 
 def comm_unique_id() -> bytes:
     buf = np.zeros(128, dtype=np.uint8)

@@ -641,3 +641,56 @@ def test_classic_round_recovers_a_population_without_fast_quorum(E):
     svc.decideViewChange(cut)
     assert new_cfg == oview.getCurrentConfigurationId() == view.getCurrentConfigurationId()
     assert view.getMembershipSize() == n - 1 and not view.isHostPresent(cut[0])
+
+
+# ------------------------------------------------------------------------- RCCL path on one GPU
+def test_vote_count_through_a_one_rank_communicator(E):
+    """The sharded vote count (R/FastPaxos.java:104, 125-156 with the N x N unicast fan-out of
+    R/UnicastToAllBroadcaster.java:46-52 replaced by collectives) executed on ONE GPU: an engine with a 1-rank RCCL
+    communicator runs every collective of rapid_sim_count_votes -- the histogram all-reduce, the max-reduce that elects
+    the rank holding the representative (rank-tag trick), the max-reduce that hands its list to everybody, the
+    sum-reduce of the verification counters -- and must decide exactly what the engine without a communicator decides:
+    a crash burst with a quorum, a churn round (joins + crashes), and a population without a fast quorum."""
+    n, K, H, L = 2000, 10, 9, 4
+    pop = S.Population.make(n)
+    members = list(range(0, n - 40))
+
+    def run(with_comm, case):
+        eng, view = make_engine(E, pop, K, H, L, members=members)
+        if with_comm:
+            eng.comm_init(E.comm_unique_id(), 0, 1)
+            assert eng.comm_info() == (0, 1)
+        else:
+            assert eng.comm_info() == (0, 1)
+        obs, subj, member = view.tables()
+        cfg = view.getCurrentConfigurationId()
+        if case == "crash":
+            sc = S.build_churn_scenario(obs, member, cfg, 20, 0, H, L)
+        elif case == "churn":
+            sc = S.build_churn_scenario(obs, member, cfg, 12, 15, H, L)
+        else:  # 3 % of the (receiver, batch) deliveries are lost: the proposals differ and none reaches the quorum
+            sc = S.build_churn_scenario(obs, member, cfg, 25, 0, H, L, materialise=False)
+            recs, off, nb = S.deliver(sc.batches, sc.receivers, 77, loss=0.03)
+            sc.records, sc.rec_off = recs, off
+        sim = E.ClusterSimulation(eng)
+        sim.load_streams(sc.records, sc.rec_off)
+        sim.tally()
+        rr = sim.count_votes()
+        out = dict(decided=rr.decided, cut_size=rr.cut_size, quorum=rr.quorum, votes_total=rr.votes_total,
+                   votes_winner=rr.votes_winner, membership=rr.membership_size,
+                   cut=sim.decided_cut() if rr.decided else None, results=[a.copy() for a in sim.results()])
+        if rr.decided:
+            out["new_cfg"] = sim.apply_cut(out["cut"])
+        eng.close()
+        return out, sc
+
+    for case in ("crash", "churn", "noquorum"):
+        a, sc = run(False, case)
+        b, _ = run(True, case)
+        for k in ("decided", "cut_size", "quorum", "votes_total", "votes_winner", "membership", "cut"):
+            assert a[k] == b[k], (case, k, a[k], b[k])
+        assert all(np.array_equal(x, y) for x, y in zip(a["results"], b["results"])), case
+        if case == "noquorum":
+            assert a["decided"] == 0 and 0 < a["votes_winner"] < a["quorum"]
+        else:
+            assert a["decided"] == 1 and sorted(a["cut"]) == sc.faulty.tolist() and a["new_cfg"] == b["new_cfg"]
