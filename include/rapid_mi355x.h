@@ -144,8 +144,24 @@ int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64
  * one of them, flags aside -- one AlertMessage is broadcast to all receivers, R/UnicastToAllBroadcaster.java:46-52).
  * The per-round index (which subjects can reach the L watermark at all, their adjacency) and the one-time validation
  * of the alerts against the current view are then computed from these n_alerts records instead of from a pass over
- * every delivered record.  Without it the library scans the delivered streams. */
+ * every delivered record.  Without it the library scans the delivered streams.
+ *
+ * What the engine does with the promise, and what it still checks on every DELIVERED record:
+ *   - if any declared alert fails the filter of R/MembershipService.java:644-675 under the CURRENT view (e.g. a set left
+ *     over from before a view change: its configuration id no longer matches), nothing is trusted: the tally re-runs the
+ *     whole filter per delivery, exactly as without a declared set;
+ *   - otherwise the tally does not re-read the configuration id of the delivered records (8 of their 20 bytes), but it does
+ *     check the subject's range, UP / DOWN against the membership, and that the reported rings are among those the index
+ *     was built for.  A delivered record that fails any of these makes the next call that reads results
+ *     (rapid_sim_results, rapid_sim_count_votes, rapid_sim_round, rapid_sim_proposal) return RAPID_EINVAL: the round's
+ *     results are void, the set was wrong;
+ *   - NOT detected: a delivered record that equals a declared alert in subject, rings and status but carries another
+ *     configuration id.  A caller that cannot rule that out must not declare a set (or must set bit 64 of
+ *     rapid_sim_set_force_exact, which keeps the index from the set but filters every delivery). */
 int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, int64_t n_alerts);
+/* Starts another round over the streams (and the declared alert set) that are loaded: the per-round index is built again
+ * by the next tally, as it is after a load.  What a round costs = index + tally + vote count; bench.py times exactly that. */
+int rapid_sim_new_round(rapid_engine* h);
 /* alert-tally kernel over all loaded receivers (asynchronous on the engine's stream) */
 int rapid_sim_tally(rapid_engine* h);
 /* per-receiver results of the last tally: index of the batch whose processing announced a proposal (-1 if

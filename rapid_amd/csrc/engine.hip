@@ -114,9 +114,11 @@ struct rapid_engine {
     DevBuf<unsigned char> d_alert_set;  // the round's distinct alerts, if the host declared them
     long long n_alert_set = -1;
     bool trusted = false, all_down = false;
-    DevBuf<unsigned int> d_gmask, d_adj;
-    DevBuf<unsigned short> d_dict, d_adj_off;
-    DevBuf<int> d_node_of_slot, d_deg, d_cursor, d_info;
+    DevBuf<unsigned int> d_adj;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // timing events, created once (no create / destroy per call, nothing to leak on an error path)
+    DevBuf<unsigned short> d_dict, d_decl, d_adj_off;
+    DevBuf<unsigned int> d_errflags;  // sticky per loaded stream set: bit0 = a delivered report is not covered by the declared alert set
+    DevBuf<int> d_node_of_slot, d_idxwork;  // d_idxwork = gmask[N] | info[8] of the round index build
     int n_slots = 0, n_hot = 0, n_adj = 0;
     float index_ms = 0.f;
     // launch geometry chosen from the index
@@ -129,8 +131,12 @@ struct rapid_engine {
     DevBuf<int> d_ref;
     std::vector<int> decided_cut;  // ring-0 order
     bool have_decision = false;
-    unsigned long long* h_pinned = nullptr;  // pinned staging for the vote read-back
-    size_t h_pinned_ref_len = 0;
+    unsigned long long* h_pinned = nullptr;  // pinned staging for the vote read-back (sharded populations)
+    // host-mapped mailbox the kernels write their small answers into (no copy enqueued, the host reads it after a
+    // synchronisation): [0, 64) the round index's info[8], [64, ...) the vote count's res[] + representative list
+    unsigned char* h_mail = nullptr;
+    unsigned char* d_mail = nullptr;
+    size_t mail_bytes = 0;
 
     // ---- multi-GPU ----
     ncclComm_t comm = nullptr;
@@ -313,67 +319,71 @@ int copy_list(rapid_engine* h, const int* src, int n, int32_t* out, int32_t cap,
     return RAPID_OK;
 }
 
+int ensure_mailbox(rapid_engine* h) {
+    // [0, 64) index info | [64, 64 + A) vote answer written by the kernels | [.., + A) staging of the copied answer (sharded
+    // populations); ONE page-granular allocation: two small hipHostMalloc blocks of one engine were observed to share
+    // their fate (freeing the first made hipHostFree of the second fail with "invalid argument")
+    const size_t answer = (10 * 8 + ((size_t)h->max_cut + 1) * sizeof(int) + 63) & ~(size_t)63;
+    const size_t need = (64 + 2 * answer + 4095) & ~(size_t)4095;
+    if (h->h_mail && h->mail_bytes >= need) return RAPID_OK;
+    if (h->h_mail) (void)hipHostFree(h->h_mail);
+    h->h_mail = nullptr;
+    h->h_pinned = nullptr;
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_mail), need, hipHostMallocMapped));
+    HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_mail), h->h_mail, 0));
+    std::memset(h->h_mail, 0, need);
+    h->mail_bytes = need;
+    h->h_pinned = reinterpret_cast<unsigned long long*>(h->h_mail + 64 + answer);
+    return RAPID_OK;
+}
+
 // Builds the per-round index (touched / hot subjects, slot dictionary, hot adjacency) for the loaded streams under
 // the current view, and picks the launch geometry of the tally kernel.
 int build_round_index(rapid_engine* h) {
     const int N = h->n_nodes, K = h->cfg.K, L = h->cfg.L;
     hipStream_t st = h->stream;
-    HIPCHK(h, h->d_gmask.ensure((size_t)N));
+    {
+        const int rc = ensure_mailbox(h);
+        if (rc) return rc;
+    }
+    HIPCHK(h, h->d_idxwork.ensure((size_t)N + 8));
     HIPCHK(h, h->d_dict.ensure((size_t)N));
+    HIPCHK(h, h->d_decl.ensure((size_t)N));
     HIPCHK(h, h->d_node_of_slot.ensure((size_t)N));
-    HIPCHK(h, h->d_deg.ensure((size_t)N));
-    HIPCHK(h, h->d_cursor.ensure((size_t)N));
     HIPCHK(h, h->d_adj_off.ensure((size_t)N + 1));
-    HIPCHK(h, h->d_info.ensure(8));
-    hipEvent_t e0, e1;
-    HIPCHK(h, hipEventCreate(&e0));
-    HIPCHK(h, hipEventCreate(&e1));
+    unsigned int* const d_gmask = reinterpret_cast<unsigned int*>(h->d_idxwork.p);
+    int* const d_info = h->d_idxwork.p + (size_t)N;
+    if (!h->ev0) HIPCHK(h, hipEventCreate(&h->ev0));
+    if (!h->ev1) HIPCHK(h, hipEventCreate(&h->ev1));
+    const hipEvent_t e0 = h->ev0, e1 = h->ev1;
     HIPCHK(h, hipEventRecord(e0, st));
-    HIPCHK(h, hipMemsetAsync(h->d_gmask.p, 0, sizeof(unsigned int) * (size_t)N, st));
-    HIPCHK(h, hipMemsetAsync(h->d_deg.p, 0, sizeof(int) * (size_t)N, st));
-    HIPCHK(h, hipMemsetAsync(h->d_cursor.p, 0, sizeof(int) * (size_t)N, st));
-    HIPCHK(h, hipMemsetAsync(h->d_info.p, 0, sizeof(int) * 8, st));
+    // gmask | info live in one allocation: one memset, then the touch pass (whole GPU), then everything else in one
+    // workgroup, which leaves info[] in host-mapped memory: one synchronisation, no copy
+    HIPCHK(h, hipMemsetAsync(h->d_idxwork.p, 0, sizeof(int) * ((size_t)N + 8), st));
     const unsigned char* scan = h->n_alert_set >= 0 ? h->d_alert_set.p : h->d_records;
     const long long n_scan = h->n_alert_set >= 0 ? h->n_alert_set : h->n_records_total;
     if (n_scan > 0)
         hipLaunchKernelGGL(rapid::index_touch_kernel, dim3((unsigned)std::min<long long>(h->num_cus * 8, (n_scan + 255) / 256)),
-                           dim3(256), 0, st, scan, n_scan, N, (1u << K) - 1u, (long long)h->config_id, h->d_member.p, h->d_gmask.p,
-                           reinterpret_cast<unsigned int*>(h->d_info.p + 4));
-    hipLaunchKernelGGL(rapid::index_slots_kernel, dim3(1), dim3(1024), 0, st, h->d_gmask.p, h->d_member.p, N, L, h->d_dict.p,
-                       h->d_node_of_slot.p, h->d_info.p);
-    int info[8] = {0};
-    HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof info, hipMemcpyDeviceToHost, st));
+                           dim3(256), 0, st, scan, n_scan, N, (1u << K) - 1u, (long long)h->config_id, h->d_member.p, d_gmask,
+                           reinterpret_cast<unsigned int*>(d_info + 4));
+    const int adj_cap = 65536;
+    HIPCHK(h, h->d_adj.ensure((size_t)adj_cap + 1));
+    hipLaunchKernelGGL(rapid::index_build_block_kernel, dim3(1), dim3(1024), 0, st, d_gmask, h->d_member.p, h->d_obs.p, N, K, L,
+                       h->d_dict.p, h->d_decl.p, h->d_node_of_slot.p, h->d_adj_off.p, h->d_adj.p, adj_cap, d_info,
+                       reinterpret_cast<volatile int*>(h->d_mail));
+    HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
+    int info[8];
+    std::memcpy(info, h->h_mail, sizeof info);  // written by the kernel into host-mapped memory
+    HIPCHK(h, hipEventElapsedTime(&h->index_ms, e0, e1));
     if (info[2] & 1) return fail(h, RAPID_ECAPACITY, "the round has %d hot subjects; at most 16318 are supported", info[0]);
+    if (info[2] & 2)
+        return fail(h, RAPID_ECAPACITY, "hot adjacency has %d entries; at most 65535 are supported", info[3]);
     h->trusted = (info[4] & 1) == 0;
     h->all_down = (info[4] & 2) == 0;
     h->n_slots = info[0];
     h->n_hot = info[1];
-    h->n_adj = 0;
-    HIPCHK(h, h->d_adj.ensure((size_t)std::max(1, 2 * K * h->n_hot)));
-    if (h->n_hot > 0) {
-        const unsigned g = grid_for((long long)h->n_hot * K, 256);
-        hipLaunchKernelGGL(rapid::index_adj_kernel, dim3(g), dim3(256), 0, st, h->d_obs.p, h->d_dict.p, h->d_node_of_slot.p,
-                           h->n_hot, K, h->d_deg.p, h->d_adj_off.p, h->d_cursor.p, h->d_adj.p, 0);
-        hipLaunchKernelGGL(rapid::index_adj_scan_kernel, dim3(1), dim3(64), 0, st, h->d_deg.p, h->n_hot, h->d_adj_off.p,
-                           h->d_info.p);
-        hipLaunchKernelGGL(rapid::index_adj_kernel, dim3(g), dim3(256), 0, st, h->d_obs.p, h->d_dict.p, h->d_node_of_slot.p,
-                           h->n_hot, K, h->d_deg.p, h->d_adj_off.p, h->d_cursor.p, h->d_adj.p, 1);
-        hipLaunchKernelGGL(rapid::index_adj_flag_kernel, dim3(grid_for(h->n_hot, 256)), dim3(256), 0, st, h->d_deg.p,
-                           h->d_node_of_slot.p, h->n_hot, h->d_dict.p);
-        HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof info, hipMemcpyDeviceToHost, st));
-    } else {
-        HIPCHK(h, hipMemsetAsync(h->d_adj_off.p, 0, sizeof(unsigned short) * 2, st));
-    }
-    HIPCHK(h, hipEventRecord(e1, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventElapsedTime(&h->index_ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (info[2] & 2)
-        return fail(h, RAPID_ECAPACITY, "hot adjacency has %d entries; at most 65535 are supported", info[3]);
     h->n_adj = h->n_hot > 0 ? info[3] : 0;
 
     // ---- launch geometry: fill the CU's LDS with as many receiver-waves as possible ----
@@ -427,6 +437,8 @@ int launch_tally(rapid_engine* h) {
     p.L = h->cfg.L;
     p.cfg_id = h->config_id;
     p.idx.dict = h->d_dict.p;
+    p.idx.decl = h->d_decl.p;
+    p.error_flags = h->d_errflags.p;
     p.idx.node_of_slot = h->d_node_of_slot.p;
     p.idx.adj_off = h->d_adj_off.p;
     p.idx.adj = h->d_adj.p;
@@ -457,9 +469,11 @@ int launch_tally(rapid_engine* h) {
 int prepare_tally(rapid_engine* h) {
     if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
     if (!h->streams_loaded) return fail(h, RAPID_ESTATE, "no alert streams loaded");
+    HIPCHK(h, h->d_errflags.ensure(2));
     if (!h->index_valid) {
         int rc = build_round_index(h);
         if (rc) return rc;
+        HIPCHK(h, hipMemsetAsync(h->d_errflags.p, 0, 2 * sizeof(unsigned int), h->stream));
     }
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel<true, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -520,12 +534,20 @@ int rapid_engine_create(const rapid_engine_config* cfg, rapid_engine** out) {
 void rapid_engine_destroy(rapid_engine* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device_id);
+    // a failure here has nobody to be reported to, but it must not be left behind as the thread's "last error" for an
+    // unrelated later call (rocPRIM checks hipGetLastError after its launches) to trip over
+    auto quiet = [](hipError_t e, const char* what) {
+        if (e != hipSuccess) {
+            if (getenv("RAPID_DEBUG")) fprintf(stderr, "rapid_engine_destroy: %s: %s\n", what, hipGetErrorString(e));
+            (void)hipGetLastError();
+        }
+    };
     if (h->comm) (void)ncclCommDestroy(h->comm);
-    if (h->h_pinned) (void)hipHostFree(h->h_pinned);
-    if (h->stream) {
-        (void)hipStreamSynchronize(h->stream);
-        (void)hipStreamDestroy(h->stream);
-    }
+    if (h->stream) quiet(hipStreamSynchronize(h->stream), "hipStreamSynchronize");
+    if (h->ev0) quiet(hipEventDestroy(h->ev0), "hipEventDestroy");
+    if (h->ev1) quiet(hipEventDestroy(h->ev1), "hipEventDestroy");
+    if (h->h_mail) quiet(hipHostFree(h->h_mail), "hipHostFree(mailbox)");
+    if (h->stream) quiet(hipStreamDestroy(h->stream), "hipStreamDestroy");
     h->d_blob.release(); h->d_host_off.release(); h->d_ports.release(); h->d_keys.release();
     h->d_hx_host0.release(); h->d_hx_port0.release(); h->d_member.release(); h->d_members.release();
     h->d_sort_keys.release(); h->d_sort_vals.release(); h->d_ring_skeys.release(); h->d_ring.release();
@@ -533,9 +555,10 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
     h->d_records_own.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
-    h->d_alert_set.release(); h->d_next.release(); h->d_gmask.release(); h->d_adj.release(); h->d_dict.release();
-    h->d_adj_off.release(); h->d_node_of_slot.release(); h->d_deg.release(); h->d_cursor.release(); h->d_info.release();
+    h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release();
+    h->d_adj_off.release(); h->d_node_of_slot.release();
     h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release(); h->d_voteback.release();
+    (void)hipGetLastError();
     delete h;
 }
 
@@ -894,6 +917,15 @@ int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, i
     return RAPID_OK;
 }
 
+int rapid_sim_new_round(rapid_engine* h) {
+    if (!h) return RAPID_EINVAL;
+    if (!h->streams_loaded) return fail(h, RAPID_ESTATE, "no alert streams loaded");
+    h->index_valid = false;  // rebuilt by the next tally, as after a load
+    h->tallied = false;
+    h->have_decision = false;
+    return RAPID_OK;
+}
+
 int rapid_sim_tally(rapid_engine* h) {
     if (!h) return RAPID_EINVAL;
     int rc = use_device(h);
@@ -906,6 +938,17 @@ int rapid_sim_tally(rapid_engine* h) {
     }
     h->tallied = true;
     h->have_decision = false;
+    return RAPID_OK;
+}
+
+// The tally kernel's sticky error word, read at the calls that synchronise with it anyway.
+static int check_tally_errors(rapid_engine* h) {
+    unsigned int flags[2] = {0u, 0u};
+    HIPCHK(h, hipMemcpyAsync(flags, h->d_errflags.p, sizeof flags, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (flags[0] & 1u)
+        return fail(h, RAPID_EINVAL, "a delivered alert names a subject / ring that the declared alert set does not contain "
+                                    "(rapid_sim_set_alert_set must be given every distinct alert of the loaded streams)");
     return RAPID_OK;
 }
 
@@ -925,7 +968,7 @@ int rapid_sim_results(rapid_engine* h, int32_t* emit_batch, int32_t* num_proposa
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
-    return RAPID_OK;
+    return check_tally_errors(h);
 }
 
 static void sort_ring0(rapid_engine* h, std::vector<int>& v) {
@@ -971,18 +1014,13 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
     const size_t ref_len = (size_t)h->max_cut + 1;
     // One device buffer for everything the host reads back: res[8] = {winning bucket, its votes, voters, non-empty buckets,
     // max fingerprint, max ~fingerprint, mismatching voters, verified voters}, then ref[1 + max_cut]; one pinned copy of it.
-    const size_t res_words = 8;
+    const size_t res_words = 10;  // ... + the tally kernel's sticky error word (res[8])
     const size_t back_bytes = res_words * 8 + ref_len * sizeof(int);
     HIPCHK(h, h->d_hist.ensure(HB));
     HIPCHK(h, h->d_winner.ensure(4));
     HIPCHK(h, h->d_mm.ensure(8));
     HIPCHK(h, h->d_voteback.ensure((back_bytes + 7) / 8));
-    if (!h->h_pinned || h->h_pinned_ref_len != ref_len) {
-        if (h->h_pinned) (void)hipHostFree(h->h_pinned);
-        h->h_pinned = nullptr;
-        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned), back_bytes, hipHostMallocDefault));
-        h->h_pinned_ref_len = ref_len;
-    }
+    if ((rc = ensure_mailbox(h))) return rc;
     unsigned long long* const d_res = h->d_voteback.p;
     unsigned long long* const d_mismatch = d_res + 6;
     int* const d_ref = reinterpret_cast<int*>(d_res + res_words);
@@ -1002,10 +1040,11 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
     for (unsigned long long salt = 0; salt < 4; ++salt) {
         if (local) {
             hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st,
-                               h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, d_res, d_ref);
-            if (R)
-                hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(grid_for((long long)R * 64, 1024)), dim3(1024), 0, st, h->d_fp.p,
-                                   h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch);
+                               h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
+            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * 64, 1024))), dim3(1024), 0, st,
+                               h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, d_res,
+                               (int)res_words, reinterpret_cast<unsigned int*>(d_res + 9),
+                               reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64));
         } else {
             HIPCHK(h, hipMemsetAsync(h->d_hist.p, 0, HB * 8, st));
             HIPCHK(h, hipMemsetAsync(h->d_mm.p, 0, 64, st));
@@ -1028,13 +1067,21 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
             if (h->comm) NCCLCHK(h, ncclAllReduce(d_ref, d_ref, ref_len, ncclInt32, ncclMax, h->comm, st));
             if (R)
                 hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(grid_for((long long)R * 64, 1024)), dim3(1024), 0, st, h->d_fp.p,
-                                   h->d_pcount.p, h->d_props.p, h->max_cut, R, h->d_mm.p, d_ref, d_mismatch);
+                                   h->d_pcount.p, h->d_props.p, h->max_cut, R, h->d_mm.p, d_ref, d_mismatch, nullptr, 0, nullptr, nullptr);
             if (h->comm) NCCLCHK(h, ncclAllReduce(d_mismatch, d_mismatch, 2, ncclUint64, ncclSum, h->comm, st));
             HIPCHK(h, hipMemcpyAsync(d_res + 4, h->d_mm.p, 16, hipMemcpyDeviceToDevice, st));
+            HIPCHK(h, hipMemcpyAsync(d_res + 8, h->d_errflags.p, 8, hipMemcpyDeviceToDevice, st));
         }
-        HIPCHK(h, hipMemcpyAsync(hres, d_res, back_bytes, hipMemcpyDeviceToHost, st));
+        if (!local) HIPCHK(h, hipMemcpyAsync(hres, d_res, back_bytes, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
         HIPCHK(h, hipGetLastError());
+        if (local) {  // the last workgroup of the verification wrote the answer into host-mapped memory
+            hres = reinterpret_cast<unsigned long long*>(h->h_mail + 64);
+            href = reinterpret_cast<int*>(hres + res_words);
+        }
+        if ((unsigned int)hres[8] & 1u)
+            return fail(h, RAPID_EINVAL, "a delivered alert names a subject / ring that the declared alert set does not contain "
+                                        "(rapid_sim_set_alert_set must be given every distinct alert of the loaded streams)");
         const unsigned long long* hw = hres;
         const unsigned long long* hmm = hres + 4;
         const unsigned long long* hmis = hres + 6;
@@ -1188,9 +1235,9 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg) {
     if (rc) return rc;
     if ((rc = prepare_tally(h))) return rc;
     if (h->n_receivers == 0) return fail(h, RAPID_ESTATE, "no receivers");
-    hipEvent_t e0, e1;
-    HIPCHK(h, hipEventCreate(&e0));
-    HIPCHK(h, hipEventCreate(&e1));
+    if (!h->ev0) HIPCHK(h, hipEventCreate(&h->ev0));
+    if (!h->ev1) HIPCHK(h, hipEventCreate(&h->ev1));
+    const hipEvent_t e0 = h->ev0, e1 = h->ev1;
     HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * (size_t)std::max(h->grid_blocks, 1), h->stream));
     launch_tally(h);  // untimed warm-up
     HIPCHK(h, hipEventRecord(e0, h->stream));
@@ -1200,8 +1247,6 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg) {
     HIPCHK(h, hipGetLastError());
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *ms_avg = ms / (float)reps;
     h->tallied = true;
     return RAPID_OK;
@@ -1215,9 +1260,9 @@ int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, in
     if (rc) return rc;
     if (!h->streams_loaded || h->n_receivers == 0) return fail(h, RAPID_ESTATE, "no alert streams loaded");
     HIPCHK(h, h->d_next.ensure(4));
-    hipEvent_t e0, e1;
-    HIPCHK(h, hipEventCreate(&e0));
-    HIPCHK(h, hipEventCreate(&e1));
+    if (!h->ev0) HIPCHK(h, hipEventCreate(&h->ev0));
+    if (!h->ev1) HIPCHK(h, hipEventCreate(&h->ev1));
+    const hipEvent_t e0 = h->ev0, e1 = h->ev1;
     int per_cu = 16;  // waves per CU
     if (const char* e = getenv("RAPID_PROBE_WAVES_PER_CU")) per_cu = std::max(1, std::min(32, atoi(e)));
     const dim3 grid((unsigned)h->num_cus * (unsigned)std::max(1, per_cu / waves)), block((unsigned)waves * 64u);
@@ -1251,8 +1296,6 @@ int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, in
     HIPCHK(h, hipGetLastError());
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *ms_avg = ms / (float)reps;
     return RAPID_OK;
 }

@@ -40,8 +40,11 @@ __global__ void index_touch_kernel(const unsigned char* records, long long n_rec
 // One block.  Slot numbering: the hot subjects (>= L distinct rings named by the round's alert set), ascending by
 // node index.  Every node gets a dictionary entry  member << 15 | has_adjacency << 14 | slot  with slot = 0x3FFF for
 // subjects that are not hot.  info[0] = info[1] = n_hot, info[2] = overflow flag.
+// decl[node] = the rings the round's alert set names for the node (all rings for a hot one), bit 15 = member: what the tally kernel
+// checks every delivered report about a subject WITHOUT a slot against, so that a declared alert set that does not
+// cover the delivered streams is reported instead of silently under-counting.
 __global__ void index_slots_kernel(const unsigned int* gmask, const unsigned char* member, int n_nodes, int L,
-                                   unsigned short* dict, int* node_of_slot, int* info) {
+                                   unsigned short* dict, unsigned short* decl, int* node_of_slot, int* info) {
     __shared__ int s_hot[1024];
     const int T = (int)blockDim.x, t = (int)threadIdx.x;
     const int per = (n_nodes + T - 1) / T;
@@ -72,6 +75,7 @@ __global__ void index_slots_kernel(const unsigned int* gmask, const unsigned cha
             ++ph;
         }
         dict[n] = (unsigned short)(slot | (member[n] ? 0x8000 : 0));
+        decl[n] = (unsigned short)((slot != 0x3FFF ? 0x3FFFu : (gmask[n] & 0x3FFFu)) | (member[n] ? 0x8000u : 0u));
     }
 }
 
@@ -129,6 +133,106 @@ __global__ void index_adj_scan_kernel(const int* deg, int n_hot, unsigned short*
 __global__ void index_adj_flag_kernel(const int* deg, const int* node_of_slot, int n_hot, unsigned short* dict) {
     const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (e < n_hot && deg[e] > 0) dict[node_of_slot[e]] |= (unsigned short)0x4000;
+}
+
+
+// Exclusive scan of one value per thread over a workgroup of up to 1024 threads (wave shuffles + one LDS hop);
+// *total receives the sum.  s_wave: 16 ints of LDS scratch.
+__device__ inline int block_exclusive_scan(int v, int* s_wave, int* total) {
+    const int t = (int)threadIdx.x, lane = t & 63, wv = t >> 6, nw = ((int)blockDim.x + 63) >> 6;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    __syncthreads();  // s_wave may still be read from a previous call
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    int base = 0, sum = 0;
+    for (int i = 0; i < nw; ++i) {
+        const int w = s_wave[i];
+        if (i < wv) base += w;
+        sum += w;
+    }
+    *total = sum;
+    return base + incl - v;
+}
+
+// The whole index after the touch pass in ONE workgroup (the round's hot set is a few hundred to a few thousand
+// subjects): slot numbering + dictionary + declared masks, then the hot adjacency.  One launch and one read-back of
+// info[] instead of six launches and two synchronisations, and no atomics: the list of a hot slot e is built by the
+// thread that owns e from its row of the observer table -- one entry (observer slot | ring << 16) per ring on which a
+// hot node observes e (for a joiner: its expected observers, R/MembershipView.java:292-322).  These are the
+// (subject, observer, ring) triples of the implicit invalidation; the tally kernel needs nothing else (the mirrored
+// "e observes s" entries that index_adj_kernel also produces are not used by it any more).
+// adj has room for adj_cap entries (info[2] |= 2 if more are needed: nothing is written past it).  info_out: a second
+// copy of info[0..7] (host-mapped memory: the host reads it after synchronising, no copy is enqueued).
+__global__ __launch_bounds__(1024) void index_build_block_kernel(const unsigned int* gmask, const unsigned char* member, const int* obs,
+                                                                 int n_nodes, int K, int L, unsigned short* dict,
+                                                                 unsigned short* decl, int* node_of_slot, unsigned short* adj_off,
+                                                                 unsigned int* adj, int adj_cap, int* info, volatile int* info_out) {
+    __shared__ int s_wave[16];
+    const int T = (int)blockDim.x, t = (int)threadIdx.x;
+    // ---- slots (ascending node order), dictionary, declared ring masks ----
+    const int per = (n_nodes + T - 1) / T;
+    const int beg = min(n_nodes, t * per), end = min(n_nodes, beg + per);
+    int nh = 0;
+    for (int n = beg; n < end; ++n)
+        if (__popc(gmask[n]) >= L) ++nh;
+    int n_hot_all = 0;
+    int ph = block_exclusive_scan(nh, s_wave, &n_hot_all);
+    for (int n = beg; n < end; ++n) {
+        int slot = 0x3FFF;
+        if (__popc(gmask[n]) >= L) {
+            slot = ph < 16319 ? ph : 0x3FFF;
+            if (ph < 16319) node_of_slot[ph] = n;
+            ++ph;
+        }
+        dict[n] = (unsigned short)(slot | (member[n] ? 0x8000 : 0));
+        decl[n] = (unsigned short)((slot != 0x3FFF ? 0x3FFFu : (gmask[n] & 0x3FFFu)) | (member[n] ? 0x8000u : 0u));
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int n_hot = min(n_hot_all, 16318);
+    // ---- list lengths: thread t owns the hot slots t, t + T, ... ----
+    const int per2 = (n_hot + T - 1) / T;
+    const int b2 = min(n_hot, t * per2), e2 = min(n_hot, b2 + per2);  // a contiguous chunk, so that adj_off comes out of one scan
+    int mine = 0;
+    for (int e = b2; e < e2; ++e) {
+        const int node = node_of_slot[e];
+        int c = 0;
+        for (int k = 0; k < K; ++k) {
+            const int o = obs[node * K + k];
+            if (o >= 0 && (int)(dict[o] & 0x3FFF) < n_hot) ++c;
+        }
+        mine += c;
+    }
+    int total = 0;
+    int at = block_exclusive_scan(mine, s_wave, &total);
+    const bool fits = total <= 65535 && total <= adj_cap;
+    // ---- fill (role 0: `other` is the observer of e on ring k) ----
+    for (int e = b2; e < e2; ++e) {
+        const int node = node_of_slot[e];
+        adj_off[e] = (unsigned short)(at > 65535 ? 65535 : at);
+        const int at0 = at;
+        for (int k = 0; k < K; ++k) {
+            const int o = obs[node * K + k];
+            const int eo = o >= 0 ? (int)(dict[o] & 0x3FFF) : 0x3FFF;
+            if (eo < n_hot) {
+                if (fits) adj[at] = (unsigned)eo | ((unsigned)k << 16);
+                ++at;
+            }
+        }
+        if (at > at0) dict[node] |= (unsigned short)0x4000;  // only this thread touches dict[node] after the barrier above
+    }
+    if (t == T - 1 || (n_hot == 0 && t == 0)) adj_off[n_hot] = (unsigned short)(total > 65535 ? 65535 : total);
+    if (t == 0) {
+        info[0] = n_hot_all;
+        info[1] = n_hot_all;
+        info[2] = (n_hot_all > 16318 ? 1 : 0) | (fits ? 0 : 2);  // 64 slot numbers are kept for the tally kernel's dummy slots
+        info[3] = total;
+        for (int i = 0; i < 8; ++i) info_out[i] = info[i];  // info[4] was written by the touch pass
+    }
 }
 
 }  // namespace rapid

@@ -59,4 +59,9 @@ __device__ __forceinline__ void stream_store(unsigned long long* p, unsigned lon
     asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
+// Sets bits in a word of global memory (no value returned); rare, issued from assembly like the stores.
+__device__ __forceinline__ void stream_flag_or(unsigned int* p, unsigned int bits) {
+    asm volatile("global_atomic_or %0, %1, off" ::"v"(p), "v"(bits) : "memory");
+}
+
 }  // namespace rapid

@@ -81,9 +81,11 @@ constexpr unsigned int kDecEob = 1u << 29;
 // ones that can ever enter preProposal/proposal at any receiver -- in ascending node order.
 struct RoundIndex {
     const unsigned short* dict;     // [n_nodes] node -> kDictMember | kDictHasAdj | slot (kNoSlot: not hot)
+    const unsigned short* decl;     // [n_nodes] rings the round's alert set names for the node (all rings for a hot one) | member << 15
     const int* node_of_slot;        // [n_hot]
     const unsigned short* adj_off;  // [n_hot + 1] CSR over hot slots
-    const unsigned int* adj;        // [n_adj] other_slot | ring << 16 | role << 20 (role 1: `other` is the subject)
+    const unsigned int* adj;        // [n_adj] other_slot | ring << 16 | role << 20 (role 0: `other` observes the slot on that ring;
+                                    // role 1, the mirrored entry, is ignored)
     int n_hot, n_adj;
 };
 
@@ -103,17 +105,18 @@ struct TallyParams {
     int* props;                       // [R][prop_cap] ascending node index
     int prop_cap;
     unsigned long long* stats;        // [workgroups][8], accumulated over launches
+    unsigned int* error_flags;        // sticky: bit0 = a delivered report is not covered by the index (see RoundIndex::decl)
     int waves_per_block;
     int flags;                        // bit0: exact path only, bit3: careful path only (both for tests); bit5: stream only
 };
 
 __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
-// LDS budget.  Shared: the node -> slot dictionary (n_dict = n_nodes when it is staged in LDS, 0 when it stays in
-// memory), the round's (subject, observer, ring) triples [count, triples ...], the per-slot masks of the rings on
+// LDS budget.  Shared: the node -> slot dictionary and the declared ring masks (n_dict = n_nodes when they are staged in
+// LDS, 0 when they stay in memory), the round's (subject, observer, ring) triples [count, triples ...], the per-slot masks of the rings on
 // which a hot observer watches the slot, and slot -> node.  Per wave: detector state (hot + dummy slots),
 // decoded-record scratch, undo list.
 __host__ __device__ inline int tally_shared_bytes(int n_dict, int n_hot, int n_adj) {
-    return align16(n_dict * 2) + align16((n_adj / 2 + 1) * 4) + align16((n_hot + kDummySlots) * 2) + align16(n_hot * 4);
+    return 2 * align16(n_dict * 2) + align16((n_adj + 1) * 4) + align16((n_hot + kDummySlots) * 2) + align16(n_hot * 4);
 }
 // per-workgroup statistics accumulator at the very end of the dynamic LDS segment
 constexpr int kBlockStatsBytes = 80;  // eight counters + the workgroup's claim counter
@@ -374,12 +377,16 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // ---- shared read-only tables ----
     // Subjects that are not hot get DUMMY slots n_hot .. n_hot + 63 (spread over the banks): a report about them is ORed
     // into a word nobody reads, so the fast window needs neither a "hot?" test nor an execution mask per record.
-    const int dict_bytes = kTablesInLds ? align16(p.n_nodes * 2) : 0;
-    const int pairs_bytes = align16((p.idx.n_adj / 2 + 1) * 4);
+    const int dict_bytes = kTablesInLds ? 2 * align16(p.n_nodes * 2) : 0;
+    const int pairs_bytes = align16((p.idx.n_adj + 1) * 4);
     const int shared_bytes = tally_shared_bytes(kTablesInLds ? p.n_nodes : 0, n_hot, p.idx.n_adj);
     const unsigned short* dict = p.idx.dict;
+    const unsigned short* decl = p.idx.decl;
     if (kTablesInLds) {
         unsigned short* l_dict = reinterpret_cast<unsigned short*>(smem);
+        unsigned short* l_decl = reinterpret_cast<unsigned short*>(smem + align16(p.n_nodes * 2));
+        for (int i = (int)threadIdx.x; i < p.n_nodes; i += (int)blockDim.x) l_decl[i] = p.idx.decl[i];
+        decl = l_decl;
         for (int i = (int)threadIdx.x; i < p.n_nodes; i += (int)blockDim.x) {
             const unsigned int de = (unsigned int)p.idx.dict[i];
             unsigned int sl = de & kSlotMask;
@@ -495,6 +502,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         unsigned int slot, bits;
         bool down;
     };
+    unsigned int uncovered = 0u;  // per lane: ring bits of delivered reports that the index was not built for
     auto decode_rec = [&](const Win& c, int q) -> Dec {
         Dec r;
         const unsigned int w3 = c.w3[q], w4 = c.w4[q];
@@ -504,9 +512,14 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         if (kTrusted) {
             // every delivered record is a validated alert (or a zero past the end of the stream); the clamp only keeps a
             // broken promise from reading outside the dictionary
-            de = (unsigned int)dict[min(w3, node_last)];
+            const unsigned int idx = min(w3, node_last);
+            de = (unsigned int)dict[idx];
             r.bits = rb;
             r.down = dn;
+            // what can be checked without reading the configuration id: subject in range, UP / DOWN against the
+            // membership (R/MembershipService.java:659-668), rings among those the index was built for
+            const unsigned int dm = (unsigned int)decl[idx];
+            uncovered |= (rb & ~dm) | (w3 > node_last ? 1u : 0u) | (rb != 0u && dn != ((dm >> 15) != 0u) ? 1u : 0u);
         } else {
             const bool in = w3 < (unsigned int)p.n_nodes;
             de = (unsigned int)dict[in ? w3 : 0u];
@@ -514,6 +527,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                                      ((dn ? 1u : 0u) ^ (de >> 15)) | (in ? 0u : 1u) | (rb == 0u ? 1u : 0u);
             r.bits = bad == 0u ? rb : 0u;
             r.down = dn && bad == 0u;
+            uncovered |= r.bits & ~(unsigned int)decl[in ? w3 : 0u] & 0x3FFFu;
         }
         if (kTablesInLds) {
             r.slot = kTrusted ? de : (de & kSlotMask);  // dummy slots were assigned when the dictionary was staged
@@ -1087,6 +1101,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             }
             fp = wave_sum64(fp) + mix64(0x5EEDull + (unsigned long long)count);
             if (fp == 0) fp = 1;
+        }
+        if (wave_ballot(uncovered != 0u) != 0ull) {  // the declared alert set does not cover what was delivered: the results are void
+            if (lane == 0) stream_flag_or(p.error_flags, 1u);
+            uncovered = 0u;
         }
         if (lane == 0) {
 #ifndef RAPID_PHASE_TIMERS

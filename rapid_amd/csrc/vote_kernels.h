@@ -131,13 +131,18 @@ __global__ void vote_prepare_ref_kernel(const unsigned long long* mm, unsigned l
 // fingerprint when it is pure) must hold exactly the list ref[1..ref[0]].  mismatch[0] counts offenders, mismatch[1]
 // the verified voters.  One wavefront per receiver; the counts are reduced per workgroup first -- thousands of waves
 // adding to the same two words would queue up behind each other for longer than the comparison takes.
+// publish != nullptr (population held by one rank): the LAST workgroup to finish copies the round's answer --
+// res[0 .. res_words) and ref[0 .. 1 + size] -- into host-mapped memory, so the host reads it after synchronising
+// without a copy being enqueued; done[0] counts the finished workgroups and is left at zero.
 __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop_count, const int* props, int prop_cap,
                                    int n_receivers, const unsigned long long* mm, const int* ref,
-                                   unsigned long long* mismatch) {
-    __shared__ unsigned int s_bad, s_seen;
+                                   unsigned long long* mismatch, const unsigned long long* res, int res_words,
+                                   unsigned int* done, volatile unsigned long long* publish) {
+    __shared__ unsigned int s_bad, s_seen, s_last;
     if (threadIdx.x == 0) {
         s_bad = 0u;
         s_seen = 0u;
+        s_last = 0u;
     }
     __syncthreads();
     const int r = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -160,20 +165,34 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
     if (threadIdx.x == 0) {
         if (s_bad) atomicAdd(&mismatch[0], (unsigned long long)s_bad);
         if (s_seen) atomicAdd(&mismatch[1], (unsigned long long)s_seen);
+        if (publish != nullptr) {
+            __threadfence();
+            s_last = atomicAdd(done, 1u) == gridDim.x - 1u ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    if (publish != nullptr && s_last != 0u) {
+        __threadfence();
+        int n = ref[0];
+        n = (n < 0 || n > prop_cap) ? 0 : n;
+        volatile int* const pref = reinterpret_cast<volatile int*>(publish + res_words);
+        for (int i = (int)threadIdx.x; i < 1 + n; i += (int)blockDim.x) pref[i] = ref[i];
+        for (int i = (int)threadIdx.x; i < res_words; i += (int)blockDim.x)
+            publish[i] = __hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // mismatch[] was updated by atomics in L2
+        if (threadIdx.x == 0) *done = 0u;
     }
 }
-
 
 // The whole count for a population held by ONE rank, in one workgroup: histogram of the fingerprints in LDS (64 KiB),
 // winner, purity of the winning bucket (min == max fingerprint), the representative = the lowest receiver voting for
 // it, its node list.  res[0..3] as vote_winner_kernel's out[], res[4] = max fingerprint of the winning bucket,
 // res[5] = max of ~fingerprint (~min), res[6] = mismatch[0] = 0, res[7] = mismatch[1] = 0 (filled by
-// vote_verify_kernel, which follows on the stream and reads res[4] as its mm[0]); ref[0] = size of the
+// vote_verify_kernel, which follows on the stream and reads res[4] as its mm[0]), res[8] = tally_errors[0]; ref[0] = size of the
 // representative's list (-1: larger than prop_cap), ref[1..] = the list.  A few tens of thousands of receivers take a
 // few microseconds; larger populations use the multi-kernel path.
 __global__ __launch_bounds__(1024) void vote_count_local_kernel(const unsigned long long* fp, const int* prop_count, const int* props,
                                                                 int prop_cap, int n_receivers, unsigned long long salt,
-                                                                unsigned long long* res, int* ref) {
+                                                                const unsigned int* tally_errors, unsigned long long* res, int* ref) {
     extern __shared__ __attribute__((aligned(16))) unsigned char vote_smem[];
     unsigned int* const hist = reinterpret_cast<unsigned int*>(vote_smem);                          // [kVoteBuckets]
     unsigned long long* const red64 = reinterpret_cast<unsigned long long*>(hist + kVoteBuckets);  // [2][16] per-wave partials
@@ -277,6 +296,8 @@ __global__ __launch_bounds__(1024) void vote_count_local_kernel(const unsigned l
         res[5] = b;
         res[6] = 0ull;
         res[7] = 0ull;
+        res[8] = (unsigned long long)tally_errors[0];  // the tally kernel's sticky error word rides along
+        res[9] = 0ull;                                  // vote_verify_kernel's count of finished workgroups
     }
     __syncthreads();
     const bool have = s_rep != 0xFFFFFFFFu;

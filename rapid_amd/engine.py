@@ -383,5 +383,9 @@ class ClusterSimulation:
         self.e._check(self.e._lib.rapid_debug_stream_probe(self.e._h, variant, waves, reps, C.byref(ms)))
         return ms.value
 
+    def new_round(self):
+        """Another round over the loaded streams: the per-round index is rebuilt by the next tally."""
+        self.e._check(self.e._lib.rapid_sim_new_round(self.e._h))
+
     def set_force_exact(self, on):
         self.e._check(self.e._lib.rapid_sim_set_force_exact(self.e._h, int(on)))

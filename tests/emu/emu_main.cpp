@@ -134,7 +134,7 @@ int emu_tally_shared_bytes(int n_dict, int n_hot, int n_adj) { return rapid::tal
 
 // Runs the population kernel: `grid` persistent workgroups of `waves` waves, one workgroup at a time.
 int emu_tally_run(const unsigned char* records, unsigned long long records_bytes, const long long* rec_off,
-                  int n_receivers, int n_nodes, int K, int H, int L, long long cfg_id, const unsigned short* dict,
+                  int n_receivers, int n_nodes, int K, int H, int L, long long cfg_id, const unsigned short* dict, const unsigned short* decl,
                   const int* node_of_slot, const unsigned short* adj_off,
                   const unsigned int* adj, int n_hot, int n_adj, int* emit_batch, int* num_proposals,
                   int* prop_count, unsigned long long* fingerprint, int* props, int prop_cap, unsigned long long* stats,
@@ -153,6 +153,10 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     p.L = L;
     p.cfg_id = cfg_id;
     p.idx.dict = dict;
+    p.idx.decl = decl;
+    static unsigned int error_flags[2];
+    error_flags[0] = error_flags[1] = 0u;
+    p.error_flags = error_flags;
     p.idx.node_of_slot = node_of_slot;
     p.idx.adj_off = adj_off;
     p.idx.adj = adj;
@@ -179,7 +183,7 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
         else
             emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { rapid::tally_population_kernel<false, false>(p); }, seed + (unsigned)b);
     }
-    return 0;
+    return error_flags[0] != 0u ? -1 : 0;
 }
 
 int emu_cd_run(unsigned short* state, int* scal, const unsigned char* alerts, int n_alerts, int n_nodes, int K, int H,

@@ -59,7 +59,8 @@ def build_round_index(records, n_nodes, K, L, obs, member):
         if lists[e]:
             dict_[node_of_slot[e]] |= 0x4000
     dict_ = dict_.astype(np.uint16)
-    return dict(dict=dict_, node_of_slot=np.concatenate([node_of_slot, [0]]).astype(np.int32), adj_off=adj_off,
+    decl = (np.where(slot_of < n_hot, 0x3FFF, gmask & 0x3FFF) | np.where(np.asarray(member) != 0, 0x8000, 0)).astype(np.uint16)
+    return dict(dict=dict_, decl=decl, node_of_slot=np.concatenate([node_of_slot, [0]]).astype(np.int32), adj_off=adj_off,
                 adj=adj, n_hot=n_hot, n_adj=int(adj_off[-1]))
 
 
@@ -78,7 +79,10 @@ def validate_alerts(records, n_nodes, K, cfg_id, member):
 
 
 def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_cap=None, force_exact=0, seed=1, waves=3,
-          grid=2, tables_in_lds=1, trusted=False):
+          grid=2, tables_in_lds=1, trusted=False, declared=None):
+    """`declared`: build the round index from these records (the round's distinct alert set) instead of the delivered
+    ones; the call then returns (results ..., covered) with covered = False if the kernel found a delivered report that
+    the declared set does not contain."""
     L_ = lib()
     recs = np.ascontiguousarray(records)
     raw = np.zeros(((recs.nbytes + 15) // 16) * 16 + 32, dtype=np.uint8)
@@ -86,7 +90,7 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     rec_off = np.ascontiguousarray(rec_off, dtype=np.int64)
     R = len(rec_off) - 1
     prop_cap = n_nodes if prop_cap is None else prop_cap
-    ix = build_round_index(recs, n_nodes, K, L, np.asarray(obs), member)
+    ix = build_round_index(recs if declared is None else np.ascontiguousarray(declared), n_nodes, K, L, np.asarray(obs), member)
     if trusted:
         ok, all_down = validate_alerts(recs, n_nodes, K, cfg_id, member)
         assert ok, "trusted variant requested for a stream with alerts that fail the filter"
@@ -99,9 +103,12 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     stats = np.zeros((grid, 8), dtype=np.uint64)  # one row per workgroup, as the kernel writes them
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     rc = L_.emu_tally_run(p(raw), C.c_ulonglong((raw.nbytes // 16) * 16), p(rec_off), R, n_nodes, K, H, L, C.c_longlong(cfg_id),
-                          p(ix["dict"]), p(ix["node_of_slot"]), p(ix["adj_off"]), p(ix["adj"]),
+                          p(ix["dict"]), p(ix["decl"]), p(ix["node_of_slot"]), p(ix["adj_off"]), p(ix["adj"]),
                           ix["n_hot"], ix["n_adj"], p(emit), p(nprop), p(pcount), p(fp), p(props), prop_cap, p(stats),
                           force_exact, waves, grid, tables_in_lds, C.c_ulonglong(seed))
+    if declared is not None:
+        assert rc in (0, -1), rc
+        return emit, nprop, pcount, fp, props, stats.sum(axis=0), rc == 0
     assert rc == 0, rc
     return emit, nprop, pcount, fp, props, stats.sum(axis=0)
 

@@ -27,4 +27,6 @@ inline long long stream_scalar_load(const long long* p) { return *p; }
 inline void stream_store(int* p, int v) { *p = v; }
 inline void stream_store(unsigned long long* p, unsigned long long v) { *p = v; }
 
+inline void stream_flag_or(unsigned int* p, unsigned int bits) { *p |= bits; }
+
 }  // namespace rapid

@@ -694,3 +694,48 @@ def test_vote_count_through_a_one_rank_communicator(E):
             assert a["decided"] == 0 and 0 < a["votes_winner"] < a["quorum"]
         else:
             assert a["decided"] == 1 and sorted(a["cut"]) == sc.faulty.tolist() and a["new_cfg"] == b["new_cfg"]
+
+
+def test_declared_alert_set_that_does_not_cover_the_streams_is_rejected(E):
+    """rapid_sim_set_alert_set is a promise the engine checks: a delivered report about a subject (or ring of a cold
+    subject) missing from the declared set -> RAPID_EINVAL at the next read of results, not silently different cuts; a set
+    from another configuration is simply not trusted (per-delivery filter), and an honest set changes nothing."""
+    n, K, H, L = 2000, 10, 9, 4
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_scenario("C2", subj, cfg, n=n, f=20, H=H, L=L)
+    sim, want = run_population(E, eng, sc.records, sc.rec_off)
+    # honest declaration
+    sim, res = run_population(E, eng, sc.records, sc.rec_off, alert_set=sc.batches.recs)
+    assert sim.index_info()["alerts_prevalidated"] == 1 and all(np.array_equal(a, b) for a, b in zip(want, res))
+    # every alert about one faulty subject withheld from the set
+    short = sc.batches.recs[sc.batches.recs["dst"] != sc.faulty[3]]
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(sc.records, sc.rec_off)
+    sim.set_alert_set(short)
+    sim.tally()
+    with pytest.raises(E.IllegalArgumentException):
+        sim.results()
+    with pytest.raises(E.IllegalArgumentException):
+        sim.count_votes()
+    # a delivered record with the wrong status for its subject (an UP alert about a member), set otherwise honest
+    bad = sc.records.copy()
+    k = int(np.flatnonzero(np.isin(bad["dst"], sc.faulty))[5])
+    bad["status"][k] = S.UP
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(bad, sc.rec_off)
+    sim.set_alert_set(sc.batches.recs)
+    sim.tally()
+    with pytest.raises(E.IllegalArgumentException):
+        sim.results()
+    # the same streams without a declaration: the per-delivery filter drops that record, as the reference does
+    sim, res2 = run_population(E, eng, bad, sc.rec_off)
+    fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, bad, sc.rec_off, nthreads=8)
+    assert np.array_equal(res2[0], fe) and np.array_equal(res2[2], np.diff(fo))
+    # a set stamped with another configuration id is not trusted at all: same results as without it
+    stale = sc.batches.recs.copy()
+    stale["cfg_id"] = cfg + 1
+    sim, res3 = run_population(E, eng, sc.records, sc.rec_off, alert_set=stale)
+    assert sim.index_info()["alerts_prevalidated"] == 0 and all(np.array_equal(a, b) for a, b in zip(want, res3))

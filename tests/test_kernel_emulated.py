@@ -197,3 +197,29 @@ def test_cd_instance_kernel_kat7_link_invalidation():
     ret = cd.invalidate()
     assert len(ret) == 4 and cd.num_proposals() == 1
     assert set(ret) == failed | {dst}
+
+
+def test_declared_alert_set_must_cover_the_delivered_streams():
+    """rapid_sim_set_alert_set semantics in the kernel: the index is built from the declared set; a delivered report about a
+    subject / ring the set does not contain (which could make a subject hot that has no slot) is detected and reported,
+    not silently under-counted."""
+    n, K, H, L = 300, 10, 9, 4
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K)
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_scenario("C2", subj, cfg, n=n, f=12, H=H, L=L, receivers=np.arange(0, n, 23))
+    fe, fn, fo, fp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off)
+    for trusted in (False, True):
+        *res, covered = pyemu.tally(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, trusted=trusted,
+                                    declared=sc.batches.recs)
+        assert covered and np.array_equal(res[0], fe) and np.array_equal(res[2], np.diff(fo))
+        # the set without every alert about one faulty subject: that subject is not hot in the index, but it is delivered
+        short = sc.batches.recs[sc.batches.recs["dst"] != sc.faulty[0]]
+        *_, covered = pyemu.tally(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, trusted=trusted, declared=short)
+        assert not covered
+        # ... and without ONE ring of a subject that stays hot: harmless, the slot exists and holds all K rings
+        one = np.flatnonzero((sc.batches.recs["dst"] == sc.faulty[1]))[0]
+        *res, covered = pyemu.tally(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, trusted=trusted,
+                                    declared=np.delete(sc.batches.recs, one))
+        assert covered and np.array_equal(res[0], fe) and np.array_equal(res[2], np.diff(fo))
