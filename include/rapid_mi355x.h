@@ -146,19 +146,21 @@ int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64
  * of the alerts against the current view are then computed from these n_alerts records instead of from a pass over
  * every delivered record.  Without it the library scans the delivered streams.
  *
- * What the engine does with the promise, and what it still checks on every DELIVERED record:
- *   - if any declared alert fails the filter of R/MembershipService.java:644-675 under the CURRENT view (e.g. a set left
- *     over from before a view change: its configuration id no longer matches), nothing is trusted: the tally re-runs the
- *     whole filter per delivery, exactly as without a declared set;
- *   - otherwise the tally does not re-read the configuration id of the delivered records (8 of their 20 bytes), but it does
- *     check the subject's range, UP / DOWN against the membership, and that the reported rings are among those the index
- *     was built for.  A delivered record that fails any of these makes the next call that reads results
- *     (rapid_sim_results, rapid_sim_count_votes, rapid_sim_round, rapid_sim_proposal) return RAPID_EINVAL: the round's
- *     results are void, the set was wrong;
- *   - NOT detected: a delivered record that equals a declared alert in subject, rings and status but carries another
- *     configuration id.  A caller that cannot rule that out must not declare a set (or must set bit 64 of
- *     rapid_sim_set_force_exact, which keeps the index from the set but filters every delivery). */
+ * The index alone changes nothing about the semantics: every delivered record still goes through the whole filter of
+ * R/MembershipService.java:644-675 (configuration id, UP / DOWN against the membership, range, rings), and a delivered
+ * report about a subject / ring that the declared set does not contain -- which the index was not built for -- makes the
+ * next call that reads results (rapid_sim_results, rapid_sim_count_votes, rapid_sim_round, rapid_sim_proposal) return
+ * RAPID_EINVAL: the round's results are void, the set was wrong. */
 int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, int64_t n_alerts);
+/* Opt-in, per loaded stream set (a load resets it): the caller VOUCHES that every delivered record is a byte-identical copy
+ * of a declared alert, configuration id included (true when the streams are replays of this round's broadcasts; false as
+ * soon as late deliveries of an earlier configuration can be among them, e.g. BASELINE configs[4]).  If in addition every
+ * declared alert passes the filter under the current view, the tally then does not re-read the configuration id of the
+ * delivered records (8 of their 20 bytes: fewer load instructions, same HBM traffic).  Still checked per delivery:
+ * subject range, UP / DOWN against the membership, rings covered by the index -> RAPID_EINVAL as above.  NOT detected
+ * under this promise: a delivered record that equals a declared alert in subject, rings and status but carries another
+ * configuration id -- it is tallied, where the reference would drop it. */
+int rapid_sim_trust_alert_copies(rapid_engine* h, int32_t on);
 /* Starts another round over the streams (and the declared alert set) that are loaded: the per-round index is built again
  * by the next tally, as it is after a load.  What a round costs = index + tally + vote count; bench.py times exactly that. */
 int rapid_sim_new_round(rapid_engine* h);

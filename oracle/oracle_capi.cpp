@@ -264,6 +264,14 @@ int orc_fr_decided(void* f, int32_t* out, int cap) {
 // (and by the end of the receiver's stream).  Outputs per receiver: index of the batch that announced a
 // proposal (-1 if none), getNumProposals(), number of batches consumed, and the proposal (ascending node
 // index) in a CSR list.  Returns 0 or ORC_ECAPACITY.
+// 1 (default): orc_sim_run queries getObserversOf of EVERY member before its (possibly multi-threaded) run, i.e. it models
+// nodes whose observer cache (R/MembershipView.java:210-224, quirk Q4) holds every subject.  0: the cache is filled only
+// by what the receivers of the run actually ask for (MultiNodeCutDetector.java:147-149: the subjects in preProposal) --
+// the union of the per-node caches of the simulated receivers, which is what a multi-round run must carry from one
+// configuration to the next; the run is then single-threaded (the cache is written while it is read).
+static int g_prewarm_observers = 1;
+void orc_sim_set_prewarm(int on) { g_prewarm_observers = on; }
+
 int orc_sim_run(void* view_p, int K, int H, int L, const int64_t* id_hi, const int64_t* id_lo, int n_ids,
                 const void* records, const int64_t* rec_off, int R, int snapshot_order, int nthreads,
                 int32_t* out_emit_batch, int32_t* out_num_proposals, int64_t* out_prop_off, int32_t* out_props,
@@ -274,8 +282,12 @@ int orc_sim_run(void* view_p, int K, int H, int L, const int64_t* id_hi, const i
     (void)view->getCurrentConfigurationId();
     for (int k = 0; k < K; ++k)
         for (int n = 0; n < n_ids; ++n) (void)view->ringKey(k, n);
-    for (int n = 0; n < n_ids; ++n)
-        if (view->isHostPresent(n)) (void)view->getObserversOf(n);
+    if (g_prewarm_observers) {
+        for (int n = 0; n < n_ids; ++n)
+            if (view->isHostPresent(n)) (void)view->getObserversOf(n);
+    } else {
+        nthreads = 1;
+    }
     IdTable ids;
     ids.ids.resize((size_t)n_ids);
     for (int i = 0; i < n_ids; ++i) ids.ids[(size_t)i] = NodeId{id_hi[i], id_lo[i]};

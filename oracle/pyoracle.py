@@ -105,6 +105,7 @@ def lib():
     sig("orc_fr_free", None, [vp])
     sig("orc_fr_vote", i32, [vp, i32, i64, pi32, i32])
     sig("orc_fr_decided", i32, [vp, pi32, i32])
+    sig("orc_sim_set_prewarm", None, [i32])
     sig("orc_sim_run", i32, [vp, i32, i32, i32, pi64, pi64, i32, vp, pi64, i32, i32, i32, pi32, pi32, pi64, pi32, i64])
     sig("orc_fast_sim_run", i32,
         [i32, i32, i32, i32, i64, pi32, pi32, C.POINTER(C.c_uint8), vp, pi64, i32, i32, pi32, pi32, pi64, pi32, i64])
@@ -391,8 +392,11 @@ def _csr(off, vals, R):
     return [vals[off[r]: off[r + 1]].copy() for r in range(R)]
 
 
-def sim_run(view, K, H, L, id_hi, id_lo, records, rec_off, snapshot_order=0, nthreads=1):
-    """Faithful whole-population run: one AlertBatchService per receiver over a shared view."""
+def sim_run(view, K, H, L, id_hi, id_lo, records, rec_off, snapshot_order=0, nthreads=1, prewarm_observers=True):
+    """Faithful whole-population run: one AlertBatchService per receiver over a shared view.  prewarm_observers=False:
+    the view's observer cache (quirk Q4) is only filled by what these receivers query, and survives into the next call
+    with whatever the view changes in between left of it (single-threaded)."""
+    lib().orc_sim_set_prewarm(1 if prewarm_observers else 0)
     records = np.ascontiguousarray(records, dtype=ALERT_DTYPE)
     rec_off = np.ascontiguousarray(rec_off, dtype=np.int64)
     hi = np.ascontiguousarray(id_hi, dtype=np.int64)

@@ -114,6 +114,7 @@ struct rapid_engine {
     DevBuf<unsigned char> d_alert_set;  // the round's distinct alerts, if the host declared them
     long long n_alert_set = -1;
     bool trusted = false, all_down = false;
+    bool trust_copies = false;  // the caller's promise that every delivered record is a byte copy of a declared alert
     DevBuf<unsigned int> d_adj;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // timing events, created once (no create / destroy per call, nothing to leak on an error path)
     DevBuf<unsigned short> d_dict, d_decl, d_adj_off;
@@ -454,7 +455,9 @@ int launch_tally(rapid_engine* h) {
     p.waves_per_block = h->waves_per_block;
     p.flags = h->force_exact & (1 | 4 | 8 | 16 | 32);
     const dim3 grid((unsigned)h->grid_blocks), block((unsigned)h->waves_per_block * 64u);
-    const bool trusted = h->trusted && (h->force_exact & 64) == 0;  // bit6 of the testing knob: never trust
+    // pre-validated instantiation: the scanned alerts all pass the filter AND (when they are a declared set rather than the
+    // delivered records themselves) the caller vouches that the deliveries are copies of them; bit6 of the testing knob: never
+    const bool trusted = h->trusted && (h->n_alert_set < 0 || h->trust_copies) && (h->force_exact & 64) == 0;
     if (h->tables_in_lds && trusted)
         hipLaunchKernelGGL((rapid::tally_population_kernel<true, true>), grid, block, (size_t)h->lds_bytes, h->stream, p);
     else if (h->tables_in_lds)
@@ -873,6 +876,7 @@ int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, c
     h->n_receivers = n_receivers;
     h->n_records_total = n_rec;
     h->n_alert_set = -1;
+    h->trust_copies = false;
     h->index_valid = false;
     h->streams_loaded = true;
     h->tallied = false;
@@ -896,6 +900,7 @@ int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64
     h->n_receivers = n_receivers;
     h->n_records_total = n_rec;
     h->n_alert_set = -1;
+    h->trust_copies = false;
     h->index_valid = false;
     h->streams_loaded = true;
     h->tallied = false;
@@ -914,6 +919,12 @@ int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, i
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->n_alert_set = n_alerts;
     h->index_valid = false;
+    return RAPID_OK;
+}
+
+int rapid_sim_trust_alert_copies(rapid_engine* h, int32_t on) {
+    if (!h) return RAPID_EINVAL;
+    h->trust_copies = on != 0;
     return RAPID_OK;
 }
 
@@ -1310,7 +1321,7 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
     info[2] = h->waves_per_block;
     info[3] = h->grid_blocks;
     info[4] = h->lds_bytes;
-    info[5] = h->trusted ? 1 : 0;
+    info[5] = (h->trusted && (h->n_alert_set < 0 || h->trust_copies)) ? 1 : 0;
     info[6] = h->tables_in_lds ? 1 : 0;
     info[7] = h->n_alert_set >= 0 ? 1 : 0;
     if (index_ms) *index_ms = h->index_ms;

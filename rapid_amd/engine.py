@@ -294,10 +294,12 @@ class ClusterSimulation:
         self.e._check(self.e._lib.rapid_sim_load_streams_device(self.e._h, d_records_ptr, records_bytes, d_rec_off_ptr,
                                                                 n_receivers))
 
-    def set_alert_set(self, alerts):
-        """Declares the round's distinct alerts (see rapid_sim_set_alert_set)."""
+    def set_alert_set(self, alerts, trust_copies=False):
+        """Declares the round's distinct alerts (see rapid_sim_set_alert_set).  trust_copies: the caller vouches that every
+        delivered record is a byte copy of one of them, configuration id included (rapid_sim_trust_alert_copies)."""
         alerts = np.ascontiguousarray(alerts, dtype=ALERT_DTYPE)
         self.e._check(self.e._lib.rapid_sim_set_alert_set(self.e._h, _addr(alerts) if len(alerts) else None, len(alerts)))
+        self.e._check(self.e._lib.rapid_sim_trust_alert_copies(self.e._h, 1 if trust_copies else 0))
 
     def tally(self):
         self.e._check(self.e._lib.rapid_sim_tally(self.e._h))
@@ -389,3 +391,35 @@ class ClusterSimulation:
 
     def set_force_exact(self, on):
         self.e._check(self.e._lib.rapid_sim_set_force_exact(self.e._h, int(on)))
+
+
+class ObserverCacheGuard:
+    """Quirk Q4 of the reference (R/MembershipView.java:143-152, 181-195, 210-224): getObserversOf is memoised per node of the
+    cluster and an entry survives a view change that moves the ring minimum.  The only reader on the hot path is
+    invalidateFailingEdges (R/MultiNodeCutDetector.java:147-149), which asks for the observers of the subjects in
+    preProposal -- subjects the round's alerts name on >= L rings ("hot").  The engine always works from the fresh tables,
+    so its results equal the reference's as long as no receiver can hold a STALE entry for a subject that is hot now:
+    i.e. as long as no member that is hot in this round was hot in an earlier configuration with different observers
+    (an entry only exists where it was asked for; a crashed subject's entry dies with its ringDelete).  This guard keeps
+    that condition, exactly, on the host: `check_round` returns the members for which it fails (empty: Q4 cannot fire at
+    any receiver in this round; non-empty: bit-exactness against the Java is not guaranteed for this round and the
+    caller must say so)."""
+
+    def __init__(self):
+        self.cached = {}  # node -> observer list when it was first hot (what a receiver's cache may still hold)
+
+    def check_round(self, view, hot_nodes):
+        hot_members = [int(x) for x in hot_nodes if view.isHostPresent(int(x))]
+        at_risk = []
+        for node in hot_members:
+            fresh = view.getObserversOf(node)
+            old = self.cached.get(node)
+            if old is not None and old != fresh:
+                at_risk.append(node)
+            if old is None:
+                self.cached[node] = fresh
+        return at_risk
+
+    def on_view_change(self, removed):
+        for node in removed:  # ringDelete erases the node's own entry (R/MembershipView.java:187-191)
+            self.cached.pop(int(node), None)

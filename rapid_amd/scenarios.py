@@ -167,13 +167,15 @@ def churn_batches(obs, member, crashed, joiners, cfg_id):
 
 
 def build_churn_scenario(obs, member, cfg_id, n_crash, n_join, H, L, seed_fault=1, seed_delivery=2, receivers=None,
-                         materialise=True):
-    """`n_crash` seeded members crash and `n_join` seeded non-members join; receivers = the surviving members."""
+                         materialise=True, eligible_joiners=None):
+    """`n_crash` seeded members crash and `n_join` seeded non-members join; receivers = the surviving members.
+    eligible_joiners: the non-members that may join (default: all of them; a node that was a member before cannot come
+    back under its old NodeId, R/MembershipView.java:127-131)."""
     n, K = obs.shape
     is_member = np.asarray(member) != 0
     rng = np.random.Generator(np.random.PCG64(seed_fault))
     members = np.flatnonzero(is_member)
-    outsiders = np.flatnonzero(~is_member)
+    outsiders = np.flatnonzero(~is_member) if eligible_joiners is None else np.asarray(eligible_joiners, dtype=np.int64)
     assert n_crash <= len(members) and n_join <= len(outsiders)
     crashed = np.sort(rng.permutation(members)[:n_crash]).astype(np.int32)
     joiners = np.sort(rng.permutation(outsiders)[:n_join]).astype(np.int32)
@@ -241,6 +243,9 @@ CONFIGS = {
     "C3a": dict(n=10000, K=10, H=9, L=4, f=500, kind="ingress"),
     "C3b": dict(n=10000, K=10, H=9, L=4, f=500, kind="ingress_closed"),
     "C4": dict(n=100000, K=10, H=9, L=4, f=1000, kind="crash"),
+    # C5 = BASELINE configs[4]: continuous churn, a fresh 1 % of the members crashes in every round (plus joins), 1 % of the
+    # delivered records still carry the previous configuration id; see StreamingChurn
+    "C5": dict(n=1000000, K=10, H=9, L=4, f=10000, kind="stream"),
 }
 
 
@@ -270,3 +275,46 @@ def build_scenario(name, subj, cfg_id, seed_fault=1, seed_delivery=2, receivers=
     if materialise:
         sc.records, sc.rec_off, sc.n_batches_delivered = deliver(bs, rx, seed_delivery, loss)
     return sc
+
+
+class StreamingChurn:
+    """C5: rounds of continuous churn over one population (BASELINE configs[4]).  Every round takes the CURRENT
+    view (observer table + membership, after the previous round's cut was applied), crashes `crash_frac` of the members
+    and lets `join_frac` x members outsiders join, delivers the round's batches to a seeded sample of the surviving
+    members, and replaces `stale_rate` of the delivered records' configuration ids by the PREVIOUS configuration's id
+    (late deliveries of the last round: filtered by R/MembershipService.java:653-657).  The registry must hold the
+    joiners of all rounds as non-members: `Population.make(n_members + spare)`."""
+
+    def __init__(self, H, L, crash_frac=0.01, join_frac=0.005, stale_rate=0.01, receivers_per_round=None, seed=5):
+        self.H, self.L = H, L
+        self.crash_frac, self.join_frac, self.stale_rate = crash_frac, join_frac, stale_rate
+        self.receivers_per_round = receivers_per_round
+        self.seed = seed
+        self.round = 0
+        self.prev_cfg = None
+        self.ever_member = None  # identifiers are never pruned (quirk Q5): a node joins once
+
+    def next_round(self, obs, member, cfg_id, receivers=None):
+        is_member = np.asarray(member) != 0
+        self.ever_member = is_member.copy() if self.ever_member is None else (self.ever_member | is_member)
+        fresh = np.flatnonzero(~self.ever_member)
+        n_members = int(is_member.sum())
+        n_out = len(fresh)
+        n_crash = max(1, int(round(self.crash_frac * n_members)))
+        n_join = min(n_out, int(round(self.join_frac * n_members)))
+        sc = build_churn_scenario(obs, member, cfg_id, n_crash, n_join, self.H, self.L, seed_fault=self.seed + 1000 * self.round,
+                                  materialise=False, eligible_joiners=fresh)
+        rx = sc.receivers
+        if receivers is not None:
+            rx = np.asarray(receivers, dtype=np.int32)
+        elif self.receivers_per_round is not None and self.receivers_per_round < len(rx):
+            rng = np.random.Generator(np.random.PCG64([self.seed, self.round, 77]))
+            rx = np.sort(rng.permutation(rx)[: self.receivers_per_round]).astype(np.int32)
+        sc.receivers = rx
+        stale = self.prev_cfg is not None and self.stale_rate > 0
+        sc.records, sc.rec_off, sc.n_batches_delivered = deliver(sc.batches, rx, self.seed + 31 * self.round,
+                                                                 stale_cfg=self.prev_cfg if stale else None,
+                                                                 stale_rate=self.stale_rate if stale else 0.0)
+        self.prev_cfg = cfg_id
+        self.round += 1
+        return sc

@@ -55,7 +55,7 @@ for rnd in range(rounds):
         E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
         sim = E.ClusterSimulation(eng)
         sim.load_streams(sc.records, sc.rec_off)
-        sim.set_alert_set(sc.batches.recs)
+        sim.set_alert_set(sc.batches.recs, trust_copies=True)
         ms = sim.time_tally(reps)
         emit, nprop, pcount, fp = sim.results()
         if reference is None:

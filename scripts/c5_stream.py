@@ -1,0 +1,56 @@
+"""BASELINE configs[4] on one MI355X at a single-GPU-sized N: consecutive rounds of continuous churn (1 % crashes + 0.5 % joins
+per round, 1 % of the delivered records stale), cut applied after every round.  Prints per round: records, the tally kernel
+time, the whole round (index + tally + votes) and the view change, in records/s.
+    python scripts/c5_stream.py [members=100000] [rounds=5] [receivers_per_round=4000]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rapid_amd import engine as E  # noqa: E402
+from rapid_amd import scenarios as S  # noqa: E402
+
+n_mem = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+n_rx = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
+K, H, L = 10, 9, 4
+pop = S.Population.make(n_mem + int(0.006 * n_mem * rounds) + 64)
+eng = E.Engine(n_max=pop.n, K=K, H=H, L=L)
+view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo, members=list(range(n_mem)))
+st = S.StreamingChurn(H, L, receivers_per_round=n_rx)
+guard = E.ObserverCacheGuard()
+sim = E.ClusterSimulation(eng)
+for rnd in range(rounds):
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sc = st.next_round(obs, member, cfg)
+    at_risk = guard.check_round(view, sc.faulty)
+    sim.load_streams(sc.records, sc.rec_off)
+    sim.set_alert_set(sc.batches.recs)  # index from the round's alerts; late deliveries are among the records: no trust
+    kern_ms = sim.time_tally(5)
+    eng.sync()
+    t = time.perf_counter()
+    sim.new_round()
+    sim.tally()
+    rr = sim.count_votes()
+    round_ms = 1e3 * (time.perf_counter() - t)
+    emit, nprop, pcount, fp = sim.results()
+    cut = sc.faulty.tolist()  # what every announcing receiver proposes (most stay blocked by the stale records at this size)
+    t = time.perf_counter()
+    new_cfg = sim.apply_cut(cut)
+    eng.sync()
+    apply_ms = 1e3 * (time.perf_counter() - t)
+    guard.on_view_change(sc.crashed)
+    info = sim.index_info()
+    print(json.dumps({"round": rnd, "members": int((member != 0).sum()), "receivers": len(sc.receivers), "records": int(len(sc.records)),
+                      "stale_records": int((sc.records["cfg_id"] != cfg).sum()), "cut": len(cut), "crashed": len(sc.crashed),
+                      "joined": len(sc.joiners), "proposing": int((emit >= 0).sum()), "votes_winner": int(rr.votes_winner),
+                      "kernel_ms": round(kern_ms, 4), "kernel_records_per_s": round(len(sc.records) / kern_ms * 1e3, 1),
+                      "kernel_frac_of_8TBps": round(20 * len(sc.records) / kern_ms / 1e6 / 8000, 4),
+                      "round_ms": round(round_ms, 3), "round_records_per_s": round(len(sc.records) / round_ms * 1e3, 1),
+                      "apply_cut_ms": round(apply_ms, 3), "tables_in_lds": info["tables_in_lds"], "hot_subjects": info["hot_subjects"],
+                      "q4_at_risk": at_risk, "config_id": int(new_cfg)}), flush=True)

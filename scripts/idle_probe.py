@@ -21,7 +21,7 @@ for w in (8, 10, 13, 16):
     os.environ["RAPID_TALLY_WAVES"] = str(w)
     sim = E.ClusterSimulation(eng)
     sim.load_streams(sc.records, sc.rec_off)
-    sim.set_alert_set(sc.batches.recs)
+    sim.set_alert_set(sc.batches.recs, trust_copies=True)
     out = []
     for knob in (32, 32 | 4, 32 | 16, 0, 4):
         sim.set_force_exact(knob)

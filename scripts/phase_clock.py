@@ -12,7 +12,7 @@ obs, subj, member = view.tables()
 sc = S.build_scenario("C3b", subj, view.getCurrentConfigurationId())
 sim = E.ClusterSimulation(eng)
 sim.load_streams(sc.records, sc.rec_off)
-sim.set_alert_set(sc.batches.recs)
+sim.set_alert_set(sc.batches.recs, trust_copies=True)
 print("tally_ms (back-to-back launches)", round(sim.time_tally(5), 4))
 sim.tally()
 emit, nprop, pcount, fpw = sim.results()

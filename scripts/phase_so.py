@@ -11,7 +11,7 @@ obs, subj, member = view.tables()
 sc = S.build_scenario("C3b", subj, view.getCurrentConfigurationId())
 sim = E.ClusterSimulation(eng)
 sim.load_streams(sc.records, sc.rec_off)
-sim.set_alert_set(sc.batches.recs)
+sim.set_alert_set(sc.batches.recs, trust_copies=True)
 sim.set_force_exact(32)
 ms = sim.time_tally(3)
 s = np.zeros(8, dtype=np.uint64)

@@ -16,7 +16,7 @@ obs, subj, member = view.tables()
 sc = S.build_scenario(name, subj, view.getCurrentConfigurationId())
 sim = E.ClusterSimulation(eng)
 sim.load_streams(sc.records, sc.rec_off)
-sim.set_alert_set(sc.batches.recs)
+sim.set_alert_set(sc.batches.recs, trust_copies=True)
 reps = 3
 ms = sim.time_tally(reps)
 s = np.zeros(8, dtype=np.uint64)

@@ -8,6 +8,6 @@ eng=E.Engine(n_max=n,K=K,H=H,L=L)
 view=E.MembershipView(eng).build(pop.hostnames,pop.ports,pop.id_hi,pop.id_lo)
 obs,subj,member=view.tables(); cfg=view.getCurrentConfigurationId()
 sc=S.build_scenario("C3b",subj,cfg)
-sim=E.ClusterSimulation(eng); sim.load_streams(sc.records, sc.rec_off); sim.set_alert_set(sc.batches.recs)
+sim=E.ClusterSimulation(eng); sim.load_streams(sc.records, sc.rec_off); sim.set_alert_set(sc.batches.recs, trust_copies=True)
 sim.set_force_exact(32)
 print("stream_only ms", sim.time_tally(3), sim.index_info())

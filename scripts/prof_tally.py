@@ -18,7 +18,7 @@ cfg = view.getCurrentConfigurationId()
 sc = S.build_scenario(name, subj, cfg)
 sim = E.ClusterSimulation(eng)
 sim.load_streams(sc.records, sc.rec_off)
-sim.set_alert_set(sc.batches.recs)
+sim.set_alert_set(sc.batches.recs, trust_copies=True)
 ms = sim.time_tally(reps)
 st = sim.stats()
 probe = sim.stream_probe(0, 16, reps)

@@ -30,7 +30,7 @@ for rnd in range(2):
             sc = S.build_scenario(name, subj, view.getCurrentConfigurationId())
         sim = E.ClusterSimulation(eng)
         sim.load_streams(sc.records, sc.rec_off)
-        sim.set_alert_set(sc.batches.recs)
+        sim.set_alert_set(sc.batches.recs, trust_copies=True)
         out = []
         for knob in (0, 64, 32, 32 | 64):
             sim.set_force_exact(knob)

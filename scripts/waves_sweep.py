@@ -23,7 +23,7 @@ for w in waves:
     os.environ["RAPID_TALLY_WAVES"] = str(w)
     sim = E.ClusterSimulation(eng)
     sim.load_streams(sc.records, sc.rec_off)
-    sim.set_alert_set(sc.batches.recs)
+    sim.set_alert_set(sc.batches.recs, trust_copies=True)
     ms = min(sim.time_tally(reps) for _ in range(3))
     info = sim.index_info()
     sim.set_force_exact(32)

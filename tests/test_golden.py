@@ -70,7 +70,7 @@ def test_engine_reproduces_golden(path):
         assert np.array_equal(view.getRing(k), g["rings"][k])
     sim = E.ClusterSimulation(eng)
     sim.load_streams(g["records"], g["rec_off"])
-    sim.set_alert_set(g["alert_set"])
+    sim.set_alert_set(g["alert_set"], trust_copies=True)
     sim.tally()
     emit, nprop, pcount, fp = sim.results()
     assert np.array_equal(emit, g["emit_batch"]) and np.array_equal(nprop, g["num_proposals"])

@@ -289,12 +289,12 @@ class TestCutDetectionOnDevice:
 
 
 # ------------------------------------------------------------------------------------------ population
-def run_population(E, eng, records, rec_off, force_exact=False, alert_set=None):
+def run_population(E, eng, records, rec_off, force_exact=False, alert_set=None, trust=True):
     sim = E.ClusterSimulation(eng)
     sim.set_force_exact(force_exact)
     sim.load_streams(records, rec_off)
     if alert_set is not None:
-        sim.set_alert_set(alert_set)
+        sim.set_alert_set(alert_set, trust_copies=trust)  # the generators' streams are copies of the round's alerts
     sim.tally()
     return sim, sim.results()
 
@@ -463,7 +463,7 @@ def test_churn_round_joins_and_crashes_in_one_cut(E):
     sc = S.build_churn_scenario(obs, member, cfg, n_crash, n_join, H, L)
     sim = E.ClusterSimulation(eng)
     sim.load_streams(sc.records, sc.rec_off)
-    sim.set_alert_set(sc.batches.recs)
+    sim.set_alert_set(sc.batches.recs, trust_copies=True)
     sim.tally()
     emit, nprop, pcount, fp = sim.results()
     fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=8)
@@ -714,24 +714,34 @@ def test_declared_alert_set_that_does_not_cover_the_streams_is_rejected(E):
     short = sc.batches.recs[sc.batches.recs["dst"] != sc.faulty[3]]
     sim = E.ClusterSimulation(eng)
     sim.load_streams(sc.records, sc.rec_off)
-    sim.set_alert_set(short)
+    sim.set_alert_set(short, trust_copies=True)
     sim.tally()
     with pytest.raises(E.IllegalArgumentException):
         sim.results()
     with pytest.raises(E.IllegalArgumentException):
         sim.count_votes()
+    # ... with or without the caller vouching for the deliveries: the index simply was not built for that subject
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(sc.records, sc.rec_off)
+    sim.set_alert_set(short)
+    sim.tally()
+    with pytest.raises(E.IllegalArgumentException):
+        sim.results()
     # a delivered record with the wrong status for its subject (an UP alert about a member), set otherwise honest
     bad = sc.records.copy()
     k = int(np.flatnonzero(np.isin(bad["dst"], sc.faulty))[5])
     bad["status"][k] = S.UP
     sim = E.ClusterSimulation(eng)
     sim.load_streams(bad, sc.rec_off)
-    sim.set_alert_set(sc.batches.recs)
+    sim.set_alert_set(sc.batches.recs, trust_copies=True)
     sim.tally()
     with pytest.raises(E.IllegalArgumentException):
         sim.results()
-    # the same streams without a declaration: the per-delivery filter drops that record, as the reference does
+    # the same streams without the promise (index from the set, filter per delivery) and without a declaration: the filter
+    # drops that record, as the reference does
+    sim, res2b = run_population(E, eng, bad, sc.rec_off, alert_set=sc.batches.recs, trust=False)
     sim, res2 = run_population(E, eng, bad, sc.rec_off)
+    assert all(np.array_equal(a, b) for a, b in zip(res2, res2b))
     fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, bad, sc.rec_off, nthreads=8)
     assert np.array_equal(res2[0], fe) and np.array_equal(res2[2], np.diff(fo))
     # a set stamped with another configuration id is not trusted at all: same results as without it
@@ -794,3 +804,108 @@ def test_c4_shaped_shard_against_fast_oracle(E):
     assert np.all(fe >= 0) and sorted(sim.proposal(0)) == sc.faulty.tolist()
     rr = sim.count_votes()
     assert rr.votes_winner == len(rx) and rr.decided == 0 and rr.quorum == n - (n - 1) // 4  # a shard alone has no quorum
+
+
+# ------------------------------------------------------------------ C5: streaming rounds, stale records, quirk Q4
+def _oracle_decide(oview, K, H, L, pop, sc, cut):
+    """decideViewChange on the oracle: it learns the joiners' NodeIds from the UP alerts (only the batches that carry one
+    are replayed: the faithful detector is quadratic in the number of subjects in flux)."""
+    svc = O.AlertBatchService(oview, K, H, L, pop.id_hi, pop.id_lo)
+    r0 = sc.records[sc.rec_off[0]:sc.rec_off[1]]
+    beg = 0
+    for e in np.flatnonzero(r0["flags"] & S.FLAG_LAST_IN_BATCH) + 1:
+        b = r0[beg:int(e)]
+        if np.any((b["status"] == S.UP) & (b["cfg_id"] == oview.getCurrentConfigurationId())):
+            svc.handleBatchedAlertMessage(b)
+        beg = int(e)
+    svc.decideViewChange(cut)
+
+
+def test_streaming_rounds_with_stale_records_and_the_observer_cache(E):
+    """BASELINE configs[4] (continuous churn) at a size the faithful oracle can follow: six consecutive rounds over one
+    population -- a fresh 1 % of the members crashes and 0.5 % joins in every round, 1 % of the delivered records still carry
+    the previous configuration id (R/MembershipService.java:653-657), the decided cut is applied
+    (R/MembershipService.java:385-430) and the next round runs in the new configuration.  Every round: the engine's
+    per-receiver results equal the optimised oracle on all receivers and the FAITHFUL oracle -- whose view keeps its
+    observer cache across the rounds, quirk Q4 -- on a sample; the new configuration id and the observer table equal the
+    oracle's; and the Q4 guard shows that no receiver can hold a stale cache entry for a subject in flux."""
+    K, H, L = 10, 9, 4
+    n_mem, spare, rounds = 10000, 400, 6
+    pop = S.Population.make(n_mem + spare)
+    members = list(range(n_mem))
+    eng, view = make_engine(E, pop, K, H, L, members=members)
+    reg, oview = oracle_view(pop, K, members)
+    st = S.StreamingChurn(H, L, receivers_per_round=300)
+    guard = E.ObserverCacheGuard()
+    sim = E.ClusterSimulation(eng)
+    n = pop.n
+    for rnd in range(rounds):
+        obs, subj, member = view.tables()
+        cfg = view.getCurrentConfigurationId()
+        assert cfg == oview.getCurrentConfigurationId()
+        sc = st.next_round(obs, member, cfg)
+        if rnd > 0:
+            assert 0 < int((sc.records["cfg_id"] != cfg).sum()) < len(sc.records) // 50  # the stale records are there
+        # Q4: no member that is in flux now was in flux (= queried, cached) in an earlier configuration with other observers
+        assert guard.check_round(view, sc.faulty) == []
+        for s_ in sc.crashed[:: max(1, len(sc.crashed) // 25)]:
+            assert oview.getObserversOf(int(s_)) == oview.computeObserversOf(int(s_)) == view.getObserversOf(int(s_))
+        sim.load_streams(sc.records, sc.rec_off)
+        sim.set_alert_set(sc.batches.recs)  # the index from the round's alerts; the deliveries are NOT vouched for (stale records)
+        sim.tally()
+        emit, nprop, pcount, fp = sim.results()
+        fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=16)
+        assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
+        assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
+        m = 40  # the faithful restatement, observer cache carried over from the earlier rounds (single-threaded)
+        oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, sc.records[: sc.rec_off[m]], sc.rec_off[: m + 1],
+                                   prewarm_observers=False)
+        assert np.array_equal(emit[:m], oe) and np.array_equal(nprop[:m], on)
+        assert np.array_equal(fp[:m], proposal_fingerprints(oo, op, oe >= 0))
+        first = int(np.flatnonzero(fe >= 0)[0])
+        cut = sorted(fpp[fo[first]:fo[first + 1]].tolist())
+        assert cut == sc.faulty.tolist()
+        new_cfg = sim.apply_cut(cut)
+        _oracle_decide(oview, K, H, L, pop, sc, cut)
+        guard.on_view_change(sc.crashed)
+        assert new_cfg == oview.getCurrentConfigurationId()
+        assert view.getMembershipSize() == oview.getMembershipSize()
+    o2, s2, m2 = view.tables()
+    oo2, os2, om2 = oview.tables(n)
+    assert np.array_equal(m2, om2) and np.array_equal(s2, os2) and np.array_equal(o2, oo2)
+
+
+def test_streaming_rounds_at_100k_nodes(E):
+    """The same stream at N = 100,000 (a single-GPU-sized slice of BASELINE configs[4]): three rounds, 1,000 crashes + 500 joins
+    each, against the optimised oracle on every simulated receiver; configuration ids against the oracle's view."""
+    K, H, L = 10, 9, 4
+    n_mem, spare, rounds = 100000, 2000, 3
+    pop = S.Population.make(n_mem + spare)
+    members = list(range(n_mem))
+    eng, view = make_engine(E, pop, K, H, L, members=members)
+    reg, oview = oracle_view(pop, K, members)
+    st = S.StreamingChurn(H, L, receivers_per_round=192)
+    sim = E.ClusterSimulation(eng)
+    for rnd in range(rounds):
+        obs, subj, member = view.tables()
+        cfg = view.getCurrentConfigurationId()
+        assert cfg == oview.getCurrentConfigurationId()
+        sc = st.next_round(obs, member, cfg)
+        sim.load_streams(sc.records, sc.rec_off)
+        sim.set_alert_set(sc.batches.recs)  # the index from the round's alerts; the deliveries are NOT vouched for (stale records)
+        sim.tally()
+        emit, nprop, pcount, fp = sim.results()
+        fe, fn, fo, fpp = O.fast_sim_run(pop.n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=16)
+        assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
+        assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
+        # with 1,500 subjects in flux and 1 % of the reports lost to the stale configuration id, most receivers stay blocked
+        # (a subject short of H blocks the proposal); whoever does announce announces the whole fault set, which is the cut
+        # the round eventually settles on
+        for r_ in np.flatnonzero(fe >= 0)[:5]:
+            assert sorted(fpp[fo[r_]:fo[r_ + 1]].tolist()) == sc.faulty.tolist()
+        cut = sc.faulty.tolist()
+        new_cfg = sim.apply_cut(cut)
+        _oracle_decide(oview, K, H, L, pop, sc, cut)
+        assert new_cfg == oview.getCurrentConfigurationId() and view.getMembershipSize() == oview.getMembershipSize()
+        for s_ in (int(sc.joiners[0]), int(sc.receivers[0]), int(sc.receivers[-1])):
+            assert view.getObserversOf(s_) == oview.computeObserversOf(s_)
