@@ -333,7 +333,8 @@ int rapid_sim_stats(rapid_engine* h, uint64_t stats[8]);
 /* average duration (ms) of the tally kernel over `reps` back-to-back launches, HIP events on the engine stream */
 int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg);
 /* the per-round index of the loaded streams (built on demand): info = {hot subjects, adjacency entries, waves per
- * workgroup, workgroups, LDS bytes per workgroup, alerts pre-validated (0/1), tables staged in LDS (0/1), alert set
+ * workgroup, workgroups, LDS bytes per workgroup, alerts pre-validated (0/1), dictionary placement (0 = memory, 1 = direct
+ * tables in LDS, 2 = compressed tables in LDS), alert set
  * declared (0/1)}; index_ms = device time of the last index build */
 int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms);
 /* measurement probe (not a product path): stream the loaded records with the tally kernel's access pattern and no
@@ -342,8 +343,9 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms);
  * 9: 1 KiB x 6.  `waves` = waves per workgroup (16 waves per CU unless RAPID_PROBE_WAVES_PER_CU says otherwise) */
 int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, int32_t reps, float* ms_avg);
 /* testing / measurement knob, a bit set (0 = normal): 1 = every window through the exact sequential path, 8 = careful
- * path only (no cold / fast windows), 64 = never trust the pre-validation of the alert set, 128 = leave the node -> slot
- * dictionary in memory even when it fits the LDS (the mode of populations too large for it), 32 = measurement only:
+ * path only (no cold / fast windows), 64 = never trust the pre-validation of the alert set, 128 = no direct node -> slot
+ * tables in LDS even when they fit (the compressed form of large populations is used instead), 256 = dictionary in
+ * memory (the mode of populations too large even for that), 32 = measurement only:
  * stream the records through the registers without tallying them (results are meaningless) */
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);
 

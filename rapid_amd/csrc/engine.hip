@@ -117,7 +117,11 @@ struct rapid_engine {
     bool trust_copies = false;  // the caller's promise that every delivered record is a byte copy of a declared alert
     DevBuf<unsigned int> d_adj;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // timing events, created once (no create / destroy per call, nothing to leak on an error path)
-    DevBuf<unsigned short> d_dict, d_decl, d_adj_off;
+    DevBuf<unsigned short> d_dict, d_decl, d_adj_off, d_trank;
+    DevBuf<unsigned int> d_tbits, d_tent;  // compressed dictionary (index_build_block_kernel)
+    int n_touched = 0;
+    int dict_mode = 1;  // rapid::kDictDirect / kDictCompressed / kDictMemory
+    bool lds_attr_set = false;
     DevBuf<unsigned int> d_errflags;  // sticky per loaded stream set: bit0 = a delivered report is not covered by the declared alert set
     DevBuf<int> d_node_of_slot, d_idxwork;  // d_idxwork = gmask[N] | info[8] of the round index build
     int n_slots = 0, n_hot = 0, n_adj = 0;
@@ -352,6 +356,10 @@ int build_round_index(rapid_engine* h) {
     HIPCHK(h, h->d_decl.ensure((size_t)N));
     HIPCHK(h, h->d_node_of_slot.ensure((size_t)N));
     HIPCHK(h, h->d_adj_off.ensure((size_t)N + 1));
+    const int tent_cap = 16384;  // touched nodes the compressed dictionary can hold (64 KiB of LDS)
+    HIPCHK(h, h->d_tbits.ensure((size_t)(N + 31) / 32 + 1));
+    HIPCHK(h, h->d_trank.ensure((size_t)(N + 31) / 32 + 1));
+    HIPCHK(h, h->d_tent.ensure((size_t)tent_cap));
     unsigned int* const d_gmask = reinterpret_cast<unsigned int*>(h->d_idxwork.p);
     int* const d_info = h->d_idxwork.p + (size_t)N;
     if (!h->ev0) HIPCHK(h, hipEventCreate(&h->ev0));
@@ -370,8 +378,8 @@ int build_round_index(rapid_engine* h) {
     const int adj_cap = 65536;
     HIPCHK(h, h->d_adj.ensure((size_t)adj_cap + 1));
     hipLaunchKernelGGL(rapid::index_build_block_kernel, dim3(1), dim3(1024), 0, st, d_gmask, h->d_member.p, h->d_obs.p, N, K, L,
-                       h->d_dict.p, h->d_decl.p, h->d_node_of_slot.p, h->d_adj_off.p, h->d_adj.p, adj_cap, d_info,
-                       reinterpret_cast<volatile int*>(h->d_mail));
+                       h->d_dict.p, h->d_decl.p, h->d_node_of_slot.p, h->d_adj_off.p, h->d_adj.p, adj_cap, h->d_tbits.p, h->d_trank.p,
+                       h->d_tent.p, tent_cap, d_info, reinterpret_cast<volatile int*>(h->d_mail));
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
@@ -386,18 +394,30 @@ int build_round_index(rapid_engine* h) {
     h->n_slots = info[0];
     h->n_hot = info[1];
     h->n_adj = h->n_hot > 0 ? info[3] : 0;
+    h->n_touched = info[5];
+    const bool compressed_ok = info[6] != 0;
 
     // ---- launch geometry: fill the CU's LDS with as many receiver-waves as possible ----
     const int lds_max = 160 * 1024;
     const int per_wave = rapid::tally_wave_bytes(h->n_slots);
-    const int shared = rapid::tally_shared_bytes(N, h->n_hot, h->n_adj);  // with the node -> slot dictionary staged in LDS
-    const int shared_small = rapid::tally_shared_bytes(0, h->n_hot, h->n_adj);  // dictionary left in memory
-    if (shared_small + per_wave + rapid::kBlockStatsBytes > lds_max)
+    const int sh_direct = rapid::tally_shared_bytes(rapid::kDictDirect, N, h->n_touched, h->n_hot, h->n_adj);
+    const int sh_comp = rapid::tally_shared_bytes(rapid::kDictCompressed, N, h->n_touched, h->n_hot, h->n_adj);
+    const int sh_mem = rapid::tally_shared_bytes(rapid::kDictMemory, N, h->n_touched, h->n_hot, h->n_adj);
+    if (sh_mem + per_wave + rapid::kBlockStatsBytes > lds_max)
         return fail(h, RAPID_ECAPACITY, "%d subjects need %d B of LDS per receiver (max %d)", h->n_slots,
-                    shared_small + per_wave + rapid::kBlockStatsBytes, lds_max);
-    // the dictionary goes to LDS when at least four receivers still fit next to it (bit 7 of the testing knob: never)
-    h->tables_in_lds = shared + 4 * per_wave + rapid::kBlockStatsBytes <= lds_max && (h->force_exact & 128) == 0;
-    const int sh = h->tables_in_lds ? shared : shared_small;
+                    sh_mem + per_wave + rapid::kBlockStatsBytes, lds_max);
+    // Where the node -> slot dictionary lives: in LDS as plain tables (4 B per node) when at least eight receivers still fit
+    // next to them; else compressed (3 bits per node + 4 B per node the alert set names: 100,000 nodes in ~25 KB); else in
+    // memory.  Testing knob: bit 7 = never direct, bit 8 = never in LDS at all.
+    const bool no_direct = (h->force_exact & (128 | 256)) != 0, no_lds = (h->force_exact & 256) != 0;
+    if (!no_direct && sh_direct + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
+        h->dict_mode = rapid::kDictDirect;
+    else if (!no_lds && compressed_ok && sh_comp + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
+        h->dict_mode = rapid::kDictCompressed;
+    else
+        h->dict_mode = rapid::kDictMemory;
+    h->tables_in_lds = h->dict_mode != rapid::kDictMemory;
+    const int sh = h->dict_mode == rapid::kDictDirect ? sh_direct : h->dict_mode == rapid::kDictCompressed ? sh_comp : sh_mem;
     // Waves per CU (one workgroup per CU, its receivers claimed by its waves from a counter in LDS).  A CU's share of
     // the memory system is saturated by the stream loads of ~7 waves; with w waves a CU works through its n receivers in
     // floor(n / w) full rounds, each as long as w streams sharing the CU's bandwidth, plus a last round of the m
@@ -439,6 +459,10 @@ int launch_tally(rapid_engine* h) {
     p.cfg_id = h->config_id;
     p.idx.dict = h->d_dict.p;
     p.idx.decl = h->d_decl.p;
+    p.idx.tbits = h->d_tbits.p;
+    p.idx.trank = h->d_trank.p;
+    p.idx.tent = h->d_tent.p;
+    p.idx.n_touched = h->n_touched;
     p.error_flags = h->d_errflags.p;
     p.idx.node_of_slot = h->d_node_of_slot.p;
     p.idx.adj_off = h->d_adj_off.p;
@@ -458,14 +482,15 @@ int launch_tally(rapid_engine* h) {
     // pre-validated instantiation: the scanned alerts all pass the filter AND (when they are a declared set rather than the
     // delivered records themselves) the caller vouches that the deliveries are copies of them; bit6 of the testing knob: never
     const bool trusted = h->trusted && (h->n_alert_set < 0 || h->trust_copies) && (h->force_exact & 64) == 0;
-    if (h->tables_in_lds && trusted)
-        hipLaunchKernelGGL((rapid::tally_population_kernel<true, true>), grid, block, (size_t)h->lds_bytes, h->stream, p);
-    else if (h->tables_in_lds)
-        hipLaunchKernelGGL((rapid::tally_population_kernel<true, false>), grid, block, (size_t)h->lds_bytes, h->stream, p);
-    else if (trusted)
-        hipLaunchKernelGGL((rapid::tally_population_kernel<false, true>), grid, block, (size_t)h->lds_bytes, h->stream, p);
-    else
-        hipLaunchKernelGGL((rapid::tally_population_kernel<false, false>), grid, block, (size_t)h->lds_bytes, h->stream, p);
+    const size_t lds = (size_t)h->lds_bytes;
+    switch (h->dict_mode * 2 + (trusted ? 1 : 0)) {
+        case 0: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictMemory, false>), grid, block, lds, h->stream, p); break;
+        case 1: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictMemory, true>), grid, block, lds, h->stream, p); break;
+        case 2: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictDirect, false>), grid, block, lds, h->stream, p); break;
+        case 3: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictDirect, true>), grid, block, lds, h->stream, p); break;
+        case 4: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, false>), grid, block, lds, h->stream, p); break;
+        default: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, true>), grid, block, lds, h->stream, p); break;
+    }
     return RAPID_OK;
 }
 
@@ -478,14 +503,16 @@ int prepare_tally(rapid_engine* h) {
         if (rc) return rc;
         HIPCHK(h, hipMemsetAsync(h->d_errflags.p, 0, 2 * sizeof(unsigned int), h->stream));
     }
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel<true, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel<true, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel<false, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::tally_population_kernel<false, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (!h->lds_attr_set) {  // once per engine: every instantiation may use the whole 160 KiB of LDS
+        const void* kernels[6] = {reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, false>),
+                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, true>),
+                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictDirect, false>),
+                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictDirect, true>),
+                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictCompressed, false>),
+                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictCompressed, true>)};
+        for (const void* k : kernels) HIPCHK(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        h->lds_attr_set = true;
+    }
     const size_t R = (size_t)std::max(h->n_receivers, 1);
     HIPCHK(h, h->d_emit.ensure(R));
     HIPCHK(h, h->d_nprop.ensure(R));
@@ -558,7 +585,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
     h->d_records_own.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
-    h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release();
+    h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release(); h->d_trank.release(); h->d_tbits.release(); h->d_tent.release();
     h->d_adj_off.release(); h->d_node_of_slot.release();
     h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release(); h->d_voteback.release();
     (void)hipGetLastError();
@@ -1322,7 +1349,7 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
     info[3] = h->grid_blocks;
     info[4] = h->lds_bytes;
     info[5] = (h->trusted && (h->n_alert_set < 0 || h->trust_copies)) ? 1 : 0;
-    info[6] = h->tables_in_lds ? 1 : 0;
+    info[6] = h->dict_mode;  // 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS
     info[7] = h->n_alert_set >= 0 ? 1 : 0;
     if (index_ms) *index_ms = h->index_ms;
     return RAPID_OK;
@@ -1330,7 +1357,7 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
 
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on) {
     if (!h) return RAPID_EINVAL;
-    if (((h->force_exact ^ on) & 128) != 0) h->index_valid = false;  // the launch geometry depends on where the dictionary lives
+    if (((h->force_exact ^ on) & (128 | 256)) != 0) h->index_valid = false;  // the launch geometry depends on where the dictionary lives
     h->force_exact = on;
     return RAPID_OK;
 }

@@ -166,11 +166,14 @@ __device__ inline int block_exclusive_scan(int v, int* s_wave, int* total) {
 // (subject, observer, ring) triples of the implicit invalidation; the tally kernel needs nothing else (the mirrored
 // "e observes s" entries that index_adj_kernel also produces are not used by it any more).
 // adj has room for adj_cap entries (info[2] |= 2 if more are needed: nothing is written past it).  info_out: a second
-// copy of info[0..7] (host-mapped memory: the host reads it after synchronising, no copy is enqueued).
+// copy of info[0..7] (host-mapped memory: the host reads it after synchronising, no copy is enqueued).  info[5] = touched
+// nodes, info[6] = 1 if the compressed tables are complete (at most 65535 touched nodes and tent_cap entries).
 __global__ __launch_bounds__(1024) void index_build_block_kernel(const unsigned int* gmask, const unsigned char* member, const int* obs,
                                                                  int n_nodes, int K, int L, unsigned short* dict,
                                                                  unsigned short* decl, int* node_of_slot, unsigned short* adj_off,
-                                                                 unsigned int* adj, int adj_cap, int* info, volatile int* info_out) {
+                                                                 unsigned int* adj, int adj_cap, unsigned int* tbits,
+                                                                 unsigned short* trank, unsigned int* tent, int tent_cap, int* info,
+                                                                 volatile int* info_out) {
     __shared__ int s_wave[16];
     const int T = (int)blockDim.x, t = (int)threadIdx.x;
     // ---- slots (ascending node order), dictionary, declared ring masks ----
@@ -226,6 +229,42 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(const unsigned 
         if (at > at0) dict[node] |= (unsigned short)0x4000;  // only this thread touches dict[node] after the barrier above
     }
     if (t == T - 1 || (n_hot == 0 && t == 0)) adj_off[n_hot] = (unsigned short)(total > 65535 ? 65535 : total);
+    __threadfence_block();
+    __syncthreads();  // dict[] is final (adjacency flags included)
+    // ---- the compressed form of dict[] / decl[] for populations whose direct tables do not fit the LDS: one bit per node
+    // (touched = named by the alert set at all), touched nodes before each 32-node word, one entry per touched node ----
+    const int n_words = (n_nodes + 31) / 32;
+    const int perw = (n_words + T - 1) / T;
+    const int w0 = min(n_words, t * perw), w1 = min(n_words, w0 + perw);
+    int cnt = 0;
+    for (int w = w0; w < w1; ++w) {
+        unsigned int bits = 0u;
+        for (int b = 0; b < 32; ++b) {
+            const int n = w * 32 + b;
+            if (n < n_nodes && (decl[n] & 0x3FFFu) != 0u) bits |= 1u << b;
+        }
+        tbits[w] = bits;
+        cnt += __popc(bits);
+    }
+    int n_touched = 0;
+    int rk = block_exclusive_scan(cnt, s_wave, &n_touched);
+    const bool tfits = n_touched <= 65535 && n_touched <= tent_cap;
+    for (int w = w0; w < w1; ++w) {
+        trank[w] = (unsigned short)(rk > 65535 ? 65535 : rk);
+        unsigned int bits = tbits[w];
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1u;
+            const int n = w * 32 + b;
+            if (tfits) tent[rk] = ((unsigned int)decl[n] << 16) | ((unsigned int)dict[n] & 0x3FFFu);
+            ++rk;
+        }
+    }
+    if (t == 0) {
+        info[5] = n_touched;
+        info[6] = tfits ? 1 : 0;
+    }
+    __syncthreads();
     if (t == 0) {
         info[0] = n_hot_all;
         info[1] = n_hot_all;

@@ -82,6 +82,13 @@ constexpr unsigned int kDecEob = 1u << 29;
 struct RoundIndex {
     const unsigned short* dict;     // [n_nodes] node -> kDictMember | kDictHasAdj | slot (kNoSlot: not hot)
     const unsigned short* decl;     // [n_nodes] rings the round's alert set names for the node (all rings for a hot one) | member << 15
+    // the same two tables in compressed form, for populations whose direct tables do not fit the LDS: a node is TOUCHED if
+    // the round's alert set names it at all; tbits = one bit per node, trank[w] = touched nodes before word w,
+    // tent[rank] = (decl entry) << 16 | slot (kNoSlot: touched but not hot)
+    const unsigned int* tbits;      // [(n_nodes + 31) / 32]
+    const unsigned short* trank;    // [(n_nodes + 31) / 32]
+    const unsigned int* tent;       // [n_touched]
+    int n_touched;
     const int* node_of_slot;        // [n_hot]
     const unsigned short* adj_off;  // [n_hot + 1] CSR over hot slots
     const unsigned int* adj;        // [n_adj] other_slot | ring << 16 | role << 20 (role 0: `other` observes the slot on that ring;
@@ -111,12 +118,19 @@ struct TallyParams {
 };
 
 __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
-// LDS budget.  Shared: the node -> slot dictionary and the declared ring masks (n_dict = n_nodes when they are staged in
-// LDS, 0 when they stay in memory), the round's (subject, observer, ring) triples [count, triples ...], the per-slot masks of the rings on
+// LDS budget.  Shared: the node -> slot dictionary and the declared ring masks (direct: 4 B per node; compressed: 3 bits per
+// node + 4 B per touched node; or left in memory), the round's (subject, observer, ring) triples [count, triples ...], the per-slot masks of the rings on
 // which a hot observer watches the slot, and slot -> node.  Per wave: detector state (hot + dummy slots),
 // decoded-record scratch, undo list.
-__host__ __device__ inline int tally_shared_bytes(int n_dict, int n_hot, int n_adj) {
-    return 2 * align16(n_dict * 2) + align16((n_adj + 1) * 4) + align16((n_hot + kDummySlots) * 2) + align16(n_hot * 4);
+// dictionary placement: where node -> (slot, declared rings, member) is looked up
+enum { kDictMemory = 0, kDictDirect = 1, kDictCompressed = 2 };
+__host__ __device__ inline int tally_dict_bytes(int mode, int n_nodes, int n_touched) {
+    if (mode == kDictDirect) return 2 * align16(n_nodes * 2);
+    if (mode == kDictCompressed) return align16(((n_nodes + 31) / 32) * 4) + align16(((n_nodes + 31) / 32) * 2) + align16(n_touched * 4);
+    return 0;
+}
+__host__ __device__ inline int tally_shared_bytes(int mode, int n_nodes, int n_touched, int n_hot, int n_adj) {
+    return tally_dict_bytes(mode, n_nodes, n_touched) + align16((n_adj + 1) * 4) + align16((n_hot + kDummySlots) * 2) + align16(n_hot * 4);
 }
 // per-workgroup statistics accumulator at the very end of the dynamic LDS segment
 constexpr int kBlockStatsBytes = 80;  // eight counters + the workgroup's claim counter
@@ -367,8 +381,9 @@ struct Window {  // the dwords of kQ x 64 records that the tally looks at, lane 
 };
 enum { kApplied = 0, kWitnessFails = 1, kNotFastable = 2 };  // outcome of a fast-window attempt
 
-template <bool kTablesInLds, bool kTrusted>
+template <int kDictMode, bool kTrusted>
 __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kernel(TallyParams p) {
+    constexpr bool kTablesInLds = kDictMode == kDictDirect;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = (int)(threadIdx.x >> 6);
@@ -377,9 +392,26 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // ---- shared read-only tables ----
     // Subjects that are not hot get DUMMY slots n_hot .. n_hot + 63 (spread over the banks): a report about them is ORed
     // into a word nobody reads, so the fast window needs neither a "hot?" test nor an execution mask per record.
-    const int dict_bytes = kTablesInLds ? 2 * align16(p.n_nodes * 2) : 0;
+    const int dict_bytes = tally_dict_bytes(kDictMode, p.n_nodes, p.idx.n_touched);
     const int pairs_bytes = align16((p.idx.n_adj + 1) * 4);
-    const int shared_bytes = tally_shared_bytes(kTablesInLds ? p.n_nodes : 0, n_hot, p.idx.n_adj);
+    const int shared_bytes = tally_shared_bytes(kDictMode, p.n_nodes, p.idx.n_touched, n_hot, p.idx.n_adj);
+    const unsigned int* tbits = p.idx.tbits;
+    const unsigned short* trank = p.idx.trank;
+    const unsigned int* tent = p.idx.tent;
+    if (kDictMode == kDictCompressed) {
+        const int n_words = (p.n_nodes + 31) / 32;
+        unsigned int* l_bits = reinterpret_cast<unsigned int*>(smem);
+        unsigned short* l_rank = reinterpret_cast<unsigned short*>(smem + align16(n_words * 4));
+        unsigned int* l_ent = reinterpret_cast<unsigned int*>(smem + align16(n_words * 4) + align16(n_words * 2));
+        for (int i = (int)threadIdx.x; i < n_words; i += (int)blockDim.x) {
+            l_bits[i] = p.idx.tbits[i];
+            l_rank[i] = p.idx.trank[i];
+        }
+        for (int i = (int)threadIdx.x; i < p.idx.n_touched; i += (int)blockDim.x) l_ent[i] = p.idx.tent[i];
+        tbits = l_bits;
+        trank = l_rank;
+        tent = l_ent;
+    }
     const unsigned short* dict = p.idx.dict;
     const unsigned short* decl = p.idx.decl;
     if (kTablesInLds) {
@@ -508,26 +540,39 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         const unsigned int w3 = c.w3[q], w4 = c.w4[q];
         const unsigned int rb = w4 & d.kmask;
         const bool dn = (w4 & 0x00FF0000u) != 0u;
-        unsigned int de;
-        if (kTrusted) {
-            // every delivered record is a validated alert (or a zero past the end of the stream); the clamp only keeps a
-            // broken promise from reading outside the dictionary
-            const unsigned int idx = min(w3, node_last);
+        // de: dictionary entry (member << 15 | slot), dm: declared rings | member << 15 of the subject
+        unsigned int de, dm;
+        const bool in = w3 <= node_last && p.n_nodes > 0;
+        const unsigned int idx = min(w3, node_last);
+        if (kDictMode == kDictCompressed) {
+            // bit test + rank: two independent LDS reads, then the entry of a touched node.  A node the alert set never
+            // names has no entry: a valid report about it is exactly what the coverage check exists for.
+            const unsigned int word = tbits[idx >> 5], before = (unsigned int)trank[idx >> 5];
+            const unsigned int bit = idx & 31u;
+            const bool touched = ((word >> bit) & 1u) != 0u;
+            const unsigned int ent = touched ? tent[before + (unsigned int)__popc(word & ((1u << bit) - 1u))] : kNoSlot;
+            dm = ent >> 16;
+            de = (ent & kSlotMask) | (dm & kDictMember);
+        } else {
             de = (unsigned int)dict[idx];
+            dm = (unsigned int)decl[idx];
+        }
+        if (kTrusted) {
+            // every delivered record is vouched for as a copy of a validated alert (or is a zero past the end of the stream).
+            // What can be checked without reading the configuration id: subject in range, UP / DOWN against the membership
+            // (R/MembershipService.java:659-668), rings among those the index was built for
             r.bits = rb;
             r.down = dn;
-            // what can be checked without reading the configuration id: subject in range, UP / DOWN against the
-            // membership (R/MembershipService.java:659-668), rings among those the index was built for
-            const unsigned int dm = (unsigned int)decl[idx];
-            uncovered |= (rb & ~dm) | (w3 > node_last ? 1u : 0u) | (rb != 0u && dn != ((dm >> 15) != 0u) ? 1u : 0u);
+            uncovered |= (rb & ~dm) | (in ? 0u : 1u) | (rb != 0u && dn != ((dm >> 15) != 0u) ? 1u : 0u);
         } else {
-            const bool in = w3 < (unsigned int)p.n_nodes;
-            de = (unsigned int)dict[in ? w3 : 0u];
-            const unsigned int bad = (c.w0[kTrusted ? 0 : q] ^ cfg_lo) | (c.w1[kTrusted ? 0 : q] ^ cfg_hi) |
-                                     ((dn ? 1u : 0u) ^ (de >> 15)) | (in ? 0u : 1u) | (rb == 0u ? 1u : 0u);
+            const bool untouched = kDictMode == kDictCompressed && (de & kSlotMask) == kNoSlot && (dm & 0x3FFFu) == 0u;
+            const unsigned int bad0 = (c.w0[kTrusted ? 0 : q] ^ cfg_lo) | (c.w1[kTrusted ? 0 : q] ^ cfg_hi) | (in ? 0u : 1u) | (rb == 0u ? 1u : 0u);
+            // (the membership of a node the alert set never names is not in the compressed tables: such a report is
+            // not tallied, and flagged if it is otherwise valid)
+            const unsigned int bad = bad0 | ((dn ? 1u : 0u) ^ ((dm >> 15) & 1u)) | (untouched ? 1u : 0u);
             r.bits = bad == 0u ? rb : 0u;
             r.down = dn && bad == 0u;
-            uncovered |= r.bits & ~(unsigned int)decl[in ? w3 : 0u] & 0x3FFFu;
+            uncovered |= (untouched ? (bad0 == 0u ? rb : 0u) : (r.bits & ~dm)) & 0x3FFFu;
         }
         if (kTablesInLds) {
             r.slot = kTrusted ? de : (de & kSlotMask);  // dummy slots were assigned when the dictionary was staged

@@ -375,8 +375,9 @@ class ClusterSimulation:
         ms = C.c_float(0)
         self.e._check(self.e._lib.rapid_sim_index_info(self.e._h, _addr(info), C.byref(ms)))
         keys = ("hot_subjects", "adjacency_entries", "waves_per_workgroup", "workgroups", "lds_bytes_per_workgroup",
-                "alerts_prevalidated", "tables_in_lds", "alert_set_declared")
+                "alerts_prevalidated", "dict_mode", "alert_set_declared")
         out = {k: int(v) for k, v in zip(keys, info)}
+        out["tables_in_lds"] = int(out["dict_mode"] != 0)  # dict_mode: 0 = memory, 1 = direct tables in LDS, 2 = compressed
         out["index_build_ms"] = round(ms.value, 4)
         return out
 

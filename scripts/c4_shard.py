@@ -38,7 +38,7 @@ for tag, declare in (("filter_per_delivery", False), ("alert_set_declared", True
     ms = min(sim.time_tally(reps) for _ in range(2))
     info = sim.index_info()
     out[tag] = {"kernel_ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1), "frac_of_8TBps": round(nbytes / ms / 1e6 / 8000, 4),
-                "tables_in_lds": info["tables_in_lds"], "waves_per_workgroup": info["waves_per_workgroup"],
+                "dict_mode": info["dict_mode"], "waves_per_workgroup": info["waves_per_workgroup"],
                 "index_build_ms": round(info["index_build_ms"], 4)}
 t = time.perf_counter()
 sim.new_round()

@@ -130,7 +130,7 @@ using rapid::smem;
 extern "C" {
 int emu_window_records() { return rapid::kWin; }
 int emu_tally_wave_bytes(int n_slots) { return rapid::tally_wave_bytes(n_slots); }
-int emu_tally_shared_bytes(int n_dict, int n_hot, int n_adj) { return rapid::tally_shared_bytes(n_dict, n_hot, n_adj); }
+int emu_tally_shared_bytes(int mode, int n_nodes, int n_touched, int n_hot, int n_adj) { return rapid::tally_shared_bytes(mode, n_nodes, n_touched, n_hot, n_adj); }
 
 // Runs the population kernel: `grid` persistent workgroups of `waves` waves, one workgroup at a time.
 int emu_tally_run(const unsigned char* records, unsigned long long records_bytes, const long long* rec_off,
@@ -138,8 +138,10 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
                   const int* node_of_slot, const unsigned short* adj_off,
                   const unsigned int* adj, int n_hot, int n_adj, int* emit_batch, int* num_proposals,
                   int* prop_count, unsigned long long* fingerprint, int* props, int prop_cap, unsigned long long* stats,
-                  int flags, int waves, int grid, int tables_in_lds, unsigned long long seed) {
-    const int lds = rapid::tally_shared_bytes(tables_in_lds ? n_nodes : 0, n_hot, n_adj) + waves * rapid::tally_wave_bytes(n_hot) +
+                  int flags, int waves, int grid, int tables_in_lds, unsigned long long seed, const unsigned int* tbits,
+                  const unsigned short* trank, const unsigned int* tent, int n_touched) {
+    // tables_in_lds: 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS
+    const int lds = rapid::tally_shared_bytes(tables_in_lds, n_nodes, n_touched, n_hot, n_adj) + waves * rapid::tally_wave_bytes(n_hot) +
                     rapid::kBlockStatsBytes;
     if (lds > (int)sizeof(smem)) return -5;
     rapid::TallyParams p;
@@ -154,6 +156,10 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     p.cfg_id = cfg_id;
     p.idx.dict = dict;
     p.idx.decl = decl;
+    p.idx.tbits = tbits;
+    p.idx.trank = trank;
+    p.idx.tent = tent;
+    p.idx.n_touched = n_touched;
     static unsigned int error_flags[2];
     error_flags[0] = error_flags[1] = 0u;
     p.error_flags = error_flags;
@@ -174,14 +180,15 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     for (int b = 0; b < grid; ++b) {
         std::memset(smem, 0xCD, sizeof(smem));  // poison: the kernel must initialise what it reads
         const bool trusted = (flags & 256) != 0;  // emulator-only selector of the kTrusted instantiation
-        if (tables_in_lds && trusted)
-            emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { rapid::tally_population_kernel<true, true>(p); }, seed + (unsigned)b);
-        else if (tables_in_lds)
-            emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { rapid::tally_population_kernel<true, false>(p); }, seed + (unsigned)b);
-        else if (trusted)
-            emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { rapid::tally_population_kernel<false, true>(p); }, seed + (unsigned)b);
-        else
-            emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { rapid::tally_population_kernel<false, false>(p); }, seed + (unsigned)b);
+        auto run = [&](auto kern) { emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { kern(p); }, seed + (unsigned)b); };
+        switch (tables_in_lds * 2 + (trusted ? 1 : 0)) {
+            case 0: run(rapid::tally_population_kernel<rapid::kDictMemory, false>); break;
+            case 1: run(rapid::tally_population_kernel<rapid::kDictMemory, true>); break;
+            case 2: run(rapid::tally_population_kernel<rapid::kDictDirect, false>); break;
+            case 3: run(rapid::tally_population_kernel<rapid::kDictDirect, true>); break;
+            case 4: run(rapid::tally_population_kernel<rapid::kDictCompressed, false>); break;
+            default: run(rapid::tally_population_kernel<rapid::kDictCompressed, true>); break;
+        }
     }
     return error_flags[0] != 0u ? -1 : 0;
 }

@@ -60,7 +60,19 @@ def build_round_index(records, n_nodes, K, L, obs, member):
             dict_[node_of_slot[e]] |= 0x4000
     dict_ = dict_.astype(np.uint16)
     decl = (np.where(slot_of < n_hot, 0x3FFF, gmask & 0x3FFF) | np.where(np.asarray(member) != 0, 0x8000, 0)).astype(np.uint16)
-    return dict(dict=dict_, decl=decl, node_of_slot=np.concatenate([node_of_slot, [0]]).astype(np.int32), adj_off=adj_off,
+    # the compressed form (index_build_block_kernel): one bit per node named by the alert set, touched nodes before each
+    # 32-node word, (decl << 16 | slot) per touched node
+    touched = (decl & 0x3FFF) != 0
+    n_words = (n_nodes + 31) // 32
+    padded = np.zeros(n_words * 32, dtype=bool)
+    padded[:n_nodes] = touched
+    tbits = (padded.reshape(n_words, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+    per_word = padded.reshape(n_words, 32).sum(axis=1)
+    trank = np.concatenate([[0], np.cumsum(per_word)[:-1]]).astype(np.uint16)
+    tn = np.flatnonzero(touched)
+    tent = ((decl[tn].astype(np.uint32) << 16) | (dict_[tn].astype(np.uint32) & 0x3FFF)).astype(np.uint32)
+    tent = np.concatenate([tent, np.zeros(1, dtype=np.uint32)])
+    return dict(dict=dict_, decl=decl, tbits=tbits, trank=trank, tent=tent, n_touched=len(tn), node_of_slot=np.concatenate([node_of_slot, [0]]).astype(np.int32), adj_off=adj_off,
                 adj=adj, n_hot=n_hot, n_adj=int(adj_off[-1]))
 
 
@@ -105,7 +117,8 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     rc = L_.emu_tally_run(p(raw), C.c_ulonglong((raw.nbytes // 16) * 16), p(rec_off), R, n_nodes, K, H, L, C.c_longlong(cfg_id),
                           p(ix["dict"]), p(ix["decl"]), p(ix["node_of_slot"]), p(ix["adj_off"]), p(ix["adj"]),
                           ix["n_hot"], ix["n_adj"], p(emit), p(nprop), p(pcount), p(fp), p(props), prop_cap, p(stats),
-                          force_exact, waves, grid, tables_in_lds, C.c_ulonglong(seed))
+                          force_exact, waves, grid, tables_in_lds, C.c_ulonglong(seed), p(ix["tbits"]), p(ix["trank"]), p(ix["tent"]),
+                          ix["n_touched"])
     if declared is not None:
         assert rc in (0, -1), rc
         return emit, nprop, pcount, fp, props, stats.sum(axis=0), rc == 0

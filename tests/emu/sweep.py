@@ -2,7 +2,7 @@
 cases of tests/test_kernel_emulated.py:  python tests/emu/sweep.py <first_seed> <last_seed>
 Every seed draws a population (8..63 nodes, random membership), K, H, L, ten receiver streams of 0..699 records with
 random batch lengths, multi-ring alerts and (two seeds out of three) invalid alerts, a random number of waves per
-workgroup and of workgroups, and both table placements.  Prints the failing seeds; `done, failures: 0` otherwise."""
+workgroup and of workgroups, and the three dictionary placements (memory / direct tables / compressed tables in LDS).  Prints the failing seeds; `done, failures: 0` otherwise."""
 import os
 import sys
 
@@ -30,7 +30,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         recs.append(random_stream(rng, n_nodes, K, member, cfg, n_rec, hot, p_eob=float(rng.choice([0.02, 0.1, 0.3, 0.6, 1.0])), p_multi=float(rng.choice([0.0,0.15,0.5])), p_bad_cfg=pb, p_bad_status=pb))
         off.append(off[-1] + n_rec)
     try:
-        _check(np.concatenate(recs), np.array(off), n_nodes, K, H, L, cfg, obs, subj, member, seed=seed, waves=int(rng.integers(1,5)), grid=int(rng.integers(1,4)), tables_in_lds=int(seed%2))
+        _check(np.concatenate(recs), np.array(off), n_nodes, K, H, L, cfg, obs, subj, member, seed=seed, waves=int(rng.integers(1,5)), grid=int(rng.integers(1,4)), tables_in_lds=int(seed%3))
     except AssertionError as e:
         bad+=1; print("FAIL seed", seed, n_nodes,K,H,L, str(e)[:200])
 print("done, failures:", bad)

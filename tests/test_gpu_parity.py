@@ -754,9 +754,10 @@ def test_declared_alert_set_that_does_not_cover_the_streams_is_rejected(E):
 # ------------------------------------------------------------- the dictionary-in-memory instantiations (C4's mode)
 @pytest.mark.parametrize("name,n,f,K,H,L", [("C2", 2000, 20, 10, 9, 4), ("C3b", 1500, 40, 10, 9, 4)])
 def test_tables_in_memory_mode_vs_faithful_oracle(E, name, n, f, K, H, L):
-    """Populations whose node -> slot dictionary does not fit the LDS (N >~ 35,000) run the tally kernel with the
-    dictionary and the declared ring masks in memory.  Knob 128 forces that mode at a size the faithful oracle can
-    check: both instantiations (alert set declared / per-delivery filter) must give the oracle's results."""
+    """Populations whose plain node -> slot tables do not fit the LDS (N >~ 30,000) run the tally kernel with the
+    compressed tables (bitmap + rank) in LDS, and beyond that with the dictionary in memory.  Knobs 128 / 256 force these
+    modes at a size the faithful oracle can check: both instantiations (deliveries vouched for / per-delivery filter) of
+    both modes must give the oracle's results."""
     pop = S.Population.make(n)
     eng, view = make_engine(E, pop, K, H, L)
     reg, oview = oracle_view(pop, K)
@@ -772,13 +773,15 @@ def test_tables_in_memory_mode_vs_faithful_oracle(E, name, n, f, K, H, L):
     oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, np.concatenate(parts), sub_off, nthreads=8)
     want_fp = proposal_fingerprints(oo, op, oe >= 0)
     sim0, ref = run_population(E, eng, sc.records, sc.rec_off)
-    assert sim0.index_info()["tables_in_lds"] == 1
-    # 128: the pre-validated instantiation (every delivered alert passes the filter); | 64: per-delivery filter; | 1: exact path
-    for kw in (dict(force_exact=128), dict(force_exact=128 | 64), dict(force_exact=128, alert_set=sc.batches.recs),
-               dict(force_exact=128 | 64, alert_set=sc.batches.recs), dict(force_exact=128 | 1)):
+    assert sim0.index_info()["dict_mode"] == 1
+    # 128: compressed tables in LDS, 256: dictionary in memory; alone: the pre-validated instantiation (every delivered alert
+    # passes the filter); | 64: per-delivery filter; | 1: exact path
+    for mode_knob, mode in ((128, 2), (256, 0)):
+      for kw in (dict(force_exact=mode_knob), dict(force_exact=mode_knob | 64), dict(force_exact=mode_knob, alert_set=sc.batches.recs),
+                 dict(force_exact=mode_knob | 64, alert_set=sc.batches.recs), dict(force_exact=mode_knob | 1)):
         sim, res = run_population(E, eng, sc.records, sc.rec_off, **kw)
         info = sim.index_info()
-        assert info["tables_in_lds"] == 0 and info["alert_set_declared"] == (1 if "alert_set" in kw else 0)
+        assert info["dict_mode"] == mode and info["alert_set_declared"] == (1 if "alert_set" in kw else 0)
         assert all(np.array_equal(a, b) for a, b in zip(ref, res)), kw
         assert np.array_equal(res[0][rx], oe) and np.array_equal(res[1][rx], on) and np.array_equal(res[3][rx], want_fp)
 
@@ -798,9 +801,11 @@ def test_c4_shaped_shard_against_fast_oracle(E):
     fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=16)
     for kw in (dict(), dict(alert_set=sc.batches.recs)):
         sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off, **kw)
-        assert sim.index_info()["tables_in_lds"] == 0
+        assert sim.index_info()["dict_mode"] == 2  # 2 x 200 KB of plain tables do not fit the LDS, the compressed form does
         assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
         assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
+    sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off, force_exact=256)  # ... and from memory
+    assert sim.index_info()["dict_mode"] == 0 and np.array_equal(emit, fe) and np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
     assert np.all(fe >= 0) and sorted(sim.proposal(0)) == sc.faulty.tolist()
     rr = sim.count_votes()
     assert rr.votes_winner == len(rx) and rr.decided == 0 and rr.quorum == n - (n - 1) // 4  # a shard alone has no quorum

@@ -108,6 +108,28 @@ def test_churn_scenario(n, n_out, n_crash, n_join, K, H, L):
     _check(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member)
 
 
+@pytest.mark.parametrize("mode", [0, 2])
+def test_other_dictionary_placements(mode):
+    """The tally kernel with the node -> slot dictionary in memory (0) and as compressed tables -- bitmap + rank -- in LDS
+    (2), on scenario and adversarial streams (the other tests run the direct tables)."""
+    n, K, H, L = 300, 10, 9, 4
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K, list(range(0, n - 20)))
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_churn_scenario(obs, member, cfg, 10, 8, H, L)
+    sc = S.build_churn_scenario(obs, member, cfg, 10, 8, H, L, receivers=sc.receivers[::13])
+    _check(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode)
+    rng = np.random.default_rng(99 + mode)
+    recs, off = [], [0]
+    for r in range(12):
+        hot = rng.permutation(n)[:10]
+        n_rec = int(rng.integers(0, 600))
+        recs.append(random_stream(rng, n, K, member, cfg, n_rec, hot, p_eob=float(rng.choice([0.05, 0.5]))))
+        off.append(off[-1] + n_rec)
+    _check(np.concatenate(recs), np.array(off), n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode)
+
+
 def test_unaligned_starts_and_empty_receivers():
     n, K, H, L = 24, 5, 4, 2
     pop = S.Population.make(n)
