@@ -97,6 +97,12 @@ int rapid_device_count(void); /* number of usable gfx950 devices (0 on a CPU-onl
 int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* host_off, const int32_t* ports,
                      const int64_t* id_hi, const int64_t* id_lo, int32_t n_nodes, const int32_t* members,
                      int32_t n_members, const int64_t* extra_id_hi, const int64_t* extra_id_lo, int32_t n_extra);
+/* Appends n_new endpoints (hostname bytes, port, NodeId) to the registry, as NON-members, without touching the membership, the
+ * identifiers seen, detector instances or loaded streams: the nodes *first_index_out .. + n_new - 1 can then be named by
+ * alerts (a receiver first hears of most joiners through an UP alert, R/MembershipService.java:677-685), passed to
+ * rapid_view_ring_add, and have expected observers (:292-303).  n_max of the engine bounds the registry. */
+int rapid_view_register_endpoints(rapid_engine* h, const uint8_t* hostnames, const int32_t* host_off, const int32_t* ports,
+                                  const int64_t* id_hi, const int64_t* id_lo, int32_t n_new, int32_t* first_index_out);
 /* isSafeToJoin(Endpoint, NodeId) (:100-115) and ringAdd(Endpoint, NodeId) (:123-160): the NodeId is explicit, as in
  * the Java; a successful ringAdd records it as node's identifier.  Order of checks as in the reference:
  * identifier already seen -> RAPID_EUUID_SEEN, else already a member -> RAPID_ENODE_EXISTS. */
@@ -233,6 +239,23 @@ int rapid_decode_batched_alerts(const rapid_endpoint_map* m, const uint8_t* msg,
                                 int32_t* sender_out);
 /* one remoting.FastRoundPhase2bMessage (rapid.proto:124-129) -> sender, configuration id, the proposed endpoints in
  * message order (the vote that rapid_fast_round_vote takes) */
+/* The join path of a live service: most receivers first hear of a joiner through an UP alert (its endpoint is in no map yet,
+ * R/MembershipService.java:677-685).  rapid_decode_batched_alerts_ex decodes EVERY alert of the message and reports them
+ * one by one: status[i] = RAPID_OK (out[i] is valid), RAPID_ENODE_MISSING (an endpoint of alert i is not in the map:
+ * unresolved[2 i] / [2 i + 1] = offset and length, inside msg, of that serialized Endpoint; id_hi / id_lo[i] still carry the
+ * alert's NodeId) or RAPID_EINVAL (malformed alert).  The call itself only fails on a malformed envelope or cap < alerts.
+ * The facade registers the endpoint -- rapid_endpoint_map_add_wire here, rapid_view_register_endpoints on the engine,
+ * which hands out the same index -- and decodes the message again; nothing else of the batch is lost. */
+int rapid_decode_batched_alerts_ex(const rapid_endpoint_map* m, const uint8_t* msg, int64_t len, int32_t K,
+                                   rapid_alert_record* out, int64_t* id_hi, int64_t* id_lo, int32_t* status, int64_t* unresolved,
+                                   int32_t cap, int32_t* n_out, int32_t* sender_out);
+/* appends an endpoint (next free index) unless it is there already; node_out = its index either way */
+int rapid_endpoint_map_add(rapid_endpoint_map* m, const uint8_t* hostname, int32_t hostname_len, int32_t port, int32_t* node_out);
+/* the same from a serialized remoting.Endpoint (what `unresolved` points at) */
+int rapid_endpoint_map_add_wire(rapid_endpoint_map* m, const uint8_t* endpoint_msg, int64_t len, int32_t* node_out);
+int32_t rapid_endpoint_map_size(const rapid_endpoint_map* m);
+int rapid_endpoint_map_get(const rapid_endpoint_map* m, int32_t node, uint8_t* hostname_out, int32_t cap, int32_t* hostname_len,
+                           int32_t* port_out);
 int rapid_decode_fast_round_vote(const rapid_endpoint_map* m, const uint8_t* msg, int64_t len, int32_t* sender_out,
                                  int64_t* config_id_out, int32_t* endpoints_out, int32_t cap, int32_t* n_out);
 

@@ -115,6 +115,7 @@ def _signatures():
         "rapid_sim_new_round": (i32, [vp]),
         "rapid_sim_trust_alert_copies": (i32, [vp, i32]),
         "rapid_view_build": (i32, [vp, p, p, p, p, p, i32, p, i32, p, p, i32]),
+        "rapid_view_register_endpoints": (i32, [vp, p, p, p, p, p, i32, pi32]),
         "rapid_view_is_safe_to_join": (i32, [vp, i32, i64, i64, pi32]),
         "rapid_view_ring_add": (i32, [vp, i32, i64, i64]),
         "rapid_view_ring_delete": (i32, [vp, i32]),
@@ -154,6 +155,11 @@ def _signatures():
         "rapid_endpoint_map_lookup": (i32, [vp, p, i32, i32, pi32]),
         "rapid_decode_request": (i32, [p, i64, pi32, pi64, pi64]),
         "rapid_decode_batched_alerts": (i32, [vp, p, i64, i32, p, p, p, i32, pi32, pi32]),
+        "rapid_decode_batched_alerts_ex": (i32, [vp, p, i64, i32, p, p, p, p, p, i32, pi32, pi32]),
+        "rapid_endpoint_map_add": (i32, [vp, p, i32, i32, pi32]),
+        "rapid_endpoint_map_add_wire": (i32, [vp, p, i64, pi32]),
+        "rapid_endpoint_map_size": (i32, [vp]),
+        "rapid_endpoint_map_get": (i32, [vp, i32, p, i32, pi32, pi32]),
         "rapid_decode_fast_round_vote": (i32, [vp, p, i64, pi32, pi64, p, i32, pi32]),
         "rapid_consensus_create": (i32, [i32, i32, i64, i32, C.POINTER(vp)]),
         "rapid_consensus_destroy": (None, [vp]),

@@ -61,6 +61,8 @@ struct rapid_engine {
     // ---- registry (host) ----
     int n_nodes = 0;
     std::vector<int64_t> id_hi, id_lo;
+    std::vector<uint8_t> reg_blob;  // the registry as given to rapid_view_build (+ rapid_view_register_endpoints): hostname bytes,
+    std::vector<int> reg_off, reg_ports;  // offsets [n_nodes + 1], ports
     std::vector<uint8_t> member;  // host mirror
     int n_members = 0;
     std::set<std::pair<int64_t, int64_t>> ids_seen;  // identifiersSeen (signed lexicographic == NodeIdComparator)
@@ -620,6 +622,9 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
     h->ids_dirty = true;
 
     const size_t blob_bytes = (size_t)host_off[n_nodes];
+    h->reg_blob.assign(hostnames, hostnames + blob_bytes);
+    h->reg_off.assign(host_off, host_off + n_nodes + 1);
+    h->reg_ports.assign(ports, ports + n_nodes);
     HIPCHK(h, h->d_blob.ensure(std::max<size_t>(blob_bytes, 1)));
     HIPCHK(h, h->d_host_off.ensure((size_t)n_nodes + 1));
     HIPCHK(h, h->d_ports.ensure((size_t)n_nodes));
@@ -637,6 +642,50 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
     h->ring_member.clear();  // new endpoints, new ring keys: nothing to compact from
     h->ring_m = 0;
     return rebuild_view(h);
+}
+
+int rapid_view_register_endpoints(rapid_engine* h, const uint8_t* hostnames, const int32_t* host_off, const int32_t* ports,
+                                  const int64_t* id_hi, const int64_t* id_lo, int32_t n_new, int32_t* first_index_out) {
+    if (!h) return RAPID_EINVAL;
+    if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
+    if (n_new < 0 || (n_new > 0 && (!hostnames || !host_off || !ports || !id_hi || !id_lo)) || (n_new > 0 && host_off[0] < 0))
+        return fail(h, RAPID_EINVAL, "bad arguments to rapid_view_register_endpoints");
+    if (h->n_nodes + n_new > h->cfg.n_max)
+        return fail(h, RAPID_ECAPACITY, "%d registered endpoints + %d new exceed n_max=%d", h->n_nodes, n_new, h->cfg.n_max);
+    for (int i = 0; i < n_new; ++i)
+        if (host_off[i + 1] < host_off[i]) return fail(h, RAPID_EINVAL, "hostname offsets must not decrease");
+    if (first_index_out) *first_index_out = h->n_nodes;
+    if (n_new == 0) return RAPID_OK;
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int K = h->cfg.K, n_old = h->n_nodes, n_nodes = n_old + n_new;
+    const int base = h->reg_off[(size_t)n_old];
+    h->reg_blob.insert(h->reg_blob.end(), hostnames + host_off[0], hostnames + host_off[n_new]);
+    for (int i = 1; i <= n_new; ++i) h->reg_off.push_back(base + (host_off[i] - host_off[0]));
+    h->reg_ports.insert(h->reg_ports.end(), ports, ports + n_new);
+    h->id_hi.insert(h->id_hi.end(), id_hi, id_hi + n_new);
+    h->id_lo.insert(h->id_lo.end(), id_lo, id_lo + n_new);
+    h->member.resize((size_t)n_nodes, 0);  // registered, not members: rapid_view_ring_add admits them
+    h->n_nodes = n_nodes;
+    // the ring keys are laid out [K][n_nodes]: with another stride they are computed again for everybody (a few us per
+    // ten thousand endpoints), and the rings are sorted afresh -- the members and their order are the same
+    const size_t blob_bytes = h->reg_blob.size();
+    HIPCHK(h, h->d_blob.ensure(std::max<size_t>(blob_bytes, 1)));
+    HIPCHK(h, h->d_host_off.ensure((size_t)n_nodes + 1));
+    HIPCHK(h, h->d_ports.ensure((size_t)n_nodes));
+    HIPCHK(h, h->d_keys.ensure((size_t)K * n_nodes));
+    HIPCHK(h, h->d_hx_host0.ensure((size_t)n_nodes));
+    HIPCHK(h, h->d_hx_port0.ensure((size_t)n_nodes));
+    HIPCHK(h, hipMemcpyAsync(h->d_blob.p, h->reg_blob.data(), blob_bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_host_off.p, h->reg_off.data(), sizeof(int) * ((size_t)n_nodes + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_ports.p, h->reg_ports.data(), sizeof(int) * (size_t)n_nodes, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(rapid::ring_keys_kernel, dim3(grid_for((long long)K * n_nodes, 256)), dim3(256), 0, h->stream,
+                       h->d_blob.p, h->d_host_off.p, h->d_ports.p, n_nodes, K, h->d_keys.p, h->d_hx_host0.p, h->d_hx_port0.p);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->host_tables_valid = false;
+    h->ring_member.clear();
+    h->ring_m = 0;
+    return rebuild_view(h);  // loaded streams stay loaded (their indices are still valid); the per-round index is rebuilt
 }
 
 int rapid_view_is_safe_to_join(rapid_engine* h, int32_t node, int64_t id_hi, int64_t id_lo, int32_t* status_out) {

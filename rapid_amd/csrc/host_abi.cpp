@@ -156,6 +156,85 @@ int rapid_decode_batched_alerts(const rapid_endpoint_map* m, const uint8_t* msg,
     return RAPID_OK;
 }
 
+int rapid_endpoint_map_add(rapid_endpoint_map* m, const uint8_t* hostname, int32_t hostname_len, int32_t port, int32_t* node_out) {
+    if (!m || !node_out || hostname_len < 0 || (hostname_len > 0 && !hostname)) return RAPID_EINVAL;
+    static const uint8_t empty = 0;
+    const uint8_t* hp = hostname ? hostname : &empty;
+    const std::string key = rapid_endpoint_map::key(hp, (size_t)hostname_len, port);
+    const auto it = m->index.find(key);
+    if (it != m->index.end()) {  // already registered: the first registration wins
+        *node_out = it->second;
+        return RAPID_OK;
+    }
+    const int32_t idx = (int32_t)m->hostname.size();
+    m->hostname.emplace_back(reinterpret_cast<const char*>(hp), (size_t)hostname_len);
+    m->port.push_back(port);
+    m->index.emplace(key, idx);
+    *node_out = idx;
+    return RAPID_OK;
+}
+
+int rapid_endpoint_map_add_wire(rapid_endpoint_map* m, const uint8_t* endpoint_msg, int64_t len, int32_t* node_out) {
+    if (!m || !node_out || len < 0 || (len > 0 && !endpoint_msg)) return RAPID_EINVAL;
+    const uint8_t* host;
+    size_t host_len;
+    int32_t port;
+    if (!rapid_wire::parse_endpoint(rapid_wire::Reader(endpoint_msg, len), &host, &host_len, &port)) return RAPID_EINVAL;
+    return rapid_endpoint_map_add(m, host, (int32_t)host_len, port, node_out);
+}
+
+int32_t rapid_endpoint_map_size(const rapid_endpoint_map* m) { return m ? (int32_t)m->hostname.size() : 0; }
+
+int rapid_endpoint_map_get(const rapid_endpoint_map* m, int32_t node, uint8_t* hostname_out, int32_t cap, int32_t* hostname_len,
+                           int32_t* port_out) {
+    if (!m || node < 0 || node >= (int32_t)m->hostname.size() || cap < 0 || (cap > 0 && !hostname_out)) return RAPID_EINVAL;
+    const std::string& hn = m->hostname[(size_t)node];
+    if (hostname_len) *hostname_len = (int32_t)hn.size();
+    if (port_out) *port_out = m->port[(size_t)node];
+    if ((int32_t)hn.size() > cap) return RAPID_ECAPACITY;
+    std::memcpy(hostname_out, hn.data(), hn.size());
+    return RAPID_OK;
+}
+
+int rapid_decode_batched_alerts_ex(const rapid_endpoint_map* m, const uint8_t* msg, int64_t len, int32_t K,
+                                   rapid_alert_record* out, int64_t* id_hi, int64_t* id_lo, int32_t* status, int64_t* unresolved,
+                                   int32_t cap, int32_t* n_out, int32_t* sender_out) {
+    if (!m || (!msg && len > 0) || len < 0 || cap < 0 || (cap > 0 && (!out || !status)) || !n_out || K < 1 || K > RAPID_MAX_K)
+        return RAPID_EINVAL;
+    rapid_wire::Reader r(msg, len);
+    int32_t n = 0, sender = -1;
+    bool ok = true;
+    while (!r.done()) {
+        int wt;
+        const uint32_t f = r.tag(&wt);
+        if (f == 1 && wt == 2) {
+            sender = rapid_wire::read_endpoint(r.sub(), *m, &ok);
+        } else if (f == 3 && wt == 2) {
+            rapid_wire::Reader a = r.sub();
+            if (n < cap) {
+                std::memset(out + n, 0, sizeof(rapid_alert_record));
+                if (unresolved) unresolved[2 * n] = unresolved[2 * n + 1] = -1;
+                status[n] = rapid_wire::read_alert(a, *m, K, out + n, id_hi ? id_hi + n : nullptr, id_lo ? id_lo + n : nullptr, msg,
+                                                   unresolved ? unresolved + 2 * n : nullptr);
+            }
+            ++n;
+        } else {
+            r.skip(wt);
+        }
+    }
+    if (!r.ok || !ok) return RAPID_EINVAL;
+    *n_out = n;
+    if (sender_out) *sender_out = sender;
+    if (n > cap) return RAPID_ECAPACITY;
+    // the batch ends at its last alert, decodable or not: the flag goes on the last record the caller can use
+    for (int32_t i = n - 1; i >= 0; --i)
+        if (status[i] == RAPID_OK) {
+            out[i].flags |= RAPID_ALERT_LAST_IN_BATCH;
+            break;
+        }
+    return RAPID_OK;
+}
+
 int rapid_decode_fast_round_vote(const rapid_endpoint_map* m, const uint8_t* msg, int64_t len, int32_t* sender_out,
                                  int64_t* config_id_out, int32_t* endpoints_out, int32_t cap, int32_t* n_out) {
     if (!m || (!msg && len > 0) || len < 0 || cap < 0 || (cap > 0 && !endpoints_out) || !n_out) return RAPID_EINVAL;

@@ -106,6 +106,28 @@ inline int32_t read_endpoint(Reader r, const rapid_endpoint_map& m, bool* ok) {
     return it == m.index.end() ? -1 : it->second;
 }
 
+// Parses a serialized remoting.Endpoint into (hostname bytes, port).
+inline bool parse_endpoint(Reader r, const uint8_t** host, size_t* host_len, int32_t* port) {
+    static const uint8_t empty = 0;
+    *host = &empty;
+    *host_len = 0;
+    *port = 0;
+    while (!r.done()) {
+        int wt;
+        const uint32_t f = r.tag(&wt);
+        if (f == 1 && wt == 2) {
+            Reader h = r.sub();
+            *host = h.p;
+            *host_len = (size_t)(h.end - h.p);
+        } else if (f == 2 && wt == 0) {
+            *port = (int32_t)r.varint();
+        } else {
+            r.skip(wt);
+        }
+    }
+    return r.ok;
+}
+
 // remoting.NodeId { int64 high = 1; int64 low = 2; }
 inline void read_node_id(Reader r, int64_t* hi, int64_t* lo, bool* ok) {
     *hi = 0;
@@ -125,9 +147,15 @@ inline void read_node_id(Reader r, int64_t* hi, int64_t* lo, bool* ok) {
 
 // remoting.AlertMessage -> one packed record.  Returns RAPID_OK, RAPID_EINVAL (malformed, ring number out of range) or
 // RAPID_ENODE_MISSING (an endpoint that is not in the map).
-inline int read_alert(Reader r, const rapid_endpoint_map& m, int K, rapid_alert_record* rec, int64_t* id_hi, int64_t* id_lo) {
+// unresolved (optional): [0] / [1] = offset (from `base`) and length of the serialized Endpoint of the FIRST endpoint of the
+// alert that the map does not know (edgeSrc before edgeDst), untouched otherwise.
+inline int read_alert(Reader r, const rapid_endpoint_map& m, int K, rapid_alert_record* rec, int64_t* id_hi, int64_t* id_lo,
+                      const uint8_t* base = nullptr, int64_t* unresolved = nullptr) {
     bool ok = true;
     int32_t src = -1, dst = -1;
+    const uint8_t* src_p = nullptr;
+    const uint8_t* dst_p = nullptr;
+    int64_t src_n = 0, dst_n = 0;
     bool have_src = false, have_dst = false;
     uint32_t mask = 0;
     int64_t cfg = 0;
@@ -144,10 +172,16 @@ inline int read_alert(Reader r, const rapid_endpoint_map& m, int K, rapid_alert_
         int wt;
         const uint32_t f = r.tag(&wt);
         if (f == 1 && wt == 2) {
-            src = read_endpoint(r.sub(), m, &ok);
+            const Reader e = r.sub();
+            src_p = e.p;
+            src_n = (int64_t)(e.end - e.p);
+            src = read_endpoint(e, m, &ok);
             have_src = true;
         } else if (f == 2 && wt == 2) {
-            dst = read_endpoint(r.sub(), m, &ok);
+            const Reader e = r.sub();
+            dst_p = e.p;
+            dst_n = (int64_t)(e.end - e.p);
+            dst = read_endpoint(e, m, &ok);
             have_dst = true;
         } else if (f == 3 && wt == 0) {
             status = (uint32_t)r.varint();
@@ -166,7 +200,20 @@ inline int read_alert(Reader r, const rapid_endpoint_map& m, int K, rapid_alert_
         }
     }
     if (!r.ok || !ok || status > 1u) return RAPID_EINVAL;
-    if (!have_src || !have_dst || src < 0 || dst < 0) return RAPID_ENODE_MISSING;
+    if (id_hi) *id_hi = hi;  // the NodeId of a joiner is what the facade needs to register it
+    if (id_lo) *id_lo = lo;
+    if (!have_src || !have_dst || src < 0 || dst < 0) {
+        if (unresolved && base) {
+            if (have_src && src < 0) {
+                unresolved[0] = (int64_t)(src_p - base);
+                unresolved[1] = src_n;
+            } else if (have_dst && dst < 0) {
+                unresolved[0] = (int64_t)(dst_p - base);
+                unresolved[1] = dst_n;
+            }
+        }
+        return RAPID_ENODE_MISSING;
+    }
     rec->cfg_id = cfg;
     rec->src = (uint32_t)src;
     rec->dst = (uint32_t)dst;

@@ -125,6 +125,20 @@ class MembershipView:
         self.e._check(fn(self.e._h, *args, _addr(out), cap, C.byref(n)))
         return out[: n.value].tolist()
 
+    def registerEndpoints(self, hostnames, ports, id_hi, id_lo):
+        """Appends endpoints to the registry as non-members (rapid_view_register_endpoints); -> index of the first one."""
+        blob = np.frombuffer(b"".join(hostnames), dtype=np.uint8).copy() if len(hostnames) else np.zeros(1, dtype=np.uint8)
+        off = np.zeros(len(hostnames) + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(h) for h in hostnames])
+        ports = np.ascontiguousarray(ports, dtype=np.int32)
+        hi = np.ascontiguousarray(id_hi, dtype=np.int64)
+        lo = np.ascontiguousarray(id_lo, dtype=np.int64)
+        first = C.c_int32(-1)
+        self.e._check(self.e._lib.rapid_view_register_endpoints(self.e._h, _addr(blob), _addr(off), _addr(ports), _addr(hi), _addr(lo),
+                                                                len(hostnames), C.byref(first)))
+        self.e.n_nodes += len(hostnames)
+        return first.value
+
     def isSafeToJoin(self, node, node_id):
         s = C.c_int32(0)
         self.e._check(self.e._lib.rapid_view_is_safe_to_join(self.e._h, node, int(node_id[0]), int(node_id[1]), C.byref(s)))

@@ -60,6 +60,47 @@ class EndpointMap:
         _raise_for(rc, "rapid_decode_batched_alerts")
         return out[: n.value].copy(), list(zip(hi[: n.value].tolist(), lo[: n.value].tolist())), sender.value
 
+    def decode_batched_alerts_ex(self, msg, K, cap=4096):
+        """Every alert of the message on its own (rapid_decode_batched_alerts_ex): -> (records, node ids, status per alert,
+        serialized Endpoint of the first unknown endpoint per alert or None, sender index)."""
+        arr, a = _bytes_addr(msg)
+        out = np.zeros(cap, dtype=ALERT_DTYPE)
+        hi = np.zeros(cap, dtype=np.int64)
+        lo = np.zeros(cap, dtype=np.int64)
+        status = np.zeros(cap, dtype=np.int32)
+        unresolved = np.full(2 * cap, -1, dtype=np.int64)
+        n, sender = C.c_int32(0), C.c_int32(-1)
+        rc = self._lib.rapid_decode_batched_alerts_ex(self._h, a, len(msg), K, _addr(out), _addr(hi), _addr(lo), _addr(status),
+                                                      _addr(unresolved), cap, C.byref(n), C.byref(sender))
+        _raise_for(rc, "rapid_decode_batched_alerts_ex")
+        k = n.value
+        unknown = [bytes(msg[unresolved[2 * i]: unresolved[2 * i] + unresolved[2 * i + 1]]) if status[i] == N.ENODE_MISSING else None
+                   for i in range(k)]
+        return out[:k].copy(), list(zip(hi[:k].tolist(), lo[:k].tolist())), status[:k].tolist(), unknown, sender.value
+
+    def add(self, hostname, port):
+        """Registers an endpoint (next free index) unless it is known; -> its index."""
+        arr, a = _bytes_addr(hostname)
+        out = C.c_int32(-1)
+        _raise_for(self._lib.rapid_endpoint_map_add(self._h, a, len(hostname), port, C.byref(out)), "rapid_endpoint_map_add")
+        return out.value
+
+    def add_wire(self, endpoint_msg):
+        """The same from a serialized remoting.Endpoint."""
+        arr, a = _bytes_addr(endpoint_msg)
+        out = C.c_int32(-1)
+        _raise_for(self._lib.rapid_endpoint_map_add_wire(self._h, a, len(endpoint_msg), C.byref(out)), "rapid_endpoint_map_add_wire")
+        return out.value
+
+    def size(self):
+        return int(self._lib.rapid_endpoint_map_size(self._h))
+
+    def get(self, node):
+        buf = np.zeros(512, dtype=np.uint8)
+        ln, port = C.c_int32(0), C.c_int32(0)
+        _raise_for(self._lib.rapid_endpoint_map_get(self._h, node, _addr(buf), len(buf), C.byref(ln), C.byref(port)), "rapid_endpoint_map_get")
+        return bytes(buf[: ln.value]), int(port.value)
+
     def decode_fast_round_vote(self, msg, cap=4096):
         """-> (sender index, configuration id, endpoint indices in message order)"""
         arr, a = _bytes_addr(msg)

@@ -914,3 +914,113 @@ def test_streaming_rounds_at_100k_nodes(E):
         assert new_cfg == oview.getCurrentConfigurationId() and view.getMembershipSize() == oview.getMembershipSize()
         for s_ in (int(sc.joiners[0]), int(sc.receivers[0]), int(sc.receivers[-1])):
             assert view.getObserversOf(s_) == oview.computeObserversOf(s_)
+
+
+# ------------------------------------------------------------------ f3: serialized rapid.proto bytes -> device tally
+def test_wire_bytes_to_device_tally_with_joiners_unknown_at_start(E):
+    """SURVEY 8f rank 3 end to end: a churn round as the reference puts it on the wire -- one serialized
+    RapidRequest{BatchedAlertMessage} per sender (rapid.proto:95-129), delivered to every receiver in its own order -- goes
+    through rapid_decode_request / rapid_decode_batched_alerts_ex into packed records, is loaded and tallied on the GPU, and
+    must give what the oracle gives when it is fed the SAME messages decoded by the Python protobuf runtime.  The joiners'
+    endpoints are in neither the endpoint map nor the engine's registry when the round starts (a receiver first hears of
+    them through the UP alerts, R/MembershipService.java:677-685): the facade registers them on both sides
+    (rapid_endpoint_map_add_wire, rapid_view_register_endpoints) and decodes again; then the fast round decides and the
+    cut (crashed members out, joiners in) gives the oracle's next configuration."""
+    from rapid_amd import wire as W
+    from tests import proto_rapid as P
+    n_all, n_mem, K, H, L = 760, 700, 10, 9, 4
+    pop = S.Population.make(n_all)
+    members = list(range(n_mem))
+    reg, oview = oracle_view(pop, K, members)  # the oracle's registry holds everybody (handle == index into pop)
+    obs_o, subj_o, member_o = oview.tables(n_all)
+    cfg = oview.getCurrentConfigurationId()
+    sc = S.build_churn_scenario(obs_o, member_o, cfg, 14, 9, H, L)
+    rx = sc.receivers[:: max(1, len(sc.receivers) // 48)][:48]
+    sc = S.build_churn_scenario(obs_o, member_o, cfg, 14, 9, H, L, receivers=rx)
+
+    def ep(i):
+        return P.Endpoint(hostname=pop.hostnames[i], port=int(pop.ports[i]))
+
+    # one serialized request per batch of the round
+    bs = sc.batches
+    wire_msgs = []
+    for b in range(bs.n_batches):
+        msg = P.BatchedAlertMessage(sender=ep(int(bs.sender[b])))
+        for rec in bs.recs[bs.off[b]:bs.off[b + 1]]:
+            a = P.AlertMessage(edgeSrc=ep(int(rec["src"])), edgeDst=ep(int(rec["dst"])), edgeStatus=int(rec["status"]),
+                               configurationId=int(rec["cfg_id"]))
+            a.ringNumber.extend([k for k in range(K) if (int(rec["ring_mask"]) >> k) & 1])
+            if int(rec["status"]) == S.UP:
+                a.nodeId.high, a.nodeId.low = int(pop.id_hi[int(rec["dst"])]), int(pop.id_lo[int(rec["dst"])])
+            msg.messages.append(a)
+        wire_msgs.append(P.RapidRequest(batchedAlertMessage=msg).SerializeToString())
+    # the engine knows the members only
+    eng = E.Engine(n_max=n_all, K=K, H=H, L=L)
+    view = E.MembershipView(eng).build(pop.hostnames[:n_mem], pop.ports[:n_mem], pop.id_hi[:n_mem], pop.id_lo[:n_mem])
+    assert view.getCurrentConfigurationId() == cfg
+    emap = W.EndpointMap(pop.hostnames[:n_mem], pop.ports[:n_mem])
+    # pass 1: decode every distinct message; register what is unknown, in the order it is met
+    new_hosts, new_ports, new_hi, new_lo = [], [], [], []
+    for req in wire_msgs:
+        kind, payload = W.decode_request(req)
+        assert kind == W.MSG_BATCHED_ALERT
+        recs_, ids_, status, unknown, sender = emap.decode_batched_alerts_ex(payload, K)
+        for i, st_ in enumerate(status):
+            if st_ == E.N.ENODE_MISSING:
+                before = emap.size()
+                idx = emap.add_wire(unknown[i])
+                if idx == before:  # first time: the engine gets the same index
+                    h_, p_ = emap.get(idx)
+                    new_hosts.append(h_); new_ports.append(p_); new_hi.append(ids_[i][0]); new_lo.append(ids_[i][1])
+            else:
+                assert st_ == E.N.OK
+    assert len(new_hosts) == len(sc.joiners)
+    assert view.registerEndpoints(new_hosts, new_ports, new_hi, new_lo) == n_mem
+    assert view.getCurrentConfigurationId() == cfg  # the membership did not change
+    to_pop = {i: i for i in range(n_mem)}
+    for j, h_ in enumerate(new_hosts):
+        to_pop[n_mem + j] = pop.hostnames.index(h_)
+    # pass 2: every receiver's deliveries, message by message, in its own order (S.deliver's permutation)
+    streams, off = [], [0]
+    for r in sc.receivers:
+        rng = np.random.Generator(np.random.PCG64([2, int(r)]))
+        parts = []
+        for b in rng.permutation(bs.n_batches):
+            kind, payload = W.decode_request(wire_msgs[int(b)])
+            recs_, ids_, status, unknown, sender = emap.decode_batched_alerts_ex(payload, K)
+            assert all(s_ == E.N.OK for s_ in status)
+            parts.append(recs_)
+        streams.append(np.concatenate(parts))
+        off.append(off[-1] + len(streams[-1]))
+    records = np.concatenate(streams)
+    # the same deliveries through the Python protobuf runtime, in the oracle's numbering
+    idx_of = {(pop.hostnames[i], int(pop.ports[i])): i for i in range(n_all)}
+    o_streams = []
+    for r in sc.receivers:
+        rng = np.random.Generator(np.random.PCG64([2, int(r)]))
+        parts = []
+        for b in rng.permutation(bs.n_batches):
+            m_ = P.RapidRequest.FromString(wire_msgs[int(b)]).batchedAlertMessage
+            recs_ = np.zeros(len(m_.messages), dtype=S.ALERT_DTYPE)
+            for i, a in enumerate(m_.messages):
+                recs_[i] = (a.configurationId, idx_of[(a.edgeSrc.hostname, a.edgeSrc.port)], idx_of[(a.edgeDst.hostname, a.edgeDst.port)],
+                            sum(1 << k for k in a.ringNumber), a.edgeStatus, 0)
+            recs_["flags"][-1] = S.FLAG_LAST_IN_BATCH
+            parts.append(recs_)
+        o_streams.append(np.concatenate(parts))
+    o_records = np.concatenate(o_streams)
+    assert np.array_equal(o_records, sc.records)  # (and both equal what the generator delivers directly)
+    oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, o_records, np.array(off), nthreads=8)
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(records, np.array(off))
+    sim.tally()
+    emit, nprop, pcount, fp = sim.results()
+    assert np.array_equal(emit, oe) and np.array_equal(nprop, on) and np.array_equal(pcount, np.diff(oo))
+    for r in range(len(oe)):
+        assert sorted(to_pop[x] for x in sim.proposal(r)) == op[oo[r]:oo[r + 1]].tolist() == sc.faulty.tolist()
+    # the 48 receivers agree but are no quorum of 700: the cut they all announce is applied, joiners enter with their NodeIds
+    new_cfg = sim.apply_cut(sim.proposal(0))
+    _oracle_decide(oview, K, H, L, pop, sc, sc.faulty.tolist())
+    assert new_cfg == oview.getCurrentConfigurationId() and view.getMembershipSize() == n_mem - 14 + 9
+    for node in (n_mem, n_mem + 3):
+        assert sorted(to_pop[x] for x in view.getObserversOf(node)) == sorted(oview.getObserversOf(to_pop[node]))

@@ -142,3 +142,50 @@ def test_fast_round_vote_feeds_the_fast_round_object():
     with pytest.raises(N.NodeNotInRingException):
         m.decode_fast_round_vote(P.FastRoundPhase2bMessage(sender=ep(pop, 1), configurationId=1,
                                                            endpoints=[P.Endpoint(hostname=b"x", port=1)]).SerializeToString())
+
+
+def test_up_alert_about_an_endpoint_not_yet_in_the_map():
+    """The join path of a live service (R/MembershipService.java:677-685): most receivers first hear of a joiner through an UP
+    alert.  The map built at start-up does not know its endpoint: rapid_decode_batched_alerts_ex still decodes every other
+    alert of the batch, reports the unknown one with the bytes of its Endpoint and its NodeId, the facade registers it
+    (rapid_endpoint_map_add_wire) and the second decode yields the whole batch."""
+    n, K = 60, 10
+    pop = S.Population.make(n)
+    known = 50  # endpoints 50..59 are strangers to the map
+    m = W.EndpointMap(pop.hostnames[:known], pop.ports[:known])
+    recs = np.zeros(4, dtype=S.ALERT_DTYPE)
+    recs["src"], recs["dst"] = [3, 3, 4, 55], [7, 55, 56, 8]
+    recs["ring_mask"], recs["status"], recs["cfg_id"] = [1, 6, 8, 2], [S.DOWN, S.UP, S.UP, S.DOWN], 99
+    msg = P.BatchedAlertMessage(sender=ep(pop, 3))
+    for i, rec in enumerate(recs):
+        msg.messages.append(alert_msg(pop, rec, (100 + i, 200 + i) if rec["status"] == S.UP else None))
+    payload = msg.SerializeToString()
+    with pytest.raises(N.NodeNotInRingException):
+        m.decode_batched_alerts(payload, K)  # the all-or-nothing entry point still says so
+    got, ids, status, unknown, sender = m.decode_batched_alerts_ex(payload, K)
+    assert sender == 3 and status == [N.OK, N.ENODE_MISSING, N.ENODE_MISSING, N.ENODE_MISSING]
+    assert got[0].tobytes()[:19] == recs[0].tobytes()[:19] and got[0]["flags"] == S.FLAG_LAST_IN_BATCH  # the last usable record closes the batch
+    assert ids[1] == (101, 201) and ids[2] == (102, 202)
+    assert unknown[0] is None and P.Endpoint.FromString(unknown[1]).hostname == pop.hostnames[55]
+    assert P.Endpoint.FromString(unknown[2]).hostname == pop.hostnames[56]
+    assert P.Endpoint.FromString(unknown[3]).hostname == pop.hostnames[55]  # edgeSrc is looked at first
+    first = m.size()
+    assert first == known
+    assert m.add_wire(unknown[1]) == known and m.add_wire(unknown[2]) == known + 1 and m.add_wire(unknown[3]) == known  # idempotent
+    assert m.size() == known + 2 and m.get(known) == (pop.hostnames[55], int(pop.ports[55]))
+    got, ids, status, unknown, sender = m.decode_batched_alerts_ex(payload, K)
+    assert status == [N.OK] * 4 and unknown == [None] * 4
+    want = recs.copy()
+    want["src"], want["dst"] = [3, 3, 4, known], [7, known, known + 1, 8]  # the map's own numbering of the newcomers
+    want["flags"][-1] = S.FLAG_LAST_IN_BATCH
+    assert got.tobytes() == want.tobytes()
+    got2, ids2, sender2 = m.decode_batched_alerts(payload, K)
+    assert got2.tobytes() == want.tobytes() and ids2 == ids
+    # malformed alert inside an otherwise good batch: reported for that alert only
+    bad = P.BatchedAlertMessage(sender=ep(pop, 3))
+    bad.messages.append(alert_msg(pop, recs[0]))
+    a = alert_msg(pop, recs[0])
+    a.ringNumber.append(77)  # not a ring of this cluster
+    bad.messages.append(a)
+    got, ids, status, unknown, sender = m.decode_batched_alerts_ex(bad.SerializeToString(), K)
+    assert status == [N.OK, N.EINVAL] and got[0]["flags"] == S.FLAG_LAST_IN_BATCH
