@@ -36,6 +36,21 @@ static void throw_for(JNIEnv* env, const char* detail, int rc) {
         if (rc_ != RAPID_OK) throw_for(env, rapid_last_error(ENGINE(h)), rc_); \
     } while (0)
 
+static void throw_iae(JNIEnv* env, const char* what) {
+    (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), what);
+}
+/* [off, off + len) of a direct buffer, or NULL after throwing IllegalArgumentException: a bug in the facade becomes a Java
+ * exception, not a read or write outside the buffer in native code */
+static uint8_t* direct_region(JNIEnv* env, jobject buf, jlong off, jlong len, const char* what) {
+    uint8_t* base = buf ? (uint8_t*)(*env)->GetDirectBufferAddress(env, buf) : NULL;
+    const jlong cap = buf ? (*env)->GetDirectBufferCapacity(env, buf) : -1;
+    if (!base || cap < 0 || off < 0 || len < 0 || off > cap || len > cap - off) {
+        throw_iae(env, what);
+        return NULL;
+    }
+    return base + off;
+}
+
 static jintArray to_java(JNIEnv* env, const int32_t* v, int32_t n) {
     jintArray a = (*env)->NewIntArray(env, n);
     if (a) (*env)->SetIntArrayRegion(env, a, 0, n, (const jint*)v);
@@ -220,7 +235,13 @@ JNIEXPORT jint JNICALL Java_com_vrg_rapid_NativeCutEngine_decodeRequest(JNIEnv* 
     (void)self;
     int32_t kind = 0;
     int64_t ol[2] = {0, 0};
-    const int rc = rapid_decode_request((const uint8_t*)(*env)->GetDirectBufferAddress(env, wire), len, &kind, &ol[0], &ol[1]);
+    const uint8_t* in = direct_region(env, wire, 0, len, "wire: length outside the buffer");
+    if (!in) return -1;
+    if (!payloadOffLen || (*env)->GetArrayLength(env, payloadOffLen) < 2) {
+        throw_iae(env, "payloadOffLen must hold two longs");
+        return -1;
+    }
+    const int rc = rapid_decode_request(in, len, &kind, &ol[0], &ol[1]);
     if (rc != RAPID_OK) {
         throw_for(env, "rapid_decode_request", rc);
         return -1;
@@ -229,19 +250,35 @@ JNIEXPORT jint JNICALL Java_com_vrg_rapid_NativeCutEngine_decodeRequest(JNIEnv* 
     return kind;
 }
 
-/* -> number of alerts; recordsOut: direct buffer with room for idHi.length records */
+/* -> number of alerts; recordsOut: direct buffer with room for idHi.length records (20 bytes each); idLo at least as long as idHi */
 JNIEXPORT jint JNICALL Java_com_vrg_rapid_NativeCutEngine_decodeBatchedAlerts(JNIEnv* env, jobject self, jlong map, jobject wire,
                                                                               jlong off, jlong len, jint K, jobject recordsOut,
                                                                               jlongArray idHi, jlongArray idLo) {
     (void)self;
+    if (!idHi || !idLo) {
+        throw_iae(env, "idHi / idLo");
+        return -1;
+    }
     const jsize cap = (*env)->GetArrayLength(env, idHi);
+    if ((*env)->GetArrayLength(env, idLo) < cap) {
+        throw_iae(env, "idLo is shorter than idHi");
+        return -1;
+    }
+    const uint8_t* in = direct_region(env, wire, off, len, "wire: offset / length outside the buffer");
+    if (!in) return -1;
+    uint8_t* out = direct_region(env, recordsOut, 0, (jlong)cap * 20, "recordsOut: smaller than idHi.length records");
+    if (!out) return -1;
     jlong* hi = (*env)->GetLongArrayElements(env, idHi, NULL);
     jlong* lo = (*env)->GetLongArrayElements(env, idLo, NULL);
+    if (!hi || !lo) {
+        if (lo) (*env)->ReleaseLongArrayElements(env, idLo, lo, JNI_ABORT);
+        if (hi) (*env)->ReleaseLongArrayElements(env, idHi, hi, JNI_ABORT);
+        throw_iae(env, "idHi / idLo not accessible");
+        return -1;
+    }
     int32_t n = 0, sender = -1;
-    const int rc = rapid_decode_batched_alerts((const rapid_endpoint_map*)(intptr_t)map,
-                                               (const uint8_t*)(*env)->GetDirectBufferAddress(env, wire) + off, len, K,
-                                               (rapid_alert_record*)(*env)->GetDirectBufferAddress(env, recordsOut), (int64_t*)hi,
-                                               (int64_t*)lo, cap, &n, &sender);
+    const int rc = rapid_decode_batched_alerts((const rapid_endpoint_map*)(intptr_t)map, in, len, K, (rapid_alert_record*)out,
+                                               (int64_t*)hi, (int64_t*)lo, cap, &n, &sender);
     (*env)->ReleaseLongArrayElements(env, idLo, lo, 0);
     (*env)->ReleaseLongArrayElements(env, idHi, hi, 0);
     if (rc != RAPID_OK) {
@@ -279,11 +316,20 @@ JNIEXPORT void JNICALL Java_com_vrg_rapid_NativeFastPaxos_propose(JNIEnv* env, j
 JNIEXPORT void JNICALL Java_com_vrg_rapid_NativeFastPaxos_handle(JNIEnv* env, jobject self, jlong h, jlong endpointMap,
                                                                  jint contentCase, jobject wire, jlong off, jlong len) {
     (void)self;
+    const uint8_t* in = direct_region(env, wire, off, len, "wire: offset / length outside the buffer");
+    if (!in) return;
     rapid_consensus_msg msg;
-    int32_t eps[MAX_LIST];
-    int rc = rapid_decode_consensus_message((const rapid_endpoint_map*)(intptr_t)endpointMap, contentCase,
-                                            (const uint8_t*)(*env)->GetDirectBufferAddress(env, wire) + off, len, &msg, eps, MAX_LIST);
+    /* a serialized Endpoint takes at least two bytes: len / 2 bounds the value list of any message, however large the cluster */
+    const int32_t cap = (int32_t)(len / 2 + 1 < MAX_LIST ? MAX_LIST : len / 2 + 1);
+    int32_t stack_eps[MAX_LIST];
+    int32_t* eps = cap > MAX_LIST ? (int32_t*)malloc(sizeof(int32_t) * (size_t)cap) : stack_eps;
+    if (!eps) {
+        throw_for(env, "out of memory", RAPID_ESTATE);
+        return;
+    }
+    int rc = rapid_decode_consensus_message((const rapid_endpoint_map*)(intptr_t)endpointMap, contentCase, in, len, &msg, eps, cap);
     if (rc == RAPID_OK) rc = rapid_consensus_handle((rapid_consensus*)(intptr_t)h, &msg, eps);
+    if (eps != stack_eps) free(eps);
     if (rc != RAPID_OK) throw_for(env, "consensus message", rc);
 }
 
@@ -294,19 +340,37 @@ JNIEXPORT void JNICALL Java_com_vrg_rapid_NativeFastPaxos_startClassicRound(JNIE
 }
 
 /* next outgoing message as a serialized RapidRequest in requestOut; -> its destination (-1 = broadcast), -2 if none;
- * lenOut[0] receives the number of bytes */
+ * lenOut[0] receives the number of bytes (native int poll(long h, long endpointMap, ByteBuffer requestOut, long[] lenOut)) */
 JNIEXPORT jint JNICALL Java_com_vrg_rapid_NativeFastPaxos_poll(JNIEnv* env, jobject self, jlong h, jlong endpointMap,
                                                                jobject requestOut, jlongArray lenOut) {
     (void)self;
+    if (!lenOut || (*env)->GetArrayLength(env, lenOut) < 1) {
+        throw_iae(env, "lenOut must hold one long");
+        return -2;
+    }
+    const jlong out_cap = requestOut ? (*env)->GetDirectBufferCapacity(env, requestOut) : -1;
+    uint8_t* out = direct_region(env, requestOut, 0, out_cap < 0 ? 0 : out_cap, "requestOut must be a direct buffer");
+    if (!out) return -2;
     rapid_consensus_msg msg;
-    int32_t eps[MAX_LIST], got = 0;
+    int32_t stack_eps[MAX_LIST], got = 0;
+    int32_t* eps = stack_eps;
     int rc = rapid_consensus_poll((rapid_consensus*)(intptr_t)h, &msg, eps, MAX_LIST, &got);
-    if (rc == RAPID_OK && !got) return -2;
+    if (rc == RAPID_ECAPACITY && msg.n_endpoints > MAX_LIST) {  /* the message stays queued: take it with a list of its own size */
+        eps = (int32_t*)malloc(sizeof(int32_t) * (size_t)msg.n_endpoints);
+        if (!eps) {
+            throw_for(env, "out of memory", RAPID_ESTATE);
+            return -2;
+        }
+        rc = rapid_consensus_poll((rapid_consensus*)(intptr_t)h, &msg, eps, msg.n_endpoints, &got);
+    }
+    if (rc == RAPID_OK && !got) {
+        if (eps != stack_eps) free(eps);
+        return -2;
+    }
     int64_t len = 0;
     if (rc == RAPID_OK)
-        rc = rapid_encode_consensus_request((const rapid_endpoint_map*)(intptr_t)endpointMap, &msg, eps,
-                                            (uint8_t*)(*env)->GetDirectBufferAddress(env, requestOut),
-                                            (*env)->GetDirectBufferCapacity(env, requestOut), &len);
+        rc = rapid_encode_consensus_request((const rapid_endpoint_map*)(intptr_t)endpointMap, &msg, eps, out, out_cap, &len);
+    if (eps != stack_eps) free(eps);
     if (rc != RAPID_OK) {
         throw_for(env, "outgoing consensus message", rc);
         return -2;
@@ -318,14 +382,24 @@ JNIEXPORT jint JNICALL Java_com_vrg_rapid_NativeFastPaxos_poll(JNIEnv* env, jobj
 /* the decided value (what onDecide receives), or null while there is none */
 JNIEXPORT jintArray JNICALL Java_com_vrg_rapid_NativeFastPaxos_decision(JNIEnv* env, jobject self, jlong h) {
     (void)self;
-    int32_t out[MAX_LIST], n = 0;
-    const int rc = rapid_consensus_decision((rapid_consensus*)(intptr_t)h, out, MAX_LIST, &n);
-    if (rc == RAPID_ESTATE) return NULL;
-    if (rc != RAPID_OK) {
-        throw_for(env, "rapid_consensus_decision", rc);
-        return NULL;
+    int32_t stack_out[MAX_LIST], n = 0;
+    int32_t* out = stack_out;
+    int rc = rapid_consensus_decision((rapid_consensus*)(intptr_t)h, out, MAX_LIST, &n);
+    if (rc == RAPID_ECAPACITY && n > MAX_LIST) {
+        out = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+        if (!out) {
+            throw_for(env, "out of memory", RAPID_ESTATE);
+            return NULL;
+        }
+        rc = rapid_consensus_decision((rapid_consensus*)(intptr_t)h, out, n, &n);
     }
-    return to_java(env, out, n);
+    jintArray res = NULL;
+    if (rc == RAPID_OK)
+        res = to_java(env, out, n);
+    else if (rc != RAPID_ESTATE)
+        throw_for(env, "rapid_consensus_decision", rc);
+    if (out != stack_out) free(out);
+    return res;
 }
 
 JNIEXPORT jlong JNICALL Java_com_vrg_rapid_NativeFastPaxos_fallbackDelayMs(JNIEnv* env, jclass cls, jint membershipSize,

@@ -602,7 +602,7 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
                      int32_t n_members, const int64_t* extra_id_hi, const int64_t* extra_id_lo, int32_t n_extra) {
     if (!h) return RAPID_EINVAL;
     if (!hostnames || !host_off || !ports || !id_hi || !id_lo || n_nodes <= 0 || n_nodes > h->cfg.n_max || n_members < 0 ||
-        (n_members > 0 && !members) || n_extra < 0)
+        (n_members > 0 && !members) || n_extra < 0 || (n_extra > 0 && (!extra_id_hi || !extra_id_lo)) || host_off[0] < 0)
         return fail(h, RAPID_EINVAL, "bad arguments to rapid_view_build (n_nodes=%d, n_max=%d)", n_nodes, h->cfg.n_max);
     int rc = use_device(h);
     if (rc) return rc;
@@ -621,6 +621,8 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
     for (int i = 0; i < n_extra; ++i) h->ids_seen.insert({extra_id_hi[i], extra_id_lo[i]});
     h->ids_dirty = true;
 
+    for (int i = 0; i < n_nodes; ++i)
+        if (host_off[i + 1] < host_off[i]) return fail(h, RAPID_EINVAL, "hostname offsets must not decrease (entry %d)", i);
     const size_t blob_bytes = (size_t)host_off[n_nodes];
     h->reg_blob.assign(hostnames, hostnames + blob_bytes);
     h->reg_off.assign(host_off, host_off + n_nodes + 1);

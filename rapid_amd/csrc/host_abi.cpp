@@ -57,7 +57,7 @@ int rapid_fast_round_vote(rapid_fast_round* f, int32_t sender, int64_t config_id
 }
 
 int rapid_fast_round_decision(rapid_fast_round* f, int32_t* out, int32_t cap, int32_t* n_out) {
-    if (!f) return RAPID_EINVAL;
+    if (!f || cap < 0 || (cap > 0 && !out)) return RAPID_EINVAL;
     if (!f->decided) return RAPID_ESTATE;
     if (n_out) *n_out = (int32_t)f->decision.size();
     if ((int32_t)f->decision.size() > cap) return RAPID_ECAPACITY;
@@ -68,7 +68,7 @@ int rapid_fast_round_decision(rapid_fast_round* f, int32_t* out, int32_t cap, in
 // -------------------------------------------------------------------------------------- wire ingest (host only)
 int rapid_endpoint_map_create(const uint8_t* hostnames, const int32_t* host_off, const int32_t* ports, int32_t n,
                               rapid_endpoint_map** out) {
-    if (!out || n < 0 || (n > 0 && (!hostnames || !host_off || !ports))) return RAPID_EINVAL;
+    if (!out || n < 0 || (n > 0 && (!hostnames || !host_off || !ports)) || (n > 0 && host_off[0] < 0)) return RAPID_EINVAL;
     rapid_endpoint_map* m = new rapid_endpoint_map();
     m->index.reserve((size_t)n * 2);
     m->hostname.reserve((size_t)n);
