@@ -226,3 +226,31 @@ def classic_round_times(proposal_ms, receivers, vote_key, n, latency, base_delay
         dec[a:a + 256] = np.partition(arr, need - 1, axis=1)[:, need - 1]
     out.update(phase2a_ms=t_2a, decision_ms=dec)
     return out
+
+
+def engine_round_on_the_time_line(sim, subj, crash_ms, start_ms, cfg_id, n, model=None, latency=None, receivers=None):
+    """One round of the engine driven by the reference's timers instead of a seeded shuffle: the alert producer model turns
+    crash times into BatchedAlertMessages with send times, every receiver gets them in arrival order, the GPU tallies the
+    streams, and the announcing batch of every receiver is mapped back onto the protocol time line -- proposal time, fast-round
+    decision time (R/FastPaxos.java:142-150).  `sim`: a rapid_amd.engine.ClusterSimulation of an engine whose view has the
+    topology `subj`.  -> dict(emit_batch, num_proposals, prop_count, fingerprint, proposal_ms, decision_ms, receivers,
+    batches, send_ms, records, rec_off, arrival, arr_off, time_to_stable_cut_ms = last decision - first crash, or None)."""
+    model = model or ProducerModel()
+    latency = latency or LatencyModel()
+    crash_ms = np.asarray(crash_ms, dtype=np.int64)
+    bs, send = batches(model, subj, crash_ms, start_ms, cfg_id)
+    rx = np.flatnonzero(crash_ms == NEVER).astype(np.int32) if receivers is None else np.asarray(receivers, dtype=np.int32)
+    records, rec_off, arrival, arr_off = deliver_timed(bs, send, rx, n, latency)
+    sim.load_streams(records, rec_off)
+    sim.set_alert_set(bs.recs, trust_copies=True)  # the deliveries are copies of these batches by construction
+    sim.tally()
+    emit, nprop, pcount, fp = sim.results()
+    t_prop = proposal_times(emit, arrival, arr_off)
+    t_dec = fast_round_decision_times(t_prop, rx, fp, n, latency)
+    crashed = crash_ms[crash_ms != NEVER]
+    ttsc = None
+    if len(crashed) and np.all(t_dec != NEVER) and len(t_dec):
+        ttsc = int(t_dec.max() - crashed.min())
+    return dict(emit_batch=emit, num_proposals=nprop, prop_count=pcount, fingerprint=fp, proposal_ms=t_prop, decision_ms=t_dec,
+                receivers=rx, batches=bs, send_ms=send, records=records, rec_off=rec_off, arrival=arrival, arr_off=arr_off,
+                time_to_stable_cut_ms=ttsc)

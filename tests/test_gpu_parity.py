@@ -1024,3 +1024,51 @@ def test_wire_bytes_to_device_tally_with_joiners_unknown_at_start(E):
     assert new_cfg == oview.getCurrentConfigurationId() and view.getMembershipSize() == n_mem - 14 + 9
     for node in (n_mem, n_mem + 3):
         assert sorted(to_pop[x] for x in view.getObserversOf(node)) == sorted(oview.getObserversOf(to_pop[node]))
+
+
+# ------------------------------------------------------------------ f4: the round on the reference's own time line
+def test_round_driven_by_the_failure_detector_and_batching_timers(E):
+    """SURVEY 8f rank 4 wired to the engine: crashes at given instants -> PingPongFailureDetector notifications
+    (R/monitoring/impl/PingPongFailureDetector.java:41-85) -> AlertBatcher flushes (R/MembershipService.java:613-637) ->
+    arrival order at every receiver -> tally ON THE GPU -> proposal and fast-round decision times.  Results against the
+    faithful oracle on the same timed streams, the producer side against its literal event simulation, and the protocol's
+    time-to-stable-cut (~10 s of failure detection + batching + network) next to the engine's compute time."""
+    from rapid_amd import timeline as T
+    n, K, H, L = 2000, 10, 9, 4
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    reg, oview = oracle_view(pop, K)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    rng = np.random.default_rng(8)
+    faulty = np.sort(rng.choice(n, 20, replace=False))
+    crash = np.full(n, T.NEVER, dtype=np.int64)
+    crash[faulty] = rng.integers(2_000, 2_800, len(faulty))
+    start = rng.integers(0, 1000, n)
+    model, lat = T.ProducerModel(), T.LatencyModel(base_ms=1, jitter_ms=6, seed=9)
+    sim = E.ClusterSimulation(eng)
+    out = T.engine_round_on_the_time_line(sim, subj, crash, start, cfg, n, model, lat)
+    rx = out["receivers"]
+    # the producer side equals the literal event simulation (one PingPongFailureDetector object per detector, one AlertBatcher per node)
+    from tests.test_timeline import as_tuples, oracle_batches
+    t_end = int(crash[faulty].max() + 14 * model.fd_interval_ms + 10 * model.batching_window_ms)
+    assert as_tuples(out["batches"], out["send_ms"]) == oracle_batches(subj, crash, start, t_end, model)
+    # the tally on the device == the faithful oracle on the same timed streams
+    m = np.arange(0, len(rx), max(1, len(rx) // 120))
+    sub_off = np.zeros(len(m) + 1, dtype=np.int64)
+    parts = []
+    for i, r in enumerate(m):
+        parts.append(out["records"][out["rec_off"][r]:out["rec_off"][r + 1]])
+        sub_off[i + 1] = sub_off[i] + len(parts[-1])
+    oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, np.concatenate(parts), sub_off, nthreads=8)
+    assert np.array_equal(out["emit_batch"][m], oe) and np.array_equal(out["num_proposals"][m], on)
+    assert np.array_equal(out["fingerprint"][m], proposal_fingerprints(oo, op, oe >= 0))
+    assert np.all(out["emit_batch"] >= 0) and sorted(sim.proposal(0)) == faulty.tolist()
+    # on the time line: ten failed probes, one per second, then the batching window and the network
+    t_prop, t_dec = out["proposal_ms"], out["decision_ms"]
+    assert t_prop.min() > crash[faulty].min() + 10_000 and t_prop.max() < crash[faulty].max() + 11_000 + 2 * model.batching_window_ms + 10
+    quorum = n - (n - 1) // 4
+    assert np.all(t_dec >= np.sort(t_prop)[quorum - 1] + 1) and np.all(t_dec <= t_prop.max() + 7)
+    assert 10_000 < out["time_to_stable_cut_ms"] < 12_500
+    rr = sim.count_votes()
+    assert rr.decided == 1 and sorted(sim.decided_cut()) == faulty.tolist()
