@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-reps", type=int, default=20)
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE pass that measures roofline.traffic")
     return ap.parse_args()
 
 
@@ -146,8 +147,15 @@ def main():
     sim.set_force_exact(0)
     # what the memory system delivers for the SAME access pattern with no processing (measurement probe)
     probe_ms = sim.stream_probe(0, 16, 5)
+    traffic, traffic_source = (None, "not measured at %d ranks" % world)
+    if world == 1 and rank == 0 and not args.no_pmc:
+        traffic, traffic_source = measure_traffic(cfgname)
+    if traffic is None and world == 1:
+        committed = traffic_from_profiles(cfgname, world)
+        if committed is not None:
+            traffic, traffic_source = committed, "profiles/tally_traffic_%s.json (committed PMC pass; live pass: %s)" % (cfgname, traffic_source)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(cfgname, world),
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "tally_population_kernel", "kernel_ms": round(kern_ms, 4),
                 "kernel_ms_filter_per_delivery": round(kern_filter_ms, 4),
                 "frac_filter_per_delivery": round(20.0 * consumed / (kern_filter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -201,6 +209,50 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def measure_traffic(cfgname):
+    """HBM bytes per tally launch, measured in THIS run: a `rocprofv3 --pmc FETCH_SIZE` pass (its own process, counters only,
+    no tracing domains) over scripts/prof_tally.py, which replays the same workload and also runs the stream probe -- same
+    access pattern, known byte count -- that calibrates the counter (MI355X_MICROARCH.md, HBM section: FETCH_SIZE is in
+    KiB and under-reports wide coalesced reads on gfx950 by ~2x; calibrate on a known byte count of your own pattern).
+    -> (bytes or None, how it was obtained)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            cmd = [exe, "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+                   os.path.join(ROOT, "scripts", "prof_tally.py"), cfgname, "3"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "rocprofv3 --pmc produced no counter file (rc %d)" % r.returncode
+            stream_bytes = None
+            for line in r.stdout.splitlines():
+                t = line.split()
+                if t and t[0] == "workload" and "stream_bytes" in t:
+                    stream_bytes = float(t[t.index("stream_bytes") + 1])
+            tally, probe = [], []
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != "FETCH_SIZE":
+                    continue
+                if "tally_population" in row["Kernel_Name"]:
+                    tally.append(float(row["Counter_Value"]))
+                elif "stream_probe" in row["Kernel_Name"]:
+                    probe.append(float(row["Counter_Value"]))
+            if not tally or not probe or not stream_bytes or sum(probe) == 0:
+                return None, "counter file without tally / probe rows"
+            factor = stream_bytes / (1024.0 * sum(probe) / len(probe))
+            return int(1024.0 * sum(tally) / len(tally) * factor), \
+                "rocprofv3 --pmc FETCH_SIZE in this run, calibrated x%.3f on the stream probe (known byte count)" % factor
+    except Exception as e:  # a measurement aid must not take the bench line down
+        return None, "PMC pass failed: %s" % str(e)[:120]
 
 
 def traffic_from_profiles(cfgname, world):

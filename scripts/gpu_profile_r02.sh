@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 export TMPDIR=/tmp; cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_bench" -o bench -- \
-    python "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.log" 2>&1
+    python "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-pmc > "$GRAFT_REPO_ROOT/gpurun_out/prof_bench.log" 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_fetch" -o pmc -- \
     python "$GRAFT_REPO_ROOT/scripts/prof_tally.py" C3b 3 > "$GRAFT_REPO_ROOT/gpurun_out/prof_fetch.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_write" -o pmc -- \
