@@ -365,6 +365,8 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms);
  * 4: 1 KiB x 8, 5: 1 KiB x 16, 6: 1 KiB x 4; LDS-DMA loads (the tally kernel's path): 7: 1 KiB x 4, 8: 1 KiB x 8,
  * 9: 1 KiB x 6.  `waves` = waves per workgroup (16 waves per CU unless RAPID_PROBE_WAVES_PER_CU says otherwise) */
 int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, int32_t reps, float* ms_avg);
+/* measurement aid: the tally kernel's counters per workgroup ([rows][8], the rows rapid_sim_stats sums) */
+int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, int32_t* rows_out);
 /* testing / measurement knob, a bit set (0 = normal): 1 = every window through the exact sequential path, 8 = careful
  * path only (no cold / fast windows), 64 = never trust the pre-validation of the alert set, 128 = no direct node -> slot
  * tables in LDS even when they fit (the compressed form of large populations is used instead), 256 = dictionary in

@@ -113,6 +113,7 @@ def _signatures():
         "rapid_device_count": (i32, []),
         "rapid_engine_comm_info": (i32, [vp, pi32, pi32]),
         "rapid_sim_new_round": (i32, [vp]),
+        "rapid_debug_block_stats": (i32, [vp, p, i32, pi32]),
         "rapid_sim_trust_alert_copies": (i32, [vp, i32]),
         "rapid_view_build": (i32, [vp, p, p, p, p, p, i32, p, i32, p, p, i32]),
         "rapid_view_register_endpoints": (i32, [vp, p, p, p, p, p, i32, pi32]),

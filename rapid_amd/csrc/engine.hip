@@ -467,8 +467,8 @@ int launch_tally(rapid_engine* h) {
     p.idx.n_touched = h->n_touched;
     p.error_flags = h->d_errflags.p;
     p.idx.node_of_slot = h->d_node_of_slot.p;
-    p.idx.adj_off = h->d_adj_off.p;
-    p.idx.adj = h->d_adj.p;
+    p.idx.smask = h->d_adj_off.p;  // (the buffers keep their round-1 names: per-slot masks, flat triple list)
+    p.idx.pairs = h->d_adj.p;
     p.idx.n_hot = h->n_hot;
     p.idx.n_adj = h->n_adj;
     p.emit_batch = h->d_emit.p;
@@ -1403,6 +1403,18 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
     info[6] = h->dict_mode;  // 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS
     info[7] = h->n_alert_set >= 0 ? 1 : 0;
     if (index_ms) *index_ms = h->index_ms;
+    return RAPID_OK;
+}
+
+int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, int32_t* rows_out) {
+    if (!h || !rows_out || cap_rows < 0 || (cap_rows > 0 && !out)) return RAPID_EINVAL;
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int rows = std::max(h->grid_blocks, 1);
+    *rows_out = rows;
+    if (rows > cap_rows) return RAPID_ECAPACITY;
+    HIPCHK(h, hipMemcpyAsync(out, h->d_stats.p, (size_t)rows * 64, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return RAPID_OK;
 }
 

@@ -37,104 +37,12 @@ __global__ void index_touch_kernel(const unsigned char* records, long long n_rec
     if (f) atomicOr(vflags, f);
 }
 
-// One block.  Slot numbering: the hot subjects (>= L distinct rings named by the round's alert set), ascending by
-// node index.  Every node gets a dictionary entry  member << 15 | has_adjacency << 14 | slot  with slot = 0x3FFF for
-// subjects that are not hot.  info[0] = info[1] = n_hot, info[2] = overflow flag.
-// decl[node] = the rings the round's alert set names for the node (all rings for a hot one), bit 15 = member: what the tally kernel
-// checks every delivered report about a subject WITHOUT a slot against, so that a declared alert set that does not
-// cover the delivered streams is reported instead of silently under-counting.
-__global__ void index_slots_kernel(const unsigned int* gmask, const unsigned char* member, int n_nodes, int L,
-                                   unsigned short* dict, unsigned short* decl, int* node_of_slot, int* info) {
-    __shared__ int s_hot[1024];
-    const int T = (int)blockDim.x, t = (int)threadIdx.x;
-    const int per = (n_nodes + T - 1) / T;
-    const int beg = min(n_nodes, t * per), end = min(n_nodes, beg + per);
-    int nh = 0;
-    for (int n = beg; n < end; ++n)
-        if (__popc(gmask[n]) >= L) ++nh;
-    s_hot[t] = nh;
-    __syncthreads();
-    if (t == 0) {  // exclusive scan over 1024 partial counts
-        int ah = 0;
-        for (int i = 0; i < T; ++i) {
-            const int h = s_hot[i];
-            s_hot[i] = ah;
-            ah += h;
-        }
-        info[0] = ah;
-        info[1] = ah;
-        info[2] = (ah > 16318) ? 1 : 0;  // 64 slot numbers are kept for the tally kernel's dummy slots
-    }
-    __syncthreads();
-    int ph = s_hot[t];
-    for (int n = beg; n < end; ++n) {
-        int slot = 0x3FFF;
-        if (__popc(gmask[n]) >= L) {
-            slot = ph < 16383 ? ph : 0x3FFF;
-            if (ph < 16383) node_of_slot[ph] = n;
-            ++ph;
-        }
-        dict[n] = (unsigned short)(slot | (member[n] ? 0x8000 : 0));
-        decl[n] = (unsigned short)((slot != 0x3FFF ? 0x3FFFu : (gmask[n] & 0x3FFFu)) | (member[n] ? 0x8000u : 0u));
-    }
-}
-
-// phase 0: deg[e] += 1 for both ends of every hot-hot (subject e, ring k, observer o) triple;
-// phase 1: fill adj[] at cursor positions.  One thread per (hot slot, ring).
-__global__ void index_adj_kernel(const int* obs, const unsigned short* dict, const int* node_of_slot, int n_hot, int K,
-                                 int* deg, const unsigned short* adj_off, int* cursor, unsigned int* adj, int phase) {
-    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (t >= n_hot * K) return;
-    const int e = t / K, k = t - e * K;
-    const int s_node = node_of_slot[e];
-    const int o_node = obs[s_node * K + k];
-    if (o_node < 0) return;
-    const int eo = (int)(dict[o_node] & 0x3FFF);
-    if (eo >= n_hot) return;  // observer not hot (or not touched): can never vouch
-    if (phase == 0) {
-        atomicAdd(&deg[e], 1);
-        atomicAdd(&deg[eo], 1);
-    } else {
-        // role 0: `other` is the observer of e on ring k; role 1: `other` is the subject that eo observes on ring k
-        adj[(int)adj_off[e] + atomicAdd(&cursor[e], 1)] = (unsigned)eo | ((unsigned)k << 16);
-        adj[(int)adj_off[eo] + atomicAdd(&cursor[eo], 1)] = (unsigned)e | ((unsigned)k << 16) | (1u << 20);
-    }
-}
-
-// One wavefront: adj_off = exclusive scan of deg (u16); info[3] = n_adj; info[2] |= 2 on overflow.  Lane l owns the
-// consecutive chunk [l * per, (l + 1) * per); the chunk totals are scanned across the wave with shuffles.
-__global__ void index_adj_scan_kernel(const int* deg, int n_hot, unsigned short* adj_off, int* info) {
-    const int lane = (int)(threadIdx.x & 63u);
-    if (threadIdx.x >= 64u) return;
-    const int per = (n_hot + 63) / 64;
-    const int beg = min(n_hot, lane * per), end = min(n_hot, beg + per);
-    long long mine = 0;
-    for (int i = beg; i < end; ++i) mine += deg[i];
-    long long incl = mine;  // inclusive scan of the chunk totals
-    for (int off = 1; off < 64; off <<= 1) {
-        const long long lo = (long long)(unsigned int)__shfl_up((int)(unsigned int)incl, off, 64);
-        const long long hi = (long long)__shfl_up((int)(incl >> 32), off, 64);
-        if (lane >= off) incl += (hi << 32) | lo;
-    }
-    long long acc = incl - mine;
-    for (int i = beg; i < end; ++i) {
-        adj_off[i] = (unsigned short)(acc > 65535 ? 65535 : acc);
-        acc += deg[i];
-    }
-    const long long total = ((long long)__shfl((int)(incl >> 32), 63, 64) << 32) | (long long)(unsigned int)__shfl((int)(unsigned int)incl, 63, 64);
-    if (lane == 0) {
-        adj_off[n_hot] = (unsigned short)(total > 65535 ? 65535 : total);
-        info[3] = (int)(total > 0x7FFFFFFF ? 0x7FFFFFFF : total);
-        if (total > 65535) info[2] |= 2;
-    }
-}
-
-// dict[node] |= has-adjacency flag for every hot slot with at least one adjacency entry
-__global__ void index_adj_flag_kernel(const int* deg, const int* node_of_slot, int n_hot, unsigned short* dict) {
-    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (e < n_hot && deg[e] > 0) dict[node_of_slot[e]] |= (unsigned short)0x4000;
-}
-
+// Dictionary format (built by index_build_block_kernel below).  Slot numbering: the hot subjects (>= L distinct rings
+// named by the round's alert set), ascending by node index.  Every node gets a dictionary entry
+// member << 15 | has_adjacency << 14 | slot  with slot = 0x3FFF for subjects that are not hot.
+// decl[node] = the rings the round's alert set names for the node (all rings for a hot one), bit 15 = member: what the
+// tally kernel checks every delivered report about a subject WITHOUT a slot against, so that a declared alert set that
+// does not cover the delivered streams is reported instead of silently under-counting.
 
 // Exclusive scan of one value per thread over a workgroup of up to 1024 threads (wave shuffles + one LDS hop);
 // *total receives the sum.  s_wave: 16 ints of LDS scratch.
@@ -161,17 +69,16 @@ __device__ inline int block_exclusive_scan(int v, int* s_wave, int* total) {
 // The whole index after the touch pass in ONE workgroup (the round's hot set is a few hundred to a few thousand
 // subjects): slot numbering + dictionary + declared masks, then the hot adjacency.  One launch and one read-back of
 // info[] instead of six launches and two synchronisations, and no atomics: the list of a hot slot e is built by the
-// thread that owns e from its row of the observer table -- one entry (observer slot | ring << 16) per ring on which a
-// hot node observes e (for a joiner: its expected observers, R/MembershipView.java:292-322).  These are the
-// (subject, observer, ring) triples of the implicit invalidation; the tally kernel needs nothing else (the mirrored
-// "e observes s" entries that index_adj_kernel also produces are not used by it any more).
-// adj has room for adj_cap entries (info[2] |= 2 if more are needed: nothing is written past it).  info_out: a second
+// thread that owns e from its row of the observer table -- one triple (subject slot | observer slot << 14 | ring << 28)
+// per ring on which a hot node observes e (for a joiner: its expected observers, R/MembershipView.java:292-322): the
+// potential implicit reports of R/MultiNodeCutDetector.java:137-164; smask[e] = the rings of e's triples.
+// pairs has room for adj_cap entries (info[2] |= 2 if more are needed: nothing is written past it).  info_out: a second
 // copy of info[0..7] (host-mapped memory: the host reads it after synchronising, no copy is enqueued).  info[5] = touched
 // nodes, info[6] = 1 if the compressed tables are complete (at most 65535 touched nodes and tent_cap entries).
 __global__ __launch_bounds__(1024) void index_build_block_kernel(const unsigned int* gmask, const unsigned char* member, const int* obs,
                                                                  int n_nodes, int K, int L, unsigned short* dict,
-                                                                 unsigned short* decl, int* node_of_slot, unsigned short* adj_off,
-                                                                 unsigned int* adj, int adj_cap, unsigned int* tbits,
+                                                                 unsigned short* decl, int* node_of_slot, unsigned short* smask,
+                                                                 unsigned int* pairs, int adj_cap, unsigned int* tbits,
                                                                  unsigned short* trank, unsigned int* tent, int tent_cap, int* info,
                                                                  volatile int* info_out) {
     __shared__ int s_wave[16];
@@ -197,38 +104,35 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(const unsigned 
     __threadfence_block();
     __syncthreads();
     const int n_hot = min(n_hot_all, 16318);
-    // ---- list lengths: thread t owns the hot slots t, t + T, ... ----
+    // ---- the hot adjacency as a flat list: thread t owns a contiguous chunk of the hot slots ----
     const int per2 = (n_hot + T - 1) / T;
-    const int b2 = min(n_hot, t * per2), e2 = min(n_hot, b2 + per2);  // a contiguous chunk, so that adj_off comes out of one scan
+    const int b2 = min(n_hot, t * per2), e2 = min(n_hot, b2 + per2);
     int mine = 0;
     for (int e = b2; e < e2; ++e) {
         const int node = node_of_slot[e];
-        int c = 0;
         for (int k = 0; k < K; ++k) {
             const int o = obs[node * K + k];
-            if (o >= 0 && (int)(dict[o] & 0x3FFF) < n_hot) ++c;
+            if (o >= 0 && (int)(dict[o] & 0x3FFF) < n_hot) ++mine;
         }
-        mine += c;
     }
     int total = 0;
     int at = block_exclusive_scan(mine, s_wave, &total);
     const bool fits = total <= 65535 && total <= adj_cap;
-    // ---- fill (role 0: `other` is the observer of e on ring k) ----
     for (int e = b2; e < e2; ++e) {
         const int node = node_of_slot[e];
-        adj_off[e] = (unsigned short)(at > 65535 ? 65535 : at);
-        const int at0 = at;
+        unsigned int am = 0u;
         for (int k = 0; k < K; ++k) {
             const int o = obs[node * K + k];
             const int eo = o >= 0 ? (int)(dict[o] & 0x3FFF) : 0x3FFF;
-            if (eo < n_hot) {
-                if (fits) adj[at] = (unsigned)eo | ((unsigned)k << 16);
+            if (eo < n_hot) {  // a hot node observes e on ring k (for a joiner: one of its expected observers)
+                if (fits) pairs[at] = (unsigned int)e | ((unsigned int)eo << 14) | ((unsigned int)k << 28);
                 ++at;
+                am |= 1u << k;
             }
         }
-        if (at > at0) dict[node] |= (unsigned short)0x4000;  // only this thread touches dict[node] after the barrier above
+        smask[e] = (unsigned short)am;
+        if (am != 0u) dict[node] |= (unsigned short)0x4000;  // only this thread touches dict[node] after the barrier above
     }
-    if (t == T - 1 || (n_hot == 0 && t == 0)) adj_off[n_hot] = (unsigned short)(total > 65535 ? 65535 : total);
     __threadfence_block();
     __syncthreads();  // dict[] is final (adjacency flags included)
     // ---- the compressed form of dict[] / decl[] for populations whose direct tables do not fit the LDS: one bit per node

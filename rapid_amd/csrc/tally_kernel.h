@@ -53,6 +53,11 @@ constexpr int kRecBytes = 20;
 #ifndef RAPID_QUARTERS
 #define RAPID_QUARTERS 4
 #endif
+#ifndef RAPID_WINDOWS_IN_FLIGHT
+#define RAPID_WINDOWS_IN_FLIGHT 1
+#endif
+constexpr int kInFlight = RAPID_WINDOWS_IN_FLIGHT;  // windows requested ahead of the one being tallied (1 or 2)
+static_assert(kInFlight == 1 || kInFlight == 2, "one or two register sets");
 constexpr int kQ = RAPID_QUARTERS;        // quarters (64 records each) per window
 constexpr int kWin = kQ * kWave;          // 256 records = 5 KiB of stream per window
 constexpr int kQuarterBytes = kWave * kRecBytes;
@@ -90,9 +95,11 @@ struct RoundIndex {
     const unsigned int* tent;       // [n_touched]
     int n_touched;
     const int* node_of_slot;        // [n_hot]
-    const unsigned short* adj_off;  // [n_hot + 1] CSR over hot slots
-    const unsigned int* adj;        // [n_adj] other_slot | ring << 16 | role << 20 (role 0: `other` observes the slot on that ring;
-                                    // role 1, the mirrored entry, is ignored)
+    // the hot adjacency: pairs[a] = subject slot | observer slot << 14 | ring << 28 for every (subject, ring, observer) triple
+    // among hot slots -- one potential implicit report each (R/MultiNodeCutDetector.java:137-164); smask[slot] = the rings on
+    // which a hot observer watches the slot = the implicit reports it can ever receive
+    const unsigned int* pairs;      // [n_adj]
+    const unsigned short* smask;    // [n_hot]
     int n_hot, n_adj;
 };
 
@@ -427,37 +434,14 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         }
         dict = l_dict;
     }
-    // the hot adjacency as a flat list of (subject slot, observer slot, ring): one potential implicit report each;
-    // smask[slot] = rings on which a hot observer watches the slot = the implicit reports that slot can ever receive
+    // the hot adjacency (flat list of triples, count first) and the per-slot masks, copied from the round index
     unsigned int* const l_pairs = reinterpret_cast<unsigned int*>(smem + dict_bytes);
     unsigned short* const l_smask = reinterpret_cast<unsigned short*>(smem + dict_bytes + pairs_bytes);
     int* const l_nos = reinterpret_cast<int*>(smem + dict_bytes + pairs_bytes + align16((n_hot + kDummySlots) * 2));
-    if (threadIdx.x == 0) l_pairs[0] = 0u;
-    __syncthreads();
-    for (int i = (int)threadIdx.x; i < n_hot + kDummySlots; i += (int)blockDim.x) {
-        if (i >= n_hot) {
-            l_smask[i] = 0;
-            continue;
-        }
-        l_nos[i] = p.idx.node_of_slot[i];
-        const int a0 = (int)p.idx.adj_off[i], a1 = (int)p.idx.adj_off[i + 1];
-        unsigned int am = 0u;
-        int c = 0;
-        for (int a = a0; a < a1; ++a) {
-            const unsigned int ent = p.idx.adj[a];
-            if (((ent >> 20) & 1u) == 0u) {  // role 0: slot i is the subject on that ring
-                am |= 1u << ((ent >> 16) & 15u);
-                ++c;
-            }
-        }
-        l_smask[i] = (unsigned short)am;
-        if (c == 0) continue;
-        unsigned int at = atomicAdd(&l_pairs[0], (unsigned int)c);
-        for (int a = a0; a < a1; ++a) {
-            const unsigned int ent = p.idx.adj[a];
-            if (((ent >> 20) & 1u) == 0u) l_pairs[1 + at++] = (unsigned int)i | ((ent & 0x3FFFu) << 14) | (((ent >> 16) & 15u) << 28);
-        }
-    }
+    if (threadIdx.x == 0) l_pairs[0] = (unsigned int)p.idx.n_adj;
+    for (int i = (int)threadIdx.x; i < p.idx.n_adj; i += (int)blockDim.x) l_pairs[1 + i] = p.idx.pairs[i];
+    for (int i = (int)threadIdx.x; i < n_hot + kDummySlots; i += (int)blockDim.x) l_smask[i] = i < n_hot ? p.idx.smask[i] : (unsigned short)0;
+    for (int i = (int)threadIdx.x; i < n_hot; i += (int)blockDim.x) l_nos[i] = p.idx.node_of_slot[i];
     const unsigned int* const pairs = l_pairs;
     const unsigned short* const smask = l_smask;
     const int* const node_of_slot = l_nos;
@@ -468,6 +452,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         reinterpret_cast<unsigned long long*>(smem + shared_bytes + (int)(blockDim.x >> 6) * tally_wave_bytes(n_hot));
     unsigned int* const block_claims = reinterpret_cast<unsigned int*>(block_stats + 8);  // receivers claimed by this workgroup
     if (threadIdx.x < 8u) block_stats[threadIdx.x] = 0ull;
+#ifdef RAPID_PHASE_TIMERS
+    if (threadIdx.x == 7u) block_stats[7] = ~0ull;
+#endif
     if (threadIdx.x == 8u) *block_claims = blockDim.x >> 6;  // claims 0 .. waves - 1 are the first deal
     __syncthreads();
 
@@ -492,6 +479,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #ifdef RAPID_PHASE_TIMERS
     unsigned long long t_total = 0, t_ensure = 0, t_lean = 0, t_careful = 0, t_out = 0, t_flush = 0, t_rx = 0;
     RAPID_T0(t_kernel0);
+    const unsigned long long t_real_start = __builtin_amdgcn_s_memrealtime();
 #endif
     int n_applied = 0;
     unsigned int sink = 0u;  // stream-only mode: keeps the loads alive
@@ -597,7 +585,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // crosses that channel waits with them.
     const int n_blocks = (int)gridDim.x;
     int r = uniform(wave * n_blocks + (int)blockIdx.x);  // the first deal: claim number `wave` of this workgroup
-    Win W;  // the window in flight
+    Win W, W2;  // the windows in flight: window w of a receiver lives in W (w even) or W2 (w odd) when kInFlight = 2
     Stream rsrc;
     rsrc.base = p.records;
     rsrc.bytes = 0u;
@@ -611,6 +599,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         nrec = (int)(rec1 - rec0);
         rsrc = make_stream(rec0, rec1);
         load_window(rsrc, lane20, W);
+        if (kInFlight > 1) load_window(rsrc, lane20 + (unsigned int)(kWin * kRecBytes), W2);
     }
     while (r < p.n_receivers) {
 #ifdef RAPID_PHASE_TIMERS
@@ -1070,18 +1059,20 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 restart = false;
                 exact_only = true;
                 load_window(rsrc, lane20, W);
+                if (kInFlight > 1) load_window(rsrc, lane20 + (unsigned int)(kWin * kRecBytes), W2);
             }
             wave_lds_fence();
-            unsigned int voff = lane20;
-            for (int w = 0; w < nwin && emit_batch < 0 && !restart; ++w) {
-                const Win cur = W;
-                voff += (unsigned int)(kWin * kRecBytes);
-                load_window(rsrc, voff, W);  // the next window is in flight while this one is tallied
+            // One step: window w out of its register set X, which is refilled with window w + kInFlight right away -- so kInFlight
+            // windows (5 KiB each) are on their way while one is tallied.  The sets keep their roles, so the loop body is
+            // kInFlight steps long (the step is instantiated once per set).
+            auto step = [&](Win& X, int w) {
+                const Win cur = X;
+                load_window(rsrc, lane20 + (unsigned int)(w + kInFlight) * (unsigned int)(kWin * kRecBytes), X);
                 if (!claimed && w + kClaimAhead >= nwin) claim();
                 if ((p.flags & 32) != 0) {  // measurement aid: stream the records through the registers without tallying them
 #pragma unroll
                     for (int q = 0; q < kQ; ++q) sink ^= cur.w3[q] ^ cur.w4[q] ^ (kTrusted ? 0u : cur.w0[kTrusted ? 0 : q] ^ cur.w1[kTrusted ? 0 : q]);
-                    continue;
+                    return;
                 }
                 bool done = false;
                 swept = false;
@@ -1109,6 +1100,15 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     RAPID_T1(t_lean, tl0);
                 }
                 if (!done) slow_window(cur, w);
+            };
+            for (int w = 0; w < nwin && emit_batch < 0 && !restart;) {
+                step(W, w);
+                ++w;
+                if (kInFlight > 1) {
+                    if (!(w < nwin && emit_batch < 0 && !restart)) break;
+                    step(W2, w);
+                    ++w;
+                }
             }
             if (!restart) break;
         }
@@ -1124,6 +1124,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             nrec_next = (int)(rec1 - rec0);
             rsrc = make_stream(rec0, rec1);
             load_window(rsrc, lane20, W);
+            if (kInFlight > 1) load_window(rsrc, lane20 + (unsigned int)(kWin * kRecBytes), W2);
         }
 
         // ---- outputs: the proposal = every flushed (hot) slot, ascending node index ----
@@ -1182,14 +1183,41 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     mine_stats[0] = n_slow; mine_stats[1] = n_fast; mine_stats[2] = n_sweeps; mine_stats[3] = n_restart;
     mine_stats[4] = (unsigned long long)n_applied; mine_stats[5] = n_records; mine_stats[6] = n_pipe; mine_stats[7] = n_careful;
 #endif
+#ifdef RAPID_PHASE_TIMERS
+    // profiling build: [1] = when the workgroup's last wave finished, [7] = when its first wave got here after the tables were
+    // staged (constant-rate counter, 10 ns ticks) -- per workgroup through rapid_debug_block_stats
+    mine_stats[1] = __builtin_amdgcn_s_memrealtime();
+    mine_stats[7] = t_real_start;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i == 1)
+                atomicMax(&block_stats[i], mine_stats[i]);
+            else if (i == 7)
+                atomicMin(&block_stats[i], mine_stats[i]);
+            else
+                atomicAdd(&block_stats[i], mine_stats[i]);
+        }
+    }
+#else
     if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) atomicAdd(&block_stats[i], mine_stats[i]);
     }
+#endif
     if ((p.flags & 32) != 0 && sink == 0x12345678u) block_stats[0] = 1ull;
     __syncthreads();
     // p.stats = [gridDim.x][8], accumulated over launches; one plain read-modify-write per workgroup and counter
+#ifdef RAPID_PHASE_TIMERS
+    if (threadIdx.x < 8u && p.stats != nullptr) {
+        if (threadIdx.x == 1u || threadIdx.x == 7u)
+            p.stats[(size_t)blockIdx.x * 8 + threadIdx.x] = block_stats[threadIdx.x];
+        else
+            p.stats[(size_t)blockIdx.x * 8 + threadIdx.x] += block_stats[threadIdx.x];
+    }
+#else
     if (threadIdx.x < 8u && p.stats != nullptr) p.stats[(size_t)blockIdx.x * 8 + threadIdx.x] += block_stats[threadIdx.x];
+#endif
 }
 
 // --------------------------------------------------------------------------------------------------------------

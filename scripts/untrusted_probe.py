@@ -16,8 +16,10 @@ spec = S.CONFIGS[name]
 n, K, H, L = spec["n"], spec["K"], spec["H"], spec["L"]
 pop = S.Population.make(n)
 libs = {"default": os.path.join(ROOT, "rapid_amd", "librapid_mi355x.so")}
-for path in sorted(glob.glob(os.path.join(ROOT, "rapid_amd", "librapid_mi355x_q*.so"))):
-    libs[os.path.basename(path)[len("librapid_mi355x_"):-3]] = path
+for path in sorted(glob.glob(os.path.join(ROOT, "rapid_amd", "librapid_mi355x_*.so"))):
+    tag = os.path.basename(path)[len("librapid_mi355x_"):-3]
+    if not tag.startswith("timers"):
+        libs[tag] = path
 sc = None
 for rnd in range(2):
     for tag, path in libs.items():

@@ -135,8 +135,8 @@ int emu_tally_shared_bytes(int mode, int n_nodes, int n_touched, int n_hot, int 
 // Runs the population kernel: `grid` persistent workgroups of `waves` waves, one workgroup at a time.
 int emu_tally_run(const unsigned char* records, unsigned long long records_bytes, const long long* rec_off,
                   int n_receivers, int n_nodes, int K, int H, int L, long long cfg_id, const unsigned short* dict, const unsigned short* decl,
-                  const int* node_of_slot, const unsigned short* adj_off,
-                  const unsigned int* adj, int n_hot, int n_adj, int* emit_batch, int* num_proposals,
+                  const int* node_of_slot, const unsigned short* smask,
+                  const unsigned int* pairs, int n_hot, int n_adj, int* emit_batch, int* num_proposals,
                   int* prop_count, unsigned long long* fingerprint, int* props, int prop_cap, unsigned long long* stats,
                   int flags, int waves, int grid, int tables_in_lds, unsigned long long seed, const unsigned int* tbits,
                   const unsigned short* trank, const unsigned int* tent, int n_touched) {
@@ -164,8 +164,8 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     error_flags[0] = error_flags[1] = 0u;
     p.error_flags = error_flags;
     p.idx.node_of_slot = node_of_slot;
-    p.idx.adj_off = adj_off;
-    p.idx.adj = adj;
+    p.idx.smask = smask;
+    p.idx.pairs = pairs;
     p.idx.n_hot = n_hot;
     p.idx.n_adj = n_adj;
     p.emit_batch = emit_batch;

@@ -39,7 +39,10 @@ def build_round_index(records, n_nodes, K, L, obs, member):
     assert n_hot <= 16318
     slot_of = np.full(n_nodes, 0x3FFF, dtype=np.int64)
     slot_of[node_of_slot] = np.arange(n_hot)
-    lists = [[] for _ in range(n_hot)]
+    # the hot adjacency as index_build_block_kernel produces it: one triple (subject slot | observer slot << 14 | ring << 28)
+    # per ring on which a hot node observes a hot slot, and the per-slot mask of those rings
+    pairs, smask = [], np.zeros(n_hot + 1, dtype=np.uint16)
+    dict_ = slot_of | np.where(np.asarray(member) != 0, 0x8000, 0)
     for e in range(n_hot):
         s_node = int(node_of_slot[e])
         for k in range(K):
@@ -49,15 +52,11 @@ def build_round_index(records, n_nodes, K, L, obs, member):
             eo = int(slot_of[o])
             if eo >= n_hot:
                 continue
-            lists[e].append(eo | (k << 16))
-            lists[eo].append(e | (k << 16) | (1 << 20))
-    adj_off = np.zeros(n_hot + 1, dtype=np.uint16)
-    adj_off[1:] = np.cumsum([len(x) for x in lists])
-    adj = np.array([x for l in lists for x in l] + [0], dtype=np.uint32)
-    dict_ = slot_of | np.where(np.asarray(member) != 0, 0x8000, 0)
-    for e in range(n_hot):
-        if lists[e]:
-            dict_[node_of_slot[e]] |= 0x4000
+            pairs.append(e | (eo << 14) | (k << 28))
+            smask[e] |= 1 << k
+        if smask[e]:
+            dict_[s_node] |= 0x4000
+    adj_off, adj = smask, np.array(pairs + [0], dtype=np.uint32)
     dict_ = dict_.astype(np.uint16)
     decl = (np.where(slot_of < n_hot, 0x3FFF, gmask & 0x3FFF) | np.where(np.asarray(member) != 0, 0x8000, 0)).astype(np.uint16)
     # the compressed form (index_build_block_kernel): one bit per node named by the alert set, touched nodes before each
@@ -73,7 +72,7 @@ def build_round_index(records, n_nodes, K, L, obs, member):
     tent = ((decl[tn].astype(np.uint32) << 16) | (dict_[tn].astype(np.uint32) & 0x3FFF)).astype(np.uint32)
     tent = np.concatenate([tent, np.zeros(1, dtype=np.uint32)])
     return dict(dict=dict_, decl=decl, tbits=tbits, trank=trank, tent=tent, n_touched=len(tn), node_of_slot=np.concatenate([node_of_slot, [0]]).astype(np.int32), adj_off=adj_off,
-                adj=adj, n_hot=n_hot, n_adj=int(adj_off[-1]))
+                adj=adj, n_hot=n_hot, n_adj=len(pairs))
 
 
 def validate_alerts(records, n_nodes, K, cfg_id, member):
