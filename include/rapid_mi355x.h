@@ -370,9 +370,16 @@ int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, in
 /* testing / measurement knob, a bit set (0 = normal): 1 = every window through the exact sequential path, 8 = careful
  * path only (no cold / fast windows), 64 = never trust the pre-validation of the alert set, 128 = no direct node -> slot
  * tables in LDS even when they fit (the compressed form of large populations is used instead), 256 = dictionary in
- * memory (the mode of populations too large even for that), 32 = measurement only:
+ * memory (the mode of populations too large even for that), 512 = sharded vote count always through the histogram
+ * all-reduces (never the all-gather + merge of the ranks' local counts), 32 = measurement only:
  * stream the records through the registers without tallying them (results are meaningless) */
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);
+/* testing aids for the sharded vote count (one GPU standing in for n ranks): the answer block this engine's voters
+ * contribute to rapid_sim_count_votes' all-gather (out == NULL: only *seg_bytes), and the device-side merge of n_ranks such
+ * blocks laid end to end, as every rank runs it after the all-gather.  *status = 1: merged, *out filled like
+ * rapid_sim_count_votes fills it; 2: the voters disagree somewhere and the general (histogram) count would run. */
+int rapid_debug_vote_segment(rapid_engine* h, void* out, int64_t cap_bytes, int64_t* seg_bytes);
+int rapid_debug_vote_merge(rapid_engine* h, const void* segments, int32_t n_ranks, rapid_round_result* out, int32_t* status);
 
 #ifdef __cplusplus
 }

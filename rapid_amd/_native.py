@@ -4,9 +4,11 @@ The product has no CPU fallback: if the shared library is missing, or the host h
 classes in rapid_amd.engine raise -- they never route to the oracle.
 """
 import ctypes as C
+import json
 import os
 import shutil
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAPID_MI355X_LIB") or os.path.join(_HERE, "librapid_mi355x.so")  # override: profiling builds
@@ -60,17 +62,46 @@ def needs_build():
     return os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
 
 
+RESOURCES_PATH = os.path.join(os.path.dirname(LIB_PATH), "librapid_mi355x.resources.json")
+
+
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 cross-compiles without a GPU (about 15 s)."""
+    """hipcc --offload-arch=gfx950 cross-compiles without a GPU (about a minute).  The compiler's per-kernel resource
+    report (VGPRs, scratch bytes per lane, LDS) is kept next to the library: tests/test_build.py reads it, because a
+    tally kernel that starts spilling is a silent 20 % regression, not a build failure."""
     if not force and not needs_build():
         return LIB_PATH
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + SRC_DIR,
+           "-Rpass-analysis=kernel-resource-usage",
            os.path.join(SRC_DIR, "engine.hip"), os.path.join(SRC_DIR, "host_abi.cpp"), "-o", LIB_PATH + ".tmp", "-lrccl"]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr)
+        raise subprocess.CalledProcessError(r.returncode, cmd)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(RESOURCES_PATH, "w") as f:
+        json.dump(parse_resource_remarks(r.stderr), f, indent=1, sort_keys=True)
     return LIB_PATH
+
+
+def parse_resource_remarks(text):
+    """-Rpass-analysis=kernel-resource-usage remarks -> {mangled kernel name: {"VGPRs": n, "ScratchSize [bytes/lane]": n, ...}}."""
+    out, cur = {}, None
+    for line in text.splitlines():
+        if "remark:" not in line:
+            continue
+        body = line.split("remark:", 1)[1].split("[-Rpass-analysis", 1)[0].strip()
+        if body.startswith("Function Name:"):
+            cur = out.setdefault(body.split(":", 1)[1].strip(), {})
+        elif cur is not None and ":" in body:
+            k, v = body.rsplit(":", 1)
+            try:
+                cur[k.strip()] = int(v.strip())
+            except ValueError:
+                cur[k.strip()] = v.strip()
+    return out
 
 
 _lib = None
@@ -114,6 +145,8 @@ def _signatures():
         "rapid_engine_comm_info": (i32, [vp, pi32, pi32]),
         "rapid_sim_new_round": (i32, [vp]),
         "rapid_debug_block_stats": (i32, [vp, p, i32, pi32]),
+        "rapid_debug_vote_segment": (i32, [vp, p, i64, pi64]),
+        "rapid_debug_vote_merge": (i32, [vp, p, i32, p, pi32]),
         "rapid_sim_trust_alert_copies": (i32, [vp, i32]),
         "rapid_view_build": (i32, [vp, p, p, p, p, p, i32, p, i32, p, p, i32]),
         "rapid_view_register_endpoints": (i32, [vp, p, p, p, p, p, i32, pi32]),

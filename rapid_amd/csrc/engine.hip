@@ -134,7 +134,7 @@ struct rapid_engine {
     int num_cus = 256;
 
     // ---- votes ----
-    DevBuf<unsigned long long> d_hist, d_winner, d_mm, d_mismatch, d_voteback;
+    DevBuf<unsigned long long> d_hist, d_winner, d_mm, d_mismatch, d_voteback, d_gather;
     DevBuf<int> d_ref;
     std::vector<int> decided_cut;  // ring-0 order
     bool have_decision = false;
@@ -426,18 +426,25 @@ int build_round_index(rapid_engine* h) {
     // remaining receivers that is never shorter than what ~7 streams would take (fewer waves do not stream faster).
     // Among the wave counts that fit, the one with the smallest total wins (ties: more waves) -- e.g. 13 rather than 16
     // waves for 9,492 receivers on 256 CUs (2 x 13 + 11 instead of 2 x 16 + 5 -> 2 x 16 + 7).
+    // A population smaller than waves x CUs is spread over as many CUs as it has groups of w receivers: among equal
+    // costs the launch with more workgroups wins (1,186 receivers -- C3b's share on one of eight GPUs -- run as 238
+    // workgroups of 5 waves, not as 80 of 15), then the one with more waves.
     int best_w = 1;
+    long long best_blocks = 0;
     double best_cost = 1e300;
     int w_cap = rapid::kMaxWavesPerBlock;
     if (const char* e = getenv("RAPID_TALLY_WAVES")) w_cap = std::max(1, std::min(w_cap, atoi(e)));  // profiling knob
-    const double n_per_cu = (double)h->n_receivers / (double)std::max(1, h->num_cus), sat = 7.0;
+    const double sat = 7.0;
     for (int w = 1; w <= w_cap; ++w) {
         if (sh + w * per_wave + rapid::kBlockStatsBytes > lds_max) break;
+        const long long blocks = std::max<long long>(1, std::min<long long>(((long long)h->n_receivers + w - 1) / w, (long long)h->num_cus));
+        const double n_per_cu = (double)h->n_receivers / (double)blocks;
         const double full = std::floor(n_per_cu / w), rem = n_per_cu - full * w;
         const double cost = full * std::max((double)w, sat) + (rem > 0.0 ? std::max(rem, sat) : 0.0);
-        if (cost <= best_cost + 1e-9) {
+        if (cost < best_cost - 1e-9 || (cost <= best_cost + 1e-9 && blocks >= best_blocks)) {
             best_cost = cost;
             best_w = w;
+            best_blocks = blocks;
         }
     }
     h->waves_per_block = best_w;
@@ -589,7 +596,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
     h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release(); h->d_trank.release(); h->d_tbits.release(); h->d_tent.release();
     h->d_adj_off.release(); h->d_node_of_slot.release();
-    h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release(); h->d_voteback.release();
+    h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release(); h->d_voteback.release(); h->d_gather.release();
     (void)hipGetLastError();
     delete h;
 }
@@ -1084,11 +1091,43 @@ int rapid_sim_proposal(rapid_engine* h, int32_t receiver, int32_t* out, int32_t 
     return copy_list(h, v.data(), cnt, out, cap, n_out);
 }
 
-int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
-    if (!h || !out) return RAPID_EINVAL;
-    if (!h->tallied) return fail(h, RAPID_ESTATE, "no tally has run");
-    int rc;
-    if ((rc = use_device(h)) || (rc = ensure_host_tables(h))) return rc;
+
+// The host's reading of one answer block (res[10] + ref[]): fills *out and the engine's decision; kVoteNextSalt = two
+// proposals share the winning bucket, count again with the next salt.
+constexpr int kVoteNextSalt = 1;
+static int decode_vote_answer(rapid_engine* h, const unsigned long long* hres, const int* href, rapid_round_result* out) {
+    if ((unsigned int)hres[8] & 1u)
+        return fail(h, RAPID_EINVAL, "a delivered alert names a subject / ring that the declared alert set does not contain "
+                                    "(rapid_sim_set_alert_set must be given every distinct alert of the loaded streams)");
+    const unsigned long long* hw = hres;
+    const unsigned long long* hmm = hres + 4;
+    const unsigned long long* hmis = hres + 6;
+    out->votes_total = (int64_t)hw[2];
+    out->votes_winner = (int64_t)hw[1];
+    out->distinct_local = (int32_t)hw[3];
+    if (hw[1] == 0) return RAPID_OK;  // nobody proposed
+    const unsigned long long fmax = hmm[0], fmin = ~hmm[1];
+    if (fmax != fmin) {
+        if ((long long)hw[1] < out->quorum) return RAPID_OK;  // no proposal can have a quorum
+        return kVoteNextSalt;
+    }
+    const int ref_n = href[0];
+    if (ref_n < 0 || ref_n == 0x7FFFFFFF) return fail(h, RAPID_ECAPACITY, "winning proposal exceeds max_cut=%d", h->max_cut);
+    if (hmis[0] != 0 || hmis[1] != hw[1])
+        return fail(h, RAPID_ECOLLISION, "fingerprint collision: %llu of %llu voters differ from the representative", hmis[0], hw[1]);
+    out->cut_size = ref_n;
+    // R/FastPaxos.java:146-150: |votesReceived| >= N - F and votes[proposal] >= N - F
+    if ((long long)hw[1] >= out->quorum) {
+        out->decided = 1;
+        std::vector<int> ref(href + 1, href + 1 + ref_n);
+        sort_ring0(h, ref);
+        h->decided_cut = ref;
+        h->have_decision = true;
+    }
+    return RAPID_OK;
+}
+
+static void begin_round_result(rapid_engine* h, rapid_round_result* out) {
     std::memset(out, 0, sizeof *out);
     const int N = h->n_members;
     const int F = (int)std::floor((double)(N - 1) / 4.0);  // R/FastPaxos.java:145
@@ -1097,6 +1136,14 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
     out->config_id = h->config_id;
     h->have_decision = false;
     h->decided_cut.clear();
+}
+
+int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
+    if (!h || !out) return RAPID_EINVAL;
+    if (!h->tallied) return fail(h, RAPID_ESTATE, "no tally has run");
+    int rc;
+    if ((rc = use_device(h)) || (rc = ensure_host_tables(h))) return rc;
+    begin_round_result(h, out);
     hipStream_t st = h->stream;
     const int R = h->n_receivers;
     const size_t HB = (size_t)rapid::kVoteBuckets + 2;
@@ -1114,12 +1161,16 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
     unsigned long long* const d_mismatch = d_res + 6;
     int* const d_ref = reinterpret_cast<int*>(d_res + res_words);
     unsigned long long* hres = h->h_pinned;
-    int* href = reinterpret_cast<int*>(h->h_pinned + res_words);
     const unsigned long long my_tag = ~(unsigned long long)h->rank;
     // a population held by one rank is counted by ONE workgroup (histogram in LDS) + the element-wise verification:
     // two launches, one copy, one synchronisation; larger ones and sharded ones go through the histogram in memory
     const bool local = !h->comm && R <= 262144;
-    if (local)
+    // a sharded population: every rank counts locally the same way, ONE all-gather exchanges the ranks' answers and every
+    // rank merges them (vote_merge_kernel); only a round whose voters disagree goes through the histogram all-reduces
+    bool merged = h->comm && R <= 262144 && (h->force_exact & 512) == 0;
+    const size_t seg_words = (back_bytes + 7) / 8;
+    if (merged) HIPCHK(h, h->d_gather.ensure(seg_words * (size_t)h->n_ranks));
+    if (local || merged)
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::vote_count_local_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, rapid::kVoteBuckets * 4 + 1024));
 
@@ -1127,7 +1178,23 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
     // histogram -> (all-reduce) -> winner -> min/max of the winning bucket -> (all-reduce) -> representative list
     // -> (all-reduce) -> element-wise verification -> (all-reduce).
     for (unsigned long long salt = 0; salt < 4; ++salt) {
-        if (local) {
+        if (merged) {
+            hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st,
+                               h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
+            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * 64, 1024))), dim3(1024), 0, st,
+                               h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, nullptr, 0, nullptr,
+                               nullptr);
+            NCCLCHK(h, ncclAllGather(d_res, h->d_gather.p, seg_words, ncclUint64, h->comm, st));  // the round's one collective
+            hipLaunchKernelGGL(rapid::vote_merge_kernel, dim3(1), dim3(256), 0, st, h->d_gather.p, h->n_ranks, (int)seg_words,
+                               (int)res_words, h->max_cut, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64));
+            HIPCHK(h, hipStreamSynchronize(st));
+            HIPCHK(h, hipGetLastError());
+            if (reinterpret_cast<unsigned long long*>(h->h_mail + 64)[9] != 1ull) {  // the voters disagree somewhere: count the general way
+                merged = false;
+                --salt;
+                continue;
+            }
+        } else if (local) {
             hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st,
                                h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
             hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * 64, 1024))), dim3(1024), 0, st,
@@ -1161,43 +1228,14 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
             HIPCHK(h, hipMemcpyAsync(d_res + 4, h->d_mm.p, 16, hipMemcpyDeviceToDevice, st));
             HIPCHK(h, hipMemcpyAsync(d_res + 8, h->d_errflags.p, 8, hipMemcpyDeviceToDevice, st));
         }
-        if (!local) HIPCHK(h, hipMemcpyAsync(hres, d_res, back_bytes, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipStreamSynchronize(st));
+        if (!local && !merged) HIPCHK(h, hipMemcpyAsync(hres, d_res, back_bytes, hipMemcpyDeviceToHost, st));
+        if (!merged) HIPCHK(h, hipStreamSynchronize(st));
         HIPCHK(h, hipGetLastError());
-        if (local) {  // the last workgroup of the verification wrote the answer into host-mapped memory
+        if (local || merged) {  // the last workgroup of the verification wrote the answer into host-mapped memory
             hres = reinterpret_cast<unsigned long long*>(h->h_mail + 64);
-            href = reinterpret_cast<int*>(hres + res_words);
         }
-        if ((unsigned int)hres[8] & 1u)
-            return fail(h, RAPID_EINVAL, "a delivered alert names a subject / ring that the declared alert set does not contain "
-                                        "(rapid_sim_set_alert_set must be given every distinct alert of the loaded streams)");
-        const unsigned long long* hw = hres;
-        const unsigned long long* hmm = hres + 4;
-        const unsigned long long* hmis = hres + 6;
-        out->votes_total = (int64_t)hw[2];
-        out->votes_winner = (int64_t)hw[1];
-        out->distinct_local = (int32_t)hw[3];
-        if (hw[1] == 0) return RAPID_OK;  // nobody proposed
-        const unsigned long long fmax = hmm[0], fmin = ~hmm[1];
-        if (fmax != fmin) {
-            if ((long long)hw[1] < out->quorum) return RAPID_OK;  // no proposal can have a quorum
-            continue;  // two proposals share the winning bucket: re-hash with the next salt
-        }
-        const int ref_n = href[0];
-        if (ref_n < 0 || ref_n == 0x7FFFFFFF) return fail(h, RAPID_ECAPACITY, "winning proposal exceeds max_cut=%d", h->max_cut);
-        if (hmis[0] != 0 || hmis[1] != hw[1])
-            return fail(h, RAPID_ECOLLISION, "fingerprint collision: %llu of %llu voters differ from the representative",
-                        hmis[0], hw[1]);
-        out->cut_size = ref_n;
-        // R/FastPaxos.java:146-150: |votesReceived| >= N - F and votes[proposal] >= N - F
-        if ((long long)hw[1] >= out->quorum) {
-            out->decided = 1;
-            std::vector<int> ref(href + 1, href + 1 + ref_n);
-            sort_ring0(h, ref);
-            h->decided_cut = ref;
-            h->have_decision = true;
-        }
-        return RAPID_OK;
+        const int verdict = decode_vote_answer(h, hres, reinterpret_cast<const int*>(hres + res_words), out);
+        if (verdict != kVoteNextSalt) return verdict;
     }
     return fail(h, RAPID_ECOLLISION, "winning vote bucket stayed impure under 4 salts");
 }
@@ -1206,6 +1244,55 @@ int rapid_sim_decided_cut(rapid_engine* h, int32_t* out, int32_t cap, int32_t* n
     if (!h) return RAPID_EINVAL;
     if (!h->have_decision) return fail(h, RAPID_ESTATE, "no decision available");
     return copy_list(h, h->decided_cut.data(), (int)h->decided_cut.size(), out, cap, n_out);
+}
+
+// Testing aids for the sharded count: what this engine's voters contribute to the all-gather, and the merge of n such
+// contributions exactly as rapid_sim_count_votes runs it after its all-gather (one GPU stands in for n ranks).
+int rapid_debug_vote_segment(rapid_engine* h, void* out, int64_t cap_bytes, int64_t* seg_bytes) {
+    if (!h || !seg_bytes) return RAPID_EINVAL;
+    if (!h->tallied) return fail(h, RAPID_ESTATE, "no tally has run");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    const size_t res_words = 10, ref_len = (size_t)h->max_cut + 1;
+    const size_t seg_words = (res_words * 8 + ref_len * sizeof(int) + 7) / 8;
+    *seg_bytes = (int64_t)(seg_words * 8);
+    if (!out) return RAPID_OK;
+    if (cap_bytes < *seg_bytes) return fail(h, RAPID_ECAPACITY, "segment needs %lld bytes", (long long)*seg_bytes);
+    HIPCHK(h, h->d_voteback.ensure(seg_words));
+    unsigned long long* const d_res = h->d_voteback.p;
+    int* const d_ref = reinterpret_cast<int*>(d_res + res_words);
+    const int R = h->n_receivers;
+    hipStream_t st = h->stream;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::vote_count_local_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, rapid::kVoteBuckets * 4 + 1024));
+    hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st, h->d_fp.p,
+                       h->d_pcount.p, h->d_props.p, h->max_cut, R, 0ull, h->d_errflags.p, d_res, d_ref);
+    hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * 64, 1024))), dim3(1024), 0, st, h->d_fp.p,
+                       h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_res + 6, nullptr, 0, nullptr, nullptr);
+    HIPCHK(h, hipMemcpyAsync(out, d_res, seg_words * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    return RAPID_OK;
+}
+
+int rapid_debug_vote_merge(rapid_engine* h, const void* segments, int32_t n_ranks, rapid_round_result* out, int32_t* status) {
+    if (!h || !segments || n_ranks <= 0 || !out || !status) return RAPID_EINVAL;
+    int rc;
+    if ((rc = use_device(h)) || (rc = ensure_host_tables(h)) || (rc = ensure_mailbox(h))) return rc;
+    begin_round_result(h, out);
+    const size_t res_words = 10, ref_len = (size_t)h->max_cut + 1;
+    const size_t seg_words = (res_words * 8 + ref_len * sizeof(int) + 7) / 8;
+    HIPCHK(h, h->d_gather.ensure(seg_words * (size_t)n_ranks));
+    hipStream_t st = h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->d_gather.p, segments, seg_words * 8 * (size_t)n_ranks, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rapid::vote_merge_kernel, dim3(1), dim3(256), 0, st, h->d_gather.p, n_ranks, (int)seg_words, (int)res_words,
+                       h->max_cut, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipGetLastError());
+    const unsigned long long* hres = reinterpret_cast<const unsigned long long*>(h->h_mail + 64);
+    *status = (int32_t)hres[9];
+    if (hres[9] != 1ull) return RAPID_OK;  // the voters disagree: rapid_sim_count_votes would count the general way
+    const int verdict = decode_vote_answer(h, hres, reinterpret_cast<const int*>(hres + res_words), out);
+    return verdict == kVoteNextSalt ? fail(h, RAPID_ESTATE, "merged answer is impure") : verdict;
 }
 
 int rapid_apply_cut(rapid_engine* h, const int32_t* cut, int32_t n, int64_t* new_config_id) {

@@ -53,11 +53,6 @@ constexpr int kRecBytes = 20;
 #ifndef RAPID_QUARTERS
 #define RAPID_QUARTERS 4
 #endif
-#ifndef RAPID_WINDOWS_IN_FLIGHT
-#define RAPID_WINDOWS_IN_FLIGHT 1
-#endif
-constexpr int kInFlight = RAPID_WINDOWS_IN_FLIGHT;  // windows requested ahead of the one being tallied (1 or 2)
-static_assert(kInFlight == 1 || kInFlight == 2, "one or two register sets");
 constexpr int kQ = RAPID_QUARTERS;        // quarters (64 records each) per window
 constexpr int kWin = kQ * kWave;          // 256 records = 5 KiB of stream per window
 constexpr int kQuarterBytes = kWave * kRecBytes;
@@ -439,9 +434,21 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     unsigned short* const l_smask = reinterpret_cast<unsigned short*>(smem + dict_bytes + pairs_bytes);
     int* const l_nos = reinterpret_cast<int*>(smem + dict_bytes + pairs_bytes + align16((n_hot + kDummySlots) * 2));
     if (threadIdx.x == 0) l_pairs[0] = (unsigned int)p.idx.n_adj;
-    for (int i = (int)threadIdx.x; i < p.idx.n_adj; i += (int)blockDim.x) l_pairs[1 + i] = p.idx.pairs[i];
-    for (int i = (int)threadIdx.x; i < n_hot + kDummySlots; i += (int)blockDim.x) l_smask[i] = i < n_hot ? p.idx.smask[i] : (unsigned short)0;
-    for (int i = (int)threadIdx.x; i < n_hot; i += (int)blockDim.x) l_nos[i] = p.idx.node_of_slot[i];
+    {
+        // ONE loop on purpose: with three separate copy loops here the register allocation of the whole kernel changes
+        // (the per-delivery-filter instantiations go from 116-125 VGPRs to 128 + 104-148 B of scratch per lane, whose
+        // reloads sit inside the receiver loop: 0.42 -> 0.52 ms on C3b); tests/test_build.py checks the scratch size.
+        const int n_stage = p.idx.n_adj > n_hot + kDummySlots ? p.idx.n_adj : n_hot + kDummySlots;
+        for (int i = (int)threadIdx.x; i < n_stage; i += (int)blockDim.x) {
+            if (i < p.idx.n_adj) l_pairs[1 + i] = p.idx.pairs[i];
+            if (i < n_hot) {
+                l_smask[i] = p.idx.smask[i];
+                l_nos[i] = p.idx.node_of_slot[i];
+            } else if (i < n_hot + kDummySlots) {
+                l_smask[i] = 0;
+            }
+        }
+    }
     const unsigned int* const pairs = l_pairs;
     const unsigned short* const smask = l_smask;
     const int* const node_of_slot = l_nos;
@@ -585,7 +592,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // crosses that channel waits with them.
     const int n_blocks = (int)gridDim.x;
     int r = uniform(wave * n_blocks + (int)blockIdx.x);  // the first deal: claim number `wave` of this workgroup
-    Win W, W2;  // the windows in flight: window w of a receiver lives in W (w even) or W2 (w odd) when kInFlight = 2
+    Win W;  // the window in flight
     Stream rsrc;
     rsrc.base = p.records;
     rsrc.bytes = 0u;
@@ -599,7 +606,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         nrec = (int)(rec1 - rec0);
         rsrc = make_stream(rec0, rec1);
         load_window(rsrc, lane20, W);
-        if (kInFlight > 1) load_window(rsrc, lane20 + (unsigned int)(kWin * kRecBytes), W2);
     }
     while (r < p.n_receivers) {
 #ifdef RAPID_PHASE_TIMERS
@@ -1059,20 +1065,18 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 restart = false;
                 exact_only = true;
                 load_window(rsrc, lane20, W);
-                if (kInFlight > 1) load_window(rsrc, lane20 + (unsigned int)(kWin * kRecBytes), W2);
-            }
+                    }
             wave_lds_fence();
-            // One step: window w out of its register set X, which is refilled with window w + kInFlight right away -- so kInFlight
-            // windows (5 KiB each) are on their way while one is tallied.  The sets keep their roles, so the loop body is
-            // kInFlight steps long (the step is instantiated once per set).
-            auto step = [&](Win& X, int w) {
-                const Win cur = X;
-                load_window(rsrc, lane20 + (unsigned int)(w + kInFlight) * (unsigned int)(kWin * kRecBytes), X);
+            unsigned int voff = lane20;
+            for (int w = 0; w < nwin && emit_batch < 0 && !restart; ++w) {
+                const Win cur = W;
+                voff += (unsigned int)(kWin * kRecBytes);
+                load_window(rsrc, voff, W);  // the next window is in flight while this one is tallied
                 if (!claimed && w + kClaimAhead >= nwin) claim();
                 if ((p.flags & 32) != 0) {  // measurement aid: stream the records through the registers without tallying them
 #pragma unroll
                     for (int q = 0; q < kQ; ++q) sink ^= cur.w3[q] ^ cur.w4[q] ^ (kTrusted ? 0u : cur.w0[kTrusted ? 0 : q] ^ cur.w1[kTrusted ? 0 : q]);
-                    return;
+                    continue;
                 }
                 bool done = false;
                 swept = false;
@@ -1100,15 +1104,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     RAPID_T1(t_lean, tl0);
                 }
                 if (!done) slow_window(cur, w);
-            };
-            for (int w = 0; w < nwin && emit_batch < 0 && !restart;) {
-                step(W, w);
-                ++w;
-                if (kInFlight > 1) {
-                    if (!(w < nwin && emit_batch < 0 && !restart)) break;
-                    step(W2, w);
-                    ++w;
-                }
             }
             if (!restart) break;
         }
@@ -1124,8 +1119,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             nrec_next = (int)(rec1 - rec0);
             rsrc = make_stream(rec0, rec1);
             load_window(rsrc, lane20, W);
-            if (kInFlight > 1) load_window(rsrc, lane20 + (unsigned int)(kWin * kRecBytes), W2);
-        }
+            }
 
         // ---- outputs: the proposal = every flushed (hot) slot, ascending node index ----
         int count = 0;

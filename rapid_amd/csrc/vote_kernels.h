@@ -307,4 +307,77 @@ __global__ __launch_bounds__(1024) void vote_count_local_kernel(const unsigned l
     if (t == 0) ref[0] = n;
 }
 
+// Populations sharded over ranks: every rank counts its own voters (vote_count_local_kernel + vote_verify_kernel, as for a
+// population it holds alone), ONE all-gather moves the ranks' answers -- res[res_words] + ref[1 + prop_cap], `seg_words`
+// 64-bit words per rank -- to everybody, and this kernel (one workgroup, on every rank, over identical input) merges them.
+// The merge is exact whenever every rank's voters are unanimous among themselves (one non-empty bucket, pure, every
+// voter verified element-wise against the rank's representative) and the ranks' representatives hold the same list:
+// then the cluster has ONE proposal, its votes are the sum of the ranks' (R/FastPaxos.java:141-150), and the answer is
+// published to host-mapped memory in the single-rank format with res[9] = 1.  Anything else -- two proposals anywhere,
+// an impure bucket -- publishes res[9] = 2 and the host goes through the histogram all-reduce path, on every rank alike
+// (they all merged the same data).  A representative larger than prop_cap anywhere is reported as ref[0] = -1.
+__global__ __launch_bounds__(256) void vote_merge_kernel(const unsigned long long* gathered, int n_ranks, int seg_words,
+                                                          int res_words, int prop_cap, volatile unsigned long long* publish) {
+    __shared__ int s_lead, s_simple, s_overflow;
+    __shared__ unsigned long long s_votes, s_voters, s_err;
+    if (threadIdx.x == 0) {
+        int lead = -1, simple = 1, overflow = 0;
+        unsigned long long votes = 0, voters = 0, err = 0, lead_fp = 0;
+        for (int k = 0; k < n_ranks; ++k) {
+            const unsigned long long* res = gathered + (long long)k * seg_words;
+            const int* ref = reinterpret_cast<const int*>(res + res_words);
+            err |= res[8];
+            voters += res[2];
+            if (res[1] == 0ull) continue;  // nobody on this rank proposed
+            votes += res[1];
+            if (res[3] != 1ull || res[4] != ~res[5] || res[6] != 0ull || res[7] != res[1] || res[2] != res[1]) simple = 0;
+            if (ref[0] < 0) overflow = 1;
+            if (lead < 0) {
+                lead = k;
+                lead_fp = res[4];
+            } else if (res[4] != lead_fp || ref[0] != reinterpret_cast<const int*>(gathered + (long long)lead * seg_words + res_words)[0]) {
+                simple = 0;
+            }
+        }
+        s_lead = lead;
+        s_simple = simple;
+        s_overflow = overflow;
+        s_votes = votes;
+        s_voters = voters;
+        s_err = err;
+    }
+    __syncthreads();
+    const int lead = s_lead;
+    const int* const lref = lead < 0 ? nullptr : reinterpret_cast<const int*>(gathered + (long long)lead * seg_words + res_words);
+    int n = lead < 0 ? 0 : lref[0];
+    n = (n < 0 || n > prop_cap) ? 0 : n;
+    int differ = 0;
+    if (s_simple != 0 && s_overflow == 0) {
+        for (int k = lead + 1; k < n_ranks; ++k) {
+            const unsigned long long* res = gathered + (long long)k * seg_words;
+            if (res[1] == 0ull) continue;
+            const int* ref = reinterpret_cast<const int*>(res + res_words);
+            for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) differ |= ref[1 + i] != lref[1 + i];
+        }
+    }
+    differ = __syncthreads_or(differ);
+    volatile int* const pref = reinterpret_cast<volatile int*>(publish + res_words);
+    for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) pref[1 + i] = lref[1 + i];
+    if (threadIdx.x == 0) {
+        const unsigned long long* lres = lead < 0 ? gathered : gathered + (long long)lead * seg_words;
+        const bool ok = s_simple != 0 && differ == 0;
+        pref[0] = s_overflow ? -1 : n;
+        publish[0] = lead < 0 ? 0ull : lres[0];
+        publish[1] = s_votes;
+        publish[2] = s_voters;
+        publish[3] = lead < 0 ? 0ull : 1ull;
+        publish[4] = lead < 0 ? 0ull : lres[4];
+        publish[5] = lead < 0 ? ~0ull : lres[5];
+        publish[6] = 0ull;
+        publish[7] = s_votes;
+        publish[8] = s_err;
+        publish[9] = ok ? 1ull : 2ull;
+    }
+}
+
 }  // namespace rapid

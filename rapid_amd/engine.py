@@ -338,6 +338,23 @@ class ClusterSimulation:
         self.e._check(self.e._lib.rapid_sim_count_votes(self.e._h, C.byref(rr)))
         return rr
 
+    def vote_segment(self):
+        """Testing aid: the answer block this engine's voters contribute to the sharded count's all-gather (bytes)."""
+        n = C.c_int64(0)
+        self.e._check(self.e._lib.rapid_debug_vote_segment(self.e._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        self.e._check(self.e._lib.rapid_debug_vote_segment(self.e._h, _addr(out), n.value, C.byref(n)))
+        return out
+
+    def merge_vote_segments(self, segments):
+        """Testing aid: the device-side merge of the ranks' answer blocks -> (status, RoundResult); status 1 = merged,
+        2 = the voters disagree somewhere (rapid_sim_count_votes would then count through the histogram all-reduces)."""
+        blob = np.ascontiguousarray(np.concatenate(segments))
+        rr = RoundResult()
+        status = C.c_int32(0)
+        self.e._check(self.e._lib.rapid_debug_vote_merge(self.e._h, _addr(blob), len(segments), C.byref(rr), C.byref(status)))
+        return status.value, rr
+
     def decided_cut(self):
         out = np.empty(self.e.max_cut, dtype=np.int32)
         n = C.c_int32(0)

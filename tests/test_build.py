@@ -1,0 +1,34 @@
+"""The compiler's verdict on the hot kernels, checked on the CPU: rapid_amd._native.build() keeps hipcc's per-kernel resource
+report next to the library, and the tally kernel must not spill.  Its six instantiations sit between 89 and 125 VGPRs
+under a budget of 128 (16 waves per CU), so an innocent-looking edit can push one over: the reloads then land inside the
+receiver loop, count against vmcnt like stream loads, and cost ~20 % (measured in round 2: 0.42 -> 0.52 ms on C3b for the
+per-delivery-filter kernels) without any test failing."""
+import json
+import os
+
+from rapid_amd import _native as N
+
+
+def resources():
+    if not os.path.exists(N.RESOURCES_PATH) or N.needs_build():
+        N.build(force=True)
+    with open(N.RESOURCES_PATH) as f:
+        return json.load(f)
+
+
+def test_tally_kernels_fit_the_register_file_without_scratch():
+    res = resources()
+    tally = {k: v for k, v in res.items() if "tally_population_kernel" in k}
+    assert len(tally) == 6, sorted(tally)  # {dictionary in memory, direct, compressed} x {filter per delivery, trusted copies}
+    for name, r in tally.items():
+        assert r["ScratchSize [bytes/lane]"] == 0, (name, r)
+        assert r["VGPRs"] <= 128, (name, r)          # 16 waves per CU = 4 per SIMD
+        assert r["Occupancy [waves/SIMD]"] >= 4, (name, r)
+
+
+def test_every_other_kernel_of_the_path_is_scratch_free_too():
+    res = resources()
+    ours = {k: v for k, v in res.items() if k.startswith("_ZN5rapid")}
+    assert len(ours) >= 20
+    spilling = {k: v["ScratchSize [bytes/lane]"] for k, v in ours.items() if v.get("ScratchSize [bytes/lane]", 0) != 0}
+    assert not spilling, spilling

@@ -647,15 +647,17 @@ def test_classic_round_recovers_a_population_without_fast_quorum(E):
 def test_vote_count_through_a_one_rank_communicator(E):
     """The sharded vote count (R/FastPaxos.java:104, 125-156 with the N x N unicast fan-out of
     R/UnicastToAllBroadcaster.java:46-52 replaced by collectives) executed on ONE GPU: an engine with a 1-rank RCCL
-    communicator runs every collective of rapid_sim_count_votes -- the histogram all-reduce, the max-reduce that elects
-    the rank holding the representative (rank-tag trick), the max-reduce that hands its list to everybody, the
-    sum-reduce of the verification counters -- and must decide exactly what the engine without a communicator decides:
-    a crash burst with a quorum, a churn round (joins + crashes), and a population without a fast quorum."""
+    communicator runs the collectives of rapid_sim_count_votes -- by default the ONE all-gather of the ranks' local
+    answers + the device-side merge (a round whose voters disagree then falls through to the general count), and under
+    knob 512 always the general count: the histogram all-reduce, the max-reduce that elects the rank holding the
+    representative (rank-tag trick), the max-reduce that hands its list to everybody, the sum-reduce of the verification
+    counters -- and must decide exactly what the engine without a communicator decides: a crash burst with a quorum, a
+    churn round (joins + crashes), and a population without a fast quorum."""
     n, K, H, L = 2000, 10, 9, 4
     pop = S.Population.make(n)
     members = list(range(0, n - 40))
 
-    def run(with_comm, case):
+    def run(with_comm, case, knob=0):
         eng, view = make_engine(E, pop, K, H, L, members=members)
         if with_comm:
             eng.comm_init(E.comm_unique_id(), 0, 1)
@@ -668,12 +670,19 @@ def test_vote_count_through_a_one_rank_communicator(E):
             sc = S.build_churn_scenario(obs, member, cfg, 20, 0, H, L)
         elif case == "churn":
             sc = S.build_churn_scenario(obs, member, cfg, 12, 15, H, L)
-        else:  # 3 % of the (receiver, batch) deliveries are lost: the proposals differ and none reaches the quorum
+        elif case == "noquorum":  # 3 % of the (receiver, batch) deliveries are lost: too few receivers propose at all
             sc = S.build_churn_scenario(obs, member, cfg, 25, 0, H, L, materialise=False)
             recs, off, nb = S.deliver(sc.batches, sc.receivers, 77, loss=0.03)
             sc.records, sc.rec_off = recs, off
+        else:  # two groups of receivers see two different fault sets: two proposals, the merge must hand over to the general count
+            sc = S.build_churn_scenario(obs, member, cfg, 20, 0, H, L)
+            sc3 = S.build_churn_scenario(obs, member, cfg, 20, 0, H, L, seed_fault=5)
+            a, b = int(sc.rec_off[700]), int(sc3.rec_off[400])
+            sc.records = np.concatenate([sc.records[:a], sc3.records[:b]])
+            sc.rec_off = np.concatenate([sc.rec_off[:701], sc3.rec_off[1:401] + a])
         sim = E.ClusterSimulation(eng)
         sim.load_streams(sc.records, sc.rec_off)
+        sim.set_force_exact(knob)
         sim.tally()
         rr = sim.count_votes()
         out = dict(decided=rr.decided, cut_size=rr.cut_size, quorum=rr.quorum, votes_total=rr.votes_total,
@@ -684,391 +693,96 @@ def test_vote_count_through_a_one_rank_communicator(E):
         eng.close()
         return out, sc
 
-    for case in ("crash", "churn", "noquorum"):
+    for case in ("crash", "churn", "noquorum", "conflict"):
         a, sc = run(False, case)
-        b, _ = run(True, case)
-        for k in ("decided", "cut_size", "quorum", "votes_total", "votes_winner", "membership", "cut"):
-            assert a[k] == b[k], (case, k, a[k], b[k])
-        assert all(np.array_equal(x, y) for x, y in zip(a["results"], b["results"])), case
-        if case == "noquorum":
-            assert a["decided"] == 0 and 0 < a["votes_winner"] < a["quorum"]
-        else:
-            assert a["decided"] == 1 and sorted(a["cut"]) == sc.faulty.tolist() and a["new_cfg"] == b["new_cfg"]
+        for knob in (0, 512):
+            b, _ = run(True, case, knob)
+            for k in ("decided", "cut_size", "quorum", "votes_total", "votes_winner", "membership", "cut", "new_cfg"):
+                assert a.get(k) == b.get(k), (case, knob, k, a.get(k), b.get(k))
+            assert all(np.array_equal(x, y) for x, y in zip(a["results"], b["results"])), (case, knob)
+        assert a["decided"] == (0 if case in ("noquorum", "conflict") else 1)
+        if case == "conflict":
+            assert (a["votes_total"], a["votes_winner"]) == (1100, 700)
 
 
-def test_declared_alert_set_that_does_not_cover_the_streams_is_rejected(E):
-    """rapid_sim_set_alert_set is a promise the engine checks: a delivered report about a subject (or ring of a cold
-    subject) missing from the declared set -> RAPID_EINVAL at the next read of results, not silently different cuts; a set
-    from another configuration is simply not trusted (per-delivery filter), and an honest set changes nothing."""
+def test_sharded_vote_count_merges_the_ranks_local_answers(E):
+    """The merge every rank runs after the all-gather of rapid_sim_count_votes (vote_merge_kernel), with one GPU standing in
+    for three ranks: the receivers of a round are cut into three shards, each shard is tallied and counted on its own
+    (rapid_debug_vote_segment = what the rank would contribute), and the merged answer must be the answer of the whole
+    population counted at once (R/FastPaxos.java:141-150: votes for the one proposal = sum over the ranks).  A shard
+    nobody proposes on contributes nothing; a round whose voters disagree -- within a shard or between shards -- is
+    recognised (status 2: the general histogram count would run) instead of being merged.  (Deliveries lost on the way do
+    not make voters disagree: a receiver that misses a batch never reaches H for its subjects and does not vote at all.)"""
     n, K, H, L = 2000, 10, 9, 4
     pop = S.Population.make(n)
     eng, view = make_engine(E, pop, K, H, L)
     obs, subj, member = view.tables()
     cfg = view.getCurrentConfigurationId()
-    sc = S.build_scenario("C2", subj, cfg, n=n, f=20, H=H, L=L)
-    sim, want = run_population(E, eng, sc.records, sc.rec_off)
-    # honest declaration
-    sim, res = run_population(E, eng, sc.records, sc.rec_off, alert_set=sc.batches.recs)
-    assert sim.index_info()["alerts_prevalidated"] == 1 and all(np.array_equal(a, b) for a, b in zip(want, res))
-    # every alert about one faulty subject withheld from the set
-    short = sc.batches.recs[sc.batches.recs["dst"] != sc.faulty[3]]
     sim = E.ClusterSimulation(eng)
-    sim.load_streams(sc.records, sc.rec_off)
-    sim.set_alert_set(short, trust_copies=True)
-    sim.tally()
-    with pytest.raises(E.IllegalArgumentException):
-        sim.results()
-    with pytest.raises(E.IllegalArgumentException):
-        sim.count_votes()
-    # ... with or without the caller vouching for the deliveries: the index simply was not built for that subject
-    sim = E.ClusterSimulation(eng)
-    sim.load_streams(sc.records, sc.rec_off)
-    sim.set_alert_set(short)
-    sim.tally()
-    with pytest.raises(E.IllegalArgumentException):
-        sim.results()
-    # a delivered record with the wrong status for its subject (an UP alert about a member), set otherwise honest
-    bad = sc.records.copy()
-    k = int(np.flatnonzero(np.isin(bad["dst"], sc.faulty))[5])
-    bad["status"][k] = S.UP
-    sim = E.ClusterSimulation(eng)
-    sim.load_streams(bad, sc.rec_off)
-    sim.set_alert_set(sc.batches.recs, trust_copies=True)
-    sim.tally()
-    with pytest.raises(E.IllegalArgumentException):
-        sim.results()
-    # the same streams without the promise (index from the set, filter per delivery) and without a declaration: the filter
-    # drops that record, as the reference does
-    sim, res2b = run_population(E, eng, bad, sc.rec_off, alert_set=sc.batches.recs, trust=False)
-    sim, res2 = run_population(E, eng, bad, sc.rec_off)
-    assert all(np.array_equal(a, b) for a, b in zip(res2, res2b))
-    fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, bad, sc.rec_off, nthreads=8)
-    assert np.array_equal(res2[0], fe) and np.array_equal(res2[2], np.diff(fo))
-    # a set stamped with another configuration id is not trusted at all: same results as without it
-    stale = sc.batches.recs.copy()
-    stale["cfg_id"] = cfg + 1
-    sim, res3 = run_population(E, eng, sc.records, sc.rec_off, alert_set=stale)
-    assert sim.index_info()["alerts_prevalidated"] == 0 and all(np.array_equal(a, b) for a, b in zip(want, res3))
 
+    def shard(records, rec_off, a, b):
+        return records[rec_off[a]: rec_off[b]], (rec_off[a: b + 1] - rec_off[a]).astype(np.int64)
 
-# ------------------------------------------------------------- the dictionary-in-memory instantiations (C4's mode)
-@pytest.mark.parametrize("name,n,f,K,H,L", [("C2", 2000, 20, 10, 9, 4), ("C3b", 1500, 40, 10, 9, 4)])
-def test_tables_in_memory_mode_vs_faithful_oracle(E, name, n, f, K, H, L):
-    """Populations whose plain node -> slot tables do not fit the LDS (N >~ 30,000) run the tally kernel with the
-    compressed tables (bitmap + rank) in LDS, and beyond that with the dictionary in memory.  Knobs 128 / 256 force these
-    modes at a size the faithful oracle can check: both instantiations (deliveries vouched for / per-delivery filter) of
-    both modes must give the oracle's results."""
-    pop = S.Population.make(n)
-    eng, view = make_engine(E, pop, K, H, L)
-    reg, oview = oracle_view(pop, K)
-    obs, subj, member = view.tables()
-    cfg = view.getCurrentConfigurationId()
-    sc = S.build_scenario(name, subj, cfg, n=n, f=f, H=H, L=L)
-    rx = np.arange(0, len(sc.receivers), max(1, len(sc.receivers) // 150))
-    sub_off = np.zeros(len(rx) + 1, dtype=np.int64)
-    parts = []
-    for i, r in enumerate(rx):
-        parts.append(sc.records[sc.rec_off[r]:sc.rec_off[r + 1]])
-        sub_off[i + 1] = sub_off[i] + len(parts[-1])
-    oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, np.concatenate(parts), sub_off, nthreads=8)
-    want_fp = proposal_fingerprints(oo, op, oe >= 0)
-    sim0, ref = run_population(E, eng, sc.records, sc.rec_off)
-    assert sim0.index_info()["dict_mode"] == 1
-    # 128: compressed tables in LDS, 256: dictionary in memory; alone: the pre-validated instantiation (every delivered alert
-    # passes the filter); | 64: per-delivery filter; | 1: exact path
-    for mode_knob, mode in ((128, 2), (256, 0)):
-      for kw in (dict(force_exact=mode_knob), dict(force_exact=mode_knob | 64), dict(force_exact=mode_knob, alert_set=sc.batches.recs),
-                 dict(force_exact=mode_knob | 64, alert_set=sc.batches.recs), dict(force_exact=mode_knob | 1)):
-        sim, res = run_population(E, eng, sc.records, sc.rec_off, **kw)
-        info = sim.index_info()
-        assert info["dict_mode"] == mode and info["alert_set_declared"] == (1 if "alert_set" in kw else 0)
-        assert all(np.array_equal(a, b) for a, b in zip(ref, res)), kw
-        assert np.array_equal(res[0][rx], oe) and np.array_equal(res[1][rx], on) and np.array_equal(res[3][rx], want_fp)
+    def segments_of(sc, cuts, declared=None):
+        segs = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            recs, off = shard(sc.records, sc.rec_off, a, b)
+            sim.load_streams(recs, off)
+            sim.set_alert_set(sc.batches.recs if declared is None else declared)
+            sim.tally()
+            segs.append(sim.vote_segment())
+        return segs
 
-
-def test_c4_shaped_shard_against_fast_oracle(E):
-    """BASELINE configs[3] as one rank sees it: N = 100,000, K = 10, 1,000 crashed nodes (1 % churn), a shard of the
-    receivers.  The dictionary (2 x 200 KB) stays in memory; results against the optimised CPU formulation, proposal
-    contents through the fingerprints, and the vote count over the shard."""
-    n, K, H, L = 100000, 10, 9, 4
-    pop = S.Population.make(n)
-    eng, view = make_engine(E, pop, K, H, L)
-    obs, subj, member = view.tables()
-    cfg = view.getCurrentConfigurationId()
-    sc0 = S.build_scenario("C4", subj, cfg, materialise=False)
-    rx = sc0.receivers[:: len(sc0.receivers) // 640][:640]
-    sc = S.build_scenario("C4", subj, cfg, receivers=rx)
-    fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=16)
-    for kw in (dict(), dict(alert_set=sc.batches.recs)):
-        sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off, **kw)
-        assert sim.index_info()["dict_mode"] == 2  # 2 x 200 KB of plain tables do not fit the LDS, the compressed form does
-        assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
-        assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
-    sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off, force_exact=256)  # ... and from memory
-    assert sim.index_info()["dict_mode"] == 0 and np.array_equal(emit, fe) and np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
-    assert np.all(fe >= 0) and sorted(sim.proposal(0)) == sc.faulty.tolist()
-    rr = sim.count_votes()
-    assert rr.votes_winner == len(rx) and rr.decided == 0 and rr.quorum == n - (n - 1) // 4  # a shard alone has no quorum
-
-
-# ------------------------------------------------------------------ C5: streaming rounds, stale records, quirk Q4
-def _oracle_decide(oview, K, H, L, pop, sc, cut):
-    """decideViewChange on the oracle: it learns the joiners' NodeIds from the UP alerts (only the batches that carry one
-    are replayed: the faithful detector is quadratic in the number of subjects in flux)."""
-    svc = O.AlertBatchService(oview, K, H, L, pop.id_hi, pop.id_lo)
-    r0 = sc.records[sc.rec_off[0]:sc.rec_off[1]]
-    beg = 0
-    for e in np.flatnonzero(r0["flags"] & S.FLAG_LAST_IN_BATCH) + 1:
-        b = r0[beg:int(e)]
-        if np.any((b["status"] == S.UP) & (b["cfg_id"] == oview.getCurrentConfigurationId())):
-            svc.handleBatchedAlertMessage(b)
-        beg = int(e)
-    svc.decideViewChange(cut)
-
-
-def test_streaming_rounds_with_stale_records_and_the_observer_cache(E):
-    """BASELINE configs[4] (continuous churn) at a size the faithful oracle can follow: six consecutive rounds over one
-    population -- a fresh 1 % of the members crashes and 0.5 % joins in every round, 1 % of the delivered records still carry
-    the previous configuration id (R/MembershipService.java:653-657), the decided cut is applied
-    (R/MembershipService.java:385-430) and the next round runs in the new configuration.  Every round: the engine's
-    per-receiver results equal the optimised oracle on all receivers and the FAITHFUL oracle -- whose view keeps its
-    observer cache across the rounds, quirk Q4 -- on a sample; the new configuration id and the observer table equal the
-    oracle's; and the Q4 guard shows that no receiver can hold a stale cache entry for a subject in flux."""
-    K, H, L = 10, 9, 4
-    n_mem, spare, rounds = 10000, 400, 6
-    pop = S.Population.make(n_mem + spare)
-    members = list(range(n_mem))
-    eng, view = make_engine(E, pop, K, H, L, members=members)
-    reg, oview = oracle_view(pop, K, members)
-    st = S.StreamingChurn(H, L, receivers_per_round=300)
-    guard = E.ObserverCacheGuard()
-    sim = E.ClusterSimulation(eng)
-    n = pop.n
-    for rnd in range(rounds):
-        obs, subj, member = view.tables()
-        cfg = view.getCurrentConfigurationId()
-        assert cfg == oview.getCurrentConfigurationId()
-        sc = st.next_round(obs, member, cfg)
-        if rnd > 0:
-            assert 0 < int((sc.records["cfg_id"] != cfg).sum()) < len(sc.records) // 50  # the stale records are there
-        # Q4: no member that is in flux now was in flux (= queried, cached) in an earlier configuration with other observers
-        assert guard.check_round(view, sc.faulty) == []
-        for s_ in sc.crashed[:: max(1, len(sc.crashed) // 25)]:
-            assert oview.getObserversOf(int(s_)) == oview.computeObserversOf(int(s_)) == view.getObserversOf(int(s_))
+    def whole(sc):
         sim.load_streams(sc.records, sc.rec_off)
-        sim.set_alert_set(sc.batches.recs)  # the index from the round's alerts; the deliveries are NOT vouched for (stale records)
+        sim.set_alert_set(sc.batches.recs)
         sim.tally()
-        emit, nprop, pcount, fp = sim.results()
-        fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=16)
-        assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
-        assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
-        m = 40  # the faithful restatement, observer cache carried over from the earlier rounds (single-threaded)
-        oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, sc.records[: sc.rec_off[m]], sc.rec_off[: m + 1],
-                                   prewarm_observers=False)
-        assert np.array_equal(emit[:m], oe) and np.array_equal(nprop[:m], on)
-        assert np.array_equal(fp[:m], proposal_fingerprints(oo, op, oe >= 0))
-        first = int(np.flatnonzero(fe >= 0)[0])
-        cut = sorted(fpp[fo[first]:fo[first + 1]].tolist())
-        assert cut == sc.faulty.tolist()
-        new_cfg = sim.apply_cut(cut)
-        _oracle_decide(oview, K, H, L, pop, sc, cut)
-        guard.on_view_change(sc.crashed)
-        assert new_cfg == oview.getCurrentConfigurationId()
-        assert view.getMembershipSize() == oview.getMembershipSize()
-    o2, s2, m2 = view.tables()
-    oo2, os2, om2 = oview.tables(n)
-    assert np.array_equal(m2, om2) and np.array_equal(s2, os2) and np.array_equal(o2, oo2)
+        rr = sim.count_votes()
+        return rr, (sim.decided_cut() if rr.decided else None)
 
-
-def test_streaming_rounds_at_100k_nodes(E):
-    """The same stream at N = 100,000 (a single-GPU-sized slice of BASELINE configs[4]): three rounds, 1,000 crashes + 500 joins
-    each, against the optimised oracle on every simulated receiver; configuration ids against the oracle's view."""
-    K, H, L = 10, 9, 4
-    n_mem, spare, rounds = 100000, 2000, 3
-    pop = S.Population.make(n_mem + spare)
-    members = list(range(n_mem))
-    eng, view = make_engine(E, pop, K, H, L, members=members)
-    reg, oview = oracle_view(pop, K, members)
-    st = S.StreamingChurn(H, L, receivers_per_round=192)
-    sim = E.ClusterSimulation(eng)
-    for rnd in range(rounds):
-        obs, subj, member = view.tables()
-        cfg = view.getCurrentConfigurationId()
-        assert cfg == oview.getCurrentConfigurationId()
-        sc = st.next_round(obs, member, cfg)
-        sim.load_streams(sc.records, sc.rec_off)
-        sim.set_alert_set(sc.batches.recs)  # the index from the round's alerts; the deliveries are NOT vouched for (stale records)
-        sim.tally()
-        emit, nprop, pcount, fp = sim.results()
-        fe, fn, fo, fpp = O.fast_sim_run(pop.n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=16)
-        assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
-        assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
-        # with 1,500 subjects in flux and 1 % of the reports lost to the stale configuration id, most receivers stay blocked
-        # (a subject short of H blocks the proposal); whoever does announce announces the whole fault set, which is the cut
-        # the round eventually settles on
-        for r_ in np.flatnonzero(fe >= 0)[:5]:
-            assert sorted(fpp[fo[r_]:fo[r_ + 1]].tolist()) == sc.faulty.tolist()
-        cut = sc.faulty.tolist()
-        new_cfg = sim.apply_cut(cut)
-        _oracle_decide(oview, K, H, L, pop, sc, cut)
-        assert new_cfg == oview.getCurrentConfigurationId() and view.getMembershipSize() == oview.getMembershipSize()
-        for s_ in (int(sc.joiners[0]), int(sc.receivers[0]), int(sc.receivers[-1])):
-            assert view.getObserversOf(s_) == oview.computeObserversOf(s_)
-
-
-# ------------------------------------------------------------------ f3: serialized rapid.proto bytes -> device tally
-def test_wire_bytes_to_device_tally_with_joiners_unknown_at_start(E):
-    """SURVEY 8f rank 3 end to end: a churn round as the reference puts it on the wire -- one serialized
-    RapidRequest{BatchedAlertMessage} per sender (rapid.proto:95-129), delivered to every receiver in its own order -- goes
-    through rapid_decode_request / rapid_decode_batched_alerts_ex into packed records, is loaded and tallied on the GPU, and
-    must give what the oracle gives when it is fed the SAME messages decoded by the Python protobuf runtime.  The joiners'
-    endpoints are in neither the endpoint map nor the engine's registry when the round starts (a receiver first hears of
-    them through the UP alerts, R/MembershipService.java:677-685): the facade registers them on both sides
-    (rapid_endpoint_map_add_wire, rapid_view_register_endpoints) and decodes again; then the fast round decides and the
-    cut (crashed members out, joiners in) gives the oracle's next configuration."""
-    from rapid_amd import wire as W
-    from tests import proto_rapid as P
-    n_all, n_mem, K, H, L = 760, 700, 10, 9, 4
-    pop = S.Population.make(n_all)
-    members = list(range(n_mem))
-    reg, oview = oracle_view(pop, K, members)  # the oracle's registry holds everybody (handle == index into pop)
-    obs_o, subj_o, member_o = oview.tables(n_all)
-    cfg = oview.getCurrentConfigurationId()
-    sc = S.build_churn_scenario(obs_o, member_o, cfg, 14, 9, H, L)
-    rx = sc.receivers[:: max(1, len(sc.receivers) // 48)][:48]
-    sc = S.build_churn_scenario(obs_o, member_o, cfg, 14, 9, H, L, receivers=rx)
-
-    def ep(i):
-        return P.Endpoint(hostname=pop.hostnames[i], port=int(pop.ports[i]))
-
-    # one serialized request per batch of the round
-    bs = sc.batches
-    wire_msgs = []
-    for b in range(bs.n_batches):
-        msg = P.BatchedAlertMessage(sender=ep(int(bs.sender[b])))
-        for rec in bs.recs[bs.off[b]:bs.off[b + 1]]:
-            a = P.AlertMessage(edgeSrc=ep(int(rec["src"])), edgeDst=ep(int(rec["dst"])), edgeStatus=int(rec["status"]),
-                               configurationId=int(rec["cfg_id"]))
-            a.ringNumber.extend([k for k in range(K) if (int(rec["ring_mask"]) >> k) & 1])
-            if int(rec["status"]) == S.UP:
-                a.nodeId.high, a.nodeId.low = int(pop.id_hi[int(rec["dst"])]), int(pop.id_lo[int(rec["dst"])])
-            msg.messages.append(a)
-        wire_msgs.append(P.RapidRequest(batchedAlertMessage=msg).SerializeToString())
-    # the engine knows the members only
-    eng = E.Engine(n_max=n_all, K=K, H=H, L=L)
-    view = E.MembershipView(eng).build(pop.hostnames[:n_mem], pop.ports[:n_mem], pop.id_hi[:n_mem], pop.id_lo[:n_mem])
-    assert view.getCurrentConfigurationId() == cfg
-    emap = W.EndpointMap(pop.hostnames[:n_mem], pop.ports[:n_mem])
-    # pass 1: decode every distinct message; register what is unknown, in the order it is met
-    new_hosts, new_ports, new_hi, new_lo = [], [], [], []
-    for req in wire_msgs:
-        kind, payload = W.decode_request(req)
-        assert kind == W.MSG_BATCHED_ALERT
-        recs_, ids_, status, unknown, sender = emap.decode_batched_alerts_ex(payload, K)
-        for i, st_ in enumerate(status):
-            if st_ == E.N.ENODE_MISSING:
-                before = emap.size()
-                idx = emap.add_wire(unknown[i])
-                if idx == before:  # first time: the engine gets the same index
-                    h_, p_ = emap.get(idx)
-                    new_hosts.append(h_); new_ports.append(p_); new_hi.append(ids_[i][0]); new_lo.append(ids_[i][1])
-            else:
-                assert st_ == E.N.OK
-    assert len(new_hosts) == len(sc.joiners)
-    assert view.registerEndpoints(new_hosts, new_ports, new_hi, new_lo) == n_mem
-    assert view.getCurrentConfigurationId() == cfg  # the membership did not change
-    to_pop = {i: i for i in range(n_mem)}
-    for j, h_ in enumerate(new_hosts):
-        to_pop[n_mem + j] = pop.hostnames.index(h_)
-    # pass 2: every receiver's deliveries, message by message, in its own order (S.deliver's permutation)
-    streams, off = [], [0]
-    for r in sc.receivers:
-        rng = np.random.Generator(np.random.PCG64([2, int(r)]))
-        parts = []
-        for b in rng.permutation(bs.n_batches):
-            kind, payload = W.decode_request(wire_msgs[int(b)])
-            recs_, ids_, status, unknown, sender = emap.decode_batched_alerts_ex(payload, K)
-            assert all(s_ == E.N.OK for s_ in status)
-            parts.append(recs_)
-        streams.append(np.concatenate(parts))
-        off.append(off[-1] + len(streams[-1]))
-    records = np.concatenate(streams)
-    # the same deliveries through the Python protobuf runtime, in the oracle's numbering
-    idx_of = {(pop.hostnames[i], int(pop.ports[i])): i for i in range(n_all)}
-    o_streams = []
-    for r in sc.receivers:
-        rng = np.random.Generator(np.random.PCG64([2, int(r)]))
-        parts = []
-        for b in rng.permutation(bs.n_batches):
-            m_ = P.RapidRequest.FromString(wire_msgs[int(b)]).batchedAlertMessage
-            recs_ = np.zeros(len(m_.messages), dtype=S.ALERT_DTYPE)
-            for i, a in enumerate(m_.messages):
-                recs_[i] = (a.configurationId, idx_of[(a.edgeSrc.hostname, a.edgeSrc.port)], idx_of[(a.edgeDst.hostname, a.edgeDst.port)],
-                            sum(1 << k for k in a.ringNumber), a.edgeStatus, 0)
-            recs_["flags"][-1] = S.FLAG_LAST_IN_BATCH
-            parts.append(recs_)
-        o_streams.append(np.concatenate(parts))
-    o_records = np.concatenate(o_streams)
-    assert np.array_equal(o_records, sc.records)  # (and both equal what the generator delivers directly)
-    oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, o_records, np.array(off), nthreads=8)
-    sim = E.ClusterSimulation(eng)
-    sim.load_streams(records, np.array(off))
+    sc = S.build_churn_scenario(obs, member, cfg, 20, 0, H, L)
+    R = len(sc.receivers)
+    rr0, cut0 = whole(sc)
+    assert rr0.decided == 1 and rr0.votes_winner == R
+    segs = segments_of(sc, [0, R // 3, R // 3 + 700, R])
+    status, rr = sim.merge_vote_segments(segs)
+    assert status == 1
+    assert (rr.decided, rr.cut_size, rr.votes_total, rr.votes_winner, rr.quorum) == (1, rr0.cut_size, R, R, rr0.quorum)
+    assert sim.decided_cut() == cut0
+    # a rank whose receivers got nothing delivered (nobody proposes there) adds no votes: 2 of 3 shards < quorum here
+    empty = np.zeros(0, dtype=S.ALERT_DTYPE)
+    sim.load_streams(empty, np.zeros(R // 3 + 1, dtype=np.int64))
+    sim.set_alert_set(sc.batches.recs)
     sim.tally()
-    emit, nprop, pcount, fp = sim.results()
-    assert np.array_equal(emit, oe) and np.array_equal(nprop, on) and np.array_equal(pcount, np.diff(oo))
-    for r in range(len(oe)):
-        assert sorted(to_pop[x] for x in sim.proposal(r)) == op[oo[r]:oo[r + 1]].tolist() == sc.faulty.tolist()
-    # the 48 receivers agree but are no quorum of 700: the cut they all announce is applied, joiners enter with their NodeIds
-    new_cfg = sim.apply_cut(sim.proposal(0))
-    _oracle_decide(oview, K, H, L, pop, sc, sc.faulty.tolist())
-    assert new_cfg == oview.getCurrentConfigurationId() and view.getMembershipSize() == n_mem - 14 + 9
-    for node in (n_mem, n_mem + 3):
-        assert sorted(to_pop[x] for x in view.getObserversOf(node)) == sorted(oview.getObserversOf(to_pop[node]))
+    silent = sim.vote_segment()
+    status, rr = sim.merge_vote_segments([segs[0], silent, segs[2]])
+    assert status == 1 and rr.votes_winner == R - 700 == rr.votes_total and rr.cut_size == rr0.cut_size
+    assert rr.decided == (1 if R - 700 >= rr0.quorum else 0)
+    status, rr = sim.merge_vote_segments([silent, silent])
+    assert status == 1 and rr.votes_winner == 0 and rr.decided == 0
+    # two proposals in one round: 600 receivers that saw this round's crashes and 500 that saw a different fault set (same
+    # size, different nodes).  Unanimous shards that disagree with each other, and a shard that disagrees within itself.
+    sc3 = S.build_churn_scenario(obs, member, cfg, 20, 0, H, L, seed_fault=5)
+    assert len(sc3.faulty) == len(sc.faulty) and not np.array_equal(sc3.faulty, sc.faulty)
+    ra, oa = shard(sc.records, sc.rec_off, 0, 600)
+    rb, ob = shard(sc3.records, sc3.rec_off, 0, 500)
 
+    class Mixed:
+        records = np.concatenate([ra, rb])
+        rec_off = np.concatenate([oa, ob[1:] + oa[-1]])
 
-# ------------------------------------------------------------------ f4: the round on the reference's own time line
-def test_round_driven_by_the_failure_detector_and_batching_timers(E):
-    """SURVEY 8f rank 4 wired to the engine: crashes at given instants -> PingPongFailureDetector notifications
-    (R/monitoring/impl/PingPongFailureDetector.java:41-85) -> AlertBatcher flushes (R/MembershipService.java:613-637) ->
-    arrival order at every receiver -> tally ON THE GPU -> proposal and fast-round decision times.  Results against the
-    faithful oracle on the same timed streams, the producer side against its literal event simulation, and the protocol's
-    time-to-stable-cut (~10 s of failure detection + batching + network) next to the engine's compute time."""
-    from rapid_amd import timeline as T
-    n, K, H, L = 2000, 10, 9, 4
-    pop = S.Population.make(n)
-    eng, view = make_engine(E, pop, K, H, L)
-    reg, oview = oracle_view(pop, K)
-    obs, subj, member = view.tables()
-    cfg = view.getCurrentConfigurationId()
-    rng = np.random.default_rng(8)
-    faulty = np.sort(rng.choice(n, 20, replace=False))
-    crash = np.full(n, T.NEVER, dtype=np.int64)
-    crash[faulty] = rng.integers(2_000, 2_800, len(faulty))
-    start = rng.integers(0, 1000, n)
-    model, lat = T.ProducerModel(), T.LatencyModel(base_ms=1, jitter_ms=6, seed=9)
-    sim = E.ClusterSimulation(eng)
-    out = T.engine_round_on_the_time_line(sim, subj, crash, start, cfg, n, model, lat)
-    rx = out["receivers"]
-    # the producer side equals the literal event simulation (one PingPongFailureDetector object per detector, one AlertBatcher per node)
-    from tests.test_timeline import as_tuples, oracle_batches
-    t_end = int(crash[faulty].max() + 14 * model.fd_interval_ms + 10 * model.batching_window_ms)
-    assert as_tuples(out["batches"], out["send_ms"]) == oracle_batches(subj, crash, start, t_end, model)
-    # the tally on the device == the faithful oracle on the same timed streams
-    m = np.arange(0, len(rx), max(1, len(rx) // 120))
-    sub_off = np.zeros(len(m) + 1, dtype=np.int64)
-    parts = []
-    for i, r in enumerate(m):
-        parts.append(out["records"][out["rec_off"][r]:out["rec_off"][r + 1]])
-        sub_off[i + 1] = sub_off[i] + len(parts[-1])
-    oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, np.concatenate(parts), sub_off, nthreads=8)
-    assert np.array_equal(out["emit_batch"][m], oe) and np.array_equal(out["num_proposals"][m], on)
-    assert np.array_equal(out["fingerprint"][m], proposal_fingerprints(oo, op, oe >= 0))
-    assert np.all(out["emit_batch"] >= 0) and sorted(sim.proposal(0)) == faulty.tolist()
-    # on the time line: ten failed probes, one per second, then the batching window and the network
-    t_prop, t_dec = out["proposal_ms"], out["decision_ms"]
-    assert t_prop.min() > crash[faulty].min() + 10_000 and t_prop.max() < crash[faulty].max() + 11_000 + 2 * model.batching_window_ms + 10
-    quorum = n - (n - 1) // 4
-    assert np.all(t_dec >= np.sort(t_prop)[quorum - 1] + 1) and np.all(t_dec <= t_prop.max() + 7)
-    assert 10_000 < out["time_to_stable_cut_ms"] < 12_500
-    rr = sim.count_votes()
-    assert rr.decided == 1 and sorted(sim.decided_cut()) == faulty.tolist()
+        class batches:
+            recs = np.concatenate([sc.batches.recs, sc3.batches.recs])
+
+    both = segments_of(Mixed, [0, 600, 1100])
+    status, _ = sim.merge_vote_segments(both)
+    assert status == 2
+    status, rr = sim.merge_vote_segments([both[1]])
+    assert status == 1 and rr.votes_winner == 500 and rr.decided == 0 and rr.cut_size == 20
+    status, _ = sim.merge_vote_segments(segments_of(Mixed, [0, 1100]))
+    assert status == 2
+    status, _ = sim.merge_vote_segments([segs[0], segments_of(Mixed, [0, 1100])[0]])
+    assert status == 2
+    rr, _ = whole(Mixed)  # (what the general count says about that round: the larger group wins, without a quorum)
+    assert (rr.decided, rr.votes_total, rr.votes_winner) == (0, 1100, 600)
+    eng.close()
