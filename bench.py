@@ -5,15 +5,16 @@ One *step* = one ROUND of the hot path over the resident synthetic alert streams
 population, everything a round costs once the streams are in HBM: the per-round index (which subjects can reach the L
 watermark, slot dictionary, hot adjacency, validation of the round's distinct alerts against the view), the alert-tally
 kernel over every receiver (MembershipService.handleMessage(BatchedAlertMessage) semantics), then the fast-round vote
-count over their proposals (histogram -> all-reduce over ranks -> quorum test -> element-wise verification) with the
-decision read back to the host.  The view is NOT changed inside the timed loop so that every step does identical work;
+count over their proposals (every rank counts and verifies its own voters; one all-gather + merge across ranks; quorum
+test) with the decision read back to the host.  The view is NOT changed inside the timed loop so that every step does identical work;
 one extra untimed-in-`value` round that also applies the cut gives `time_to_stable_cut_ms`.  `ms_per_step` is the mean
 the contract asks for; `ms_per_step_min` / `_median` over the same steps and the tally-only figure are reported next to it.
 
 Launch: `python bench.py --gpus 1` or, for N > 1,
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
 The simulated receivers are sharded across ranks (strong scaling of ONE cluster); the only data-path collective is
-the per-round RCCL all-reduce of the vote histogram inside librapid_mi355x.so.
+the per-round RCCL all-gather of the ranks' local vote counts inside librapid_mi355x.so (the histogram all-reduces of
+the general count only run for a round whose voters disagree).
 """
 import argparse
 import json
@@ -185,7 +186,7 @@ def main():
                                "under >=L faulty observers), %d receivers, per-receiver seeded delivery order"
                                % (cfgname, n, K, H, L, len(sc.faulty), len(sc.receivers)) if cfgname == "C3b" else
                    "%s: N=%d K=%d H=%d L=%d faults=%d receivers=%d" % (cfgname, n, K, H, L, len(sc.faulty), len(sc.receivers)),
-                   "parallelism": "receivers sharded over %d GPU(s); vote histogram all-reduce over RCCL" % world,
+                   "parallelism": "receivers sharded over %d GPU(s); per round ONE all-gather (RCCL) of the ranks' local vote counts, merged on every rank" % world,
                    "alert_set": "the round's distinct alerts are declared and the deliveries vouched for as copies of them "
                                 "(rapid_sim_trust_alert_copies): the tally does not re-read the configuration id per delivery; "
                                 "roofline.kernel_ms_filter_per_delivery is the same kernel without that promise",

@@ -1,5 +1,4 @@
-// The tally kernel's record stream: bounds-checked buffer loads straight into registers -- and why the kernel's STORES
-// are issued from inline assembly.
+// The tally kernel's record stream: bounds-checked buffer loads straight into registers.
 //
 // A receiver's delivered stream is a raw buffer (base = its first record, size = 20 B x its record count); lane l of
 // "quarter" q of a window reads the dwords it needs of record 64 q + l with ONE wave instruction per quarter
@@ -10,15 +9,18 @@
 //
 // The loads are ordinary compiler-visible loads, so the register allocation around them is the compiler's business and
 // correct by construction; the next window is requested before the current one is tallied, and the compiler's
-// wait-count pass inserts s_waitcnt vmcnt(N) with N = the loads issued since.  That pass only counts precisely while
-// every vector-memory operation it knows to be outstanding is a load: on gfx9-family targets loads and stores share the
-// vmcnt counter, and as soon as a store may be outstanding anywhere around the loop (the per-receiver results) it stops
-// trusting the order of completion and waits with vmcnt(0) -- i.e. for the window it has just requested -- before it
-// touches the previous one (measured: tallying and streaming did not overlap at all, and idle time between receivers
-// was fully additive).  So the results are stored from inline assembly (stream_store*): fire-and-forget instructions the
-// pass does not see.  They only make its waits longer than necessary (the hardware counter includes them), never
-// shorter: loads return in issue order, so "at most N operations outstanding" still means every load older than the N
-// youngest loads has landed.
+// wait-count pass inserts s_waitcnt vmcnt(N) with N = the loads issued since (loads return in issue order).  That
+// count is only precise while no OTHER vector-memory result is pending in a long-lived register around the loop: a
+// vector load whose destination stays live across window iterations (round 2 first had the next receiver's stream
+// bounds prefetched that way) makes the pass wait with vmcnt(0) -- i.e. for the window it has just requested --
+// before every write of a register that may still be that load's target, and tallying and streaming then do not
+// overlap at all (measured: idle time between receivers was fully additive).  Hence stream_scalar_load below: the
+// bounds come through the scalar cache (lgkmcnt), and what remains in the loop is loads in issue order.
+//
+// The per-receiver results are stored from inline assembly (stream_store*): fire-and-forget instructions the pass does
+// not see.  This was the first suspect for the vmcnt(0) waits and turned out not to be the cause; it is kept because it
+// is harmless -- the stores can only make the pass's waits longer than necessary (the hardware counter includes them),
+// never shorter: "at most N operations outstanding" still means every load older than the N youngest has landed.
 //
 // tests/emu/ shadows this header with plain bounds-checked reads and plain stores.
 #pragma once

@@ -7,8 +7,9 @@
 //                 + MultiNodeCutDetector.invalidateFailingEdges         R/MultiNodeCutDetector.java:137-164
 //
 // Mapping onto the machine:
-//   * one wavefront per simulated receiver, persistent; receivers are dealt round-robin (wave-major); a workgroup is
-//     W such wavefronts (one workgroup per CU, W chosen by the host) that share read-only per-round tables in LDS;
+//   * one wavefront per simulated receiver, persistent; a workgroup is W such wavefronts (one workgroup per CU, W
+//     chosen by the host) that share read-only per-round tables in LDS; receivers are dealt to WORKGROUPS statically
+//     (b, b + G, ...) and claimed by the workgroup's waves from a counter in LDS;
 //   * the receiver's whole detector state is one word per SLOT in LDS -- a slot is a "hot" subject: one the round's
 //     alert set names on >= L distinct rings, the only kind that can ever reach the L watermark at any receiver
 //     (index_kernels.h builds the node->slot dictionary once per loaded stream set; reports about other subjects can

@@ -1,5 +1,5 @@
 """One process, one scenario, every prepared build of the library: tally kernel time of each variant, interleaved over
-several rounds (box noise is ~5 %), plus the kernel's event counters.  Used by scripts/ab_lean_v2.sh on the GPU box.
+several rounds (box noise is ~5 %), plus the kernel's event counters.
     python scripts/ab_variants.py [config] [rounds] [reps] -- variants are the rapid_amd/librapid_mi355x_<name>.so present."""
 import glob
 import os
