@@ -71,18 +71,20 @@ def build(force=False, verbose=False):
     tally kernel that starts spilling is a silent 20 % regression, not a build failure."""
     if not force and not needs_build():
         return LIB_PATH
+    tmp = "%s.tmp%d" % (LIB_PATH, os.getpid())  # concurrent builders (pytest-xdist workers) must not share the output file
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + SRC_DIR,
            "-Rpass-analysis=kernel-resource-usage",
-           os.path.join(SRC_DIR, "engine.hip"), os.path.join(SRC_DIR, "host_abi.cpp"), "-o", LIB_PATH + ".tmp", "-lrccl"]
+           os.path.join(SRC_DIR, "engine.hip"), os.path.join(SRC_DIR, "host_abi.cpp"), "-o", tmp, "-lrccl"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr)
         raise subprocess.CalledProcessError(r.returncode, cmd)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    with open(RESOURCES_PATH, "w") as f:
+    with open(tmp + ".json", "w") as f:
         json.dump(parse_resource_remarks(r.stderr), f, indent=1, sort_keys=True)
+    os.replace(tmp + ".json", RESOURCES_PATH)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
