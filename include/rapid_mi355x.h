@@ -371,7 +371,8 @@ int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, in
  * path only (no cold / fast windows), 64 = never trust the pre-validation of the alert set, 128 = no direct node -> slot
  * tables in LDS even when they fit (the compressed form of large populations is used instead), 256 = dictionary in
  * memory (the mode of populations too large even for that), 512 = sharded vote count always through the histogram
- * all-reduces (never the all-gather + merge of the ranks' local counts), 32 = measurement only:
+ * all-reduces (never the all-gather + merge of the ranks' local counts), 1024 = every receiver dealt to the workgroups
+ * statically (no common pool for the last eighth), 32 = measurement only:
  * stream the records through the registers without tallying them (results are meaningless) */
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);
 /* testing aids for the sharded vote count (one GPU standing in for n ranks): the answer block this engine's voters

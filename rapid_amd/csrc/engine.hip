@@ -487,6 +487,21 @@ int launch_tally(rapid_engine* h) {
     p.stats = h->d_stats.p;  // [grid_blocks][8]
     p.waves_per_block = h->waves_per_block;
     p.flags = h->force_exact & (1 | 4 | 8 | 16 | 32);
+    // The last eighth of the receivers is not dealt to the workgroups but left in a common pool (tally_kernel.h: n_static),
+    // once a population is at least two rounds of the launch; testing knob bit 10: everything dealt statically.
+    p.n_static = h->n_receivers;
+    p.pool = nullptr;
+    {
+        const long long slots = (long long)h->grid_blocks * h->waves_per_block;
+        const char* e = getenv("RAPID_POOL_EIGHTHS");  // measurement knob: size of the pool in eighths of the population
+        const int eighths = e ? std::max(0, std::min(7, atoi(e))) : 1;
+        if ((h->force_exact & 1024) == 0 && eighths > 0 && (long long)h->n_receivers >= 2 * slots) {
+            long long ns = ((long long)h->n_receivers * (8 - eighths) / 8 / h->grid_blocks) * h->grid_blocks;
+            ns = std::max(ns, slots);
+            p.n_static = (int)ns;
+            p.pool = reinterpret_cast<unsigned int*>(h->d_stats.p + (size_t)8 * (size_t)h->grid_blocks);
+        }
+    }
     const dim3 grid((unsigned)h->grid_blocks), block((unsigned)h->waves_per_block * 64u);
     // pre-validated instantiation: the scanned alerts all pass the filter AND (when they are a declared set rather than the
     // delivered records themselves) the caller vouches that the deliveries are copies of them; bit6 of the testing knob: never
@@ -528,7 +543,7 @@ int prepare_tally(rapid_engine* h) {
     HIPCHK(h, h->d_pcount.ensure(R));
     HIPCHK(h, h->d_fp.ensure(R));
     HIPCHK(h, h->d_props.ensure(R * (size_t)h->max_cut));
-    HIPCHK(h, h->d_stats.ensure((size_t)8 * (size_t)std::max(h->grid_blocks, 1)));
+    HIPCHK(h, h->d_stats.ensure((size_t)8 * (size_t)std::max(h->grid_blocks, 1) + 1));  // + the pool words of launch_tally
     HIPCHK(h, h->d_next.ensure(4));
     return RAPID_OK;
 }
@@ -1027,7 +1042,7 @@ int rapid_sim_tally(rapid_engine* h) {
     int rc = use_device(h);
     if (rc) return rc;
     if ((rc = prepare_tally(h))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * (size_t)std::max(h->grid_blocks, 1), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * (size_t)std::max(h->grid_blocks, 1) + 8, h->stream));
     if (h->n_receivers > 0) {
         if ((rc = launch_tally(h))) return rc;
         HIPCHK(h, hipGetLastError());
@@ -1414,7 +1429,7 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg) {
     if (!h->ev0) HIPCHK(h, hipEventCreate(&h->ev0));
     if (!h->ev1) HIPCHK(h, hipEventCreate(&h->ev1));
     const hipEvent_t e0 = h->ev0, e1 = h->ev1;
-    HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * (size_t)std::max(h->grid_blocks, 1), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * (size_t)std::max(h->grid_blocks, 1) + 8, h->stream));
     launch_tally(h);  // untimed warm-up
     HIPCHK(h, hipEventRecord(e0, h->stream));
     for (int i = 0; i < reps; ++i) launch_tally(h);

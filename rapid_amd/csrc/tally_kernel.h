@@ -117,6 +117,13 @@ struct TallyParams {
     unsigned long long* stats;        // [workgroups][8], accumulated over launches
     unsigned int* error_flags;        // sticky: bit0 = a delivered report is not covered by the index (see RoundIndex::decl)
     int waves_per_block;
+    // Receivers [0, n_static) are dealt to the workgroups statically (n_static is a multiple of the grid size); the rest
+    // is a common pool claimed through pool[0] by waves whose workgroup has worked off its own deal -- workgroups do not
+    // run equally fast (their finishing times spread by ~ +-10 %), and the pool lets the fast ones take the difference.
+    // pool[1] counts finished workgroups; the last one zeroes both words for the next launch.  n_static = n_receivers and
+    // pool = nullptr: everything dealt statically.
+    int n_static;
+    unsigned int* pool;
     int flags;                        // bit0: exact path only, bit3: careful path only (both for tests); bit5: stream only
 };
 
@@ -593,6 +600,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // crosses that channel waits with them.
     const int n_blocks = (int)gridDim.x;
     int r = uniform(wave * n_blocks + (int)blockIdx.x);  // the first deal: claim number `wave` of this workgroup
+    if (r >= p.n_static) r = p.n_receivers;              // (the host sizes the static part so that this never takes pool work away)
     Win W;  // the window in flight
     Stream rsrc;
     rsrc.base = p.records;
@@ -625,6 +633,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             unsigned int v = 0u;
             if (lane == 0) v = atomicAdd(block_claims, 1u);
             r_next = (int)uniform(v) * n_blocks + (int)blockIdx.x;
+            if (r_next >= p.n_static) r_next = p.n_receivers;  // the workgroup's own deal is worked off (the pool: after the stream)
             if (r_next < p.n_receivers) {  // scalar loads: no vector register waits for them inside the window loop
                 next0 = stream_scalar_load(p.rec_off + r_next);
                 next1 = stream_scalar_load(p.rec_off + r_next + 1);
@@ -1113,6 +1122,20 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
         }
         if (!claimed) claim();
+        if (r_next >= p.n_receivers && p.pool != nullptr) {
+            // Own deal worked off: one receiver from the common pool.  Claimed here and not windows ahead like the others --
+            // the answer of a global atomic lives in a vector register, and one that stays live across window iterations
+            // costs the precise wait counts of the stream (stream_load.h); here nothing is in flight.  The round trip
+            // (~2 us) is paid by the last eighth of the receivers only.
+            unsigned int g = 0u;
+            if (lane == 0) g = atomicAdd(p.pool, 1u);
+            const unsigned int gi = uniform(g);
+            if (gi < (unsigned int)(p.n_receivers - p.n_static)) {
+                r_next = p.n_static + (int)gi;
+                next0 = stream_scalar_load(p.rec_off + r_next);
+                next1 = stream_scalar_load(p.rec_off + r_next + 1);
+            }
+        }
         // start the next receiver's stream now; its first window lands while this receiver's results are written
         int nrec_next = 0;
         if (r_next < p.n_receivers) {
@@ -1202,6 +1225,12 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #endif
     if ((p.flags & 32) != 0 && sink == 0x12345678u) block_stats[0] = 1ull;
     __syncthreads();
+    if (threadIdx.x == 0 && p.pool != nullptr) {
+        if (atomicAdd(&p.pool[1], 1u) == gridDim.x - 1u) {  // every other workgroup has made its last claim
+            p.pool[0] = 0u;
+            p.pool[1] = 0u;
+        }
+    }
     // p.stats = [gridDim.x][8], accumulated over launches; one plain read-modify-write per workgroup and counter
 #ifdef RAPID_PHASE_TIMERS
     if (threadIdx.x < 8u && p.stats != nullptr) {

@@ -177,6 +177,16 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     p.stats = stats;
     p.waves_per_block = waves;
     p.flags = flags;
+    // emulator-only selector (bit 9): everything beyond the first deal comes from the common pool (workgroups run one
+    // after the other here, so the first one takes all of it -- the claims, the hand-over and the reset are what is tested)
+    static unsigned int pool[2];
+    pool[0] = pool[1] = 0u;
+    p.n_static = n_receivers;
+    p.pool = nullptr;
+    if ((flags & 512) != 0 && n_receivers > grid * waves) {
+        p.n_static = grid * waves;
+        p.pool = pool;
+    }
     for (int b = 0; b < grid; ++b) {
         std::memset(smem, 0xCD, sizeof(smem));  // poison: the kernel must initialise what it reads
         const bool trusted = (flags & 256) != 0;  // emulator-only selector of the kTrusted instantiation
@@ -190,6 +200,7 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
             default: run(rapid::tally_population_kernel<rapid::kDictCompressed, true>); break;
         }
     }
+    if (pool[0] != 0u || pool[1] != 0u) return -7;  // the last workgroup must leave the pool words zeroed for the next launch
     return error_flags[0] != 0u ? -1 : 0;
 }
 

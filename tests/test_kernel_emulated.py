@@ -130,6 +130,21 @@ def test_other_dictionary_placements(mode):
     _check(np.concatenate(recs), np.array(off), n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode)
 
 
+def test_receivers_claimed_from_the_common_pool():
+    """Beyond the first deal the receivers come from the pool every workgroup may claim from (on the device: the last
+    eighth of a large population, so that fast workgroups take work off slow ones): same results, and the last workgroup
+    leaves the pool words zeroed (checked by the emulator's entry point)."""
+    n, K, H, L = 300, 10, 9, 4
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K)
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_scenario("C3b", subj, cfg, n=n, f=15, H=H, L=L, receivers=np.arange(0, n, 9))
+    assert len(sc.receivers) > 4 * 6  # several claims per wave at the emulator's 2 workgroups x 3 waves
+    _check(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, pool=True)
+    _check(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, pool=True, waves=2, grid=3, tables_in_lds=2)
+
+
 def test_unaligned_starts_and_empty_receivers():
     n, K, H, L = 24, 5, 4, 2
     pop = S.Population.make(n)
