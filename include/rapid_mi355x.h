@@ -139,11 +139,16 @@ int rapid_cd_clear(rapid_cd* cd);                                               
 /* ---- whole population: MembershipService.handleMessage(BatchedAlertMessage) at every receiver ---------
  * (R/MembershipService.java:300-354 with the filter of :644-675).  records = the receivers' delivered
  * streams back to back, rec_off[r]..rec_off[r+1] (in records) = receiver r; every receiver starts the round
- * with an empty detector and announcedProposal == false in the engine's current configuration. */
+ * with an empty detector and announcedProposal == false in the engine's current configuration.
+ * The records are borrowed for the call: the engine keeps them SPLIT in its own memory -- 8 bytes per record that the
+ * tally always reads {dst, ring_mask, status, flags} and, in a second array, the 8 bytes of its configuration id that only
+ * the per-delivery filter reads (src is never read, as in R/MultiNodeCutDetector.java:101) -- 16 B per delivered record
+ * resident, of which a tally launch pulls 8 or 16 from HBM. */
 int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, const int64_t* rec_off,
                            int32_t n_receivers);
-/* same, records already on this device (borrowed until the next load; `records_bytes` readable bytes, which
- * must extend at least 16 bytes past the last record); d_rec_off is a device pointer to n_receivers+1 int64 */
+/* same, records already on this device (`records_bytes` readable bytes covering them; borrowed for the call, split into
+ * the engine's arrays like the host form); d_rec_off is a device pointer to n_receivers+1 int64 and IS borrowed until
+ * the next load */
 int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64_t records_bytes,
                                   const int64_t* d_rec_off, int32_t n_receivers);
 /* Optional, after a load: declares the round's DISTINCT alerts (every delivered record is a byte-identical copy of

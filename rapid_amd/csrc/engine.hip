@@ -98,9 +98,10 @@ struct rapid_engine {
     std::vector<long long> h_keys;
 
     // ---- simulated population ----
-    DevBuf<unsigned char> d_records_own;
-    const unsigned char* d_records = nullptr;
-    unsigned long long records_bytes = 0;
+    // delivered streams, resident split: d_core[i] = {dst, mask | status | flags}, d_cfg[i] = configuration id of record i;
+    // d_stage = bounded staging area for the 20-byte records on their way in
+    DevBuf<unsigned char> d_core, d_cfg, d_stage;
+    unsigned long long records_bytes = 0;  // readable bytes at d_core.p (probes)
     DevBuf<long long> d_rec_off_own;
     const long long* d_rec_off = nullptr;
     int n_receivers = 0;
@@ -371,12 +372,14 @@ int build_round_index(rapid_engine* h) {
     // gmask | info live in one allocation: one memset, then the touch pass (whole GPU), then everything else in one
     // workgroup, which leaves info[] in host-mapped memory: one synchronisation, no copy
     HIPCHK(h, hipMemsetAsync(h->d_idxwork.p, 0, sizeof(int) * ((size_t)N + 8), st));
-    const unsigned char* scan = h->n_alert_set >= 0 ? h->d_alert_set.p : h->d_records;
     const long long n_scan = h->n_alert_set >= 0 ? h->n_alert_set : h->n_records_total;
-    if (n_scan > 0)
-        hipLaunchKernelGGL(rapid::index_touch_kernel, dim3((unsigned)std::min<long long>(h->num_cus * 8, (n_scan + 255) / 256)),
-                           dim3(256), 0, st, scan, n_scan, N, (1u << K) - 1u, (long long)h->config_id, h->d_member.p, d_gmask,
-                           reinterpret_cast<unsigned int*>(d_info + 4));
+    const dim3 touch_grid((unsigned)std::min<long long>(h->num_cus * 8, (n_scan + 255) / 256));
+    if (n_scan > 0 && h->n_alert_set >= 0)
+        hipLaunchKernelGGL(rapid::index_touch_kernel<false>, touch_grid, dim3(256), 0, st, h->d_alert_set.p, nullptr, n_scan, N,
+                           (1u << K) - 1u, (long long)h->config_id, h->d_member.p, d_gmask, reinterpret_cast<unsigned int*>(d_info + 4));
+    else if (n_scan > 0)
+        hipLaunchKernelGGL(rapid::index_touch_kernel<true>, touch_grid, dim3(256), 0, st, h->d_core.p, h->d_cfg.p, n_scan, N,
+                           (1u << K) - 1u, (long long)h->config_id, h->d_member.p, d_gmask, reinterpret_cast<unsigned int*>(d_info + 4));
     const int adj_cap = 65536;
     HIPCHK(h, h->d_adj.ensure((size_t)adj_cap + 1));
     hipLaunchKernelGGL(rapid::index_build_block_kernel, dim3(1), dim3(1024), 0, st, d_gmask, h->d_member.p, h->d_obs.p, N, K, L,
@@ -450,15 +453,17 @@ int build_round_index(rapid_engine* h) {
     h->waves_per_block = best_w;
     h->lds_bytes = sh + best_w * per_wave + rapid::kBlockStatsBytes;
     const long long want = ((long long)h->n_receivers + best_w - 1) / best_w;
-    h->grid_blocks = (int)std::max<long long>(1, std::min<long long>(want, (long long)h->num_cus));
+    int blocks_per_cu = 1;
+    if (const char* e = getenv("RAPID_TALLY_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::min(4, atoi(e)));  // profiling knob
+    h->grid_blocks = (int)std::max<long long>(1, std::min<long long>(want, (long long)h->num_cus * blocks_per_cu));
     h->index_valid = true;
     return RAPID_OK;
 }
 
 int launch_tally(rapid_engine* h) {
     rapid::TallyParams p;
-    p.records = h->d_records;
-    p.records_bytes = h->records_bytes;
+    p.core = h->d_core.p;
+    p.cfg = h->d_cfg.p;
     p.rec_off = h->d_rec_off;
     p.n_receivers = h->n_receivers;
     p.n_nodes = h->n_nodes;
@@ -607,7 +612,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_sort_keys.release(); h->d_sort_vals.release(); h->d_ring_skeys.release(); h->d_ring.release();
     h->d_pos.release(); h->d_obs.release(); h->d_subj.release();
     h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
-    h->d_records_own.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
+    h->d_core.release(); h->d_cfg.release(); h->d_stage.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
     h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release(); h->d_trank.release(); h->d_tbits.release(); h->d_tent.release();
     h->d_adj_off.release(); h->d_node_of_slot.release();
@@ -952,6 +957,44 @@ int rapid_cd_clear(rapid_cd* cd) {
 }
 
 // ------------------------------------------------------------------------------------------ population
+// 20-byte records (host or device memory) -> the resident split arrays.  Host records travel through a bounded staging
+// buffer, so a population's footprint is 16 B per delivered record + 256 MiB, not 36 B.
+static int load_split(rapid_engine* h, const unsigned char* src, bool src_on_device, long long n_rec) {
+    const size_t core_bytes = (((size_t)n_rec * 8 + 15) / 16) * 16 + 64;
+    HIPCHK(h, h->d_core.ensure(core_bytes));
+    HIPCHK(h, h->d_cfg.ensure(core_bytes));
+    const size_t tail = ((size_t)n_rec * 8 / 16) * 16;  // zeros behind the last record (the split pass below rewrites what it owns)
+    HIPCHK(h, hipMemsetAsync(h->d_core.p + tail, 0, core_bytes - tail, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_cfg.p + tail, 0, core_bytes - tail, h->stream));
+    const long long chunk = 12ll << 20;  // records per staging round (240 MiB)
+    if (!src_on_device && n_rec > 0) HIPCHK(h, h->d_stage.ensure((size_t)std::min(chunk, n_rec) * 20 + 16));
+    for (long long at = 0; at < n_rec; at += chunk) {
+        const long long n = std::min(chunk, n_rec - at);
+        const unsigned char* from = src + (size_t)at * 20;
+        if (!src_on_device) {
+            HIPCHK(h, hipMemcpyAsync(h->d_stage.p, from, (size_t)n * 20, hipMemcpyHostToDevice, h->stream));
+            from = h->d_stage.p;
+        }
+        hipLaunchKernelGGL(rapid::split_records_kernel, dim3((unsigned)std::min<long long>((long long)h->num_cus * 16, (n + 255) / 256)),
+                           dim3(256), 0, h->stream, from, n, reinterpret_cast<uint2*>(h->d_core.p) + at, reinterpret_cast<uint2*>(h->d_cfg.p) + at);
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    h->records_bytes = core_bytes - 48;
+    return RAPID_OK;
+}
+
+static void streams_replaced(rapid_engine* h, int n_receivers, long long n_rec) {
+    h->n_receivers = n_receivers;
+    h->n_records_total = n_rec;
+    h->n_alert_set = -1;
+    h->trust_copies = false;
+    h->index_valid = false;
+    h->streams_loaded = true;
+    h->tallied = false;
+    h->have_decision = false;
+}
+
 int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, const int64_t* rec_off,
                            int32_t n_receivers) {
     if (!h || !rec_off || n_receivers < 0) return RAPID_EINVAL;
@@ -961,26 +1004,12 @@ int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, c
     if (n_rec < 0 || (n_rec > 0 && !records)) return fail(h, RAPID_EINVAL, "bad record stream");
     for (int r = 0; r < n_receivers; ++r)
         if (rec_off[r + 1] < rec_off[r]) return fail(h, RAPID_EINVAL, "rec_off not monotone at %d", r);
-    const size_t bytes = (size_t)n_rec * 20;
-    const size_t padded = ((bytes + 15) / 16) * 16 + 64;
-    HIPCHK(h, h->d_records_own.ensure(padded));
     HIPCHK(h, h->d_rec_off_own.ensure((size_t)n_receivers + 1));
-    HIPCHK(h, hipMemsetAsync(h->d_records_own.p + (bytes / 16) * 16, 0, padded - (bytes / 16) * 16, h->stream));
-    if (bytes) HIPCHK(h, hipMemcpyAsync(h->d_records_own.p, records, bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_rec_off_own.p, rec_off, sizeof(long long) * ((size_t)n_receivers + 1), hipMemcpyHostToDevice,
                              h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->d_records = h->d_records_own.p;
-    h->records_bytes = padded;
+    if ((rc = load_split(h, reinterpret_cast<const unsigned char*>(records), false, n_rec))) return rc;
     h->d_rec_off = h->d_rec_off_own.p;
-    h->n_receivers = n_receivers;
-    h->n_records_total = n_rec;
-    h->n_alert_set = -1;
-    h->trust_copies = false;
-    h->index_valid = false;
-    h->streams_loaded = true;
-    h->tallied = false;
-    h->have_decision = false;
+    streams_replaced(h, n_receivers, n_rec);
     return RAPID_OK;
 }
 
@@ -991,20 +1020,12 @@ int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64
     if (rc) return rc;
     long long n_rec = 0;
     HIPCHK(h, hipMemcpy(&n_rec, reinterpret_cast<const long long*>(d_rec_off) + n_receivers, 8, hipMemcpyDeviceToHost));
-    if (n_rec < 0 || (unsigned long long)n_rec * 20ull + 16ull > records_bytes + 0ull)
-        return fail(h, RAPID_EINVAL, "records_bytes=%llu does not cover %lld records plus 16 bytes of padding",
-                    (unsigned long long)records_bytes, n_rec);
-    h->d_records = static_cast<const unsigned char*>(d_records);
-    h->records_bytes = records_bytes & ~15ull;
+    if (n_rec < 0 || (unsigned long long)n_rec * 20ull > records_bytes + 0ull)
+        return fail(h, RAPID_EINVAL, "records_bytes=%llu does not cover %lld records", (unsigned long long)records_bytes, n_rec);
+    // the records are split into the engine's own arrays right here; the offsets stay where they are (borrowed)
+    if ((rc = load_split(h, static_cast<const unsigned char*>(d_records), true, n_rec))) return rc;
     h->d_rec_off = reinterpret_cast<const long long*>(d_rec_off);
-    h->n_receivers = n_receivers;
-    h->n_records_total = n_rec;
-    h->n_alert_set = -1;
-    h->trust_copies = false;
-    h->index_valid = false;
-    h->streams_loaded = true;
-    h->tallied = false;
-    h->have_decision = false;
+    streams_replaced(h, n_receivers, n_rec);
     return RAPID_OK;
 }
 
@@ -1467,16 +1488,16 @@ int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, in
         (void)hipMemsetAsync(h->d_next.p, 0, 4, h->stream);
         (void)hipMemcpyAsync(h->d_next.p + 2, &ring_off, 4, hipMemcpyHostToDevice, h->stream);
         switch (variant) {
-            case 0: hipLaunchKernelGGL((rapid::stream_probe_kernel<2, 8>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
-            case 1: hipLaunchKernelGGL((rapid::stream_probe_kernel<4, 4>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
-            case 2: hipLaunchKernelGGL((rapid::stream_probe_kernel<8, 2>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
-            case 9: hipLaunchKernelGGL((rapid::dma_probe_kernel<6>), grid, block, (size_t)waves * 6 * 1024 + lds_pad, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
-            case 7: hipLaunchKernelGGL((rapid::dma_probe_kernel<4>), grid, block, (size_t)waves * 4 * 1024, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
-            case 8: hipLaunchKernelGGL((rapid::dma_probe_kernel<8>), grid, block, (size_t)waves * 8 * 1024, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
-            case 4: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 8>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
-            case 5: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 16>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
-            case 6: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 4>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
-            default: hipLaunchKernelGGL((rapid::stream_probe_kernel<2, 4>), grid, block, 0, h->stream, h->d_records, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1); break;
+            case 0: hipLaunchKernelGGL((rapid::stream_probe_kernel<2, 8>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
+            case 1: hipLaunchKernelGGL((rapid::stream_probe_kernel<4, 4>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
+            case 2: hipLaunchKernelGGL((rapid::stream_probe_kernel<8, 2>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
+            case 9: hipLaunchKernelGGL((rapid::dma_probe_kernel<6>), grid, block, (size_t)waves * 6 * 1024 + lds_pad, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
+            case 7: hipLaunchKernelGGL((rapid::dma_probe_kernel<4>), grid, block, (size_t)waves * 4 * 1024, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
+            case 8: hipLaunchKernelGGL((rapid::dma_probe_kernel<8>), grid, block, (size_t)waves * 8 * 1024, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
+            case 4: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 8>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
+            case 5: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 16>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
+            case 6: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 4>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
+            default: hipLaunchKernelGGL((rapid::stream_probe_kernel<2, 4>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
         }
     };
     launch();

@@ -18,23 +18,44 @@ namespace rapid {
 // stale, L1-cached) pre-test avoids almost all atomics.  Also validates the records once: vflags bit0 is set if ANY
 // record fails the filter of R/MembershipService.java:644-675 under the current view (or names a node out of range
 // or no ring), bit1 if any record is an UP alert.
-__global__ void index_touch_kernel(const unsigned char* records, long long n_records, int n_nodes, unsigned int kmask,
-                                   long long cfg_id, const unsigned char* member, unsigned int* gmask,
+// Two record sources: the round's declared alert set as it crossed the boundary (20-byte records), or -- when nothing was
+// declared -- every delivered record of the resident split streams (core = dwords 3, 4; cfg = the configuration id).
+template <bool kSplit>
+__global__ void index_touch_kernel(const unsigned char* records, const unsigned char* cfg, long long n_records, int n_nodes,
+                                   unsigned int kmask, long long cfg_id, const unsigned char* member, unsigned int* gmask,
                                    unsigned int* vflags) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
     unsigned int f = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
-        const unsigned int* w = reinterpret_cast<const unsigned int*>(records + i * 20);
-        const unsigned int dst = w[3];
-        const unsigned int bits = w[4] & kmask;
-        const bool down = (w[4] & 0x00FF0000u) != 0u;
+        unsigned int c0, c1, dst, w4;
+        if (kSplit) {
+            const uint2 a = reinterpret_cast<const uint2*>(records)[i], b = reinterpret_cast<const uint2*>(cfg)[i];
+            dst = a.x, w4 = a.y, c0 = b.x, c1 = b.y;
+        } else {
+            const unsigned int* w = reinterpret_cast<const unsigned int*>(records + i * 20);
+            c0 = w[0], c1 = w[1], dst = w[3], w4 = w[4];
+        }
+        const unsigned int bits = w4 & kmask;
+        const bool down = (w4 & 0x00FF0000u) != 0u;
         if (dst < (unsigned)n_nodes && bits != 0u && (bits & ~gmask[dst]) != 0u) atomicOr(&gmask[dst], bits);
-        const bool ok = w[0] == cfg_lo && w[1] == cfg_hi && dst < (unsigned)n_nodes && bits != 0u &&
+        const bool ok = c0 == cfg_lo && c1 == cfg_hi && dst < (unsigned)n_nodes && bits != 0u &&
                         ((member[dst < (unsigned)n_nodes ? dst : 0u] != 0) == down);
         f |= (ok ? 0u : 1u) | (down ? 0u : 2u);
     }
     if (f) atomicOr(vflags, f);
+}
+
+// The boundary hands over 20-byte records (include/rapid_mi355x.h); resident they are split: core[i] = {dst, ring mask |
+// status << 16 | flags << 24}, cfg[i] = configuration id.  One pass at load time, outside every timed region; 16-byte
+// granules of the source are not aligned with records, so each thread reads its record's five dwords.
+__global__ void split_records_kernel(const unsigned char* records, long long n_records, uint2* core, uint2* cfg) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
+        const unsigned int* w = reinterpret_cast<const unsigned int*>(records + i * 20);
+        cfg[i] = make_uint2(w[0], w[1]);
+        core[i] = make_uint2(w[3], w[4]);
+    }
 }
 
 // Dictionary format (built by index_build_block_kernel below).  Slot numbering: the hot subjects (>= L distinct rings

@@ -15,12 +15,14 @@
 //     (index_kernels.h builds the node->slot dictionary once per loaded stream set; reports about other subjects can
 //     never change any receiver's outcome and only contribute to seenLinkDownEvents): bits 0..K-1 = rings reported,
 //     bit 14 = already flushed into an emitted proposal;
-//   * the delivered stream is read ONCE from HBM, straight into registers (stream_load.h): a WINDOW is kQ quarters of
-//     64 records at fixed positions of the stream, lane l of quarter q owns record 64 q + l and loads only the dwords
-//     the tally looks at (dst, ring mask | status | flags; the configuration id too unless the round's alert set has
-//     been validated).  The next window's loads are issued before the current one is tallied, so every wave keeps
-//     kQ x 1.25 KiB in flight without a byte of LDS -- the in-flight data of a CU lives in its 512 KiB of VGPRs, and
-//     the LDS holds 16 waves' detectors instead of 10 waves' staging rings;
+//   * the delivered stream is read ONCE from HBM, straight into registers (stream_load.h).  Resident, a record is split:
+//     core[i] = {dst, ring mask | status | flags} (8 B) and cfg[i] = its configuration id (8 B; src is never read by the
+//     reference either).  A WINDOW is kQ quarters of 64 records at fixed positions of the stream; lane l of quarter q
+//     owns record 64 q + l and loads its core entry with one buffer_load_dwordx2 (lane stride 8 B: a quarter is 512
+//     contiguous bytes) -- and its cfg entry the same way only when deliveries are not vouched-for copies of a validated
+//     alert set.  The next window's loads are issued before the current one is tallied, so every wave keeps a window in
+//     flight without a byte of LDS -- the in-flight data of a CU lives in its 512 KiB of VGPRs, and the LDS holds
+//     15-16 waves' detectors instead of 10 waves' staging rings;
 //   * FAST window (the steady state): while a WITNESS exists -- a slot in preProposal that provably stays below H
 //     through the window even if it is credited with every implicit report it can ever get -- updatesInProgress
 //     stays >= 1, so the reference cannot emit inside the window (R/MultiNodeCutDetector.java:110-121) and the
@@ -50,13 +52,15 @@
 namespace rapid {
 
 constexpr int kWave = 64;
-constexpr int kRecBytes = 20;
+constexpr int kRecBytes = 20;   // a rapid_alert_record as it crosses the boundary
+constexpr int kCoreBytes = 8;   // what stays resident per delivered record: {dst, ring mask | status << 16 | flags << 24} -- and, in a
+                                // second array, the 8 bytes of its configuration id (src is never read: R/MultiNodeCutDetector.java:101)
 #ifndef RAPID_QUARTERS
 #define RAPID_QUARTERS 4
 #endif
 constexpr int kQ = RAPID_QUARTERS;        // quarters (64 records each) per window
 constexpr int kWin = kQ * kWave;          // 256 records = 5 KiB of stream per window
-constexpr int kQuarterBytes = kWave * kRecBytes;
+constexpr int kQuarterBytes = kWave * kCoreBytes;
 static_assert(kQ >= 1 && kQ <= 16, "window size");
 constexpr int kScratchWords = (kQ + 1) * kWave;  // carried quarter + window, one decoded word per record
 constexpr int kUndoCap = 128;                    // implicit bits set inside one careful sub-chunk
@@ -100,8 +104,11 @@ struct RoundIndex {
 };
 
 struct TallyParams {
-    const unsigned char* records;      // packed rapid_alert_record[]
-    unsigned long long records_bytes;  // readable bytes at `records` (multiple of 16, covering the last record)
+    // The delivered streams, resident SPLIT (engine.hip: split_records_kernel): core[i] = dwords 3, 4 of record i (all the
+    // tally ever looks at of a record that is a vouched-for copy of a declared alert), cfg[i] = its configuration id (read
+    // only by the per-delivery filter).  The bytes a launch pulls from HBM are 8 or 16 per delivered record, not 20.
+    const unsigned char* core;         // [n_records][8]
+    const unsigned char* cfg;          // [n_records][8]
     const long long* rec_off;          // [R+1], in records
     int n_receivers;
     int n_nodes;
@@ -506,6 +513,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     };
     // one window of the stream `st` starting at this lane's byte offset `voff`: kQ (2 kQ when the configuration id
     // is needed) wave instructions, nothing waited for
+    const unsigned long long cfg_delta = (unsigned long long)p.cfg - (unsigned long long)p.core;  // record i of both arrays: same offset
     auto load_window = [&](const Stream& st, unsigned int voff, Win& W) {
         // declared wave-uniform right here (it is: every lane computes it from the wave's receiver index), so that the
         // descriptor is in SGPRs whatever the compiler concluded about the loops it travelled through
@@ -514,15 +522,20 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             reinterpret_cast<const unsigned char*>(((unsigned long long)uniform((unsigned int)(b >> 32)) << 32) | (unsigned long long)uniform((unsigned int)b)),
             uniform(st.bytes));
 #pragma unroll
-        for (int q = 0; q < kQ; ++q) {
-            stream_load2(rsrc, voff, (unsigned int)(q * kQuarterBytes + 12), W.w3[q], W.w4[q]);
-            if (!kTrusted) stream_load2(rsrc, voff, (unsigned int)(q * kQuarterBytes), W.w0[kTrusted ? 0 : q], W.w1[kTrusted ? 0 : q]);
+        for (int q = 0; q < kQ; ++q) stream_load2(rsrc, voff, (unsigned int)(q * kQuarterBytes), W.w3[q], W.w4[q]);
+        if (!kTrusted) {  // the same positions of the configuration-id array
+            const unsigned long long c = b + cfg_delta;
+            const stream_rsrc_t rsrc_cfg = stream_make_rsrc(
+                reinterpret_cast<const unsigned char*>(((unsigned long long)uniform((unsigned int)(c >> 32)) << 32) | (unsigned long long)uniform((unsigned int)c)),
+                uniform(st.bytes));
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) stream_load2(rsrc_cfg, voff, (unsigned int)(q * kQuarterBytes), W.w0[kTrusted ? 0 : q], W.w1[kTrusted ? 0 : q]);
         }
     };
     auto make_stream = [&](long long rec0, long long rec1) -> Stream {
         Stream st;
-        st.base = p.records + (unsigned long long)rec0 * kRecBytes;
-        st.bytes = (unsigned int)((rec1 - rec0) * kRecBytes);
+        st.base = p.core + (unsigned long long)rec0 * kCoreBytes;
+        st.bytes = (unsigned int)((rec1 - rec0) * kCoreBytes);
         return st;
     };
     auto uniform64 = [&](long long v) -> long long {  // a vector load of a wave-uniform address: back into SGPRs
@@ -603,9 +616,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     if (r >= p.n_static) r = p.n_receivers;              // (the host sizes the static part so that this never takes pool work away)
     Win W;  // the window in flight
     Stream rsrc;
-    rsrc.base = p.records;
+    rsrc.base = p.core;
     rsrc.bytes = 0u;
-    const unsigned int lane20 = (unsigned int)lane * (unsigned int)kRecBytes;
+    const unsigned int lane_off = (unsigned int)lane * (unsigned int)kCoreBytes;  // this lane's byte offset inside a quarter
     if ((p.flags & 16) != 0 && (wave & 1) != 0) {  // measurement aid: every other wave starts half a receiver late
         for (int i = 0; i < 15; ++i) __builtin_amdgcn_s_sleep(127);
     }
@@ -614,7 +627,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         const long long rec0 = stream_scalar_load(p.rec_off + r), rec1 = stream_scalar_load(p.rec_off + r + 1);
         nrec = (int)(rec1 - rec0);
         rsrc = make_stream(rec0, rec1);
-        load_window(rsrc, lane20, W);
+        load_window(rsrc, lane_off, W);
     }
     while (r < p.n_receivers) {
 #ifdef RAPID_PHASE_TIMERS
@@ -1074,13 +1087,13 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             if (restart) {  // the stream again, from its first window
                 restart = false;
                 exact_only = true;
-                load_window(rsrc, lane20, W);
+                load_window(rsrc, lane_off, W);
                     }
             wave_lds_fence();
-            unsigned int voff = lane20;
+            unsigned int voff = lane_off;
             for (int w = 0; w < nwin && emit_batch < 0 && !restart; ++w) {
                 const Win cur = W;
-                voff += (unsigned int)(kWin * kRecBytes);
+                voff += (unsigned int)(kWin * kCoreBytes);
                 load_window(rsrc, voff, W);  // the next window is in flight while this one is tallied
                 if (!claimed && w + kClaimAhead >= nwin) claim();
                 if ((p.flags & 32) != 0) {  // measurement aid: stream the records through the registers without tallying them
@@ -1142,7 +1155,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             const long long rec0 = next0, rec1 = next1;
             nrec_next = (int)(rec1 - rec0);
             rsrc = make_stream(rec0, rec1);
-            load_window(rsrc, lane20, W);
+            load_window(rsrc, lane_off, W);
             }
 
         // ---- outputs: the proposal = every flushed (hot) slot, ascending node index ----
@@ -1318,7 +1331,7 @@ __global__ __launch_bounds__(64) void cd_instance_kernel(CdParams p) {
 template <int TILE_VEC, int DEPTH>
 __global__ __launch_bounds__(1024) void stream_probe_kernel(const unsigned char* records, unsigned long long records_bytes,
                                                             const long long* rec_off, int n_receivers,
-                                                            unsigned int* next_receiver, unsigned int* sink) {
+                                                            unsigned int* next_receiver, unsigned int* sink, unsigned long long rec_bytes) {
     const int lane = (int)(threadIdx.x & 63u);
     unsigned int acc = 0;
     for (;;) {
@@ -1326,7 +1339,7 @@ __global__ __launch_bounds__(1024) void stream_probe_kernel(const unsigned char*
         if (lane == 0) r = (int)atomicAdd(next_receiver, 1u);
         r = __builtin_amdgcn_readfirstlane(r);
         if (r >= n_receivers) break;
-        const unsigned long long b0 = (unsigned long long)rec_off[r] * 20ull, b1 = (unsigned long long)rec_off[r + 1] * 20ull;
+        const unsigned long long b0 = (unsigned long long)rec_off[r] * rec_bytes, b1 = (unsigned long long)rec_off[r + 1] * rec_bytes;
         const unsigned long long a0 = b0 & ~15ull;
         const int tile_bytes = TILE_VEC * 1024;
         const int ntiles = (int)((b1 - a0 + tile_bytes - 1) / tile_bytes);
@@ -1361,7 +1374,7 @@ __global__ __launch_bounds__(1024) void stream_probe_kernel(const unsigned char*
 template <int kD>
 __global__ __launch_bounds__(1024) void dma_probe_kernel(const unsigned char* records, unsigned long long records_bytes,
                                                          const long long* rec_off, int n_receivers,
-                                                         unsigned int* next_receiver, unsigned int* sink) {
+                                                         unsigned int* next_receiver, unsigned int* sink, unsigned long long rec_bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = (int)(threadIdx.x >> 6);
@@ -1373,7 +1386,7 @@ __global__ __launch_bounds__(1024) void dma_probe_kernel(const unsigned char* re
         if (lane == 0) r = (int)atomicAdd(next_receiver, 1u);
         r = __builtin_amdgcn_readfirstlane(r);
         if (r >= n_receivers) break;
-        const unsigned long long b0 = (unsigned long long)rec_off[r] * 20ull, b1 = (unsigned long long)rec_off[r + 1] * 20ull;
+        const unsigned long long b0 = (unsigned long long)rec_off[r] * rec_bytes, b1 = (unsigned long long)rec_off[r + 1] * rec_bytes;
         const unsigned long long a0 = b0 & ~15ull;
         const int nk = (int)((b1 - a0 + 1023ull) / 1024ull);
         const dma_rsrc_t rsrc = dma_make_rsrc(records + a0, (unsigned int)(((b1 - a0) + 15ull) & ~15ull));

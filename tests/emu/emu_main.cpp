@@ -145,8 +145,19 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
                     rapid::kBlockStatsBytes;
     if (lds > (int)sizeof(smem)) return -5;
     rapid::TallyParams p;
-    p.records = records;
-    p.records_bytes = records_bytes;
+    // the 20-byte records as the boundary hands them over -> the split resident form (what engine.hip's
+    // split_records_kernel produces); exactly sized, so that a read past a stream's end is caught by the bounds model
+    const long long n_rec_all = rec_off[n_receivers];
+    (void)records_bytes;
+    std::vector<unsigned int> core((size_t)n_rec_all * 2 + 2), cfgs((size_t)n_rec_all * 2 + 2);
+    for (long long i = 0; i < n_rec_all; ++i) {
+        unsigned int w[5];
+        std::memcpy(w, records + i * 20, 20);
+        cfgs[2 * i] = w[0], cfgs[2 * i + 1] = w[1];
+        core[2 * i] = w[3], core[2 * i + 1] = w[4];
+    }
+    p.core = reinterpret_cast<const unsigned char*>(core.data());
+    p.cfg = reinterpret_cast<const unsigned char*>(cfgs.data());
     p.rec_off = rec_off;
     p.n_receivers = n_receivers;
     p.n_nodes = n_nodes;
