@@ -384,7 +384,8 @@ int build_round_index(rapid_engine* h) {
     HIPCHK(h, h->d_adj.ensure((size_t)adj_cap + 1));
     hipLaunchKernelGGL(rapid::index_build_block_kernel, dim3(1), dim3(1024), 0, st, d_gmask, h->d_member.p, h->d_obs.p, N, K, L,
                        h->d_dict.p, h->d_decl.p, h->d_node_of_slot.p, h->d_adj_off.p, h->d_adj.p, adj_cap, h->d_tbits.p, h->d_trank.p,
-                       h->d_tent.p, tent_cap, d_info, reinterpret_cast<volatile int*>(h->d_mail));
+                       h->d_tent.p, tent_cap, d_info, reinterpret_cast<volatile int*>(h->d_mail),
+                       (h->force_exact & (128 | 256)) != 0 ? -1 : 160 * 1024 - rapid::kBlockStatsBytes);  // (lds_max below)
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "tally_kernel.h"  // the LDS budget formulas: this kernel and the host must agree on where the dictionary will live
+
 namespace rapid {
 
 // gmask[dst] |= ring_mask over every record given (the round's distinct alert set if the host declared one, else
@@ -101,26 +103,43 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(const unsigned 
                                                                  unsigned short* decl, int* node_of_slot, unsigned short* smask,
                                                                  unsigned int* pairs, int adj_cap, unsigned int* tbits,
                                                                  unsigned short* trank, unsigned int* tent, int tent_cap, int* info,
-                                                                 volatile int* info_out) {
+                                                                 volatile int* info_out, int direct_budget) {
     __shared__ int s_wave[16];
     const int T = (int)blockDim.x, t = (int)threadIdx.x;
     // ---- slots (ascending node order), dictionary, declared ring masks ----
-    const int per = (n_nodes + T - 1) / T;
-    const int beg = min(n_nodes, t * per), end = min(n_nodes, beg + per);
+    // Wave w owns a contiguous range of nodes and walks it 64 at a time (coalesced; this kernel is one workgroup and lives on
+    // memory latency, not bandwidth): a node's slot = hot nodes of earlier waves + of earlier steps + of lower lanes.
+    const int lane = t & 63, wv = t >> 6, nw = T >> 6;
+    const int per_wave_nodes = ((n_nodes + nw * 64 - 1) / (nw * 64)) * 64;
+    const int beg = min(n_nodes, wv * per_wave_nodes), end = min(n_nodes, beg + per_wave_nodes);
     int nh = 0;
-    for (int n = beg; n < end; ++n)
-        if (__popc(gmask[n]) >= L) ++nh;
+#pragma unroll 4
+    for (int n0 = beg; n0 < end; n0 += 64) {
+        const int n = n0 + lane;
+        nh += __popcll(__ballot(n < end && __popc(gmask[n < end ? n : beg]) >= L));
+    }
     int n_hot_all = 0;
-    int ph = block_exclusive_scan(nh, s_wave, &n_hot_all);
-    for (int n = beg; n < end; ++n) {
-        int slot = 0x3FFF;
-        if (__popc(gmask[n]) >= L) {
-            slot = ph < 16319 ? ph : 0x3FFF;
-            if (ph < 16319) node_of_slot[ph] = n;
-            ++ph;
+    int ph = block_exclusive_scan(lane == 0 ? nh : 0, s_wave, &n_hot_all);
+    ph = __shfl(ph, 0, 64);  // hot nodes of the waves before this one
+#pragma unroll 4
+    for (int n0 = beg; n0 < end; n0 += 64) {
+        const int n = n0 + lane;
+        const bool in = n < end;
+        const unsigned int g = gmask[in ? n : beg];
+        const unsigned int mem = member[in ? n : beg] ? 0x8000u : 0u;
+        const bool hot = in && __popc(g) >= L;
+        const unsigned long long hots = __ballot(hot);
+        const int mine_slot = ph + __popcll(hots & ((1ull << lane) - 1ull));
+        ph += __popcll(hots);
+        unsigned int slot = 0x3FFFu;
+        if (hot && mine_slot < 16319) {
+            slot = (unsigned int)mine_slot;
+            node_of_slot[mine_slot] = n;
         }
-        dict[n] = (unsigned short)(slot | (member[n] ? 0x8000 : 0));
-        decl[n] = (unsigned short)((slot != 0x3FFF ? 0x3FFFu : (gmask[n] & 0x3FFFu)) | (member[n] ? 0x8000u : 0u));
+        if (in) {
+            dict[n] = (unsigned short)(slot | mem);
+            decl[n] = (unsigned short)((slot != 0x3FFFu ? 0x3FFFu : (g & 0x3FFFu)) | mem);
+        }
     }
     __threadfence_block();
     __syncthreads();
@@ -158,7 +177,10 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(const unsigned 
     __syncthreads();  // dict[] is final (adjacency flags included)
     // ---- the compressed form of dict[] / decl[] for populations whose direct tables do not fit the LDS: one bit per node
     // (touched = named by the alert set at all), touched nodes before each 32-node word, one entry per touched node ----
-    const int n_words = (n_nodes + 31) / 32;
+    // Skipped when the direct tables will be used anyway -- the same test as the host's (engine.hip: build_round_index), on
+    // the same numbers; direct_budget < 0: always build them.  info[7] tells the host which way it went.
+    const bool direct_fits = direct_budget >= 0 && tally_shared_bytes(kDictDirect, n_nodes, 0, n_hot, total) + 8 * tally_wave_bytes(n_hot) <= direct_budget;
+    const int n_words = direct_fits ? 0 : (n_nodes + 31) / 32;
     const int perw = (n_words + T - 1) / T;
     const int w0 = min(n_words, t * perw), w1 = min(n_words, w0 + perw);
     int cnt = 0;
@@ -187,7 +209,8 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(const unsigned 
     }
     if (t == 0) {
         info[5] = n_touched;
-        info[6] = tfits ? 1 : 0;
+        info[6] = tfits && !direct_fits ? 1 : 0;
+        info[7] = direct_fits ? 1 : 0;
     }
     __syncthreads();
     if (t == 0) {

@@ -197,109 +197,126 @@ __global__ __launch_bounds__(1024) void vote_count_local_kernel(const unsigned l
     unsigned int* const hist = reinterpret_cast<unsigned int*>(vote_smem);                          // [kVoteBuckets]
     unsigned long long* const red64 = reinterpret_cast<unsigned long long*>(hist + kVoteBuckets);  // [2][16] per-wave partials
     unsigned int* const red32 = reinterpret_cast<unsigned int*>(red64 + 32);                       // [4][16]
-    __shared__ unsigned int s_win_bucket, s_win_count, s_total, s_nz, s_rep;
+    __shared__ unsigned int s_win_bucket, s_win_count, s_total, s_nz, s_rep, s_unanimous;
     __shared__ unsigned long long s_fmax, s_fminc;
     const int t = (int)threadIdx.x, T = (int)blockDim.x, lane = t & 63, wv = t >> 6, nw = T >> 6;
-    for (int b = t; b < kVoteBuckets; b += T) hist[b] = 0u;
-    __syncthreads();
-    unsigned int mine = 0;
-    for (int r = t; r < n_receivers; r += T) {
-        if (prop_count[r] != 0) {  // -1 = proposal larger than max_cut: still a vote
-            atomicAdd(&hist[vote_bucket(fp[r], salt)], 1u);
-            ++mine;
-        }
-    }
-    __syncthreads();
-    // winner: most votes, lowest bucket among equals; number of non-empty buckets; total voters
-    unsigned int bc = 0, bi = 0, nz = 0;
-    for (int b = t; b < kVoteBuckets; b += T) {
-        const unsigned int c = hist[b];
-        nz += c != 0u ? 1u : 0u;
-        if (c > bc) {
-            bc = c;
-            bi = (unsigned int)b;
-        }
-    }
-    unsigned long long key = ((unsigned long long)bc << 32) | (unsigned long long)(0xFFFFFFFFu - bi);  // max key = max count, then min bucket
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(key, off, 64);
-        key = o > key ? o : key;
-        nz += (unsigned int)__shfl_xor((int)nz, off, 64);
-        mine += (unsigned int)__shfl_xor((int)mine, off, 64);
-    }
-    if (lane == 0) {
-        red64[wv] = key;
-        red32[wv] = nz;
-        red32[16 + wv] = mine;
-    }
-    __syncthreads();
-    if (t == 0) {
-        unsigned long long k = 0;
-        unsigned int z = 0, m = 0;
-        for (int i = 0; i < nw; ++i) {
-            k = red64[i] > k ? red64[i] : k;
-            z += red32[i];
-            m += red32[16 + i];
-        }
-        s_win_count = (unsigned int)(k >> 32);
-        s_win_bucket = 0xFFFFFFFFu - (unsigned int)(k & 0xFFFFFFFFull);
-        s_nz = z;
-        s_total = m;
-    }
-    __syncthreads();
-    // the winning bucket: max fingerprint, max ~fingerprint, lowest voter
-    const unsigned int wb = s_win_bucket;
-    unsigned long long fmx = 0ull, fmn = 0ull;
-    unsigned int rep = 0xFFFFFFFFu;
-    if (s_win_count != 0u) {
+
+    // max fingerprint, max ~fingerprint and lowest index over the voters `sel` picks; the three land in s_fmax, s_fminc, s_rep
+    auto range_of = [&](auto sel, unsigned int* count_out) {
+        unsigned long long fmx = 0ull, fmn = 0ull;
+        unsigned int rep = 0xFFFFFFFFu, cnt = 0u;
         for (int r = t; r < n_receivers; r += T) {
-            if (prop_count[r] != 0) {
+            if (prop_count[r] != 0) {  // -1 = proposal larger than max_cut: still a vote
                 const unsigned long long f = fp[r];
-                if (vote_bucket(f, salt) == wb) {
+                if (sel(f)) {
+                    ++cnt;
                     fmx = f > fmx ? f : fmx;
                     fmn = ~f > fmn ? ~f : fmn;
                     rep = (unsigned int)r < rep ? (unsigned int)r : rep;
                 }
             }
         }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long a = __shfl_xor(fmx, off, 64), b = __shfl_xor(fmn, off, 64);
-        const unsigned int c = (unsigned int)__shfl_xor((int)rep, off, 64);
-        fmx = a > fmx ? a : fmx;
-        fmn = b > fmn ? b : fmn;
-        rep = c < rep ? c : rep;
-    }
-    __syncthreads();
-    if (lane == 0) {
-        red64[wv] = fmx;
-        red64[16 + wv] = fmn;
-        red32[wv] = rep;
-    }
-    __syncthreads();
-    if (t == 0) {
-        unsigned long long a = 0, b = 0;
-        unsigned int c = 0xFFFFFFFFu;
-        for (int i = 0; i < nw; ++i) {
-            a = red64[i] > a ? red64[i] : a;
-            b = red64[16 + i] > b ? red64[16 + i] : b;
-            c = red32[i] < c ? red32[i] : c;
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long a = __shfl_xor(fmx, off, 64), b = __shfl_xor(fmn, off, 64);
+            const unsigned int c = (unsigned int)__shfl_xor((int)rep, off, 64);
+            fmx = a > fmx ? a : fmx;
+            fmn = b > fmn ? b : fmn;
+            rep = c < rep ? c : rep;
+            cnt += (unsigned int)__shfl_xor((int)cnt, off, 64);
         }
-        s_fmax = a;
-        s_fminc = b;
-        s_rep = c;
+        __syncthreads();  // the reduction arrays may still be read from a previous use
+        if (lane == 0) {
+            red64[wv] = fmx;
+            red64[16 + wv] = fmn;
+            red32[wv] = rep;
+            red32[16 + wv] = cnt;
+        }
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long a = 0, b = 0;
+            unsigned int c = 0xFFFFFFFFu, m = 0u;
+            for (int i = 0; i < nw; ++i) {
+                a = red64[i] > a ? red64[i] : a;
+                b = red64[16 + i] > b ? red64[16 + i] : b;
+                c = red32[i] < c ? red32[i] : c;
+                m += red32[16 + i];
+            }
+            s_fmax = a;
+            s_fminc = b;
+            s_rep = c;
+            *count_out = m;
+        }
+        __syncthreads();
+    };
+
+    // The common round first: every voter holds the same fingerprint (one pass over the fingerprints, no histogram).
+    range_of([](unsigned long long) { return true; }, &s_total);
+    if (t == 0) {
+        s_unanimous = (s_total == 0u || s_fmax == ~s_fminc) ? 1u : 0u;
+        if (s_unanimous) {
+            s_win_bucket = s_total != 0u ? vote_bucket(s_fmax, salt) : 0u;
+            s_win_count = s_total;
+            s_nz = s_total != 0u ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    if (s_unanimous == 0u) {
+        // several proposals: histogram of the fingerprints over kVoteBuckets positions in LDS
+        for (int b = t; b < kVoteBuckets; b += T) hist[b] = 0u;
+        __syncthreads();
+        for (int r = t; r < n_receivers; r += T)
+            if (prop_count[r] != 0) atomicAdd(&hist[vote_bucket(fp[r], salt)], 1u);
+        __syncthreads();
+        // winner: most votes, lowest bucket among equals; number of non-empty buckets
+        unsigned int bc = 0, bi = 0, nz = 0;
+        for (int b = t; b < kVoteBuckets; b += T) {
+            const unsigned int c = hist[b];
+            nz += c != 0u ? 1u : 0u;
+            if (c > bc) {
+                bc = c;
+                bi = (unsigned int)b;
+            }
+        }
+        unsigned long long key = ((unsigned long long)bc << 32) | (unsigned long long)(0xFFFFFFFFu - bi);  // max key = max count, then min bucket
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off, 64);
+            key = o > key ? o : key;
+            nz += (unsigned int)__shfl_xor((int)nz, off, 64);
+        }
+        if (lane == 0) {
+            red64[wv] = key;
+            red32[wv] = nz;
+        }
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long k = 0;
+            unsigned int z = 0;
+            for (int i = 0; i < nw; ++i) {
+                k = red64[i] > k ? red64[i] : k;
+                z += red32[i];
+            }
+            s_win_count = (unsigned int)(k >> 32);
+            s_win_bucket = 0xFFFFFFFFu - (unsigned int)(k & 0xFFFFFFFFull);
+            s_nz = z;
+        }
+        __syncthreads();
+        // the winning bucket: max fingerprint, max ~fingerprint, lowest voter
+        const unsigned int wb = s_win_bucket;
+        __shared__ unsigned int s_ignored;
+        range_of([&](unsigned long long f) { return vote_bucket(f, salt) == wb; }, &s_ignored);
+    }
+    if (t == 0) {
         res[0] = s_win_bucket;
         res[1] = s_win_count;
         res[2] = s_total;
         res[3] = s_nz;
-        res[4] = a;
-        res[5] = b;
+        res[4] = s_fmax;
+        res[5] = s_fminc;
         res[6] = 0ull;
         res[7] = 0ull;
         res[8] = (unsigned long long)tally_errors[0];  // the tally kernel's sticky error word rides along
         res[9] = 0ull;                                  // vote_verify_kernel's count of finished workgroups
     }
-    __syncthreads();
     const bool have = s_rep != 0xFFFFFFFFu;
     int n = have ? prop_count[s_rep] : 0;
     if (n < 0) n = -1;  // the representative's proposal overflowed max_cut: reported by the host
