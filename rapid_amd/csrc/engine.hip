@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -119,6 +121,11 @@ struct rapid_engine {
     bool trusted = false, all_down = false;
     bool trust_copies = false;  // the caller's promise that every delivered record is a byte copy of a declared alert
     DevBuf<unsigned int> d_adj;
+    hipEvent_t ev_idx0 = nullptr, ev_idx1 = nullptr;  // around the round-index kernels; read lazily (rapid_sim_index_info)
+    bool index_ms_pending = false;
+    const int* idxwork_clean_at = nullptr;  // the index work area is known to be all zero for this allocation and node count
+    int idxwork_clean_n = -1;
+    bool stats_fresh = false;  // the statistics were zeroed by the index build of this very call
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // timing events, created once (no create / destroy per call, nothing to leak on an error path)
     DevBuf<unsigned short> d_dict, d_decl, d_adj_off, d_trank;
     DevBuf<unsigned int> d_tbits, d_tent;  // compressed dictionary (index_build_block_kernel)
@@ -143,6 +150,7 @@ struct rapid_engine {
     // host-mapped mailbox the kernels write their small answers into (no copy enqueued, the host reads it after a
     // synchronisation): [0, 64) the round index's info[8], [64, ...) the vote count's res[] + representative list
     unsigned char* h_mail = nullptr;
+    unsigned int mail_seq = 0;  // sequence numbers of the answers polled from the mailbox
     unsigned char* d_mail = nullptr;
     size_t mail_bytes = 0;
 
@@ -345,8 +353,34 @@ int ensure_mailbox(rapid_engine* h) {
     return RAPID_OK;
 }
 
+// Waits for a kernel's answer in the host-mapped mailbox: the kernel's last act is a system-scope fence and the write of
+// `want` into the polled word (bytes 56..63 of the page), so the host need not go through the runtime's completion path
+// (hipStreamSynchronize costs ~20 us of wake-up latency, twice per round).  Falls back to it after 2 ms without an answer --
+// a faulted kernel never answers.
+static int await_mail(rapid_engine* h, int word_index, unsigned int want) {
+    volatile unsigned int* const w = reinterpret_cast<volatile unsigned int*>(h->h_mail) + word_index;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int i = 0; i < 64; ++i) {
+            if (*w == want) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                return RAPID_OK;
+            }
+            __builtin_ia32_pause();
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    if (*w != want) return fail(h, RAPID_EDEVICE, "kernel finished without publishing its answer");
+    return RAPID_OK;
+}
+
 // Builds the per-round index (touched / hot subjects, slot dictionary, hot adjacency) for the loaded streams under
 // the current view, and picks the launch geometry of the tally kernel.
+// launch statistics [workgroups][8] + the pool words of launch_tally, sized for the largest grid a launch can have
+static size_t stats_words(const rapid_engine* h) { return (size_t)8 * (size_t)std::max(h->num_cus, 1) * 4 + 8; }
+
 int build_round_index(rapid_engine* h) {
     const int N = h->n_nodes, K = h->cfg.K, L = h->cfg.L;
     hipStream_t st = h->stream;
@@ -365,13 +399,17 @@ int build_round_index(rapid_engine* h) {
     HIPCHK(h, h->d_tent.ensure((size_t)tent_cap));
     unsigned int* const d_gmask = reinterpret_cast<unsigned int*>(h->d_idxwork.p);
     int* const d_info = h->d_idxwork.p + (size_t)N;
-    if (!h->ev0) HIPCHK(h, hipEventCreate(&h->ev0));
-    if (!h->ev1) HIPCHK(h, hipEventCreate(&h->ev1));
-    const hipEvent_t e0 = h->ev0, e1 = h->ev1;
+    if (!h->ev_idx0) HIPCHK(h, hipEventCreate(&h->ev_idx0));
+    if (!h->ev_idx1) HIPCHK(h, hipEventCreate(&h->ev_idx1));
+    const hipEvent_t e0 = h->ev_idx0, e1 = h->ev_idx1;
     HIPCHK(h, hipEventRecord(e0, st));
-    // gmask | info live in one allocation: one memset, then the touch pass (whole GPU), then everything else in one
-    // workgroup, which leaves info[] in host-mapped memory: one synchronisation, no copy
-    HIPCHK(h, hipMemsetAsync(h->d_idxwork.p, 0, sizeof(int) * ((size_t)N + 8), st));
+    // gmask | info live in one allocation; the touch pass (whole GPU), then everything else in one workgroup, which leaves
+    // info[] in host-mapped memory and the work area, the launch statistics and the error flags zeroed: no memset, no
+    // copy, and the host polls the mapped page for the answer instead of waiting for the stream
+    if (h->idxwork_clean_at != h->d_idxwork.p || h->idxwork_clean_n != N) {  // (the build kernel leaves it zeroed for the next round)
+        HIPCHK(h, hipMemsetAsync(h->d_idxwork.p, 0, sizeof(int) * ((size_t)N + 8), st));
+    }
+    h->idxwork_clean_at = nullptr;  // dirty from here until the build kernel has answered
     const long long n_scan = h->n_alert_set >= 0 ? h->n_alert_set : h->n_records_total;
     const dim3 touch_grid((unsigned)std::min<long long>(h->num_cus * 8, (n_scan + 255) / 256));
     if (n_scan > 0 && h->n_alert_set >= 0)
@@ -385,13 +423,16 @@ int build_round_index(rapid_engine* h) {
     hipLaunchKernelGGL(rapid::index_build_block_kernel, dim3(1), dim3(1024), 0, st, d_gmask, h->d_member.p, h->d_obs.p, N, K, L,
                        h->d_dict.p, h->d_decl.p, h->d_node_of_slot.p, h->d_adj_off.p, h->d_adj.p, adj_cap, h->d_tbits.p, h->d_trank.p,
                        h->d_tent.p, tent_cap, d_info, reinterpret_cast<volatile int*>(h->d_mail),
-                       (h->force_exact & (128 | 256)) != 0 ? -1 : 160 * 1024 - rapid::kBlockStatsBytes);  // (lds_max below)
+                       (h->force_exact & (128 | 256)) != 0 ? -1 : 160 * 1024 - rapid::kBlockStatsBytes,  // (lds_max below)
+                       h->d_stats.p, (int)stats_words(h), h->d_errflags.p, (int)++h->mail_seq);
     HIPCHK(h, hipEventRecord(e1, st));
-    HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
+    if (int rc = await_mail(h, 15, h->mail_seq)) return rc;
+    h->idxwork_clean_at = h->d_idxwork.p;
+    h->idxwork_clean_n = N;
     int info[8];
     std::memcpy(info, h->h_mail, sizeof info);  // written by the kernel into host-mapped memory
-    HIPCHK(h, hipEventElapsedTime(&h->index_ms, e0, e1));
+    h->index_ms_pending = true;  // the events are read when somebody asks (no wait for them here)
     if (info[2] & 1) return fail(h, RAPID_ECAPACITY, "the round has %d hot subjects; at most 16318 are supported", info[0]);
     if (info[2] & 2)
         return fail(h, RAPID_ECAPACITY, "hot adjacency has %d entries; at most 65535 are supported", info[3]);
@@ -528,10 +569,12 @@ int prepare_tally(rapid_engine* h) {
     if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
     if (!h->streams_loaded) return fail(h, RAPID_ESTATE, "no alert streams loaded");
     HIPCHK(h, h->d_errflags.ensure(2));
+    HIPCHK(h, h->d_stats.ensure(stats_words(h)));
+    h->stats_fresh = false;
     if (!h->index_valid) {
-        int rc = build_round_index(h);
+        int rc = build_round_index(h);  // also zeroes the error flags and the launch statistics / pool words
         if (rc) return rc;
-        HIPCHK(h, hipMemsetAsync(h->d_errflags.p, 0, 2 * sizeof(unsigned int), h->stream));
+        h->stats_fresh = true;
     }
     if (!h->lds_attr_set) {  // once per engine: every instantiation may use the whole 160 KiB of LDS
         const void* kernels[6] = {reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, false>),
@@ -549,7 +592,6 @@ int prepare_tally(rapid_engine* h) {
     HIPCHK(h, h->d_pcount.ensure(R));
     HIPCHK(h, h->d_fp.ensure(R));
     HIPCHK(h, h->d_props.ensure(R * (size_t)h->max_cut));
-    HIPCHK(h, h->d_stats.ensure((size_t)8 * (size_t)std::max(h->grid_blocks, 1) + 1));  // + the pool words of launch_tally
     HIPCHK(h, h->d_next.ensure(4));
     return RAPID_OK;
 }
@@ -604,6 +646,8 @@ void rapid_engine_destroy(rapid_engine* h) {
     };
     if (h->comm) (void)ncclCommDestroy(h->comm);
     if (h->stream) quiet(hipStreamSynchronize(h->stream), "hipStreamSynchronize");
+    if (h->ev_idx0) quiet(hipEventDestroy(h->ev_idx0), "hipEventDestroy");
+    if (h->ev_idx1) quiet(hipEventDestroy(h->ev_idx1), "hipEventDestroy");
     if (h->ev0) quiet(hipEventDestroy(h->ev0), "hipEventDestroy");
     if (h->ev1) quiet(hipEventDestroy(h->ev1), "hipEventDestroy");
     if (h->h_mail) quiet(hipHostFree(h->h_mail), "hipHostFree(mailbox)");
@@ -1064,7 +1108,7 @@ int rapid_sim_tally(rapid_engine* h) {
     int rc = use_device(h);
     if (rc) return rc;
     if ((rc = prepare_tally(h))) return rc;
-    HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * (size_t)std::max(h->grid_blocks, 1) + 8, h->stream));
+    if (!h->stats_fresh) HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * ((size_t)std::max(h->grid_blocks, 1) + 1), h->stream));
     if (h->n_receivers > 0) {
         if ((rc = launch_tally(h))) return rc;
         HIPCHK(h, hipGetLastError());
@@ -1220,12 +1264,13 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
                                h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
             hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * 64, 1024))), dim3(1024), 0, st,
                                h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, nullptr, 0, nullptr,
-                               nullptr);
+                               nullptr, nullptr, 0u);
             NCCLCHK(h, ncclAllGather(d_res, h->d_gather.p, seg_words, ncclUint64, h->comm, st));  // the round's one collective
             hipLaunchKernelGGL(rapid::vote_merge_kernel, dim3(1), dim3(256), 0, st, h->d_gather.p, h->n_ranks, (int)seg_words,
-                               (int)res_words, h->max_cut, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64));
-            HIPCHK(h, hipStreamSynchronize(st));
+                               (int)res_words, h->max_cut, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
+                               reinterpret_cast<volatile unsigned int*>(h->d_mail) + 14, ++h->mail_seq);
             HIPCHK(h, hipGetLastError());
+            if ((rc = await_mail(h, 14, h->mail_seq))) return rc;
             if (reinterpret_cast<unsigned long long*>(h->h_mail + 64)[9] != 1ull) {  // the voters disagree somewhere: count the general way
                 merged = false;
                 --salt;
@@ -1237,7 +1282,8 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
             hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * 64, 1024))), dim3(1024), 0, st,
                                h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, d_res,
                                (int)res_words, reinterpret_cast<unsigned int*>(d_res + 9),
-                               reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64));
+                               reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
+                               reinterpret_cast<volatile unsigned int*>(h->d_mail) + 14, ++h->mail_seq);
         } else {
             HIPCHK(h, hipMemsetAsync(h->d_hist.p, 0, HB * 8, st));
             HIPCHK(h, hipMemsetAsync(h->d_mm.p, 0, 64, st));
@@ -1260,14 +1306,18 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
             if (h->comm) NCCLCHK(h, ncclAllReduce(d_ref, d_ref, ref_len, ncclInt32, ncclMax, h->comm, st));
             if (R)
                 hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(grid_for((long long)R * 64, 1024)), dim3(1024), 0, st, h->d_fp.p,
-                                   h->d_pcount.p, h->d_props.p, h->max_cut, R, h->d_mm.p, d_ref, d_mismatch, nullptr, 0, nullptr, nullptr);
+                                   h->d_pcount.p, h->d_props.p, h->max_cut, R, h->d_mm.p, d_ref, d_mismatch, nullptr, 0, nullptr, nullptr, nullptr, 0u);
             if (h->comm) NCCLCHK(h, ncclAllReduce(d_mismatch, d_mismatch, 2, ncclUint64, ncclSum, h->comm, st));
             HIPCHK(h, hipMemcpyAsync(d_res + 4, h->d_mm.p, 16, hipMemcpyDeviceToDevice, st));
             HIPCHK(h, hipMemcpyAsync(d_res + 8, h->d_errflags.p, 8, hipMemcpyDeviceToDevice, st));
         }
         if (!local && !merged) HIPCHK(h, hipMemcpyAsync(hres, d_res, back_bytes, hipMemcpyDeviceToHost, st));
-        if (!merged) HIPCHK(h, hipStreamSynchronize(st));
         HIPCHK(h, hipGetLastError());
+        if (local) {
+            if ((rc = await_mail(h, 14, h->mail_seq))) return rc;
+        } else if (!merged) {
+            HIPCHK(h, hipStreamSynchronize(st));
+        }
         if (local || merged) {  // the last workgroup of the verification wrote the answer into host-mapped memory
             hres = reinterpret_cast<unsigned long long*>(h->h_mail + 64);
         }
@@ -1305,7 +1355,7 @@ int rapid_debug_vote_segment(rapid_engine* h, void* out, int64_t cap_bytes, int6
     hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st, h->d_fp.p,
                        h->d_pcount.p, h->d_props.p, h->max_cut, R, 0ull, h->d_errflags.p, d_res, d_ref);
     hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * 64, 1024))), dim3(1024), 0, st, h->d_fp.p,
-                       h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_res + 6, nullptr, 0, nullptr, nullptr);
+                       h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_res + 6, nullptr, 0, nullptr, nullptr, nullptr, 0u);
     HIPCHK(h, hipMemcpyAsync(out, d_res, seg_words * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     return RAPID_OK;
@@ -1322,7 +1372,7 @@ int rapid_debug_vote_merge(rapid_engine* h, const void* segments, int32_t n_rank
     hipStream_t st = h->stream;
     HIPCHK(h, hipMemcpyAsync(h->d_gather.p, segments, seg_words * 8 * (size_t)n_ranks, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(rapid::vote_merge_kernel, dim3(1), dim3(256), 0, st, h->d_gather.p, n_ranks, (int)seg_words, (int)res_words,
-                       h->max_cut, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64));
+                       h->max_cut, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64), nullptr, 0u);
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
     const unsigned long long* hres = reinterpret_cast<const unsigned long long*>(h->h_mail + 64);
@@ -1451,7 +1501,7 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg) {
     if (!h->ev0) HIPCHK(h, hipEventCreate(&h->ev0));
     if (!h->ev1) HIPCHK(h, hipEventCreate(&h->ev1));
     const hipEvent_t e0 = h->ev0, e1 = h->ev1;
-    HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * (size_t)std::max(h->grid_blocks, 1) + 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * ((size_t)std::max(h->grid_blocks, 1) + 1), h->stream));
     launch_tally(h);  // untimed warm-up
     HIPCHK(h, hipEventRecord(e0, h->stream));
     for (int i = 0; i < reps; ++i) launch_tally(h);
@@ -1526,6 +1576,11 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
     info[5] = (h->trusted && (h->n_alert_set < 0 || h->trust_copies)) ? 1 : 0;
     info[6] = h->dict_mode;  // 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS
     info[7] = h->n_alert_set >= 0 ? 1 : 0;
+    if (h->index_ms_pending && h->ev_idx0 && h->ev_idx1) {
+        h->index_ms_pending = false;
+        if (hipEventSynchronize(h->ev_idx1) == hipSuccess) (void)hipEventElapsedTime(&h->index_ms, h->ev_idx0, h->ev_idx1);
+        (void)hipGetLastError();
+    }
     if (index_ms) *index_ms = h->index_ms;
     return RAPID_OK;
 }

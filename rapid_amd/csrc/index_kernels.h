@@ -98,14 +98,20 @@ __device__ inline int block_exclusive_scan(int v, int* s_wave, int* total) {
 // pairs has room for adj_cap entries (info[2] |= 2 if more are needed: nothing is written past it).  info_out: a second
 // copy of info[0..7] (host-mapped memory: the host reads it after synchronising, no copy is enqueued).  info[5] = touched
 // nodes, info[6] = 1 if the compressed tables are complete (at most 65535 touched nodes and tent_cap entries).
-__global__ __launch_bounds__(1024) void index_build_block_kernel(const unsigned int* gmask, const unsigned char* member, const int* obs,
+__global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* gmask, const unsigned char* member, const int* obs,
                                                                  int n_nodes, int K, int L, unsigned short* dict,
                                                                  unsigned short* decl, int* node_of_slot, unsigned short* smask,
                                                                  unsigned int* pairs, int adj_cap, unsigned int* tbits,
                                                                  unsigned short* trank, unsigned int* tent, int tent_cap, int* info,
-                                                                 volatile int* info_out, int direct_budget) {
+                                                                 volatile int* info_out, int direct_budget,
+                                                                 unsigned long long* zero_words, int n_zero_words,
+                                                                 unsigned int* zero_flags, int seq) {
     __shared__ int s_wave[16];
     const int T = (int)blockDim.x, t = (int)threadIdx.x;
+    // the round's launch statistics / pool words and the sticky error flags start at zero: cleared here instead of by
+    // memsets of their own between this kernel and the tally (each costs a launch gap)
+    for (int i = t; i < n_zero_words; i += T) zero_words[i] = 0ull;
+    if (t < 2 && zero_flags != nullptr) zero_flags[t] = 0u;
     // ---- slots (ascending node order), dictionary, declared ring masks ----
     // Wave w owns a contiguous range of nodes and walks it 64 at a time (coalesced; this kernel is one workgroup and lives on
     // memory latency, not bandwidth): a node's slot = hot nodes of earlier waves + of earlier steps + of lower lanes.
@@ -219,7 +225,15 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(const unsigned 
         info[2] = (n_hot_all > 16318 ? 1 : 0) | (fits ? 0 : 2);  // 64 slot numbers are kept for the tally kernel's dummy slots
         info[3] = total;
         for (int i = 0; i < 8; ++i) info_out[i] = info[i];  // info[4] was written by the touch pass
+        // the host does not wait for the stream: it polls this word of the mapped page (what it reads afterwards was written
+        // before the fence; the zeroing above is ordered before the tally kernel by the stream)
+        __threadfence_system();
+        info_out[15] = seq;
     }
+    // leave the work area as the next round's touch pass needs it (all zero): nobody reads gmask[] / info[] after this point
+    __syncthreads();
+    for (int n = t; n < n_nodes; n += T) gmask[n] = 0u;
+    if (t < 8) info[t] = 0;
 }
 
 }  // namespace rapid

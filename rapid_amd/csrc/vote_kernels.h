@@ -137,7 +137,8 @@ __global__ void vote_prepare_ref_kernel(const unsigned long long* mm, unsigned l
 __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop_count, const int* props, int prop_cap,
                                    int n_receivers, const unsigned long long* mm, const int* ref,
                                    unsigned long long* mismatch, const unsigned long long* res, int res_words,
-                                   unsigned int* done, volatile unsigned long long* publish) {
+                                   unsigned int* done, volatile unsigned long long* publish, volatile unsigned int* seq_out,
+                                   unsigned int seq) {
     __shared__ unsigned int s_bad, s_seen, s_last;
     if (threadIdx.x == 0) {
         s_bad = 0u;
@@ -180,6 +181,9 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
         for (int i = (int)threadIdx.x; i < res_words; i += (int)blockDim.x)
             publish[i] = __hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // mismatch[] was updated by atomics in L2
         if (threadIdx.x == 0) *done = 0u;
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0 && seq_out != nullptr) *seq_out = seq;  // the host polls this word instead of waiting for the stream
     }
 }
 
@@ -334,7 +338,8 @@ __global__ __launch_bounds__(1024) void vote_count_local_kernel(const unsigned l
 // an impure bucket -- publishes res[9] = 2 and the host goes through the histogram all-reduce path, on every rank alike
 // (they all merged the same data).  A representative larger than prop_cap anywhere is reported as ref[0] = -1.
 __global__ __launch_bounds__(256) void vote_merge_kernel(const unsigned long long* gathered, int n_ranks, int seg_words,
-                                                          int res_words, int prop_cap, volatile unsigned long long* publish) {
+                                                          int res_words, int prop_cap, volatile unsigned long long* publish,
+                                                          volatile unsigned int* seq_out, unsigned int seq) {
     __shared__ int s_lead, s_simple, s_overflow;
     __shared__ unsigned long long s_votes, s_voters, s_err;
     if (threadIdx.x == 0) {
@@ -395,6 +400,9 @@ __global__ __launch_bounds__(256) void vote_merge_kernel(const unsigned long lon
         publish[8] = s_err;
         publish[9] = ok ? 1ull : 2ull;
     }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && seq_out != nullptr) *seq_out = seq;
 }
 
 }  // namespace rapid
