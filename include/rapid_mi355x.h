@@ -195,7 +195,8 @@ typedef struct rapid_round_result {
     int32_t membership_size;    /* N */
     int64_t votes_total;        /* receivers (all ranks) that proposed */
     int64_t votes_winner;       /* votes for the most popular proposal */
-    int32_t distinct_local;     /* distinct proposals among this rank's receivers */
+    int32_t distinct_local;     /* distinct proposals among this rank's receivers (when a quorum was confirmed without
+                                 * counting the other proposals: 1 = every voter voted for the winner, 2 = at least two) */
     int32_t reserved;
     int64_t config_id;          /* configuration the round ran in */
 } rapid_round_result;
@@ -377,7 +378,8 @@ int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, in
  * tables in LDS even when they fit (the compressed form of large populations is used instead), 256 = dictionary in
  * memory (the mode of populations too large even for that), 512 = sharded vote count always through the histogram
  * all-reduces (never the all-gather + merge of the ranks' local counts), 1024 = every receiver dealt to the workgroups
- * statically (no common pool for the last eighth), 32 = measurement only:
+ * statically (no common pool for the last eighth), 2048 = the vote count never uses the statistics the tally kernel gathers
+ * (always a counting pass), 32 = measurement only:
  * stream the records through the registers without tallying them (results are meaningless) */
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);
 /* testing aids for the sharded vote count (one GPU standing in for n ranks): the answer block this engine's voters

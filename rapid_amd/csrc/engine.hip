@@ -125,6 +125,7 @@ struct rapid_engine {
     bool index_ms_pending = false;
     const int* idxwork_clean_at = nullptr;  // the index work area is known to be all zero for this allocation and node count
     int idxwork_clean_n = -1;
+    bool tally_votes_valid = false;  // d_voteback holds the vote statistics of the last tally launch (tally_kernel.h: vote_res)
     bool stats_fresh = false;  // the statistics were zeroed by the index build of this very call
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // timing events, created once (no create / destroy per call, nothing to leak on an error path)
     DevBuf<unsigned short> d_dict, d_decl, d_adj_off, d_trank;
@@ -538,6 +539,10 @@ int launch_tally(rapid_engine* h) {
     // once a population is at least two rounds of the launch; testing knob bit 10: everything dealt statically.
     p.n_static = h->n_receivers;
     p.pool = nullptr;
+    // the words behind the launch's statistics rows: [0] = pool, [1..5] = vote accumulators (zeroed with the rows)
+    p.vote_acc = h->d_stats.p + (size_t)8 * (size_t)h->grid_blocks + 1;
+    p.vote_res = h->d_voteback.p;
+    h->tally_votes_valid = true;
     {
         const long long slots = (long long)h->grid_blocks * h->waves_per_block;
         const char* e = getenv("RAPID_POOL_EIGHTHS");  // measurement knob: size of the pool in eighths of the population
@@ -570,6 +575,7 @@ int prepare_tally(rapid_engine* h) {
     if (!h->streams_loaded) return fail(h, RAPID_ESTATE, "no alert streams loaded");
     HIPCHK(h, h->d_errflags.ensure(2));
     HIPCHK(h, h->d_stats.ensure(stats_words(h)));
+    HIPCHK(h, h->d_voteback.ensure((10 * 8 + ((size_t)h->max_cut + 1) * sizeof(int) + 7) / 8));  // launch_tally: vote_res
     h->stats_fresh = false;
     if (!h->index_valid) {
         int rc = build_round_index(h);  // also zeroes the error flags and the launch statistics / pool words
@@ -1258,13 +1264,16 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
     // Everything below is enqueued on the engine stream and read back with ONE synchronisation per salt:
     // histogram -> (all-reduce) -> winner -> min/max of the winning bucket -> (all-reduce) -> representative list
     // -> (all-reduce) -> element-wise verification -> (all-reduce).
+    bool from_tally_used = false;
     for (unsigned long long salt = 0; salt < 4; ++salt) {
+        from_tally_used = false;
         if (merged) {
+            h->tally_votes_valid = false;
             hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st,
                                h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
             hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * 64, 1024))), dim3(1024), 0, st,
                                h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, nullptr, 0, nullptr,
-                               nullptr, nullptr, 0u);
+                               nullptr, nullptr, 0u, 0, nullptr);
             NCCLCHK(h, ncclAllGather(d_res, h->d_gather.p, seg_words, ncclUint64, h->comm, st));  // the round's one collective
             hipLaunchKernelGGL(rapid::vote_merge_kernel, dim3(1), dim3(256), 0, st, h->d_gather.p, h->n_ranks, (int)seg_words,
                                (int)res_words, h->max_cut, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
@@ -1277,13 +1286,20 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
                 continue;
             }
         } else if (local) {
-            hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st,
-                               h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
+            // the tally kernel gathered the voters' statistics itself (tally_kernel.h: vote_acc): if they are unanimous -- the
+            // common round -- no counting pass runs at all; the verification below reads the representative's list in place
+            const bool from_tally = h->tally_votes_valid && salt == 0 && (h->force_exact & 2048) == 0;
+            h->tally_votes_valid = false;  // consumed: the verification below adds its counters to them
+            if (!from_tally)
+                hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st,
+                                   h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
+            from_tally_used = from_tally;
             hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * 64, 1024))), dim3(1024), 0, st,
                                h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, d_res,
                                (int)res_words, reinterpret_cast<unsigned int*>(d_res + 9),
                                reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
-                               reinterpret_cast<volatile unsigned int*>(h->d_mail) + 14, ++h->mail_seq);
+                               reinterpret_cast<volatile unsigned int*>(h->d_mail) + 14, ++h->mail_seq, from_tally ? 1 : 0,
+                               h->d_errflags.p);
         } else {
             HIPCHK(h, hipMemsetAsync(h->d_hist.p, 0, HB * 8, st));
             HIPCHK(h, hipMemsetAsync(h->d_mm.p, 0, 64, st));
@@ -1306,7 +1322,7 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
             if (h->comm) NCCLCHK(h, ncclAllReduce(d_ref, d_ref, ref_len, ncclInt32, ncclMax, h->comm, st));
             if (R)
                 hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(grid_for((long long)R * 64, 1024)), dim3(1024), 0, st, h->d_fp.p,
-                                   h->d_pcount.p, h->d_props.p, h->max_cut, R, h->d_mm.p, d_ref, d_mismatch, nullptr, 0, nullptr, nullptr, nullptr, 0u);
+                                   h->d_pcount.p, h->d_props.p, h->max_cut, R, h->d_mm.p, d_ref, d_mismatch, nullptr, 0, nullptr, nullptr, nullptr, 0u, 0, nullptr);
             if (h->comm) NCCLCHK(h, ncclAllReduce(d_mismatch, d_mismatch, 2, ncclUint64, ncclSum, h->comm, st));
             HIPCHK(h, hipMemcpyAsync(d_res + 4, h->d_mm.p, 16, hipMemcpyDeviceToDevice, st));
             HIPCHK(h, hipMemcpyAsync(d_res + 8, h->d_errflags.p, 8, hipMemcpyDeviceToDevice, st));
@@ -1315,6 +1331,16 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
         HIPCHK(h, hipGetLastError());
         if (local) {
             if ((rc = await_mail(h, 14, h->mail_seq))) return rc;
+            if (from_tally_used) {
+                // settled iff the candidate (the lowest voter's proposal) has a quorum, or every voter holds it, or nobody
+                // voted; otherwise the exact plurality count is owed: histogram pass, same salt again
+                const unsigned long long* q = reinterpret_cast<unsigned long long*>(h->h_mail + 64);
+                const unsigned long long votes = q[1], voters = q[2];
+                if (!(voters == 0ull || votes == voters || (long long)votes >= (long long)out->quorum) && q[6] == 0ull) {
+                    --salt;
+                    continue;
+                }
+            }
         } else if (!merged) {
             HIPCHK(h, hipStreamSynchronize(st));
         }
@@ -1346,6 +1372,7 @@ int rapid_debug_vote_segment(rapid_engine* h, void* out, int64_t cap_bytes, int6
     if (!out) return RAPID_OK;
     if (cap_bytes < *seg_bytes) return fail(h, RAPID_ECAPACITY, "segment needs %lld bytes", (long long)*seg_bytes);
     HIPCHK(h, h->d_voteback.ensure(seg_words));
+    h->tally_votes_valid = false;
     unsigned long long* const d_res = h->d_voteback.p;
     int* const d_ref = reinterpret_cast<int*>(d_res + res_words);
     const int R = h->n_receivers;
@@ -1355,7 +1382,7 @@ int rapid_debug_vote_segment(rapid_engine* h, void* out, int64_t cap_bytes, int6
     hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st, h->d_fp.p,
                        h->d_pcount.p, h->d_props.p, h->max_cut, R, 0ull, h->d_errflags.p, d_res, d_ref);
     hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * 64, 1024))), dim3(1024), 0, st, h->d_fp.p,
-                       h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_res + 6, nullptr, 0, nullptr, nullptr, nullptr, 0u);
+                       h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_res + 6, nullptr, 0, nullptr, nullptr, nullptr, 0u, 0, nullptr);
     HIPCHK(h, hipMemcpyAsync(out, d_res, seg_words * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     return RAPID_OK;

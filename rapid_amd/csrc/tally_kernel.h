@@ -131,6 +131,15 @@ struct TallyParams {
     // pool = nullptr: everything dealt statically.
     int n_static;
     unsigned int* pool;
+    // Fast-round vote statistics gathered while the proposals are written (R/FastPaxos.java:125-156 counts identical
+    // proposals): vote_acc[2] = voters, [3] = max of ~(index of a voter) (= ~lowest voter), [4] = finished workgroups
+    // ([0], [1] unused); all zero between launches.  The last workgroup turns them into vote_res[0..9] -- [0] = the lowest
+    // voter (0xFFFFFFFF: nobody voted), [2] = voters, the rest zero, in the layout vote_verify_kernel (vote_kernels.h)
+    // completes: it takes the lowest voter's proposal as the candidate and counts + verifies the voters that hold it,
+    // which settles every round in which that candidate has a quorum without a counting pass -- and zeroes them again.
+    // nullptr: not gathered.
+    unsigned long long* vote_acc;
+    unsigned long long* vote_res;
     int flags;                        // bit0: exact path only, bit3: careful path only (both for tests); bit5: stream only
 };
 
@@ -150,7 +159,7 @@ __host__ __device__ inline int tally_shared_bytes(int mode, int n_nodes, int n_t
     return tally_dict_bytes(mode, n_nodes, n_touched) + align16((n_adj + 1) * 4) + align16((n_hot + kDummySlots) * 2) + align16(n_hot * 4);
 }
 // per-workgroup statistics accumulator at the very end of the dynamic LDS segment
-constexpr int kBlockStatsBytes = 80;  // eight counters + the workgroup's claim counter
+constexpr int kBlockStatsBytes = 112;  // eight counters, the workgroup's claim counter, four vote accumulators
 __host__ __device__ inline int tally_wave_bytes(int n_slots) {
     return align16((n_slots + kDummySlots) * 4) + kScratchWords * 4 + kUndoCap * 4;
 }
@@ -474,6 +483,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         reinterpret_cast<unsigned long long*>(smem + shared_bytes + (int)(blockDim.x >> 6) * tally_wave_bytes(n_hot));
     unsigned int* const block_claims = reinterpret_cast<unsigned int*>(block_stats + 8);  // receivers claimed by this workgroup
     if (threadIdx.x < 8u) block_stats[threadIdx.x] = 0ull;
+    unsigned long long* const block_votes = block_stats + 10;  // [4], see TallyParams::vote_acc
+    if (threadIdx.x >= 16u && threadIdx.x < 20u) block_votes[threadIdx.x - 16u] = 0ull;
 #ifdef RAPID_PHASE_TIMERS
     if (threadIdx.x == 7u) block_stats[7] = ~0ull;
 #endif
@@ -1189,6 +1200,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             stream_store(p.num_proposals + r, s.proposal_count);
             stream_store(p.prop_count + r, count > p.prop_cap ? -1 : count);
             stream_store(p.fingerprint + r, fp);
+            if (count != 0 && p.vote_acc != nullptr) {  // this receiver votes (an oversized proposal is still a vote)
+                atomicAdd(&block_votes[2], 1ull);
+                atomicMax(&block_votes[3], ~(unsigned long long)(unsigned int)r);
+            }
 #else
             stream_store(p.emit_batch + r, emit_batch);
             // profiling build: cycles spent on this receiver, in total and per phase
@@ -1242,6 +1257,20 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         if (atomicAdd(&p.pool[1], 1u) == gridDim.x - 1u) {  // every other workgroup has made its last claim
             p.pool[0] = 0u;
             p.pool[1] = 0u;
+        }
+    }
+    if (threadIdx.x == 0 && p.vote_acc != nullptr) {
+        if (block_votes[2] != 0ull) {
+            atomicAdd(&p.vote_acc[2], block_votes[2]);
+            atomicMax(&p.vote_acc[3], block_votes[3]);
+        }
+        if (atomicAdd(&p.vote_acc[4], 1ull) == (unsigned long long)gridDim.x - 1ull) {  // the last workgroup: every other one has added its share
+            const unsigned long long voters = atomicAdd(&p.vote_acc[2], 0ull), repc = atomicAdd(&p.vote_acc[3], 0ull);
+            p.vote_res[0] = voters != 0ull ? (~repc & 0xFFFFFFFFull) : 0xFFFFFFFFull;
+            p.vote_res[1] = 0ull;
+            p.vote_res[2] = voters;
+            for (int i = 3; i < 10; ++i) p.vote_res[i] = 0ull;
+            for (int i = 0; i < 5; ++i) p.vote_acc[i] = 0ull;
         }
     }
     // p.stats = [gridDim.x][8], accumulated over launches; one plain read-modify-write per workgroup and counter

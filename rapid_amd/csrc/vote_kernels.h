@@ -138,7 +138,7 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
                                    int n_receivers, const unsigned long long* mm, const int* ref,
                                    unsigned long long* mismatch, const unsigned long long* res, int res_words,
                                    unsigned int* done, volatile unsigned long long* publish, volatile unsigned int* seq_out,
-                                   unsigned int seq) {
+                                   unsigned int seq, int rep_in_res, const unsigned int* tally_errors) {
     __shared__ unsigned int s_bad, s_seen, s_last;
     if (threadIdx.x == 0) {
         s_bad = 0u;
@@ -148,13 +148,32 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
     __syncthreads();
     const int r = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = (int)(threadIdx.x & 63u);
-    const bool voter = r < n_receivers && prop_count[r] != 0 && fp[r] == mm[0];
+    // The proposal the voters are compared with.  After a counting kernel: the winning bucket's only fingerprint mm[0] and
+    // the representative's list it copied out (ref[0] = size, ref[1..]).  rep_in_res -- no counting kernel ran, res[] came
+    // from the tally kernel (tally_kernel.h: vote_res): the CANDIDATE is the proposal of the lowest voter res[0], read in
+    // place; mismatch[1] then is the candidate's vote count, and if that is a quorum (N - floor((N-1)/4) > N/2 voters,
+    // R/FastPaxos.java:145-150) no other proposal can have one: the round is settled without a histogram.
+    int ref_n;
+    const int* ref_list;
+    unsigned long long cand;
+    bool have = true;
+    if (rep_in_res) {
+        const unsigned int rep = (unsigned int)res[0];
+        have = rep < (unsigned int)n_receivers;
+        cand = have ? fp[rep] : 0ull;
+        ref_n = have ? prop_count[rep] : 0;
+        ref_list = props + (long long)(have ? rep : 0u) * prop_cap;
+    } else {
+        cand = mm[0];
+        ref_n = ref[0];
+        ref_list = ref + 1;
+    }
+    const bool voter = have && r < n_receivers && prop_count[r] != 0 && fp[r] == cand;
     if (voter) {
-        const int ref_n = ref[0];
         bool bad = prop_count[r] != ref_n;
         if (!bad) {
             const int* mine = props + (long long)r * prop_cap;
-            for (int i = lane; i < ref_n; i += 64) bad |= mine[i] != ref[1 + i];
+            for (int i = lane; i < ref_n; i += 64) bad |= mine[i] != ref_list[i];
         }
         const unsigned long long any_bad = __ballot(bad);
         if (lane == 0) {
@@ -174,12 +193,23 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
     __syncthreads();
     if (publish != nullptr && s_last != 0u) {
         __threadfence();
-        int n = ref[0];
-        n = (n < 0 || n > prop_cap) ? 0 : n;
+        int n = (ref_n < 0 || ref_n > prop_cap) ? 0 : ref_n;
         volatile int* const pref = reinterpret_cast<volatile int*>(publish + res_words);
-        for (int i = (int)threadIdx.x; i < 1 + n; i += (int)blockDim.x) pref[i] = ref[i];
-        for (int i = (int)threadIdx.x; i < res_words; i += (int)blockDim.x)
-            publish[i] = __hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // mismatch[] was updated by atomics in L2
+        if (threadIdx.x == 0) pref[0] = ref_n;
+        for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) pref[1 + i] = ref_list[i];
+        for (int i = (int)threadIdx.x; i < res_words; i += (int)blockDim.x) {
+            unsigned long long v = __hip_atomic_load(&res[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // mismatch[] was updated by atomics in L2
+            if (i == 8 && tally_errors != nullptr) v = (unsigned long long)tally_errors[0];  // the tally kernel's sticky error word, final by now
+            if (rep_in_res) {  // complete the answer in the counting kernel's layout: votes of the candidate, its fingerprint
+                const unsigned long long votes = __hip_atomic_load(&res[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long voters = __hip_atomic_load(&res[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i == 1) v = votes;
+                if (i == 3) v = voters == 0ull ? 0ull : (votes == voters ? 1ull : 2ull);  // 2 = at least two proposals
+                if (i == 4) v = cand;
+                if (i == 5) v = ~cand;
+            }
+            publish[i] = v;
+        }
         if (threadIdx.x == 0) *done = 0u;
         __threadfence_system();
         __syncthreads();

@@ -139,7 +139,7 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
                   const unsigned int* pairs, int n_hot, int n_adj, int* emit_batch, int* num_proposals,
                   int* prop_count, unsigned long long* fingerprint, int* props, int prop_cap, unsigned long long* stats,
                   int flags, int waves, int grid, int tables_in_lds, unsigned long long seed, const unsigned int* tbits,
-                  const unsigned short* trank, const unsigned int* tent, int n_touched) {
+                  const unsigned short* trank, const unsigned int* tent, int n_touched, unsigned long long* vote_res_out) {
     // tables_in_lds: 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS
     const int lds = rapid::tally_shared_bytes(tables_in_lds, n_nodes, n_touched, n_hot, n_adj) + waves * rapid::tally_wave_bytes(n_hot) +
                     rapid::kBlockStatsBytes;
@@ -194,6 +194,11 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     pool[0] = pool[1] = 0u;
     p.n_static = n_receivers;
     p.pool = nullptr;
+    static unsigned long long vote_acc[5], vote_res[10];
+    for (int i = 0; i < 5; ++i) vote_acc[i] = 0ull;
+    for (int i = 0; i < 10; ++i) vote_res[i] = 0xDEADull;
+    p.vote_acc = vote_acc;
+    p.vote_res = vote_res;
     if ((flags & 512) != 0 && n_receivers > grid * waves) {
         p.n_static = grid * waves;
         p.pool = pool;
@@ -211,6 +216,10 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
             default: run(rapid::tally_population_kernel<rapid::kDictCompressed, true>); break;
         }
     }
+    for (int i = 0; i < 5; ++i)
+        if (vote_acc[i] != 0ull) return -8;  // the last workgroup leaves the vote accumulators zeroed, too
+    if (vote_res_out != nullptr)
+        for (int i = 0; i < 10; ++i) vote_res_out[i] = vote_res[i];
     if (pool[0] != 0u || pool[1] != 0u) return -7;  // the last workgroup must leave the pool words zeroed for the next launch
     return error_flags[0] != 0u ? -1 : 0;
 }

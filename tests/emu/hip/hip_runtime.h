@@ -121,6 +121,12 @@ inline unsigned atomicAnd(unsigned* p, unsigned v) {
     *p = o & v;
     return o;
 }
+inline void __threadfence() {}
+inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {
+    const unsigned long long o = *p;
+    if (v > o) *p = v;
+    return o;
+}
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
     unsigned long long o = *p;
     *p = o + v;

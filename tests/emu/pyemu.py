@@ -115,12 +115,18 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     fp = np.zeros(R, dtype=np.uint64)
     props = np.full((R, prop_cap), -1, dtype=np.int32)
     stats = np.zeros((grid, 8), dtype=np.uint64)  # one row per workgroup, as the kernel writes them
+    vote_res = np.zeros(10, dtype=np.uint64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     rc = L_.emu_tally_run(p(raw), C.c_ulonglong((raw.nbytes // 16) * 16), p(rec_off), R, n_nodes, K, H, L, C.c_longlong(cfg_id),
                           p(ix["dict"]), p(ix["decl"]), p(ix["node_of_slot"]), p(ix["adj_off"]), p(ix["adj"]),
                           ix["n_hot"], ix["n_adj"], p(emit), p(nprop), p(pcount), p(fp), p(props), prop_cap, p(stats),
                           force_exact, waves, grid, tables_in_lds, C.c_ulonglong(seed), p(ix["tbits"]), p(ix["trank"]), p(ix["tent"]),
-                          ix["n_touched"])
+                          ix["n_touched"], p(vote_res))
+    # the vote statistics the kernel gathers next to the proposals (TallyParams::vote_res) against the results themselves
+    voters = np.flatnonzero(pcount != 0)
+    assert int(vote_res[2]) == len(voters), (vote_res, len(voters))
+    assert int(vote_res[0]) == (int(voters[0]) if len(voters) else 0xFFFFFFFF), vote_res
+    assert not vote_res[[1, 3, 4, 5, 6, 7, 9]].any(), vote_res
     if declared is not None:
         assert rc in (0, -1), rc
         return emit, nprop, pcount, fp, props, stats.sum(axis=0), rc == 0

@@ -695,8 +695,8 @@ def test_vote_count_through_a_one_rank_communicator(E):
 
     for case in ("crash", "churn", "noquorum", "conflict"):
         a, sc = run(False, case)
-        for knob in (0, 512):
-            b, _ = run(True, case, knob)
+        for with_comm, knob in ((True, 0), (True, 512), (False, 2048)):  # 2048: count without the statistics the tally kernel gathers
+            b, _ = run(with_comm, case, knob)
             for k in ("decided", "cut_size", "quorum", "votes_total", "votes_winner", "membership", "cut", "new_cfg"):
                 assert a.get(k) == b.get(k), (case, knob, k, a.get(k), b.get(k))
             assert all(np.array_equal(x, y) for x, y in zip(a["results"], b["results"])), (case, knob)
