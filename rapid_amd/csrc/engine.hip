@@ -1156,8 +1156,15 @@ int rapid_sim_results(rapid_engine* h, int32_t* emit_batch, int32_t* num_proposa
 
 static void sort_ring0(rapid_engine* h, std::vector<int>& v) {
     // R/MembershipService.java:346-348: sorted(membershipView.getRingZeroComparator()) -- signed key compare
+    // (keys gathered first: the comparisons then run on a few KB instead of chasing an 80 KB table per compare; equal keys
+    // keep the order they came in, ascending node index, like a stable sort of the list)
     const long long* k0 = h->h_keys.data();
-    std::stable_sort(v.begin(), v.end(), [k0](int a, int b) { return k0[a] < k0[b]; });
+    std::vector<std::pair<long long, int>> kv(v.size());
+    for (size_t i = 0; i < v.size(); ++i) kv[i] = {k0[v[i]], (int)i};
+    std::sort(kv.begin(), kv.end());
+    std::vector<int> out(v.size());
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[(size_t)kv[i].second];
+    v.swap(out);
 }
 
 int rapid_sim_proposal(rapid_engine* h, int32_t receiver, int32_t* out, int32_t cap, int32_t* n_out) {

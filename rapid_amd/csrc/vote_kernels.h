@@ -183,16 +183,26 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (s_bad) atomicAdd(&mismatch[0], (unsigned long long)s_bad);
-        if (s_seen) atomicAdd(&mismatch[1], (unsigned long long)s_seen);
-        if (publish != nullptr) {
-            __threadfence();
-            s_last = atomicAdd(done, 1u) == gridDim.x - 1u ? 1u : 0u;
+        if (publish == nullptr) {
+            if (s_bad) atomicAdd(&mismatch[0], (unsigned long long)s_bad);
+            if (s_seen) atomicAdd(&mismatch[1], (unsigned long long)s_seen);
+        } else {
+            // ONE atomic per workgroup: finished workgroups << 44 | offenders << 22 | verified voters (a rank holds at most
+            // 262,144 receivers on this path); whoever brings the count to gridDim.x has the totals in its hands -- nothing the
+            // other workgroups WROTE is read by it, so no fence is needed either
+            unsigned long long* const packed = reinterpret_cast<unsigned long long*>(done);
+            const unsigned long long mine = (1ull << 44) | ((unsigned long long)s_bad << 22) | (unsigned long long)s_seen;
+            const unsigned long long total = atomicAdd(packed, mine) + mine;
+            if ((total >> 44) == (unsigned long long)gridDim.x) {
+                s_last = 1u;
+                mismatch[0] = (total >> 22) & 0x3FFFFFull;
+                mismatch[1] = total & 0x3FFFFFull;
+                *packed = 0ull;
+            }
         }
     }
     __syncthreads();
     if (publish != nullptr && s_last != 0u) {
-        __threadfence();
         int n = (ref_n < 0 || ref_n > prop_cap) ? 0 : ref_n;
         volatile int* const pref = reinterpret_cast<volatile int*>(publish + res_words);
         if (threadIdx.x == 0) pref[0] = ref_n;
@@ -210,7 +220,6 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
             }
             publish[i] = v;
         }
-        if (threadIdx.x == 0) *done = 0u;
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0 && seq_out != nullptr) *seq_out = seq;  // the host polls this word instead of waiting for the stream
