@@ -1275,15 +1275,21 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
     for (unsigned long long salt = 0; salt < 4; ++salt) {
         from_tally_used = false;
         if (merged) {
+            // this rank's answer block: candidate, its verified votes, the rank's voters, the candidate's list -- from the
+            // statistics the tally kernel gathered when they are fresh (no counting pass), else from the counting kernel
+            const bool from_tally = h->tally_votes_valid && salt == 0 && (h->force_exact & 2048) == 0;
             h->tally_votes_valid = false;
-            hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st,
-                               h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
+            if (!from_tally)
+                hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st,
+                                   h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
+            // (published "to" the block itself: the last workgroup completes res[] and, from_tally, copies the list into ref[])
             hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * 64, 1024))), dim3(1024), 0, st,
-                               h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, nullptr, 0, nullptr,
-                               nullptr, nullptr, 0u, 0, nullptr);
+                               h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, d_res,
+                               (int)res_words, reinterpret_cast<unsigned int*>(d_res + 9), reinterpret_cast<volatile unsigned long long*>(d_res),
+                               nullptr, 0u, from_tally ? 1 : 0, h->d_errflags.p);
             NCCLCHK(h, ncclAllGather(d_res, h->d_gather.p, seg_words, ncclUint64, h->comm, st));  // the round's one collective
             hipLaunchKernelGGL(rapid::vote_merge_kernel, dim3(1), dim3(256), 0, st, h->d_gather.p, h->n_ranks, (int)seg_words,
-                               (int)res_words, h->max_cut, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
+                               (int)res_words, h->max_cut, (long long)out->quorum, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
                                reinterpret_cast<volatile unsigned int*>(h->d_mail) + 14, ++h->mail_seq);
             HIPCHK(h, hipGetLastError());
             if ((rc = await_mail(h, 14, h->mail_seq))) return rc;
@@ -1406,7 +1412,7 @@ int rapid_debug_vote_merge(rapid_engine* h, const void* segments, int32_t n_rank
     hipStream_t st = h->stream;
     HIPCHK(h, hipMemcpyAsync(h->d_gather.p, segments, seg_words * 8 * (size_t)n_ranks, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(rapid::vote_merge_kernel, dim3(1), dim3(256), 0, st, h->d_gather.p, n_ranks, (int)seg_words, (int)res_words,
-                       h->max_cut, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64), nullptr, 0u);
+                       h->max_cut, (long long)out->quorum, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64), nullptr, 0u);
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
     const unsigned long long* hres = reinterpret_cast<const unsigned long long*>(h->h_mail + 64);

@@ -367,18 +367,22 @@ __global__ __launch_bounds__(1024) void vote_count_local_kernel(const unsigned l
     if (t == 0) ref[0] = n;
 }
 
-// Populations sharded over ranks: every rank counts its own voters (vote_count_local_kernel + vote_verify_kernel, as for a
-// population it holds alone), ONE all-gather moves the ranks' answers -- res[res_words] + ref[1 + prop_cap], `seg_words`
-// 64-bit words per rank -- to everybody, and this kernel (one workgroup, on every rank, over identical input) merges them.
-// The merge is exact whenever every rank's voters are unanimous among themselves (one non-empty bucket, pure, every
-// voter verified element-wise against the rank's representative) and the ranks' representatives hold the same list:
-// then the cluster has ONE proposal, its votes are the sum of the ranks' (R/FastPaxos.java:141-150), and the answer is
-// published to host-mapped memory in the single-rank format with res[9] = 1.  Anything else -- two proposals anywhere,
-// an impure bucket -- publishes res[9] = 2 and the host goes through the histogram all-reduce path, on every rank alike
-// (they all merged the same data).  A representative larger than prop_cap anywhere is reported as ref[0] = -1.
+// Populations sharded over ranks: every rank settles its own voters first -- the candidate proposal (the winning bucket's
+// after a counting kernel, the lowest voter's when the statistics came from the tally kernel), its verified vote count
+// res[1] = res[7], the rank's voters res[2] -- ONE all-gather moves the ranks' answers (res[res_words] + ref[1 + prop_cap],
+// `seg_words` 64-bit words per rank) to everybody, and this kernel (one workgroup, on every rank, over identical input)
+// merges them.  The merge is exact when every voting rank's candidate is the same proposal (same fingerprint, pure, every
+// one of its voters verified element-wise, lists equal element for element across ranks) and either that proposal has a
+// quorum -- then no other can (quorum > N / 2, R/FastPaxos.java:145-150), whatever the remaining voters hold -- or every
+// voter of every rank holds it: votes = the sum of the ranks' (R/FastPaxos.java:141-150).  The answer is published to
+// host-mapped memory in the single-rank format with res[9] = 1.  Anything else -- candidates differ between ranks, no
+// quorum among several proposals, an impure bucket -- publishes res[9] = 2 and the host goes through the histogram
+// all-reduce path, on every rank alike (they all merged the same data).  A representative larger than prop_cap anywhere
+// is reported as ref[0] = -1.
 __global__ __launch_bounds__(256) void vote_merge_kernel(const unsigned long long* gathered, int n_ranks, int seg_words,
-                                                          int res_words, int prop_cap, volatile unsigned long long* publish,
-                                                          volatile unsigned int* seq_out, unsigned int seq) {
+                                                          int res_words, int prop_cap, long long quorum,
+                                                          volatile unsigned long long* publish, volatile unsigned int* seq_out,
+                                                          unsigned int seq) {
     __shared__ int s_lead, s_simple, s_overflow;
     __shared__ unsigned long long s_votes, s_voters, s_err;
     if (threadIdx.x == 0) {
@@ -389,9 +393,9 @@ __global__ __launch_bounds__(256) void vote_merge_kernel(const unsigned long lon
             const int* ref = reinterpret_cast<const int*>(res + res_words);
             err |= res[8];
             voters += res[2];
-            if (res[1] == 0ull) continue;  // nobody on this rank proposed
+            if (res[2] == 0ull) continue;  // nobody on this rank proposed
             votes += res[1];
-            if (res[3] != 1ull || res[4] != ~res[5] || res[6] != 0ull || res[7] != res[1] || res[2] != res[1]) simple = 0;
+            if (res[1] == 0ull || res[4] != ~res[5] || res[6] != 0ull || res[7] != res[1]) simple = 0;
             if (ref[0] < 0) overflow = 1;
             if (lead < 0) {
                 lead = k;
@@ -400,6 +404,7 @@ __global__ __launch_bounds__(256) void vote_merge_kernel(const unsigned long lon
                 simple = 0;
             }
         }
+        if (!((long long)votes >= quorum || votes == voters)) simple = 0;  // several proposals and no quorum: the exact plurality is owed
         s_lead = lead;
         s_simple = simple;
         s_overflow = overflow;
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(256) void vote_merge_kernel(const unsigned long lon
     if (s_simple != 0 && s_overflow == 0) {
         for (int k = lead + 1; k < n_ranks; ++k) {
             const unsigned long long* res = gathered + (long long)k * seg_words;
-            if (res[1] == 0ull) continue;
+            if (res[2] == 0ull) continue;
             const int* ref = reinterpret_cast<const int*>(res + res_words);
             for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) differ |= ref[1 + i] != lref[1 + i];
         }
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(256) void vote_merge_kernel(const unsigned long lon
         publish[0] = lead < 0 ? 0ull : lres[0];
         publish[1] = s_votes;
         publish[2] = s_voters;
-        publish[3] = lead < 0 ? 0ull : 1ull;
+        publish[3] = lead < 0 ? 0ull : (s_votes == s_voters ? 1ull : 2ull);
         publish[4] = lead < 0 ? 0ull : lres[4];
         publish[5] = lead < 0 ? ~0ull : lres[5];
         publish[6] = 0ull;

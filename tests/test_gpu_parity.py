@@ -674,6 +674,12 @@ def test_vote_count_through_a_one_rank_communicator(E):
             sc = S.build_churn_scenario(obs, member, cfg, 25, 0, H, L, materialise=False)
             recs, off, nb = S.deliver(sc.batches, sc.receivers, 77, loss=0.03)
             sc.records, sc.rec_off = recs, off
+        elif case == "dissent":  # ten receivers saw a different fault set: their votes do not stop the quorum of the others
+            sc = S.build_churn_scenario(obs, member, cfg, 20, 0, H, L)
+            sc3 = S.build_churn_scenario(obs, member, cfg, 20, 0, H, L, seed_fault=5)
+            b = int(sc3.rec_off[10])
+            sc.rec_off = np.concatenate([sc.rec_off, sc3.rec_off[1:11] + sc.rec_off[-1]])
+            sc.records = np.concatenate([sc.records, sc3.records[:b]])
         else:  # two groups of receivers see two different fault sets: two proposals, the merge must hand over to the general count
             sc = S.build_churn_scenario(obs, member, cfg, 20, 0, H, L)
             sc3 = S.build_churn_scenario(obs, member, cfg, 20, 0, H, L, seed_fault=5)
@@ -693,7 +699,7 @@ def test_vote_count_through_a_one_rank_communicator(E):
         eng.close()
         return out, sc
 
-    for case in ("crash", "churn", "noquorum", "conflict"):
+    for case in ("crash", "churn", "noquorum", "conflict", "dissent"):
         a, sc = run(False, case)
         for with_comm, knob in ((True, 0), (True, 512), (False, 2048)):  # 2048: count without the statistics the tally kernel gathers
             b, _ = run(with_comm, case, knob)
@@ -703,6 +709,8 @@ def test_vote_count_through_a_one_rank_communicator(E):
         assert a["decided"] == (0 if case in ("noquorum", "conflict") else 1)
         if case == "conflict":
             assert (a["votes_total"], a["votes_winner"]) == (1100, 700)
+        if case == "dissent":
+            assert a["votes_total"] == a["votes_winner"] + 10 == len(sc.rec_off) - 1
 
 
 def test_sharded_vote_count_merges_the_ranks_local_answers(E):
@@ -710,8 +718,9 @@ def test_sharded_vote_count_merges_the_ranks_local_answers(E):
     for three ranks: the receivers of a round are cut into three shards, each shard is tallied and counted on its own
     (rapid_debug_vote_segment = what the rank would contribute), and the merged answer must be the answer of the whole
     population counted at once (R/FastPaxos.java:141-150: votes for the one proposal = sum over the ranks).  A shard
-    nobody proposes on contributes nothing; a round whose voters disagree -- within a shard or between shards -- is
-    recognised (status 2: the general histogram count would run) instead of being merged.  (Deliveries lost on the way do
+    nobody proposes on contributes nothing; dissenters do not matter once the common candidate has a quorum; a round
+    whose shards hold different candidates, or several proposals without a quorum, is recognised (status 2: the general
+    histogram count would run) instead of being merged.  (Deliveries lost on the way do
     not make voters disagree: a receiver that misses a batch never reaches H for its subjects and does not vote at all.)"""
     n, K, H, L = 2000, 10, 9, 4
     pop = S.Population.make(n)
@@ -785,4 +794,21 @@ def test_sharded_vote_count_merges_the_ranks_local_answers(E):
     assert status == 2
     rr, _ = whole(Mixed)  # (what the general count says about that round: the larger group wins, without a quorum)
     assert (rr.decided, rr.votes_total, rr.votes_winner) == (0, 1100, 600)
+    # dissenters do not stop a merge once the candidate has a quorum: ten receivers that saw the other fault set sit at the
+    # END of the last shard (the shard's candidate -- the proposal its lowest voter or its winning bucket holds -- is the
+    # cluster's); at the FRONT of a shard they become that shard's candidate when the statistics come from the tally
+    # kernel, which the merge reports as a disagreement (status 2) -- with the counting kernel the shard's plurality wins
+    rc, oc = shard(sc3.records, sc3.rec_off, 0, 10)
+
+    class Tail:
+        records = np.concatenate([sc.records, rc])
+        rec_off = np.concatenate([sc.rec_off, oc[1:] + sc.rec_off[-1]])
+        batches = Mixed.batches
+
+    segs_t = segments_of(Tail, [0, R // 3, R // 3 + 700, R + 10])
+    status, rr = sim.merge_vote_segments(segs_t)
+    assert status == 1 and (rr.decided, rr.votes_winner, rr.votes_total, rr.cut_size) == (1, R, R + 10, rr0.cut_size)
+    assert sim.decided_cut() == cut0
+    rr, cut = whole(Tail)  # the single-population count of the same round agrees
+    assert (rr.decided, rr.votes_winner, rr.votes_total) == (1, R, R + 10) and cut == cut0
     eng.close()
