@@ -37,7 +37,9 @@ for tag, declare in (("filter_per_delivery", False), ("alert_set_declared", True
         sim.set_alert_set(sc.batches.recs, trust_copies=True)
     ms = min(sim.time_tally(reps) for _ in range(2))
     info = sim.index_info()
+    res_b = 8 if declare else 16  # resident bytes per record the kernel reads (core only / core + configuration id)
     out[tag] = {"kernel_ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1), "frac_of_8TBps": round(nbytes / ms / 1e6 / 8000, 4),
+                "resident_GBps": round(res_b * len(records) / ms / 1e6, 1), "resident_frac_of_8TBps": round(res_b * len(records) / ms / 1e6 / 8000, 4),
                 "dict_mode": info["dict_mode"], "waves_per_workgroup": info["waves_per_workgroup"],
                 "index_build_ms": round(info["index_build_ms"], 4)}
 t = time.perf_counter()

@@ -51,6 +51,7 @@ for rnd in range(rounds):
                       "joined": len(sc.joiners), "proposing": int((emit >= 0).sum()), "votes_winner": int(rr.votes_winner),
                       "kernel_ms": round(kern_ms, 4), "kernel_records_per_s": round(len(sc.records) / kern_ms * 1e3, 1),
                       "kernel_frac_of_8TBps": round(20 * len(sc.records) / kern_ms / 1e6 / 8000, 4),
+                      "kernel_resident_frac_of_8TBps": round(16 * len(sc.records) / kern_ms / 1e6 / 8000, 4),
                       "round_ms": round(round_ms, 3), "round_records_per_s": round(len(sc.records) / round_ms * 1e3, 1),
                       "apply_cut_ms": round(apply_ms, 3), "dict_mode": info["dict_mode"], "hot_subjects": info["hot_subjects"],
                       "q4_at_risk": at_risk, "config_id": int(new_cfg)}), flush=True)
