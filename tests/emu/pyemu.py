@@ -71,6 +71,8 @@ def build_round_index(records, n_nodes, K, L, obs, member):
     tn = np.flatnonzero(touched)
     tent = ((decl[tn].astype(np.uint32) << 16) | (dict_[tn].astype(np.uint32) & 0x3FFF)).astype(np.uint32)
     tent = np.concatenate([tent, np.zeros(1, dtype=np.uint32)])
+    pad = np.zeros(8, dtype=np.uint16)  # the kernel stages both tables 16 bytes at a time: allocated with slack, as on the device
+    dict_, decl = np.concatenate([dict_.astype(np.uint16), pad]), np.concatenate([np.asarray(decl).astype(np.uint16), pad])
     return dict(dict=dict_, decl=decl, tbits=tbits, trank=trank, tent=tent, n_touched=len(tn), node_of_slot=np.concatenate([node_of_slot, [0]]).astype(np.int32), adj_off=adj_off,
                 adj=adj, n_hot=n_hot, n_adj=len(pairs))
 

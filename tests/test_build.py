@@ -32,3 +32,19 @@ def test_every_other_kernel_of_the_path_is_scratch_free_too():
     assert len(ours) >= 20
     spilling = {k: v["ScratchSize [bytes/lane]"] for k, v in ours.items() if v.get("ScratchSize [bytes/lane]", 0) != 0}
     assert not spilling, spilling
+
+
+def test_register_allocation_of_the_tally_kernel_is_the_measured_one():
+    """A canary, not a law: edits far from the window loop (the table-staging code, twice in round 2) have changed the
+    register allocation and schedule of the whole kernel and with it its speed by 20-30 % -- once through spills, once
+    with no spill at all (89 -> 93 VGPRs, 0.214 -> 0.285 ms on C3b) -- while every parity test stayed green.  These are the
+    counts of the build whose timings are in profiles/r02_*; if they move, time the tally kernel on a GPU
+    (scripts/pool_ab.py prints it in seconds) before accepting the new numbers here."""
+    res = resources()
+    got = {}
+    for name, r in res.items():
+        if "tally_population_kernel" in name:
+            mode = name.split("tally_population_kernelILi")[1][0]
+            trusted = "Lb1E" in name
+            got[(int(mode), trusted)] = r["VGPRs"]
+    assert got == {(0, False): 125, (0, True): 99, (1, False): 116, (1, True): 89, (2, False): 125, (2, True): 98}, got
