@@ -155,8 +155,12 @@ __host__ __device__ inline int tally_dict_bytes(int mode, int n_nodes, int n_tou
     if (mode == kDictCompressed) return align16(((n_nodes + 31) / 32) * 4) + align16(((n_nodes + 31) / 32) * 2) + align16(n_touched * 4);
     return 0;
 }
+// slot -> node (read once per proposed node, when a receiver's proposal is written) stays in memory when a round has so
+// many hot subjects that the LDS is better spent on receivers: C5's ~15,000 hot subjects per round at N = 10^6
+constexpr int kSlotNodesInLdsMax = 4096;
 __host__ __device__ inline int tally_shared_bytes(int mode, int n_nodes, int n_touched, int n_hot, int n_adj) {
-    return tally_dict_bytes(mode, n_nodes, n_touched) + align16((n_adj + 1) * 4) + align16((n_hot + kDummySlots) * 2) + align16(n_hot * 4);
+    return tally_dict_bytes(mode, n_nodes, n_touched) + align16((n_adj + 1) * 4) + align16((n_hot + kDummySlots) * 2) +
+           (n_hot <= kSlotNodesInLdsMax ? align16(n_hot * 4) : 0);
 }
 // per-workgroup statistics accumulator at the very end of the dynamic LDS segment
 constexpr int kBlockStatsBytes = 112;  // eight counters, the workgroup's claim counter, four vote accumulators
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             if (i < p.idx.n_adj) l_pairs[1 + i] = p.idx.pairs[i];
             if (i < n_hot) {
                 l_smask[i] = p.idx.smask[i];
-                l_nos[i] = p.idx.node_of_slot[i];
+                if (n_hot <= kSlotNodesInLdsMax) l_nos[i] = p.idx.node_of_slot[i];
             } else if (i < n_hot + kDummySlots) {
                 l_smask[i] = 0;
             }
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     }
     const unsigned int* const pairs = l_pairs;
     const unsigned short* const smask = l_smask;
-    const int* const node_of_slot = l_nos;
+    const bool nos_in_lds = n_hot <= kSlotNodesInLdsMax;  // (two typed pointers, not one generic one: a flat load would cost the precise wait counts)
     // The launch statistics are summed per workgroup in LDS and stored once per workgroup: thousands of waves adding to
     // the same eight global words at the end of their lives queue up behind each other in one L2 channel -- measured:
     // 0.13 ms of a 0.63 ms kernel, and every stream that crosses that channel waits with them.
@@ -1181,7 +1185,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 const unsigned long long mk = wave_ballot(take);
                 const int idx = count + __popcll(mk & lanes_lt(lane));
                 if (take) {
-                    const int node = node_of_slot[i];
+                    const int node = nos_in_lds ? l_nos[i] : p.idx.node_of_slot[i];
                     if (idx < p.prop_cap) stream_store(out + idx, node);
                     fp += mix64((unsigned long long)node);
                 }

@@ -19,7 +19,7 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 n_rx = int(sys.argv[3]) if len(sys.argv) > 3 else 4000
 K, H, L = 10, 9, 4
 pop = S.Population.make(n_mem + int(0.006 * n_mem * rounds) + 64)
-eng = E.Engine(n_max=pop.n, K=K, H=H, L=L)
+eng = E.Engine(n_max=pop.n, K=K, H=H, L=L, max_cut=max(4096, int(0.02 * n_mem)))  # a round's cut: ~1.5 % of the members
 view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo, members=list(range(n_mem)))
 st = S.StreamingChurn(H, L, receivers_per_round=n_rx)
 guard = E.ObserverCacheGuard()

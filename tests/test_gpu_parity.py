@@ -812,3 +812,423 @@ def test_sharded_vote_count_merges_the_ranks_local_answers(E):
     rr, cut = whole(Tail)  # the single-population count of the same round agrees
     assert (rr.decided, rr.votes_winner, rr.votes_total) == (1, R, R + 10) and cut == cut0
     eng.close()
+
+
+def test_streams_handed_over_in_device_memory(E):
+    """rapid_sim_load_streams_device: the 20-byte records already sit in device memory (as a producer on the same GPU
+    would leave them; here allocated through the HIP runtime the library itself uses) -- split into the engine's resident
+    arrays by the same pass as the host form, with the same results; the record buffer may be released right after the
+    call, the offsets stay borrowed."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes, hip.hipMemcpy.argtypes, hip.hipFree.argtypes = [C.POINTER(C.c_void_p), C.c_size_t], [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int], [C.c_void_p]
+
+    def to_device(a):
+        a = np.ascontiguousarray(a)
+        ptr = C.c_void_p()
+        assert hip.hipMalloc(C.byref(ptr), max(a.nbytes, 16)) == 0
+        assert hip.hipMemcpy(ptr, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0  # hipMemcpyHostToDevice, synchronous
+        return ptr
+
+    n, K, H, L = 1500, 10, 9, 4
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_churn_scenario(obs, member, cfg, 15, 0, H, L)
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(sc.records, sc.rec_off)
+    sim.tally()
+    want = [a.copy() for a in sim.results()]
+    rr0 = sim.count_votes()
+    raw = np.ascontiguousarray(sc.records).view(np.uint8).reshape(-1)
+    d_rec, d_off = to_device(raw), to_device(np.ascontiguousarray(sc.rec_off, dtype=np.int64))
+    sim.load_streams_device(d_rec.value, raw.nbytes, d_off.value, len(sc.rec_off) - 1)
+    assert hip.hipFree(d_rec) == 0  # borrowed for the call only
+    sim.set_alert_set(sc.batches.recs)
+    sim.tally()
+    got = sim.results()
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    rr = sim.count_votes()
+    assert (rr.decided, rr.votes_winner, rr.cut_size) == (rr0.decided, rr0.votes_winner, rr0.cut_size) and rr.decided == 1
+    eng.close()
+    assert hip.hipFree(d_off) == 0
+
+
+
+def test_declared_alert_set_that_does_not_cover_the_streams_is_rejected(E):
+    """rapid_sim_set_alert_set is a promise the engine checks: a delivered report about a subject (or ring of a cold
+    subject) missing from the declared set -> RAPID_EINVAL at the next read of results, not silently different cuts; a set
+    from another configuration is simply not trusted (per-delivery filter), and an honest set changes nothing."""
+    n, K, H, L = 2000, 10, 9, 4
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_scenario("C2", subj, cfg, n=n, f=20, H=H, L=L)
+    sim, want = run_population(E, eng, sc.records, sc.rec_off)
+    # honest declaration
+    sim, res = run_population(E, eng, sc.records, sc.rec_off, alert_set=sc.batches.recs)
+    assert sim.index_info()["alerts_prevalidated"] == 1 and all(np.array_equal(a, b) for a, b in zip(want, res))
+    # every alert about one faulty subject withheld from the set
+    short = sc.batches.recs[sc.batches.recs["dst"] != sc.faulty[3]]
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(sc.records, sc.rec_off)
+    sim.set_alert_set(short, trust_copies=True)
+    sim.tally()
+    with pytest.raises(E.IllegalArgumentException):
+        sim.results()
+    with pytest.raises(E.IllegalArgumentException):
+        sim.count_votes()
+    # ... with or without the caller vouching for the deliveries: the index simply was not built for that subject
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(sc.records, sc.rec_off)
+    sim.set_alert_set(short)
+    sim.tally()
+    with pytest.raises(E.IllegalArgumentException):
+        sim.results()
+    # a delivered record with the wrong status for its subject (an UP alert about a member), set otherwise honest
+    bad = sc.records.copy()
+    k = int(np.flatnonzero(np.isin(bad["dst"], sc.faulty))[5])
+    bad["status"][k] = S.UP
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(bad, sc.rec_off)
+    sim.set_alert_set(sc.batches.recs, trust_copies=True)
+    sim.tally()
+    with pytest.raises(E.IllegalArgumentException):
+        sim.results()
+    # the same streams without the promise (index from the set, filter per delivery) and without a declaration: the filter
+    # drops that record, as the reference does
+    sim, res2b = run_population(E, eng, bad, sc.rec_off, alert_set=sc.batches.recs, trust=False)
+    sim, res2 = run_population(E, eng, bad, sc.rec_off)
+    assert all(np.array_equal(a, b) for a, b in zip(res2, res2b))
+    fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, bad, sc.rec_off, nthreads=8)
+    assert np.array_equal(res2[0], fe) and np.array_equal(res2[2], np.diff(fo))
+    # a set stamped with another configuration id is not trusted at all: same results as without it
+    stale = sc.batches.recs.copy()
+    stale["cfg_id"] = cfg + 1
+    sim, res3 = run_population(E, eng, sc.records, sc.rec_off, alert_set=stale)
+    assert sim.index_info()["alerts_prevalidated"] == 0 and all(np.array_equal(a, b) for a, b in zip(want, res3))
+
+
+# ------------------------------------------------------------- the dictionary-in-memory instantiations (C4's mode)
+@pytest.mark.parametrize("name,n,f,K,H,L", [("C2", 2000, 20, 10, 9, 4), ("C3b", 1500, 40, 10, 9, 4)])
+def test_tables_in_memory_mode_vs_faithful_oracle(E, name, n, f, K, H, L):
+    """Populations whose plain node -> slot tables do not fit the LDS (N >~ 30,000) run the tally kernel with the
+    compressed tables (bitmap + rank) in LDS, and beyond that with the dictionary in memory.  Knobs 128 / 256 force these
+    modes at a size the faithful oracle can check: both instantiations (deliveries vouched for / per-delivery filter) of
+    both modes must give the oracle's results."""
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    reg, oview = oracle_view(pop, K)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_scenario(name, subj, cfg, n=n, f=f, H=H, L=L)
+    rx = np.arange(0, len(sc.receivers), max(1, len(sc.receivers) // 150))
+    sub_off = np.zeros(len(rx) + 1, dtype=np.int64)
+    parts = []
+    for i, r in enumerate(rx):
+        parts.append(sc.records[sc.rec_off[r]:sc.rec_off[r + 1]])
+        sub_off[i + 1] = sub_off[i] + len(parts[-1])
+    oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, np.concatenate(parts), sub_off, nthreads=8)
+    want_fp = proposal_fingerprints(oo, op, oe >= 0)
+    sim0, ref = run_population(E, eng, sc.records, sc.rec_off)
+    assert sim0.index_info()["dict_mode"] == 1
+    # 128: compressed tables in LDS, 256: dictionary in memory; alone: the pre-validated instantiation (every delivered alert
+    # passes the filter); | 64: per-delivery filter; | 1: exact path
+    for mode_knob, mode in ((128, 2), (256, 0)):
+      for kw in (dict(force_exact=mode_knob), dict(force_exact=mode_knob | 64), dict(force_exact=mode_knob, alert_set=sc.batches.recs),
+                 dict(force_exact=mode_knob | 64, alert_set=sc.batches.recs), dict(force_exact=mode_knob | 1)):
+        sim, res = run_population(E, eng, sc.records, sc.rec_off, **kw)
+        info = sim.index_info()
+        assert info["dict_mode"] == mode and info["alert_set_declared"] == (1 if "alert_set" in kw else 0)
+        assert all(np.array_equal(a, b) for a, b in zip(ref, res)), kw
+        assert np.array_equal(res[0][rx], oe) and np.array_equal(res[1][rx], on) and np.array_equal(res[3][rx], want_fp)
+
+
+def test_c4_shaped_shard_against_fast_oracle(E):
+    """BASELINE configs[3] as one rank sees it: N = 100,000, K = 10, 1,000 crashed nodes (1 % churn), a shard of the
+    receivers.  The dictionary (2 x 200 KB) stays in memory; results against the optimised CPU formulation, proposal
+    contents through the fingerprints, and the vote count over the shard."""
+    n, K, H, L = 100000, 10, 9, 4
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sc0 = S.build_scenario("C4", subj, cfg, materialise=False)
+    rx = sc0.receivers[:: len(sc0.receivers) // 640][:640]
+    sc = S.build_scenario("C4", subj, cfg, receivers=rx)
+    fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=16)
+    for kw in (dict(), dict(alert_set=sc.batches.recs)):
+        sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off, **kw)
+        assert sim.index_info()["dict_mode"] == 2  # 2 x 200 KB of plain tables do not fit the LDS, the compressed form does
+        assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
+        assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
+    sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off, force_exact=256)  # ... and from memory
+    assert sim.index_info()["dict_mode"] == 0 and np.array_equal(emit, fe) and np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
+    assert np.all(fe >= 0) and sorted(sim.proposal(0)) == sc.faulty.tolist()
+    rr = sim.count_votes()
+    assert rr.votes_winner == len(rx) and rr.decided == 0 and rr.quorum == n - (n - 1) // 4  # a shard alone has no quorum
+
+
+# ------------------------------------------------------------------ C5: streaming rounds, stale records, quirk Q4
+def _oracle_decide(oview, K, H, L, pop, sc, cut):
+    """decideViewChange on the oracle: it learns the joiners' NodeIds from the UP alerts (only the batches that carry one
+    are replayed: the faithful detector is quadratic in the number of subjects in flux)."""
+    svc = O.AlertBatchService(oview, K, H, L, pop.id_hi, pop.id_lo)
+    r0 = sc.records[sc.rec_off[0]:sc.rec_off[1]]
+    beg = 0
+    for e in np.flatnonzero(r0["flags"] & S.FLAG_LAST_IN_BATCH) + 1:
+        b = r0[beg:int(e)]
+        if np.any((b["status"] == S.UP) & (b["cfg_id"] == oview.getCurrentConfigurationId())):
+            svc.handleBatchedAlertMessage(b)
+        beg = int(e)
+    svc.decideViewChange(cut)
+
+
+def test_streaming_rounds_with_stale_records_and_the_observer_cache(E):
+    """BASELINE configs[4] (continuous churn) at a size the faithful oracle can follow: six consecutive rounds over one
+    population -- a fresh 1 % of the members crashes and 0.5 % joins in every round, 1 % of the delivered records still carry
+    the previous configuration id (R/MembershipService.java:653-657), the decided cut is applied
+    (R/MembershipService.java:385-430) and the next round runs in the new configuration.  Every round: the engine's
+    per-receiver results equal the optimised oracle on all receivers and the FAITHFUL oracle -- whose view keeps its
+    observer cache across the rounds, quirk Q4 -- on a sample; the new configuration id and the observer table equal the
+    oracle's; and the Q4 guard shows that no receiver can hold a stale cache entry for a subject in flux."""
+    K, H, L = 10, 9, 4
+    n_mem, spare, rounds = 10000, 400, 6
+    pop = S.Population.make(n_mem + spare)
+    members = list(range(n_mem))
+    eng, view = make_engine(E, pop, K, H, L, members=members)
+    reg, oview = oracle_view(pop, K, members)
+    st = S.StreamingChurn(H, L, receivers_per_round=300)
+    guard = E.ObserverCacheGuard()
+    sim = E.ClusterSimulation(eng)
+    n = pop.n
+    for rnd in range(rounds):
+        obs, subj, member = view.tables()
+        cfg = view.getCurrentConfigurationId()
+        assert cfg == oview.getCurrentConfigurationId()
+        sc = st.next_round(obs, member, cfg)
+        if rnd > 0:
+            assert 0 < int((sc.records["cfg_id"] != cfg).sum()) < len(sc.records) // 50  # the stale records are there
+        # Q4: no member that is in flux now was in flux (= queried, cached) in an earlier configuration with other observers
+        assert guard.check_round(view, sc.faulty) == []
+        for s_ in sc.crashed[:: max(1, len(sc.crashed) // 25)]:
+            assert oview.getObserversOf(int(s_)) == oview.computeObserversOf(int(s_)) == view.getObserversOf(int(s_))
+        sim.load_streams(sc.records, sc.rec_off)
+        sim.set_alert_set(sc.batches.recs)  # the index from the round's alerts; the deliveries are NOT vouched for (stale records)
+        sim.tally()
+        emit, nprop, pcount, fp = sim.results()
+        fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=16)
+        assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
+        assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
+        m = 40  # the faithful restatement, observer cache carried over from the earlier rounds (single-threaded)
+        oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, sc.records[: sc.rec_off[m]], sc.rec_off[: m + 1],
+                                   prewarm_observers=False)
+        assert np.array_equal(emit[:m], oe) and np.array_equal(nprop[:m], on)
+        assert np.array_equal(fp[:m], proposal_fingerprints(oo, op, oe >= 0))
+        first = int(np.flatnonzero(fe >= 0)[0])
+        cut = sorted(fpp[fo[first]:fo[first + 1]].tolist())
+        assert cut == sc.faulty.tolist()
+        new_cfg = sim.apply_cut(cut)
+        _oracle_decide(oview, K, H, L, pop, sc, cut)
+        guard.on_view_change(sc.crashed)
+        assert new_cfg == oview.getCurrentConfigurationId()
+        assert view.getMembershipSize() == oview.getMembershipSize()
+    o2, s2, m2 = view.tables()
+    oo2, os2, om2 = oview.tables(n)
+    assert np.array_equal(m2, om2) and np.array_equal(s2, os2) and np.array_equal(o2, oo2)
+
+
+def test_streaming_rounds_at_100k_nodes(E):
+    """The same stream at N = 100,000 (a single-GPU-sized slice of BASELINE configs[4]): three rounds, 1,000 crashes + 500 joins
+    each, against the optimised oracle on every simulated receiver; configuration ids against the oracle's view."""
+    K, H, L = 10, 9, 4
+    n_mem, spare, rounds = 100000, 2000, 3
+    pop = S.Population.make(n_mem + spare)
+    members = list(range(n_mem))
+    eng, view = make_engine(E, pop, K, H, L, members=members)
+    reg, oview = oracle_view(pop, K, members)
+    st = S.StreamingChurn(H, L, receivers_per_round=192)
+    sim = E.ClusterSimulation(eng)
+    for rnd in range(rounds):
+        obs, subj, member = view.tables()
+        cfg = view.getCurrentConfigurationId()
+        assert cfg == oview.getCurrentConfigurationId()
+        sc = st.next_round(obs, member, cfg)
+        sim.load_streams(sc.records, sc.rec_off)
+        sim.set_alert_set(sc.batches.recs)  # the index from the round's alerts; the deliveries are NOT vouched for (stale records)
+        sim.tally()
+        emit, nprop, pcount, fp = sim.results()
+        fe, fn, fo, fpp = O.fast_sim_run(pop.n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=16)
+        assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
+        assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
+        # with 1,500 subjects in flux and 1 % of the reports lost to the stale configuration id, most receivers stay blocked
+        # (a subject short of H blocks the proposal); whoever does announce announces the whole fault set, which is the cut
+        # the round eventually settles on
+        for r_ in np.flatnonzero(fe >= 0)[:5]:
+            assert sorted(fpp[fo[r_]:fo[r_ + 1]].tolist()) == sc.faulty.tolist()
+        cut = sc.faulty.tolist()
+        new_cfg = sim.apply_cut(cut)
+        _oracle_decide(oview, K, H, L, pop, sc, cut)
+        assert new_cfg == oview.getCurrentConfigurationId() and view.getMembershipSize() == oview.getMembershipSize()
+        for s_ in (int(sc.joiners[0]), int(sc.receivers[0]), int(sc.receivers[-1])):
+            assert view.getObserversOf(s_) == oview.computeObserversOf(s_)
+
+
+# ------------------------------------------------------------------ f3: serialized rapid.proto bytes -> device tally
+def test_wire_bytes_to_device_tally_with_joiners_unknown_at_start(E):
+    """SURVEY 8f rank 3 end to end: a churn round as the reference puts it on the wire -- one serialized
+    RapidRequest{BatchedAlertMessage} per sender (rapid.proto:95-129), delivered to every receiver in its own order -- goes
+    through rapid_decode_request / rapid_decode_batched_alerts_ex into packed records, is loaded and tallied on the GPU, and
+    must give what the oracle gives when it is fed the SAME messages decoded by the Python protobuf runtime.  The joiners'
+    endpoints are in neither the endpoint map nor the engine's registry when the round starts (a receiver first hears of
+    them through the UP alerts, R/MembershipService.java:677-685): the facade registers them on both sides
+    (rapid_endpoint_map_add_wire, rapid_view_register_endpoints) and decodes again; then the fast round decides and the
+    cut (crashed members out, joiners in) gives the oracle's next configuration."""
+    from rapid_amd import wire as W
+    from tests import proto_rapid as P
+    n_all, n_mem, K, H, L = 760, 700, 10, 9, 4
+    pop = S.Population.make(n_all)
+    members = list(range(n_mem))
+    reg, oview = oracle_view(pop, K, members)  # the oracle's registry holds everybody (handle == index into pop)
+    obs_o, subj_o, member_o = oview.tables(n_all)
+    cfg = oview.getCurrentConfigurationId()
+    sc = S.build_churn_scenario(obs_o, member_o, cfg, 14, 9, H, L)
+    rx = sc.receivers[:: max(1, len(sc.receivers) // 48)][:48]
+    sc = S.build_churn_scenario(obs_o, member_o, cfg, 14, 9, H, L, receivers=rx)
+
+    def ep(i):
+        return P.Endpoint(hostname=pop.hostnames[i], port=int(pop.ports[i]))
+
+    # one serialized request per batch of the round
+    bs = sc.batches
+    wire_msgs = []
+    for b in range(bs.n_batches):
+        msg = P.BatchedAlertMessage(sender=ep(int(bs.sender[b])))
+        for rec in bs.recs[bs.off[b]:bs.off[b + 1]]:
+            a = P.AlertMessage(edgeSrc=ep(int(rec["src"])), edgeDst=ep(int(rec["dst"])), edgeStatus=int(rec["status"]),
+                               configurationId=int(rec["cfg_id"]))
+            a.ringNumber.extend([k for k in range(K) if (int(rec["ring_mask"]) >> k) & 1])
+            if int(rec["status"]) == S.UP:
+                a.nodeId.high, a.nodeId.low = int(pop.id_hi[int(rec["dst"])]), int(pop.id_lo[int(rec["dst"])])
+            msg.messages.append(a)
+        wire_msgs.append(P.RapidRequest(batchedAlertMessage=msg).SerializeToString())
+    # the engine knows the members only
+    eng = E.Engine(n_max=n_all, K=K, H=H, L=L)
+    view = E.MembershipView(eng).build(pop.hostnames[:n_mem], pop.ports[:n_mem], pop.id_hi[:n_mem], pop.id_lo[:n_mem])
+    assert view.getCurrentConfigurationId() == cfg
+    emap = W.EndpointMap(pop.hostnames[:n_mem], pop.ports[:n_mem])
+    # pass 1: decode every distinct message; register what is unknown, in the order it is met
+    new_hosts, new_ports, new_hi, new_lo = [], [], [], []
+    for req in wire_msgs:
+        kind, payload = W.decode_request(req)
+        assert kind == W.MSG_BATCHED_ALERT
+        recs_, ids_, status, unknown, sender = emap.decode_batched_alerts_ex(payload, K)
+        for i, st_ in enumerate(status):
+            if st_ == E.N.ENODE_MISSING:
+                before = emap.size()
+                idx = emap.add_wire(unknown[i])
+                if idx == before:  # first time: the engine gets the same index
+                    h_, p_ = emap.get(idx)
+                    new_hosts.append(h_); new_ports.append(p_); new_hi.append(ids_[i][0]); new_lo.append(ids_[i][1])
+            else:
+                assert st_ == E.N.OK
+    assert len(new_hosts) == len(sc.joiners)
+    assert view.registerEndpoints(new_hosts, new_ports, new_hi, new_lo) == n_mem
+    assert view.getCurrentConfigurationId() == cfg  # the membership did not change
+    to_pop = {i: i for i in range(n_mem)}
+    for j, h_ in enumerate(new_hosts):
+        to_pop[n_mem + j] = pop.hostnames.index(h_)
+    # pass 2: every receiver's deliveries, message by message, in its own order (S.deliver's permutation)
+    streams, off = [], [0]
+    for r in sc.receivers:
+        rng = np.random.Generator(np.random.PCG64([2, int(r)]))
+        parts = []
+        for b in rng.permutation(bs.n_batches):
+            kind, payload = W.decode_request(wire_msgs[int(b)])
+            recs_, ids_, status, unknown, sender = emap.decode_batched_alerts_ex(payload, K)
+            assert all(s_ == E.N.OK for s_ in status)
+            parts.append(recs_)
+        streams.append(np.concatenate(parts))
+        off.append(off[-1] + len(streams[-1]))
+    records = np.concatenate(streams)
+    # the same deliveries through the Python protobuf runtime, in the oracle's numbering
+    idx_of = {(pop.hostnames[i], int(pop.ports[i])): i for i in range(n_all)}
+    o_streams = []
+    for r in sc.receivers:
+        rng = np.random.Generator(np.random.PCG64([2, int(r)]))
+        parts = []
+        for b in rng.permutation(bs.n_batches):
+            m_ = P.RapidRequest.FromString(wire_msgs[int(b)]).batchedAlertMessage
+            recs_ = np.zeros(len(m_.messages), dtype=S.ALERT_DTYPE)
+            for i, a in enumerate(m_.messages):
+                recs_[i] = (a.configurationId, idx_of[(a.edgeSrc.hostname, a.edgeSrc.port)], idx_of[(a.edgeDst.hostname, a.edgeDst.port)],
+                            sum(1 << k for k in a.ringNumber), a.edgeStatus, 0)
+            recs_["flags"][-1] = S.FLAG_LAST_IN_BATCH
+            parts.append(recs_)
+        o_streams.append(np.concatenate(parts))
+    o_records = np.concatenate(o_streams)
+    assert np.array_equal(o_records, sc.records)  # (and both equal what the generator delivers directly)
+    oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, o_records, np.array(off), nthreads=8)
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(records, np.array(off))
+    sim.tally()
+    emit, nprop, pcount, fp = sim.results()
+    assert np.array_equal(emit, oe) and np.array_equal(nprop, on) and np.array_equal(pcount, np.diff(oo))
+    for r in range(len(oe)):
+        assert sorted(to_pop[x] for x in sim.proposal(r)) == op[oo[r]:oo[r + 1]].tolist() == sc.faulty.tolist()
+    # the 48 receivers agree but are no quorum of 700: the cut they all announce is applied, joiners enter with their NodeIds
+    new_cfg = sim.apply_cut(sim.proposal(0))
+    _oracle_decide(oview, K, H, L, pop, sc, sc.faulty.tolist())
+    assert new_cfg == oview.getCurrentConfigurationId() and view.getMembershipSize() == n_mem - 14 + 9
+    for node in (n_mem, n_mem + 3):
+        assert sorted(to_pop[x] for x in view.getObserversOf(node)) == sorted(oview.getObserversOf(to_pop[node]))
+
+
+# ------------------------------------------------------------------ f4: the round on the reference's own time line
+def test_round_driven_by_the_failure_detector_and_batching_timers(E):
+    """SURVEY 8f rank 4 wired to the engine: crashes at given instants -> PingPongFailureDetector notifications
+    (R/monitoring/impl/PingPongFailureDetector.java:41-85) -> AlertBatcher flushes (R/MembershipService.java:613-637) ->
+    arrival order at every receiver -> tally ON THE GPU -> proposal and fast-round decision times.  Results against the
+    faithful oracle on the same timed streams, the producer side against its literal event simulation, and the protocol's
+    time-to-stable-cut (~10 s of failure detection + batching + network) next to the engine's compute time."""
+    from rapid_amd import timeline as T
+    n, K, H, L = 2000, 10, 9, 4
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    reg, oview = oracle_view(pop, K)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    rng = np.random.default_rng(8)
+    faulty = np.sort(rng.choice(n, 20, replace=False))
+    crash = np.full(n, T.NEVER, dtype=np.int64)
+    crash[faulty] = rng.integers(2_000, 2_800, len(faulty))
+    start = rng.integers(0, 1000, n)
+    model, lat = T.ProducerModel(), T.LatencyModel(base_ms=1, jitter_ms=6, seed=9)
+    sim = E.ClusterSimulation(eng)
+    out = T.engine_round_on_the_time_line(sim, subj, crash, start, cfg, n, model, lat)
+    rx = out["receivers"]
+    # the producer side equals the literal event simulation (one PingPongFailureDetector object per detector, one AlertBatcher per node)
+    from tests.test_timeline import as_tuples, oracle_batches
+    t_end = int(crash[faulty].max() + 14 * model.fd_interval_ms + 10 * model.batching_window_ms)
+    assert as_tuples(out["batches"], out["send_ms"]) == oracle_batches(subj, crash, start, t_end, model)
+    # the tally on the device == the faithful oracle on the same timed streams
+    m = np.arange(0, len(rx), max(1, len(rx) // 120))
+    sub_off = np.zeros(len(m) + 1, dtype=np.int64)
+    parts = []
+    for i, r in enumerate(m):
+        parts.append(out["records"][out["rec_off"][r]:out["rec_off"][r + 1]])
+        sub_off[i + 1] = sub_off[i] + len(parts[-1])
+    oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, np.concatenate(parts), sub_off, nthreads=8)
+    assert np.array_equal(out["emit_batch"][m], oe) and np.array_equal(out["num_proposals"][m], on)
+    assert np.array_equal(out["fingerprint"][m], proposal_fingerprints(oo, op, oe >= 0))
+    assert np.all(out["emit_batch"] >= 0) and sorted(sim.proposal(0)) == faulty.tolist()
+    # on the time line: ten failed probes, one per second, then the batching window and the network
+    t_prop, t_dec = out["proposal_ms"], out["decision_ms"]
+    assert t_prop.min() > crash[faulty].min() + 10_000 and t_prop.max() < crash[faulty].max() + 11_000 + 2 * model.batching_window_ms + 10
+    quorum = n - (n - 1) // 4
+    assert np.all(t_dec >= np.sort(t_prop)[quorum - 1] + 1) and np.all(t_dec <= t_prop.max() + 7)
+    assert 10_000 < out["time_to_stable_cut_ms"] < 12_500
+    rr = sim.count_votes()
+    assert rr.decided == 1 and sorted(sim.decided_cut()) == faulty.tolist()
