@@ -321,8 +321,9 @@ int rapid_paxos_select_proposal(int32_t membership_size, const rapid_rank* vrnd,
                                 const int32_t* vvals, int32_t n_msgs, int32_t* chosen_out);
 /* One classic round (round 2, one coordinator, no message loss) for a whole population whose fast round did not reach
  * its quorum -- what rapid_sim_count_votes reports as decided = 0.  Acceptor i (one per live receiver) voted in the fast
- * round iff voted[i] != 0, for the proposal identified by vote_key[i] (rapid_sim_results' fingerprint: equal keys <=>
- * equal proposals, which rapid_sim_count_votes has verified); arrival[j] = the acceptor whose Phase1b reaches the
+ * round iff voted[i] != 0, for the proposal identified by vote_key[i] (rapid_sim_results' 64-bit fingerprint: equal
+ * proposals have equal keys; the converse is only CHECKED element-wise by rapid_sim_count_votes for the proposal it
+ * reports as the winner, for the others it rests on the fingerprint); arrival[j] = the acceptor whose Phase1b reaches the
  * coordinator j-th (NULL = index order).  Equivalent to running n_acceptors rapid_consensus objects message by message
  * (tests/test_consensus.py does). */
 typedef struct rapid_classic_round_result {
