@@ -391,7 +391,7 @@ int build_round_index(rapid_engine* h) {
     }
     HIPCHK(h, h->d_idxwork.ensure((size_t)N + 8));
     HIPCHK(h, h->d_dict.ensure((size_t)N + 8));  // (+ 8: the tally kernel stages them 16 bytes at a time)
-    HIPCHK(h, h->d_decl.ensure((size_t)N + 8));
+    HIPCHK(h, h->d_decl.ensure((size_t)N + 40));  // (the index build reads it 64 bytes at a time)
     HIPCHK(h, h->d_node_of_slot.ensure((size_t)N));
     HIPCHK(h, h->d_adj_off.ensure((size_t)N + 1));
     const int tent_cap = 16384;  // touched nodes the compressed dictionary can hold (64 KiB of LDS)

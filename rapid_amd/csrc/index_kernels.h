@@ -118,33 +118,48 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     const int lane = t & 63, wv = t >> 6, nw = T >> 6;
     const int per_wave_nodes = ((n_nodes + nw * 64 - 1) / (nw * 64)) * 64;
     const int beg = min(n_nodes, wv * per_wave_nodes), end = min(n_nodes, beg + per_wave_nodes);
+    // (eight steps' loads are issued before the first ballot: left to itself the compiler keeps every load next to the
+    // ballot that consumes it, and a pass over 10^5 nodes then costs 98 memory round trips per wave instead of 13)
+    constexpr int kBatch = 8;
     int nh = 0;
-#pragma unroll 4
-    for (int n0 = beg; n0 < end; n0 += 64) {
-        const int n = n0 + lane;
-        nh += __popcll(__ballot(n < end && __popc(gmask[n < end ? n : beg]) >= L));
+    for (int n0 = beg; n0 < end; n0 += 64 * kBatch) {
+        unsigned int g[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int n = n0 + 64 * j + lane;
+            g[j] = n < end ? gmask[n] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) nh += __popcll(__ballot(__popc(g[j]) >= L));
     }
     int n_hot_all = 0;
     int ph = block_exclusive_scan(lane == 0 ? nh : 0, s_wave, &n_hot_all);
     ph = __shfl(ph, 0, 64);  // hot nodes of the waves before this one
-#pragma unroll 4
-    for (int n0 = beg; n0 < end; n0 += 64) {
-        const int n = n0 + lane;
-        const bool in = n < end;
-        const unsigned int g = gmask[in ? n : beg];
-        const unsigned int mem = member[in ? n : beg] ? 0x8000u : 0u;
-        const bool hot = in && __popc(g) >= L;
-        const unsigned long long hots = __ballot(hot);
-        const int mine_slot = ph + __popcll(hots & ((1ull << lane) - 1ull));
-        ph += __popcll(hots);
-        unsigned int slot = 0x3FFFu;
-        if (hot && mine_slot < 16319) {
-            slot = (unsigned int)mine_slot;
-            node_of_slot[mine_slot] = n;
+    for (int n0 = beg; n0 < end; n0 += 64 * kBatch) {
+        unsigned int g[kBatch], mem[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int n = n0 + 64 * j + lane;
+            g[j] = n < end ? gmask[n] : 0u;
+            mem[j] = (n < end && member[n]) ? 0x8000u : 0u;
         }
-        if (in) {
-            dict[n] = (unsigned short)(slot | mem);
-            decl[n] = (unsigned short)((slot != 0x3FFFu ? 0x3FFFu : (g & 0x3FFFu)) | mem);
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int n = n0 + 64 * j + lane;
+            const bool in = n < end;
+            const bool hot = in && __popc(g[j]) >= L;
+            const unsigned long long hots = __ballot(hot);
+            const int mine_slot = ph + __popcll(hots & ((1ull << lane) - 1ull));
+            ph += __popcll(hots);
+            unsigned int slot = 0x3FFFu;
+            if (hot && mine_slot < 16319) {
+                slot = (unsigned int)mine_slot;
+                node_of_slot[mine_slot] = n;
+            }
+            if (in) {
+                dict[n] = (unsigned short)(slot | mem[j]);
+                decl[n] = (unsigned short)((slot != 0x3FFFu ? 0x3FFFu : (g[j] & 0x3FFFu)) | mem[j]);
+            }
         }
     }
     __threadfence_block();
@@ -191,11 +206,22 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     const int w0 = min(n_words, t * perw), w1 = min(n_words, w0 + perw);
     int cnt = 0;
     for (int w = w0; w < w1; ++w) {
+        // the 32 entries of a word are 64 contiguous, 64-byte aligned bytes of decl[]: four 16-byte loads instead of 32
+        // two-byte ones (this single workgroup lives on memory latency; decl[] is allocated with 40 entries of slack)
+        const uint4* const v = reinterpret_cast<const uint4*>(decl + (size_t)w * 32);
         unsigned int bits = 0u;
-        for (int b = 0; b < 32; ++b) {
-            const int n = w * 32 + b;
-            if (n < n_nodes && (decl[n] & 0x3FFFu) != 0u) bits |= 1u << b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 e = v[q];
+            const unsigned int ws[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if ((ws[j] & 0x3FFFu) != 0u) bits |= 1u << (q * 8 + 2 * j);
+                if (((ws[j] >> 16) & 0x3FFFu) != 0u) bits |= 1u << (q * 8 + 2 * j + 1);
+            }
         }
+        const int valid = n_nodes - w * 32;  // entries of this word that are nodes
+        if (valid < 32) bits &= (1u << valid) - 1u;
         tbits[w] = bits;
         cnt += __popc(bits);
     }
