@@ -7,8 +7,11 @@ and deterministically on every rank.  The only exchange per round is the sum all
 histogram (rapid_amd/csrc/vote_kernels.h) -- it replaces the N x N unicast fan-out of the fast-round votes
 (R/UnicastToAllBroadcaster.java:46-52, R/FastPaxos.java:104).
 
-merge_histograms / decide_from_histogram are the host-side reference of what the engine does with RCCL on the
-device; the world_size-2 gloo tests exercise exactly this logic on CPU.
+local_candidate / merge_candidates are the host-side statement of the ONE-collective round (every rank's candidate
+proposal with its verified votes, one all-gather, the same merge on every rank: vote_merge_kernel in
+rapid_amd/csrc/vote_kernels.h); local_histogram / decide_from_histogram of the general count it falls back to when the
+ranks' candidates differ or several proposals leave no quorum.  The world_size-2 gloo tests exercise exactly this logic
+on CPU.
 """
 import numpy as np
 
@@ -64,6 +67,53 @@ def all_reduce_histogram(hist, dist=None):
     t = torch.from_numpy(hist.astype(np.int64))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.numpy().astype(np.uint64)
+
+
+def local_candidate(emit_batch, fingerprint, proposal_of):
+    """What a rank contributes to the round's all-gather: its CANDIDATE = the proposal of its lowest voter
+    (proposal_of(local receiver) -> list of node indices), how many of its voters hold exactly that proposal (compared
+    element for element, as vote_verify_kernel does), and its number of voters.  -> dict(voters, votes, fp, cut)."""
+    emit = np.asarray(emit_batch)
+    fp = np.asarray(fingerprint, dtype=np.uint64)
+    voters = np.flatnonzero(emit >= 0)
+    if len(voters) == 0:
+        return dict(voters=0, votes=0, fp=0, cut=None)
+    rep = int(voters[0])
+    cut = list(proposal_of(rep))
+    same = [int(r) for r in voters if fp[r] == fp[rep]]
+    bad = [r for r in same if list(proposal_of(r)) != cut]
+    if bad:
+        raise ValueError("fingerprint collision: receivers %s share a fingerprint with %d but not its proposal" % (bad[:3], rep))
+    return dict(voters=int(len(voters)), votes=len(same), fp=int(fp[rep]), cut=cut)
+
+
+def merge_candidates(blocks, membership_size):
+    """The merge every rank runs over the gathered blocks (vote_merge_kernel).  -> (settled, votes, voters, cut):
+    settled iff every voting rank's candidate is the same proposal and it has a quorum (then no other proposal can have
+    one, R/FastPaxos.java:145-150, whatever the remaining voters hold) or every voter of every rank holds it; otherwise
+    the caller owes the exact plurality (histogram path).  cut = the decided proposal iff votes >= quorum."""
+    voting = [b for b in blocks if b["voters"] > 0]
+    voters = sum(b["voters"] for b in blocks)
+    if not voting:
+        return True, 0, 0, None
+    lead = voting[0]
+    if any(b["fp"] != lead["fp"] or b["cut"] != lead["cut"] for b in voting[1:]):
+        return False, 0, voters, None
+    votes = sum(b["votes"] for b in voting)
+    quorum = fast_quorum(membership_size)
+    if not (votes >= quorum or votes == voters):
+        return False, votes, voters, None
+    return True, votes, voters, (lead["cut"] if votes >= quorum else None)
+
+
+def count_votes_sharded(membership_size, emit_batch, fingerprint, proposal_of, dist=None):
+    """One collective: all-gather of the ranks' candidate blocks, merged identically everywhere."""
+    mine = local_candidate(emit_batch, fingerprint, proposal_of)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return merge_candidates([mine], membership_size)
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, mine)
+    return merge_candidates(parts, membership_size)
 
 
 def classic_round_sharded(membership_size, emit_batch, fingerprint, local_proposal, dist=None, arrival=None):

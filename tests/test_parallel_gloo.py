@@ -57,7 +57,23 @@ WORKER = textwrap.dedent("""
     fps = [hash(tuple(props[off[r]:off[r + 1]].tolist())) & ((1 << 64) - 1) if e[r] >= 0 else 0 for r in range(len(e))]
     hist = P.all_reduce_histogram(P.local_histogram(fps, np.diff(off)), dist)
     b, votes, total, ok = P.decide_from_histogram(hist, n)
-    print(json.dumps({"rank": rank, "lo": lo, "hi": hi, "bucket": b, "votes": votes, "total": total, "decided": bool(ok)}))
+    # the one-collective form of the same round: candidates all-gathered and merged by quorum
+    settled, cvotes, cvoters, cut = P.count_votes_sharded(n, e, np.array(fps, dtype=np.uint64), lambda r: props[off[r]:off[r + 1]].tolist(), dist)
+    # ... and of a round with a few dissenters at the END of the last rank's receivers (they must not stop the quorum) and at
+    # the FRONT of the first rank's (they become its candidate: the merge hands over to the general count)
+    def with_dissenters(front):
+        e2, f2 = e.copy(), np.array(fps, dtype=np.uint64)
+        mine = (rank == 0) if front else (rank == world - 1)
+        idx = list(range(3)) if front else list(range(len(e2) - 3, len(e2)))
+        if mine:
+            for i in idx:
+                e2[i], f2[i] = 0, np.uint64(12345)
+        prop = lambda r: [0, 1, 2] if (mine and r in idx) else props[off[r]:off[r + 1]].tolist()
+        return P.count_votes_sharded(n, e2, f2, prop, dist)
+    tail, front = with_dissenters(False), with_dissenters(True)
+    print(json.dumps({"rank": rank, "lo": lo, "hi": hi, "bucket": b, "votes": votes, "total": total, "decided": bool(ok),
+                      "merged": [bool(settled), cvotes, cvoters, cut], "tail": [bool(tail[0]), tail[1], tail[2], tail[3]],
+                      "front": [bool(front[0]), front[1], front[2]]}))
     dist.destroy_process_group()
 """)
 
@@ -90,6 +106,14 @@ def test_two_rank_gloo_decision_equals_single_rank():
     assert two[0]["hi"] == two[1]["lo"] and two[0]["lo"] == 0
     for t in two:
         assert (t["bucket"], t["votes"], t["total"], t["decided"]) == (one["bucket"], one["votes"], one["total"], one["decided"])
+        # the one-collective merge says the same, on every rank, and hands out the decided cut itself
+        assert t["merged"] == one["merged"] and t["merged"][:3] == [True, one["votes"], one["total"]] and len(t["merged"][3]) == 10
+        # three dissenting voters behind the others: still settled, their votes only count as voters
+        assert t["tail"] == one["tail"] and t["tail"][0] and t["tail"][3] == t["merged"][3]
+        assert t["tail"][2] == one["total"] and t["tail"][1] >= P.fast_quorum(400)
+        # dissenters that are a rank's lowest voters make the ranks' candidates differ: not merged
+        assert t["front"][0] is False
+    assert one["front"][0] is False  # (a single rank whose lowest voters dissent: three votes, no quorum, not unanimous)
 
 
 RECOVERY_WORKER = textwrap.dedent("""
