@@ -35,10 +35,10 @@ def test_every_other_kernel_of_the_path_is_scratch_free_too():
 
 
 def test_register_allocation_of_the_tally_kernel_is_the_measured_one():
-    """A canary, not a law: edits far from the window loop (the table-staging code, twice in round 2) have changed the
-    register allocation and schedule of the whole kernel and with it its speed by 20-30 % -- once through spills, once
-    with no spill at all (89 -> 93 VGPRs, 0.214 -> 0.285 ms on C3b) -- while every parity test stayed green.  These are the
-    counts of the build whose timings are in profiles/r02_*; if they move, time the tally kernel on a GPU
+    """A canary, not a law: changes that leave every result identical can still cost 20-30 % -- in round 2 once through
+    spills after an edit of the table-staging loop, once because a rewrite of that loop left a table pointer aimed at global
+    memory instead of its LDS copy (89 -> 93 VGPRs, 0.214 -> 0.285 ms on C3b) -- while every parity test stayed green.
+    These are the counts of the build whose timings are in profiles/r02_*; if they move, time the tally kernel on a GPU
     (scripts/pool_ab.py prints it in seconds) before accepting the new numbers here."""
     res = resources()
     got = {}
