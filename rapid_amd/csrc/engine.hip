@@ -134,6 +134,7 @@ struct rapid_engine {
     int dict_mode = 1;  // rapid::kDictDirect / kDictCompressed / kDictMemory
     bool lds_attr_set = false;
     DevBuf<unsigned int> d_errflags;  // sticky per loaded stream set: bit0 = a delivered report is not covered by the declared alert set
+    DevBuf<int> d_idxblk;  // per-workgroup hot / touched counts of the chunked index build
     DevBuf<int> d_node_of_slot, d_idxwork;  // d_idxwork = gmask[N] | info[8] of the round index build
     int n_slots = 0, n_hot = 0, n_adj = 0;
     float index_ms = 0.f;
@@ -421,11 +422,22 @@ int build_round_index(rapid_engine* h) {
                            (1u << K) - 1u, (long long)h->config_id, h->d_member.p, d_gmask, reinterpret_cast<unsigned int*>(d_info + 4));
     const int adj_cap = 65536;
     HIPCHK(h, h->d_adj.ensure((size_t)adj_cap + 1));
+    // large populations: the walk over the nodes in several workgroups (two more launches, a tenth of the latency); testing
+    // knob bit 12: also for small ones.  Such a round never has direct tables (kIndexChunkedMin nodes do not fit the LDS).
+    const bool chunked = N >= rapid::kIndexChunkedMin || (h->force_exact & 4096) != 0;
+    const int n_chunks = chunked ? (N + rapid::kIndexChunk - 1) / rapid::kIndexChunk : 0;
+    if (chunked) {
+        HIPCHK(h, h->d_idxblk.ensure((size_t)2 * (size_t)std::max(n_chunks, 1)));
+        hipLaunchKernelGGL(rapid::index_count_kernel, dim3((unsigned)n_chunks), dim3(1024), 0, st, d_gmask, N, L, h->d_idxblk.p);
+        hipLaunchKernelGGL(rapid::index_assign_kernel, dim3((unsigned)n_chunks), dim3(1024), 0, st, d_gmask, h->d_member.p, N, L,
+                           h->d_idxblk.p, h->d_dict.p, h->d_decl.p, h->d_node_of_slot.p, h->d_tbits.p, h->d_trank.p, h->d_tent.p, tent_cap);
+    }
     hipLaunchKernelGGL(rapid::index_build_block_kernel, dim3(1), dim3(1024), 0, st, d_gmask, h->d_member.p, h->d_obs.p, N, K, L,
                        h->d_dict.p, h->d_decl.p, h->d_node_of_slot.p, h->d_adj_off.p, h->d_adj.p, adj_cap, h->d_tbits.p, h->d_trank.p,
                        h->d_tent.p, tent_cap, d_info, reinterpret_cast<volatile int*>(h->d_mail),
-                       (h->force_exact & (128 | 256)) != 0 ? -1 : 160 * 1024 - rapid::kBlockStatsBytes,  // (lds_max below)
-                       h->d_stats.p, (int)stats_words(h), h->d_errflags.p, (int)++h->mail_seq);
+                       ((h->force_exact & (128 | 256)) != 0 || chunked) ? -1 : 160 * 1024 - rapid::kBlockStatsBytes,  // (lds_max below)
+                       h->d_stats.p, (int)stats_words(h), h->d_errflags.p, (int)++h->mail_seq,
+                       chunked ? h->d_idxblk.p : nullptr, n_chunks);
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipGetLastError());
     if (int rc = await_mail(h, 15, h->mail_seq)) return rc;
@@ -457,7 +469,7 @@ int build_round_index(rapid_engine* h) {
     // Where the node -> slot dictionary lives: in LDS as plain tables (4 B per node) when at least eight receivers still fit
     // next to them; else compressed (3 bits per node + 4 B per node the alert set names: 100,000 nodes in ~25 KB); else in
     // memory.  Testing knob: bit 7 = never direct, bit 8 = never in LDS at all.
-    const bool no_direct = (h->force_exact & (128 | 256)) != 0, no_lds = (h->force_exact & 256) != 0;
+    const bool no_direct = (h->force_exact & (128 | 256)) != 0 || info[7] == 0, no_lds = (h->force_exact & 256) != 0;  // info[7]: the build kernel's own verdict
     if (!no_direct && sh_direct + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
         h->dict_mode = rapid::kDictDirect;
     else if (!no_lds && compressed_ok && sh_comp + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
@@ -665,7 +677,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
     h->d_core.release(); h->d_cfg.release(); h->d_stage.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
-    h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release(); h->d_trank.release(); h->d_tbits.release(); h->d_tent.release();
+    h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_idxblk.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release(); h->d_trank.release(); h->d_tbits.release(); h->d_tent.release();
     h->d_adj_off.release(); h->d_node_of_slot.release();
     h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release(); h->d_voteback.release(); h->d_gather.release();
     (void)hipGetLastError();
@@ -1639,7 +1651,7 @@ int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, in
 
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on) {
     if (!h) return RAPID_EINVAL;
-    if (((h->force_exact ^ on) & (128 | 256)) != 0) h->index_valid = false;  // the launch geometry depends on where the dictionary lives
+    if (((h->force_exact ^ on) & (128 | 256 | 4096)) != 0) h->index_valid = false;  // the launch geometry depends on where the dictionary lives
     h->force_exact = on;
     return RAPID_OK;
 }

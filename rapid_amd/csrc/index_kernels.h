@@ -89,6 +89,120 @@ __device__ inline int block_exclusive_scan(int v, int* s_wave, int* total) {
     return base + incl - v;
 }
 
+// ---- large populations (N >= kIndexChunkedMin): the walk over the nodes in several workgroups -------------------------
+// One workgroup walking 10^5 .. 10^6 nodes lives on memory latency (0.13 ms at 10^5).  Here workgroup b owns the nodes
+// [b * kIndexChunk, (b + 1) * kIndexChunk): index_count_kernel counts its hot and its touched nodes, index_assign_kernel
+// turns the counts of the workgroups before it into its first slot / first rank and writes everything that is per node --
+// dict, decl, node_of_slot, and the compressed tables tbits / trank / tent (a population of this size never has direct
+// tables) -- and index_build_block_kernel then only does what needs the whole dictionary: the hot adjacency, the counts
+// for the host, the zeroing.  Slot numbering is the same (hot subjects ascending by node index).
+constexpr int kIndexChunk = 8192;        // nodes per workgroup: 16 waves x 8 steps of 64
+constexpr int kIndexChunkedMin = 40000;  // below: one workgroup does it all (direct tables may still fit there)
+
+__global__ __launch_bounds__(1024) void index_count_kernel(const unsigned int* gmask, int n_nodes, int L, int* blk_counts) {
+    __shared__ int s_hot, s_touched;
+    if (threadIdx.x == 0) {
+        s_hot = 0;
+        s_touched = 0;
+    }
+    __syncthreads();
+    const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+    const int n0 = (int)blockIdx.x * kIndexChunk + wv * 512;
+    unsigned int g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = n0 + 64 * j + lane;
+        g[j] = n < n_nodes ? gmask[n] : 0u;
+    }
+    int hot = 0, touched = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hot += __popcll(__ballot(__popc(g[j]) >= L));
+        touched += __popcll(__ballot(g[j] != 0u));
+    }
+    if (lane == 0) {
+        atomicAdd(&s_hot, hot);
+        atomicAdd(&s_touched, touched);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blk_counts[2 * blockIdx.x] = s_hot;
+        blk_counts[2 * blockIdx.x + 1] = s_touched;
+    }
+}
+
+__global__ __launch_bounds__(1024) void index_assign_kernel(const unsigned int* gmask, const unsigned char* member, int n_nodes, int L,
+                                                            const int* blk_counts, unsigned short* dict, unsigned short* decl,
+                                                            int* node_of_slot, unsigned int* tbits, unsigned short* trank,
+                                                            unsigned int* tent, int tent_cap) {
+    __shared__ int s_base_hot, s_base_touched, s_wave_hot[16], s_wave_touched[16];
+    const int t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) {
+        s_base_hot = 0;
+        s_base_touched = 0;
+    }
+    __syncthreads();
+    // hot / touched nodes of the workgroups before this one
+    for (int b = t; b < (int)blockIdx.x; b += (int)blockDim.x) {
+        atomicAdd(&s_base_hot, blk_counts[2 * b]);
+        atomicAdd(&s_base_touched, blk_counts[2 * b + 1]);
+    }
+    const int n0 = (int)blockIdx.x * kIndexChunk + wv * 512;
+    unsigned int g[8], mem[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = n0 + 64 * j + lane;
+        g[j] = n < n_nodes ? gmask[n] : 0u;
+        mem[j] = (n < n_nodes && member[n]) ? 0x8000u : 0u;
+    }
+    int hot = 0, touched = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hot += __popcll(__ballot(__popc(g[j]) >= L));
+        touched += __popcll(__ballot(g[j] != 0u));
+    }
+    if (lane == 0) {
+        s_wave_hot[wv] = hot;
+        s_wave_touched[wv] = touched;
+    }
+    __syncthreads();
+    int ph = s_base_hot, pt = s_base_touched;  // first slot / first rank of this wave's nodes
+    for (int i = 0; i < wv; ++i) {
+        ph += s_wave_hot[i];
+        pt += s_wave_touched[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = n0 + 64 * j + lane;
+        const bool in = n < n_nodes;
+        const bool is_hot = __popc(g[j]) >= L, is_touched = g[j] != 0u;  // (out-of-range lanes loaded 0: neither)
+        const unsigned long long hots = __ballot(is_hot), tch = __ballot(is_touched);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int my_slot = ph + __popcll(hots & below), my_rank = pt + __popcll(tch & below);
+        unsigned int slot = 0x3FFFu;
+        if (is_hot && my_slot < 16319) {
+            slot = (unsigned int)my_slot;
+            node_of_slot[my_slot] = n;
+        }
+        const unsigned int dcl = (slot != 0x3FFFu ? 0x3FFFu : (g[j] & 0x3FFFu)) | mem[j];
+        if (in) {
+            dict[n] = (unsigned short)(slot | mem[j]);
+            decl[n] = (unsigned short)dcl;
+        }
+        // compressed tables: the two 32-node words of this step, the touched nodes before each, one entry per touched node
+        if (in && (lane & 31) == 0) {
+            const int w = n >> 5;
+            tbits[w] = lane == 0 ? (unsigned int)tch : (unsigned int)(tch >> 32);
+            const int r = lane == 0 ? pt : pt + __popcll(tch & 0xFFFFFFFFull);
+            trank[w] = (unsigned short)(r > 65535 ? 65535 : r);
+        }
+        if (is_touched && my_rank < tent_cap) tent[my_rank] = (dcl << 16) | slot;
+        ph += __popcll(hots);
+        pt += __popcll(tch);
+    }
+}
+
+
 // The whole index after the touch pass in ONE workgroup (the round's hot set is a few hundred to a few thousand
 // subjects): slot numbering + dictionary + declared masks, then the hot adjacency.  One launch and one read-back of
 // info[] instead of six launches and two synchronisations, and no atomics: the list of a hot slot e is built by the
@@ -105,9 +219,16 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
                                                                  unsigned short* trank, unsigned int* tent, int tent_cap, int* info,
                                                                  volatile int* info_out, int direct_budget,
                                                                  unsigned long long* zero_words, int n_zero_words,
-                                                                 unsigned int* zero_flags, int seq) {
+                                                                 unsigned int* zero_flags, int seq, const int* blk_counts,
+                                                                 int n_chunks) {
     __shared__ int s_wave[16];
+    __shared__ int s_pre_hot, s_pre_touched;
     const int T = (int)blockDim.x, t = (int)threadIdx.x;
+    const bool prebuilt = blk_counts != nullptr;  // index_count_kernel + index_assign_kernel did everything that is per node
+    if (t == 0) {
+        s_pre_hot = 0;
+        s_pre_touched = 0;
+    }
     // the round's launch statistics / pool words and the sticky error flags start at zero: cleared here instead of by
     // memsets of their own between this kernel and the tally (each costs a launch gap)
     for (int i = t; i < n_zero_words; i += T) zero_words[i] = 0ull;
@@ -120,47 +241,56 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     const int beg = min(n_nodes, wv * per_wave_nodes), end = min(n_nodes, beg + per_wave_nodes);
     // (eight steps' loads are issued before the first ballot: left to itself the compiler keeps every load next to the
     // ballot that consumes it, and a pass over 10^5 nodes then costs 98 memory round trips per wave instead of 13)
-    constexpr int kBatch = 8;
-    int nh = 0;
-    for (int n0 = beg; n0 < end; n0 += 64 * kBatch) {
-        unsigned int g[kBatch];
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const int n = n0 + 64 * j + lane;
-            g[j] = n < end ? gmask[n] : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) nh += __popcll(__ballot(__popc(g[j]) >= L));
-    }
     int n_hot_all = 0;
-    int ph = block_exclusive_scan(lane == 0 ? nh : 0, s_wave, &n_hot_all);
-    ph = __shfl(ph, 0, 64);  // hot nodes of the waves before this one
-    for (int n0 = beg; n0 < end; n0 += 64 * kBatch) {
-        unsigned int g[kBatch], mem[kBatch];
+    if (!prebuilt) {
+        constexpr int kBatch = 8;
+        int nh = 0;
+        for (int n0 = beg; n0 < end; n0 += 64 * kBatch) {
+            unsigned int g[kBatch];
 #pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const int n = n0 + 64 * j + lane;
-            g[j] = n < end ? gmask[n] : 0u;
-            mem[j] = (n < end && member[n]) ? 0x8000u : 0u;
-        }
+            for (int j = 0; j < kBatch; ++j) {
+                const int n = n0 + 64 * j + lane;
+                g[j] = n < end ? gmask[n] : 0u;
+            }
 #pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            const int n = n0 + 64 * j + lane;
-            const bool in = n < end;
-            const bool hot = in && __popc(g[j]) >= L;
-            const unsigned long long hots = __ballot(hot);
-            const int mine_slot = ph + __popcll(hots & ((1ull << lane) - 1ull));
-            ph += __popcll(hots);
-            unsigned int slot = 0x3FFFu;
-            if (hot && mine_slot < 16319) {
-                slot = (unsigned int)mine_slot;
-                node_of_slot[mine_slot] = n;
+            for (int j = 0; j < kBatch; ++j) nh += __popcll(__ballot(__popc(g[j]) >= L));
+        }
+        int ph = block_exclusive_scan(lane == 0 ? nh : 0, s_wave, &n_hot_all);
+        ph = __shfl(ph, 0, 64);  // hot nodes of the waves before this one
+        for (int n0 = beg; n0 < end; n0 += 64 * kBatch) {
+            unsigned int g[kBatch], mem[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int n = n0 + 64 * j + lane;
+                g[j] = n < end ? gmask[n] : 0u;
+                mem[j] = (n < end && member[n]) ? 0x8000u : 0u;
             }
-            if (in) {
-                dict[n] = (unsigned short)(slot | mem[j]);
-                decl[n] = (unsigned short)((slot != 0x3FFFu ? 0x3FFFu : (g[j] & 0x3FFFu)) | mem[j]);
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int n = n0 + 64 * j + lane;
+                const bool in = n < end;
+                const bool hot = in && __popc(g[j]) >= L;
+                const unsigned long long hots = __ballot(hot);
+                const int mine_slot = ph + __popcll(hots & ((1ull << lane) - 1ull));
+                ph += __popcll(hots);
+                unsigned int slot = 0x3FFFu;
+                if (hot && mine_slot < 16319) {
+                    slot = (unsigned int)mine_slot;
+                    node_of_slot[mine_slot] = n;
+                }
+                if (in) {
+                    dict[n] = (unsigned short)(slot | mem[j]);
+                    decl[n] = (unsigned short)((slot != 0x3FFFu ? 0x3FFFu : (g[j] & 0x3FFFu)) | mem[j]);
+                }
             }
         }
+    } else {
+        for (int b = t; b < n_chunks; b += T) {
+            atomicAdd(&s_pre_hot, blk_counts[2 * b]);
+            atomicAdd(&s_pre_touched, blk_counts[2 * b + 1]);
+        }
+        __syncthreads();
+        n_hot_all = s_pre_hot;
     }
     __threadfence_block();
     __syncthreads();
@@ -201,7 +331,7 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     // Skipped when the direct tables will be used anyway -- the same test as the host's (engine.hip: build_round_index), on
     // the same numbers; direct_budget < 0: always build them.  info[7] tells the host which way it went.
     const bool direct_fits = direct_budget >= 0 && tally_shared_bytes(kDictDirect, n_nodes, 0, n_hot, total) + 8 * tally_wave_bytes(n_hot) <= direct_budget;
-    const int n_words = direct_fits ? 0 : (n_nodes + 31) / 32;
+    const int n_words = (direct_fits || prebuilt) ? 0 : (n_nodes + 31) / 32;
     const int perw = (n_words + T - 1) / T;
     const int w0 = min(n_words, t * perw), w1 = min(n_words, w0 + perw);
     int cnt = 0;
@@ -227,6 +357,7 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     }
     int n_touched = 0;
     int rk = block_exclusive_scan(cnt, s_wave, &n_touched);
+    if (prebuilt) n_touched = s_pre_touched;  // tbits / trank / tent were written by index_assign_kernel
     const bool tfits = n_touched <= 65535 && n_touched <= tent_cap;
     for (int w = w0; w < w1; ++w) {
         trank[w] = (unsigned short)(rk > 65535 ? 65535 : rk);

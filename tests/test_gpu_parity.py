@@ -915,8 +915,8 @@ def test_declared_alert_set_that_does_not_cover_the_streams_is_rejected(E):
 @pytest.mark.parametrize("name,n,f,K,H,L", [("C2", 2000, 20, 10, 9, 4), ("C3b", 1500, 40, 10, 9, 4)])
 def test_tables_in_memory_mode_vs_faithful_oracle(E, name, n, f, K, H, L):
     """Populations whose plain node -> slot tables do not fit the LDS (N >~ 30,000) run the tally kernel with the
-    compressed tables (bitmap + rank) in LDS, and beyond that with the dictionary in memory.  Knobs 128 / 256 force these
-    modes at a size the faithful oracle can check: both instantiations (deliveries vouched for / per-delivery filter) of
+    compressed tables (bitmap + rank) in LDS, and beyond that with the dictionary in memory; from 40,000 nodes on their
+    round index is built by several workgroups.  Knobs 128 / 256 / 4096 force these forms at a size the faithful oracle can check: both instantiations (deliveries vouched for / per-delivery filter) of
     both modes must give the oracle's results."""
     pop = S.Population.make(n)
     eng, view = make_engine(E, pop, K, H, L)
@@ -936,7 +936,8 @@ def test_tables_in_memory_mode_vs_faithful_oracle(E, name, n, f, K, H, L):
     assert sim0.index_info()["dict_mode"] == 1
     # 128: compressed tables in LDS, 256: dictionary in memory; alone: the pre-validated instantiation (every delivered alert
     # passes the filter); | 64: per-delivery filter; | 1: exact path
-    for mode_knob, mode in ((128, 2), (256, 0)):
+    # 4096: the round index built by several workgroups (count / assign / adjacency), the form of populations >= 40,000 nodes
+    for mode_knob, mode in ((128, 2), (256, 0), (4096, 2), (4096 | 256, 0)):
       for kw in (dict(force_exact=mode_knob), dict(force_exact=mode_knob | 64), dict(force_exact=mode_knob, alert_set=sc.batches.recs),
                  dict(force_exact=mode_knob | 64, alert_set=sc.batches.recs), dict(force_exact=mode_knob | 1)):
         sim, res = run_population(E, eng, sc.records, sc.rec_off, **kw)
