@@ -7,7 +7,10 @@ watermark, slot dictionary, hot adjacency, validation of the round's distinct al
 kernel over every receiver (MembershipService.handleMessage(BatchedAlertMessage) semantics), then the fast-round vote
 count over their proposals (every rank counts and verifies its own voters; one all-gather + merge across ranks; quorum
 test) with the decision read back to the host.  The view is NOT changed inside the timed loop so that every step does identical work;
-one extra untimed-in-`value` round that also applies the cut gives `time_to_stable_cut_ms`.  `ms_per_step` is the mean
+one extra untimed-in-`value` round that also applies the cut gives `time_to_stable_cut_ms`.  The streams are resident in
+the engine's split layout (8 B per delivered record on the tally's path + 8 B of configuration id beside it; the
+20-byte boundary records are split once at load time, before anything is timed): `roofline` reports SURVEY's 20-B
+accounting AND the kernel against the bytes it really reads, with the PMC-measured traffic next to both.  `ms_per_step` is the mean
 the contract asks for; `ms_per_step_min` / `_median` over the same steps and the tally-only figure are reported next to it.
 
 Launch: `python bench.py --gpus 1` or, for N > 1,
