@@ -15,6 +15,11 @@ namespace rapid {
 
 constexpr int kVoteBuckets = 1 << 14;
 
+// the workgroup's dynamic LDS segment (tests/emu/ supplies its own definition: a CPU build has no such thing)
+#ifndef RAPID_DYNAMIC_LDS
+#define RAPID_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
 __device__ __forceinline__ unsigned int vote_bucket(unsigned long long fp, unsigned long long salt) {
     unsigned long long x = fp ^ (salt * 0xD6E8FEB86659FD93ull);
     x ^= x >> 32;
@@ -236,7 +241,7 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
 __global__ __launch_bounds__(1024) void vote_count_local_kernel(const unsigned long long* fp, const int* prop_count, const int* props,
                                                                 int prop_cap, int n_receivers, unsigned long long salt,
                                                                 const unsigned int* tally_errors, unsigned long long* res, int* ref) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char vote_smem[];
+    RAPID_DYNAMIC_LDS(vote_smem);
     unsigned int* const hist = reinterpret_cast<unsigned int*>(vote_smem);                          // [kVoteBuckets]
     unsigned long long* const red64 = reinterpret_cast<unsigned long long*>(hist + kVoteBuckets);  // [2][16] per-wave partials
     unsigned int* const red32 = reinterpret_cast<unsigned int*>(red64 + 32);                       // [4][16]

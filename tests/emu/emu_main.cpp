@@ -246,3 +246,107 @@ int emu_cd_run(unsigned short* state, int* scal, const unsigned char* alerts, in
     return 0;
 }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The round-index kernels (rapid_amd/csrc/index_kernels.h) under the same emulator.  They use static __shared__
+// variables (the tally kernel carves everything from the dynamic segment): one copy per workgroup = one copy here, since
+// workgroups run one after the other and every kernel initialises what it reads.
+// ---------------------------------------------------------------------------------------------------------------
+#undef __shared__
+#define __shared__ static
+#include "index_kernels.h"
+
+extern "C" int emu_index_run(const unsigned char* alerts, long long n_alerts, int n_nodes, int K, int L, long long cfg_id,
+                             const unsigned char* member, const int* obs, int chunked, int direct_budget, unsigned short* dict,
+                             unsigned short* decl, int* node_of_slot, unsigned short* smask, unsigned int* pairs, int adj_cap,
+                             unsigned int* tbits, unsigned short* trank, unsigned int* tent, int tent_cap, int* info_out,
+                             unsigned long long seed) {
+    std::vector<unsigned int> work((size_t)n_nodes + 8, 0u);
+    unsigned int* gmask = work.data();
+    int* info = reinterpret_cast<int*>(work.data() + n_nodes);
+    const int touch_grid = (int)std::max<long long>(1, std::min<long long>(8, (n_alerts + 255) / 256));
+    for (int b = 0; b < touch_grid && n_alerts > 0; ++b)
+        emu::run_block((unsigned)b, (unsigned)touch_grid, 256u, [&] {
+            rapid::index_touch_kernel<false>(alerts, nullptr, n_alerts, n_nodes, (1u << K) - 1u, cfg_id, member, gmask,
+                                             reinterpret_cast<unsigned int*>(info + 4));
+        }, seed + 100 + (unsigned)b);
+    std::vector<int> blk;
+    int n_chunks = 0;
+    if (chunked) {
+        n_chunks = (n_nodes + rapid::kIndexChunk - 1) / rapid::kIndexChunk;
+        blk.assign((size_t)2 * (size_t)std::max(n_chunks, 1), -1);
+        for (int b = 0; b < n_chunks; ++b)
+            emu::run_block((unsigned)b, (unsigned)n_chunks, 1024u, [&] { rapid::index_count_kernel(gmask, n_nodes, L, blk.data()); }, seed + 200 + (unsigned)b);
+        for (int b = 0; b < n_chunks; ++b)
+            emu::run_block((unsigned)b, (unsigned)n_chunks, 1024u, [&] {
+                rapid::index_assign_kernel(gmask, member, n_nodes, L, blk.data(), dict, decl, node_of_slot, tbits, trank, tent, tent_cap);
+            }, seed + 300 + (unsigned)b);
+    }
+    static unsigned long long zero_words[64];
+    static unsigned int zero_flags[2];
+    for (auto& z : zero_words) z = ~0ull;
+    zero_flags[0] = zero_flags[1] = 7u;
+    int mail[16];
+    for (int& m : mail) m = -1;
+    emu::run_block(0u, 1u, 1024u, [&] {
+        rapid::index_build_block_kernel(gmask, member, obs, n_nodes, K, L, dict, decl, node_of_slot, smask, pairs, adj_cap, tbits, trank, tent,
+                                        tent_cap, info, mail, chunked ? -1 : direct_budget, zero_words, 64, zero_flags, 4242,
+                                        chunked ? blk.data() : nullptr, n_chunks);
+    }, seed + 400);
+    for (int i = 0; i < 8; ++i) info_out[i] = mail[i];
+    if (mail[15] != 4242) return -2;                       // the sequence word behind the answer
+    for (auto z : zero_words) if (z != 0ull) return -3;    // what the round's launches expect zeroed
+    if (zero_flags[0] != 0u || zero_flags[1] != 0u) return -4;
+    for (int n = 0; n < n_nodes + 8; ++n) if (work[(size_t)n] != 0u) return -5;  // the work area, left clean for the next round
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The fast-round vote kernels (rapid_amd/csrc/vote_kernels.h): counting pass, verification (after a counting pass, or
+// with the candidate taken from the statistics the tally kernel gathers), and the merge of the ranks' answers.
+// ---------------------------------------------------------------------------------------------------------------
+#define RAPID_DYNAMIC_LDS(name) alignas(16) static unsigned char name[(1 << 16) + 4096]
+#include "vote_kernels.h"
+
+extern "C" {
+// mode 0: vote_count_local_kernel + vote_verify_kernel; mode 1: res[] as the tally kernel leaves it (lowest voter, voters) +
+// vote_verify_kernel with the candidate read in place.  block[] = res[10] followed by ref[1 + prop_cap] (as published).
+int emu_vote_settle(const unsigned long long* fp, const int* prop_count, const int* props, int prop_cap, int n_receivers,
+                    unsigned long long salt, int mode, unsigned long long* block, unsigned long long seed) {
+    const int res_words = 10;
+    std::vector<unsigned long long> dev((size_t)res_words + (size_t)(prop_cap + 2) / 2 + 1, 0ull);
+    unsigned long long* res = dev.data();
+    int* ref = reinterpret_cast<int*>(res + res_words);
+    unsigned int errs[2] = {0u, 0u};
+    if (mode == 0) {
+        emu::run_block(0u, 1u, 1024u, [&] { rapid::vote_count_local_kernel(fp, prop_count, props, prop_cap, n_receivers, salt, errs, res, ref); }, seed);
+    } else {
+        unsigned long long voters = 0, rep = 0xFFFFFFFFull;
+        for (int r = n_receivers - 1; r >= 0; --r)
+            if (prop_count[r] != 0) {
+                ++voters;
+                rep = (unsigned long long)r;
+            }
+        res[0] = rep;
+        res[2] = voters;
+    }
+    const int grid = std::max(1, (n_receivers * 64 + 1023) / 1024);
+    unsigned int seq_word = 0u;
+    for (int b = 0; b < grid; ++b)
+        emu::run_block((unsigned)b, (unsigned)grid, 1024u, [&] {
+            rapid::vote_verify_kernel(fp, prop_count, props, prop_cap, n_receivers, res + 4, ref, res + 6, res, res_words,
+                                      reinterpret_cast<unsigned int*>(res + 9), block, &seq_word, 77u, mode, errs);
+        }, seed + 10 + (unsigned)b);
+    if (seq_word != 77u) return -2;
+    if (res[9] != 0ull) return -3;  // the packed counter is left at zero
+    return 0;
+}
+
+int emu_vote_merge(const unsigned long long* gathered, int n_ranks, int seg_words, int prop_cap, long long quorum,
+                   unsigned long long* block, unsigned long long seed) {
+    unsigned int seq_word = 0u;
+    emu::run_block(0u, 1u, 256u, [&] { rapid::vote_merge_kernel(gathered, n_ranks, seg_words, 10, prop_cap, quorum, block, &seq_word, 5u); }, seed);
+    return seq_word == 5u ? 0 : -2;
+}
+}
+

@@ -27,6 +27,10 @@ struct uint4 {
     unsigned int x, y, z, w;
 };
 inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
+struct uint2 {
+    unsigned int x, y;
+};
+inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 
 namespace emu {
 struct Dim {
@@ -74,16 +78,33 @@ inline unsigned long long __ballot(int p) { return emu::park(emu::OP_BALLOT, p ?
 inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return emu::park(emu::OP_BALLOT, p ? 1 : 0, 0); }
 inline int __shfl(int v, int src, int = 64) { return (int)(uint32_t)emu::park(emu::OP_SHFL, (uint32_t)v, (unsigned)src & 63u); }
 inline unsigned __shfl(unsigned v, int src, int = 64) { return (unsigned)emu::park(emu::OP_SHFL, v, (unsigned)src & 63u); }
+inline int __shfl_up(int v, unsigned delta, int = 64) {  // lanes below `delta` keep their own value
+    const unsigned l = (unsigned)emu::cur_lane();
+    return (int)(uint32_t)emu::park(emu::OP_SHFL, (uint32_t)v, l >= delta ? l - delta : l);
+}
 inline int __shfl_xor(int v, int m, int = 64) {
     return (int)(uint32_t)emu::park(emu::OP_SHFL, (uint32_t)v, (unsigned)(emu::cur_lane() ^ m) & 63u);
 }
 inline unsigned __shfl_xor(unsigned v, int m, int = 64) {
     return (unsigned)emu::park(emu::OP_SHFL, v, (unsigned)(emu::cur_lane() ^ m) & 63u);
 }
+inline unsigned long long __shfl_xor(unsigned long long v, int m, int = 64) {
+    const unsigned lo = __shfl_xor((unsigned)v, m), hi = __shfl_xor((unsigned)(v >> 32), m);
+    return ((unsigned long long)hi << 32) | lo;
+}
 // readlane / readfirstlane: uniform reads (all live lanes of a wave execute them together)
 inline int __builtin_amdgcn_readlane(int v, int src) { return (int)(uint32_t)emu::park(emu::OP_SHFL, (uint32_t)v, (unsigned)src & 63u); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)emu::park(emu::OP_FIRST, (uint32_t)v, 0); }
 inline void __syncthreads() { (void)emu::park(emu::OP_BLOCK_SYNC, 0, 0); }
+inline int __syncthreads_or(int p) {  // (fibers run one at a time: a plain accumulator between two barriers)
+    static int acc;
+    __syncthreads();
+    if (threadIdx.x == 0) acc = 0;
+    __syncthreads();
+    if (p) acc = 1;
+    __syncthreads();
+    return acc;
+}
 // wave-local LDS ordering point of the kernels (compiler-only on the device): a rendezvous here, so that the
 // emulator keeps shuffling the lane order around every point where lanes exchange data through LDS
 inline unsigned int __builtin_amdgcn_mbcnt_lo(unsigned int m, unsigned int add) {
@@ -122,6 +143,8 @@ inline unsigned atomicAnd(unsigned* p, unsigned v) {
     return o;
 }
 inline void __threadfence() {}
+inline void __threadfence_block() {}
+inline void __threadfence_system() {}
 inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {
     const unsigned long long o = *p;
     if (v > o) *p = v;

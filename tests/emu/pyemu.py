@@ -77,6 +77,32 @@ def build_round_index(records, n_nodes, K, L, obs, member):
                 adj=adj, n_hot=n_hot, n_adj=len(pairs))
 
 
+def index_run(records, n_nodes, K, L, cfg_id, obs, member, chunked=False, direct_budget=-1, seed=1):
+    """Runs the round-index KERNELS (rapid_amd/csrc/index_kernels.h: touch, then one workgroup -- or count / assign / one
+    workgroup, the form of large populations) under the emulator.  -> dict shaped like build_round_index's, plus `info`
+    (the eight words the host reads from the mailbox)."""
+    L_ = lib()
+    recs = np.ascontiguousarray(records)
+    raw = np.zeros(recs.nbytes + 32, dtype=np.uint8)
+    raw[: recs.nbytes] = recs.view(np.uint8).reshape(-1)
+    member = np.ascontiguousarray(member, dtype=np.uint8)
+    obs = np.ascontiguousarray(obs, dtype=np.int32)
+    n_words = (n_nodes + 31) // 32
+    adj_cap, tent_cap = 65536, 16384
+    out = dict(dict=np.full(n_nodes + 40, 0xEEEE, dtype=np.uint16), decl=np.full(n_nodes + 40, 0xEEEE, dtype=np.uint16),
+               node_of_slot=np.full(n_nodes + 1, -7, dtype=np.int32), smask=np.full(n_nodes + 1, 0xEEEE, dtype=np.uint16),
+               pairs=np.zeros(adj_cap + 1, dtype=np.uint32), tbits=np.full(n_words + 1, 0xEEEEEEEE, dtype=np.uint32),
+               trank=np.full(n_words + 1, 0xEEEE, dtype=np.uint16), tent=np.full(tent_cap, 0xEEEEEEEE, dtype=np.uint32),
+               info=np.zeros(8, dtype=np.int32))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L_.emu_index_run.restype = C.c_int
+    rc = L_.emu_index_run(p(raw), C.c_longlong(len(recs)), n_nodes, K, L, C.c_longlong(cfg_id), p(member), p(obs), 1 if chunked else 0,
+                          direct_budget, p(out["dict"]), p(out["decl"]), p(out["node_of_slot"]), p(out["smask"]), p(out["pairs"]), adj_cap,
+                          p(out["tbits"]), p(out["trank"]), p(out["tent"]), tent_cap, p(out["info"]), C.c_ulonglong(seed))
+    assert rc == 0, rc
+    return out
+
+
 def validate_alerts(records, n_nodes, K, cfg_id, member):
     """(every record passes the filter of MembershipService.java:644-675, every record is DOWN) -- what
     index_touch_kernel computes once per round."""
@@ -165,3 +191,53 @@ class CdInstance:
 
     def num_proposals(self):
         return int(self.scal[1])
+
+
+RES_WORDS = 10
+
+
+def vote_settle(fp, prop_count, props, mode, salt=0, seed=1):
+    """vote_count_local_kernel + vote_verify_kernel (mode 0) or vote_verify_kernel on the statistics the tally kernel leaves
+    (mode 1: candidate = the lowest voter's proposal) under the emulator.  -> (res[10] as published, ref list or None if it
+    overflowed)."""
+    L_ = lib()
+    fp = np.ascontiguousarray(fp, dtype=np.uint64)
+    prop_count = np.ascontiguousarray(prop_count, dtype=np.int32)
+    props = np.ascontiguousarray(props, dtype=np.int32)
+    R, cap = props.shape
+    block = np.zeros(RES_WORDS + (cap + 2) // 2 + 1, dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L_.emu_vote_settle.restype = C.c_int
+    rc = L_.emu_vote_settle(p(fp), p(prop_count), p(props), cap, R, C.c_ulonglong(salt), mode, p(block), C.c_ulonglong(seed))
+    assert rc == 0, rc
+    ref = block[RES_WORDS:].view(np.int32)
+    n = int(ref[0])
+    return block[:RES_WORDS].copy(), (ref[1: 1 + n].tolist() if n >= 0 else None)
+
+
+def vote_block(votes, voters, fp, cut, prop_cap, bad=0, err=0):
+    """A rank's answer block as rapid_sim_count_votes all-gathers it: res[10] + ref[1 + prop_cap], padded to 8 bytes."""
+    seg_words = RES_WORDS + (prop_cap + 2) // 2 + 1
+    b = np.zeros(seg_words, dtype=np.uint64)
+    M = (1 << 64) - 1
+    b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8] = votes, voters, (0 if voters == 0 else 1 if votes == voters else 2), fp, (~fp) & M, bad, votes, err
+    ref = b[RES_WORDS:].view(np.int32)
+    ref[0] = len(cut) if cut is not None else 0
+    if cut:
+        ref[1: 1 + len(cut)] = cut
+    return b
+
+
+def vote_merge(blocks, prop_cap, quorum, seed=1):
+    """vote_merge_kernel over the ranks' blocks.  -> (status, votes, voters, cut)."""
+    L_ = lib()
+    gathered = np.ascontiguousarray(np.concatenate(blocks))
+    seg_words = len(blocks[0])
+    out = np.zeros(seg_words, dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L_.emu_vote_merge.restype = C.c_int
+    rc = L_.emu_vote_merge(p(gathered), len(blocks), seg_words, prop_cap, C.c_longlong(quorum), p(out), C.c_ulonglong(seed))
+    assert rc == 0, rc
+    ref = out[RES_WORDS:].view(np.int32)
+    n = int(ref[0])
+    return int(out[9]), int(out[1]), int(out[2]), (ref[1: 1 + n].tolist() if n > 0 else None), out[:RES_WORDS].copy()

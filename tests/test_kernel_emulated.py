@@ -260,3 +260,133 @@ def test_declared_alert_set_must_cover_the_delivered_streams():
         *res, covered = pyemu.tally(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, trusted=trusted,
                                     declared=np.delete(sc.batches.recs, one))
         assert covered and np.array_equal(res[0], fe) and np.array_equal(res[2], np.diff(fo))
+
+
+@pytest.mark.parametrize("n,n_out,n_crash,n_join,chunked", [(300, 30, 10, 12, False), (300, 30, 10, 12, True), (9000, 60, 120, 40, True),
+                                                            (17000, 40, 200, 30, True)])
+def test_round_index_kernels_match_their_host_statement(n, n_out, n_crash, n_join, chunked):
+    """The kernels that build the per-round index (rapid_amd/csrc/index_kernels.h), emulated: the one-workgroup form and the
+    form of large populations (nodes walked by workgroups of 8,192: count, assign, then one workgroup for the adjacency)
+    must produce, entry for entry, what pyemu.build_round_index states in numpy -- the statement every emulated tally test
+    already runs on: slots ascending by node, dictionary and declared masks, the hot adjacency triples and per-slot masks,
+    the compressed tables, the counts and validation flags the host reads, and a work area left zeroed."""
+    K, H, L = 10, 9, 4
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K, list(range(0, n - n_out)))
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_churn_scenario(obs, member, cfg, n_crash, n_join, H, L, receivers=[0])
+    alerts = sc.batches.recs
+    want = pyemu.build_round_index(alerts, n, K, L, np.asarray(obs), member)
+    got = pyemu.index_run(alerts, n, K, L, cfg, obs, member, chunked=chunked)
+    nh, na, nt = want["n_hot"], want["n_adj"], want["n_touched"]
+    assert (int(got["info"][0]), int(got["info"][1]), int(got["info"][3]), int(got["info"][5])) == (nh, nh, na, nt)
+    assert got["info"][2] == 0 and got["info"][6] == 1 and got["info"][7] == 0
+    ok, all_down = pyemu.validate_alerts(alerts, n, K, cfg, member)
+    assert int(got["info"][4]) == (0 if ok else 1) | (0 if all_down else 2)
+    assert np.array_equal(got["dict"][:n], want["dict"][:n]) and np.array_equal(got["decl"][:n], want["decl"][:n])
+    assert np.array_equal(got["node_of_slot"][:nh], want["node_of_slot"][:nh])
+    assert np.array_equal(got["smask"][:nh], want["adj_off"][:nh]) and np.array_equal(got["pairs"][:na], want["adj"][:na])
+    nw = (n + 31) // 32
+    assert np.array_equal(got["tbits"][:nw], want["tbits"]) and np.array_equal(got["trank"][:nw], want["trank"])
+    assert np.array_equal(got["tent"][:nt], want["tent"][:nt])
+    if not chunked:  # with room for the direct tables the one-workgroup form skips the compressed ones and says so
+        lean = pyemu.index_run(alerts, n, K, L, cfg, obs, member, direct_budget=160 * 1024)
+        assert lean["info"][7] == 1 and lean["info"][6] == 0 and np.array_equal(lean["dict"][:n], want["dict"][:n])
+        assert np.array_equal(lean["pairs"][:na], want["adj"][:na]) and (lean["tbits"][:nw] == 0xEEEEEEEE).all()
+
+
+def _population_of_voters(rng, R, n_props, prop_cap, p_vote=0.8):
+    """R receivers, each silent or voting for one of n_props random node lists (skewed towards the first)."""
+    cuts = [sorted(rng.choice(5000, size=int(rng.integers(1, prop_cap + 1)), replace=False).tolist()) for _ in range(n_props)]
+    w = np.array([8.0] + [1.0] * (n_props - 1))
+    which = rng.choice(n_props, size=R, p=w / w.sum())
+    votes = rng.random(R) < p_vote
+    props = np.zeros((R, prop_cap), dtype=np.int32)
+    pcount = np.zeros(R, dtype=np.int32)
+    poff = [0]
+    flat = []
+    for r in range(R):
+        if votes[r]:
+            c = cuts[which[r]]
+            props[r, : len(c)] = c
+            pcount[r] = len(c)
+            flat += c
+        poff.append(len(flat))
+    fp = proposal_fingerprints(np.array(poff), np.array(flat, dtype=np.int64), votes)
+    return cuts, which, votes, props, pcount, fp
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_vote_kernels_settle_a_round(seed):
+    """The fast-round kernels (rapid_amd/csrc/vote_kernels.h), emulated, against a direct count (R/FastPaxos.java:125-156:
+    votes per identical proposal): the counting pass + verification find the plurality proposal, its votes and its list;
+    the verification alone, on the statistics the tally kernel gathers, settles the lowest voter's proposal; a receiver whose
+    list differs under an equal fingerprint is counted as an offender, never as a vote."""
+    rng = np.random.default_rng(4200 + seed)
+    R, prop_cap = int(rng.integers(1, 700)), 12
+    n_props = int(rng.integers(1, 5))
+    cuts, which, votes, props, pcount, fp = _population_of_voters(rng, R, n_props, prop_cap, p_vote=float(rng.choice([0.0, 0.5, 0.95])) if seed else 0.9)
+    voters = np.flatnonzero(votes)
+    counts = np.bincount(which[voters], minlength=n_props) if len(voters) else np.zeros(n_props, dtype=int)
+    res, ref = pyemu.vote_settle(fp, pcount, props, mode=0)
+    assert int(res[2]) == len(voters)
+    if len(voters) == 0:
+        assert int(res[1]) == 0
+    else:
+        best = int(counts.max())
+        assert int(res[1]) == best == int(res[7]) and int(res[6]) == 0
+        winners = [i for i in range(n_props) if counts[i] == best]
+        assert ref in [cuts[i] for i in winners]
+        assert int(res[4]) == int(fp[voters[which[voters] == cuts.index(ref)][0]]) and int(res[5]) == (~int(res[4])) & ((1 << 64) - 1)
+        assert int(res[3]) == int((counts > 0).sum())
+        # the candidate form: the lowest voter's proposal, whatever the others hold
+        res1, ref1 = pyemu.vote_settle(fp, pcount, props, mode=1)
+        lead = int(which[voters[0]])
+        assert ref1 == cuts[lead] and int(res1[1]) == int(counts[lead]) == int(res1[7]) and int(res1[2]) == len(voters)
+        assert int(res1[3]) == (1 if counts[lead] == len(voters) else 2) and int(res1[4]) == int(fp[voters[0]]) and int(res1[6]) == 0
+        # an equal fingerprint over a different list: an offender
+        if len(voters) >= 3:
+            forged = int(voters[-1])
+            if which[forged] == lead:
+                props2 = props.copy()
+                props2[forged, 0] += 1
+                res2, _ = pyemu.vote_settle(fp, pcount, props2, mode=1)
+                assert int(res2[6]) == 1 and int(res2[7]) == int(counts[lead])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_vote_merge_kernel_equals_the_host_statement(seed):
+    """vote_merge_kernel (what every rank runs over the all-gathered answers) against rapid_amd.parallel.merge_candidates on
+    random ranks: a common candidate with and without a quorum, dissenters, silent ranks, ranks whose candidates differ,
+    lists that differ under an equal fingerprint."""
+    from rapid_amd import parallel as P
+    rng = np.random.default_rng(9100 + seed)
+    prop_cap, membership = 16, int(rng.integers(40, 400))
+    quorum = P.fast_quorum(membership)
+    cut_a = sorted(rng.choice(1000, size=int(rng.integers(1, 12)), replace=False).tolist())
+    cut_b = sorted(rng.choice(1000, size=len(cut_a), replace=False).tolist())
+    fa, fb = 0x1111222233334444 + seed, 0x9999AAAABBBBCCCC + seed
+    for trial in range(12):
+        n_ranks = int(rng.integers(1, 6))
+        blocks, host = [], []
+        for k in range(n_ranks):
+            kind = rng.choice(["silent", "a", "a_dissent", "b", "a_otherlist"], p=[0.15, 0.45, 0.2, 0.1, 0.1])
+            voters = 0 if kind == "silent" else int(rng.integers(1, membership // max(1, n_ranks) + 2))
+            votes = voters if kind != "a_dissent" else max(1, voters - int(rng.integers(1, 4)))
+            fp, cut = (fb, cut_b) if kind == "b" else (fa, cut_a)
+            if kind == "a_otherlist":
+                cut = cut_b
+            if voters == 0:
+                fp, cut, votes = 0, None, 0
+            blocks.append(pyemu.vote_block(votes, voters, fp, cut, prop_cap))
+            host.append(dict(voters=voters, votes=votes, fp=fp, cut=cut))
+        settled, hvotes, hvoters, hcut = P.merge_candidates(host, membership)
+        status, votes, voters, cut, res = pyemu.vote_merge(blocks, prop_cap, quorum, seed=trial + 1)
+        assert (status == 1) == settled, (host, status)
+        assert voters == hvoters
+        if settled:
+            assert votes == hvotes and int(res[7]) == votes and int(res[6]) == 0
+            if hvoters:
+                assert cut == host[[h["voters"] > 0 for h in host].index(True)]["cut"]
+                assert (hcut is not None) == (votes >= quorum)
