@@ -10,6 +10,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// the workgroup's dynamic LDS segment (tests/emu/ supplies its own definition: a CPU build has no such thing)
+#ifndef RAPID_DYNAMIC_LDS
+#define RAPID_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
 namespace rapid {
 
 // ---- XXH64 ------------------------------------------------------------------------------------------------
@@ -210,7 +215,7 @@ __global__ void ring_tables_kernel(const int* ring, const unsigned long long* ri
 __global__ void config_id_kernel(const long long* ids_hi, const long long* ids_lo, int n_ids, const int* ring0,
                                  int n_members, const unsigned long long* hx_host0, const unsigned long long* hx_port0,
                                  long long* out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    RAPID_DYNAMIC_LDS(smem_raw);
     unsigned long long* sv = reinterpret_cast<unsigned long long*>(smem_raw);
     unsigned long long* sm = sv + blockDim.x;
     const long long total = 2ll * n_ids + 2ll * n_members;

@@ -350,3 +350,61 @@ int emu_vote_merge(const unsigned long long* gathered, int n_ranks, int seg_word
 }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The view kernels (rapid_amd/csrc/view_kernels.h): ring keys (XXH64 on the device), ring tables, ring compaction,
+// configuration id.  The K sorts between them are a library call on the device (rocPRIM segmented radix sort of the
+// sign-flipped keys); here std::stable_sort plays that part.
+// ---------------------------------------------------------------------------------------------------------------
+#include "view_kernels.h"
+
+#include <algorithm>
+#include <numeric>
+
+extern "C" int emu_view_build(const unsigned char* blob, const int* host_off, const int* ports, int n_nodes, int K, const int* members,
+                              int n_members, const long long* ids_hi_sorted, const long long* ids_lo_sorted, int n_ids,
+                              const unsigned char* keep /* nullable: members kept by a removal-only change */, long long* keys_out,
+                              int* ring_out, int* obs_out, int* subj_out, long long* cfg_out, int* ring2_out, int* n_members2_out,
+                              unsigned long long seed) {
+    const size_t KN = (size_t)K * (size_t)n_nodes, KM = (size_t)K * (size_t)std::max(n_members, 1);
+    std::vector<unsigned long long> hx_host(n_nodes + 1), hx_port(n_nodes + 1), skeys(KM), sk2(KM);
+    std::vector<int> vals(KM), pos(KN + 1, -1);
+    auto launch = [&](long long n_threads, unsigned threads, const std::function<void()>& body, unsigned long long sd) {
+        const unsigned grid = (unsigned)std::max<long long>(1, (n_threads + threads - 1) / threads);
+        for (unsigned b = 0; b < grid; ++b) emu::run_block(b, grid, threads, body, sd + b);
+    };
+    launch((long long)KN, 256u, [&] { rapid::ring_keys_kernel(blob, host_off, ports, n_nodes, K, keys_out, hx_host.data(), hx_port.data()); }, seed);
+    std::vector<unsigned char> member(n_nodes + 1, 0);
+    for (int i = 0; i < n_members; ++i) member[members[i]] = 1;
+    launch((long long)K * n_members, 256u, [&] { rapid::ring_gather_kernel(keys_out, members, n_members, n_nodes, K, skeys.data(), vals.data()); }, seed + 1000);
+    for (int k = 0; k < K; ++k) {  // the segmented sort
+        std::vector<int> order(n_members);
+        std::iota(order.begin(), order.end(), 0);
+        const unsigned long long* sk = skeys.data() + (size_t)k * n_members;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sk[a] < sk[b]; });
+        for (int i = 0; i < n_members; ++i) {
+            ring_out[(size_t)k * n_members + i] = vals[(size_t)k * n_members + order[i]];
+            sk2[(size_t)k * n_members + i] = sk[order[i]];
+        }
+    }
+    launch((long long)K * n_members, 256u, [&] {
+        rapid::ring_tables_kernel(ring_out, sk2.data(), keys_out, member.data(), n_nodes, n_members, K, pos.data(), obs_out, subj_out, 0);
+    }, seed + 2000);
+    launch((long long)KN, 256u, [&] {
+        rapid::ring_tables_kernel(ring_out, sk2.data(), keys_out, member.data(), n_nodes, n_members, K, pos.data(), obs_out, subj_out, 1);
+    }, seed + 3000);
+    emu::run_block(0u, 1u, 1024u, [&] {
+        rapid::config_id_kernel(ids_hi_sorted, ids_lo_sorted, n_ids, ring_out, n_members, hx_host.data(), hx_port.data(), cfg_out);
+    }, seed + 4000);
+    if (keep != nullptr) {  // removal-only view change: every ring compacted in place of a new sort
+        int m_new = 0;
+        for (int i = 0; i < n_members; ++i) m_new += keep[members[i]] ? 1 : 0;
+        *n_members2_out = m_new;
+        std::vector<unsigned long long> sk3((size_t)K * (size_t)std::max(m_new, 1));
+        for (int k = 0; k < K; ++k)
+            emu::run_block((unsigned)k, (unsigned)K, 1024u, [&] {
+                rapid::ring_compact_kernel(ring_out, sk2.data(), n_members, keep, ring2_out, sk3.data(), m_new);
+            }, seed + 5000 + (unsigned)k);
+    }
+    return 0;
+}
+

@@ -241,3 +241,36 @@ def vote_merge(blocks, prop_cap, quorum, seed=1):
     ref = out[RES_WORDS:].view(np.int32)
     n = int(ref[0])
     return int(out[9]), int(out[1]), int(out[2]), (ref[1: 1 + n].tolist() if n > 0 else None), out[:RES_WORDS].copy()
+
+
+def view_build(hostnames, ports, id_hi, id_lo, K, members, keep=None, seed=1):
+    """The view kernels of rapid_amd/csrc/view_kernels.h under the emulator (std::stable_sort standing in for the device's
+    segmented radix sort): ring keys, rings, observer / subject tables, configuration id of the view over `members`; with
+    `keep` (bool per node) also the rings of a removal-only view change by compaction."""
+    L_ = lib()
+    n = len(hostnames)
+    blob = np.frombuffer(b"".join(hostnames) + b"\0" * 8, dtype=np.uint8).copy()
+    off = np.zeros(n + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(h) for h in hostnames])
+    ports = np.ascontiguousarray(ports, dtype=np.int32)
+    members = np.ascontiguousarray(members, dtype=np.int32)
+    M = len(members)
+    ids = sorted((int(id_hi[m]), int(id_lo[m])) for m in members)  # signed order: high, then low (R/MembershipView.java:474-500)
+    hi = np.array([a for a, _ in ids] + [0], dtype=np.int64)
+    lo = np.array([b for _, b in ids] + [0], dtype=np.int64)
+    out = dict(keys=np.zeros(K * n + 1, dtype=np.int64), ring=np.full(K * max(M, 1), -1, dtype=np.int32),
+               obs=np.full(n * K + 1, -9, dtype=np.int32), subj=np.full(n * K + 1, -9, dtype=np.int32), cfg=np.zeros(1, dtype=np.int64),
+               ring2=np.full(K * max(M, 1), -1, dtype=np.int32), m2=np.zeros(1, dtype=np.int32))
+    keep_a = None if keep is None else np.ascontiguousarray(np.concatenate([np.asarray(keep, dtype=np.uint8), np.zeros(1, dtype=np.uint8)]))
+    p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    L_.emu_view_build.restype = C.c_int
+    rc = L_.emu_view_build(p(blob), p(off), p(ports), n, K, p(members), M, p(hi), p(lo), M, p(keep_a), p(out["keys"]), p(out["ring"]),
+                           p(out["obs"]), p(out["subj"]), p(out["cfg"]), p(out["ring2"]), p(out["m2"]), C.c_ulonglong(seed))
+    assert rc == 0, rc
+    out["keys"] = out["keys"][: K * n].reshape(K, n)
+    out["ring"] = out["ring"][: K * M].reshape(K, M) if M else np.zeros((K, 0), dtype=np.int32)
+    out["obs"], out["subj"] = out["obs"][: n * K].reshape(n, K), out["subj"][: n * K].reshape(n, K)
+    if keep is not None:
+        m2 = int(out["m2"][0])
+        out["ring2"] = out["ring2"][: K * m2].reshape(K, m2)
+    return out

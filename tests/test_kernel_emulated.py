@@ -390,3 +390,34 @@ def test_vote_merge_kernel_equals_the_host_statement(seed):
             if hvoters:
                 assert cut == host[[h["voters"] > 0 for h in host].index(True)]["cut"]
                 assert (hcut is not None) == (votes >= quorum)
+
+
+@pytest.mark.parametrize("n,K,n_members", [(1, 10, 1), (2, 10, 2), (3, 10, 3), (50, 3, 50), (64, 10, 40), (300, 10, 270), (1100, 7, 1100)])
+def test_view_kernels_match_the_oracle(n, K, n_members):
+    """The view kernels (rapid_amd/csrc/view_kernels.h), emulated, against the restated MembershipView: XXH64 ring keys
+    (R/MembershipView.java:562-587; hostnames of every tail length, negative ports), the K rings, observers / subjects of
+    members and expected observers of non-members (:210-322), the configuration id (:544-556, the ordered (v, 37^len)
+    reduction), and the rings of a removal-only view change obtained by compaction instead of a new sort (:167-201)."""
+    rng = np.random.default_rng(77 + n)
+    pop = S.Population.make(n)
+    if n >= 50:  # every XXH64 path: short tails, the 32-byte stripe loop, ports with the sign bit set
+        pop.hostnames = [bytes(rng.integers(33, 127, size=int(l)).astype(np.uint8)) + b"-%d" % i for i, l in enumerate(rng.integers(0, 90, size=n))]
+        pop.ports = rng.integers(-2**31, 2**31 - 1, size=n).astype(np.int32)
+    members = sorted(rng.permutation(n)[:n_members].tolist())
+    reg, oview = oracle_view(pop, K, members)
+    keep = np.zeros(n, dtype=bool)
+    keep[members] = True
+    gone = members[:: max(2, n_members // 7)] if n_members > 3 else []
+    keep[gone] = False
+    got = pyemu.view_build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo, K, members, keep=keep)
+    for k in range(K):
+        for node in range(0, n, max(1, n // 40)):
+            assert int(got["keys"][k, node]) == oview.ringKey(k, node), (k, node)
+        assert np.array_equal(got["ring"][k], oview.getRing(k)), k
+    oobs, osubj, omember = oview.tables(n)
+    assert np.array_equal(got["obs"], oobs) and np.array_equal(got["subj"], osubj)
+    assert int(got["cfg"][0]) == oview.getCurrentConfigurationId()
+    for node in gone:
+        oview.ringDelete(node)
+    for k in range(K):
+        assert np.array_equal(got["ring2"][k], oview.getRing(k)), ("compaction", k)
