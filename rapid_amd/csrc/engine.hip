@@ -125,6 +125,7 @@ struct rapid_engine {
     bool index_ms_pending = false;
     const int* idxwork_clean_at = nullptr;  // the index work area is known to be all zero for this allocation and node count
     int idxwork_clean_n = -1;
+    bool packed_slots = false;  // this round's tally keeps two slots per LDS word
     bool tally_votes_valid = false;  // d_voteback holds the vote statistics of the last tally launch (tally_kernel.h: vote_res)
     bool stats_fresh = false;  // the statistics were zeroed by the index build of this very call
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // timing events, created once (no create / destroy per call, nothing to leak on an error path)
@@ -435,7 +436,7 @@ int build_round_index(rapid_engine* h) {
     hipLaunchKernelGGL(rapid::index_build_block_kernel, dim3(1), dim3(1024), 0, st, d_gmask, h->d_member.p, h->d_obs.p, N, K, L,
                        h->d_dict.p, h->d_decl.p, h->d_node_of_slot.p, h->d_adj_off.p, h->d_adj.p, adj_cap, h->d_tbits.p, h->d_trank.p,
                        h->d_tent.p, tent_cap, d_info, reinterpret_cast<volatile int*>(h->d_mail),
-                       ((h->force_exact & (128 | 256)) != 0 || chunked) ? -1 : 160 * 1024 - rapid::kBlockStatsBytes,  // (lds_max below)
+                       ((h->force_exact & (128 | 256 | 8192)) != 0 || chunked) ? -1 : 160 * 1024 - rapid::kBlockStatsBytes,  // (lds_max below)
                        h->d_stats.p, (int)stats_words(h), h->d_errflags.p, (int)++h->mail_seq,
                        chunked ? h->d_idxblk.p : nullptr, n_chunks);
     HIPCHK(h, hipEventRecord(e1, st));
@@ -459,7 +460,10 @@ int build_round_index(rapid_engine* h) {
 
     // ---- launch geometry: fill the CU's LDS with as many receiver-waves as possible ----
     const int lds_max = 160 * 1024;
-    const int per_wave = rapid::tally_wave_bytes(h->n_slots);
+    // rounds with many hot subjects pack two slots per LDS word and never use the direct tables (tally_kernel.h:
+    // kPackedSlotsMin); testing knob bit 13: packed whatever the number
+    h->packed_slots = h->n_slots > rapid::kPackedSlotsMin || (h->force_exact & 8192) != 0;
+    const int per_wave = rapid::tally_wave_bytes(h->n_slots, h->packed_slots);
     const int sh_direct = rapid::tally_shared_bytes(rapid::kDictDirect, N, h->n_touched, h->n_hot, h->n_adj);
     const int sh_comp = rapid::tally_shared_bytes(rapid::kDictCompressed, N, h->n_touched, h->n_hot, h->n_adj);
     const int sh_mem = rapid::tally_shared_bytes(rapid::kDictMemory, N, h->n_touched, h->n_hot, h->n_adj);
@@ -469,7 +473,7 @@ int build_round_index(rapid_engine* h) {
     // Where the node -> slot dictionary lives: in LDS as plain tables (4 B per node) when at least eight receivers still fit
     // next to them; else compressed (3 bits per node + 4 B per node the alert set names: 100,000 nodes in ~25 KB); else in
     // memory.  Testing knob: bit 7 = never direct, bit 8 = never in LDS at all.
-    const bool no_direct = (h->force_exact & (128 | 256)) != 0 || info[7] == 0, no_lds = (h->force_exact & 256) != 0;  // info[7]: the build kernel's own verdict
+    const bool no_direct = (h->force_exact & (128 | 256)) != 0 || info[7] == 0 || h->packed_slots, no_lds = (h->force_exact & 256) != 0;  // info[7]: the build kernel's own verdict
     if (!no_direct && sh_direct + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
         h->dict_mode = rapid::kDictDirect;
     else if (!no_lds && compressed_ok && sh_comp + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
@@ -571,13 +575,18 @@ int launch_tally(rapid_engine* h) {
     // delivered records themselves) the caller vouches that the deliveries are copies of them; bit6 of the testing knob: never
     const bool trusted = h->trusted && (h->n_alert_set < 0 || h->trust_copies) && (h->force_exact & 64) == 0;
     const size_t lds = (size_t)h->lds_bytes;
-    switch (h->dict_mode * 2 + (trusted ? 1 : 0)) {
+    switch ((h->packed_slots ? 8 : 0) + h->dict_mode * 2 + (trusted ? 1 : 0)) {
         case 0: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictMemory, false>), grid, block, lds, h->stream, p); break;
         case 1: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictMemory, true>), grid, block, lds, h->stream, p); break;
         case 2: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictDirect, false>), grid, block, lds, h->stream, p); break;
         case 3: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictDirect, true>), grid, block, lds, h->stream, p); break;
         case 4: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, false>), grid, block, lds, h->stream, p); break;
-        default: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, true>), grid, block, lds, h->stream, p); break;
+        case 5: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, true>), grid, block, lds, h->stream, p); break;
+        case 8: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictMemory, false, true>), grid, block, lds, h->stream, p); break;
+        case 9: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictMemory, true, true>), grid, block, lds, h->stream, p); break;
+        case 12: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, false, true>), grid, block, lds, h->stream, p); break;
+        case 13: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, true, true>), grid, block, lds, h->stream, p); break;
+        default: return fail(h, RAPID_ESTATE, "no tally kernel for dictionary mode %d with packed slots", h->dict_mode);
     }
     return RAPID_OK;
 }
@@ -595,7 +604,11 @@ int prepare_tally(rapid_engine* h) {
         h->stats_fresh = true;
     }
     if (!h->lds_attr_set) {  // once per engine: every instantiation may use the whole 160 KiB of LDS
-        const void* kernels[6] = {reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, false>),
+        const void* kernels[10] = {reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, false, true>),
+                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, true, true>),
+                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictCompressed, false, true>),
+                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictCompressed, true, true>),
+                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, false>),
                                   reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, true>),
                                   reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictDirect, false>),
                                   reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictDirect, true>),
@@ -1651,7 +1664,7 @@ int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, in
 
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on) {
     if (!h) return RAPID_EINVAL;
-    if (((h->force_exact ^ on) & (128 | 256 | 4096)) != 0) h->index_valid = false;  // the launch geometry depends on where the dictionary lives
+    if (((h->force_exact ^ on) & (128 | 256 | 4096 | 8192)) != 0) h->index_valid = false;  // the launch geometry depends on where the dictionary lives
     h->force_exact = on;
     return RAPID_OK;
 }

@@ -330,7 +330,8 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     // (touched = named by the alert set at all), touched nodes before each 32-node word, one entry per touched node ----
     // Skipped when the direct tables will be used anyway -- the same test as the host's (engine.hip: build_round_index), on
     // the same numbers; direct_budget < 0: always build them.  info[7] tells the host which way it went.
-    const bool direct_fits = direct_budget >= 0 && tally_shared_bytes(kDictDirect, n_nodes, 0, n_hot, total) + 8 * tally_wave_bytes(n_hot) <= direct_budget;
+    const bool direct_fits = direct_budget >= 0 && n_hot <= kPackedSlotsMin &&  // (rounds with more hot subjects pack their slots and never use direct tables)
+                             tally_shared_bytes(kDictDirect, n_nodes, 0, n_hot, total) + 8 * tally_wave_bytes(n_hot) <= direct_budget;
     const int n_words = (direct_fits || prebuilt) ? 0 : (n_nodes + 31) / 32;
     const int perw = (n_words + T - 1) / T;
     const int w0 = min(n_words, t * perw), w1 = min(n_words, w0 + perw);

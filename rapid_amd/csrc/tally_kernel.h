@@ -164,8 +164,12 @@ __host__ __device__ inline int tally_shared_bytes(int mode, int n_nodes, int n_t
 }
 // per-workgroup statistics accumulator at the very end of the dynamic LDS segment
 constexpr int kBlockStatsBytes = 112;  // eight counters, the workgroup's claim counter, four vote accumulators
-__host__ __device__ inline int tally_wave_bytes(int n_slots) {
-    return align16((n_slots + kDummySlots) * 4) + kScratchWords * 4 + kUndoCap * 4;
+// Rounds with more than kPackedSlotsMin hot subjects (C5: ~15,000 at N = 10^6) keep TWO slots per LDS word -- a slot's
+// state is 15 bits (K <= 14 ring bits + "flushed") -- so that twice as many receivers fit a CU; they never use the direct
+// dictionary tables.  Below that a slot has a word of its own and an update is one plain ds_or_b32 with no shifting.
+constexpr int kPackedSlotsMin = 4096;
+__host__ __device__ inline int tally_wave_bytes(int n_slots, bool packed = false) {
+    return align16((n_slots + kDummySlots) * (packed ? 2 : 4)) + kScratchWords * 4 + kUndoCap * 4;
 }
 
 // ---- small wave helpers ---------------------------------------------------------------------------------------
@@ -228,6 +232,23 @@ struct SlotDetector {
     __device__ __forceinline__ int count(unsigned int m) const { return __popc(m & kmask); }
     __device__ __forceinline__ unsigned int or_bits(int i, unsigned int bits) const { return atomicOr(&st[i], bits); }
     __device__ __forceinline__ void clear_bits(int i, unsigned int bits) const { atomicAnd(&st[i], ~bits); }
+    __device__ __forceinline__ void sync() const { wave_lds_fence(); }
+};
+
+// Two slots per word (see kPackedSlotsMin): slot i lives in half (i & 1) of word i >> 1.
+struct PackedSlotDetector {
+    unsigned int* st;
+    int n_scan;
+    int H, L;
+    unsigned int kmask;
+    __device__ __forceinline__ unsigned int load(int i) const { return (st[i >> 1] >> (16 * (i & 1))) & 0xFFFFu; }
+    __device__ __forceinline__ void store(int i, unsigned int v) const { reinterpret_cast<unsigned short*>(st)[i] = (unsigned short)v; }
+    __device__ __forceinline__ int count(unsigned int m) const { return __popc(m & kmask); }
+    __device__ __forceinline__ unsigned int or_bits(int i, unsigned int bits) const {
+        const int sh = 16 * (i & 1);
+        return (atomicOr(&st[i >> 1], bits << sh) >> sh) & 0xFFFFu;
+    }
+    __device__ __forceinline__ void clear_bits(int i, unsigned int bits) const { atomicAnd(&st[i >> 1], ~(bits << (16 * (i & 1)))); }
     __device__ __forceinline__ void sync() const { wave_lds_fence(); }
 };
 
@@ -326,7 +347,8 @@ __device__ inline void exact_apply(const D& d, RxScalars& s, int dst, unsigned i
 // proposal U preProposal; both require >= L explicit reports, so only hot slots take part and every triple is one
 // potential implicit report.  A few hundred triples, 64 per step.  Returns the number of H crossings caused; logs
 // every bit actually set when undo != nullptr.
-__device__ inline int invalidate_pairs(const SlotDetector& d, const unsigned int* pairs, unsigned int* undo, int* n_undo, int lane,
+template <class D>
+__device__ inline int invalidate_pairs(const D& d, const unsigned int* pairs, unsigned int* undo, int* n_undo, int lane,
                                        int* n_applied) {
     int nH = 0;
     const int np = uniform((int)pairs[0]);
@@ -383,7 +405,8 @@ __device__ inline int invalidate_table(const TableDetector& d, int lane) {
 
 // EXACT end-of-batch step of the population kernel: invalidateFailingEdges as invoked at
 // R/MembershipService.java:330.  A pass can only apply something if a subject crossed L since the previous one.
-__device__ inline void exact_batch_end(const SlotDetector& d, RxScalars& s, const unsigned int* pairs, int lane, int* n_applied) {
+template <class D>
+__device__ inline void exact_batch_end(const D& d, RxScalars& s, const unsigned int* pairs, int lane, int* n_applied) {
     if (!s.seen_down || !s.entered) return;
     const int nH = invalidate_pairs(d, pairs, nullptr, nullptr, lane, n_applied);
     s.entered = false;
@@ -411,7 +434,7 @@ struct Window {  // the dwords of kQ x 64 records that the tally looks at, lane 
 };
 enum { kApplied = 0, kWitnessFails = 1, kNotFastable = 2 };  // outcome of a fast-window attempt
 
-template <int kDictMode, bool kTrusted>
+template <int kDictMode, bool kTrusted, bool kPacked = false>
 __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kernel(TallyParams p) {
     constexpr bool kTablesInLds = kDictMode == kDictDirect;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -484,7 +507,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // the same eight global words at the end of their lives queue up behind each other in one L2 channel -- measured:
     // 0.13 ms of a 0.63 ms kernel, and every stream that crosses that channel waits with them.
     unsigned long long* const block_stats =
-        reinterpret_cast<unsigned long long*>(smem + shared_bytes + (int)(blockDim.x >> 6) * tally_wave_bytes(n_hot));
+        reinterpret_cast<unsigned long long*>(smem + shared_bytes + (int)(blockDim.x >> 6) * tally_wave_bytes(n_hot, kPacked));
     unsigned int* const block_claims = reinterpret_cast<unsigned int*>(block_stats + 8);  // receivers claimed by this workgroup
     if (threadIdx.x < 8u) block_stats[threadIdx.x] = 0ull;
     unsigned long long* const block_votes = block_stats + 10;  // [4], see TallyParams::vote_acc
@@ -496,12 +519,12 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     __syncthreads();
 
     // ---- this wave's private LDS ----
-    const int state_bytes = align16((n_hot + kDummySlots) * 4);
-    unsigned char* const mine = smem + shared_bytes + wave * tally_wave_bytes(n_hot);
+    const int state_bytes = align16((n_hot + kDummySlots) * (kPacked ? 2 : 4));
+    unsigned char* const mine = smem + shared_bytes + wave * tally_wave_bytes(n_hot, kPacked);
     unsigned int* const scratch = reinterpret_cast<unsigned int*>(mine + state_bytes);
     unsigned int* const undo = scratch + kScratchWords;
 
-    SlotDetector d;
+    typename std::conditional<kPacked, PackedSlotDetector, SlotDetector>::type d;
     d.st = reinterpret_cast<unsigned int*>(mine);
     d.n_scan = n_hot;
     d.H = p.H;
