@@ -164,10 +164,13 @@ __host__ __device__ inline int tally_shared_bytes(int mode, int n_nodes, int n_t
 }
 // per-workgroup statistics accumulator at the very end of the dynamic LDS segment
 constexpr int kBlockStatsBytes = 112;  // eight counters, the workgroup's claim counter, four vote accumulators
-// Rounds with more than kPackedSlotsMin hot subjects (C5: ~15,000 at N = 10^6) keep TWO slots per LDS word -- a slot's
-// state is 15 bits (K <= 14 ring bits + "flushed") -- so that twice as many receivers fit a CU; they never use the direct
-// dictionary tables.  Below that a slot has a word of its own and an update is one plain ds_or_b32 with no shifting.
-constexpr int kPackedSlotsMin = 4096;
+// A round may keep TWO slots per LDS word -- a slot's state is 15 bits (K <= 14 ring bits + "flushed") -- so that twice as
+// many receivers fit a CU when a round has very many hot subjects (C5: ~15,000 at N = 10^6: 60 KB of state per receiver
+// otherwise); such rounds never use the direct dictionary tables.  Parity-green on the device, but MEASURED without gain
+// where it was tried (N = 10^6, 1,024 receivers: 2.44 ms packed vs 2.34 ms with a word per slot -- that round is bound
+// by its dictionary reads from memory, not by occupancy), so the threshold below keeps it off: no round has more than
+// 16,318 hot subjects.  rapid_sim_set_force_exact bit 13 selects it for tests and further measurements.
+constexpr int kPackedSlotsMin = 16384;
 __host__ __device__ inline int tally_wave_bytes(int n_slots, bool packed = false) {
     return align16((n_slots + kDummySlots) * (packed ? 2 : 4)) + kScratchWords * 4 + kUndoCap * 4;
 }
