@@ -381,8 +381,8 @@ int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, in
  * all-reduces (never the all-gather + merge of the ranks' local counts), 1024 = every receiver dealt to the workgroups
  * statically (no common pool for the last eighth), 2048 = the vote count never uses the statistics the tally kernel gathers
  * (always a counting pass), 4096 = the round index built by several workgroups (the form of populations >= 40,000 nodes)
- * whatever the size, 8192 = two slots per LDS word in the tally (the form of rounds with more than 4,096 hot subjects)
- * whatever their number, 32 = measurement only:
+ * whatever the size, 8192 = two slots per LDS word in the tally (twice the receivers per CU in rounds with very many hot
+ * subjects; built, parity-checked, measured without gain so far and therefore never chosen by itself), 32 = measurement only:
  * stream the records through the registers without tallying them (results are meaningless) */
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);
 /* testing aids for the sharded vote count (one GPU standing in for n ranks): the answer block this engine's voters

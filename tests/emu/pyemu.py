@@ -125,7 +125,7 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     from the kernel's common pool."""
     if pool:
         force_exact = force_exact | 512
-    if packed:  # two slots per LDS word (the form of rounds with > 4,096 hot subjects); dictionary modes 0 and 2 only
+    if packed:  # two slots per LDS word (the packed detector); dictionary modes 0 and 2 only
         assert tables_in_lds in (0, 2)
         force_exact = force_exact | 2048
     L_ = lib()
