@@ -163,14 +163,16 @@ int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64
  * next call that reads results (rapid_sim_results, rapid_sim_count_votes, rapid_sim_round, rapid_sim_proposal) return
  * RAPID_EINVAL: the round's results are void, the set was wrong. */
 int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, int64_t n_alerts);
-/* Opt-in, per loaded stream set (a load resets it): the caller VOUCHES that every delivered record is a byte-identical copy
- * of a declared alert, configuration id included (true when the streams are replays of this round's broadcasts; false as
- * soon as late deliveries of an earlier configuration can be among them, e.g. BASELINE configs[4]).  If in addition every
- * declared alert passes the filter under the current view, the tally then does not re-read the configuration id of the
- * delivered records (8 of their 20 bytes: fewer load instructions, same HBM traffic).  Still checked per delivery:
- * subject range, UP / DOWN against the membership, rings covered by the index -> RAPID_EINVAL as above.  NOT detected
- * under this promise: a delivered record that equals a declared alert in subject, rings and status but carries another
- * configuration id -- it is tallied, where the reference would drop it. */
+/* Opt-in, per loaded stream set (a load resets it): asks the tally not to re-read the configuration id of every delivered
+ * record (8 of the 16 resident bytes per record: half the HBM traffic of a launch).  The request is honoured on VERIFIED facts
+ * only -- nothing rests on the caller's word: (1) when the streams were loaded, the pass that splits the 20-byte records
+ * compared every record's configuration id with the view's current one (the bytes pass through it anyway) and found no
+ * other; (2) the view has not changed since; (3) every declared alert passes the filter of R/MembershipService.java:644-675
+ * under the current view.  If any of these fails -- e.g. late deliveries of an earlier configuration are among the streams,
+ * BASELINE configs[4] -- the tally silently runs the per-delivery filter instead and drops those records as the reference
+ * does (:653-657).  Checked per delivery either way: subject range, UP / DOWN against the membership, rings covered by the
+ * index -> RAPID_EINVAL as above.  A delivered record that passes these checks passes the reference's filter, so the
+ * results are the reference's for ANY stream that is accepted, not only for byte copies of the declared alerts. */
 int rapid_sim_trust_alert_copies(rapid_engine* h, int32_t on);
 /* Starts another round over the streams (and the declared alert set) that are loaded: the per-round index is built again
  * by the next tally, as it is after a load.  What a round costs = index + tally + vote count; bench.py times exactly that. */
@@ -185,9 +187,11 @@ int rapid_sim_results(rapid_engine* h, int32_t* emit_batch, int32_t* num_proposa
 int rapid_sim_proposal(rapid_engine* h, int32_t receiver, int32_t* out, int32_t cap, int32_t* n_out);
 
 /* ---- fast round over the population (R/FastPaxos.java:125-156) -----------------------------------------
- * Every receiver that announced a proposal votes for it; identical proposals are counted (fingerprint
- * histogram, verified element by element), summed over all ranks with one RCCL all-reduce when the engine
- * has a communicator, and the quorum test N - floor((N-1)/4) is applied with N = current membership size. */
+ * Every receiver that announced a proposal votes for it; identical proposals are counted and verified element by
+ * element (nothing is decided on fingerprints alone).  With a communicator every rank settles its own voters (candidate =
+ * its lowest voter's proposal, verified votes, voters), ONE RCCL all-gather moves the ranks' answer blocks and every rank
+ * merges them identically; only a round whose ranks hold different candidates without a quorum falls back to the
+ * all-reduce of the positional vote histogram.  The quorum test N - floor((N-1)/4) uses N = current membership size. */
 typedef struct rapid_round_result {
     int32_t decided;            /* 1 if some proposal reached the fast quorum */
     int32_t cut_size;           /* size of the decided proposal */
@@ -344,7 +348,8 @@ int rapid_decode_consensus_message(const rapid_endpoint_map* m, int32_t kind, co
 int rapid_encode_consensus_request(const rapid_endpoint_map* m, const rapid_consensus_msg* msg, const int32_t* endpoints,
                                    uint8_t* out, int64_t cap, int64_t* len_out);
 
-/* ---- multi-GPU: one engine per rank, receivers sharded, vote histogram all-reduced over RCCL/xGMI ------- */
+/* ---- multi-GPU: one engine per rank, receivers sharded; per round one RCCL all-gather of the ranks' vote answers
+ * over xGMI + the same merge on every rank (fallback: all-reduce of the vote histogram) ------- */
 #define RAPID_UNIQUE_ID_BYTES 128
 int rapid_comm_unique_id(uint8_t out[RAPID_UNIQUE_ID_BYTES]); /* rank 0 creates, host layer broadcasts */
 int rapid_engine_comm_init(rapid_engine* h, const uint8_t id[RAPID_UNIQUE_ID_BYTES], int32_t rank, int32_t n_ranks);

@@ -119,7 +119,12 @@ struct rapid_engine {
     DevBuf<unsigned char> d_alert_set;  // the round's distinct alerts, if the host declared them
     long long n_alert_set = -1;
     bool trusted = false, all_down = false;
-    bool trust_copies = false;  // the caller's promise that every delivered record is a byte copy of a declared alert
+    bool trust_copies = false;  // the caller's request to skip the per-delivery configuration-id check (honoured only if verified at load)
+    // what split_records_kernel saw when the loaded streams passed through it: the configuration they were compared with and
+    // whether EVERY delivered record carried it (R/MembershipService.java:653-657 drops the others)
+    long long load_cfg_id = 0;
+    bool load_all_current = false;
+    DevBuf<unsigned int> d_loadflags;
     DevBuf<unsigned int> d_adj;
     hipEvent_t ev_idx0 = nullptr, ev_idx1 = nullptr;  // around the round-index kernels; read lazily (rapid_sim_index_info)
     bool index_ms_pending = false;
@@ -348,7 +353,7 @@ int ensure_mailbox(rapid_engine* h) {
     if (h->h_mail) (void)hipHostFree(h->h_mail);
     h->h_mail = nullptr;
     h->h_pinned = nullptr;
-    HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_mail), need, hipHostMallocMapped));
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_mail), need, hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_mail), h->h_mail, 0));
     std::memset(h->h_mail, 0, need);
     h->mail_bytes = need;
@@ -369,7 +374,9 @@ static int await_mail(rapid_engine* h, int word_index, unsigned int want) {
                 std::atomic_thread_fence(std::memory_order_acquire);
                 return RAPID_OK;
             }
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#endif
         }
         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
@@ -519,6 +526,18 @@ int build_round_index(rapid_engine* h) {
     return RAPID_OK;
 }
 
+// The instantiation without the per-delivery configuration-id check runs only on VERIFIED facts: either every delivered
+// record went through the validation pass itself (nothing declared: index_touch_kernel<true> saw them all), or the declared
+// alerts all pass the filter under the current view, the caller asked for it, and split_records_kernel found the current
+// configuration id on every record when the streams were loaded (and the view has not changed since).  What a delivered
+// record can then still get wrong -- subject range, UP / DOWN against the membership, rings the index was not built for --
+// is checked per delivery by the kernel (RAPID_EINVAL).  Testing knob bit 6: never.
+bool tally_is_trusted(const rapid_engine* h) {
+    if (!h->trusted || (h->force_exact & 64) != 0) return false;
+    if (h->n_alert_set < 0) return true;
+    return h->trust_copies && h->load_all_current && h->load_cfg_id == h->config_id;
+}
+
 int launch_tally(rapid_engine* h) {
     rapid::TallyParams p;
     p.core = h->d_core.p;
@@ -573,7 +592,7 @@ int launch_tally(rapid_engine* h) {
     const dim3 grid((unsigned)h->grid_blocks), block((unsigned)h->waves_per_block * 64u);
     // pre-validated instantiation: the scanned alerts all pass the filter AND (when they are a declared set rather than the
     // delivered records themselves) the caller vouches that the deliveries are copies of them; bit6 of the testing knob: never
-    const bool trusted = h->trusted && (h->n_alert_set < 0 || h->trust_copies) && (h->force_exact & 64) == 0;
+    const bool trusted = tally_is_trusted(h);
     const size_t lds = (size_t)h->lds_bytes;
     switch ((h->packed_slots ? 8 : 0) + h->dict_mode * 2 + (trusted ? 1 : 0)) {
         case 0: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictMemory, false>), grid, block, lds, h->stream, p); break;
@@ -691,7 +710,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_core.release(); h->d_cfg.release(); h->d_stage.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
     h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_idxblk.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release(); h->d_trank.release(); h->d_tbits.release(); h->d_tent.release();
-    h->d_adj_off.release(); h->d_node_of_slot.release();
+    h->d_adj_off.release(); h->d_node_of_slot.release(); h->d_loadflags.release();
     h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release(); h->d_voteback.release(); h->d_gather.release();
     (void)hipGetLastError();
     delete h;
@@ -755,7 +774,7 @@ int rapid_view_register_endpoints(rapid_engine* h, const uint8_t* hostnames, con
     if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
     if (n_new < 0 || (n_new > 0 && (!hostnames || !host_off || !ports || !id_hi || !id_lo)) || (n_new > 0 && host_off[0] < 0))
         return fail(h, RAPID_EINVAL, "bad arguments to rapid_view_register_endpoints");
-    if (h->n_nodes + n_new > h->cfg.n_max)
+    if (n_new > h->cfg.n_max - h->n_nodes)
         return fail(h, RAPID_ECAPACITY, "%d registered endpoints + %d new exceed n_max=%d", h->n_nodes, n_new, h->cfg.n_max);
     for (int i = 0; i < n_new; ++i)
         if (host_off[i + 1] < host_off[i]) return fail(h, RAPID_EINVAL, "hostname offsets must not decrease");
@@ -1042,6 +1061,10 @@ static int load_split(rapid_engine* h, const unsigned char* src, bool src_on_dev
     const size_t tail = ((size_t)n_rec * 8 / 16) * 16;  // zeros behind the last record (the split pass below rewrites what it owns)
     HIPCHK(h, hipMemsetAsync(h->d_core.p + tail, 0, core_bytes - tail, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_cfg.p + tail, 0, core_bytes - tail, h->stream));
+    HIPCHK(h, h->d_loadflags.ensure(2));
+    HIPCHK(h, hipMemsetAsync(h->d_loadflags.p, 0, 8, h->stream));
+    h->load_all_current = false;
+    h->load_cfg_id = h->config_id;
     const long long chunk = 12ll << 20;  // records per staging round (240 MiB)
     if (!src_on_device && n_rec > 0) HIPCHK(h, h->d_stage.ensure((size_t)std::min(chunk, n_rec) * 20 + 16));
     for (long long at = 0; at < n_rec; at += chunk) {
@@ -1052,10 +1075,14 @@ static int load_split(rapid_engine* h, const unsigned char* src, bool src_on_dev
             from = h->d_stage.p;
         }
         hipLaunchKernelGGL(rapid::split_records_kernel, dim3((unsigned)std::min<long long>((long long)h->num_cus * 16, (n + 255) / 256)),
-                           dim3(256), 0, h->stream, from, n, reinterpret_cast<uint2*>(h->d_core.p) + at, reinterpret_cast<uint2*>(h->d_cfg.p) + at);
+                           dim3(256), 0, h->stream, from, n, reinterpret_cast<uint2*>(h->d_core.p) + at, reinterpret_cast<uint2*>(h->d_cfg.p) + at,
+                           (long long)h->config_id, h->d_loadflags.p);
     }
+    unsigned int load_flags[2] = {1u, 0u};
+    HIPCHK(h, hipMemcpyAsync(load_flags, h->d_loadflags.p, sizeof load_flags, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
+    h->load_all_current = h->view_built && (load_flags[0] & 1u) == 0u;
     h->records_bytes = core_bytes - 48;
     return RAPID_OK;
 }
@@ -1069,6 +1096,7 @@ static void streams_replaced(rapid_engine* h, int n_receivers, long long n_rec) 
     h->streams_loaded = true;
     h->tallied = false;
     h->have_decision = false;
+    h->tally_votes_valid = false;
 }
 
 int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, const int64_t* rec_off,
@@ -1131,6 +1159,7 @@ int rapid_sim_new_round(rapid_engine* h) {
     h->index_valid = false;  // rebuilt by the next tally, as after a load
     h->tallied = false;
     h->have_decision = false;
+    h->tally_votes_valid = false;
     return RAPID_OK;
 }
 
@@ -1138,6 +1167,7 @@ int rapid_sim_tally(rapid_engine* h) {
     if (!h) return RAPID_EINVAL;
     int rc = use_device(h);
     if (rc) return rc;
+    h->tally_votes_valid = false;  // (set again by the launch below; a call that launches nothing must not leave an older launch's statistics valid)
     if ((rc = prepare_tally(h))) return rc;
     if (!h->stats_fresh) HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * ((size_t)std::max(h->grid_blocks, 1) + 1), h->stream));
     if (h->n_receivers > 0) {
@@ -1638,7 +1668,7 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
     info[2] = h->waves_per_block;
     info[3] = h->grid_blocks;
     info[4] = h->lds_bytes;
-    info[5] = (h->trusted && (h->n_alert_set < 0 || h->trust_copies)) ? 1 : 0;
+    info[5] = tally_is_trusted(h) ? 1 : 0;
     info[6] = h->dict_mode;  // 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS
     info[7] = h->n_alert_set >= 0 ? 1 : 0;
     if (h->index_ms_pending && h->ev_idx0 && h->ev_idx1) {

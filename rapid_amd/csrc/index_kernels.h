@@ -51,13 +51,24 @@ __global__ void index_touch_kernel(const unsigned char* records, const unsigned 
 // The boundary hands over 20-byte records (include/rapid_mi355x.h); resident they are split: core[i] = {dst, ring mask |
 // status << 16 | flags << 24}, cfg[i] = configuration id.  One pass at load time, outside every timed region; 16-byte
 // granules of the source are not aligned with records, so each thread reads its record's five dwords.
-__global__ void split_records_kernel(const unsigned char* records, long long n_records, uint2* core, uint2* cfg) {
+//
+// Every configuration id passes through this kernel anyway, so it is compared with the view's current one right here
+// (R/MembershipService.java:653-657 drops an alert of another configuration): load_flags bit0 = some delivered record
+// carries another id.  The engine selects the tally instantiation that skips the per-delivery id check only for a load
+// whose flag stayed clear (engine.hip: launch_tally) -- the caller's promise costs no traffic to verify.
+__global__ void split_records_kernel(const unsigned char* records, long long n_records, uint2* core, uint2* cfg, long long cfg_id,
+                                     unsigned int* load_flags) {
     const long long stride = (long long)gridDim.x * blockDim.x;
+    const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
+    unsigned int other = 0u;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
         const unsigned int* w = reinterpret_cast<const unsigned int*>(records + i * 20);
-        cfg[i] = make_uint2(w[0], w[1]);
+        const unsigned int c0 = w[0], c1 = w[1];
+        other |= (c0 ^ cfg_lo) | (c1 ^ cfg_hi);
+        cfg[i] = make_uint2(c0, c1);
         core[i] = make_uint2(w[3], w[4]);
     }
+    if (__ballot(other != 0u) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(load_flags, 1u);
 }
 
 // Dictionary format (built by index_build_block_kernel below).  Slot numbering: the hot subjects (>= L distinct rings
@@ -229,6 +240,7 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
         s_pre_hot = 0;
         s_pre_touched = 0;
     }
+    __syncthreads();  // (more than 64 chunks: the adds below come from several waves)
     // the round's launch statistics / pool words and the sticky error flags start at zero: cleared here instead of by
     // memsets of their own between this kernel and the tally (each costs a launch gap)
     for (int i = t; i < n_zero_words; i += T) zero_words[i] = 0ull;

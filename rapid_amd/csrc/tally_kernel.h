@@ -1294,7 +1294,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             atomicAdd(&p.vote_acc[2], block_votes[2]);
             atomicMax(&p.vote_acc[3], block_votes[3]);
         }
+        __threadfence();  // this workgroup's share is visible before its count is (release; once per workgroup)
         if (atomicAdd(&p.vote_acc[4], 1ull) == (unsigned long long)gridDim.x - 1ull) {  // the last workgroup: every other one has added its share
+            __threadfence();  // (acquire)
             const unsigned long long voters = atomicAdd(&p.vote_acc[2], 0ull), repc = atomicAdd(&p.vote_acc[3], 0ull);
             p.vote_res[0] = voters != 0ull ? (~repc & 0xFFFFFFFFull) : 0xFFFFFFFFull;
             p.vote_res[1] = 0ull;

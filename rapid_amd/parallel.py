@@ -3,8 +3,10 @@
 Receivers (simulated nodes) are independent units: each has its own cut-detector state and its own delivered
 alert stream (R/MultiNodeCutDetector.java state is per MembershipService instance).  Rank g of G owns the
 contiguous receiver range shard_range(R, g, G); the view (ring tables, configuration id) is rebuilt redundantly
-and deterministically on every rank.  The only exchange per round is the sum all-reduce of the positional vote
-histogram (rapid_amd/csrc/vote_kernels.h) -- it replaces the N x N unicast fan-out of the fast-round votes
+and deterministically on every rank.  The only exchange per round is ONE all-gather of the ranks' answer blocks
+(candidate proposal, its verified votes, the rank's voters), merged identically on every rank (vote_merge_kernel in
+rapid_amd/csrc/vote_kernels.h); the sum all-reduce of the positional vote histogram is the fallback for rounds whose
+ranks hold different candidates without a quorum.  It replaces the N x N unicast fan-out of the fast-round votes
 (R/UnicastToAllBroadcaster.java:46-52, R/FastPaxos.java:104).
 
 local_candidate / merge_candidates are the host-side statement of the ONE-collective round (every rank's candidate

@@ -574,6 +574,17 @@ def test_full_size_c3_against_fast_oracle(E):
         assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
         for r in range(0, len(fe), 97):
             assert sorted(sim.proposal(r)) == fpp[fo[r]:fo[r + 1]].tolist()
+        # bench.py's own form of the round: the distinct alerts declared (index built from the set, not from the streams) and
+        # the per-delivery configuration-id check waived on the load pass's verdict -- the instantiation `value` is measured with
+        sim_b, res_b = run_population(E, eng, sc.records, sc.rec_off, alert_set=sc.batches.recs, trust=True)
+        info_b = sim_b.index_info()
+        assert info_b["alerts_prevalidated"] == 1 and info_b["alert_set_declared"] == 1 and info_b["dict_mode"] == 1
+        assert all(np.array_equal(a_, b_) for a_, b_ in zip((emit, nprop, pcount, fp), res_b))
+        for r in range(0, len(fe), 997):
+            assert sorted(sim_b.proposal(r)) == fpp[fo[r]:fo[r + 1]].tolist()
+        sim_b, res_b = run_population(E, eng, sc.records, sc.rec_off, alert_set=sc.batches.recs, trust=False)
+        assert sim_b.index_info()["alerts_prevalidated"] == 0
+        assert all(np.array_equal(a_, b_) for a_, b_ in zip((emit, nprop, pcount, fp), res_b))
         # ... and the faithful restatement of the Java (quadratic: a sample of >= 200 receivers) on the same streams
         rx = np.arange(0, len(fe), len(fe) // 210)
         sub_off = np.zeros(len(rx) + 1, dtype=np.int64)
@@ -904,6 +915,26 @@ def test_declared_alert_set_that_does_not_cover_the_streams_is_rejected(E):
     assert all(np.array_equal(a, b) for a, b in zip(res2, res2b))
     fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, bad, sc.rec_off, nthreads=8)
     assert np.array_equal(res2[0], fe) and np.array_equal(res2[2], np.diff(fo))
+    # The request not to re-check the configuration id per delivery is honoured on verified facts only: ONE delivered copy
+    # with another configuration id (a late delivery, R/MembershipService.java:653-657) is seen by the load pass, the tally
+    # runs the per-delivery filter, and the record is dropped as the reference drops it -- same results as without the
+    # request, as without any declaration, and as the oracle fed the same bytes
+    late = sc.records.copy()
+    k = int(np.flatnonzero(np.isin(late["dst"], sc.faulty))[11])
+    late["cfg_id"][k] = cfg + 5
+    sim, res_t = run_population(E, eng, late, sc.rec_off, alert_set=sc.batches.recs, trust=True)
+    assert sim.index_info()["alerts_prevalidated"] == 0  # the fast instantiation was NOT selected
+    sim, res_u = run_population(E, eng, late, sc.rec_off, alert_set=sc.batches.recs, trust=False)
+    sim, res_n = run_population(E, eng, late, sc.rec_off)
+    fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, late, sc.rec_off, nthreads=8)
+    for res_x in (res_t, res_u, res_n):
+        assert np.array_equal(res_x[0], fe) and np.array_equal(res_x[1], fn) and np.array_equal(res_x[2], np.diff(fo))
+        assert np.array_equal(res_x[3], proposal_fingerprints(fo, fpp, fe >= 0))
+    # clean streams: the request is honoured (and, unrequested, it is not)
+    sim, res_c = run_population(E, eng, sc.records, sc.rec_off, alert_set=sc.batches.recs, trust=True)
+    assert sim.index_info()["alerts_prevalidated"] == 1 and all(np.array_equal(a, b) for a, b in zip(want, res_c))
+    sim, res_c = run_population(E, eng, sc.records, sc.rec_off, alert_set=sc.batches.recs, trust=False)
+    assert sim.index_info()["alerts_prevalidated"] == 0 and all(np.array_equal(a, b) for a, b in zip(want, res_c))
     # a set stamped with another configuration id is not trusted at all: same results as without it
     stale = sc.batches.recs.copy()
     stale["cfg_id"] = cfg + 1
@@ -971,6 +1002,41 @@ def test_c4_shaped_shard_against_fast_oracle(E):
     assert np.all(fe >= 0) and sorted(sim.proposal(0)) == sc.faulty.tolist()
     rr = sim.count_votes()
     assert rr.votes_winner == len(rx) and rr.decided == 0 and rr.quorum == n - (n - 1) // 4  # a shard alone has no quorum
+
+
+def test_c4_full_shard_against_fast_oracle(E):
+    """BASELINE configs[3] exactly as `bench.py --config C4 --gpus 1` runs it: shard 0 of the eight (all 12,375 receivers
+    of P.shard_range(99,000, 0, 8), ~122 M delivered records), the round's alerts declared and the per-delivery
+    configuration-id check waived on the load pass's verdict.  Every receiver against the optimised CPU formulation
+    (announcing batch, getNumProposals, proposal size, proposal contents through the fingerprints); the same streams
+    through the per-delivery filter give the same results; a shard alone has no quorum."""
+    from rapid_amd import parallel as P
+    n, K, H, L = 100000, 10, 9, 4
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sc0 = S.build_scenario("C4", subj, cfg, materialise=False)
+    lo, hi = P.shard_range(len(sc0.receivers), 0, 8)
+    rx = sc0.receivers[lo:hi]
+    assert len(rx) == 12375
+    records, rec_off, nb = S.deliver(sc0.batches, rx, seed_delivery=2)  # bench.py's delivery seed
+    fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, records, rec_off, nthreads=64)
+    want_fp = proposal_fingerprints(fo, fpp, fe >= 0)
+    sim, (emit, nprop, pcount, fp) = run_population(E, eng, records, rec_off, alert_set=sc0.batches.recs, trust=True)
+    info = sim.index_info()
+    assert info["alerts_prevalidated"] == 1 and info["dict_mode"] == 2
+    assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
+    assert np.array_equal(fp, want_fp)
+    assert np.all(fe >= 0) and np.all(pcount == len(sc0.faulty))
+    for r in (0, 6000, len(rx) - 1):
+        assert sorted(sim.proposal(r)) == sc0.faulty.tolist()
+    rr = sim.count_votes()
+    assert rr.votes_winner == len(rx) and rr.decided == 0 and rr.quorum == n - (n - 1) // 4
+    sim, res_f = run_population(E, eng, records, rec_off, alert_set=sc0.batches.recs, trust=False)
+    assert sim.index_info()["alerts_prevalidated"] == 0
+    assert all(np.array_equal(a_, b_) for a_, b_ in zip((emit, nprop, pcount, fp), res_f))
+    eng.close()
 
 
 # ------------------------------------------------------------------ C5: streaming rounds, stale records, quirk Q4
@@ -1076,6 +1142,67 @@ def test_streaming_rounds_at_100k_nodes(E):
         assert new_cfg == oview.getCurrentConfigurationId() and view.getMembershipSize() == oview.getMembershipSize()
         for s_ in (int(sc.joiners[0]), int(sc.receivers[0]), int(sc.receivers[-1])):
             assert view.getObserversOf(s_) == oview.computeObserversOf(s_)
+
+
+def test_streaming_rounds_at_one_million_nodes(E):
+    """BASELINE configs[4] at its own population: N = 1,000,000 members, K = 10, continuous churn -- every round 10,000
+    members crash and 5,000 nodes join (15,000 subjects in flux), 1 % of the delivered records are late deliveries of the
+    previous configuration (R/MembershipService.java:653-657), the round's cut is applied (R/MembershipService.java:385-430)
+    and the next round runs in the new configuration.  Two consecutive rounds, 256 simulated receivers per round (one GPU's
+    sample of the population: ~150,000 delivered records each): EVERY receiver against the optimised oracle (announcing
+    batch, getNumProposals, proposal size and contents), and after each view change the configuration id, the membership
+    size and sampled observer lists against the oracle's MembershipView, whose rings went through the same
+    ringDelete / ringAdd sequence (R/MembershipView.java:123-201)."""
+    K, H, L = 10, 9, 4
+    n_mem, spare, rounds, n_rx = 1000000, 12000, 2, 256
+    pop = S.Population.make(n_mem + spare)
+    members = list(range(n_mem))
+    eng, view = make_engine(E, pop, K, H, L, members=members, max_cut=16384)
+    reg, oview = oracle_view(pop, K, members)
+    st = S.StreamingChurn(H, L, receivers_per_round=n_rx)
+    sim = E.ClusterSimulation(eng)
+    guard = E.ObserverCacheGuard()
+    for rnd in range(rounds):
+        obs, subj, member = view.tables()
+        cfg = view.getCurrentConfigurationId()
+        assert cfg == oview.getCurrentConfigurationId()
+        sc = st.next_round(obs, member, cfg)
+        assert len(sc.receivers) == n_rx and len(sc.crashed) >= 9900 and len(sc.joiners) >= 4900
+        if rnd > 0:
+            assert 0 < int((sc.records["cfg_id"] != cfg).sum()) < len(sc.records) // 50  # the late deliveries are there
+        assert guard.check_round(view, sc.faulty[:: 50]) == []  # Q4 (sampled: the guard is host-side bookkeeping)
+        sim.load_streams(sc.records, sc.rec_off)
+        sim.set_alert_set(sc.batches.recs, trust_copies=True)  # asked for; honoured only in round 0 (no late deliveries there)
+        sim.tally()
+        assert sim.index_info()["alerts_prevalidated"] == (1 if rnd == 0 else 0)
+        emit, nprop, pcount, fp = sim.results()
+        fe, fn, fo, fpp = O.fast_sim_run(pop.n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=64)
+        assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
+        assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
+        if rnd == 0:  # nothing is lost in the first round: every receiver announces the whole fault set, and they agree
+            assert np.all(fe >= 0) and np.all(pcount == len(sc.faulty))
+            assert sorted(sim.proposal(0)) == sc.faulty.tolist()
+            rr = sim.count_votes()
+            assert rr.votes_winner == n_rx and rr.cut_size == len(sc.faulty)
+        for r_ in np.flatnonzero(fe >= 0)[:3]:
+            assert sorted(fpp[fo[r_]:fo[r_ + 1]].tolist()) == sc.faulty.tolist()
+        # the cut the round settles on, applied in the order FastPaxos hands it over (ring-0 order of the decided list is
+        # irrelevant to the resulting view: deletes and adds commute on the sorted sets)
+        cut = sc.faulty.tolist()
+        new_cfg = sim.apply_cut(cut)
+        is_member = member != 0
+        for node in cut:  # decideViewChange on the oracle's view (R/MembershipService.java:394-413), joiner ids from the registry
+            if is_member[node]:
+                oview.ringDelete(int(node))
+            else:
+                oview.ringAdd(int(node), (int(pop.id_hi[node]), int(pop.id_lo[node])))
+        guard.on_view_change(sc.crashed)
+        assert new_cfg == oview.getCurrentConfigurationId() == view.getCurrentConfigurationId()
+        assert view.getMembershipSize() == oview.getMembershipSize() == int(is_member.sum()) - len(sc.crashed) + len(sc.joiners)
+        for s_ in (int(sc.joiners[0]), int(sc.joiners[-1]), int(sc.receivers[0]), int(sc.receivers[-1])):
+            assert view.getObserversOf(s_) == oview.computeObserversOf(s_)
+            assert view.getSubjectsOf(s_) == oview.getSubjectsOf(s_)
+    eng.close()
 
 
 # ------------------------------------------------------------------ f3: serialized rapid.proto bytes -> device tally
