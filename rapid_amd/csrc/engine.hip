@@ -123,14 +123,13 @@ struct rapid_engine {
     // what split_records_kernel saw when the loaded streams passed through it: the configuration they were compared with and
     // whether EVERY delivered record carried it (R/MembershipService.java:653-657 drops the others)
     long long load_cfg_id = 0;
-    bool load_all_current = false;
+    bool load_all_current = false, load_in_range = false;
     DevBuf<unsigned int> d_loadflags;
     DevBuf<unsigned int> d_adj;
     hipEvent_t ev_idx0 = nullptr, ev_idx1 = nullptr;  // around the round-index kernels; read lazily (rapid_sim_index_info)
     bool index_ms_pending = false;
     const int* idxwork_clean_at = nullptr;  // the index work area is known to be all zero for this allocation and node count
     int idxwork_clean_n = -1;
-    bool packed_slots = false;  // this round's tally keeps two slots per LDS word
     bool tally_votes_valid = false;  // d_voteback holds the vote statistics of the last tally launch (tally_kernel.h: vote_res)
     bool stats_fresh = false;  // the statistics were zeroed by the index build of this very call
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // timing events, created once (no create / destroy per call, nothing to leak on an error path)
@@ -467,10 +466,7 @@ int build_round_index(rapid_engine* h) {
 
     // ---- launch geometry: fill the CU's LDS with as many receiver-waves as possible ----
     const int lds_max = 160 * 1024;
-    // rounds with many hot subjects pack two slots per LDS word and never use the direct tables (tally_kernel.h:
-    // kPackedSlotsMin); testing knob bit 13: packed whatever the number
-    h->packed_slots = h->n_slots > rapid::kPackedSlotsMin || (h->force_exact & 8192) != 0;
-    const int per_wave = rapid::tally_wave_bytes(h->n_slots, h->packed_slots);
+    const int per_wave = rapid::tally_wave_bytes(h->n_slots);
     const int sh_direct = rapid::tally_shared_bytes(rapid::kDictDirect, N, h->n_touched, h->n_hot, h->n_adj);
     const int sh_comp = rapid::tally_shared_bytes(rapid::kDictCompressed, N, h->n_touched, h->n_hot, h->n_adj);
     const int sh_mem = rapid::tally_shared_bytes(rapid::kDictMemory, N, h->n_touched, h->n_hot, h->n_adj);
@@ -480,7 +476,7 @@ int build_round_index(rapid_engine* h) {
     // Where the node -> slot dictionary lives: in LDS as plain tables (4 B per node) when at least eight receivers still fit
     // next to them; else compressed (3 bits per node + 4 B per node the alert set names: 100,000 nodes in ~25 KB); else in
     // memory.  Testing knob: bit 7 = never direct, bit 8 = never in LDS at all.
-    const bool no_direct = (h->force_exact & (128 | 256)) != 0 || info[7] == 0 || h->packed_slots, no_lds = (h->force_exact & 256) != 0;  // info[7]: the build kernel's own verdict
+    const bool no_direct = (h->force_exact & (128 | 256)) != 0 || info[7] == 0, no_lds = (h->force_exact & 256) != 0;  // info[7]: the build kernel's own verdict
     if (!no_direct && sh_direct + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
         h->dict_mode = rapid::kDictDirect;
     else if (!no_lds && compressed_ok && sh_comp + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
@@ -535,7 +531,7 @@ int build_round_index(rapid_engine* h) {
 bool tally_is_trusted(const rapid_engine* h) {
     if (!h->trusted || (h->force_exact & 64) != 0) return false;
     if (h->n_alert_set < 0) return true;
-    return h->trust_copies && h->load_all_current && h->load_cfg_id == h->config_id;
+    return h->trust_copies && h->load_all_current && h->load_in_range && h->load_cfg_id == h->config_id;
 }
 
 int launch_tally(rapid_engine* h) {
@@ -594,18 +590,14 @@ int launch_tally(rapid_engine* h) {
     // delivered records themselves) the caller vouches that the deliveries are copies of them; bit6 of the testing knob: never
     const bool trusted = tally_is_trusted(h);
     const size_t lds = (size_t)h->lds_bytes;
-    switch ((h->packed_slots ? 8 : 0) + h->dict_mode * 2 + (trusted ? 1 : 0)) {
+    switch (h->dict_mode * 2 + (trusted ? 1 : 0)) {
         case 0: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictMemory, false>), grid, block, lds, h->stream, p); break;
         case 1: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictMemory, true>), grid, block, lds, h->stream, p); break;
         case 2: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictDirect, false>), grid, block, lds, h->stream, p); break;
         case 3: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictDirect, true>), grid, block, lds, h->stream, p); break;
         case 4: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, false>), grid, block, lds, h->stream, p); break;
         case 5: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, true>), grid, block, lds, h->stream, p); break;
-        case 8: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictMemory, false, true>), grid, block, lds, h->stream, p); break;
-        case 9: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictMemory, true, true>), grid, block, lds, h->stream, p); break;
-        case 12: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, false, true>), grid, block, lds, h->stream, p); break;
-        case 13: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, true, true>), grid, block, lds, h->stream, p); break;
-        default: return fail(h, RAPID_ESTATE, "no tally kernel for dictionary mode %d with packed slots", h->dict_mode);
+        default: return fail(h, RAPID_ESTATE, "no tally kernel for dictionary mode %d", h->dict_mode);
     }
     return RAPID_OK;
 }
@@ -616,6 +608,24 @@ int prepare_tally(rapid_engine* h) {
     HIPCHK(h, h->d_errflags.ensure(2));
     HIPCHK(h, h->d_stats.ensure(stats_words(h)));
     HIPCHK(h, h->d_voteback.ensure((10 * 8 + ((size_t)h->max_cut + 1) * sizeof(int) + 7) / 8));  // launch_tally: vote_res
+    if (h->load_cfg_id != h->config_id) {
+        // The view changed while these streams stayed loaded: which records carry the engine's configuration id
+        // (R/MembershipService.java:653-657) is marked in the resident records themselves (tally_kernel.h: kCoreStale), so
+        // the marks are brought up to date -- one pass over the retained ids, once per view change.
+        HIPCHK(h, hipMemsetAsync(h->d_loadflags.p, 0, 8, h->stream));
+        const long long n = h->n_records_total;
+        if (n > 0)
+            hipLaunchKernelGGL(rapid::remark_records_kernel, dim3((unsigned)std::min<long long>((long long)h->num_cus * 16, (n + 255) / 256)), dim3(256), 0,
+                               h->stream, n, reinterpret_cast<uint2*>(h->d_core.p), reinterpret_cast<const uint2*>(h->d_cfg.p), (long long)h->config_id,
+                               h->d_loadflags.p);
+        unsigned int load_flags[2] = {1u, 0u};
+        HIPCHK(h, hipMemcpyAsync(load_flags, h->d_loadflags.p, sizeof load_flags, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipGetLastError());
+        h->load_all_current = (load_flags[0] & 1u) == 0u;
+        h->load_cfg_id = h->config_id;
+        h->index_valid = false;  // (the undeclared index validates against the marks)
+    }
     h->stats_fresh = false;
     if (!h->index_valid) {
         int rc = build_round_index(h);  // also zeroes the error flags and the launch statistics / pool words
@@ -623,11 +633,7 @@ int prepare_tally(rapid_engine* h) {
         h->stats_fresh = true;
     }
     if (!h->lds_attr_set) {  // once per engine: every instantiation may use the whole 160 KiB of LDS
-        const void* kernels[10] = {reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, false, true>),
-                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, true, true>),
-                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictCompressed, false, true>),
-                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictCompressed, true, true>),
-                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, false>),
+        const void* kernels[6] = {reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, false>),
                                   reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, true>),
                                   reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictDirect, false>),
                                   reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictDirect, true>),
@@ -1063,7 +1069,7 @@ static int load_split(rapid_engine* h, const unsigned char* src, bool src_on_dev
     HIPCHK(h, hipMemsetAsync(h->d_cfg.p + tail, 0, core_bytes - tail, h->stream));
     HIPCHK(h, h->d_loadflags.ensure(2));
     HIPCHK(h, hipMemsetAsync(h->d_loadflags.p, 0, 8, h->stream));
-    h->load_all_current = false;
+    h->load_all_current = h->load_in_range = false;
     h->load_cfg_id = h->config_id;
     const long long chunk = 12ll << 20;  // records per staging round (240 MiB)
     if (!src_on_device && n_rec > 0) HIPCHK(h, h->d_stage.ensure((size_t)std::min(chunk, n_rec) * 20 + 16));
@@ -1076,13 +1082,14 @@ static int load_split(rapid_engine* h, const unsigned char* src, bool src_on_dev
         }
         hipLaunchKernelGGL(rapid::split_records_kernel, dim3((unsigned)std::min<long long>((long long)h->num_cus * 16, (n + 255) / 256)),
                            dim3(256), 0, h->stream, from, n, reinterpret_cast<uint2*>(h->d_core.p) + at, reinterpret_cast<uint2*>(h->d_cfg.p) + at,
-                           (long long)h->config_id, h->d_loadflags.p);
+                           (long long)h->config_id, (unsigned int)h->n_nodes, h->d_loadflags.p);
     }
     unsigned int load_flags[2] = {1u, 0u};
     HIPCHK(h, hipMemcpyAsync(load_flags, h->d_loadflags.p, sizeof load_flags, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
-    h->load_all_current = h->view_built && (load_flags[0] & 1u) == 0u;
+    h->load_all_current = h->view_built && (load_flags[0] & 1u) == 0u;  // every record carries the current configuration id
+    h->load_in_range = (load_flags[0] & 2u) == 0u;                      // ... and names a subject the registry knows
     h->records_bytes = core_bytes - 48;
     return RAPID_OK;
 }

@@ -21,7 +21,7 @@ namespace rapid {
 // record fails the filter of R/MembershipService.java:644-675 under the current view (or names a node out of range
 // or no ring), bit1 if any record is an UP alert.
 // Two record sources: the round's declared alert set as it crossed the boundary (20-byte records), or -- when nothing was
-// declared -- every delivered record of the resident split streams (core = dwords 3, 4; cfg = the configuration id).
+// declared -- every delivered record of the resident streams (core entries, 8 bytes each; `cfg` is not read).
 template <bool kSplit>
 __global__ void index_touch_kernel(const unsigned char* records, const unsigned char* cfg, long long n_records, int n_nodes,
                                    unsigned int kmask, long long cfg_id, const unsigned char* member, unsigned int* gmask,
@@ -30,43 +30,66 @@ __global__ void index_touch_kernel(const unsigned char* records, const unsigned 
     const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
     unsigned int f = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
-        unsigned int c0, c1, dst, w4;
-        if (kSplit) {
-            const uint2 a = reinterpret_cast<const uint2*>(records)[i], b = reinterpret_cast<const uint2*>(cfg)[i];
-            dst = a.x, w4 = a.y, c0 = b.x, c1 = b.y;
+        unsigned int dst, cw;  // cw: the resident core word (tally_kernel.h: core_word)
+        bool current;          // the record carries the engine's configuration id
+        if (kSplit) {  // the id was compared when the record became resident (kCoreStale)
+            const uint2 a = reinterpret_cast<const uint2*>(records)[i];
+            dst = a.x & ~kCoreStale, cw = a.y, current = (a.x & kCoreStale) == 0u;
         } else {
             const unsigned int* w = reinterpret_cast<const unsigned int*>(records + i * 20);
-            c0 = w[0], c1 = w[1], dst = w[3], w4 = w[4];
+            dst = w[3], cw = core_word(w[4]), current = w[0] == cfg_lo && w[1] == cfg_hi;
         }
-        const unsigned int bits = w4 & kmask;
-        const bool down = (w4 & 0x00FF0000u) != 0u;
+        const unsigned int bits = cw & kmask;
+        const bool down = (cw & kCoreDown) != 0u;
         if (dst < (unsigned)n_nodes && bits != 0u && (bits & ~gmask[dst]) != 0u) atomicOr(&gmask[dst], bits);
-        const bool ok = c0 == cfg_lo && c1 == cfg_hi && dst < (unsigned)n_nodes && bits != 0u &&
+        const bool ok = current && dst < (unsigned)n_nodes && bits != 0u &&
                         ((member[dst < (unsigned)n_nodes ? dst : 0u] != 0) == down);
         f |= (ok ? 0u : 1u) | (down ? 0u : 2u);
     }
     if (f) atomicOr(vflags, f);
 }
 
-// The boundary hands over 20-byte records (include/rapid_mi355x.h); resident they are split: core[i] = {dst, ring mask |
-// status << 16 | flags << 24}, cfg[i] = configuration id.  One pass at load time, outside every timed region; 16-byte
-// granules of the source are not aligned with records, so each thread reads its record's five dwords.
+// The boundary hands over 20-byte records (include/rapid_mi355x.h); resident they are split: core[i] = {dst, core word
+// (tally_kernel.h: core_word -- ring mask, the status as two bits, the batch end in the sign bit)}, cfg[i] = configuration
+// id.  One pass at load time; 16-byte granules of the source are not aligned with records, so each thread reads its
+// record's five dwords.
 //
 // Every configuration id passes through this kernel anyway, so it is compared with the view's current one right here
 // (R/MembershipService.java:653-657 drops an alert of another configuration): load_flags bit0 = some delivered record
-// carries another id.  The engine selects the tally instantiation that skips the per-delivery id check only for a load
-// whose flag stayed clear (engine.hip: launch_tally) -- the caller's promise costs no traffic to verify.
+// carries another id, bit1 = some record names a subject >= n_nodes.  The engine selects the tally instantiation that skips
+// the per-delivery id check only for a load whose flags stayed clear (engine.hip: launch_tally) -- the caller's promise
+// costs no traffic to verify.
 __global__ void split_records_kernel(const unsigned char* records, long long n_records, uint2* core, uint2* cfg, long long cfg_id,
-                                     unsigned int* load_flags) {
+                                     unsigned int n_nodes, unsigned int* load_flags) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
-    unsigned int other = 0u;
+    unsigned int other = 0u, range = 0u;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
         const unsigned int* w = reinterpret_cast<const unsigned int*>(records + i * 20);
         const unsigned int c0 = w[0], c1 = w[1];
         other |= (c0 ^ cfg_lo) | (c1 ^ cfg_hi);
+        range |= w[3] >= n_nodes ? 1u : 0u;
         cfg[i] = make_uint2(c0, c1);
-        core[i] = make_uint2(w[3], w[4]);
+        // (a subject index that would collide with the mark is no node of any view: kept out of range for good)
+        core[i] = make_uint2((w[3] >= kCoreStale ? kCoreStale - 1u : w[3]) | (((c0 ^ cfg_lo) | (c1 ^ cfg_hi)) != 0u ? kCoreStale : 0u), core_word(w[4]));
+    }
+    const unsigned int f = (__ballot(other != 0u) != 0ull ? 1u : 0u) | (__ballot(range != 0u) != 0ull ? 2u : 0u);
+    if (f != 0u && (threadIdx.x & 63u) == 0u) atomicOr(load_flags, f);
+}
+
+// The view changed while streams stayed loaded: the same comparison against the new configuration id, over the retained ids
+// (8 B per record read, 4 B rewritten; once per view change, and only if the streams are tallied again at all).
+__global__ void remark_records_kernel(long long n_records, uint2* core, const uint2* cfg, long long cfg_id, unsigned int* load_flags) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
+    unsigned int other = 0u;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
+        const uint2 c = cfg[i];
+        const unsigned int stale = ((c.x ^ cfg_lo) | (c.y ^ cfg_hi)) != 0u ? kCoreStale : 0u;
+        other |= stale;
+        unsigned int* const w3 = &core[i].x;
+        const unsigned int old = *w3;
+        if (((old ^ stale) & kCoreStale) != 0u) *w3 = (old & ~kCoreStale) | stale;
     }
     if (__ballot(other != 0u) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(load_flags, 1u);
 }
@@ -342,7 +365,7 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     // (touched = named by the alert set at all), touched nodes before each 32-node word, one entry per touched node ----
     // Skipped when the direct tables will be used anyway -- the same test as the host's (engine.hip: build_round_index), on
     // the same numbers; direct_budget < 0: always build them.  info[7] tells the host which way it went.
-    const bool direct_fits = direct_budget >= 0 && n_hot <= kPackedSlotsMin &&  // (rounds with more hot subjects pack their slots and never use direct tables)
+    const bool direct_fits = direct_budget >= 0 &&
                              tally_shared_bytes(kDictDirect, n_nodes, 0, n_hot, total) + 8 * tally_wave_bytes(n_hot) <= direct_budget;
     const int n_words = (direct_fits || prebuilt) ? 0 : (n_nodes + 31) / 32;
     const int perw = (n_words + T - 1) / T;

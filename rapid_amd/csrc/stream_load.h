@@ -66,4 +66,13 @@ __device__ __forceinline__ void stream_flag_or(unsigned int* p, unsigned int bit
     asm volatile("global_atomic_or %0, %1, off" ::"v"(p), "v"(bits) : "memory");
 }
 
+// Everything computed from a window's registers must be FINISHED before those registers are requested again: if the
+// scheduler lets a use of the old contents sink below the reload (it likes to issue loads early), the reload needs other
+// destination registers, and the loop then closes with copies of a window that is still in flight -- i.e. with
+// s_waitcnt vmcnt(0) in every turn.  This is a point no memory operation crosses, at which the three values that outlive a
+// window (coverage flags, the carried word and its slot) exist in registers.
+__device__ __forceinline__ void stream_settle(unsigned int& a, unsigned int& b, unsigned int& c) {
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c)::"memory");
+}
+
 }  // namespace rapid

@@ -68,13 +68,45 @@ constexpr int kCand = 4;                         // witness candidates kept from
 constexpr int kClaimAhead = 3;                   // windows before the end of a stream at which the next receiver is claimed
 constexpr int kDummySlots = 64;                  // slots n_hot .. n_hot + 63: where reports about subjects that are not hot go
 constexpr int kMaxWavesPerBlock = 16;
-constexpr uint32_t kFlushed = 1u << 14;
+
+// The RESIDENT core word of a delivered record (second dword of core[i]; the first is the subject's node index), written by
+// split_records_kernel from dword 4 of the boundary record {ring mask, status, flags}: the status as TWO bits, exactly
+// one of which is set in a real record and none in the zeros behind a stream's end, so that "this report fails the
+// UP / DOWN filter for this subject" is one AND with the subject's dictionary entry; the batch end in the sign bit, so
+// that it is one signed compare.
+constexpr unsigned int kCoreRings = 0x3FFFu;   // bits 0..13: ring mask (K <= 14)
+constexpr unsigned int kCoreDown = 1u << 14;   // edgeStatus == DOWN
+constexpr unsigned int kCoreUp = 1u << 15;     // edgeStatus == UP
+constexpr unsigned int kCoreEob = 1u << 31;    // last record of its BatchedAlertMessage
+// ... and in the FIRST dword (the subject's node index) bit 31 marks a record whose configuration id is not the one the
+// engine is in (R/MembershipService.java:653-657 drops it): the id is compared where every id passes anyway -- when the
+// records are split at load time, and again by remark_records_kernel if the view changes while streams stay loaded -- so
+// no launch of the tally reads the configuration ids.  A marked subject is out of every node range: the record takes the
+// path of any report about an unknown node (dropped by the per-delivery filter, an error where deliveries are vouched for).
+constexpr unsigned int kCoreStale = 1u << 31;
+__host__ __device__ inline unsigned int core_word(unsigned int boundary_dword4) {
+    return (boundary_dword4 & kCoreRings) | ((boundary_dword4 & 0x00FF0000u) != 0u ? kCoreDown : kCoreUp) |
+           ((boundary_dword4 & 0x01000000u) != 0u ? kCoreEob : 0u);
+}
 
 // dictionary entry (16 bit): bit 15 = node is a member, bit 14 = slot has hot adjacency, bits 0..13 = slot
 constexpr unsigned int kDictMember = 1u << 15;
 constexpr unsigned int kDictHasAdj = 1u << 14;
 constexpr unsigned int kSlotMask = 0x3FFFu;
 constexpr unsigned int kNoSlot = 0x3FFFu;            // at most 16318 hot subjects per round (+ 64 dummy slots)
+
+// What the tally looks up per record -- ONE 32-bit word per node (staged in LDS in the direct mode, assembled from the
+// index's tables in the others), laid out against the core word so that (core & entry) & 0xFFFF != 0 <=> the report is
+// not covered by what the round index was built for:
+//   bits 0..13  rings the round's alert set does NOT name for the node (none for a hot one),
+//   bit 14      a DOWN report about the node fails the filter of R/MembershipService.java:659-668 (it is not a member),
+//   bit 15      an UP report fails it (it is a member),
+//   bits 16..30 2 x slot (a dummy slot for a node that is not hot): shifted right by 16 and added twice it is the byte
+//               offset of the slot's state word; bit 31 = 0 (the batch-end bit of the core word meets nothing).
+__host__ __device__ inline unsigned int dict_entry(unsigned int decl_entry, unsigned int slot) {
+    return (~decl_entry & kCoreRings) | ((decl_entry >> 15) != 0u ? kCoreUp : kCoreDown) | (slot << 17);
+}
+constexpr unsigned int kEntryPoison = kCoreRings | kCoreDown | kCoreUp;  // no report about such a node is covered (| slot << 17)
 
 // decoded record (scratch list, carry): bits 0..13 ring bits to apply (0: fails the filter or subject not hot),
 // bits 14..27 slot, bit 28 = a DOWN report that passed the filter, bit 29 = last record of its batch
@@ -151,7 +183,7 @@ __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
 // dictionary placement: where node -> (slot, declared rings, member) is looked up
 enum { kDictMemory = 0, kDictDirect = 1, kDictCompressed = 2 };
 __host__ __device__ inline int tally_dict_bytes(int mode, int n_nodes, int n_touched) {
-    if (mode == kDictDirect) return 2 * align16(n_nodes * 2);
+    if (mode == kDictDirect) return align16((n_nodes + 1) * 4);  // one dict_entry per node + the entry out-of-range subjects are sent to
     if (mode == kDictCompressed) return align16(((n_nodes + 31) / 32) * 4) + align16(((n_nodes + 31) / 32) * 2) + align16(n_touched * 4);
     return 0;
 }
@@ -164,15 +196,8 @@ __host__ __device__ inline int tally_shared_bytes(int mode, int n_nodes, int n_t
 }
 // per-workgroup statistics accumulator at the very end of the dynamic LDS segment
 constexpr int kBlockStatsBytes = 112;  // eight counters, the workgroup's claim counter, four vote accumulators
-// A round may keep TWO slots per LDS word -- a slot's state is 15 bits (K <= 14 ring bits + "flushed") -- so that twice as
-// many receivers fit a CU when a round has very many hot subjects (C5: ~15,000 at N = 10^6: 60 KB of state per receiver
-// otherwise); such rounds never use the direct dictionary tables.  Parity-green on the device, but MEASURED without gain
-// where it was tried (N = 10^6, 1,024 receivers: 2.44 ms packed vs 2.34 ms with a word per slot -- that round is bound
-// by its dictionary reads from memory, not by occupancy), so the threshold below keeps it off: no round has more than
-// 16,318 hot subjects.  rapid_sim_set_force_exact bit 13 selects it for tests and further measurements.
-constexpr int kPackedSlotsMin = 16384;
-__host__ __device__ inline int tally_wave_bytes(int n_slots, bool packed = false) {
-    return align16((n_slots + kDummySlots) * (packed ? 2 : 4)) + kScratchWords * 4 + kUndoCap * 4;
+__host__ __device__ inline int tally_wave_bytes(int n_slots) {
+    return align16((n_slots + kDummySlots) * 4) + kScratchWords * 4 + kUndoCap * 4;
 }
 
 // ---- small wave helpers ---------------------------------------------------------------------------------------
@@ -226,7 +251,10 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // 
 // ---- detector state accessors ---------------------------------------------------------------------------------
 // LDS flavour (population kernel): indices are slots; sweeps cover the hot slots only.
 struct SlotDetector {
-    unsigned int* st;  // one 32-bit word per hot slot (low 16 bits used): plain ds_or_b32, no sub-word shuffling
+    // one 32-bit word per slot: bits 0..K-1 = rings reported, bit 16 = already flushed into an emitted proposal.  The fast
+    // window ORs whole core words into it, so bits 14, 15 and 31 (status, batch end) hold garbage: every reader masks.
+    static constexpr unsigned int kFlushed = 1u << 16;
+    unsigned int* st;
     int n_scan;        // = n_hot
     int H, L;
     unsigned int kmask;
@@ -238,27 +266,11 @@ struct SlotDetector {
     __device__ __forceinline__ void sync() const { wave_lds_fence(); }
 };
 
-// Two slots per word (see kPackedSlotsMin): slot i lives in half (i & 1) of word i >> 1.
-struct PackedSlotDetector {
-    unsigned int* st;
-    int n_scan;
-    int H, L;
-    unsigned int kmask;
-    __device__ __forceinline__ unsigned int load(int i) const { return (st[i >> 1] >> (16 * (i & 1))) & 0xFFFFu; }
-    __device__ __forceinline__ void store(int i, unsigned int v) const { reinterpret_cast<unsigned short*>(st)[i] = (unsigned short)v; }
-    __device__ __forceinline__ int count(unsigned int m) const { return __popc(m & kmask); }
-    __device__ __forceinline__ unsigned int or_bits(int i, unsigned int bits) const {
-        const int sh = 16 * (i & 1);
-        return (atomicOr(&st[i >> 1], bits << sh) >> sh) & 0xFFFFu;
-    }
-    __device__ __forceinline__ void clear_bits(int i, unsigned int bits) const { atomicAnd(&st[i >> 1], ~(bits << (16 * (i & 1)))); }
-    __device__ __forceinline__ void sync() const { wave_lds_fence(); }
-};
-
 // Global-memory flavour (one MultiNodeCutDetector instance, rapid_cd_*): indices are node indices, the implicit
 // invalidation walks the view's observer table.  Accesses bypass the per-CU L1 (agent scope) because the atomics
 // execute in L2; ordering points drain the vector memory queue.
 struct TableDetector {
+    static constexpr unsigned int kFlushed = 1u << 14;  // 16-bit state words: ring bits 0..K-1 (K <= 14), bit 14 = flushed
     unsigned short* st16;
     unsigned int* st32;
     const int* obs;  // [n_nodes][K]
@@ -297,8 +309,8 @@ __device__ inline void flush_sweep(const D& d, int lane, int* out, int out_cap, 
     for (int i0 = 0; i0 < d.n_scan; i0 += kWave) {
         const int i = i0 + lane;
         const unsigned int m = i < d.n_scan ? d.load(i) : 0u;
-        const bool take = i < d.n_scan && d.count(m) >= d.H && !(m & kFlushed);
-        if (take) d.store(i, m | kFlushed);
+        const bool take = i < d.n_scan && d.count(m) >= d.H && !(m & D::kFlushed);
+        if (take) d.store(i, m | D::kFlushed);
         if (out_n != nullptr) {
             const unsigned long long mk = wave_ballot(take);
             const int idx = *out_n + __popcll(mk & lanes_lt(lane));
@@ -363,7 +375,7 @@ __device__ inline int invalidate_pairs(const D& d, const unsigned int* pairs, un
         const int k = (int)(pr >> 28);
         const unsigned int ms = on ? d.load(sj) : 0u, mo = on ? d.load(ob) : 0u;
         const int cs = d.count(ms), co = d.count(mo);
-        const bool apply = on && cs >= d.L && cs < d.H && co >= d.L && !(mo & kFlushed) && !(ms & (1u << k));
+        const bool apply = on && cs >= d.L && cs < d.H && co >= d.L && !(mo & D::kFlushed) && !(ms & (1u << k));
         unsigned int old = 0;
         if (apply) old = d.or_bits(sj, 1u << k);
         const bool isnew = apply && !(old & (1u << k));
@@ -394,7 +406,7 @@ __device__ inline int invalidate_table(const TableDetector& d, int lane) {
         for (int k = 0; k < d.K; ++k) {
             const int o = inpre ? d.obs[n * d.K + k] : -1;
             const unsigned int mo = o >= 0 ? d.load(o) : 0u;
-            const bool apply = o >= 0 && d.count(mo) >= d.L && !(mo & kFlushed) && !(m & (1u << k));
+            const bool apply = o >= 0 && d.count(mo) >= d.L && !(mo & TableDetector::kFlushed) && !(m & (1u << k));
             unsigned int old = 0;
             if (apply) old = d.or_bits(n, 1u << k);
             const bool isnew = apply && !(old & (1u << k));
@@ -430,14 +442,12 @@ __device__ inline void exact_batch_end(const D& d, RxScalars& s, const unsigned 
 // non-empty ring list) and that every delivered record is a copy of one of them; the kernel then neither loads nor
 // re-checks the configuration id per delivery.
 // --------------------------------------------------------------------------------------------------------------
-template <bool kTrusted>
-struct Window {  // the dwords of kQ x 64 records that the tally looks at, lane l of quarter q = record 64 q + l
-    unsigned int w3[kQ], w4[kQ];  // dst; ring mask | status << 16 | flags << 24
-    unsigned int w0[kTrusted ? 1 : kQ], w1[kTrusted ? 1 : kQ];  // configuration id (not loaded when trusted)
+struct Window {  // the resident core entries of kQ x 64 records, lane l of quarter q = record 64 q + l
+    unsigned int w3[kQ], w4[kQ];  // subject (| kCoreStale); core word
 };
 enum { kApplied = 0, kWitnessFails = 1, kNotFastable = 2 };  // outcome of a fast-window attempt
 
-template <int kDictMode, bool kTrusted, bool kPacked = false>
+template <int kDictMode, bool kTrusted>
 __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kernel(TallyParams p) {
     constexpr bool kTablesInLds = kDictMode == kDictDirect;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -468,20 +478,21 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         trank = l_rank;
         tent = l_ent;
     }
-    const unsigned short* dict = p.idx.dict;
-    const unsigned short* decl = p.idx.decl;
+    const unsigned short* const dict = p.idx.dict;
+    const unsigned short* const decl = p.idx.decl;
+    const unsigned int* entries = nullptr;  // direct mode: dict_entry per node, [n_nodes] = where out-of-range subjects are sent
     if (kTablesInLds) {
-        unsigned short* l_dict = reinterpret_cast<unsigned short*>(smem);
-        unsigned short* l_decl = reinterpret_cast<unsigned short*>(smem + align16(p.n_nodes * 2));
-        for (int i = (int)threadIdx.x; i < p.n_nodes; i += (int)blockDim.x) l_decl[i] = p.idx.decl[i];
-        decl = l_decl;
-        for (int i = (int)threadIdx.x; i < p.n_nodes; i += (int)blockDim.x) {
-            const unsigned int de = (unsigned int)p.idx.dict[i];
-            unsigned int sl = de & kSlotMask;
-            if (sl == kNoSlot) sl = (unsigned int)n_hot + ((unsigned int)i & (unsigned int)(kDummySlots - 1));
-            l_dict[i] = (unsigned short)(kTrusted ? sl : (sl | (de & kDictMember)));  // trusted: the slot and nothing else
+        unsigned int* const l_ent = reinterpret_cast<unsigned int*>(smem);
+        for (int i = (int)threadIdx.x; i <= p.n_nodes; i += (int)blockDim.x) {
+            unsigned int e = kEntryPoison | ((unsigned int)n_hot << 17);
+            if (i < p.n_nodes) {
+                unsigned int sl = (unsigned int)p.idx.dict[i] & kSlotMask;
+                if (sl == kNoSlot) sl = (unsigned int)n_hot + ((unsigned int)i & (unsigned int)(kDummySlots - 1));
+                e = dict_entry((unsigned int)p.idx.decl[i], sl);
+            }
+            l_ent[i] = e;
         }
-        dict = l_dict;
+        entries = l_ent;
     }
     // the hot adjacency (flat list of triples, count first) and the per-slot masks, copied from the round index
     unsigned int* const l_pairs = reinterpret_cast<unsigned int*>(smem + dict_bytes);
@@ -510,7 +521,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // the same eight global words at the end of their lives queue up behind each other in one L2 channel -- measured:
     // 0.13 ms of a 0.63 ms kernel, and every stream that crosses that channel waits with them.
     unsigned long long* const block_stats =
-        reinterpret_cast<unsigned long long*>(smem + shared_bytes + (int)(blockDim.x >> 6) * tally_wave_bytes(n_hot, kPacked));
+        reinterpret_cast<unsigned long long*>(smem + shared_bytes + (int)(blockDim.x >> 6) * tally_wave_bytes(n_hot));
     unsigned int* const block_claims = reinterpret_cast<unsigned int*>(block_stats + 8);  // receivers claimed by this workgroup
     if (threadIdx.x < 8u) block_stats[threadIdx.x] = 0ull;
     unsigned long long* const block_votes = block_stats + 10;  // [4], see TallyParams::vote_acc
@@ -522,20 +533,18 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     __syncthreads();
 
     // ---- this wave's private LDS ----
-    const int state_bytes = align16((n_hot + kDummySlots) * (kPacked ? 2 : 4));
-    unsigned char* const mine = smem + shared_bytes + wave * tally_wave_bytes(n_hot, kPacked);
+    const int state_bytes = align16((n_hot + kDummySlots) * 4);
+    unsigned char* const mine = smem + shared_bytes + wave * tally_wave_bytes(n_hot);
     unsigned int* const scratch = reinterpret_cast<unsigned int*>(mine + state_bytes);
     unsigned int* const undo = scratch + kScratchWords;
 
-    typename std::conditional<kPacked, PackedSlotDetector, SlotDetector>::type d;
+    SlotDetector d;
     d.st = reinterpret_cast<unsigned int*>(mine);
     d.n_scan = n_hot;
     d.H = p.H;
     d.L = p.L;
     d.kmask = (1u << p.K) - 1u;
 
-    const unsigned int cfg_lo = (unsigned int)(unsigned long long)p.cfg_id;
-    const unsigned int cfg_hi = (unsigned int)((unsigned long long)p.cfg_id >> 32);
     const unsigned int node_last = (unsigned int)(p.n_nodes > 0 ? p.n_nodes - 1 : 0);
     const unsigned int my_dummy = (unsigned int)(n_hot + lane);  // tables in memory: this lane's dummy slot
     unsigned long long n_slow = 0, n_fast = 0, n_restart = 0, n_records = 0, n_pipe = 0, n_careful = 0, n_sweeps = 0;
@@ -547,14 +556,13 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     int n_applied = 0;
     unsigned int sink = 0u;  // stream-only mode: keeps the loads alive
 
-    typedef Window<kTrusted> Win;
+    typedef Window Win;
     struct Stream {  // a receiver's delivered records
         const unsigned char* base;
         unsigned int bytes;
     };
     // one window of the stream `st` starting at this lane's byte offset `voff`: kQ (2 kQ when the configuration id
     // is needed) wave instructions, nothing waited for
-    const unsigned long long cfg_delta = (unsigned long long)p.cfg - (unsigned long long)p.core;  // record i of both arrays: same offset
     auto load_window = [&](const Stream& st, unsigned int voff, Win& W) {
         // declared wave-uniform right here (it is: every lane computes it from the wave's receiver index), so that the
         // descriptor is in SGPRs whatever the compiler concluded about the loops it travelled through
@@ -564,14 +572,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             uniform(st.bytes));
 #pragma unroll
         for (int q = 0; q < kQ; ++q) stream_load2(rsrc, voff, (unsigned int)(q * kQuarterBytes), W.w3[q], W.w4[q]);
-        if (!kTrusted) {  // the same positions of the configuration-id array
-            const unsigned long long c = b + cfg_delta;
-            const stream_rsrc_t rsrc_cfg = stream_make_rsrc(
-                reinterpret_cast<const unsigned char*>(((unsigned long long)uniform((unsigned int)(c >> 32)) << 32) | (unsigned long long)uniform((unsigned int)c)),
-                uniform(st.bytes));
-#pragma unroll
-            for (int q = 0; q < kQ; ++q) stream_load2(rsrc_cfg, voff, (unsigned int)(q * kQuarterBytes), W.w0[kTrusted ? 0 : q], W.w1[kTrusted ? 0 : q]);
-        }
     };
     auto make_stream = [&](long long rec0, long long rec1) -> Stream {
         Stream st;
@@ -584,23 +584,26 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                            (unsigned long long)uniform((unsigned int)(unsigned long long)v));
     };
 
-    // filterAlertMessages (R/MembershipService.java:644-675) + node -> slot for record (q, lane) of a window, branch-free.
-    // slot: the subject's slot, or a dummy one (>= n_hot) if it is not hot; bits: the rings to OR into it (0: the record
-    // fails the filter, or lies past the end of the stream); down: a DOWN report that passed the filter.
-    struct Dec {
-        unsigned int slot, bits;
-        bool down;
+    // ---- per record: the subject's dictionary entry, and the record's EFFECTIVE core word ----
+    // lookup: node -> dict_entry (see there).  Direct mode: one LDS read; an out-of-range subject is clamped onto the poison
+    // entry behind the table (nothing about it is covered, and it has a dummy slot).
+    struct Look {
+        unsigned int entry;
+        bool in;         // subject in range (direct mode: always true, see above)
+        bool untouched;  // compressed mode: the round's alert set never names the node -- its membership is not in the tables
     };
-    unsigned int uncovered = 0u;  // per lane: ring bits of delivered reports that the index was not built for
-    auto decode_rec = [&](const Win& c, int q) -> Dec {
-        Dec r;
-        const unsigned int w3 = c.w3[q], w4 = c.w4[q];
-        const unsigned int rb = w4 & d.kmask;
-        const bool dn = (w4 & 0x00FF0000u) != 0u;
-        // de: dictionary entry (member << 15 | slot), dm: declared rings | member << 15 of the subject
-        unsigned int de, dm;
-        const bool in = w3 <= node_last && p.n_nodes > 0;
+    const unsigned int n_nodes_u = (unsigned int)(p.n_nodes > 0 ? p.n_nodes : 0);
+    auto lookup = [&](unsigned int w3) -> Look {
+        Look k;
+        k.untouched = false;
+        if (kTablesInLds) {
+            k.in = true;
+            k.entry = entries[min(w3, n_nodes_u)];
+            return k;
+        }
+        k.in = w3 <= node_last && p.n_nodes > 0;
         const unsigned int idx = min(w3, node_last);
+        unsigned int sl, dm;
         if (kDictMode == kDictCompressed) {
             // bit test + rank: two independent LDS reads, then the entry of a touched node.  A node the alert set never
             // names has no entry: a valid report about it is exactly what the coverage check exists for.
@@ -609,34 +612,50 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             const bool touched = ((word >> bit) & 1u) != 0u;
             const unsigned int ent = touched ? tent[before + (unsigned int)__popc(word & ((1u << bit) - 1u))] : kNoSlot;
             dm = ent >> 16;
-            de = (ent & kSlotMask) | (dm & kDictMember);
+            sl = ent & kSlotMask;
+            k.untouched = sl == kNoSlot && (dm & 0x3FFFu) == 0u;
         } else {
-            de = (unsigned int)dict[idx];
+            sl = (unsigned int)dict[idx] & kSlotMask;
             dm = (unsigned int)decl[idx];
         }
+        if (sl == kNoSlot) sl = my_dummy;
+        k.entry = k.in ? dict_entry(dm, sl) : (kEntryPoison | (my_dummy << 17));
+        return k;
+    };
+    // effective: filterAlertMessages (R/MembershipService.java:644-675) applied to record (q, lane) of a window, branch-free:
+    // the core word itself if the record passes, with its rings and status cleared if it does not (the batch end stays -- a
+    // batch ends whether or not its last alert is dropped).  Past the end of a stream the word is zero.
+    //   vouched-for copies of validated alerts (kTrusted): nothing is dropped; what a delivered record can still get wrong --
+    //   subject out of range, UP / DOWN against the membership (R/MembershipService.java:659-668), rings the index was not
+    //   built for -- is ONE AND with the entry, collected in `uncovered` (sticky error, results void);
+    //   otherwise: configuration id, range, empty ring list, UP / DOWN against the membership per delivery.
+    unsigned int uncovered = 0u;  // per lane: what delivered reports name that the index was not built for
+    auto effective = [&](const Win& c, int q, const Look& k) -> unsigned int {
+        const unsigned int w = c.w4[q];
         if (kTrusted) {
-            // every delivered record is vouched for as a copy of a validated alert (or is a zero past the end of the stream).
-            // What can be checked without reading the configuration id: subject in range, UP / DOWN against the membership
-            // (R/MembershipService.java:659-668), rings among those the index was built for
-            r.bits = rb;
-            r.down = dn;
-            uncovered |= (rb & ~dm) | (in ? 0u : 1u) | (rb != 0u && dn != ((dm >> 15) != 0u) ? 1u : 0u);
-        } else {
-            const bool untouched = kDictMode == kDictCompressed && (de & kSlotMask) == kNoSlot && (dm & 0x3FFFu) == 0u;
-            const unsigned int bad0 = (c.w0[kTrusted ? 0 : q] ^ cfg_lo) | (c.w1[kTrusted ? 0 : q] ^ cfg_hi) | (in ? 0u : 1u) | (rb == 0u ? 1u : 0u);
-            // (the membership of a node the alert set never names is not in the compressed tables: such a report is
-            // not tallied, and flagged if it is otherwise valid)
-            const unsigned int bad = bad0 | ((dn ? 1u : 0u) ^ ((dm >> 15) & 1u)) | (untouched ? 1u : 0u);
-            r.bits = bad == 0u ? rb : 0u;
-            r.down = dn && bad == 0u;
-            uncovered |= (untouched ? (bad0 == 0u ? rb : 0u) : (r.bits & ~dm)) & 0x3FFFu;
+            uncovered |= w & k.entry;
+            return w;
         }
-        if (kTablesInLds) {
-            r.slot = kTrusted ? de : (de & kSlotMask);  // dummy slots were assigned when the dictionary was staged
-        } else {
-            r.slot = de & kSlotMask;
-            r.slot = r.slot == kNoSlot ? my_dummy : r.slot;
-        }
+        const unsigned int bad0 = (k.in ? 0u : 1u) | ((w & kCoreRings) == 0u ? 1u : 0u);  // (k.in: false for a stale record, too)
+        // (the membership of a node the alert set never names is not in the compressed tables: such a report is
+        // not tallied, and flagged if it is otherwise valid)
+        const unsigned int bad = bad0 | (w & k.entry & (kCoreDown | kCoreUp)) | (k.untouched ? 1u : 0u);
+        const unsigned int weff = bad == 0u ? w : (w & kCoreEob);
+        uncovered |= k.untouched ? (bad0 == 0u ? (w & kCoreRings) : 0u) : (weff & k.entry & kCoreRings);
+        return weff;
+    };
+    // the same as (slot, ring bits, DOWN) for the paths that work on decoded records
+    struct Dec {
+        unsigned int slot, bits;
+        bool down;
+    };
+    auto decode_rec = [&](const Win& c, int q) -> Dec {
+        const Look k = lookup(c.w3[q]);
+        const unsigned int w = effective(c, q, k);
+        Dec r;
+        r.slot = k.entry >> 17;
+        r.bits = w & d.kmask;
+        r.down = (w & kCoreDown) != 0u;
         return r;
     };
     // decoded word of the scratch list / the carry; reports about subjects that are not hot carry no ring bits there
@@ -655,7 +674,17 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     const int n_blocks = (int)gridDim.x;
     int r = uniform(wave * n_blocks + (int)blockIdx.x);  // the first deal: claim number `wave` of this workgroup
     if (r >= p.n_static) r = p.n_receivers;              // (the host sizes the static part so that this never takes pool work away)
-    Win W;  // the window in flight
+    // The stream runs kSets windows ahead of the tally: S[0] is the window about to be tallied, S[1 ..] the ones behind it,
+    // all requested (a window that is being tallied has kSets - 1 successors in flight -- with one, a wave would wait out a
+    // whole memory latency per window as soon as a window's tally is shorter than that, which it is since the fast window
+    // shrank to ~100 instructions: 15 waves x 2 KiB per CU are not enough bytes in flight for 8 TB/s).  Three sets of 8 registers.
+#ifndef RAPID_SETS
+#define RAPID_SETS 3
+#endif
+    constexpr int kSets = RAPID_SETS;  // (2: measurement builds)
+    static_assert(kSets == 2 || kSets == 3, "window sets");
+    constexpr unsigned int kWinBytes = (unsigned int)(kWin * kCoreBytes);
+    Win S[kSets];
     Stream rsrc;
     rsrc.base = p.core;
     rsrc.bytes = 0u;
@@ -668,7 +697,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         const long long rec0 = stream_scalar_load(p.rec_off + r), rec1 = stream_scalar_load(p.rec_off + r + 1);
         nrec = (int)(rec1 - rec0);
         rsrc = make_stream(rec0, rec1);
-        load_window(rsrc, lane_off, W);
+#pragma unroll
+        for (int i = 0; i < kSets; ++i) load_window(rsrc, lane_off + (unsigned int)i * kWinBytes, S[i]);
     }
     while (r < p.n_receivers) {
 #ifdef RAPID_PHASE_TIMERS
@@ -708,13 +738,16 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         bool need_sweep = false;     // the witness candidates are stale (a slow window was processed since the last sweep)
         bool swept = false;          // the hot slots have been swept for candidates during the current window
         int witness = -1;            // a slot in preProposal whose bound popc(state | wmask) stays below H
+        unsigned int witness_so = 0xFFFFFFFFu;  // 2 x witness, what (entry >> 16) of a report about it looks like (none: matches nothing)
         unsigned int wmask = 0u;     // rings on which the witness can receive an implicit report
+        unsigned int wstate = 0u;    // the witness's state word, kept in a scalar: between two set_witness() calls only fast windows
+                                     // touch the detector state, and they see every report about the witness they apply
         unsigned int candv = 0u;     // lane i: slot of witness candidate i
         int ncand = 0, ci = 0;
-        unsigned int carry_slot = 0u, carry_bits = 0u;  // the records after the last applied batch end (lanes >= carry_start of the previous window's last quarter)
-        bool carry_down = false;
+        // the records after the last applied batch end (lanes >= carry_start of the previous window's last quarter): 2 x slot and
+        // the effective core word (rings + status; zero in the lanes before carry_start)
+        unsigned int carry_so = 0u, carry_w = 0u;
         int carry_start = kWave;
-        unsigned int vbatch = 0u;    // per lane: batch ends applied by cold / fast windows since s.batch was last brought up to date
 
         // per-sub-chunk decode results of the slow path (one record per lane)
         int dst = 0, ncons = 0, lastE = -1, spos = 0, send = 0;
@@ -724,7 +757,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 
         auto set_witness = [&]() {
             witness = ci < ncand ? lane_value((int)candv, ci) : -1;
+            witness_so = witness >= 0 ? 2u * (unsigned int)witness : 0xFFFFFFFFu;
             wmask = witness >= 0 ? uniform((unsigned int)smask[witness]) : 0u;
+            wave_lds_fence();
+            wstate = witness >= 0 ? uniform(d.load(witness)) : 0u;
         };
         // ---- one pass over the hot slots: updatesInProgress (slots with L <= count < H), and WITNESS candidates for the
         // fast path: slots in [L, H) that stay below H even if they are given every implicit report they can ever get --
@@ -816,51 +852,56 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // branch: nothing is applied unless the certificate holds, the last quarter holds a batch end (the records after
         // it are carried into the next window) and no first DOWN report would switch the implicit invalidation on inside
         // the window.
+        auto slot_word = [&](unsigned int so) -> unsigned int* {  // the state word of the slot whose doubled number is `so`
+            return reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(d.st) + 2u * so);
+        };
         auto fast_try = [&](const Win& c) -> int {
-            const unsigned long long mEl = wave_ballot((c.w4[kQ - 1] & 0x01000000u) != 0u);
-            const int ncl = kWave - __clzll((long long)mEl);  // lanes of the last quarter up to its last batch end (0: none)
-            Dec e[kQ];
-            unsigned long long mW = wave_ballot(carry_slot == (unsigned int)witness && carry_bits != 0u);
+            unsigned int so[kQ], w[kQ];
+            unsigned long long mW = wave_ballot(carry_so == witness_so);
+            unsigned long long mEl = 0ull;
+            int nb = 0;  // batch ends in the window (none among the lanes that will be carried, by the choice of ncl)
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
-                e[q] = decode_rec(c, q);
-                mW |= wave_ballot(e[q].slot == (unsigned int)witness);
+                const Look k = lookup(c.w3[q]);
+                w[q] = effective(c, q, k);
+                so[q] = k.entry >> 16;
+                mW |= wave_ballot(so[q] == witness_so);
+                mEl = wave_ballot((int)c.w4[q] < 0);
+                nb += __popcll(mEl);
             }
+            const int ncl = kWave - __clzll((long long)mEl);  // lanes of the last quarter up to its last batch end (0: none)
             const bool inl = lane < ncl;
             unsigned int wadd = 0u;  // what the window reports about the witness (rare: ten reports in a whole stream)
             if (mW != 0ull) {
-                unsigned int acc = carry_slot == (unsigned int)witness ? carry_bits : 0u;
+                unsigned int acc = carry_so == witness_so ? carry_w : 0u;
 #pragma unroll
-                for (int q = 0; q < kQ; ++q) acc |= (e[q].slot == (unsigned int)witness && (q < kQ - 1 || inl)) ? e[q].bits : 0u;
+                for (int q = 0; q < kQ; ++q) acc |= (so[q] == witness_so && (q < kQ - 1 || inl)) ? w[q] : 0u;
                 wadd = wave_or32(acc);
             }
             bool fastable = mEl != 0ull;
             if (!s.seen_down) {
-                unsigned int any = carry_down ? 0x00010000u : 0u;
+                unsigned int any = carry_w;
 #pragma unroll
-                for (int q = 0; q < kQ; ++q) any |= c.w4[q];
-                fastable = fastable && wave_ballot((any & 0x00FF0000u) != 0u) == 0ull;
+                for (int q = 0; q < kQ; ++q) any |= w[q];
+                fastable = fastable && wave_ballot((any & kCoreDown) != 0u) == 0ull;
             }
-            const unsigned int wv = uniform(d.load(witness));
-            const bool certified = __popc((wv | wadd | wmask) & d.kmask) < d.H;
+            const bool certified = __popc((wstate | wadd | wmask) & d.kmask) < d.H;
             if (!(fastable && certified)) {
 #ifdef RAPID_TRACE
-                if (lane == 0) fprintf(stderr, "W-fail r=%d witness=%d wcount=%d fastable=%d\n", r, witness, __popc((wv | wadd) & d.kmask), (int)fastable);
+                if (lane == 0) fprintf(stderr, "W-fail r=%d witness=%d wcount=%d fastable=%d\n", r, witness, __popc((wstate | wadd) & d.kmask), (int)fastable);
 #endif
                 return fastable ? kWitnessFails : kNotFastable;
             }
-            (void)d.or_bits((int)carry_slot, carry_bits);
+            // whole core words are ORed in: the status and batch-end bits land in bits of the state word nobody reads
+            (void)atomicOr(slot_word(carry_so), carry_w);
 #pragma unroll
-            for (int q = 0; q < kQ - 1; ++q) {
-                (void)d.or_bits((int)e[q].slot, e[q].bits);
-                vbatch += (c.w4[q] >> 24) & 1u;
-            }
-            (void)d.or_bits((int)e[kQ - 1].slot, inl ? e[kQ - 1].bits : 0u);
-            vbatch += (c.w4[kQ - 1] >> 24) & 1u;  // no batch end among the carried lanes, by the choice of ncl
-            carry_slot = e[kQ - 1].slot;
-            carry_bits = inl ? 0u : e[kQ - 1].bits;
-            carry_down = !inl && e[kQ - 1].down;
+            for (int q = 0; q < kQ - 1; ++q) (void)atomicOr(slot_word(so[q]), w[q]);
+            (void)atomicOr(slot_word(so[kQ - 1]), inl ? w[kQ - 1] : 0u);
+            s.batch += nb;
+            carry_so = so[kQ - 1];
+            carry_w = inl ? 0u : w[kQ - 1];
             carry_start = ncl;
+            wstate |= wadd;
             owed = true;
             running_exact = false;
             return kApplied;
@@ -873,7 +914,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // L is seen by exactly one lane, whatever the order of the atomics) are in preProposal from here on with a bound
         // below H: the first witnesses.
         auto cold_window = [&](const Win& c) -> bool {
-            const unsigned long long mEl = wave_ballot((c.w4[kQ - 1] & 0x01000000u) != 0u);
+            const unsigned long long mEl = wave_ballot((int)c.w4[kQ - 1] < 0);
             if (mEl == 0ull) return false;
             const int ncl = kWave - __clzll((long long)mEl);
             const bool inl = lane < ncl;
@@ -886,7 +927,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             }
             const unsigned int rb_last = rb[kQ - 1];
             rb[kQ - 1] = inl ? rb_last : 0u;
-            const unsigned int cs = carry_slot, cb = carry_slot < (unsigned int)n_hot ? carry_bits : 0u;
+            const unsigned int cs = carry_so >> 1, cb = cs < (unsigned int)n_hot ? (carry_w & d.kmask) : 0u;
             unsigned int oldc = 0u;
             if (cb != 0u) oldc = d.or_bits((int)cs, cb);
 #pragma unroll
@@ -912,6 +953,15 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             for (int q = 0; q < kQ; ++q)
                 if (rb[q] != 0u && d.count(old[q]) < d.L && d.count(old[q] | rb[q]) >= d.L) ent = e[q].slot;
             unsigned long long mEnt = wave_ballot(ent != 0xFFFFFFFFu);
+            bool anyd = (carry_w & kCoreDown) != 0u;
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) anyd = anyd || (e[q].down && (q < kQ - 1 || inl));
+            if (!s.seen_down) s.seen_down = wave_ballot(anyd) != 0ull;
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) s.batch += __popcll(wave_ballot((int)c.w4[q] < 0));
+            carry_so = 2u * e[kQ - 1].slot;
+            carry_w = inl ? 0u : (e[kQ - 1].bits | (e[kQ - 1].down ? kCoreDown : 0u));
+            carry_start = ncl;
             if (mEnt != 0ull) {
                 cold = false;
                 ncand = 0;
@@ -927,16 +977,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 owed = true;
                 running_exact = false;
             }
-            bool anyd = carry_down;
-#pragma unroll
-            for (int q = 0; q < kQ; ++q) anyd = anyd || (e[q].down && (q < kQ - 1 || inl));
-            if (!s.seen_down) s.seen_down = wave_ballot(anyd) != 0ull;
-#pragma unroll
-            for (int q = 0; q < kQ; ++q) vbatch += (c.w4[q] >> 24) & 1u;
-            carry_slot = e[kQ - 1].slot;
-            carry_bits = inl ? 0u : e[kQ - 1].bits;
-            carry_down = !inl && e[kQ - 1].down;
-            carry_start = ncl;
             return true;
         };
 
@@ -1041,26 +1081,21 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // the exact path.  Everything is consumed: no carry afterwards.
         auto slow_window = [&](const Win& c, int w) {
             flush_pending();
-            if (wave_ballot(vbatch != 0u) != 0ull) {  // the batch ends applied by cold / fast windows
-                s.batch += uniform((int)(unsigned int)wave_sum64((unsigned long long)vbatch));
-                vbatch = 0u;
-            }
             const int base_rec = w * kWin;
             Dec cr;
-            cr.slot = carry_slot;
-            cr.bits = carry_bits;
-            cr.down = carry_down;
+            cr.slot = carry_so >> 1;
+            cr.bits = carry_w & d.kmask;
+            cr.down = (carry_w & kCoreDown) != 0u;
             scratch[lane] = pack_rec(cr, false);
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
                 // the stream's last record closes its batch whatever its flag says
-                const bool e_eob = (c.w4[q] & 0x01000000u) != 0u || base_rec + q * kWave + lane == nrec - 1;
+                const bool e_eob = (int)c.w4[q] < 0 || base_rec + q * kWave + lane == nrec - 1;
                 scratch[kWave + q * kWave + lane] = pack_rec(decode_rec(c, q), e_eob);
             }
             spos = carry_start;
             send = kWave + min(kWin, nrec - base_rec);
-            carry_bits = 0u;
-            carry_down = false;
+            carry_w = 0u;
             carry_start = kWave;
             wave_lds_fence();
             if (!running_exact) sweep();  // updatesInProgress, exactly (nothing is owed any more)
@@ -1119,27 +1154,82 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             witness = -1;
             ncand = 0;
             ci = 0;
-            carry_slot = 0u;
-            carry_bits = 0u;
-            carry_down = false;
+            carry_so = 0u;
+            carry_w = 0u;
             carry_start = kWave;
-            vbatch = 0u;
             careful_cap = kWave;
             if (restart) {  // the stream again, from its first window
                 restart = false;
                 exact_only = true;
-                load_window(rsrc, lane_off, W);
-                    }
+#pragma unroll
+                for (int i = 0; i < kSets; ++i) load_window(rsrc, lane_off + (unsigned int)i * kWinBytes, S[i]);
+            }
             wave_lds_fence();
-            unsigned int voff = lane_off;
+            unsigned int voff = lane_off + (unsigned int)kSets * kWinBytes;  // this lane's offset in the next window to request
             for (int w = 0; w < nwin && emit_batch < 0 && !restart; ++w) {
-                const Win cur = W;
-                voff += (unsigned int)(kWin * kCoreBytes);
-                load_window(rsrc, voff, W);  // the next window is in flight while this one is tallied
+                Win cur;
+                // ---- steady state: a run of fast windows, in a loop of its own that holds nothing but what a fast window
+                // needs (the general iteration below carries the whole receiver's bookkeeping through every window and costs
+                // several times the window's own instructions in copies and spilled scalars).  It ends at the window that
+                // owes something else -- the claim of the next receiver, the stream's last window -- or at the first
+                // window that cannot be certified, which the general iteration takes over untouched.
+                if (!exact_only && !s.batch_emitted && (p.flags & (8 | 32)) == 0 && !need_sweep && !cold && witness >= 0) {
+                    const int w_end = nwin - 1;  // the stream's last window goes the slow way
+                    const int w_first = w;
+                    RAPID_T0(tl0);
+                    // A TURN takes kSets windows, each from its own registers, and requests each set again as soon as its step is
+                    // over: the next window of that set if the step applied its window, the SAME window again if it could not
+                    // certify it or was skipped because an earlier step of the turn failed.  Every step thus ends with a load
+                    // into its set on every path -- there is no "reloaded or not" for the compiler to merge with a copy (a copy of
+                    // a register that is still in flight costs an s_waitcnt vmcnt(0) per turn: measured, the whole memory
+                    // latency exposed) -- at the price of reading a window twice after a failed certificate (a few per receiver).
+                    unsigned int vturn = voff - (unsigned int)kSets * kWinBytes;  // this lane's offset in the window held by S[0]
+                    int n_ok = kSets;
+                    while (w + kSets <= w_end && n_ok == kSets) {
+                        if (!claimed && w + kSets + kClaimAhead > nwin) claim();  // (a few windows early rather than in the middle of a turn)
+                        n_ok = 0;
+#pragma unroll
+                        for (int i = 0; i < kSets; ++i) {
+                            bool advance = false;
+                            if (n_ok == i) advance = fast_try(S[i]) == kApplied;
+                            if (advance) ++n_ok;
+                            stream_settle(uncovered, carry_w, carry_so);
+                            load_window(rsrc, vturn + (unsigned int)i * kWinBytes + (advance ? (unsigned int)kSets * kWinBytes : 0u), S[i]);
+                        }
+                        w += n_ok;
+                        vturn += (unsigned int)n_ok * kWinBytes;  // (a complete turn: all sets moved on; else: see below)
+                    }
+                    // After a turn that stopped at step i = n_ok: S[0 .. i-1] hold the windows w + kSets - i .., S[i ..] the windows
+                    // w .. (re-requested).  Back into stream order, S[0] = window w (rare; the copies wait for the data).
+                    const int failed = n_ok == kSets ? 0 : n_ok;
+                    if (failed == 1 || (kSets == 3 && failed == 2)) {
+                        const Win t = S[0];
+#pragma unroll
+                        for (int i = 0; i + 1 < kSets; ++i) S[i] = S[i + 1];
+                        S[kSets - 1] = t;
+                    }
+                    if (kSets == 3 && failed == 2) {
+                        const Win t = S[0];
+#pragma unroll
+                        for (int i = 0; i + 1 < kSets; ++i) S[i] = S[i + 1];
+                        S[kSets - 1] = t;
+                    }
+                    voff = vturn + (unsigned int)kSets * kWinBytes;
+                    RAPID_T1(t_lean, tl0);
+                    n_fast += (unsigned long long)(w - w_first);
+                    n_records += (unsigned long long)(w - w_first) * (unsigned long long)kWin;
+                }
+                {
+                    cur = S[0];
+#pragma unroll
+                    for (int i = 0; i + 1 < kSets; ++i) S[i] = S[i + 1];
+                    load_window(rsrc, voff, S[kSets - 1]);  // kSets windows ahead
+                    voff += kWinBytes;
+                }
                 if (!claimed && w + kClaimAhead >= nwin) claim();
                 if ((p.flags & 32) != 0) {  // measurement aid: stream the records through the registers without tallying them
 #pragma unroll
-                    for (int q = 0; q < kQ; ++q) sink ^= cur.w3[q] ^ cur.w4[q] ^ (kTrusted ? 0u : cur.w0[kTrusted ? 0 : q] ^ cur.w1[kTrusted ? 0 : q]);
+                    for (int q = 0; q < kQ; ++q) sink ^= cur.w3[q] ^ cur.w4[q];
                     continue;
                 }
                 bool done = false;
@@ -1196,8 +1286,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             const long long rec0 = next0, rec1 = next1;
             nrec_next = (int)(rec1 - rec0);
             rsrc = make_stream(rec0, rec1);
-            load_window(rsrc, lane_off, W);
-            }
+#pragma unroll
+            for (int i = 0; i < kSets; ++i) load_window(rsrc, lane_off + (unsigned int)i * kWinBytes, S[i]);
+        }
 
         // ---- outputs: the proposal = every flushed (hot) slot, ascending node index ----
         int count = 0;
@@ -1207,7 +1298,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             int* const out = p.props + (long long)r * p.prop_cap;
             for (int i0 = 0; i0 < n_hot; i0 += kWave) {
                 const int i = i0 + lane;
-                const bool take = i < n_hot && (d.load(i) & kFlushed) != 0;
+                const bool take = i < n_hot && (d.load(i) & SlotDetector::kFlushed) != 0;
                 const unsigned long long mk = wave_ballot(take);
                 const int idx = count + __popcll(mk & lanes_lt(lane));
                 if (take) {

@@ -141,8 +141,7 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
                   int flags, int waves, int grid, int tables_in_lds, unsigned long long seed, const unsigned int* tbits,
                   const unsigned short* trank, const unsigned int* tent, int n_touched, unsigned long long* vote_res_out) {
     // tables_in_lds: 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS
-    const bool packed = (flags & 2048) != 0;  // emulator-only selector of the kPacked instantiations (dictionary modes 0 and 2)
-    const int lds = rapid::tally_shared_bytes(tables_in_lds, n_nodes, n_touched, n_hot, n_adj) + waves * rapid::tally_wave_bytes(n_hot, packed) +
+    const int lds = rapid::tally_shared_bytes(tables_in_lds, n_nodes, n_touched, n_hot, n_adj) + waves * rapid::tally_wave_bytes(n_hot) +
                     rapid::kBlockStatsBytes;
     if (lds > (int)sizeof(smem)) return -5;
     rapid::TallyParams p;
@@ -155,7 +154,9 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
         unsigned int w[5];
         std::memcpy(w, records + i * 20, 20);
         cfgs[2 * i] = w[0], cfgs[2 * i + 1] = w[1];
-        core[2 * i] = w[3], core[2 * i + 1] = w[4];
+        const bool stale = w[0] != (unsigned int)(unsigned long long)cfg_id || w[1] != (unsigned int)((unsigned long long)cfg_id >> 32);
+        core[2 * i] = (w[3] >= rapid::kCoreStale ? rapid::kCoreStale - 1u : w[3]) | (stale ? rapid::kCoreStale : 0u);
+        core[2 * i + 1] = rapid::core_word(w[4]);
     }
     p.core = reinterpret_cast<const unsigned char*>(core.data());
     p.cfg = reinterpret_cast<const unsigned char*>(cfgs.data());
@@ -208,12 +209,7 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
         std::memset(smem, 0xCD, sizeof(smem));  // poison: the kernel must initialise what it reads
         const bool trusted = (flags & 256) != 0;  // emulator-only selector of the kTrusted instantiation
         auto run = [&](auto kern) { emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { kern(p); }, seed + (unsigned)b); };
-        switch ((packed ? 8 : 0) + tables_in_lds * 2 + (trusted ? 1 : 0)) {
-            case 8: run(rapid::tally_population_kernel<rapid::kDictMemory, false, true>); break;
-            case 9: run(rapid::tally_population_kernel<rapid::kDictMemory, true, true>); break;
-            case 12: run(rapid::tally_population_kernel<rapid::kDictCompressed, false, true>); break;
-            case 13: run(rapid::tally_population_kernel<rapid::kDictCompressed, true, true>); break;
-            case 10: case 11: return -6;  // (no packed form of the direct tables)
+        switch (tables_in_lds * 2 + (trusted ? 1 : 0)) {
             case 0: run(rapid::tally_population_kernel<rapid::kDictMemory, false>); break;
             case 1: run(rapid::tally_population_kernel<rapid::kDictMemory, true>); break;
             case 2: run(rapid::tally_population_kernel<rapid::kDictDirect, false>); break;

@@ -118,16 +118,13 @@ def validate_alerts(records, n_nodes, K, cfg_id, member):
 
 
 def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_cap=None, force_exact=0, seed=1, waves=3,
-          grid=2, tables_in_lds=1, trusted=False, declared=None, pool=False, packed=False):
+          grid=2, tables_in_lds=1, trusted=False, declared=None, pool=False):
     """`declared`: build the round index from these records (the round's distinct alert set) instead of the delivered
     ones; the call then returns (results ..., covered) with covered = False if the kernel found a delivered report that
     the declared set does not contain.  pool: only the first deal (grid x waves receivers) is static, the rest is claimed
     from the kernel's common pool."""
     if pool:
         force_exact = force_exact | 512
-    if packed:  # two slots per LDS word (the packed detector); dictionary modes 0 and 2 only
-        assert tables_in_lds in (0, 2)
-        force_exact = force_exact | 2048
     L_ = lib()
     recs = np.ascontiguousarray(records)
     raw = np.zeros(((recs.nbytes + 15) // 16) * 16 + 32, dtype=np.uint8)

@@ -28,5 +28,6 @@ inline void stream_store(int* p, int v) { *p = v; }
 inline void stream_store(unsigned long long* p, unsigned long long v) { *p = v; }
 
 inline void stream_flag_or(unsigned int* p, unsigned int bits) { *p |= bits; }
+inline void stream_settle(unsigned int&, unsigned int&, unsigned int&) {}  // a scheduling fence on the device, nothing here
 
 }  // namespace rapid

@@ -968,8 +968,7 @@ def test_tables_in_memory_mode_vs_faithful_oracle(E, name, n, f, K, H, L):
     # 128: compressed tables in LDS, 256: dictionary in memory; alone: the pre-validated instantiation (every delivered alert
     # passes the filter); | 64: per-delivery filter; | 1: exact path
     # 4096: the round index built by several workgroups (count / assign / adjacency), the form of populations >= 40,000 nodes
-    # 8192: two slots per LDS word in the tally (built for rounds with very many hot subjects; never with direct tables)
-    for mode_knob, mode in ((128, 2), (256, 0), (4096, 2), (4096 | 256, 0), (8192, 2), (8192 | 256, 0)):
+    for mode_knob, mode in ((128, 2), (256, 0), (4096, 2), (4096 | 256, 0)):
       for kw in (dict(force_exact=mode_knob), dict(force_exact=mode_knob | 64), dict(force_exact=mode_knob, alert_set=sc.batches.recs),
                  dict(force_exact=mode_knob | 64, alert_set=sc.batches.recs), dict(force_exact=mode_knob | 1)):
         sim, res = run_population(E, eng, sc.records, sc.rec_off, **kw)

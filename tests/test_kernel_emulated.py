@@ -128,9 +128,7 @@ def test_other_dictionary_placements(mode):
         recs.append(random_stream(rng, n, K, member, cfg, n_rec, hot, p_eob=float(rng.choice([0.05, 0.5]))))
         off.append(off[-1] + n_rec)
     _check(np.concatenate(recs), np.array(off), n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode)
-    # ... and with two slots per LDS word (the packed detector built for rounds with very many hot subjects)
-    _check(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode, packed=True)
-    _check(np.concatenate(recs), np.array(off), n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode, packed=True, pool=True)
+    _check(np.concatenate(recs), np.array(off), n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode, pool=True)
 
 
 def test_receivers_claimed_from_the_common_pool():
