@@ -526,7 +526,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     if (threadIdx.x < 8u) block_stats[threadIdx.x] = 0ull;
     unsigned long long* const block_votes = block_stats + 10;  // [4], see TallyParams::vote_acc
     if (threadIdx.x >= 16u && threadIdx.x < 20u) block_votes[threadIdx.x - 16u] = 0ull;
-#ifdef RAPID_PHASE_TIMERS
+#if defined(RAPID_PHASE_TIMERS) && defined(RAPID_BLOCK_STAMPS)
     if (threadIdx.x == 7u) block_stats[7] = ~0ull;
 #endif
     if (threadIdx.x == 8u) *block_claims = blockDim.x >> 6;  // claims 0 .. waves - 1 are the first deal
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     const unsigned int my_dummy = (unsigned int)(n_hot + lane);  // tables in memory: this lane's dummy slot
     unsigned long long n_slow = 0, n_fast = 0, n_restart = 0, n_records = 0, n_pipe = 0, n_careful = 0, n_sweeps = 0;
 #ifdef RAPID_PHASE_TIMERS
-    unsigned long long t_total = 0, t_ensure = 0, t_lean = 0, t_careful = 0, t_out = 0, t_flush = 0, t_rx = 0;
+    unsigned long long t_total = 0, t_ensure = 0, t_lean = 0, t_careful = 0, t_out = 0, t_flush = 0, t_rx = 0, n_tight = 0;
     RAPID_T0(t_kernel0);
     const unsigned long long t_real_start = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #define RAPID_SETS 3
 #endif
     constexpr int kSets = RAPID_SETS;  // (2: measurement builds)
-    static_assert(kSets == 2 || kSets == 3, "window sets");
+    static_assert(kSets >= 2 && kSets <= 6, "window sets");
     constexpr unsigned int kWinBytes = (unsigned int)(kWin * kCoreBytes);
     Win S[kSets];
     Stream rsrc;
@@ -876,7 +876,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 unsigned int acc = carry_so == witness_so ? carry_w : 0u;
 #pragma unroll
                 for (int q = 0; q < kQ; ++q) acc |= (so[q] == witness_so && (q < kQ - 1 || inl)) ? w[q] : 0u;
-                wadd = wave_or32(acc);
+                // (one or two lanes hold something: picked out by name instead of a six-step butterfly over the wave)
+                for (unsigned long long m = wave_ballot(acc != 0u); m != 0ull; m &= m - 1ull)
+                    wadd |= (unsigned int)lane_value((int)acc, __ffsll((long long)m) - 1);
             }
             bool fastable = mEl != 0ull;
             if (!s.seen_down) {
@@ -1057,7 +1059,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             n_slow++;
             n_records += (unsigned long long)ncons;
             // only the records that do something: a report about a hot subject, a DOWN report, or a batch end
-            for (unsigned long long todo = wave_ballot((lane < ncons) & ((bits != 0u) | down | eob)); todo != 0ull;
+            for (unsigned long long todo = wave_ballot((lane < ncons) & ((bits != 0u) | (down & !s.seen_down) | eob)); todo != 0ull;
                  todo &= todo - 1ull) {
                 const int q = __ffsll((long long)todo) - 1;
                 const int qdst = lane_value(dst, q);
@@ -1167,13 +1169,19 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             wave_lds_fence();
             unsigned int voff = lane_off + (unsigned int)kSets * kWinBytes;  // this lane's offset in the next window to request
             for (int w = 0; w < nwin && emit_batch < 0 && !restart; ++w) {
-                Win cur;
                 // ---- steady state: a run of fast windows, in a loop of its own that holds nothing but what a fast window
                 // needs (the general iteration below carries the whole receiver's bookkeeping through every window and costs
                 // several times the window's own instructions in copies and spilled scalars).  It ends at the window that
                 // owes something else -- the claim of the next receiver, the stream's last window -- or at the first
                 // window that cannot be certified, which the general iteration takes over untouched.
-                if (!exact_only && !s.batch_emitted && (p.flags & (8 | 32)) == 0 && !need_sweep && !cold && witness >= 0) {
+                swept = false;
+                const bool lean_ok = !exact_only && !s.batch_emitted && (p.flags & (8 | 32)) == 0;
+                if (lean_ok && need_sweep && !cold && w + 1 < nwin) {  // (after a slow window: updatesInProgress and fresh witness candidates)
+                    need_sweep = false;
+                    swept = true;
+                    sweep();
+                }
+                if (lean_ok && !need_sweep && (cold || witness >= 0)) {
                     const int w_end = nwin - 1;  // the stream's last window goes the slow way
                     const int w_first = w;
                     RAPID_T0(tl0);
@@ -1191,7 +1199,21 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #pragma unroll
                         for (int i = 0; i < kSets; ++i) {
                             bool advance = false;
-                            if (n_ok == i) advance = fast_try(S[i]) == kApplied;
+                            if (n_ok == i) {
+                                if (cold) {  // (the first windows of a stream: until a subject reaches L there is no witness to be had)
+                                    advance = cold_window(S[i]);
+                                } else if (witness >= 0) {
+                                    int st_ = fast_try(S[i]);
+                                    // a witness that fails is replaced right here while candidates from the last sweep are left
+                                    // (a new sweep is the general iteration's business)
+                                    while (st_ == kWitnessFails && ci + 1 < ncand) {
+                                        ++ci;
+                                        set_witness();
+                                        st_ = fast_try(S[i]);
+                                    }
+                                    advance = st_ == kApplied;
+                                }
+                            }
                             if (advance) ++n_ok;
                             stream_settle(uncovered, carry_w, carry_so);
                             load_window(rsrc, vturn + (unsigned int)i * kWinBytes + (advance ? (unsigned int)kSets * kWinBytes : 0u), S[i]);
@@ -1202,38 +1224,43 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     // After a turn that stopped at step i = n_ok: S[0 .. i-1] hold the windows w + kSets - i .., S[i ..] the windows
                     // w .. (re-requested).  Back into stream order, S[0] = window w (rare; the copies wait for the data).
                     const int failed = n_ok == kSets ? 0 : n_ok;
-                    if (failed == 1 || (kSets == 3 && failed == 2)) {
-                        const Win t = S[0];
 #pragma unroll
-                        for (int i = 0; i + 1 < kSets; ++i) S[i] = S[i + 1];
-                        S[kSets - 1] = t;
-                    }
-                    if (kSets == 3 && failed == 2) {
-                        const Win t = S[0];
+                    for (int t_ = 1; t_ < kSets; ++t_) {
+                        if (t_ <= failed) {  // one place to the left, `failed` times
+                            const Win t = S[0];
 #pragma unroll
-                        for (int i = 0; i + 1 < kSets; ++i) S[i] = S[i + 1];
-                        S[kSets - 1] = t;
+                            for (int i = 0; i + 1 < kSets; ++i) S[i] = S[i + 1];
+                            S[kSets - 1] = t;
+                        }
                     }
                     voff = vturn + (unsigned int)kSets * kWinBytes;
-                    RAPID_T1(t_lean, tl0);
+                    RAPID_T1(t_ensure, tl0);
+#ifdef RAPID_PHASE_TIMERS
+                    n_tight += (unsigned long long)(w - w_first);
+#endif
                     n_fast += (unsigned long long)(w - w_first);
                     n_records += (unsigned long long)(w - w_first) * (unsigned long long)kWin;
+                    if (w != w_first) swept = false;  // (another window now)
                 }
-                {
-                    cur = S[0];
+                // ---- the general iteration: window w, in place in S[0].  The sets move up one place and the next window is requested
+                // AFTER the window has been dealt with: the copies need the youngest request to have landed, and what this
+                // iteration does (a cold window, a sweep, a slow window) is time that request has had by then.
+                const Win& cur = S[0];
+                auto next_general = [&]() {
+                    stream_settle(uncovered, carry_w, carry_so);
 #pragma unroll
                     for (int i = 0; i + 1 < kSets; ++i) S[i] = S[i + 1];
                     load_window(rsrc, voff, S[kSets - 1]);  // kSets windows ahead
                     voff += kWinBytes;
-                }
+                };
                 if (!claimed && w + kClaimAhead >= nwin) claim();
                 if ((p.flags & 32) != 0) {  // measurement aid: stream the records through the registers without tallying them
 #pragma unroll
                     for (int q = 0; q < kQ; ++q) sink ^= cur.w3[q] ^ cur.w4[q];
+                    next_general();
                     continue;
                 }
                 bool done = false;
-                swept = false;
                 // the stream's last window always goes the slow way (its last record closes a batch without saying so)
                 if (!exact_only && !s.batch_emitted && (p.flags & 8) == 0 && w + 1 < nwin) {
                     RAPID_T0(tl0);
@@ -1258,6 +1285,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     RAPID_T1(t_lean, tl0);
                 }
                 if (!done) slow_window(cur, w);
+                next_general();
             }
             if (!restart) break;
         }
@@ -1345,14 +1373,14 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #ifdef RAPID_PHASE_TIMERS
     RAPID_T1(t_total, t_kernel0);
     mine_stats[0] = t_total; mine_stats[1] = t_ensure; mine_stats[2] = t_lean; mine_stats[3] = t_careful;
-    mine_stats[4] = t_out; mine_stats[5] = t_flush; mine_stats[6] = t_rx; mine_stats[7] = n_fast;
+    mine_stats[4] = t_out; mine_stats[5] = t_flush; mine_stats[6] = t_rx; mine_stats[7] = n_tight;
 #else
     mine_stats[0] = n_slow; mine_stats[1] = n_fast; mine_stats[2] = n_sweeps; mine_stats[3] = n_restart;
     mine_stats[4] = (unsigned long long)n_applied; mine_stats[5] = n_records; mine_stats[6] = n_pipe; mine_stats[7] = n_careful;
 #endif
-#ifdef RAPID_PHASE_TIMERS
-    // profiling build: [1] = when the workgroup's last wave finished, [7] = when its first wave got here after the tables were
-    // staged (constant-rate counter, 10 ns ticks) -- per workgroup through rapid_debug_block_stats
+#if defined(RAPID_PHASE_TIMERS) && defined(RAPID_BLOCK_STAMPS)
+    // profiling build for scripts/block_times.py: [1] = when the workgroup's last wave finished, [7] = when its first wave got
+    // here after the tables were staged (constant-rate counter, 10 ns ticks) -- per workgroup through rapid_debug_block_stats
     mine_stats[1] = __builtin_amdgcn_s_memrealtime();
     mine_stats[7] = t_real_start;
     if (lane == 0) {
@@ -1397,7 +1425,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         }
     }
     // p.stats = [gridDim.x][8], accumulated over launches; one plain read-modify-write per workgroup and counter
-#ifdef RAPID_PHASE_TIMERS
+#if defined(RAPID_PHASE_TIMERS) && defined(RAPID_BLOCK_STAMPS)
     if (threadIdx.x < 8u && p.stats != nullptr) {
         if (threadIdx.x == 1u || threadIdx.x == 7u)
             p.stats[(size_t)blockIdx.x * 8 + threadIdx.x] = block_stats[threadIdx.x];

@@ -25,10 +25,10 @@ runs = reps + 1
 tot = float(s[0])
 info = sim.index_info()
 print("tally_ms", round(ms, 4), info)
-names = ["total", "(unused)", "cold+fast windows", "slow windows", "output+init", "flush+sweeps"]
+names = ["total", "fast windows, steady-state loop", "cold + fast windows, general iteration", "slow windows", "output+init", "flush+sweeps"]
 for i, nm in enumerate(names):
-    print("%-12s %6.1f %%   %.0f cycles/receiver" % (nm, 100.0 * float(s[i]) / tot, float(s[i]) / max(1.0, float(s[6]))))
-print("receivers", int(s[6]) // runs, "lean windows/receiver", float(s[7]) / max(1.0, float(s[6])))
+    print("%-42s %6.1f %%   %.0f cycles/receiver" % (nm, 100.0 * float(s[i]) / tot, float(s[i]) / max(1.0, float(s[6]))))
+print("receivers", int(s[6]) // runs, "windows taken by the steady-state loop per receiver", float(s[7]) / max(1.0, float(s[6])))
 
 sim.tally()
 emit, nprop, pcount, fpw = sim.results()
