@@ -565,7 +565,9 @@ int launch_tally(rapid_engine* h) {
     p.prop_cap = h->max_cut;
     p.stats = h->d_stats.p;  // [grid_blocks][8]
     p.waves_per_block = h->waves_per_block;
-    p.flags = h->force_exact & (1 | 4 | 8 | 16 | 32);
+    p.flags = h->force_exact & (1 | 4 | 8 | 32);
+    p.stagger = 0;
+    if (const char* e = getenv("RAPID_TALLY_STAGGER")) p.stagger = std::max(0, std::min(64, atoi(e)));  // profiling knob
     // The last eighth of the receivers is not dealt to the workgroups but left in a common pool (tally_kernel.h: n_static),
     // once a population is at least two rounds of the launch; testing knob bit 10: everything dealt statically.
     p.n_static = h->n_receivers;

@@ -63,10 +63,17 @@ constexpr int kWin = kQ * kWave;          // 256 records = 5 KiB of stream per w
 constexpr int kQuarterBytes = kWave * kCoreBytes;
 static_assert(kQ >= 1 && kQ <= 16, "window size");
 constexpr int kScratchWords = (kQ + 1) * kWave;  // carried quarter + window, one decoded word per record
-constexpr int kUndoCap = 128;                    // implicit bits set inside one careful sub-chunk
+#ifndef RAPID_UNDO_CAP
+#define RAPID_UNDO_CAP 128
+#endif
+constexpr int kUndoCap = RAPID_UNDO_CAP;         // implicit bits set inside one careful sub-chunk (more: the receiver is redone on the exact path)
 constexpr int kCand = 4;                         // witness candidates kept from one sweep
 constexpr int kClaimAhead = 3;                   // windows before the end of a stream at which the next receiver is claimed
-constexpr int kDummySlots = 64;                  // slots n_hot .. n_hot + 63: where reports about subjects that are not hot go
+#ifndef RAPID_DUMMY_SLOTS
+#define RAPID_DUMMY_SLOTS 64
+#endif
+constexpr int kDummySlots = RAPID_DUMMY_SLOTS;   // slots n_hot .. n_hot + 63: where reports about subjects that are not hot go
+static_assert((kDummySlots & (kDummySlots - 1)) == 0 && kDummySlots >= 1 && kDummySlots <= 64, "dummy slots");
 constexpr int kMaxWavesPerBlock = 16;
 
 // The RESIDENT core word of a delivered record (second dword of core[i]; the first is the subject's node index), written by
@@ -172,6 +179,10 @@ struct TallyParams {
     // nullptr: not gathered.
     unsigned long long* vote_acc;
     unsigned long long* vote_res;
+    // Every other wave of a workgroup starts `stagger` x 8,128 cycles late.  All receivers of a round cost the same and all
+    // waves start together, so without it the waves of a launch move in step: everybody streams (the memory system
+    // saturated), then everybody tallies the end of a stream and writes results (the memory system idle).
+    int stagger;
     int flags;                        // bit0: exact path only, bit3: careful path only (both for tests); bit5: stream only
 };
 
@@ -546,7 +557,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     d.kmask = (1u << p.K) - 1u;
 
     const unsigned int node_last = (unsigned int)(p.n_nodes > 0 ? p.n_nodes - 1 : 0);
-    const unsigned int my_dummy = (unsigned int)(n_hot + lane);  // tables in memory: this lane's dummy slot
+    const unsigned int my_dummy = (unsigned int)(n_hot + (lane & (kDummySlots - 1)));  // tables in memory: this lane's dummy slot
     unsigned long long n_slow = 0, n_fast = 0, n_restart = 0, n_records = 0, n_pipe = 0, n_careful = 0, n_sweeps = 0;
 #ifdef RAPID_PHASE_TIMERS
     unsigned long long t_total = 0, t_ensure = 0, t_lean = 0, t_careful = 0, t_out = 0, t_flush = 0, t_rx = 0, n_tight = 0;
@@ -689,8 +700,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     rsrc.base = p.core;
     rsrc.bytes = 0u;
     const unsigned int lane_off = (unsigned int)lane * (unsigned int)kCoreBytes;  // this lane's byte offset inside a quarter
-    if ((p.flags & 16) != 0 && (wave & 1) != 0) {  // measurement aid: every other wave starts half a receiver late
-        for (int i = 0; i < 15; ++i) __builtin_amdgcn_s_sleep(127);
+    if (p.stagger > 0 && (wave & 1) != 0) {  // every other wave starts late (see TallyParams::stagger)
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
     int nrec = 0;
     if (r < p.n_receivers) {
@@ -856,13 +867,25 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             return reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(d.st) + 2u * so);
         };
         auto fast_try = [&](const Win& c) -> int {
+#ifdef RAPID_PROBE_STREAM  // measurement builds only (results are void): what the turn loop costs with the tally taken out
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) sink ^= c.w3[q] ^ c.w4[q];
+            return kApplied;
+#endif
             unsigned int so[kQ], w[kQ];
             unsigned long long mW = wave_ballot(carry_so == witness_so);
             unsigned long long mEl = 0ull;
             int nb = 0;  // batch ends in the window (none among the lanes that will be carried, by the choice of ncl)
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
+#ifdef RAPID_PROBE_NO_LOOKUP
+                Look k;
+                k.entry = (c.w3[q] & 0xFFu) << 17;
+                k.in = true;
+                k.untouched = false;
+#else
                 const Look k = lookup(c.w3[q]);
+#endif
                 w[q] = effective(c, q, k);
                 so[q] = k.entry >> 16;
                 mW |= wave_ballot(so[q] == witness_so);
@@ -895,10 +918,15 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 return fastable ? kWitnessFails : kNotFastable;
             }
             // whole core words are ORed in: the status and batch-end bits land in bits of the state word nobody reads
+#ifdef RAPID_PROBE_NO_OR
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) sink ^= so[q] ^ w[q];
+#else
             (void)atomicOr(slot_word(carry_so), carry_w);
 #pragma unroll
             for (int q = 0; q < kQ - 1; ++q) (void)atomicOr(slot_word(so[q]), w[q]);
             (void)atomicOr(slot_word(so[kQ - 1]), inl ? w[kQ - 1] : 0u);
+#endif
             s.batch += nb;
             carry_so = so[kQ - 1];
             carry_w = inl ? 0u : w[kQ - 1];

@@ -190,6 +190,7 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     p.stats = stats;
     p.waves_per_block = waves;
     p.flags = flags;
+    p.stagger = (flags & 16) != 0 ? 1 : 0;
     // emulator-only selector (bit 9): everything beyond the first deal comes from the common pool (workgroups run one
     // after the other here, so the first one takes all of it -- the claims, the hand-over and the reset are what is tested)
     static unsigned int pool[2];
