@@ -123,6 +123,19 @@ int rapid_view_config_id(rapid_engine* h, int64_t* id_out);                     
 /* whole tables, row-major [n_nodes][K] (observers of members = ring successors; rows of non-members hold
  * their expected observers; subjects rows of non-members are -1) -- what the scenario generators consume */
 int rapid_view_tables(rapid_engine* h, int32_t* observers, int32_t* subjects, uint8_t* member, int32_t n_nodes);
+/* Quirk Q4 of the reference, made visible to the host (R/MembershipView.java:143-152, 181-195, 210-224): getObserversOf is
+ * memoised per node, and ringAdd / ringDelete drop only the entries of the changed node's ring predecessors -- an entry can
+ * survive a view change that moves its node's observers (the ring minimum changes: the maximum's successor wraps to it).
+ * The only reader on this path is invalidateFailingEdges (R/MultiNodeCutDetector.java:147-149), which asks for the observers
+ * of the subjects in preProposal -- members the round's alerts name on >= L rings.  The engine always tallies from the
+ * fresh tables, so its results are the reference's unless some receiver may hold a stale entry for such a subject.
+ * hot[0..n): the subjects this round's alerts name on >= L rings (the caller's alert set knows them; non-members and
+ * duplicates are skipped).  For each: if it was hot in an earlier configuration and has not left the view since, its
+ * observers of that time are compared with today's; differing ones are written to out (capacity cap, *n_out = how many
+ * there are: 0 = the quirk cannot fire at any receiver in this round).  Members seen for the first time are remembered
+ * with today's observers; rapid_apply_cut / rapid_view_ring_delete forget a node that leaves (its entry dies with it,
+ * :187-191).  Conservative in one direction only: it may name a subject no receiver actually cached. */
+int rapid_view_q4_at_risk(rapid_engine* h, const int32_t* hot, int32_t n, int32_t* out, int32_t cap, int32_t* n_out);
 
 /* ---- MultiNodeCutDetector, one instance (R/MultiNodeCutDetector.java) ---------------------------------
  * State lives on the GPU; every call runs the exact sequential kernel on one wavefront.

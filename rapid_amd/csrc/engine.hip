@@ -16,6 +16,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -67,8 +68,10 @@ struct rapid_engine {
     std::vector<int> reg_off, reg_ports;  // offsets [n_nodes + 1], ports
     std::vector<uint8_t> member;  // host mirror
     int n_members = 0;
-    std::set<std::pair<int64_t, int64_t>> ids_seen;  // identifiersSeen (signed lexicographic == NodeIdComparator)
-    bool ids_dirty = true;
+    // identifiersSeen (R/MembershipView.java:474-500: ordered by signed high, then signed low == NodeIdComparator; never
+    // pruned) lives SORTED ON THE DEVICE (d_ids_hi / d_ids_lo, n_ids_dev entries): membership questions are binary searches
+    // there, and the NodeIds a change admits wait in ids_pending until rebuild_view merges them in
+    std::vector<std::pair<int64_t, int64_t>> ids_pending;
     bool view_built = false;
     int64_t config_id = -1;
 
@@ -85,14 +88,21 @@ struct rapid_engine {
     DevBuf<int> d_ring;                          // [K][M] node indices in ring order
     DevBuf<int> d_pos;                           // [K][n_nodes]
     DevBuf<int> d_obs, d_subj;                   // [n_nodes][K]
-    DevBuf<long long> d_ids_hi, d_ids_lo;
+    DevBuf<long long> d_ids_hi, d_ids_lo, d_ids_hi2, d_ids_lo2, d_ids_new;
     DevBuf<long long> d_cfg_out;
+    DevBuf<unsigned long long> d_cfg_partial;
+    DevBuf<int> d_chunk_kept, d_joiners, d_join_nodes, d_join_vals;   // incremental view change (view_kernels.h)
+    DevBuf<unsigned long long> d_join_keys, d_join_skeys;
     DevBuf<unsigned char> d_sort_tmp;
     DevBuf<int> d_seg_off;                       // [K + 1] ring boundaries inside the [K][M] sort buffers
     std::vector<int> seg_host;                   // its host copy (lives as long as the async upload needs it)
     std::vector<uint8_t> ring_member;            // member flags the device rings were built from (empty: no rings yet)
     int ring_m = 0;                              // their length
     int n_ids_dev = 0;
+
+    // Q4 (rapid_view_q4_at_risk): member -> its observers when it was first hot, until it leaves the view
+    std::unordered_map<int, std::vector<int>> q4_cached;
+    DevBuf<int> d_q4_nodes, d_q4_rows;
 
     // host mirrors of the tables (filled lazily after a rebuild)
     bool host_tables_valid = false;
@@ -216,92 +226,208 @@ int use_device(rapid_engine* h) {
 }
 
 // Rebuilds rings, tables, state template and configuration id from the host member flags.
+// Is any of `ids` (sorted, distinct) among the identifiers seen so far?  A binary search per id in the device's sorted copy.
+static int ids_seen_any(rapid_engine* h, const std::vector<std::pair<int64_t, int64_t>>& ids, bool* any) {
+    *any = false;
+    if (ids.empty() || h->n_ids_dev == 0) return RAPID_OK;
+    const size_t nn = ids.size();
+    std::vector<long long> flat(2 * nn);
+    for (size_t i = 0; i < nn; ++i) {
+        flat[i] = ids[i].first;
+        flat[nn + i] = ids[i].second;
+    }
+    HIPCHK(h, h->d_ids_new.ensure(2 * nn));
+    HIPCHK(h, h->d_loadflags.ensure(2));
+    HIPCHK(h, hipMemsetAsync(h->d_loadflags.p, 0, 8, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_ids_new.p, flat.data(), 16 * nn, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(rapid::ids_contains_kernel, dim3(grid_for((long long)nn, 256)), dim3(256), 0, h->stream, h->d_ids_hi.p, h->d_ids_lo.p, h->n_ids_dev,
+                       h->d_ids_new.p, h->d_ids_new.p + nn, (int)nn, h->d_loadflags.p);
+    unsigned int f = 0;
+    HIPCHK(h, hipMemcpyAsync(&f, h->d_loadflags.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *any = f != 0u;
+    return RAPID_OK;
+}
+
+// all K rings of `count` (key, node) pairs per ring in ONE segmented sort (ring k = segment [k count, (k + 1) count))
+static int sort_rings(rapid_engine* h, unsigned long long* keys_in, unsigned long long* keys_out, int* vals_in, int* vals_out, int count) {
+    const int K = h->cfg.K;
+    hipStream_t st = h->stream;
+    h->seg_host.resize((size_t)K + 1);
+    for (int k = 0; k <= K; ++k) h->seg_host[(size_t)k] = k * count;
+    HIPCHK(h, h->d_seg_off.ensure((size_t)K + 1));
+    HIPCHK(h, hipMemcpyAsync(h->d_seg_off.p, h->seg_host.data(), sizeof(int) * ((size_t)K + 1), hipMemcpyHostToDevice, st));
+    size_t tmp_bytes = 0;
+    HIPCHK(h, rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (unsigned int)((size_t)K * count),
+                                                  (unsigned int)K, h->d_seg_off.p, h->d_seg_off.p + 1, 0, 64, st));
+    HIPCHK(h, h->d_sort_tmp.ensure(tmp_bytes + 16));
+    HIPCHK(h, rocprim::segmented_radix_sort_pairs(h->d_sort_tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
+                                                  (unsigned int)((size_t)K * count), (unsigned int)K, h->d_seg_off.p, h->d_seg_off.p + 1, 0, 64, st));
+    return RAPID_OK;
+}
+
 int rebuild_view(rapid_engine* h) {
     const int K = h->cfg.K, N = h->n_nodes;
-    std::vector<int> members;
-    members.reserve((size_t)N);
-    for (int n = 0; n < N; ++n)
-        if (h->member[(size_t)n]) members.push_back(n);
-    const int M = (int)members.size();
-    h->n_members = M;
     hipStream_t st = h->stream;
+    const bool timing = getenv("RAPID_TIME_VIEW") != nullptr;  // profiling knob: where a view change spends its time (stderr)
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "rebuild_view %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    // What changed since the rings on the device were built: members that left, members that came (R/MembershipService.java:
+    // 385-430 applies a decided cut as a sequence of ringDelete / ringAdd).  Everybody else keeps its place in every ring.
+    const bool have_rings = h->ring_m > 0 && h->ring_member.size() == (size_t)N;
+    std::vector<int> joiners, gone;
+    int removed = 0, M = 0;
+    for (int n = 0; n < N; ++n) {
+        const bool now = h->member[(size_t)n] != 0;
+        M += now ? 1 : 0;
+        if (have_rings) {
+            const bool was = h->ring_member[(size_t)n] != 0;
+            if (now && !was) joiners.push_back(n);
+            if (was && !now) {
+                ++removed;
+                if (!h->q4_cached.empty()) gone.push_back(n);
+            }
+        }
+    }
+    // Q4 bookkeeping (rapid_view_q4_at_risk), only while something is memoised: ringDelete drops the entries of the node and
+    // of its ring predecessors (TreeSet.lower, no wrap-around) -- read off the tables of the view that is about to change
+    auto q4_drop_lower = [&](const std::vector<int>& nodes) -> int {
+        if (nodes.empty() || h->q4_cached.empty() || !h->d_subj.p || !h->d_pos.p) return RAPID_OK;
+        const size_t m = nodes.size();
+        std::vector<int> preds(m * (size_t)K);
+        HIPCHK(h, h->d_q4_nodes.ensure(m));
+        HIPCHK(h, h->d_q4_rows.ensure(m * (size_t)K));
+        HIPCHK(h, hipMemcpyAsync(h->d_q4_nodes.p, nodes.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(rapid::gather_lower_kernel, dim3(grid_for((long long)m * K, 256)), dim3(256), 0, st, h->d_subj.p, h->d_pos.p, h->d_q4_nodes.p, (int)m,
+                           N, K, h->d_q4_rows.p);
+        HIPCHK(h, hipMemcpyAsync(preds.data(), h->d_q4_rows.p, sizeof(int) * m * (size_t)K, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        for (int q : preds)
+            if (q >= 0) h->q4_cached.erase(q);
+        return RAPID_OK;
+    };
+    if (!gone.empty()) {
+        int rc = q4_drop_lower(gone);
+        if (rc) return rc;
+        for (int n : gone) h->q4_cached.erase(n);  // (:187-191)
+    }
+    h->n_members = M;
+    lap("host scan + q4");
 
     HIPCHK(h, h->d_member.ensure((size_t)N));
     HIPCHK(h, hipMemcpyAsync(h->d_member.p, h->member.data(), (size_t)N, hipMemcpyHostToDevice, st));
-    HIPCHK(h, h->d_members.ensure((size_t)std::max(M, 1)));
-    if (M) HIPCHK(h, hipMemcpyAsync(h->d_members.p, members.data(), sizeof(int) * M, hipMemcpyHostToDevice, st));
     const size_t km = (size_t)K * (size_t)std::max(M, 1);
-    HIPCHK(h, h->d_sort_keys.ensure(km));
-    HIPCHK(h, h->d_sort_vals.ensure(km));
-    HIPCHK(h, h->d_ring_skeys.ensure(km));
-    HIPCHK(h, h->d_ring.ensure(km));
+    HIPCHK(h, h->d_sort_keys.ensure(km));  // (DevBuf::ensure does not keep contents: the rings themselves are only grown where
+    HIPCHK(h, h->d_sort_vals.ensure(km));  //  they are about to be written from scratch)
     HIPCHK(h, h->d_pos.ensure((size_t)K * N));
     HIPCHK(h, h->d_obs.ensure((size_t)K * N));
     HIPCHK(h, h->d_subj.ensure((size_t)K * N));
     HIPCHK(h, h->d_cfg_out.ensure(1));
 
-    // A view change that only removes members leaves the order of the others untouched: compact the rings instead of
-    // sorting them again (the common case -- a decided cut of crashed nodes).
-    bool removals_only = M > 0 && h->ring_m >= M && h->ring_member.size() == (size_t)N;
-    for (int n = 0; removals_only && n < N; ++n)
-        if (h->member[(size_t)n] && !h->ring_member[(size_t)n]) removals_only = false;
-    if (M && removals_only) {
-        if (h->ring_m != M) {
-            hipLaunchKernelGGL(rapid::ring_compact_kernel, dim3(K), dim3(1024), 0, st, h->d_ring.p, h->d_ring_skeys.p, h->ring_m,
-                               h->d_member.p, h->d_sort_vals.p, h->d_sort_keys.p, M);
-            std::swap(h->d_ring, h->d_sort_vals);
-            std::swap(h->d_ring_skeys, h->d_sort_keys);
+    const int J = (int)joiners.size();
+    // incremental while the change is small against the view (a decided cut); a view that is mostly new is sorted afresh
+    const bool incremental = have_rings && M > 0 && (long long)J * 4 <= (long long)h->ring_m && (h->force_exact & 16384) == 0;
+    if (incremental && (removed > 0 || J > 0)) {
+        // Old ring k minus the removed nodes, merged with the joiners in the order of their ring-k keys
+        // (R/MembershipView.java:123-201: each TreeSet loses / gains the endpoint, nothing else moves): three launches over
+        // chunks of the old rings instead of a sort of all K x M keys -- and the only thing a removals-only cut needs.
+        const int m_old = h->ring_m;
+        const int n_chunks = (m_old + rapid::kRingChunk - 1) / rapid::kRingChunk;
+        HIPCHK(h, h->d_chunk_kept.ensure((size_t)K * n_chunks));
+        hipLaunchKernelGGL(rapid::ring_count_kernel, dim3((unsigned)(K * n_chunks)), dim3(rapid::kRingChunk), 0, st, h->d_ring.p, m_old, n_chunks,
+                           h->d_member.p, h->d_chunk_kept.p);
+        if (J > 0) {
+            const size_t kj = (size_t)K * J;
+            HIPCHK(h, h->d_joiners.ensure((size_t)J));
+            HIPCHK(h, h->d_join_keys.ensure(kj));
+            HIPCHK(h, h->d_join_skeys.ensure(kj));
+            HIPCHK(h, h->d_join_vals.ensure(kj));
+            HIPCHK(h, h->d_join_nodes.ensure(kj));
+            HIPCHK(h, hipMemcpyAsync(h->d_joiners.p, joiners.data(), sizeof(int) * (size_t)J, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(rapid::ring_gather_kernel, dim3(grid_for((long long)kj, 256)), dim3(256), 0, st, h->d_keys.p, h->d_joiners.p, J, N, K,
+                               h->d_join_keys.p, h->d_join_vals.p);
+            int rc = sort_rings(h, h->d_join_keys.p, h->d_join_skeys.p, h->d_join_vals.p, h->d_join_nodes.p, J);
+            if (rc) return rc;
+            HIPCHK(h, hipStreamSynchronize(st));  // (`joiners` goes out of scope)
         }
-        hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * M, 256)), dim3(256), 0, st, h->d_ring.p,
-                           h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 0);
-    } else if (M) {
+        hipLaunchKernelGGL(rapid::ring_scatter_kernel, dim3((unsigned)(K * n_chunks)), dim3(rapid::kRingChunk), 0, st, h->d_ring.p, h->d_ring_skeys.p,
+                           m_old, n_chunks, h->d_member.p, h->d_chunk_kept.p, h->d_join_skeys.p, J, h->d_sort_vals.p, h->d_sort_keys.p, M);
+        if (J > 0)
+            hipLaunchKernelGGL(rapid::ring_join_kernel, dim3(grid_for((long long)K * J * 64, 256)), dim3(256), 0, st, h->d_ring.p, h->d_ring_skeys.p,
+                               m_old, n_chunks, h->d_member.p, h->d_chunk_kept.p, h->d_join_skeys.p, h->d_join_nodes.p, J, K, h->d_sort_vals.p,
+                               h->d_sort_keys.p, M);
+        std::swap(h->d_ring, h->d_sort_vals);
+        std::swap(h->d_ring_skeys, h->d_sort_keys);
+        lap("rings: compact + merge");
+    } else if (M && !(incremental && removed == 0 && J == 0)) {
+        HIPCHK(h, h->d_ring_skeys.ensure(km));
+        HIPCHK(h, h->d_ring.ensure(km));
+        std::vector<int> members;
+        members.reserve((size_t)M);
+        for (int n = 0; n < N; ++n)
+            if (h->member[(size_t)n]) members.push_back(n);
+        HIPCHK(h, h->d_members.ensure((size_t)M));
+        HIPCHK(h, hipMemcpyAsync(h->d_members.p, members.data(), sizeof(int) * M, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(rapid::ring_gather_kernel, dim3(grid_for((long long)K * M, 256)), dim3(256), 0, st, h->d_keys.p,
                            h->d_members.p, M, N, K, h->d_sort_keys.p, h->d_sort_vals.p);
-        // all K rings in ONE segmented sort (ring k = segment [k M, (k + 1) M) of the key buffer)
-        h->seg_host.resize((size_t)K + 1);
-        for (int k = 0; k <= K; ++k) h->seg_host[(size_t)k] = k * M;
-        HIPCHK(h, h->d_seg_off.ensure((size_t)K + 1));
-        HIPCHK(h, hipMemcpyAsync(h->d_seg_off.p, h->seg_host.data(), sizeof(int) * ((size_t)K + 1), hipMemcpyHostToDevice, st));
-        size_t tmp_bytes = 0;
-        HIPCHK(h, rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, h->d_sort_keys.p, h->d_ring_skeys.p, h->d_sort_vals.p,
-                                                      h->d_ring.p, (unsigned int)((size_t)K * M), (unsigned int)K, h->d_seg_off.p,
-                                                      h->d_seg_off.p + 1, 0, 64, st));
-        HIPCHK(h, h->d_sort_tmp.ensure(tmp_bytes + 16));
-        HIPCHK(h, rocprim::segmented_radix_sort_pairs(h->d_sort_tmp.p, tmp_bytes, h->d_sort_keys.p, h->d_ring_skeys.p,
-                                                      h->d_sort_vals.p, h->d_ring.p, (unsigned int)((size_t)K * M), (unsigned int)K,
-                                                      h->d_seg_off.p, h->d_seg_off.p + 1, 0, 64, st));
+        int rc = sort_rings(h, h->d_sort_keys.p, h->d_ring_skeys.p, h->d_sort_vals.p, h->d_ring.p, M);
+        if (rc) return rc;
+        HIPCHK(h, hipStreamSynchronize(st));  // (`members` goes out of scope)
+    }
+    if (M)
         hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * M, 256)), dim3(256), 0, st, h->d_ring.p,
                            h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 0);
-    }
     hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * N, 256)), dim3(256), 0, st, h->d_ring.p,
                        h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 1);
 
-    if (h->ids_dirty) {
-        const size_t ni = h->ids_seen.size();
-        std::vector<long long> hi(ni), lo(ni);
-        size_t i = 0;
-        for (const auto& id : h->ids_seen) {
-            hi[i] = id.first;
-            lo[i] = id.second;
-            ++i;
-        }
-        HIPCHK(h, h->d_ids_hi.ensure(std::max<size_t>(ni, 1)));
-        HIPCHK(h, h->d_ids_lo.ensure(std::max<size_t>(ni, 1)));
-        if (ni) {
-            HIPCHK(h, hipMemcpyAsync(h->d_ids_hi.p, hi.data(), ni * 8, hipMemcpyHostToDevice, st));
-            HIPCHK(h, hipMemcpyAsync(h->d_ids_lo.p, lo.data(), ni * 8, hipMemcpyHostToDevice, st));
-            HIPCHK(h, hipStreamSynchronize(st));  // hi/lo go out of scope
-        }
-        h->n_ids_dev = (int)ni;
-        h->ids_dirty = false;
+    lap("tables");
+    if (have_rings && !joiners.empty()) {  // ringAdd drops the entries of the joiner's new ring predecessors (:143-152)
+        int rc = q4_drop_lower(joiners);
+        if (rc) return rc;
     }
-    const int T = 1024;
-    hipLaunchKernelGGL(rapid::config_id_kernel, dim3(1), dim3(T), (size_t)T * 16, st, h->d_ids_hi.p, h->d_ids_lo.p,
-                       h->n_ids_dev, h->d_ring.p, M, h->d_hx_host0.p, h->d_hx_port0.p, h->d_cfg_out.p);
+
+    // identifiersSeen, sorted, on the device: everything again after a build; a cut's few new NodeIds are merged in
+    if (!h->ids_pending.empty()) {
+        std::sort(h->ids_pending.begin(), h->ids_pending.end());
+        const size_t nn = h->ids_pending.size(), ni = (size_t)h->n_ids_dev + nn;
+        std::vector<long long> flat(2 * nn);
+        for (size_t i = 0; i < nn; ++i) {
+            flat[i] = h->ids_pending[i].first;
+            flat[nn + i] = h->ids_pending[i].second;
+        }
+        HIPCHK(h, h->d_ids_new.ensure(2 * nn));
+        HIPCHK(h, h->d_ids_hi2.ensure(ni));
+        HIPCHK(h, h->d_ids_lo2.ensure(ni));
+        HIPCHK(h, hipMemcpyAsync(h->d_ids_new.p, flat.data(), 16 * nn, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(rapid::ids_merge_kernel, dim3(grid_for((long long)ni, 256)), dim3(256), 0, st, h->d_ids_hi.p, h->d_ids_lo.p, h->n_ids_dev,
+                           h->d_ids_new.p, h->d_ids_new.p + nn, (int)nn, h->d_ids_hi2.p, h->d_ids_lo2.p);
+        HIPCHK(h, hipStreamSynchronize(st));  // (`flat` goes out of scope)
+        std::swap(h->d_ids_hi, h->d_ids_hi2);
+        std::swap(h->d_ids_lo, h->d_ids_lo2);
+        h->n_ids_dev = (int)ni;
+        h->ids_pending.clear();
+    }
+    lap("identifiers");
+    {
+        const int T = 1024;
+        const long long total = 2ll * h->n_ids_dev + 2ll * M;
+        const int G = (int)std::max<long long>(1, std::min<long long>(512, total / 8192));
+        HIPCHK(h, h->d_cfg_partial.ensure((size_t)2 * G));
+        hipLaunchKernelGGL(rapid::config_id_kernel, dim3((unsigned)G), dim3(T), (size_t)T * 16, st, h->d_ids_hi.p, h->d_ids_lo.p,
+                           h->n_ids_dev, h->d_ring.p, M, h->d_hx_host0.p, h->d_hx_port0.p, h->d_cfg_out.p, h->d_cfg_partial.p);
+        if (G > 1) hipLaunchKernelGGL(rapid::config_id_final_kernel, dim3(1), dim3(64), 0, st, h->d_cfg_partial.p, G, h->d_cfg_out.p);
+    }
     long long cfg = 0;
     HIPCHK(h, hipMemcpyAsync(&cfg, h->d_cfg_out.p, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
+    lap("configuration id");
     h->config_id = cfg;
     h->ring_member = h->member;
     h->ring_m = M;
@@ -715,6 +841,9 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_sort_keys.release(); h->d_sort_vals.release(); h->d_ring_skeys.release(); h->d_ring.release();
     h->d_pos.release(); h->d_obs.release(); h->d_subj.release();
     h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
+    h->d_q4_nodes.release(); h->d_q4_rows.release();
+    h->d_ids_hi2.release(); h->d_ids_lo2.release(); h->d_ids_new.release(); h->d_cfg_partial.release(); h->d_chunk_kept.release();
+    h->d_joiners.release(); h->d_join_nodes.release(); h->d_join_vals.release(); h->d_join_keys.release(); h->d_join_skeys.release();
     h->d_core.release(); h->d_cfg.release(); h->d_stage.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
     h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_idxblk.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release(); h->d_trank.release(); h->d_tbits.release(); h->d_tent.release();
@@ -741,15 +870,35 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
     h->id_hi.assign(id_hi, id_hi + n_nodes);
     h->id_lo.assign(id_lo, id_lo + n_nodes);
     h->member.assign((size_t)n_nodes, 0);
-    h->ids_seen.clear();
+    std::vector<std::pair<int64_t, int64_t>> ids;
+    ids.reserve((size_t)n_members + (size_t)n_extra);
     for (int i = 0; i < n_members; ++i) {
         const int m = members[i];
         if (m < 0 || m >= n_nodes) return fail(h, RAPID_EINVAL, "member index %d out of range", m);
         h->member[(size_t)m] = 1;  // Set semantics, like TreeSet.addAll (R/MembershipView.java:82-85)
-        h->ids_seen.insert({id_hi[m], id_lo[m]});
+        ids.push_back({id_hi[m], id_lo[m]});
     }
-    for (int i = 0; i < n_extra; ++i) h->ids_seen.insert({extra_id_hi[i], extra_id_lo[i]});
-    h->ids_dirty = true;
+    for (int i = 0; i < n_extra; ++i) ids.push_back({extra_id_hi[i], extra_id_lo[i]});
+    std::sort(ids.begin(), ids.end());  // the order of the reference's TreeSet<NodeId> (:474-500); a set: duplicates collapse
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    {
+        const size_t ni = ids.size();
+        std::vector<long long> hi(ni), lo(ni);
+        for (size_t i = 0; i < ni; ++i) {
+            hi[i] = ids[i].first;
+            lo[i] = ids[i].second;
+        }
+        HIPCHK(h, h->d_ids_hi.ensure(std::max<size_t>(ni, 1)));
+        HIPCHK(h, h->d_ids_lo.ensure(std::max<size_t>(ni, 1)));
+        if (ni) {
+            HIPCHK(h, hipMemcpyAsync(h->d_ids_hi.p, hi.data(), ni * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->d_ids_lo.p, lo.data(), ni * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+        h->n_ids_dev = (int)ni;
+    }
+    h->ids_pending.clear();
+    h->q4_cached.clear();  // a new MembershipView object: nothing memoised
 
     for (int i = 0; i < n_nodes; ++i)
         if (host_off[i + 1] < host_off[i]) return fail(h, RAPID_EINVAL, "hostname offsets must not decrease (entry %d)", i);
@@ -824,8 +973,11 @@ int rapid_view_is_safe_to_join(rapid_engine* h, int32_t node, int64_t id_hi, int
     int rc = check_node(h, node);
     if (rc) return rc;
     if (h->member[(size_t)node]) *status_out = RAPID_HOSTNAME_ALREADY_IN_RING;
-    else if (h->ids_seen.count({id_hi, id_lo})) *status_out = RAPID_UUID_ALREADY_IN_RING;
-    else *status_out = RAPID_SAFE_TO_JOIN;
+    else {
+        bool seen = false;
+        if ((rc = use_device(h)) || (rc = ids_seen_any(h, {{id_hi, id_lo}}, &seen))) return rc;
+        *status_out = seen ? RAPID_UUID_ALREADY_IN_RING : RAPID_SAFE_TO_JOIN;
+    }
     return RAPID_OK;
 }
 
@@ -834,13 +986,14 @@ int rapid_view_ring_add(rapid_engine* h, int32_t node, int64_t id_hi, int64_t id
     if (rc) return rc;
     if ((rc = use_device(h))) return rc;
     const std::pair<int64_t, int64_t> id{id_hi, id_lo};
-    if (h->ids_seen.count(id)) return fail(h, RAPID_EUUID_SEEN, "identifier of node %d already seen", node);  // :127-129
+    bool seen = false;
+    if ((rc = ids_seen_any(h, {id}, &seen))) return rc;
+    if (seen) return fail(h, RAPID_EUUID_SEEN, "identifier of node %d already seen", node);  // :127-129
     if (h->member[(size_t)node]) return fail(h, RAPID_ENODE_EXISTS, "node %d already in ring", node);          // :133-135
     h->member[(size_t)node] = 1;
     h->id_hi[(size_t)node] = id_hi;
     h->id_lo[(size_t)node] = id_lo;
-    h->ids_seen.insert(id);
-    h->ids_dirty = true;
+    h->ids_pending.push_back(id);
     return rebuild_view(h);
 }
 
@@ -933,6 +1086,49 @@ int rapid_view_size(rapid_engine* h, int32_t* n_out) {
 int rapid_view_config_id(rapid_engine* h, int64_t* id_out) {
     if (!h || !h->view_built) return fail(h, RAPID_ESTATE, "view not built");
     *id_out = h->config_id;
+    return RAPID_OK;
+}
+
+int rapid_view_q4_at_risk(rapid_engine* h, const int32_t* hot, int32_t n, int32_t* out, int32_t cap, int32_t* n_out) {
+    if (!h || n < 0 || (n > 0 && !hot) || cap < 0 || (cap > 0 && !out) || !n_out) return RAPID_EINVAL;
+    if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int K = h->cfg.K;
+    std::vector<int> nodes;
+    nodes.reserve((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (hot[i] < 0 || hot[i] >= h->n_nodes) return fail(h, RAPID_EINVAL, "node index %d out of range", hot[i]);
+        if (h->member[(size_t)hot[i]]) nodes.push_back(hot[i]);
+    }
+    std::sort(nodes.begin(), nodes.end());
+    nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+    *n_out = 0;
+    if (nodes.empty()) return RAPID_OK;
+    const size_t m = nodes.size();
+    std::vector<int> rows(m * (size_t)K);
+    HIPCHK(h, h->d_q4_nodes.ensure(m));
+    HIPCHK(h, h->d_q4_rows.ensure(m * (size_t)K));
+    HIPCHK(h, hipMemcpyAsync(h->d_q4_nodes.p, nodes.data(), sizeof(int) * m, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(rapid::gather_rows_kernel, dim3(grid_for((long long)m * K, 256)), dim3(256), 0, h->stream, h->d_obs.p, h->d_q4_nodes.p, (int)m, K,
+                       h->d_q4_rows.p);
+    HIPCHK(h, hipMemcpyAsync(rows.data(), h->d_q4_rows.p, sizeof(int) * m * (size_t)K, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int at_risk = 0;
+    for (size_t i = 0; i < m; ++i) {
+        // (a view of one member has no observers: computeObserversOf returns the empty list, :240-242)
+        std::vector<int> fresh;
+        if (h->n_members > 1) fresh.assign(rows.begin() + (long)(i * (size_t)K), rows.begin() + (long)((i + 1) * (size_t)K));
+        auto it = h->q4_cached.find(nodes[i]);
+        if (it == h->q4_cached.end()) {
+            h->q4_cached.emplace(nodes[i], std::move(fresh));
+        } else if (it->second != fresh) {
+            if (at_risk < cap) out[at_risk] = nodes[i];
+            ++at_risk;
+        }
+    }
+    *n_out = at_risk;
+    if (at_risk > cap) return fail(h, RAPID_ECAPACITY, "%d subjects at risk, capacity %d", at_risk, cap);
     return RAPID_OK;
 }
 
@@ -1493,25 +1689,25 @@ int rapid_apply_cut(rapid_engine* h, const int32_t* cut, int32_t n, int64_t* new
     if (rc) return rc;
     // validate first so that a failing call leaves the view untouched
     std::vector<uint8_t> mem = h->member;
-    std::set<std::pair<int64_t, int64_t>> added;
+    std::vector<std::pair<int64_t, int64_t>> added;
     for (int i = 0; i < n; ++i) {
         const int node = cut[i];
         if (node < 0 || node >= h->n_nodes) return fail(h, RAPID_EINVAL, "node index %d out of range", node);
         if (mem[(size_t)node]) {
             mem[(size_t)node] = 0;  // ringDelete (R/MembershipService.java:399-400)
         } else {
-            const std::pair<int64_t, int64_t> id{h->id_hi[(size_t)node], h->id_lo[(size_t)node]};
-            if (h->ids_seen.count(id) || added.count(id))
-                return fail(h, RAPID_EUUID_SEEN, "identifier of joiner %d already seen", node);  // ringAdd :127-129
-            added.insert(id);
+            added.push_back({h->id_hi[(size_t)node], h->id_lo[(size_t)node]});
             mem[(size_t)node] = 1;  // ringAdd (R/MembershipService.java:404-407)
         }
     }
-    h->member.swap(mem);
-    if (!added.empty()) {
-        h->ids_seen.insert(added.begin(), added.end());
-        h->ids_dirty = true;
+    if (!added.empty()) {  // ringAdd :127-129: an identifier seen before -- in an earlier configuration, or earlier in this cut
+        std::sort(added.begin(), added.end());
+        bool seen = std::adjacent_find(added.begin(), added.end()) != added.end();
+        if (!seen && (rc = ids_seen_any(h, added, &seen))) return rc;
+        if (seen) return fail(h, RAPID_EUUID_SEEN, "the identifier of a joiner in the cut was already seen");
     }
+    h->member.swap(mem);
+    h->ids_pending.insert(h->ids_pending.end(), added.begin(), added.end());
     rc = rebuild_view(h);  // new rings, tables, configuration id; cutDetection.clear() == fresh state next tally
     if (rc) return rc;
     if (new_config_id) *new_config_id = h->config_id;

@@ -134,41 +134,6 @@ __global__ void ring_gather_kernel(const long long* keys, const int* members, in
     sort_vals[t] = n;
 }
 
-// Removal-only view change: the ring order of the remaining members does not change, so every ring is its old self
-// minus the deleted nodes (R/MembershipView.java:167-201 removes the endpoint from each TreeSet, nothing moves).
-// One workgroup per ring: stable compaction of the (sortable key, node) pairs by the new member flags.
-__global__ void ring_compact_kernel(const int* ring_in, const unsigned long long* skeys_in, int m_old,
-                                    const unsigned char* member, int* ring_out, unsigned long long* skeys_out, int m_new) {
-    __shared__ int s_count[1024];
-    const int k = (int)blockIdx.x, T = (int)blockDim.x, t = (int)threadIdx.x;
-    const int per = (m_old + T - 1) / T;
-    const int beg = min(m_old, t * per), end = min(m_old, beg + per);
-    const int* rin = ring_in + (long long)k * m_old;
-    const unsigned long long* kin = skeys_in + (long long)k * m_old;
-    int kept = 0;
-    for (int i = beg; i < end; ++i) kept += member[rin[i]] ? 1 : 0;
-    s_count[t] = kept;
-    __syncthreads();
-    // inclusive Hillis-Steele scan over the T partial counts
-    for (int off = 1; off < T; off <<= 1) {
-        const int v = t >= off ? s_count[t - off] : 0;
-        __syncthreads();
-        s_count[t] += v;
-        __syncthreads();
-    }
-    int w = s_count[t] - kept;  // exclusive prefix
-    int* rout = ring_out + (long long)k * m_new;
-    unsigned long long* kout = skeys_out + (long long)k * m_new;
-    for (int i = beg; i < end; ++i) {
-        const int node = rin[i];
-        if (member[node] && w < m_new) {
-            rout[w] = node;
-            kout[w] = kin[i];
-            ++w;
-        }
-    }
-}
-
 // after the K sorts: ring[k][pos] = node, ring_skeys[k][pos] = sortable key.  Members get successor /
 // predecessor rows; non-members get their expected observers (predecessor of their key on every ring).
 __global__ void ring_tables_kernel(const int* ring, const unsigned long long* ring_skeys, const long long* keys,
@@ -207,22 +172,190 @@ __global__ void ring_tables_kernel(const int* ring, const unsigned long long* ri
     subj[t] = s;
 }
 
+// ---- incremental view change (R/MembershipView.java:123-160 ringAdd, :167-201 ringDelete) ---------------------------------
+// A decided cut removes some members and admits some joiners; everybody else keeps its place in every ring.  The new ring k
+// is therefore the old ring k without the removed nodes, merged with the (few) joiners sorted by their ring-k key -- a
+// stable compaction plus a merge by binary search, spread over workgroups of kRingChunk old positions, instead of sorting
+// all K x M keys again.  Three launches:
+//   ring_count_kernel    chunk_kept[k][c] = survivors among the old positions of chunk c of ring k
+//   ring_scatter_kernel  survivor at old position p  ->  new position (survivors before p) + (joiners with a smaller key)
+//   ring_join_kernel     joiner j of ring k          ->  new position j + (survivors with a smaller key)
+constexpr int kRingChunk = 1024;
+
+__device__ inline int lower_bound_u64(const unsigned long long* a, int n, unsigned long long key) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// grid = K x n_chunks (blockIdx.x = k * n_chunks + c), block = kRingChunk
+__global__ __launch_bounds__(kRingChunk) void ring_count_kernel(const int* ring_in, int m_old, int n_chunks, const unsigned char* member,
+                                                                int* chunk_kept) {
+    __shared__ int s_total;
+    if (threadIdx.x == 0) s_total = 0;
+    __syncthreads();
+    const int k = (int)blockIdx.x / n_chunks, c = (int)blockIdx.x - k * n_chunks;
+    const int p = c * kRingChunk + (int)threadIdx.x;
+    const bool keep = p < m_old && member[ring_in[(long long)k * m_old + p]] != 0;
+    const unsigned long long b = __ballot(keep);
+    if ((threadIdx.x & 63u) == 0u && b != 0ull) atomicAdd(&s_total, __popcll(b));
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_kept[blockIdx.x] = s_total;
+}
+
+// survivors before old position p of ring k: the chunks before p's chunk (block-wide sum, every thread gets it) ...
+__device__ inline int ring_chunks_before(const int* chunk_kept_k, int c, int* s_acc) {
+    if (threadIdx.x == 0) *s_acc = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = (int)threadIdx.x; i < c; i += (int)blockDim.x) mine += chunk_kept_k[i];
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if ((threadIdx.x & 63u) == 0u && mine != 0) atomicAdd(s_acc, mine);
+    __syncthreads();
+    return *s_acc;
+}
+
+__global__ __launch_bounds__(kRingChunk) void ring_scatter_kernel(const int* ring_in, const unsigned long long* skeys_in, int m_old, int n_chunks,
+                                                                  const unsigned char* member, const int* chunk_kept,
+                                                                  const unsigned long long* join_skeys, int n_join, int* ring_out,
+                                                                  unsigned long long* skeys_out, int m_new) {
+    __shared__ int s_acc;
+    __shared__ int s_wave[kRingChunk / 64];
+    const int k = (int)blockIdx.x / n_chunks, c = (int)blockIdx.x - k * n_chunks;
+    const int base = ring_chunks_before(chunk_kept + (long long)k * n_chunks, c, &s_acc);
+    const int p = c * kRingChunk + (int)threadIdx.x;
+    int node = 0;
+    unsigned long long key = 0ull;
+    bool keep = false;
+    if (p < m_old) {
+        node = ring_in[(long long)k * m_old + p];
+        key = skeys_in[(long long)k * m_old + p];
+        keep = member[node] != 0;
+    }
+    const unsigned long long b = __ballot(keep);
+    const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+    if (lane == 0) s_wave[wv] = __popcll(b);
+    __syncthreads();
+    int before = base + __popcll(b & ((1ull << lane) - 1ull));
+    for (int i = 0; i < wv; ++i) before += s_wave[i];
+    if (keep) {
+        const int at = before + (n_join > 0 ? lower_bound_u64(join_skeys + (long long)k * n_join, n_join, key) : 0);
+        if (at < m_new) {
+            ring_out[(long long)k * m_new + at] = node;
+            skeys_out[(long long)k * m_new + at] = key;
+        }
+    }
+}
+
+// one wavefront per (ring, joiner): grid = ceil(K * n_join / waves per block)
+__global__ __launch_bounds__(256) void ring_join_kernel(const int* ring_in, const unsigned long long* skeys_in, int m_old, int n_chunks,
+                                                        const unsigned char* member, const int* chunk_kept, const unsigned long long* join_skeys,
+                                                        const int* join_nodes, int n_join, int K, int* ring_out, unsigned long long* skeys_out,
+                                                        int m_new) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const long long w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= (long long)K * n_join) return;
+    const int k = (int)(w / n_join), j = (int)(w - (long long)k * n_join);
+    const unsigned long long key = join_skeys[w];
+    const int* rk = ring_in + (long long)k * m_old;
+    const int p = lower_bound_u64(skeys_in + (long long)k * m_old, m_old, key);  // old positions with a smaller key: [0, p)
+    const int c = p / kRingChunk;
+    int kept = 0;
+    for (int i = lane; i < c; i += 64) kept += chunk_kept[(long long)k * n_chunks + i];
+    for (int i = c * kRingChunk + lane; i < p; i += 64) kept += member[rk[i]] != 0 ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
+    if (lane == 0 && j + kept < m_new) {
+        ring_out[(long long)k * m_new + j + kept] = join_nodes[w];
+        skeys_out[(long long)k * m_new + j + kept] = key;
+    }
+}
+
+// identifiersSeen (R/MembershipView.java:474-500: ordered by signed high, then signed low; never pruned) lives sorted on the
+// device; the NodeIds a cut admits (sorted the same way on the host, a handful) are merged in: one thread per element
+__device__ inline bool id_less(long long ah, long long al, long long bh, long long bl) { return ah < bh || (ah == bh && al < bl); }
+// flag[0] |= 1 if any of the `n_new` ids is among the `n_old` sorted ones (UUIDAlreadySeenException, R/MembershipView.java:127-129)
+__global__ void ids_contains_kernel(const long long* old_hi, const long long* old_lo, int n_old, const long long* new_hi, const long long* new_lo,
+                                    int n_new, unsigned int* flag) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_new) return;
+    const long long h = new_hi[t], l = new_lo[t];
+    int lo = 0, hi = n_old;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (id_less(old_hi[mid], old_lo[mid], h, l)) lo = mid + 1; else hi = mid;
+    }
+    if (lo < n_old && old_hi[lo] == h && old_lo[lo] == l) atomicOr(flag, 1u);
+}
+
+__global__ void ids_merge_kernel(const long long* old_hi, const long long* old_lo, int n_old, const long long* new_hi, const long long* new_lo,
+                                 int n_new, long long* out_hi, long long* out_lo) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_old) {
+        const long long h = old_hi[t], l = old_lo[t];
+        int lo = 0, hi = n_new;  // new ids smaller than this one
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (id_less(new_hi[mid], new_lo[mid], h, l)) lo = mid + 1; else hi = mid;
+        }
+        out_hi[t + lo] = h;
+        out_lo[t + lo] = l;
+    } else if (t < (long long)n_old + n_new) {
+        const int j = (int)(t - n_old);
+        const long long h = new_hi[j], l = new_lo[j];
+        int lo = 0, hi = n_old;  // old ids smaller than this one
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (id_less(old_hi[mid], old_lo[mid], h, l)) lo = mid + 1; else hi = mid;
+        }
+        out_hi[j + lo] = h;
+        out_lo[j + lo] = l;
+    }
+}
+
+// rows[i][0..K) = table[nodes[i]][0..K): a few rows of the observer table for the host (rapid_view_q4_at_risk)
+__global__ void gather_rows_kernel(const int* table, const int* nodes, int n, int K, int* rows) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n * K) return;
+    const int i = (int)(t / K), k = (int)(t - (long long)i * K);
+    rows[t] = table[(long long)nodes[i] * K + k];
+}
+
+// preds[i][k] = the ring-k predecessor of nodes[i] WITHOUT wrap-around (TreeSet.lower: -1 for the ring minimum) -- the node
+// whose memoised observers ringAdd / ringDelete of nodes[i] drop (R/MembershipView.java:143-152, 181-195)
+__global__ void gather_lower_kernel(const int* subj, const int* pos, const int* nodes, int n, int n_nodes, int K, int* preds) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n * K) return;
+    const int i = (int)(t / K), k = (int)(t - (long long)i * K);
+    const int node = nodes[i];
+    preds[t] = pos[(long long)k * n_nodes + node] > 0 ? subj[(long long)node * K + k] : -1;
+}
+
 // ---- configuration id -------------------------------------------------------------------------------------------
 // hash = 1; for id in sorted ids: hash = hash*37 + xx0(high); hash = hash*37 + xx0(low);
 //           for ep in ring 0:     hash = hash*37 + xx0(hostname); hash = hash*37 + xx0(port)
-// A segment of the sequence maps h -> h * m + v with m = 37^len; segments compose associatively, so the block
-// reduces (v, m) pairs.  One block; thread t folds a contiguous slice with Horner's rule.
+// A segment of the sequence maps h -> h * m + v with m = 37^len; segments compose associatively (the affine maps
+// h -> h m + v form a monoid), so the sequence is cut into gridDim.x contiguous slices: workgroup b reduces slice b to one
+// (v, m) pair -- thread t folds a contiguous piece with Horner's rule, an ordered tree combines the pieces -- and
+// config_id_final_kernel folds the workgroups' pairs in order.  With one workgroup (small views) the first kernel writes
+// the configuration id itself.
 __global__ void config_id_kernel(const long long* ids_hi, const long long* ids_lo, int n_ids, const int* ring0,
                                  int n_members, const unsigned long long* hx_host0, const unsigned long long* hx_port0,
-                                 long long* out) {
+                                 long long* out, unsigned long long* partial) {
     RAPID_DYNAMIC_LDS(smem_raw);
     unsigned long long* sv = reinterpret_cast<unsigned long long*>(smem_raw);
     unsigned long long* sm = sv + blockDim.x;
     const long long total = 2ll * n_ids + 2ll * n_members;
     const int T = (int)blockDim.x;
     const int t = (int)threadIdx.x;
-    const long long per = (total + T - 1) / T;
-    const long long beg = per * t, end = (beg + per < total) ? beg + per : total;
+    const long long G = (long long)gridDim.x;
+    const long long per_block = (total + G - 1) / G;
+    const long long b0 = per_block * (long long)blockIdx.x, b1 = (b0 + per_block < total) ? b0 + per_block : total;
+    const long long span = b1 > b0 ? b1 - b0 : 0;
+    const long long per = (span + T - 1) / T;
+    const long long beg = b0 + per * t, end = (beg + per < b1) ? beg + per : b1;
     unsigned long long v = 0, m = 1;
     for (long long i = beg; i < end; ++i) {
         unsigned long long x;
@@ -249,7 +382,22 @@ __global__ void config_id_kernel(const long long* ids_hi, const long long* ids_l
         }
         __syncthreads();
     }
-    if (t == 0) out[0] = (long long)(1ull * sm[0] + sv[0]);
+    if (t == 0) {
+        if (gridDim.x == 1) {
+            out[0] = (long long)(1ull * sm[0] + sv[0]);
+        } else {
+            partial[2 * blockIdx.x] = sv[0];
+            partial[2 * blockIdx.x + 1] = sm[0];
+        }
+    }
+}
+
+// the workgroups' (v, m) pairs, in order, applied to h = 1 (one wavefront; a few hundred pairs)
+__global__ void config_id_final_kernel(const unsigned long long* partial, int n_pairs, long long* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long h = 1ull;
+    for (int i = 0; i < n_pairs; ++i) h = h * partial[2 * i + 1] + partial[2 * i];
+    out[0] = (long long)h;
 }
 
 }  // namespace rapid

@@ -430,28 +430,20 @@ class ObserverCacheGuard:
     cluster and an entry survives a view change that moves the ring minimum.  The only reader on the hot path is
     invalidateFailingEdges (R/MultiNodeCutDetector.java:147-149), which asks for the observers of the subjects in
     preProposal -- subjects the round's alerts name on >= L rings ("hot").  The engine always works from the fresh tables,
-    so its results equal the reference's as long as no receiver can hold a STALE entry for a subject that is hot now:
-    i.e. as long as no member that is hot in this round was hot in an earlier configuration with different observers
-    (an entry only exists where it was asked for; a crashed subject's entry dies with its ringDelete).  This guard keeps
-    that condition, exactly, on the host: `check_round` returns the members for which it fails (empty: Q4 cannot fire at
-    any receiver in this round; non-empty: bit-exactness against the Java is not guaranteed for this round and the
-    caller must say so)."""
-
-    def __init__(self):
-        self.cached = {}  # node -> observer list when it was first hot (what a receiver's cache may still hold)
+    so its results equal the reference's as long as no receiver can hold a STALE entry for a subject that is hot now.
+    The bookkeeping lives behind the C ABI (rapid_view_q4_at_risk; updated by rapid_apply_cut / rapid_view_ring_delete);
+    this class is the host-side handle tests and scripts use: `check_round` returns the members for which the condition
+    fails (empty: Q4 cannot fire at any receiver in this round; non-empty: bit-exactness against the Java is not guaranteed
+    for this round and the caller must say so)."""
 
     def check_round(self, view, hot_nodes):
-        hot_members = [int(x) for x in hot_nodes if view.isHostPresent(int(x))]
-        at_risk = []
-        for node in hot_members:
-            fresh = view.getObserversOf(node)
-            old = self.cached.get(node)
-            if old is not None and old != fresh:
-                at_risk.append(node)
-            if old is None:
-                self.cached[node] = fresh
-        return at_risk
+        e = view.e
+        hot = np.ascontiguousarray(hot_nodes, dtype=np.int32)
+        out = np.empty(max(len(hot), 1), dtype=np.int32)
+        n = C.c_int32(0)
+        e._check(e._lib.rapid_view_q4_at_risk(e._h, _addr(hot) if len(hot) else None, len(hot), _addr(out), len(out), C.byref(n)))
+        return out[: n.value].tolist()
 
     def on_view_change(self, removed):
-        for node in removed:  # ringDelete erases the node's own entry (R/MembershipView.java:187-191)
-            self.cached.pop(int(node), None)
+        """(kept for callers of the round-2 interface: the engine forgets a node when it leaves the view)"""
+        return None

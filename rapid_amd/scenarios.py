@@ -194,8 +194,10 @@ def build_churn_scenario(obs, member, cfg_id, n_crash, n_join, H, L, seed_fault=
 def deliver(batches, receivers, seed_delivery, loss=0.0, stale_cfg=None, stale_rate=0.0):
     """Every receiver gets every batch once, in a receiver-specific seeded order (paper Fig.11 methodology);
     `loss` drops (receiver, batch) pairs i.i.d.  Returns (records, rec_off[R+1], batches_per_receiver[R]).
-    With `stale_rate`, that fraction of delivered records has its cfg_id replaced by `stale_cfg` (exercises
-    the filter of MembershipService.java:653-657)."""
+    With `stale_rate`, every receiver ALSO gets that fraction of the batches (seeded, at random places of its order) as late
+    deliveries from the previous configuration: whole BatchedAlertMessages whose alerts carry `stale_cfg` and are dropped by
+    the filter of MembershipService.java:653-657 (their batch end still counts: invalidateFailingEdges runs after every
+    batch, R/MembershipService.java:330).  Nothing of the current round is lost to them."""
     B = batches.n_batches
     blen = np.diff(batches.off)
     R = len(receivers)
@@ -205,6 +207,13 @@ def deliver(batches, receivers, seed_delivery, loss=0.0, stale_cfg=None, stale_r
         perm = rng.permutation(B)
         if loss > 0:
             perm = perm[rng.random(B) >= loss]
+        late = np.zeros(len(perm), dtype=bool)
+        if stale_rate > 0 and B:
+            n_late = max(1, int(round(stale_rate * B)))
+            perm = np.concatenate([perm, rng.integers(0, B, size=n_late)])
+            late = np.concatenate([late, np.ones(n_late, dtype=bool)])
+            order = rng.permutation(len(perm))
+            perm, late = perm[order], late[order]
         lens = blen[perm]
         tot = int(lens.sum())
         # gather indices: for each delivered batch, off[b] + arange(len)
@@ -212,8 +221,7 @@ def deliver(batches, receivers, seed_delivery, loss=0.0, stale_cfg=None, stale_r
         idx = starts + np.arange(tot, dtype=np.int64)
         recs = batches.recs[idx]
         if stale_rate > 0 and tot:
-            st = rng.random(tot) < stale_rate
-            recs["cfg_id"][st] = stale_cfg
+            recs["cfg_id"][np.repeat(late, lens)] = stale_cfg
         out.append(recs)
         rec_off[i + 1] = rec_off[i] + tot
         nb[i] = len(perm)
@@ -281,8 +289,8 @@ class StreamingChurn:
     """C5: rounds of continuous churn over one population (BASELINE configs[4]).  Every round takes the CURRENT
     view (observer table + membership, after the previous round's cut was applied), crashes `crash_frac` of the members
     and lets `join_frac` x members outsiders join, delivers the round's batches to a seeded sample of the surviving
-    members, and replaces `stale_rate` of the delivered records' configuration ids by the PREVIOUS configuration's id
-    (late deliveries of the last round: filtered by R/MembershipService.java:653-657).  The registry must hold the
+    members, and interleaves late deliveries from the PREVIOUS configuration (`stale_rate` x the round's batches, carrying the
+    previous configuration id: filtered by R/MembershipService.java:653-657).  The registry must hold the
     joiners of all rounds as non-members: `Population.make(n_members + spare)`."""
 
     def __init__(self, H, L, crash_frac=0.01, join_frac=0.005, stale_rate=0.01, receivers_per_round=None, seed=5):

@@ -395,19 +395,75 @@ extern "C" int emu_view_build(const unsigned char* blob, const int* host_off, co
     launch((long long)KN, 256u, [&] {
         rapid::ring_tables_kernel(ring_out, sk2.data(), keys_out, member.data(), n_nodes, n_members, K, pos.data(), obs_out, subj_out, 1);
     }, seed + 3000);
-    emu::run_block(0u, 1u, 1024u, [&] {
-        rapid::config_id_kernel(ids_hi_sorted, ids_lo_sorted, n_ids, ring_out, n_members, hx_host.data(), hx_port.data(), cfg_out);
-    }, seed + 4000);
-    if (keep != nullptr) {  // removal-only view change: every ring compacted in place of a new sort
-        int m_new = 0;
-        for (int i = 0; i < n_members; ++i) m_new += keep[members[i]] ? 1 : 0;
-        *n_members2_out = m_new;
-        std::vector<unsigned long long> sk3((size_t)K * (size_t)std::max(m_new, 1));
-        for (int k = 0; k < K; ++k)
-            emu::run_block((unsigned)k, (unsigned)K, 1024u, [&] {
-                rapid::ring_compact_kernel(ring_out, sk2.data(), n_members, keep, ring2_out, sk3.data(), m_new);
-            }, seed + 5000 + (unsigned)k);
+    {   // one workgroup, and the same sequence cut into three slices whose (v, m) pairs are folded in order
+        std::vector<unsigned long long> partial(8, 0ull);
+        emu::run_block(0u, 1u, 1024u, [&] {
+            rapid::config_id_kernel(ids_hi_sorted, ids_lo_sorted, n_ids, ring_out, n_members, hx_host.data(), hx_port.data(), cfg_out, partial.data());
+        }, seed + 4000);
+        long long cfg3 = 0;
+        for (unsigned b = 0; b < 3u; ++b)
+            emu::run_block(b, 3u, 256u, [&] {
+                rapid::config_id_kernel(ids_hi_sorted, ids_lo_sorted, n_ids, ring_out, n_members, hx_host.data(), hx_port.data(), &cfg3, partial.data());
+            }, seed + 4100 + b);
+        emu::run_block(0u, 1u, 64u, [&] { rapid::config_id_final_kernel(partial.data(), 3, &cfg3); }, seed + 4200);
+        if (cfg3 != cfg_out[0]) return -11;
     }
+    if (keep != nullptr) {
+        // a view change: `keep` = the new member flags.  Old rings minus the nodes that left, merged with the joiners by
+        // their ring keys (count / scatter / join over chunks of the old rings) instead of a new sort
+        std::vector<int> joiners;
+        std::vector<unsigned char> was(n_nodes + 1, 0);
+        for (int i = 0; i < n_members; ++i) was[members[i]] = 1;
+        int m_new = 0;
+        for (int n = 0; n < n_nodes; ++n) {
+            m_new += keep[n] ? 1 : 0;
+            if (keep[n] && !was[n]) joiners.push_back(n);
+        }
+        *n_members2_out = m_new;
+        const int J = (int)joiners.size();
+        const int n_chunks = (std::max(n_members, 1) + rapid::kRingChunk - 1) / rapid::kRingChunk;
+        std::vector<int> chunk_kept((size_t)K * n_chunks, -1), jvals((size_t)K * std::max(J, 1)), jnodes((size_t)K * std::max(J, 1));
+        std::vector<unsigned long long> sk3((size_t)K * (size_t)std::max(m_new, 1)), jkeys((size_t)K * std::max(J, 1)), jskeys((size_t)K * std::max(J, 1));
+        for (int b = 0; b < K * n_chunks; ++b)
+            emu::run_block((unsigned)b, (unsigned)(K * n_chunks), (unsigned)rapid::kRingChunk, [&] {
+                rapid::ring_count_kernel(ring_out, n_members, n_chunks, keep, chunk_kept.data());
+            }, seed + 5000 + (unsigned)b);
+        if (J > 0) {
+            launch((long long)K * J, 256u, [&] { rapid::ring_gather_kernel(keys_out, joiners.data(), J, n_nodes, K, jkeys.data(), jvals.data()); }, seed + 5500);
+            for (int k = 0; k < K; ++k) {
+                std::vector<int> order(J);
+                std::iota(order.begin(), order.end(), 0);
+                const unsigned long long* sk = jkeys.data() + (size_t)k * J;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sk[a] < sk[b]; });
+                for (int i = 0; i < J; ++i) {
+                    jnodes[(size_t)k * J + i] = jvals[(size_t)k * J + order[i]];
+                    jskeys[(size_t)k * J + i] = sk[order[i]];
+                }
+            }
+        }
+        for (int b = 0; b < K * n_chunks; ++b)
+            emu::run_block((unsigned)b, (unsigned)(K * n_chunks), (unsigned)rapid::kRingChunk, [&] {
+                rapid::ring_scatter_kernel(ring_out, sk2.data(), n_members, n_chunks, keep, chunk_kept.data(), jskeys.data(), J, ring2_out, sk3.data(), m_new);
+            }, seed + 6000 + (unsigned)b);
+        if (J > 0)
+            launch((long long)K * J * 64, 256u, [&] {
+                rapid::ring_join_kernel(ring_out, sk2.data(), n_members, n_chunks, keep, chunk_kept.data(), jskeys.data(), jnodes.data(), J, K, ring2_out,
+                                        sk3.data(), m_new);
+            }, seed + 7000);
+        for (int k = 0; k < K; ++k)  // the new rings are sorted by key
+            for (int i = 1; i < m_new; ++i)
+                if (sk3[(size_t)k * m_new + i - 1] >= sk3[(size_t)k * m_new + i]) return -12;
+    }
+    return 0;
+}
+
+// identifiersSeen merged on the device (ids_merge_kernel): two sorted lists of (high, low) -> one
+extern "C" int emu_ids_merge(const long long* old_hi, const long long* old_lo, int n_old, const long long* new_hi, const long long* new_lo, int n_new,
+                             long long* out_hi, long long* out_lo, unsigned long long seed) {
+    const long long n = (long long)n_old + n_new;
+    const unsigned grid = (unsigned)std::max<long long>(1, (n + 255) / 256);
+    for (unsigned b = 0; b < grid; ++b)
+        emu::run_block(b, grid, 256u, [&] { rapid::ids_merge_kernel(old_hi, old_lo, n_old, new_hi, new_lo, n_new, out_hi, out_lo); }, seed + b);
     return 0;
 }
 

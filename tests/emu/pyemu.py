@@ -246,7 +246,8 @@ def vote_merge(blocks, prop_cap, quorum, seed=1):
 def view_build(hostnames, ports, id_hi, id_lo, K, members, keep=None, seed=1):
     """The view kernels of rapid_amd/csrc/view_kernels.h under the emulator (std::stable_sort standing in for the device's
     segmented radix sort): ring keys, rings, observer / subject tables, configuration id of the view over `members`; with
-    `keep` (bool per node) also the rings of a removal-only view change by compaction."""
+    `keep` (bool per node = the member flags after a view change) also the rings of that change, obtained from the old rings
+    by compaction + merge of the joiners (ring_count / ring_scatter / ring_join kernels)."""
     L_ = lib()
     n = len(hostnames)
     blob = np.frombuffer(b"".join(hostnames) + b"\0" * 8, dtype=np.uint8).copy()
@@ -260,7 +261,7 @@ def view_build(hostnames, ports, id_hi, id_lo, K, members, keep=None, seed=1):
     lo = np.array([b for _, b in ids] + [0], dtype=np.int64)
     out = dict(keys=np.zeros(K * n + 1, dtype=np.int64), ring=np.full(K * max(M, 1), -1, dtype=np.int32),
                obs=np.full(n * K + 1, -9, dtype=np.int32), subj=np.full(n * K + 1, -9, dtype=np.int32), cfg=np.zeros(1, dtype=np.int64),
-               ring2=np.full(K * max(M, 1), -1, dtype=np.int32), m2=np.zeros(1, dtype=np.int32))
+               ring2=np.full(K * max(n, 1), -1, dtype=np.int32), m2=np.zeros(1, dtype=np.int32))
     keep_a = None if keep is None else np.ascontiguousarray(np.concatenate([np.asarray(keep, dtype=np.uint8), np.zeros(1, dtype=np.uint8)]))
     p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
     L_.emu_view_build.restype = C.c_int
@@ -274,3 +275,19 @@ def view_build(hostnames, ports, id_hi, id_lo, K, members, keep=None, seed=1):
         m2 = int(out["m2"][0])
         out["ring2"] = out["ring2"][: K * m2].reshape(K, m2)
     return out
+
+
+def ids_merge(old, new, seed=1):
+    """ids_merge_kernel: two lists of (high, low) NodeIds sorted the way identifiersSeen is -> the merged list."""
+    L_ = lib()
+    oh = np.array([a for a, _ in old] + [0], dtype=np.int64)
+    ol = np.array([b for _, b in old] + [0], dtype=np.int64)
+    nh = np.array([a for a, _ in new] + [0], dtype=np.int64)
+    nl = np.array([b for _, b in new] + [0], dtype=np.int64)
+    n = len(old) + len(new)
+    out_h, out_l = np.zeros(n + 1, dtype=np.int64), np.zeros(n + 1, dtype=np.int64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L_.emu_ids_merge.restype = C.c_int
+    rc = L_.emu_ids_merge(p(oh), p(ol), len(old), p(nh), p(nl), len(new), p(out_h), p(out_l), C.c_ulonglong(seed))
+    assert rc == 0, rc
+    return list(zip(out_h[:n].tolist(), out_l[:n].tolist()))

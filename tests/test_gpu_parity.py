@@ -1107,6 +1107,59 @@ def test_streaming_rounds_with_stale_records_and_the_observer_cache(E):
     assert np.array_equal(m2, om2) and np.array_equal(s2, os2) and np.array_equal(o2, oo2)
 
 
+def test_q4_stale_observer_cache_is_reported_through_the_c_abi(E):
+    """rapid_view_q4_at_risk against the oracle's faithful cachedObservers (R/MembershipView.java:143-152, 181-195, 210-224).
+    A subject that was hot once (its observers memoised) and stays in the view: (1) an unrelated removal changes nothing;
+    (2) removing its successor on a ring drops its entry in the Java as well (lower(successor) == subject): no risk, and the
+    entry is re-created from today's observers; (3) removing the ring MINIMUM while the subject is that ring's MAXIMUM changes
+    the subject's observer on that ring but not its memoised list -- the quirk: the Java now reads a stale list, and the
+    call names the subject."""
+    K, H, L = 10, 9, 4
+    n = 300
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    reg, oview = oracle_view(pop, K)
+    guard = E.ObserverCacheGuard()
+    sim = E.ClusterSimulation(eng)
+    ring0 = view.getRing(0)
+    x = int(ring0[-1])                         # the maximum of ring 0: its ring-0 observer is the minimum (wrap-around)
+    assert view.getObserversOf(x)[0] == int(ring0[0])
+    assert guard.check_round(view, [x]) == [] and oview.getObserversOf(x) == view.getObserversOf(x)   # memoised on both sides
+
+    def cut(nodes):
+        sim.apply_cut(nodes)
+        for v in nodes:
+            oview.ringDelete(int(v))
+
+    # (1) somebody nowhere near x
+    obs_x = set(view.getObserversOf(x)) | set(view.getSubjectsOf(x)) | {x, int(ring0[0])}
+    far = next(int(v) for v in ring0[5:] if int(v) not in obs_x and x not in view.getObserversOf(int(v)) + view.getSubjectsOf(int(v)))
+    cut([far])
+    assert oview.getObserversOf(x) == oview.computeObserversOf(x) == view.getObserversOf(x)
+    assert guard.check_round(view, [x]) == []
+    # (2) x's successor on ring 1 (x is not the maximum of ring 1, or pick another ring where it is not)
+    k = next(k for k in range(1, K) if int(view.getRing(k)[-1]) != x)
+    succ = view.getObserversOf(x)[k]
+    before = view.getObserversOf(x)
+    cut([succ])
+    assert view.getObserversOf(x) != before
+    assert oview.getObserversOf(x) == oview.computeObserversOf(x) == view.getObserversOf(x)    # the Java dropped the entry, too
+    assert guard.check_round(view, [x]) == []
+    # (3) the minimum of ring 0 goes; x stays the maximum
+    ring0 = view.getRing(0)
+    assert int(ring0[-1]) == x
+    m0 = int(ring0[0])
+    if x in [int(view.getRing(kk)[max(0, list(view.getRing(kk)).index(m0) - 1)]) for kk in range(1, K) if list(view.getRing(kk)).index(m0) > 0]:
+        pytest.skip("the ring-0 minimum is also x's direct successor elsewhere: the entry is dropped legitimately")
+    cut([m0])
+    assert view.getObserversOf(x)[0] == int(view.getRing(0)[0]) != m0
+    assert oview.getObserversOf(x) != oview.computeObserversOf(x) == view.getObserversOf(x)    # the reference reads the stale list
+    assert guard.check_round(view, [x, int(ring0[1])]) == [x]
+    # ... until x itself leaves the view: its entry dies with it
+    cut([x])
+    assert guard.check_round(view, [x]) == []
+
+
 def test_streaming_rounds_at_100k_nodes(E):
     """The same stream at N = 100,000 (a single-GPU-sized slice of BASELINE configs[4]): three rounds, 1,000 crashes + 500 joins
     each, against the optimised oracle on every simulated receiver; configuration ids against the oracle's view."""
@@ -1130,9 +1183,9 @@ def test_streaming_rounds_at_100k_nodes(E):
         fe, fn, fo, fpp = O.fast_sim_run(pop.n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=16)
         assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
         assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
-        # with 1,500 subjects in flux and 1 % of the reports lost to the stale configuration id, most receivers stay blocked
-        # (a subject short of H blocks the proposal); whoever does announce announces the whole fault set, which is the cut
-        # the round eventually settles on
+        # the late deliveries of the previous configuration are dropped, nothing of this round is lost to them: every receiver
+        # announces, and announces the whole fault set
+        assert (fe >= 0).all()
         for r_ in np.flatnonzero(fe >= 0)[:5]:
             assert sorted(fpp[fo[r_]:fo[r_ + 1]].tolist()) == sc.faulty.tolist()
         cut = sc.faulty.tolist()

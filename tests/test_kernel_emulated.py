@@ -410,6 +410,9 @@ def test_view_kernels_match_the_oracle(n, K, n_members):
     keep[members] = True
     gone = members[:: max(2, n_members // 7)] if n_members > 3 else []
     keep[gone] = False
+    outsiders = [x for x in range(n) if x not in set(members)]
+    come = outsiders[:: max(1, len(outsiders) // 9)]  # joiners admitted by the same cut (none where everybody is a member)
+    keep[come] = True
     got = pyemu.view_build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo, K, members, keep=keep)
     for k in range(K):
         for node in range(0, n, max(1, n // 40)):
@@ -420,5 +423,21 @@ def test_view_kernels_match_the_oracle(n, K, n_members):
     assert int(got["cfg"][0]) == oview.getCurrentConfigurationId()
     for node in gone:
         oview.ringDelete(node)
+    for j, node in enumerate(come):
+        oview.ringAdd(node, (int(pop.id_hi[node]), int(pop.id_lo[node])))
+    assert got["ring2"].shape[1] == n_members - len(gone) + len(come)
     for k in range(K):
-        assert np.array_equal(got["ring2"][k], oview.getRing(k)), ("compaction", k)
+        assert np.array_equal(got["ring2"][k], oview.getRing(k)), ("view change", k)
+
+
+def test_identifiers_merged_on_the_device():
+    """identifiersSeen stays sorted on the device (signed high, then signed low: R/MembershipView.java:474-500); the NodeIds a
+    cut admits are merged in by ids_merge_kernel."""
+    rng = np.random.default_rng(5)
+    for n_old, n_new in ((0, 3), (5, 0), (1, 1), (700, 40), (300, 300)):
+        ids = {(int(a), int(b)) for a, b in rng.integers(-2**62, 2**62, size=(n_old + n_new, 2))}
+        ids |= {(7, -3), (7, 5), (-7, 0)} if n_old + n_new > 3 else set()
+        ids = list(ids)
+        rng.shuffle(ids)
+        old, new = sorted(ids[:n_old]), sorted(ids[n_old:])
+        assert pyemu.ids_merge(old, new) == sorted(ids)
