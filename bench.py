@@ -10,8 +10,9 @@ test) with the decision read back to the host.  The view is NOT changed inside t
 one extra untimed-in-`value` round that also applies the cut gives `time_to_stable_cut_ms`.  The streams are resident in
 the engine's own layout: 8 B per delivered record = {subject, ring mask + status + batch end}; the 20-byte boundary
 records pass through ONE load pass (rapid_sim_load_streams*: split, configuration id compared and the verdict marked in
-the record, R/MembershipService.java:653-657) that is timed separately as `load_split_ms`; `round_from_boundary_ms` =
-that pass + one step.  `roofline.achieved` / `frac` price the tally kernel against the bytes it READS (8 B per record
+the record, R/MembershipService.java:653-657; `load_split_ms`) and ONE resolve pass (every record's subject -> its slot /
+coverage entry of the round's index, `resolve_ms`), each timed separately; `round_from_boundary_ms` = both passes + one
+step.  `roofline.achieved` / `frac` price the tally kernel against the bytes it READS (8 B per record
 consumed; `traffic` is the PMC-measured HBM traffic of the same launch and must agree); SURVEY 8(d)'s 20-B-per-record
 figure is kept as the labelled extra `roofline.boundary_accounting`.  `ms_per_step` is the mean the contract asks for;
 `ms_per_step_min` / `_median` over the same steps and the tally-only figure are reported next to it.
@@ -190,7 +191,7 @@ def main():
 
     # ---- the load pass: 20-byte boundary records (already in device memory) -> resident layout.  Every NEW round of alerts
     # pays it once; it is outside `step` because a step replays resident streams.
-    load_ms = None
+    load_ms, resolve_ms = None, None
     try:
         d_rec = torch.from_numpy(records.view(np.uint8).reshape(-1)).cuda()
         d_off = torch.from_numpy(np.ascontiguousarray(rec_off, dtype=np.int64)).cuda()
@@ -203,6 +204,12 @@ def main():
             eng.sync()
             ts_.append(1e3 * (time.perf_counter() - t_))
         load_ms = min(ts_)
+        # ... and the pass that maps every record's subject to its dictionary entry of the round's index (once per stream set
+        # and alert set; the tally itself looks nothing up)
+        sim2.set_alert_set(sc.batches.recs, trust_copies=True)
+        sim2.index_info()
+        eng.sync()
+        resolve_ms = sim2.index_info()["resolve_ms"]
         del sim2, d_rec, d_off
     except Exception as e:  # (a measurement beside the line, not the line)
         load_ms = None
@@ -243,7 +250,8 @@ def main():
         "value_without_index": round(tot_batches * args.steps / elapsed_noindex, 1),
         "n_ranks_seen": eng.comm_info()[1],
         "load_split_ms": round(load_ms, 4) if load_ms is not None else None,
-        "round_from_boundary_ms": round(load_ms + ms_per_step, 4) if load_ms is not None else None,
+        "resolve_ms": resolve_ms,
+        "round_from_boundary_ms": round(load_ms + (resolve_ms or 0.0) + ms_per_step, 4) if load_ms is not None else None,
         "alert_records_per_s": round(tot_records * args.steps / elapsed, 1),
         "time_to_stable_cut_ms": round(ttsc_ms, 3) if rr_full.decided else None,
         "decided": int(rr_full.decided), "cut_size": int(rr_full.cut_size), "votes_winner": int(rr_full.votes_winner),

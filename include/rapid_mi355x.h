@@ -381,10 +381,15 @@ int rapid_sim_stats(rapid_engine* h, uint64_t stats[8]);
 /* average duration (ms) of the tally kernel over `reps` back-to-back launches, HIP events on the engine stream */
 int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg);
 /* the per-round index of the loaded streams (built on demand): info = {hot subjects, adjacency entries, waves per
- * workgroup, workgroups, LDS bytes per workgroup, alerts pre-validated (0/1), dictionary placement (0 = memory, 1 = direct
- * tables in LDS, 2 = compressed tables in LDS), alert set
- * declared (0/1)}; index_ms = device time of the last index build */
+ * workgroup, workgroups, LDS bytes per workgroup, alerts pre-validated (0/1), where node -> slot is looked up (3 = nowhere in
+ * the tally: the resident records carry their subjects' resolved entries -- the product; the cross-check modes of the testing
+ * knob: 0 = tables in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS), alert set declared (0/1)};
+ * index_ms = device time of the last index build */
 int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms);
+/* device time (ms) of the passes a stream set goes through once, outside the per-round step: out[0] = the last index build,
+ * out[1] = the last resolve pass (every resident record's subject -> its dictionary entry of the current round index; runs
+ * when streams, alert set or view changed since the records were last resolved), out[2..3] = 0 */
+int rapid_sim_pass_times(rapid_engine* h, float out[4]);
 /* measurement probe (not a product path): stream the loaded records with the tally kernel's access pattern and no
  * processing.  Register loads: variant 0 = 2 KiB tiles x 8 in flight, 1: 4 KiB x 4, 2: 8 KiB x 2, 3: 2 KiB x 4,
  * 4: 1 KiB x 8, 5: 1 KiB x 16, 6: 1 KiB x 4; LDS-DMA loads (the tally kernel's path): 7: 1 KiB x 4, 8: 1 KiB x 8,

@@ -218,6 +218,7 @@ def _signatures():
         "rapid_sim_time_tally": (i32, [vp, i32, C.POINTER(C.c_float)]),
         "rapid_sim_set_force_exact": (i32, [vp, i32]),
         "rapid_sim_index_info": (i32, [vp, p, C.POINTER(C.c_float)]),
+        "rapid_sim_pass_times": (i32, [vp, p]),
         "rapid_debug_stream_probe": (i32, [vp, i32, i32, i32, C.POINTER(C.c_float)]),
     }
 

@@ -113,6 +113,14 @@ struct rapid_engine {
     // delivered streams, resident split: d_core[i] = {dst, mask | status | flags}, d_cfg[i] = configuration id of record i;
     // d_stage = bounded staging area for the 20-byte records on their way in
     DevBuf<unsigned char> d_core, d_cfg, d_stage;
+    DevBuf<unsigned int> d_dstv;  // the subject of record i (| kCoreStale), kept beside d_core: the record's first dword holds the
+                                  // subject's resolved dictionary entry while core_state == kCoreEntries
+    enum { kCoreSubjects = 0, kCoreEntries = 1, kCoreUnknown = 2 };
+    int core_state = kCoreUnknown;
+    unsigned long long content_serial = 1, core_serial = 0;  // what the round index is built from (alert set, streams, view) / what d_core was resolved against
+    hipEvent_t ev_res0 = nullptr, ev_res1 = nullptr;
+    bool resolve_ms_pending = false;
+    float resolve_ms = 0.f;
     unsigned long long records_bytes = 0;  // readable bytes at d_core.p (probes)
     DevBuf<long long> d_rec_off_own;
     const long long* d_rec_off = nullptr;
@@ -145,8 +153,9 @@ struct rapid_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // timing events, created once (no create / destroy per call, nothing to leak on an error path)
     DevBuf<unsigned short> d_dict, d_decl, d_adj_off, d_trank;
     DevBuf<unsigned int> d_tbits, d_tent;  // compressed dictionary (index_build_block_kernel)
+    DevBuf<unsigned int> d_entries;        // dict_entry per node for rounds whose tables stay in memory
     int n_touched = 0;
-    int dict_mode = 1;  // rapid::kDictDirect / kDictCompressed / kDictMemory
+    int dict_mode = 3;  // rapid::kDictResolved (the product) / kDictDirect / kDictCompressed / kDictMemory (testing knobs)
     bool lds_attr_set = false;
     DevBuf<unsigned int> d_errflags;  // sticky per loaded stream set: bit0 = a delivered report is not covered by the declared alert set
     DevBuf<int> d_idxblk;  // per-workgroup hot / touched counts of the chunked index build
@@ -428,6 +437,7 @@ int rebuild_view(rapid_engine* h) {
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
     lap("configuration id");
+    h->content_serial++;
     h->config_id = cfg;
     h->ring_member = h->member;
     h->ring_m = M;
@@ -551,7 +561,7 @@ int build_round_index(rapid_engine* h) {
         hipLaunchKernelGGL(rapid::index_touch_kernel<false>, touch_grid, dim3(256), 0, st, h->d_alert_set.p, nullptr, n_scan, N,
                            (1u << K) - 1u, (long long)h->config_id, h->d_member.p, d_gmask, reinterpret_cast<unsigned int*>(d_info + 4));
     else if (n_scan > 0)
-        hipLaunchKernelGGL(rapid::index_touch_kernel<true>, touch_grid, dim3(256), 0, st, h->d_core.p, h->d_cfg.p, n_scan, N,
+        hipLaunchKernelGGL(rapid::index_touch_kernel<true>, touch_grid, dim3(256), 0, st, h->d_core.p, h->d_dstv.p, n_scan, N,
                            (1u << K) - 1u, (long long)h->config_id, h->d_member.p, d_gmask, reinterpret_cast<unsigned int*>(d_info + 4));
     const int adj_cap = 65536;
     HIPCHK(h, h->d_adj.ensure((size_t)adj_cap + 1));
@@ -595,21 +605,31 @@ int build_round_index(rapid_engine* h) {
     const int per_wave = rapid::tally_wave_bytes(h->n_slots);
     const int sh_direct = rapid::tally_shared_bytes(rapid::kDictDirect, N, h->n_touched, h->n_hot, h->n_adj);
     const int sh_comp = rapid::tally_shared_bytes(rapid::kDictCompressed, N, h->n_touched, h->n_hot, h->n_adj);
-    const int sh_mem = rapid::tally_shared_bytes(rapid::kDictMemory, N, h->n_touched, h->n_hot, h->n_adj);
+    const int sh_mem = rapid::tally_shared_bytes(rapid::kDictMemory, N, h->n_touched, h->n_hot, h->n_adj);  // (== kDictResolved: no tables)
     if (sh_mem + per_wave + rapid::kBlockStatsBytes > lds_max)
         return fail(h, RAPID_ECAPACITY, "%d subjects need %d B of LDS per receiver (max %d)", h->n_slots,
                     sh_mem + per_wave + rapid::kBlockStatsBytes, lds_max);
     // Where the node -> slot dictionary lives: in LDS as plain tables (4 B per node) when at least eight receivers still fit
     // next to them; else compressed (3 bits per node + 4 B per node the alert set names: 100,000 nodes in ~25 KB); else in
     // memory.  Testing knob: bit 7 = never direct, bit 8 = never in LDS at all.
+    // The product resolves every record's subject to its dictionary entry ONCE, in a streaming pass (prepare_tally), and the
+    // tally looks nothing up (kDictResolved).  The modes in which the tally itself maps node -> slot remain as cross-checks
+    // behind the testing knob: bit 15 = look up in the tally, from the tables placed as described above.
     const bool no_direct = (h->force_exact & (128 | 256)) != 0 || info[7] == 0, no_lds = (h->force_exact & 256) != 0;  // info[7]: the build kernel's own verdict
-    if (!no_direct && sh_direct + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
+    if ((h->force_exact & (128 | 256 | 32768)) == 0)
+        h->dict_mode = rapid::kDictResolved;
+    else if (!no_direct && sh_direct + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
         h->dict_mode = rapid::kDictDirect;
     else if (!no_lds && compressed_ok && sh_comp + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
         h->dict_mode = rapid::kDictCompressed;
     else
         h->dict_mode = rapid::kDictMemory;
-    h->tables_in_lds = h->dict_mode != rapid::kDictMemory;
+    h->tables_in_lds = h->dict_mode == rapid::kDictDirect || h->dict_mode == rapid::kDictCompressed;
+    if (h->dict_mode == rapid::kDictMemory || h->dict_mode == rapid::kDictResolved) {
+        HIPCHK(h, h->d_entries.ensure((size_t)N + 1));
+        hipLaunchKernelGGL(rapid::dict_entries_kernel, dim3(grid_for((long long)N + 1, 256)), dim3(256), 0, st, h->d_dict.p, h->d_decl.p, N, h->n_hot,
+                           h->d_entries.p);
+    }
     const int sh = h->dict_mode == rapid::kDictDirect ? sh_direct : h->dict_mode == rapid::kDictCompressed ? sh_comp : sh_mem;
     // Waves per CU (one workgroup per CU, its receivers claimed by its waves from a counter in LDS).  A CU's share of
     // the memory system is saturated by the stream loads of ~7 waves; with w waves a CU works through its n receivers in
@@ -677,6 +697,7 @@ int launch_tally(rapid_engine* h) {
     p.idx.trank = h->d_trank.p;
     p.idx.tent = h->d_tent.p;
     p.idx.n_touched = h->n_touched;
+    p.idx.entries = h->d_entries.p;
     p.error_flags = h->d_errflags.p;
     p.idx.node_of_slot = h->d_node_of_slot.p;
     p.idx.smask = h->d_adj_off.p;  // (the buffers keep their round-1 names: per-slot masks, flat triple list)
@@ -725,6 +746,8 @@ int launch_tally(rapid_engine* h) {
         case 3: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictDirect, true>), grid, block, lds, h->stream, p); break;
         case 4: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, false>), grid, block, lds, h->stream, p); break;
         case 5: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, true>), grid, block, lds, h->stream, p); break;
+        case 6: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictResolved, false>), grid, block, lds, h->stream, p); break;
+        case 7: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictResolved, true>), grid, block, lds, h->stream, p); break;
         default: return fail(h, RAPID_ESTATE, "no tally kernel for dictionary mode %d", h->dict_mode);
     }
     return RAPID_OK;
@@ -744,8 +767,8 @@ int prepare_tally(rapid_engine* h) {
         const long long n = h->n_records_total;
         if (n > 0)
             hipLaunchKernelGGL(rapid::remark_records_kernel, dim3((unsigned)std::min<long long>((long long)h->num_cus * 16, (n + 255) / 256)), dim3(256), 0,
-                               h->stream, n, reinterpret_cast<uint2*>(h->d_core.p), reinterpret_cast<const uint2*>(h->d_cfg.p), (long long)h->config_id,
-                               h->d_loadflags.p);
+                               h->stream, n, h->d_dstv.p, reinterpret_cast<const uint2*>(h->d_cfg.p), (long long)h->config_id, h->d_loadflags.p);
+        h->core_state = rapid_engine::kCoreUnknown;  // (the marks live in d_dstv; the records' first dwords follow below)
         unsigned int load_flags[2] = {1u, 0u};
         HIPCHK(h, hipMemcpyAsync(load_flags, h->d_loadflags.p, sizeof load_flags, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -760,8 +783,31 @@ int prepare_tally(rapid_engine* h) {
         if (rc) return rc;
         h->stats_fresh = true;
     }
+    {
+        // The records' first dwords: the subjects' dictionary entries of THIS index (kDictResolved), or the subjects themselves
+        // (the cross-check modes).  One streaming pass per (stream set, alert set, view), not per round replayed on them.
+        const int want = h->dict_mode == rapid::kDictResolved ? rapid_engine::kCoreEntries : rapid_engine::kCoreSubjects;
+        const bool ok = h->core_state == want && (want == rapid_engine::kCoreSubjects || h->core_serial == h->content_serial);
+        if (!ok && h->n_records_total > 0) {
+            const long long n = h->n_records_total;
+            if (!h->ev_res0) {
+                HIPCHK(h, hipEventCreate(&h->ev_res0));
+                HIPCHK(h, hipEventCreate(&h->ev_res1));
+            }
+            HIPCHK(h, hipEventRecord(h->ev_res0, h->stream));
+            hipLaunchKernelGGL(rapid::resolve_records_kernel, dim3((unsigned)std::min<long long>((long long)h->num_cus * 16, (n + 255) / 256)), dim3(256), 0,
+                               h->stream, n, reinterpret_cast<uint2*>(h->d_core.p), h->d_dstv.p,
+                               want == rapid_engine::kCoreEntries ? h->d_entries.p : (const unsigned int*)nullptr, (unsigned int)h->n_nodes);
+            HIPCHK(h, hipEventRecord(h->ev_res1, h->stream));
+            h->resolve_ms_pending = true;
+        }
+        h->core_state = want;
+        h->core_serial = h->content_serial;
+    }
     if (!h->lds_attr_set) {  // once per engine: every instantiation may use the whole 160 KiB of LDS
-        const void* kernels[6] = {reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, false>),
+        const void* kernels[8] = {reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictResolved, false>),
+                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictResolved, true>),
+                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, false>),
                                   reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, true>),
                                   reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictDirect, false>),
                                   reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictDirect, true>),
@@ -841,7 +887,9 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_sort_keys.release(); h->d_sort_vals.release(); h->d_ring_skeys.release(); h->d_ring.release();
     h->d_pos.release(); h->d_obs.release(); h->d_subj.release();
     h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
-    h->d_q4_nodes.release(); h->d_q4_rows.release();
+    h->d_q4_nodes.release(); h->d_q4_rows.release(); h->d_entries.release(); h->d_dstv.release();
+    if (h->ev_res0) (void)hipEventDestroy(h->ev_res0);
+    if (h->ev_res1) (void)hipEventDestroy(h->ev_res1);
     h->d_ids_hi2.release(); h->d_ids_lo2.release(); h->d_ids_new.release(); h->d_cfg_partial.release(); h->d_chunk_kept.release();
     h->d_joiners.release(); h->d_join_nodes.release(); h->d_join_vals.release(); h->d_join_keys.release(); h->d_join_skeys.release();
     h->d_core.release(); h->d_cfg.release(); h->d_stage.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
@@ -1262,6 +1310,8 @@ static int load_split(rapid_engine* h, const unsigned char* src, bool src_on_dev
     const size_t core_bytes = (((size_t)n_rec * 8 + 15) / 16) * 16 + 64;
     HIPCHK(h, h->d_core.ensure(core_bytes));
     HIPCHK(h, h->d_cfg.ensure(core_bytes));
+    HIPCHK(h, h->d_dstv.ensure((size_t)n_rec + 16));
+    h->core_state = rapid_engine::kCoreSubjects;  // (what the load pass writes)
     const size_t tail = ((size_t)n_rec * 8 / 16) * 16;  // zeros behind the last record (the split pass below rewrites what it owns)
     HIPCHK(h, hipMemsetAsync(h->d_core.p + tail, 0, core_bytes - tail, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_cfg.p + tail, 0, core_bytes - tail, h->stream));
@@ -1280,7 +1330,7 @@ static int load_split(rapid_engine* h, const unsigned char* src, bool src_on_dev
         }
         hipLaunchKernelGGL(rapid::split_records_kernel, dim3((unsigned)std::min<long long>((long long)h->num_cus * 16, (n + 255) / 256)),
                            dim3(256), 0, h->stream, from, n, reinterpret_cast<uint2*>(h->d_core.p) + at, reinterpret_cast<uint2*>(h->d_cfg.p) + at,
-                           (long long)h->config_id, (unsigned int)h->n_nodes, h->d_loadflags.p);
+                           h->d_dstv.p + at, (long long)h->config_id, (unsigned int)h->n_nodes, h->d_loadflags.p);
     }
     unsigned int load_flags[2] = {1u, 0u};
     HIPCHK(h, hipMemcpyAsync(load_flags, h->d_loadflags.p, sizeof load_flags, hipMemcpyDeviceToHost, h->stream));
@@ -1302,6 +1352,7 @@ static void streams_replaced(rapid_engine* h, int n_receivers, long long n_rec) 
     h->tallied = false;
     h->have_decision = false;
     h->tally_votes_valid = false;
+    h->content_serial++;
 }
 
 int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, const int64_t* rec_off,
@@ -1349,6 +1400,7 @@ int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, i
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->n_alert_set = n_alerts;
     h->index_valid = false;
+    h->content_serial++;
     return RAPID_OK;
 }
 
@@ -1863,6 +1915,26 @@ int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, in
     return RAPID_OK;
 }
 
+int rapid_sim_pass_times(rapid_engine* h, float out[4]) {
+    if (!h || !out) return RAPID_EINVAL;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (h->index_ms_pending && h->ev_idx0 && h->ev_idx1) {
+        h->index_ms_pending = false;
+        if (hipEventSynchronize(h->ev_idx1) == hipSuccess) (void)hipEventElapsedTime(&h->index_ms, h->ev_idx0, h->ev_idx1);
+        (void)hipGetLastError();
+    }
+    if (h->resolve_ms_pending && h->ev_res0 && h->ev_res1) {
+        h->resolve_ms_pending = false;
+        if (hipEventSynchronize(h->ev_res1) == hipSuccess) (void)hipEventElapsedTime(&h->resolve_ms, h->ev_res0, h->ev_res1);
+        (void)hipGetLastError();
+    }
+    out[0] = h->index_ms;
+    out[1] = h->resolve_ms;
+    out[2] = out[3] = 0.f;
+    return RAPID_OK;
+}
+
 int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
     if (!h || !info) return RAPID_EINVAL;
     int rc = use_device(h);
@@ -1874,7 +1946,7 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
     info[3] = h->grid_blocks;
     info[4] = h->lds_bytes;
     info[5] = tally_is_trusted(h) ? 1 : 0;
-    info[6] = h->dict_mode;  // 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS
+    info[6] = h->dict_mode;  // 3 = resolved records (no lookup in the tally); 0 / 1 / 2 = tables in memory / direct in LDS / compressed in LDS
     info[7] = h->n_alert_set >= 0 ? 1 : 0;
     if (h->index_ms_pending && h->ev_idx0 && h->ev_idx1) {
         h->index_ms_pending = false;
@@ -1899,7 +1971,7 @@ int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, in
 
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on) {
     if (!h) return RAPID_EINVAL;
-    if (((h->force_exact ^ on) & (128 | 256 | 4096 | 8192)) != 0) h->index_valid = false;  // the launch geometry depends on where the dictionary lives
+    if (((h->force_exact ^ on) & (128 | 256 | 4096 | 8192 | 32768)) != 0) h->index_valid = false;  // the launch geometry depends on where the dictionary lives
     h->force_exact = on;
     return RAPID_OK;
 }

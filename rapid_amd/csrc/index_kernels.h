@@ -21,9 +21,9 @@ namespace rapid {
 // record fails the filter of R/MembershipService.java:644-675 under the current view (or names a node out of range
 // or no ring), bit1 if any record is an UP alert.
 // Two record sources: the round's declared alert set as it crossed the boundary (20-byte records), or -- when nothing was
-// declared -- every delivered record of the resident streams (core entries, 8 bytes each; `cfg` is not read).
+// declared -- every delivered record of the resident streams (subject array + core word).
 template <bool kSplit>
-__global__ void index_touch_kernel(const unsigned char* records, const unsigned char* cfg, long long n_records, int n_nodes,
+__global__ void index_touch_kernel(const unsigned char* records, const unsigned int* dstv, long long n_records, int n_nodes,
                                    unsigned int kmask, long long cfg_id, const unsigned char* member, unsigned int* gmask,
                                    unsigned int* vflags) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -32,9 +32,9 @@ __global__ void index_touch_kernel(const unsigned char* records, const unsigned 
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
         unsigned int dst, cw;  // cw: the resident core word (tally_kernel.h: core_word)
         bool current;          // the record carries the engine's configuration id
-        if (kSplit) {  // the id was compared when the record became resident (kCoreStale)
-            const uint2 a = reinterpret_cast<const uint2*>(records)[i];
-            dst = a.x & ~kCoreStale, cw = a.y, current = (a.x & kCoreStale) == 0u;
+        if (kSplit) {  // the id was compared when the record became resident (kCoreStale); the subject from its own array
+            const unsigned int d = dstv[i];  // (the record's first dword may hold the subject's resolved entry instead)
+            dst = d & ~kCoreStale, cw = reinterpret_cast<const uint2*>(records)[i].y, current = (d & kCoreStale) == 0u;
         } else {
             const unsigned int* w = reinterpret_cast<const unsigned int*>(records + i * 20);
             dst = w[3], cw = core_word(w[4]), current = w[0] == cfg_lo && w[1] == cfg_hi;
@@ -59,8 +59,8 @@ __global__ void index_touch_kernel(const unsigned char* records, const unsigned 
 // carries another id, bit1 = some record names a subject >= n_nodes.  The engine selects the tally instantiation that skips
 // the per-delivery id check only for a load whose flags stayed clear (engine.hip: launch_tally) -- the caller's promise
 // costs no traffic to verify.
-__global__ void split_records_kernel(const unsigned char* records, long long n_records, uint2* core, uint2* cfg, long long cfg_id,
-                                     unsigned int n_nodes, unsigned int* load_flags) {
+__global__ void split_records_kernel(const unsigned char* records, long long n_records, uint2* core, uint2* cfg, unsigned int* dstv,
+                                     long long cfg_id, unsigned int n_nodes, unsigned int* load_flags) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
     unsigned int other = 0u, range = 0u;
@@ -71,15 +71,45 @@ __global__ void split_records_kernel(const unsigned char* records, long long n_r
         range |= w[3] >= n_nodes ? 1u : 0u;
         cfg[i] = make_uint2(c0, c1);
         // (a subject index that would collide with the mark is no node of any view: kept out of range for good)
-        core[i] = make_uint2((w[3] >= kCoreStale ? kCoreStale - 1u : w[3]) | (((c0 ^ cfg_lo) | (c1 ^ cfg_hi)) != 0u ? kCoreStale : 0u), core_word(w[4]));
+        const unsigned int d = (w[3] >= kCoreStale ? kCoreStale - 1u : w[3]) | (((c0 ^ cfg_lo) | (c1 ^ cfg_hi)) != 0u ? kCoreStale : 0u);
+        dstv[i] = d;  // kept beside the record: its first dword is overwritten when the subjects are resolved to their entries
+        core[i] = make_uint2(d, core_word(w[4]));
     }
     const unsigned int f = (__ballot(other != 0u) != 0ull ? 1u : 0u) | (__ballot(range != 0u) != 0ull ? 2u : 0u);
     if (f != 0u && (threadIdx.x & 63u) == 0u) atomicOr(load_flags, f);
 }
 
+// node -> dict_entry for rounds whose tables stay in memory (tally_kernel.h: RoundIndex::entries): what the tally's direct mode
+// assembles while it stages its tables in LDS, written out once per round; entries[n_nodes] = the poison entry.
+__global__ void dict_entries_kernel(const unsigned short* dict, const unsigned short* decl, int n_nodes, int n_hot, unsigned int* entries) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i > n_nodes) return;
+    unsigned int e = kEntryPoison | ((unsigned int)n_hot << 17);
+    if (i < n_nodes) {
+        unsigned int sl = (unsigned int)dict[i] & kSlotMask;
+        if (sl == kNoSlot) sl = (unsigned int)n_hot + ((unsigned int)i & (unsigned int)(kDummySlots - 1));
+        e = dict_entry((unsigned int)decl[i], sl);
+    }
+    entries[i] = e;
+}
+
+// The first dword of every resident record <- the dict_entry of its subject (entries != nullptr: kDictResolved; a stale or
+// unknown subject gets the poison entry at entries[n_nodes]) or the subject itself again (entries == nullptr: the modes that
+// look the subject up in the tally).  4 B read + 4 B written per record + a gather that hits the caches (most records name
+// one of the round's hot subjects); once per (stream set, round index), not per launch of the tally.
+__global__ void resolve_records_kernel(long long n_records, uint2* core, const unsigned int* dstv, const unsigned int* entries, unsigned int n_nodes) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
+        const unsigned int d = dstv[i];
+        uint2 r = core[i];  // (whole records are rewritten: a store of every other dword leaves half-written lines behind)
+        r.x = entries == nullptr ? d : entries[d < n_nodes ? d : n_nodes];  // (the stale mark makes d >= n_nodes)
+        core[i] = r;
+    }
+}
+
 // The view changed while streams stayed loaded: the same comparison against the new configuration id, over the retained ids
 // (8 B per record read, 4 B rewritten; once per view change, and only if the streams are tallied again at all).
-__global__ void remark_records_kernel(long long n_records, uint2* core, const uint2* cfg, long long cfg_id, unsigned int* load_flags) {
+__global__ void remark_records_kernel(long long n_records, unsigned int* dstv, const uint2* cfg, long long cfg_id, unsigned int* load_flags) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
     unsigned int other = 0u;
@@ -87,9 +117,8 @@ __global__ void remark_records_kernel(long long n_records, uint2* core, const ui
         const uint2 c = cfg[i];
         const unsigned int stale = ((c.x ^ cfg_lo) | (c.y ^ cfg_hi)) != 0u ? kCoreStale : 0u;
         other |= stale;
-        unsigned int* const w3 = &core[i].x;
-        const unsigned int old = *w3;
-        if (((old ^ stale) & kCoreStale) != 0u) *w3 = (old & ~kCoreStale) | stale;
+        const unsigned int old = dstv[i];
+        if (((old ^ stale) & kCoreStale) != 0u) dstv[i] = (old & ~kCoreStale) | stale;
     }
     if (__ballot(other != 0u) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(load_flags, 1u);
 }

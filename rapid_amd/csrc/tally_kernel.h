@@ -133,6 +133,10 @@ struct RoundIndex {
     const unsigned short* trank;    // [(n_nodes + 31) / 32]
     const unsigned int* tent;       // [n_touched]
     int n_touched;
+    // populations whose tables stay in memory: ONE gather per record instead of two -- dict_entry per node, [n_nodes] = the
+    // entry out-of-range subjects are sent to (built by dict_entries_kernel once per round; the entries of the round's hot
+    // subjects, all that most records ever ask for, stay in the caches)
+    const unsigned int* entries;
     const int* node_of_slot;        // [n_hot]
     // the hot adjacency: pairs[a] = subject slot | observer slot << 14 | ring << 28 for every (subject, ring, observer) triple
     // among hot slots -- one potential implicit report each (R/MultiNodeCutDetector.java:137-164); smask[slot] = the rings on
@@ -192,7 +196,13 @@ __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
 // which a hot observer watches the slot, and slot -> node.  Per wave: detector state (hot + dummy slots),
 // decoded-record scratch, undo list.
 // dictionary placement: where node -> (slot, declared rings, member) is looked up
-enum { kDictMemory = 0, kDictDirect = 1, kDictCompressed = 2 };
+// kDictResolved -- the product's way: there is no lookup in the tally at all.  The first dword of a resident record holds the
+// subject's dict_entry itself, written by resolve_records_kernel (index_kernels.h) once per (stream set, round index): every
+// delivered record has to be mapped from node to slot exactly once, and a streaming pass over all records with the whole
+// GPU does that at memory speed, whereas the tally would do it 64 lanes at a time between two dependent LDS or L2 round
+// trips, and give 40 KB of LDS per workgroup (or, at 10^5 .. 10^6 nodes, its whole speed) for the tables.  The other three
+// modes read the subject's node index and look it up themselves; they stay as cross-checks (testing knobs bit 7 / 8).
+enum { kDictMemory = 0, kDictDirect = 1, kDictCompressed = 2, kDictResolved = 3 };
 __host__ __device__ inline int tally_dict_bytes(int mode, int n_nodes, int n_touched) {
     if (mode == kDictDirect) return align16((n_nodes + 1) * 4);  // one dict_entry per node + the entry out-of-range subjects are sent to
     if (mode == kDictCompressed) return align16(((n_nodes + 31) / 32) * 4) + align16(((n_nodes + 31) / 32) * 2) + align16(n_touched * 4);
@@ -610,6 +620,16 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         if (kTablesInLds) {
             k.in = true;
             k.entry = entries[min(w3, n_nodes_u)];
+            return k;
+        }
+        if (kDictMode == kDictResolved) {  // the record carries its subject's entry (poison for a stale or unknown subject)
+            k.in = true;
+            k.entry = w3;
+            return k;
+        }
+        if (kDictMode == kDictMemory) {
+            k.in = true;
+            k.entry = p.idx.entries[min(w3, n_nodes_u)];
             return k;
         }
         k.in = w3 <= node_last && p.n_nodes > 0;

@@ -408,8 +408,13 @@ class ClusterSimulation:
         keys = ("hot_subjects", "adjacency_entries", "waves_per_workgroup", "workgroups", "lds_bytes_per_workgroup",
                 "alerts_prevalidated", "dict_mode", "alert_set_declared")
         out = {k: int(v) for k, v in zip(keys, info)}
-        out["tables_in_lds"] = int(out["dict_mode"] != 0)  # dict_mode: 0 = memory, 1 = direct tables in LDS, 2 = compressed
+        # dict_mode: 3 = the records carry their subjects' resolved entries (no lookup in the tally); 0 = tables in memory,
+        # 1 = direct tables in LDS, 2 = compressed tables in LDS (cross-check modes)
+        out["tables_in_lds"] = int(out["dict_mode"] in (1, 2))
         out["index_build_ms"] = round(ms.value, 4)
+        t = np.zeros(4, dtype=np.float32)
+        self.e._check(self.e._lib.rapid_sim_pass_times(self.e._h, _addr(t)))
+        out["resolve_ms"] = round(float(t[1]), 4)
         return out
 
     def stream_probe(self, variant, waves, reps=10):

@@ -67,12 +67,13 @@ for rnd in range(rounds):
     apply_ms = 1e3 * (time.perf_counter() - t)
     guard.on_view_change(sc.crashed)
     info = sim.index_info()
+    load_ms += info["resolve_ms"]  # the resolve pass (subjects -> entries of this round's index) belongs to the way in
     print(json.dumps({"round": rnd, "members": int((member != 0).sum()), "receivers": len(sc.receivers), "records": int(len(sc.records)),
                       "stale_records": int((sc.records["cfg_id"] != cfg).sum()), "cut": len(cut), "crashed": len(sc.crashed),
                       "joined": len(sc.joiners), "proposing": int((emit >= 0).sum()), "votes_winner": int(rr.votes_winner),
                       "kernel_ms": round(kern_ms, 4), "kernel_records_per_s": round(len(sc.records) / kern_ms * 1e3, 1),
                       "kernel_frac_of_8TBps": round(8 * len(sc.records) / kern_ms / 1e6 / 8000, 4),  # 8 B per record read
-                      "load_split_ms": round(load_ms, 3), "round_ms": round(round_ms, 3), "round_from_boundary_ms": round(load_ms + round_ms, 3),
+                      "load_split_and_resolve_ms": round(load_ms, 3), "resolve_ms": info["resolve_ms"], "round_ms": round(round_ms, 3), "round_from_boundary_ms": round(load_ms + round_ms, 3),
                       "round_records_per_s": round(len(sc.records) / round_ms * 1e3, 1), "decided": int(rr.decided), "cut_from": how,
                       "apply_cut_ms": round(apply_ms, 3), "dict_mode": info["dict_mode"], "hot_subjects": info["hot_subjects"],
                       "q4_at_risk": at_risk, "config_id": int(new_cfg)}), flush=True)

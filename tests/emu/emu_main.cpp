@@ -140,7 +140,8 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
                   int* prop_count, unsigned long long* fingerprint, int* props, int prop_cap, unsigned long long* stats,
                   int flags, int waves, int grid, int tables_in_lds, unsigned long long seed, const unsigned int* tbits,
                   const unsigned short* trank, const unsigned int* tent, int n_touched, unsigned long long* vote_res_out) {
-    // tables_in_lds: 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS
+    // tables_in_lds: 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS, 3 = no dictionary: the
+    // records carry their subjects' entries (kDictResolved, what resolve_records_kernel leaves in the first dword)
     const int lds = rapid::tally_shared_bytes(tables_in_lds, n_nodes, n_touched, n_hot, n_adj) + waves * rapid::tally_wave_bytes(n_hot) +
                     rapid::kBlockStatsBytes;
     if (lds > (int)sizeof(smem)) return -5;
@@ -173,6 +174,24 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     p.idx.trank = trank;
     p.idx.tent = tent;
     p.idx.n_touched = n_touched;
+    // the entry table of rounds whose dictionary stays in memory (index_kernels.h: dict_entries_kernel; included further down,
+    // so its statement is repeated here -- exactly sized: a lookup past the poison entry is caught by the address sanitiser)
+    std::vector<unsigned int> entries((size_t)n_nodes + 1);
+    for (int i = 0; i <= n_nodes; ++i) {
+        unsigned int e = rapid::kEntryPoison | ((unsigned int)n_hot << 17);
+        if (i < n_nodes) {
+            unsigned int sl = (unsigned int)dict[i] & rapid::kSlotMask;
+            if (sl == rapid::kNoSlot) sl = (unsigned int)n_hot + ((unsigned int)i & (unsigned int)(rapid::kDummySlots - 1));
+            e = rapid::dict_entry((unsigned int)decl[i], sl);
+        }
+        entries[(size_t)i] = e;
+    }
+    p.idx.entries = entries.data();
+    if (tables_in_lds == 3)
+        for (long long i = 0; i < n_rec_all; ++i) {
+            const unsigned int d = core[2 * i];
+            core[2 * i] = entries[d < (unsigned int)n_nodes ? d : (unsigned int)n_nodes];
+        }
     static unsigned int error_flags[2];
     error_flags[0] = error_flags[1] = 0u;
     p.error_flags = error_flags;
@@ -216,7 +235,9 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
             case 2: run(rapid::tally_population_kernel<rapid::kDictDirect, false>); break;
             case 3: run(rapid::tally_population_kernel<rapid::kDictDirect, true>); break;
             case 4: run(rapid::tally_population_kernel<rapid::kDictCompressed, false>); break;
-            default: run(rapid::tally_population_kernel<rapid::kDictCompressed, true>); break;
+            case 5: run(rapid::tally_population_kernel<rapid::kDictCompressed, true>); break;
+            case 6: run(rapid::tally_population_kernel<rapid::kDictResolved, false>); break;
+            default: run(rapid::tally_population_kernel<rapid::kDictResolved, true>); break;
         }
     }
     for (int i = 0; i < 5; ++i)

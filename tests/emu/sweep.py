@@ -30,7 +30,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         recs.append(random_stream(rng, n_nodes, K, member, cfg, n_rec, hot, p_eob=float(rng.choice([0.02, 0.1, 0.3, 0.6, 1.0])), p_multi=float(rng.choice([0.0,0.15,0.5])), p_bad_cfg=pb, p_bad_status=pb))
         off.append(off[-1] + n_rec)
     try:
-        _check(np.concatenate(recs), np.array(off), n_nodes, K, H, L, cfg, obs, subj, member, seed=seed, waves=int(rng.integers(1,5)), grid=int(rng.integers(1,4)), tables_in_lds=int(seed%3), pool=bool((seed >> 2) & 1))
+        _check(np.concatenate(recs), np.array(off), n_nodes, K, H, L, cfg, obs, subj, member, seed=seed, waves=int(rng.integers(1,5)), grid=int(rng.integers(1,4)), tables_in_lds=int(seed%4), pool=bool((seed >> 2) & 1))
     except AssertionError as e:
         bad+=1; print("FAIL seed", seed, n_nodes,K,H,L, str(e)[:200])
 print("done, failures:", bad)

@@ -578,7 +578,7 @@ def test_full_size_c3_against_fast_oracle(E):
         # the per-delivery configuration-id check waived on the load pass's verdict -- the instantiation `value` is measured with
         sim_b, res_b = run_population(E, eng, sc.records, sc.rec_off, alert_set=sc.batches.recs, trust=True)
         info_b = sim_b.index_info()
-        assert info_b["alerts_prevalidated"] == 1 and info_b["alert_set_declared"] == 1 and info_b["dict_mode"] == 1
+        assert info_b["alerts_prevalidated"] == 1 and info_b["alert_set_declared"] == 1 and info_b["dict_mode"] == 3
         assert all(np.array_equal(a_, b_) for a_, b_ in zip((emit, nprop, pcount, fp), res_b))
         for r in range(0, len(fe), 997):
             assert sorted(sim_b.proposal(r)) == fpp[fo[r]:fo[r + 1]].tolist()
@@ -964,11 +964,12 @@ def test_tables_in_memory_mode_vs_faithful_oracle(E, name, n, f, K, H, L):
     oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, np.concatenate(parts), sub_off, nthreads=8)
     want_fp = proposal_fingerprints(oo, op, oe >= 0)
     sim0, ref = run_population(E, eng, sc.records, sc.rec_off)
-    assert sim0.index_info()["dict_mode"] == 1
-    # 128: compressed tables in LDS, 256: dictionary in memory; alone: the pre-validated instantiation (every delivered alert
-    # passes the filter); | 64: per-delivery filter; | 1: exact path
+    assert sim0.index_info()["dict_mode"] == 3  # the product: the records carry their subjects' resolved entries
+    # the cross-check modes, in which the tally looks the subject up itself -- 32768: from the tables where they fit best
+    # (direct, in LDS), 128: compressed tables in LDS, 256: tables in memory; alone: the pre-validated instantiation (every
+    # delivered alert passes the filter); | 64: per-delivery filter; | 1: exact path
     # 4096: the round index built by several workgroups (count / assign / adjacency), the form of populations >= 40,000 nodes
-    for mode_knob, mode in ((128, 2), (256, 0), (4096, 2), (4096 | 256, 0)):
+    for mode_knob, mode in ((32768, 1), (128, 2), (256, 0), (4096, 3), (4096 | 128, 2), (4096 | 256, 0), (0, 3)):
       for kw in (dict(force_exact=mode_knob), dict(force_exact=mode_knob | 64), dict(force_exact=mode_knob, alert_set=sc.batches.recs),
                  dict(force_exact=mode_knob | 64, alert_set=sc.batches.recs), dict(force_exact=mode_knob | 1)):
         sim, res = run_population(E, eng, sc.records, sc.rec_off, **kw)
@@ -993,9 +994,12 @@ def test_c4_shaped_shard_against_fast_oracle(E):
     fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=16)
     for kw in (dict(), dict(alert_set=sc.batches.recs)):
         sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off, **kw)
-        assert sim.index_info()["dict_mode"] == 2  # 2 x 200 KB of plain tables do not fit the LDS, the compressed form does
+        assert sim.index_info()["dict_mode"] == 3
         assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
         assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
+    # the cross-check modes at this size: 2 x 200 KB of plain tables do not fit the LDS, the compressed form does ...
+    sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off, force_exact=32768)
+    assert sim.index_info()["dict_mode"] == 2 and np.array_equal(emit, fe) and np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
     sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off, force_exact=256)  # ... and from memory
     assert sim.index_info()["dict_mode"] == 0 and np.array_equal(emit, fe) and np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
     assert np.all(fe >= 0) and sorted(sim.proposal(0)) == sc.faulty.tolist()
@@ -1024,7 +1028,7 @@ def test_c4_full_shard_against_fast_oracle(E):
     want_fp = proposal_fingerprints(fo, fpp, fe >= 0)
     sim, (emit, nprop, pcount, fp) = run_population(E, eng, records, rec_off, alert_set=sc0.batches.recs, trust=True)
     info = sim.index_info()
-    assert info["alerts_prevalidated"] == 1 and info["dict_mode"] == 2
+    assert info["alerts_prevalidated"] == 1 and info["dict_mode"] == 3
     assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
     assert np.array_equal(fp, want_fp)
     assert np.all(fe >= 0) and np.all(pcount == len(sc0.faulty))

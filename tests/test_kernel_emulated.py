@@ -108,10 +108,11 @@ def test_churn_scenario(n, n_out, n_crash, n_join, K, H, L):
     _check(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member)
 
 
-@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("mode", [0, 2, 3])
 def test_other_dictionary_placements(mode):
-    """The tally kernel with the node -> slot dictionary in memory (0) and as compressed tables -- bitmap + rank -- in LDS
-    (2), on scenario and adversarial streams (the other tests run the direct tables)."""
+    """The tally kernel with the node -> slot dictionary in memory (0), as compressed tables -- bitmap + rank -- in LDS (2),
+    and with no dictionary at all: the records carry their subjects' entries (3, kDictResolved: what the engine runs), on
+    scenario and adversarial streams (the other tests run the direct tables)."""
     n, K, H, L = 300, 10, 9, 4
     pop = S.Population.make(n)
     reg, view = oracle_view(pop, K, list(range(0, n - 20)))
