@@ -153,10 +153,15 @@ int rapid_cd_clear(rapid_cd* cd);                                               
  * (R/MembershipService.java:300-354 with the filter of :644-675).  records = the receivers' delivered
  * streams back to back, rec_off[r]..rec_off[r+1] (in records) = receiver r; every receiver starts the round
  * with an empty detector and announcedProposal == false in the engine's current configuration.
- * The records are borrowed for the call: the engine keeps them SPLIT in its own memory -- 8 bytes per record that the
- * tally always reads {dst, ring_mask, status, flags} and, in a second array, the 8 bytes of its configuration id that only
- * the per-delivery filter reads (src is never read, as in R/MultiNodeCutDetector.java:101) -- 16 B per delivered record
- * resident, of which a tally launch pulls 8 or 16 from HBM. */
+ * The records are borrowed for the call and pass through ONE load pass into the engine's own layout: 8 bytes per record
+ * that a tally launch reads -- {subject, core word = ring mask + edge status + end-of-batch} -- plus, beside them and read by
+ * no tally launch, the subject again (4 B) and the configuration id (8 B).  The load pass compares every record's
+ * configuration id with the view's current one and MARKS the verdict in the resident record (R/MembershipService.java:
+ * 653-657 drops an alert of another configuration); if the view changes while the streams stay loaded the marks are
+ * brought up to date from the retained ids before the next tally.  src is never read, as in R/MultiNodeCutDetector.java:101.
+ * Before the first tally over a (stream set, alert set, view) the engine resolves every record's subject to its entry of
+ * the round's index (slot, rings and status the index covers) in one more streaming pass -- every delivered alert is
+ * mapped from node to slot exactly once, and the tally itself looks nothing up (rapid_sim_pass_times reports both passes). */
 int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, const int64_t* rec_off,
                            int32_t n_receivers);
 /* same, records already on this device (`records_bytes` readable bytes covering them; borrowed for the call, split into
@@ -176,16 +181,17 @@ int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64
  * next call that reads results (rapid_sim_results, rapid_sim_count_votes, rapid_sim_round, rapid_sim_proposal) return
  * RAPID_EINVAL: the round's results are void, the set was wrong. */
 int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, int64_t n_alerts);
-/* Opt-in, per loaded stream set (a load resets it): asks the tally not to re-read the configuration id of every delivered
- * record (8 of the 16 resident bytes per record: half the HBM traffic of a launch).  The request is honoured on VERIFIED facts
- * only -- nothing rests on the caller's word: (1) when the streams were loaded, the pass that splits the 20-byte records
- * compared every record's configuration id with the view's current one (the bytes pass through it anyway) and found no
- * other; (2) the view has not changed since; (3) every declared alert passes the filter of R/MembershipService.java:644-675
- * under the current view.  If any of these fails -- e.g. late deliveries of an earlier configuration are among the streams,
- * BASELINE configs[4] -- the tally silently runs the per-delivery filter instead and drops those records as the reference
- * does (:653-657).  Checked per delivery either way: subject range, UP / DOWN against the membership, rings covered by the
- * index -> RAPID_EINVAL as above.  A delivered record that passes these checks passes the reference's filter, so the
- * results are the reference's for ANY stream that is accepted, not only for byte copies of the declared alerts. */
+/* Opt-in, per loaded stream set (a load resets it): asks the tally to treat a delivered record that fails the filter of
+ * R/MembershipService.java:644-675 as an ERROR of the stream (RAPID_EINVAL, results void) instead of dropping it per delivery
+ * -- the instantiation without the per-delivery filter, a few instructions per record cheaper (both read the same 8 B per
+ * record).  The request is honoured on VERIFIED facts only -- nothing rests on the caller's word: (1) the load pass found the
+ * view's current configuration id on every delivered record and every subject in the registry's range; (2) the marks are
+ * current for the view the tally runs in; (3) every declared alert passes the filter under the current view.  If any of
+ * these fails -- e.g. late deliveries of an earlier configuration are among the streams, BASELINE configs[4] -- the tally
+ * silently runs the per-delivery filter instead and drops those records as the reference does (:653-657).  Checked per
+ * delivery either way: UP / DOWN against the membership, rings covered by the index -> RAPID_EINVAL as above.  A delivered
+ * record that passes these checks passes the reference's filter, so the results are the reference's for ANY stream that is
+ * accepted, not only for byte copies of the declared alerts. */
 int rapid_sim_trust_alert_copies(rapid_engine* h, int32_t on);
 /* Starts another round over the streams (and the declared alert set) that are loaded: the per-round index is built again
  * by the next tally, as it is after a load.  What a round costs = index + tally + vote count; bench.py times exactly that. */
@@ -398,15 +404,15 @@ int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, in
 /* measurement aid: the tally kernel's counters per workgroup ([rows][8], the rows rapid_sim_stats sums) */
 int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, int32_t* rows_out);
 /* testing / measurement knob, a bit set (0 = normal): 1 = every window through the exact sequential path, 8 = careful
- * path only (no cold / fast windows), 64 = never trust the pre-validation of the alert set, 128 = no direct node -> slot
- * tables in LDS even when they fit (the compressed form of large populations is used instead), 256 = dictionary in
- * memory (the mode of populations too large even for that), 512 = sharded vote count always through the histogram
- * all-reduces (never the all-gather + merge of the ranks' local counts), 1024 = every receiver dealt to the workgroups
- * statically (no common pool for the last eighth), 2048 = the vote count never uses the statistics the tally kernel gathers
- * (always a counting pass), 4096 = the round index built by several workgroups (the form of populations >= 40,000 nodes)
- * whatever the size, 8192 = two slots per LDS word in the tally (twice the receivers per CU in rounds with very many hot
- * subjects; built, parity-checked, measured without gain so far and therefore never chosen by itself), 32 = measurement only:
- * stream the records through the registers without tallying them (results are meaningless) */
+ * path only (no cold / fast windows), 64 = never trust the pre-validation of the alert set (per-delivery filter), 32768 = the
+ * tally looks every subject up itself instead of reading resolved records, from tables placed where they fit best (direct
+ * in LDS, else compressed in LDS, else in memory) -- the cross-check of the product's resolve pass; 128 = the same, never
+ * direct tables; 256 = the same, tables in memory; 512 = sharded vote count always through the histogram all-reduces (never
+ * the all-gather + merge of the ranks' local counts), 1024 = every receiver dealt to the workgroups statically (no common
+ * pool for the last eighth), 2048 = the vote count never uses the statistics the tally kernel gathers (always a counting
+ * pass), 4096 = the round index built by several workgroups (the form of populations >= 40,000 nodes) whatever the size,
+ * 16384 = a view change sorts all K rings again instead of compacting / merging the old ones, 32 = measurement only: stream
+ * the records through the registers without tallying them (results are meaningless) */
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);
 /* testing aids for the sharded vote count (one GPU standing in for n ranks): the answer block this engine's voters
  * contribute to rapid_sim_count_votes' all-gather (out == NULL: only *seg_bytes), and the device-side merge of n_ranks such

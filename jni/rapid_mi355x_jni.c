@@ -128,6 +128,26 @@ JNIEXPORT jintArray JNICALL Java_com_vrg_rapid_NativeCutEngine_expectedObservers
     return node_list(env, h, node, rapid_view_expected_observers);
 }
 
+/* int[] q4AtRisk(long h, int[] hotSubjects): the members among them whose observers, memoised by the reference when they were
+ * first in flux (MembershipView.cachedObservers), differ from today's -- empty: quirk Q4 cannot fire at any receiver this round */
+JNIEXPORT jintArray JNICALL Java_com_vrg_rapid_NativeCutEngine_q4AtRisk(JNIEnv* env, jobject self, jlong h, jintArray hot) {
+    (void)self;
+    const jsize n = (*env)->GetArrayLength(env, hot);
+    jint* in = (*env)->GetIntArrayElements(env, hot, NULL);
+    if (in == NULL) return NULL;
+    jintArray result = NULL;
+    int32_t* out = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    if (out != NULL) {
+        int32_t m = 0;
+        const int rc = rapid_view_q4_at_risk(ENGINE(h), (const int32_t*)in, (int32_t)n, out, (int32_t)n, &m);
+        if (rc != RAPID_OK) throw_for(env, rapid_last_error(ENGINE(h)), rc);
+        else result = to_java(env, out, m);
+        free(out);
+    }
+    (*env)->ReleaseIntArrayElements(env, hot, in, JNI_ABORT);
+    return result;
+}
+
 JNIEXPORT jlong JNICALL Java_com_vrg_rapid_NativeCutEngine_configurationId(JNIEnv* env, jobject self, jlong h) {
     (void)self;
     int64_t id = 0;

@@ -12,25 +12,29 @@
 //     (b, b + G, ...) and claimed by the workgroup's waves from a counter in LDS;
 //   * the receiver's whole detector state is one word per SLOT in LDS -- a slot is a "hot" subject: one the round's
 //     alert set names on >= L distinct rings, the only kind that can ever reach the L watermark at any receiver
-//     (index_kernels.h builds the node->slot dictionary once per loaded stream set; reports about other subjects can
-//     never change any receiver's outcome and only contribute to seenLinkDownEvents): bits 0..K-1 = rings reported,
-//     bit 14 = already flushed into an emitted proposal;
-//   * the delivered stream is read ONCE from HBM, straight into registers (stream_load.h).  Resident, a record is split:
-//     core[i] = {dst, ring mask | status | flags} (8 B) and cfg[i] = its configuration id (8 B; src is never read by the
-//     reference either).  A WINDOW is kQ quarters of 64 records at fixed positions of the stream; lane l of quarter q
-//     owns record 64 q + l and loads its core entry with one buffer_load_dwordx2 (lane stride 8 B: a quarter is 512
-//     contiguous bytes) -- and its cfg entry the same way only when deliveries are not vouched-for copies of a validated
-//     alert set.  The next window's loads are issued before the current one is tallied, so every wave keeps a window in
-//     flight without a byte of LDS -- the in-flight data of a CU lives in its 512 KiB of VGPRs, and the LDS holds
-//     15-16 waves' detectors instead of 10 waves' staging rings;
+//     (index_kernels.h builds the node->slot dictionary once per round; reports about other subjects can never change any
+//     receiver's outcome and only contribute to seenLinkDownEvents): bits 0..K-1 = rings reported, bit 16 = already
+//     flushed into an emitted proposal;
+//   * the delivered stream is read ONCE from HBM, straight into registers (stream_load.h), 8 bytes per record:
+//     core[i] = {the subject's DICTIONARY ENTRY, core word}.  The entry (dict_entry below: slot, rings the index was not
+//     built for, which edge status fails the membership filter) is written into the record by resolve_records_kernel
+//     once per (stream set, round index) -- the tally looks nothing up; the core word (core_word below) is the ring mask,
+//     the edge status as two bits and the end-of-batch mark, laid out against the entry so that "this delivery is not
+//     covered" is one AND and "apply it" is one ds_or of the whole word.  The configuration-id verdict of
+//     R/MembershipService.java:653-657 is marked in the record by the load pass (kCoreStale) and arrives as the poison
+//     entry: no launch reads the ids.  A WINDOW is kQ quarters of 64 records at fixed positions of the stream; lane l of
+//     quarter q owns record 64 q + l and loads it with one buffer_load_dwordx2 (lane stride 8 B: a quarter is 512
+//     contiguous bytes).  Three windows per wave are in flight (three register sets, each re-requested in place as soon
+//     as its window is applied), without a byte of LDS;
 //   * FAST window (the steady state): while a WITNESS exists -- a slot in preProposal that provably stays below H
 //     through the window even if it is credited with every implicit report it can ever get -- updatesInProgress
 //     stays >= 1, so the reference cannot emit inside the window (R/MultiNodeCutDetector.java:110-121) and the
 //     window's reports are applied order-free with ds_or_b32, nothing returned, nothing counted.  The witness is
-//     checked BEFORE anything is applied (its state + the window's own reports about it), so nothing is ever rolled
-//     back.  The records after the window's last batch end are CARRIED (decoded, in one register) into the next
+//     checked BEFORE anything is applied (its state, kept in a scalar, + the window's own reports about it), so nothing
+//     is ever rolled back.  The records after the window's last batch end are CARRIED (one register) into the next
 //     window, so the applied state always stands at a batch boundary.  Implicit reports are owed and applied by one
-//     pass over the round's (subject, observer, ring) triples among the hot slots when the fast path is left;
+//     pass over the round's (subject, observer, ring) triples among the hot slots when the fast path is left.  Fast (and
+//     cold) windows run in a loop of their own, three per turn, that holds nothing but what such a window needs;
 //   * COLD window (before any subject has reached L): applied with ds_or_rtn and kept iff no subject it touches can
 //     reach H even with every implicit report it can ever get; its entrants are the first witnesses;
 //   * SLOW window (no witness survives, the stream's last window, test modes): the window is decoded into an LDS
@@ -79,12 +83,14 @@ constexpr int kMaxWavesPerBlock = 16;
 // The RESIDENT core word of a delivered record (second dword of core[i]; the first is the subject's node index), written by
 // split_records_kernel from dword 4 of the boundary record {ring mask, status, flags}: the status as TWO bits, exactly
 // one of which is set in a real record and none in the zeros behind a stream's end, so that "this report fails the
-// UP / DOWN filter for this subject" is one AND with the subject's dictionary entry; the batch end in the sign bit, so
-// that it is one signed compare.
+// UP / DOWN filter for this subject" is one AND with the subject's dictionary entry; the batch end in bit 16 -- the low bit
+// of the word's upper half, which nothing else of the word reaches into: a lane counts the batch ends it has applied by
+// adding upper halves (one vector instruction per quarter; counting them in scalars took two more per quarter out of the one
+// scalar pipe the CU's waves share, the busiest unit of this kernel).
 constexpr unsigned int kCoreRings = 0x3FFFu;   // bits 0..13: ring mask (K <= 14)
 constexpr unsigned int kCoreDown = 1u << 14;   // edgeStatus == DOWN
 constexpr unsigned int kCoreUp = 1u << 15;     // edgeStatus == UP
-constexpr unsigned int kCoreEob = 1u << 31;    // last record of its BatchedAlertMessage
+constexpr unsigned int kCoreEob = 1u << 16;    // last record of its BatchedAlertMessage
 // ... and in the FIRST dword (the subject's node index) bit 31 marks a record whose configuration id is not the one the
 // engine is in (R/MembershipService.java:653-657 drops it): the id is compared where every id passes anyway -- when the
 // records are split at load time, and again by remark_records_kernel if the view changes while streams stay loaded -- so
@@ -109,7 +115,7 @@ constexpr unsigned int kNoSlot = 0x3FFFu;            // at most 16318 hot subjec
 //   bit 14      a DOWN report about the node fails the filter of R/MembershipService.java:659-668 (it is not a member),
 //   bit 15      an UP report fails it (it is a member),
 //   bits 16..30 2 x slot (a dummy slot for a node that is not hot): shifted right by 16 and added twice it is the byte
-//               offset of the slot's state word; bit 31 = 0 (the batch-end bit of the core word meets nothing).
+//               offset of the slot's state word; bit 16 is therefore 0 (the batch-end bit of the core word meets nothing).
 __host__ __device__ inline unsigned int dict_entry(unsigned int decl_entry, unsigned int slot) {
     return (~decl_entry & kCoreRings) | ((decl_entry >> 15) != 0u ? kCoreUp : kCoreDown) | (slot << 17);
 }
@@ -272,9 +278,9 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // 
 // ---- detector state accessors ---------------------------------------------------------------------------------
 // LDS flavour (population kernel): indices are slots; sweeps cover the hot slots only.
 struct SlotDetector {
-    // one 32-bit word per slot: bits 0..K-1 = rings reported, bit 16 = already flushed into an emitted proposal.  The fast
-    // window ORs whole core words into it, so bits 14, 15 and 31 (status, batch end) hold garbage: every reader masks.
-    static constexpr unsigned int kFlushed = 1u << 16;
+    // one 32-bit word per slot: bits 0..K-1 = rings reported, bit 17 = already flushed into an emitted proposal.  The fast
+    // window ORs whole core words into it, so bits 14, 15 and 16 (status, batch end) hold garbage: every reader masks.
+    static constexpr unsigned int kFlushed = 1u << 17;
     unsigned int* st;
     int n_scan;        // = n_hot
     int H, L;
@@ -779,6 +785,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // the effective core word (rings + status; zero in the lanes before carry_start)
         unsigned int carry_so = 0u, carry_w = 0u;
         int carry_start = kWave;
+        unsigned int vbatch = 0u;    // per lane: batch ends applied by cold / fast windows since s.batch was last brought up to date
 
         // per-sub-chunk decode results of the slow path (one record per lane)
         int dst = 0, ncons = 0, lastE = -1, spos = 0, send = 0;
@@ -804,17 +811,18 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             wave_lds_fence();
             int run = 0;
             unsigned int best = 0xFFFFFFFFu;  // bound << 16 | slot
-            for (int i0 = 0; i0 < n_hot; i0 += kWave) {
-                const int i = i0 + lane;
-                const bool in = i < n_hot;
-                const unsigned int m = in ? d.load(i) : 0u;
-                const int c = d.count(m);
-                const bool pre = in && c >= d.L && c < d.H;
-                run += __popcll(wave_ballot(pre));
-                const unsigned int am = pre ? (unsigned int)smask[i] : 0u;
-                const int bound = d.count(m | am);
-                const unsigned int key = (pre && bound < d.H) ? ((unsigned int)bound << 16) | (unsigned int)i : 0xFFFFFFFFu;
-                best = min(best, key);
+            for (int i0 = 0; i0 < n_hot; i0 += 2 * kWave) {  // two slots per lane and step: two LDS round trips in flight, half the turns
+                const int ia = i0 + lane, ib = i0 + kWave + lane;
+                const bool ina = ia < n_hot, inb = ib < n_hot;
+                const unsigned int ma = ina ? d.load(ia) : 0u, mb = inb ? d.load(ib) : 0u;
+                const int ca = d.count(ma), cb = d.count(mb);
+                const bool prea = ina && ca >= d.L && ca < d.H, preb = inb && cb >= d.L && cb < d.H;
+                run += __popcll(wave_ballot(prea)) + __popcll(wave_ballot(preb));
+                const unsigned int ama = prea ? (unsigned int)smask[ia] : 0u, amb = preb ? (unsigned int)smask[ib] : 0u;
+                const int bounda = d.count(ma | ama), boundb = d.count(mb | amb);
+                const unsigned int keya = (prea && bounda < d.H) ? ((unsigned int)bounda << 16) | (unsigned int)ia : 0xFFFFFFFFu;
+                const unsigned int keyb = (preb && boundb < d.H) ? ((unsigned int)boundb << 16) | (unsigned int)ib : 0xFFFFFFFFu;
+                best = min(best, min(keya, keyb));
             }
             s.running = run;
             running_exact = !owed;  // with nothing owed the state here is the reference's
@@ -851,6 +859,13 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             return witness >= 0;
         };
 
+        // the batch ends the cold / fast windows counted per lane -> s.batch
+        auto fold_batches = [&]() {
+            if (wave_ballot(vbatch != 0u) != 0ull) {
+                s.batch += uniform((int)(unsigned int)wave_sum64((unsigned long long)vbatch));
+                vbatch = 0u;
+            }
+        };
         // ---- apply the owed implicit reports.  Every report applied here was applied by the reference at a batch end
         // inside a window already certified emission-free (the witness of that window takes no uncounted implicit
         // report: its bound covers them all), so this cannot be where an emission happens.  Only at a batch boundary:
@@ -893,9 +908,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             return kApplied;
 #endif
             unsigned int so[kQ], w[kQ];
-            unsigned long long mW = wave_ballot(carry_so == witness_so);
-            unsigned long long mEl = 0ull;
-            int nb = 0;  // batch ends in the window (none among the lanes that will be carried, by the choice of ncl)
+            // (everything that can stay in vector registers does: the CU's waves share ONE scalar pipe, and it is the busiest
+            // unit of this kernel.  "Does the window say anything about the witness" is a running minimum of slot ^ witness,
+            // looked at once; the batch ends are counted per lane by adding upper halves.)
+            unsigned int wdiff = carry_so ^ witness_so;
+            unsigned int nbv = 0u;  // batch ends in the window (none among the lanes that will be carried, by the choice of ncl)
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
 #ifdef RAPID_PROBE_NO_LOOKUP
@@ -908,10 +925,11 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #endif
                 w[q] = effective(c, q, k);
                 so[q] = k.entry >> 16;
-                mW |= wave_ballot(so[q] == witness_so);
-                mEl = wave_ballot((int)c.w4[q] < 0);
-                nb += __popcll(mEl);
+                wdiff = min(wdiff, so[q] ^ witness_so);
+                nbv += c.w4[q] >> 16;
             }
+            const unsigned long long mW = wave_ballot(wdiff == 0u);
+            const unsigned long long mEl = wave_ballot((c.w4[kQ - 1] & kCoreEob) != 0u);
             const int ncl = kWave - __clzll((long long)mEl);  // lanes of the last quarter up to its last batch end (0: none)
             const bool inl = lane < ncl;
             unsigned int wadd = 0u;  // what the window reports about the witness (rare: ten reports in a whole stream)
@@ -947,7 +965,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             for (int q = 0; q < kQ - 1; ++q) (void)atomicOr(slot_word(so[q]), w[q]);
             (void)atomicOr(slot_word(so[kQ - 1]), inl ? w[kQ - 1] : 0u);
 #endif
-            s.batch += nb;
+            vbatch += nbv;
             carry_so = so[kQ - 1];
             carry_w = inl ? 0u : w[kQ - 1];
             carry_start = ncl;
@@ -964,7 +982,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // L is seen by exactly one lane, whatever the order of the atomics) are in preProposal from here on with a bound
         // below H: the first witnesses.
         auto cold_window = [&](const Win& c) -> bool {
-            const unsigned long long mEl = wave_ballot((int)c.w4[kQ - 1] < 0);
+            const unsigned long long mEl = wave_ballot((c.w4[kQ - 1] & kCoreEob) != 0u);
             if (mEl == 0ull) return false;
             const int ncl = kWave - __clzll((long long)mEl);
             const bool inl = lane < ncl;
@@ -1008,7 +1026,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             for (int q = 0; q < kQ; ++q) anyd = anyd || (e[q].down && (q < kQ - 1 || inl));
             if (!s.seen_down) s.seen_down = wave_ballot(anyd) != 0ull;
 #pragma unroll
-            for (int q = 0; q < kQ; ++q) s.batch += __popcll(wave_ballot((int)c.w4[q] < 0));
+            for (int q = 0; q < kQ; ++q) vbatch += c.w4[q] >> 16;
             carry_so = 2u * e[kQ - 1].slot;
             carry_w = inl ? 0u : (e[kQ - 1].bits | (e[kQ - 1].down ? kCoreDown : 0u));
             carry_start = ncl;
@@ -1131,6 +1149,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // the exact path.  Everything is consumed: no carry afterwards.
         auto slow_window = [&](const Win& c, int w) {
             flush_pending();
+            fold_batches();
             const int base_rec = w * kWin;
             Dec cr;
             cr.slot = carry_so >> 1;
@@ -1140,7 +1159,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
                 // the stream's last record closes its batch whatever its flag says
-                const bool e_eob = (int)c.w4[q] < 0 || base_rec + q * kWave + lane == nrec - 1;
+                const bool e_eob = (c.w4[q] & kCoreEob) != 0u || base_rec + q * kWave + lane == nrec - 1;
                 scratch[kWave + q * kWave + lane] = pack_rec(decode_rec(c, q), e_eob);
             }
             spos = carry_start;
@@ -1207,6 +1226,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             carry_so = 0u;
             carry_w = 0u;
             carry_start = kWave;
+            vbatch = 0u;
             careful_cap = kWave;
             if (restart) {  // the stream again, from its first window
                 restart = false;
@@ -1241,13 +1261,16 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                     // latency exposed) -- at the price of reading a window twice after a failed certificate (a few per receiver).
                     unsigned int vturn = voff - (unsigned int)kSets * kWinBytes;  // this lane's offset in the window held by S[0]
                     int n_ok = kSets;
-                    while (w + kSets <= w_end && n_ok == kSets) {
+                    // (the last turn before the stream's final window is a partial one: its remaining steps are skipped like the
+                    // steps behind a failed certificate, which re-requests the final window -- a kilobyte or two per receiver --
+                    // and saves the general iterations, with their copies and their wait, that the tail would otherwise take)
+                    while (w < w_end && n_ok == kSets) {
                         if (!claimed && w + kSets + kClaimAhead > nwin) claim();  // (a few windows early rather than in the middle of a turn)
                         n_ok = 0;
 #pragma unroll
                         for (int i = 0; i < kSets; ++i) {
                             bool advance = false;
-                            if (n_ok == i) {
+                            if (n_ok == i && w + i < w_end) {
                                 if (cold) {  // (the first windows of a stream: until a subject reaches L there is no witness to be had)
                                     advance = cold_window(S[i]);
                                 } else if (witness >= 0) {

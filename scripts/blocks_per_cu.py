@@ -17,7 +17,7 @@ eng = E.Engine(n_max=n, K=K, H=H, L=L)
 view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
 obs, subj, member = view.tables()
 sc = S.build_scenario(name, subj, view.getCurrentConfigurationId())
-for w, b in ((15, 1), (10, 2), (9, 2), (8, 2), (7, 2), (6, 3), (5, 3)):
+for w, b in ((15, 1), (16, 1), (12, 2), (11, 2), (10, 2), (8, 3), (8, 2)):
     os.environ["RAPID_TALLY_WAVES"] = str(w)
     os.environ["RAPID_TALLY_BLOCKS_PER_CU"] = str(b)
     sim = E.ClusterSimulation(eng)
