@@ -1276,11 +1276,14 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                                 } else if (witness >= 0) {
                                     int st_ = fast_try(S[i]);
                                     // a witness that fails is replaced right here while candidates from the last sweep are left
-                                    // (a new sweep is the general iteration's business)
-                                    while (st_ == kWitnessFails && ci + 1 < ncand) {
-                                        ++ci;
-                                        set_witness();
-                                        st_ = fast_try(S[i]);
+                                    // (a new sweep is the general iteration's business).  The first attempt stands alone: as the
+                                    // head of a retry loop it would start with a block of copies for everything the loop carries.
+                                    if (__builtin_expect(st_ == kWitnessFails, 0)) {
+                                        while (st_ == kWitnessFails && ci + 1 < ncand) {
+                                            ++ci;
+                                            set_witness();
+                                            st_ = fast_try(S[i]);
+                                        }
                                     }
                                     advance = st_ == kApplied;
                                 }
