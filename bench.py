@@ -215,6 +215,33 @@ def main():
         load_ms = None
         sys.stderr.write("load pass not timed: %s\n" % str(e)[:200])
 
+    # ---- the same round's deliveries GENERATED on the device (rapid_sim_generate): every receiver gets every batch in a seeded
+    # order of its own, written directly as resolved resident records -- no boundary records, no load pass, no resolve pass.
+    # (The delivery order is the generator's own hash order, not the numpy permutation of the loaded streams: same
+    # distribution, other streams; the round must decide the same cut.)
+    gen = None
+    try:
+        sim3 = E.ClusterSimulation(eng)
+        ts_ = []
+        for _ in range(3):
+            t_ = time.perf_counter()
+            sim3.generate(sc.batches, my_rx, seed=2, trust_copies=True)
+            eng.sync()
+            ts_.append(1e3 * (time.perf_counter() - t_))
+        sim3.new_round()
+        sim3.tally()
+        rr_g = sim3.count_votes()
+        gi = sim3.index_info()
+        gen = {"generate_ms": round(min(ts_), 4), "generate_device_ms": gi["generate_ms"], "records": my_records,
+               "records_per_s": round(my_records / (min(ts_) * 1e-3), 1),
+               "round_from_generator_ms": round(min(ts_) + ms_per_step, 4),
+               "decided": int(rr_g.decided), "cut_size": int(rr_g.cut_size), "votes_winner": int(rr_g.votes_winner),
+               "note": "generate_ms = host wall time of rapid_sim_generate (upload of the round's distinct alerts, index, keys, segmented sort, "
+                       "streams); generate_device_ms = keys + sort + streams on the device"}
+        del sim3
+    except Exception as e:  # (a measurement beside the line, not the line)
+        sys.stderr.write("generator not timed: %s\n" % str(e)[:200])
+
     # ---- one full round including decideViewChange: time-to-stable-cut = streams resident -> decided cut + new
     # configuration id on the host: per-round index build + tally + vote count + apply cut (rings, tables, config id)
     sim.load_streams(records, rec_off)
@@ -253,6 +280,7 @@ def main():
         "n_ranks_seen": eng.comm_info()[1],
         "load_split_ms": round(load_ms, 4) if load_ms is not None else None,
         "resolve_ms": resolve_ms,
+        "generated_streams": gen,
         "round_from_boundary_ms": round(load_ms + (resolve_ms or 0.0) + ms_per_step, 4) if load_ms is not None else None,
         "alert_records_per_s": round(tot_records * args.steps / elapsed, 1),
         "time_to_stable_cut_ms": round(ttsc_ms, 3) if rr_full.decided else None,

@@ -169,6 +169,21 @@ int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, c
  * the next load */
 int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64_t records_bytes,
                                   const int64_t* d_rec_off, int32_t n_receivers);
+/* The delivered streams made ON THE DEVICE instead of loaded (rapid_sim_generate): alerts = the round's distinct
+ * alerts in batch order, batch b = alerts[batch_off[b] .. batch_off[b + 1]) = one BatchedAlertMessage; every receiver gets
+ * every batch exactly once (the fan-out of R/UnicastToAllBroadcaster.java:46-63), receiver r in the order of
+ * key(r, b) = mix64(mix64(seed + receivers[r]) + b) ascending (mix64 = the splitmix64 finaliser; rapid_amd/scenarios.py:
+ * deliver_hashed is the same statement on the host).  The records are written directly in the resident layout with their
+ * subjects already resolved against the round's index -- the 20-byte records of the deliveries never exist, there is no load
+ * pass and no resolve pass -- and `alerts` IS the declared alert set of the round (rapid_sim_set_alert_set is implied).
+ * receivers[r] = node index of receiver r (only its value enters the order).  Late deliveries of an earlier configuration
+ * are not generated (alerts whose own configuration id differs are marked and dropped like loaded ones).
+ * rapid_sim_pass_times out[2] = the device time of the last generation. */
+int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const int64_t* batch_off, int32_t n_batches,
+                       const int32_t* receivers, int32_t n_receivers, uint64_t seed);
+/* testing aid: subject (| 0x80000000 if the record carries another configuration id) and core word (ring mask, bit 14 DOWN,
+ * bit 15 UP, bit 16 end of batch) of n resident records starting at `first` */
+int rapid_debug_read_records(rapid_engine* h, int64_t first, int32_t n, uint32_t* subjects, uint32_t* core_words);
 /* Optional, after a load: declares the round's DISTINCT alerts (every delivered record is a byte-identical copy of
  * one of them, flags aside -- one AlertMessage is broadcast to all receivers, R/UnicastToAllBroadcaster.java:46-52).
  * The per-round index (which subjects can reach the L watermark at all, their adjacency) and the one-time validation
@@ -394,7 +409,8 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg);
 int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms);
 /* device time (ms) of the passes a stream set goes through once, outside the per-round step: out[0] = the last index build,
  * out[1] = the last resolve pass (every resident record's subject -> its dictionary entry of the current round index; runs
- * when streams, alert set or view changed since the records were last resolved), out[2..3] = 0 */
+ * when streams, alert set or view changed since the records were last resolved), out[2] = the last rapid_sim_generate,
+ * out[3] = 0 */
 int rapid_sim_pass_times(rapid_engine* h, float out[4]);
 /* measurement probe (not a product path): stream the loaded records with the tally kernel's access pattern and no
  * processing.  Register loads: variant 0 = 2 KiB tiles x 8 in flight, 1: 4 KiB x 4, 2: 8 KiB x 2, 3: 2 KiB x 4,

@@ -154,6 +154,11 @@ struct rapid_engine {
     DevBuf<unsigned short> d_dict, d_decl, d_adj_off, d_trank;
     DevBuf<unsigned int> d_tbits, d_tent;  // compressed dictionary (index_build_block_kernel)
     DevBuf<unsigned int> d_entries;        // dict_entry per node for rounds whose tables stay in memory
+    DevBuf<unsigned long long> d_gen_keys, d_gen_skeys;  // rapid_sim_generate: delivery-order keys [receivers][batches], sorted
+    DevBuf<unsigned int> d_gen_vals, d_gen_perm;         // ... and the batch indices they carry
+    DevBuf<long long> d_gen_boff;
+    DevBuf<int> d_gen_rx, d_gen_seg;
+    float generate_ms = 0.f;
     int n_touched = 0;
     int dict_mode = 3;  // rapid::kDictResolved (the product) / kDictDirect / kDictCompressed / kDictMemory (testing knobs)
     bool lds_attr_set = false;
@@ -888,6 +893,8 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_pos.release(); h->d_obs.release(); h->d_subj.release();
     h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
     h->d_q4_nodes.release(); h->d_q4_rows.release(); h->d_entries.release(); h->d_dstv.release();
+    h->d_gen_keys.release(); h->d_gen_skeys.release(); h->d_gen_vals.release(); h->d_gen_perm.release(); h->d_gen_boff.release(); h->d_gen_rx.release();
+    h->d_gen_seg.release();
     if (h->ev_res0) (void)hipEventDestroy(h->ev_res0);
     if (h->ev_res1) (void)hipEventDestroy(h->ev_res1);
     h->d_ids_hi2.release(); h->d_ids_lo2.release(); h->d_ids_new.release(); h->d_cfg_partial.release(); h->d_chunk_kept.release();
@@ -1386,6 +1393,105 @@ int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64
     if ((rc = load_split(h, static_cast<const unsigned char*>(d_records), true, n_rec))) return rc;
     h->d_rec_off = reinterpret_cast<const long long*>(d_rec_off);
     streams_replaced(h, n_receivers, n_rec);
+    return RAPID_OK;
+}
+
+int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const int64_t* batch_off, int32_t n_batches, const int32_t* receivers,
+                       int32_t n_receivers, uint64_t seed) {
+    if (!h || !batch_off || n_batches < 0 || n_receivers < 0 || (n_receivers > 0 && !receivers)) return RAPID_EINVAL;
+    if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const long long A = batch_off[n_batches];
+    if (batch_off[0] != 0 || A < 0 || (A > 0 && !alerts)) return fail(h, RAPID_EINVAL, "bad batch offsets");
+    for (int b = 0; b < n_batches; ++b)
+        if (batch_off[b + 1] < batch_off[b]) return fail(h, RAPID_EINVAL, "batch offsets not monotone at %d", b);
+    const long long RB = (long long)n_receivers * (long long)n_batches, total = (long long)n_receivers * A;
+    if (RB >= (1ll << 31)) return fail(h, RAPID_ECAPACITY, "%d receivers x %d batches: at most 2^31 deliveries per call", n_receivers, n_batches);
+    hipStream_t st = h->stream;
+    if (!h->ev0) {
+        HIPCHK(h, hipEventCreate(&h->ev0));
+        HIPCHK(h, hipEventCreate(&h->ev1));
+    }
+    // the round's distinct alerts = the declared alert set; batches; receivers
+    HIPCHK(h, h->d_alert_set.ensure((size_t)std::max<long long>(A, 1) * 20 + 16));
+    HIPCHK(h, h->d_gen_boff.ensure((size_t)n_batches + 1));
+    HIPCHK(h, h->d_gen_rx.ensure((size_t)std::max(n_receivers, 1)));
+    if (A) HIPCHK(h, hipMemcpyAsync(h->d_alert_set.p, alerts, (size_t)A * 20, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->d_gen_boff.p, batch_off, sizeof(long long) * ((size_t)n_batches + 1), hipMemcpyHostToDevice, st));
+    if (n_receivers) HIPCHK(h, hipMemcpyAsync(h->d_gen_rx.p, receivers, sizeof(int) * (size_t)n_receivers, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipStreamSynchronize(st));  // (borrowed inputs)
+    // resident arrays
+    const size_t core_bytes = (((size_t)total * 8 + 15) / 16) * 16 + 64;
+    HIPCHK(h, h->d_core.ensure(core_bytes));
+    HIPCHK(h, h->d_cfg.ensure(core_bytes));
+    HIPCHK(h, h->d_dstv.ensure((size_t)total + 16));
+    const size_t tail = ((size_t)total * 8 / 16) * 16;
+    HIPCHK(h, hipMemsetAsync(h->d_core.p + tail, 0, core_bytes - tail, st));
+    HIPCHK(h, h->d_rec_off_own.ensure((size_t)n_receivers + 1));
+    HIPCHK(h, h->d_loadflags.ensure(2));
+    HIPCHK(h, hipMemsetAsync(h->d_loadflags.p, 0, 8, st));
+    hipLaunchKernelGGL(rapid::gen_offsets_kernel, dim3(grid_for((long long)n_receivers + 1, 256)), dim3(256), 0, st, h->d_rec_off_own.p, n_receivers, A);
+    h->d_rec_off = h->d_rec_off_own.p;
+    streams_replaced(h, n_receivers, total);
+    h->n_alert_set = A;  // (streams_replaced forgets a declared set: this one is the streams' own)
+    h->records_bytes = core_bytes - 48;
+    h->load_cfg_id = h->config_id;
+    h->load_all_current = h->load_in_range = false;
+    // the round's index first: the records are written with their subjects already resolved
+    h->core_state = rapid_engine::kCoreUnknown;
+    h->index_valid = false;
+    HIPCHK(h, h->d_errflags.ensure(2));
+    HIPCHK(h, h->d_stats.ensure(stats_words(h)));
+    HIPCHK(h, h->d_voteback.ensure((10 * 8 + ((size_t)h->max_cut + 1) * sizeof(int) + 7) / 8));
+    if ((rc = build_round_index(h))) return rc;
+    const bool resolved = h->dict_mode == rapid::kDictResolved;
+    HIPCHK(h, hipEventRecord(h->ev0, st));
+    if (RB > 0 && A > 0) {
+        HIPCHK(h, h->d_gen_keys.ensure((size_t)RB));
+        HIPCHK(h, h->d_gen_skeys.ensure((size_t)RB));
+        HIPCHK(h, h->d_gen_vals.ensure((size_t)RB));
+        HIPCHK(h, h->d_gen_perm.ensure((size_t)RB));
+        HIPCHK(h, h->d_gen_seg.ensure((size_t)n_receivers + 1));
+        std::vector<int> seg((size_t)n_receivers + 1);
+        for (int r = 0; r <= n_receivers; ++r) seg[(size_t)r] = r * n_batches;
+        HIPCHK(h, hipMemcpyAsync(h->d_gen_seg.p, seg.data(), sizeof(int) * seg.size(), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(rapid::gen_keys_kernel, dim3((unsigned)std::min<long long>((long long)h->num_cus * 16, (RB + 255) / 256)), dim3(256), 0, st,
+                           h->d_gen_rx.p, n_receivers, n_batches, (unsigned long long)seed, h->d_gen_keys.p, h->d_gen_vals.p);
+        size_t tmp_bytes = 0;
+        HIPCHK(h, rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, h->d_gen_keys.p, h->d_gen_skeys.p, h->d_gen_vals.p, h->d_gen_perm.p,
+                                                      (unsigned int)RB, (unsigned int)n_receivers, h->d_gen_seg.p, h->d_gen_seg.p + 1, 0, 64, st));
+        HIPCHK(h, h->d_sort_tmp.ensure(tmp_bytes + 16));
+        HIPCHK(h, rocprim::segmented_radix_sort_pairs(h->d_sort_tmp.p, tmp_bytes, h->d_gen_keys.p, h->d_gen_skeys.p, h->d_gen_vals.p, h->d_gen_perm.p,
+                                                      (unsigned int)RB, (unsigned int)n_receivers, h->d_gen_seg.p, h->d_gen_seg.p + 1, 0, 64, st));
+        hipLaunchKernelGGL(rapid::gen_streams_kernel, dim3((unsigned)n_receivers), dim3(256), 0, st, h->d_alert_set.p, h->d_gen_boff.p, n_batches,
+                           h->d_gen_perm.p, A, reinterpret_cast<uint2*>(h->d_core.p), reinterpret_cast<uint2*>(h->d_cfg.p), h->d_dstv.p,
+                           (long long)h->config_id, (unsigned int)h->n_nodes, resolved ? h->d_entries.p : (const unsigned int*)nullptr, h->d_loadflags.p);
+        HIPCHK(h, hipStreamSynchronize(st));  // (`seg`)
+    }
+    HIPCHK(h, hipEventRecord(h->ev1, st));
+    unsigned int load_flags[2] = {3u, 0u};
+    HIPCHK(h, hipMemcpyAsync(load_flags, h->d_loadflags.p, sizeof load_flags, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipGetLastError());
+    (void)hipEventElapsedTime(&h->generate_ms, h->ev0, h->ev1);
+    h->load_all_current = (load_flags[0] & 1u) == 0u;
+    h->load_in_range = (load_flags[0] & 2u) == 0u;
+    h->core_state = resolved ? rapid_engine::kCoreEntries : rapid_engine::kCoreSubjects;
+    h->core_serial = h->content_serial;
+    return RAPID_OK;
+}
+
+int rapid_debug_read_records(rapid_engine* h, int64_t first, int32_t n, uint32_t* subjects, uint32_t* core_words) {
+    if (!h || first < 0 || n < 0 || !subjects || !core_words) return RAPID_EINVAL;
+    if (!h->streams_loaded || first + n > h->n_records_total) return fail(h, RAPID_EINVAL, "records [%lld, %lld) not loaded", (long long)first, (long long)first + n);
+    int rc = use_device(h);
+    if (rc) return rc;
+    std::vector<uint32_t> both((size_t)n * 2);
+    HIPCHK(h, hipMemcpyAsync(subjects, h->d_dstv.p + first, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(both.data(), h->d_core.p + (size_t)first * 8, sizeof(uint32_t) * 2 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; ++i) core_words[i] = both[(size_t)2 * i + 1];
     return RAPID_OK;
 }
 
@@ -1931,7 +2037,8 @@ int rapid_sim_pass_times(rapid_engine* h, float out[4]) {
     }
     out[0] = h->index_ms;
     out[1] = h->resolve_ms;
-    out[2] = out[3] = 0.f;
+    out[2] = h->generate_ms;
+    out[3] = 0.f;
     return RAPID_OK;
 }
 

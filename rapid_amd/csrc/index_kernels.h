@@ -458,4 +458,76 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     if (t < 8) info[t] = 0;
 }
 
+// ---- rapid_sim_generate: the delivered streams made on the device ----------------------------------------------------
+// Every receiver gets every BatchedAlertMessage of the round exactly once, in a receiver-specific seeded order (the
+// reference's fan-out: UnicastToAllBroadcaster.java:46-63 sends each batch to all members; arrival order differs per
+// receiver -- paper Fig.11 methodology).  The order of receiver r = the batches sorted by
+//     key(r, b) = mix64(mix64(seed + node index of r) + b)            (ties, never seen, by b: the sort is stable)
+// (rapid_amd/scenarios.py: deliver_hashed states the same on the host).  gen_keys_kernel writes the keys, one segmented radix
+// sort orders every receiver's batches, and gen_streams_kernel -- one workgroup per receiver -- lays the batches down back to
+// back directly in the RESIDENT layout (core = {entry or subject, core word}, subject array, configuration ids): the 20-byte
+// records of a round's deliveries never exist, neither on the host nor on the device.
+__device__ inline unsigned long long gen_mix64(unsigned long long x) {  // splitmix64 finaliser (== mix64 of tally_kernel.h)
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void gen_keys_kernel(const int* receivers, int n_receivers, int n_batches, unsigned long long seed, unsigned long long* keys,
+                                unsigned int* vals) {
+    const long long total = (long long)n_receivers * n_batches;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int r = (int)(t / n_batches);
+        const unsigned int b = (unsigned int)(t - (long long)r * n_batches);
+        keys[t] = gen_mix64(gen_mix64(seed + (unsigned long long)(unsigned int)receivers[r]) + (unsigned long long)b);
+        vals[t] = b;
+    }
+}
+// grid = receivers, block = 256.  alerts = the round's distinct alerts (20-byte records) in batch order, boff[b] .. boff[b + 1]
+// = batch b; perm[r][j] = the j-th batch receiver r gets; every receiver gets all n_alerts records: rec_off[r] = r * n_alerts.
+// entries != nullptr: the first dword of a record is its subject's dict_entry (kDictResolved), else the subject itself.
+__global__ __launch_bounds__(256) void gen_streams_kernel(const unsigned char* alerts, const long long* boff, int n_batches, const unsigned int* perm,
+                                                          long long n_alerts, uint2* core, uint2* cfg, unsigned int* dstv, long long cfg_id,
+                                                          unsigned int n_nodes, const unsigned int* entries, unsigned int* load_flags) {
+    __shared__ int s_wave[16];
+    const int r = (int)blockIdx.x, t = (int)threadIdx.x;
+    const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
+    const long long base = (long long)r * n_alerts;
+    long long carry = 0;
+    unsigned int other = 0u, range = 0u;
+    for (int j0 = 0; j0 < n_batches; j0 += (int)blockDim.x) {
+        const int j = j0 + t;
+        long long b0 = 0;
+        int len = 0;
+        if (j < n_batches) {
+            const unsigned int b = perm[(long long)r * n_batches + j];
+            b0 = boff[b];
+            len = (int)(boff[b + 1] - b0);
+        }
+        int total = 0;
+        const long long at = base + carry + block_exclusive_scan(len, s_wave, &total);
+        carry += total;
+        for (int k = 0; k < len; ++k) {
+            const unsigned int* w = reinterpret_cast<const unsigned int*>(alerts + (b0 + k) * 20);
+            const unsigned int c0 = w[0], c1 = w[1];
+            other |= (c0 ^ cfg_lo) | (c1 ^ cfg_hi);
+            range |= w[3] >= n_nodes ? 1u : 0u;
+            const unsigned int d = (w[3] >= kCoreStale ? kCoreStale - 1u : w[3]) | (((c0 ^ cfg_lo) | (c1 ^ cfg_hi)) != 0u ? kCoreStale : 0u);
+            // (a batch ends with its last alert, whatever the flags of the set say)
+            const unsigned int word = (core_word(w[4]) & ~kCoreEob) | (k == len - 1 ? kCoreEob : 0u);
+            dstv[at + k] = d;
+            cfg[at + k] = make_uint2(c0, c1);
+            core[at + k] = make_uint2(entries == nullptr ? d : entries[d < n_nodes ? d : n_nodes], word);
+        }
+    }
+    const unsigned int f = (__ballot(other != 0u) != 0ull ? 1u : 0u) | (__ballot(range != 0u) != 0ull ? 2u : 0u);
+    if (f != 0u && (threadIdx.x & 63u) == 0u) atomicOr(load_flags, f);
+}
+__global__ void gen_offsets_kernel(long long* rec_off, int n_receivers, long long n_alerts) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i <= n_receivers) rec_off[i] = (long long)i * n_alerts;
+}
+
+
 }  // namespace rapid

@@ -308,6 +308,26 @@ class ClusterSimulation:
         self.e._check(self.e._lib.rapid_sim_load_streams_device(self.e._h, d_records_ptr, records_bytes, d_rec_off_ptr,
                                                                 n_receivers))
 
+    def generate(self, batches, receivers, seed, trust_copies=False):
+        """The round's deliveries made on the device (rapid_sim_generate): every receiver gets every batch of `batches`
+        (scenarios.BatchSet) once, in the order scenarios.deliver_hashed states on the host; `batches.recs` is the declared
+        alert set of the round."""
+        recs = np.ascontiguousarray(batches.recs, dtype=ALERT_DTYPE)
+        off = np.ascontiguousarray(batches.off, dtype=np.int64)
+        rx = np.ascontiguousarray(receivers, dtype=np.int32)
+        self.n_receivers = len(rx)
+        self.e._check(self.e._lib.rapid_sim_generate(self.e._h, _addr(recs) if len(recs) else None, _addr(off), len(off) - 1,
+                                                     _addr(rx) if len(rx) else None, len(rx), C.c_uint64(int(seed) & ((1 << 64) - 1))))
+        if trust_copies:
+            self.e._check(self.e._lib.rapid_sim_trust_alert_copies(self.e._h, 1))
+
+    def read_records(self, first, n):
+        """Testing aid: (subjects, core words) of n resident records."""
+        subj = np.zeros(max(n, 1), dtype=np.uint32)
+        words = np.zeros(max(n, 1), dtype=np.uint32)
+        self.e._check(self.e._lib.rapid_debug_read_records(self.e._h, C.c_int64(int(first)), int(n), _addr(subj), _addr(words)))
+        return subj[:n], words[:n]
+
     def set_alert_set(self, alerts, trust_copies=False):
         """Declares the round's distinct alerts (see rapid_sim_set_alert_set).  trust_copies: the caller vouches that every
         delivered record is a byte copy of one of them, configuration id included (rapid_sim_trust_alert_copies)."""
@@ -415,6 +435,7 @@ class ClusterSimulation:
         t = np.zeros(4, dtype=np.float32)
         self.e._check(self.e._lib.rapid_sim_pass_times(self.e._h, _addr(t)))
         out["resolve_ms"] = round(float(t[1]), 4)
+        out["generate_ms"] = round(float(t[2]), 4)
         return out
 
     def stream_probe(self, variant, waves, reps=10):

@@ -229,6 +229,42 @@ def deliver(batches, receivers, seed_delivery, loss=0.0, stale_cfg=None, stale_r
     return records, rec_off, nb
 
 
+def mix64(x):
+    """splitmix64 finaliser on uint64 arrays (== rapid::mix64 / gen_mix64 on the device)."""
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def hashed_order(seed, receiver, n_batches):
+    """The order in which rapid_sim_generate delivers the round's batches to `receiver` (its node index): ascending
+    key(r, b) = mix64(mix64(seed + r) + b), ties by b."""
+    with np.errstate(over="ignore"):
+        k0 = mix64(np.uint64(int(seed) & _M64) + np.uint64(int(receiver) & 0xFFFFFFFF))
+        keys = mix64(k0 + np.arange(n_batches, dtype=np.uint64))
+    return np.argsort(keys, kind="stable")
+
+
+def deliver_hashed(batches, receivers, seed):
+    """The host statement of rapid_sim_generate: every receiver gets every batch once, in hashed_order; the batch end is on
+    the last record of every batch.  Returns (records, rec_off[R+1], batches_per_receiver[R]) like deliver()."""
+    B = batches.n_batches
+    blen = np.diff(batches.off)
+    R = len(receivers)
+    A = int(batches.off[-1])
+    out = []
+    for r in receivers:
+        perm = hashed_order(seed, int(r), B)
+        lens = blen[perm]
+        starts = np.repeat(batches.off[perm] - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens)
+        out.append(batches.recs[starts + np.arange(A, dtype=np.int64)])
+    records = np.concatenate(out) if out else np.zeros(0, dtype=ALERT_DTYPE)
+    return records, np.arange(R + 1, dtype=np.int64) * A, np.full(R, B, dtype=np.int32)
+
+
 @dataclass
 class Scenario:
     name: str

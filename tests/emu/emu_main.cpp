@@ -325,6 +325,34 @@ extern "C" int emu_index_run(const unsigned char* alerts, long long n_alerts, in
     return 0;
 }
 
+// rapid_sim_generate's kernels (index_kernels.h): keys, (std::stable_sort for the device's segmented radix sort), streams laid
+// down in the resident layout.  core_out = [n][2] dwords, cfg_out = [n][2], dstv_out = [n]; entries may be null (subjects).
+extern "C" int emu_generate(const unsigned char* alerts, const long long* boff, int n_batches, const int* receivers, int n_receivers,
+                            unsigned long long seed, long long cfg_id, int n_nodes, const unsigned int* entries, unsigned int* core_out,
+                            unsigned int* cfg_out, unsigned int* dstv_out, long long* rec_off_out, unsigned int* flags_out, unsigned long long sd) {
+    const long long RB = (long long)n_receivers * n_batches, A = boff[n_batches];
+    std::vector<unsigned long long> keys((size_t)std::max<long long>(RB, 1));
+    std::vector<unsigned int> vals((size_t)std::max<long long>(RB, 1)), perm((size_t)std::max<long long>(RB, 1));
+    for (unsigned b = 0; b < 3u; ++b)
+        emu::run_block(b, 3u, 256u, [&] { rapid::gen_keys_kernel(receivers, n_receivers, n_batches, seed, keys.data(), vals.data()); }, sd + b);
+    for (int r = 0; r < n_receivers; ++r) {
+        std::vector<int> order(n_batches);
+        for (int i = 0; i < n_batches; ++i) order[i] = i;
+        const unsigned long long* k = keys.data() + (size_t)r * n_batches;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return k[a] < k[b]; });
+        for (int i = 0; i < n_batches; ++i) perm[(size_t)r * n_batches + i] = vals[(size_t)r * n_batches + order[i]];
+    }
+    flags_out[0] = flags_out[1] = 0u;
+    for (int r = 0; r < n_receivers; ++r)
+        emu::run_block((unsigned)r, (unsigned)n_receivers, 256u, [&] {
+            rapid::gen_streams_kernel(alerts, boff, n_batches, perm.data(), A, reinterpret_cast<uint2*>(core_out), reinterpret_cast<uint2*>(cfg_out), dstv_out,
+                                      cfg_id, (unsigned int)n_nodes, entries, flags_out);
+        }, sd + 100 + (unsigned)r);
+    const unsigned g = (unsigned)((n_receivers + 1 + 255) / 256);
+    for (unsigned b = 0; b < g; ++b) emu::run_block(b, g, 256u, [&] { rapid::gen_offsets_kernel(rec_off_out, n_receivers, A); }, sd + 900 + b);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The fast-round vote kernels (rapid_amd/csrc/vote_kernels.h): counting pass, verification (after a counting pass, or
 // with the candidate taken from the statistics the tally kernel gathers), and the merge of the ranks' answers.

@@ -291,3 +291,26 @@ def ids_merge(old, new, seed=1):
     rc = L_.emu_ids_merge(p(oh), p(ol), len(old), p(nh), p(nl), len(new), p(out_h), p(out_l), C.c_ulonglong(seed))
     assert rc == 0, rc
     return list(zip(out_h[:n].tolist(), out_l[:n].tolist()))
+
+
+def generate(batches, receivers, seed, cfg_id, n_nodes):
+    """rapid_sim_generate's kernels under the emulator -> (subjects, core words, configuration ids [n][2], rec_off, load flags)."""
+    L_ = lib()
+    recs = np.ascontiguousarray(batches.recs)
+    raw = np.concatenate([recs.view(np.uint8).reshape(-1), np.zeros(32, dtype=np.uint8)])
+    off = np.ascontiguousarray(batches.off, dtype=np.int64)
+    rx = np.ascontiguousarray(receivers, dtype=np.int32)
+    R, A = len(rx), int(off[-1])
+    n = R * A
+    core = np.zeros(2 * n + 2, dtype=np.uint32)
+    cfg = np.zeros(2 * n + 2, dtype=np.uint32)
+    dstv = np.zeros(n + 1, dtype=np.uint32)
+    rec_off = np.zeros(R + 1, dtype=np.int64)
+    flags = np.zeros(2, dtype=np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L_.emu_generate.restype = C.c_int
+    rc = L_.emu_generate(p(raw), p(off), len(off) - 1, p(rx), R, C.c_ulonglong(int(seed) & ((1 << 64) - 1)), C.c_longlong(cfg_id), n_nodes, None,
+                         p(core), p(cfg), p(dstv), p(rec_off), p(flags), C.c_ulonglong(3))
+    assert rc == 0, rc
+    core = core[: 2 * n].reshape(n, 2)
+    return dstv[:n], core[:, 1].copy(), core[:, 0].copy(), cfg[: 2 * n].reshape(n, 2), rec_off, flags

@@ -1111,6 +1111,57 @@ def test_streaming_rounds_with_stale_records_and_the_observer_cache(E):
     assert np.array_equal(m2, om2) and np.array_equal(s2, os2) and np.array_equal(o2, oo2)
 
 
+def test_streams_generated_on_the_device(E):
+    """rapid_sim_generate: the round's deliveries made on the device -- every receiver gets every batch once, in the
+    order of mix64(mix64(seed + receiver) + batch) -- directly in the resident layout, subjects already resolved.  Against the
+    host statement scenarios.deliver_hashed: the resident records themselves (subjects, core words) are equal; the tally over
+    the generated streams equals the tally over the same streams loaded through the boundary, and the oracle fed those
+    records; the round decides the same cut.  No load pass and no resolve pass run for generated streams."""
+    K, H, L = 10, 9, 4
+    for n, n_crash, n_join, seed in ((2000, 20, 0, 2), (1500, 30, 12, 977)):
+        pop = S.Population.make(n + 40)
+        eng, view = make_engine(E, pop, K, H, L, members=list(range(n)))
+        obs, subj, member = view.tables()
+        cfg = view.getCurrentConfigurationId()
+        sc = S.build_churn_scenario(obs, member, cfg, n_crash, n_join, H, L, materialise=False)
+        rx = sc.receivers
+        want, want_off, nb = S.deliver_hashed(sc.batches, rx, seed)
+        sim = E.ClusterSimulation(eng)
+        sim.generate(sc.batches, rx, seed)
+        info = sim.index_info()
+        assert info["dict_mode"] == 3 and info["alert_set_declared"] == 1 and info["resolve_ms"] == 0.0
+        A = int(sc.batches.off[-1])
+        for first in (0, A - 7, (len(rx) // 2) * A + 3, len(want) - 1000):
+            first = max(0, first)
+            m = min(1000, len(want) - first)
+            dst, words = sim.read_records(first, m)
+            seg = want[first:first + m]
+            assert np.array_equal(dst, seg["dst"])
+            assert np.array_equal(words, (seg["ring_mask"].astype(np.uint32) & 0x3FFF) | np.where(seg["status"] != 0, 1 << 14, 1 << 15).astype(np.uint32)
+                                  | ((seg["flags"].astype(np.uint32) & 1) << 16))
+        sim.tally()
+        got = sim.results()
+        rr = sim.count_votes()
+        cut = sim.decided_cut() if rr.decided else None
+        fe, fn, fo, fpp = O.fast_sim_run(pop.n, K, H, L, cfg, obs, subj, member, want, want_off, nthreads=16)
+        assert np.array_equal(got[0], fe) and np.array_equal(got[1], fn) and np.array_equal(got[2], np.diff(fo))
+        assert np.array_equal(got[3], proposal_fingerprints(fo, fpp, fe >= 0))
+        sim2, ref = run_population(E, eng, want, want_off, alert_set=sc.batches.recs)
+        assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+        rr2 = sim2.count_votes()
+        assert (rr.decided, rr.votes_winner, rr.cut_size) == (rr2.decided, rr2.votes_winner, rr2.cut_size) and rr.decided == 1
+        assert cut == sim2.decided_cut() and sorted(cut) == sc.faulty.tolist()
+        # the per-delivery filter and a cross-check mode on generated streams (generated again: the knob decides what the
+        # records' first dwords hold)
+        for knob in (64, 32768):
+            sim.set_force_exact(knob)
+            sim.generate(sc.batches, rx, seed)
+            sim.tally()
+            assert all(np.array_equal(a, b) for a, b in zip(ref, sim.results())), knob
+        sim.set_force_exact(0)
+        eng.close()
+
+
 def test_q4_stale_observer_cache_is_reported_through_the_c_abi(E):
     """rapid_view_q4_at_risk against the oracle's faithful cachedObservers (R/MembershipView.java:143-152, 181-195, 210-224).
     A subject that was hot once (its observers memoised) and stays in the view: (1) an unrelated removal changes nothing;

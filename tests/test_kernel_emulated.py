@@ -442,3 +442,38 @@ def test_identifiers_merged_on_the_device():
         rng.shuffle(ids)
         old, new = sorted(ids[:n_old]), sorted(ids[n_old:])
         assert pyemu.ids_merge(old, new) == sorted(ids)
+
+
+def test_streams_generated_on_the_device_equal_the_host_statement():
+    """rapid_sim_generate (gen_keys / gen_streams kernels, emulated; std::stable_sort for the device's segmented radix sort)
+    against scenarios.deliver_hashed: the same records in the same order for every receiver, in the resident layout -- subject,
+    core word (ring mask, DOWN / UP bits, end of batch on the last alert of every batch), configuration id, uniform
+    offsets; an alert of another configuration in the set is marked (and flagged), as the load pass marks it."""
+    n, K, H, L = 300, 10, 9, 4
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K, list(range(0, n - 20)))
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_churn_scenario(obs, member, cfg, 10, 8, H, L, materialise=False)
+    rx = sc.receivers[::17]
+    for seed, stale_at in ((2, None), (12345678901234567, 3)):
+        bs = sc.batches
+        if stale_at is not None:
+            recs = bs.recs.copy()
+            recs["cfg_id"][stale_at] = cfg + 1
+            bs = S.BatchSet(recs, bs.off, bs.sender)
+        want, want_off, nb = S.deliver_hashed(bs, rx, seed)
+        dst, words, first, cfgs, rec_off, flags = pyemu.generate(bs, rx, seed, cfg, n)
+        assert np.array_equal(rec_off, want_off) and len(dst) == len(want)
+        stale = want["cfg_id"] != cfg
+        assert np.array_equal(dst, want["dst"] | np.where(stale, np.uint32(1 << 31), np.uint32(0)))
+        assert np.array_equal(first, dst)  # (no entries given: the first dword is the subject)
+        w = (want["ring_mask"].astype(np.uint32) & 0x3FFF) | np.where(want["status"] != 0, 1 << 14, 1 << 15).astype(np.uint32) | \
+            ((want["flags"].astype(np.uint32) & 1) << 16)
+        assert np.array_equal(words, w)
+        assert np.array_equal(cfgs.view(np.int64).reshape(-1), want["cfg_id"])
+        assert int(flags[0]) == (1 if stale.any() else 0)
+        # every receiver got every batch once, and two receivers got them in different orders
+        A = int(bs.off[-1])
+        assert all(sorted(want["src"][r * A:(r + 1) * A].tolist()) == sorted(bs.recs["src"].tolist()) for r in range(len(rx)))
+        assert not np.array_equal(want["src"][:A], want["src"][A:2 * A])
