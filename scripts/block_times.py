@@ -1,4 +1,4 @@
-"""Profiling build only (scripts/phase_timers.sh builds it): when does every workgroup of ONE tally launch start and finish?
+"""Profiling build only (as scripts/phase_timers.sh builds it, plus -DRAPID_BLOCK_STAMPS): when does every workgroup of ONE tally launch start and finish?
     RAPID_MI355X_LIB=.../librapid_mi355x_timers.so python scripts/block_times.py [config]"""
 import ctypes as C
 import os
