@@ -221,6 +221,23 @@ JNIEXPORT void JNICALL Java_com_vrg_rapid_NativeCutEngine_simSetAlertSet(JNIEnv*
     CHECK(h, rapid_sim_set_alert_set(ENGINE(h), (const rapid_alert_record*)(*env)->GetDirectBufferAddress(env, alerts), n));
 }
 
+/* void simGenerate(long h, ByteBuffer alerts, long[] batchOff, int[] receivers, long seed): the round's deliveries made on the
+ * device (rapid_sim_generate); `alerts` = the round's distinct alerts, packed, in batch order (a direct buffer) */
+JNIEXPORT void JNICALL Java_com_vrg_rapid_NativeCutEngine_simGenerate(JNIEnv* env, jobject self, jlong h, jobject alerts, jlongArray batchOff,
+                                                                      jintArray receivers, jlong seed) {
+    (void)self;
+    const jsize nb = (*env)->GetArrayLength(env, batchOff), nr = (*env)->GetArrayLength(env, receivers);
+    jlong* off = (*env)->GetLongArrayElements(env, batchOff, NULL);
+    jint* rx = (*env)->GetIntArrayElements(env, receivers, NULL);
+    int rc = RAPID_EINVAL;
+    if (off != NULL && rx != NULL && nb >= 1)
+        rc = rapid_sim_generate(ENGINE(h), (const rapid_alert_record*)(*env)->GetDirectBufferAddress(env, alerts), (const int64_t*)off, (int32_t)(nb - 1),
+                                (const int32_t*)rx, (int32_t)nr, (uint64_t)seed);
+    if (rx != NULL) (*env)->ReleaseIntArrayElements(env, receivers, rx, JNI_ABORT);
+    if (off != NULL) (*env)->ReleaseLongArrayElements(env, batchOff, off, JNI_ABORT);
+    CHECK(h, rc);
+}
+
 /* -> {decided, cutSize, votesWinner, quorum, newConfigId} */
 JNIEXPORT jlongArray JNICALL Java_com_vrg_rapid_NativeCutEngine_simRound(JNIEnv* env, jobject self, jlong h, jboolean apply) {
     (void)self;
