@@ -261,7 +261,7 @@ def main():
     out = {
         "metric": "alert-batches/sec", "value": round(value, 1), "unit": "alert-batches/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak" if cfgname == "C4" else "strong", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+        "scaling": "weak" if cfgname == "C4" else "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": "%s: N=%d K=%d H=%d L=%d, %d ingress-loss nodes (5%% one-way failures, fault set closed "
                                "under >=L faulty observers), %d receivers, per-receiver seeded delivery order"
                                % (cfgname, n, K, H, L, len(sc.faulty), len(sc.receivers)) if cfgname == "C3b" else
