@@ -57,8 +57,9 @@ namespace rapid {
 
 constexpr int kWave = 64;
 constexpr int kRecBytes = 20;   // a rapid_alert_record as it crosses the boundary
-constexpr int kCoreBytes = 8;   // what stays resident per delivered record: {dst, ring mask | status << 16 | flags << 24} -- and, in a
-                                // second array, the 8 bytes of its configuration id (src is never read: R/MultiNodeCutDetector.java:101)
+constexpr int kCoreBytes = 8;   // what a tally launch reads per delivered record: {the subject's dictionary entry (or, in the cross-check
+                                // modes, its node index), core word} -- beside them, read by no launch: the subject again and the
+                                // configuration id (src is never read: R/MultiNodeCutDetector.java:101)
 #ifndef RAPID_QUARTERS
 #define RAPID_QUARTERS 4
 #endif
@@ -153,9 +154,10 @@ struct RoundIndex {
 };
 
 struct TallyParams {
-    // The delivered streams, resident SPLIT (engine.hip: split_records_kernel): core[i] = dwords 3, 4 of record i (all the
-    // tally ever looks at of a record that is a vouched-for copy of a declared alert), cfg[i] = its configuration id (read
-    // only by the per-delivery filter).  The bytes a launch pulls from HBM are 8 or 16 per delivered record, not 20.
+    // The delivered streams, resident (index_kernels.h: split_records_kernel, resolve_records_kernel, gen_streams_kernel):
+    // core[i] = {dict_entry of record i's subject (its node index | kCoreStale in the cross-check modes), core word}: 8 bytes,
+    // all a launch pulls from HBM per delivered record.  cfg[i] = its configuration id: not read by this kernel (the verdict
+    // of R/MembershipService.java:653-657 is marked in the record when it becomes resident).
     const unsigned char* core;         // [n_records][8]
     const unsigned char* cfg;          // [n_records][8]
     const long long* rec_off;          // [R+1], in records
@@ -461,13 +463,13 @@ __device__ inline void exact_batch_end(const D& d, RxScalars& s, const unsigned 
 }
 
 // --------------------------------------------------------------------------------------------------------------
-// Whole-population tally.  block = waves_per_block x 64; wave g of G takes receivers g, g + G, g + 2 G ...
-// kTablesInLds: the node -> slot dictionary is staged in LDS once per workgroup (the normal case); otherwise it is
-// read from global memory (populations whose dictionary does not fit next to the per-wave state).
-// kTrusted: the engine has verified once, on the round's distinct alert set, that EVERY alert passes the filter of
-// R/MembershipService.java:644-675 under the current view (configuration id, UP/DOWN vs membership, node range,
-// non-empty ring list) and that every delivered record is a copy of one of them; the kernel then neither loads nor
-// re-checks the configuration id per delivery.
+// Whole-population tally.  block = waves_per_block x 64; the workgroup's waves claim receivers from its deal (and the pool).
+// kDictMode: kDictResolved (the product) -- the records carry their subjects' dictionary entries; the other modes look the
+// subject up (tables in memory / direct in LDS / compressed in LDS) and exist as cross-checks.
+// kTrusted: the engine has verified that every declared alert passes the filter of R/MembershipService.java:644-675 under
+// the current view and that every delivered record carries the current configuration id and a known subject; a delivery
+// that still fails the membership filter or names a ring the index was not built for is then an ERROR of the stream (sticky
+// flag, RAPID_EINVAL) instead of being dropped per delivery.
 // --------------------------------------------------------------------------------------------------------------
 struct Window {  // the resident core entries of kQ x 64 records, lane l of quarter q = record 64 q + l
     unsigned int w3[kQ], w4[kQ];  // subject (| kCoreStale); core word
@@ -588,8 +590,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         const unsigned char* base;
         unsigned int bytes;
     };
-    // one window of the stream `st` starting at this lane's byte offset `voff`: kQ (2 kQ when the configuration id
-    // is needed) wave instructions, nothing waited for
+    // one window of the stream `st` starting at this lane's byte offset `voff`: kQ wave instructions, nothing waited for
     auto load_window = [&](const Stream& st, unsigned int voff, Win& W) {
         // declared wave-uniform right here (it is: every lane computes it from the wave's receiver index), so that the
         // descriptor is in SGPRs whatever the compiler concluded about the loops it travelled through
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     //   vouched-for copies of validated alerts (kTrusted): nothing is dropped; what a delivered record can still get wrong --
     //   subject out of range, UP / DOWN against the membership (R/MembershipService.java:659-668), rings the index was not
     //   built for -- is ONE AND with the entry, collected in `uncovered` (sticky error, results void);
-    //   otherwise: configuration id, range, empty ring list, UP / DOWN against the membership per delivery.
+    //   otherwise: stale or unknown subject (the poison entry), empty ring list, UP / DOWN against the membership per delivery.
     unsigned int uncovered = 0u;  // per lane: what delivered reports name that the index was not built for
     auto effective = [&](const Win& c, int q, const Look& k) -> unsigned int {
         const unsigned int w = c.w4[q];
