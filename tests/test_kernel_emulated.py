@@ -477,3 +477,34 @@ def test_streams_generated_on_the_device_equal_the_host_statement():
         A = int(bs.off[-1])
         assert all(sorted(want["src"][r * A:(r + 1) * A].tolist()) == sorted(bs.recs["src"].tolist()) for r in range(len(rx)))
         assert not np.array_equal(want["src"][:A], want["src"][A:2 * A])
+
+
+def test_generator_edge_cases_and_the_late_delivery_model():
+    """One batch / one receiver / single-alert batches through the emulated generator; and scenarios.deliver's late deliveries:
+    additional whole batches carrying the previous configuration id -- every batch of the round still arrives exactly once."""
+    n, K, H, L = 60, 10, 9, 4
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K)
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_churn_scenario(obs, member, cfg, 3, 0, H, L, materialise=False)
+    one = S.BatchSet(sc.batches.recs[: sc.batches.off[1]].copy(), sc.batches.off[:2].copy(), sc.batches.sender[:1].copy())
+    for bs, rx in ((one, sc.receivers[:1]), (one, sc.receivers[:5]), (sc.batches, sc.receivers[:1])):
+        want, want_off, nb = S.deliver_hashed(bs, rx, 7)
+        dst, words, first, cfgs, rec_off, flags = pyemu.generate(bs, rx, 7, cfg, n)
+        assert np.array_equal(dst, want["dst"]) and np.array_equal(rec_off, want_off) and int(flags[0]) == 0
+        assert np.array_equal((words >> 16) & 1, want["flags"] & 1)
+    # late deliveries
+    recs, off, nb = S.deliver(sc.batches, sc.receivers[:6], 2, stale_cfg=cfg - 1, stale_rate=0.25)
+    B = sc.batches.n_batches
+    n_late = max(1, int(round(0.25 * B)))
+    assert np.all(nb == B + n_late)
+    for r in range(6):
+        seg = recs[off[r]:off[r + 1]]
+        cur = seg[seg["cfg_id"] == cfg]
+        late = seg[seg["cfg_id"] != cfg]
+        assert len(late) > 0 and np.all(late["cfg_id"] == cfg - 1)
+        # the round's own alerts: every one exactly once, whatever was delivered late
+        key = lambda a: sorted(zip(a["src"].tolist(), a["dst"].tolist(), a["ring_mask"].tolist()))
+        assert key(cur) == key(sc.batches.recs)
+        assert int((seg["flags"] & 1).sum()) == B + n_late  # whole batches, each with its end
