@@ -1,21 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- alert-batches/sec of the cut-detection hot path on MI355X (BASELINE.json metric, N=10k K=10).
 
-One *step* = one ROUND of the hot path over the resident synthetic alert streams of the whole simulated
-population, everything a round costs once the streams are in HBM: the per-round index (which subjects can reach the L
-watermark, slot dictionary, hot adjacency, validation of the round's distinct alerts against the view), the alert-tally
-kernel over every receiver (MembershipService.handleMessage(BatchedAlertMessage) semantics), then the fast-round vote
-count over their proposals (every rank counts and verifies its own voters; one all-gather + merge across ranks; quorum
-test) with the decision read back to the host.  The view is NOT changed inside the timed loop so that every step does identical work;
-one extra untimed-in-`value` round that also applies the cut gives `time_to_stable_cut_ms`.  The streams are resident in
-the engine's own layout: 8 B per delivered record = {subject, ring mask + status + batch end}; the 20-byte boundary
-records pass through ONE load pass (rapid_sim_load_streams*: split, configuration id compared and the verdict marked in
-the record, R/MembershipService.java:653-657; `load_split_ms`) and ONE resolve pass (every record's subject -> its slot /
-coverage entry of the round's index, `resolve_ms`), each timed separately; `round_from_boundary_ms` = both passes + one
-step.  `roofline.achieved` / `frac` price the tally kernel against the bytes it READS (8 B per record
-consumed; `traffic` is the PMC-measured HBM traffic of the same launch and must agree); SURVEY 8(d)'s 20-B-per-record
-figure is kept as the labelled extra `roofline.boundary_accounting`.  `ms_per_step` is the mean the contract asks for;
-`ms_per_step_min` / `_median` over the same steps and the tally-only figure are reported next to it.
+One *step* = one FRESH ROUND of the hot path: a stream set the engine has not seen in the previous step -- the 20-byte alert
+records of every receiver's deliveries, exactly as they cross the C ABI, resident in HBM -- is attached in place
+(rapid_sim_attach_streams_device: no copy), the round's distinct alerts are declared (uploaded: 200 KB), and then everything a
+round costs runs: the per-round index (which subjects can reach the L watermark, slot dictionary, hot adjacency, validation of
+the declared alerts against the view), the alert-tally kernel over every receiver (MembershipService.handleMessage(
+BatchedAlertMessage) semantics) -- the ONLY pass that touches a delivered record: it compares the record's configuration id,
+looks its subject up (tables in LDS) and tallies it on the record's way through the registers -- and the fast-round vote count
+over the proposals (every rank counts and verifies its own voters; one all-gather + merge across ranks; quorum test) with the
+decision read back to the host.  Nothing about a stream set survives a step: the steps alternate between `--stream-sets`
+(default 2) resident sets with different delivery orders, 1.9 GB each at C3b -- far beyond the 256 MB of MALL, so every step
+reads its records from HBM.  The view is NOT changed inside the timed loop so that every step does identical work; one extra
+round that also applies the cut gives `time_to_stable_cut_ms` (attach + declare + index + tally + votes + apply cut + new
+configuration id).
+
+`roofline`: the tally kernel priced in SURVEY 8(d)'s unit -- 20 B per delivered record consumed, the record as it crosses the
+boundary -- over the kernel's own duration (HIP events on the engine's stream, back-to-back launches); `traffic` is the
+PMC-measured HBM traffic of the same launch and must agree.  `ms_per_step` is the mean the contract asks for;
+`ms_per_step_min` / `_median` over the same steps are reported next to it.
 
 Launch: `python bench.py --gpus 1` or, for N > 1,
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
@@ -50,6 +53,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE pass that measures roofline.traffic")
+    ap.add_argument("--stream-sets", type=int, default=2, help="resident stream sets (different delivery orders) the steps alternate between")
+    ap.add_argument("--no-extras", action="store_true", help="skip the measurements beside the line (generator, per-delivery filter, probe)")
     return ap.parse_args()
 
 
@@ -99,10 +104,22 @@ def main():
         raise SystemExit("%s is defined on %d shards; --gpus %d" % (cfgname, shards, world))
     lo, hi = P.shard_range(len(sc.receivers), rank, shards)
     my_rx = sc.receivers[lo:hi]
-    records, rec_off, nb = S.deliver(sc.batches, my_rx, seed_delivery=2)
+    # `--stream-sets` delivered stream sets of the SAME round (same alert set, per-receiver delivery orders from different seeds),
+    # resident in HBM as the 20-byte records of the boundary before anything is timed; set 0 (seed 2) is the workload of the
+    # earlier rounds' benches and of tests/test_gpu_parity.py::test_full_size_c3_against_fast_oracle
+    n_sets = max(1, args.stream_sets)
+    sets = []
+    for k in range(n_sets):
+        recs_k, off_k, nb_k = S.deliver(sc.batches, my_rx, seed_delivery=2 + k)
+        d_rec = torch.from_numpy(recs_k.view(np.uint8).reshape(-1)).cuda()
+        d_off = torch.from_numpy(np.ascontiguousarray(off_k, dtype=np.int64)).cuda()
+        sets.append((d_rec, d_off, len(off_k) - 1))
+        if k == 0:
+            records, rec_off, nb = recs_k, off_k, nb_k
+        del recs_k
+    torch.cuda.synchronize()
+    alert_set = np.ascontiguousarray(sc.batches.recs)
     sim = E.ClusterSimulation(eng)
-    sim.load_streams(records, rec_off)  # streams are resident in HBM before anything is timed
-    sim.set_alert_set(sc.batches.recs, trust_copies=True)   # the round's distinct alerts (the receivers' streams are copies of these)
     setup_s = time.time() - t0
     my_batches = int(nb.sum())
     my_records = int(len(records))
@@ -113,30 +130,28 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
-    def step():
-        sim.new_round()  # the per-round index is rebuilt: a round's streams are new every time
+    def fresh_round(i):
+        """A round's deliveries and its distinct alerts arrive: attached where they lie, declared (a new round: index rebuilt)."""
+        d_rec, d_off, n_rx = sets[i % n_sets]
+        sim.attach_streams_device(d_rec.data_ptr(), d_rec.numel(), d_off.data_ptr(), n_rx, keepalive=sets)
+        sim.set_alert_set(alert_set, trust_copies=True)
+
+    def step(i):
+        fresh_round(i)
         sim.tally()
         return sim.count_votes()  # blocks until the decision is on the host
 
-    for _ in range(args.warmup):
-        rr = step()
+    for i in range(args.warmup):
+        rr = step(i)
     barrier()
     per_step = []
     t1 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         ts = time.perf_counter()
-        rr = step()
+        rr = step(args.warmup + i)
         per_step.append(time.perf_counter() - ts)
     barrier()
     elapsed = time.perf_counter() - t1
-    # the same loop without the index build (what round 1 reported as its step)
-    barrier()
-    t1b = time.perf_counter()
-    for _ in range(args.steps):
-        sim.tally()
-        rr = sim.count_votes()
-    barrier()
-    elapsed_noindex = time.perf_counter() - t1b
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -149,107 +164,96 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = tot_batches * args.steps / elapsed
 
-    # ---- dominant kernel: the alert tally.  HIP events on the engine's own stream, back-to-back launches ----
-    st = sim.stats()
+    # ---- dominant kernel: the alert tally.  HIP events on the engine's own stream, back-to-back launches over stream set 0 ----
+    fresh_round(0)
     kern_ms = sim.time_tally(args.kernel_reps)
-    consumed = sim.stats()["records_consumed"] // (args.kernel_reps + 1)
-    # the same kernel with the per-delivery filter forced on (the instantiation that runs when the round's alerts do not
-    # all validate against the view, or deliveries are not vouched for): same 8 B per record -- the configuration-id verdict
-    # is marked in the resident record by the load pass
-    sim.set_force_exact(64)
-    kern_filter_ms = sim.time_tally(args.kernel_reps)
-    sim.set_force_exact(0)
-    # what the memory system delivers for the SAME access pattern with no processing (measurement probe)
-    probe_ms = sim.stream_probe(0, 16, 5)
+    st = sim.stats()
+    consumed = st["records_consumed"] // (args.kernel_reps + 1)
+    index = sim.index_info()
+    kern_filter_ms, probe_ms = None, None
+    if not args.no_extras:
+        # the same kernel with the per-delivery filter forced on (the instantiation that runs when the round's alerts do not
+        # all validate against the view, or deliveries are not vouched for)
+        sim.set_force_exact(64)
+        kern_filter_ms = sim.time_tally(args.kernel_reps)
+        sim.set_force_exact(0)
+        # what the memory system delivers for the SAME records with no processing (measurement probe)
+        probe_ms = sim.stream_probe(0, 16, 5)
     traffic, traffic_source = (None, "not measured at %d ranks" % world)
     if world == 1 and rank == 0 and not args.no_pmc:
         traffic, traffic_source = measure_traffic(cfgname)
-    if traffic is None and world == 1:
-        committed = traffic_from_profiles(cfgname, world)
-        if committed is not None:
-            traffic, traffic_source = committed, "profiles/tally_traffic_%s.json (committed PMC pass; live pass: %s)" % (cfgname, traffic_source)
-    # Accounting.  The kernel is priced against the bytes it reads: 8 B per record consumed (resident layout), cross-checked by
-    # the PMC traffic of the same launch.  SURVEY 8(d)'s unit -- 20 B per delivered record, the record as it crosses the
-    # boundary -- is reported beside it and labelled: it counts 12 bytes per record that no tally launch touches.
-    res_b = 8.0
-    achieved = res_b * consumed / (kern_ms * 1e-3) / 1e9
+    # Accounting: SURVEY 8(d)'s unit -- 20 B per delivered record, the record as it crosses the boundary; every one of those
+    # bytes is in a cache line the kernel pulls from HBM (src, 4 of the 20, is never loaded into a register), cross-checked by
+    # the PMC traffic of the same launch.
+    rec_b = 20.0
+    achieved = rec_b * consumed / (kern_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "tally_population_kernel", "kernel_ms": round(kern_ms, 4),
-                "bytes_per_launch": int(res_b * consumed), "bytes_per_record": 8, "records_consumed_per_launch": int(consumed),
+                "kernel": "tally_population_kernel<%s, %s, kFmtBoundary>" % ({0: "kDictMemory", 1: "kDictDirect", 2: "kDictCompressed"}.get(index["dict_mode"], "?"),
+                                                                               "trusted" if index["alerts_prevalidated"] else "filter"),
+                "kernel_ms": round(kern_ms, 4),
+                "bytes_per_launch": int(rec_b * consumed), "bytes_per_record": 20, "records_consumed_per_launch": int(consumed),
                 "records_delivered_per_launch": my_records,
-                "traffic_over_bytes": round(traffic / (res_b * consumed), 3) if traffic else None,
-                "kernel_ms_filter_per_delivery": round(kern_filter_ms, 4),
-                "frac_filter_per_delivery": round(res_b * consumed / (kern_filter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "stream_probe_gbs": round(res_b * my_records / (probe_ms * 1e-3) / 1e9, 1),
-                "boundary_accounting": {"bytes_per_record": 20, "bytes_per_launch": int(20 * consumed),
-                                        "achieved": round(20.0 * consumed / (kern_ms * 1e-3) / 1e9, 1),
-                                        "frac": round(20.0 * consumed / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                        "note": "SURVEY 8(d)'s unit (the 20-byte record as it crosses the boundary); NOT a roofline "
-                                                "fraction of this kernel -- 12 of the 20 bytes are dropped by the load pass"}}
-    index = sim.index_info()
-
-    # ---- the load pass: 20-byte boundary records (already in device memory) -> resident layout.  Every NEW round of alerts
-    # pays it once; it is outside `step` because a step replays resident streams.
-    load_ms, resolve_ms = None, None
-    try:
-        d_rec = torch.from_numpy(records.view(np.uint8).reshape(-1)).cuda()
-        d_off = torch.from_numpy(np.ascontiguousarray(rec_off, dtype=np.int64)).cuda()
-        torch.cuda.synchronize()
-        sim2 = E.ClusterSimulation(eng)
-        ts_ = []
-        for _ in range(3):
-            t_ = time.perf_counter()
-            sim2.load_streams_device(d_rec.data_ptr(), d_rec.numel(), d_off.data_ptr(), len(rec_off) - 1, keepalive=(d_rec, d_off))
-            eng.sync()
-            ts_.append(1e3 * (time.perf_counter() - t_))
-        load_ms = min(ts_)
-        # ... and the pass that maps every record's subject to its dictionary entry of the round's index (once per stream set
-        # and alert set; the tally itself looks nothing up)
-        sim2.set_alert_set(sc.batches.recs, trust_copies=True)
-        sim2.index_info()
-        eng.sync()
-        resolve_ms = sim2.index_info()["resolve_ms"]
-        del sim2, d_rec, d_off
-    except Exception as e:  # (a measurement beside the line, not the line)
-        load_ms = None
-        sys.stderr.write("load pass not timed: %s\n" % str(e)[:200])
+                "traffic_over_bytes": round(traffic / (rec_b * consumed), 3) if traffic else None,
+                "kernel_ms_filter_per_delivery": round(kern_filter_ms, 4) if kern_filter_ms else None,
+                "frac_filter_per_delivery": round(rec_b * consumed / (kern_filter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern_filter_ms else None,
+                "stream_probe_gbs": round(rec_b * my_records / (probe_ms * 1e-3) / 1e9, 1) if probe_ms else None,
+                "passes_over_a_delivered_record": 1}
 
     # ---- the same round's deliveries GENERATED on the device (rapid_sim_generate): every receiver gets every batch in a seeded
-    # order of its own, written directly as resolved resident records -- no boundary records, no load pass, no resolve pass.
-    # (The delivery order is the generator's own hash order, not the numpy permutation of the loaded streams: same
-    # distribution, other streams; the round must decide the same cut.)
+    # permutation of its own, written directly as resolved 8-byte records (the 20-byte records never exist; the tally reads 8 B
+    # per record and looks nothing up) or as the 20-byte boundary records.  (The delivery order is the generator's own, not the
+    # numpy permutation of the loaded streams: same distribution, other streams; the round must decide the same cut.)
     gen = None
-    try:
-        sim3 = E.ClusterSimulation(eng)
-        ts_ = []
-        for _ in range(3):
-            t_ = time.perf_counter()
-            sim3.generate(sc.batches, my_rx, seed=2, trust_copies=True)
-            eng.sync()
-            ts_.append(1e3 * (time.perf_counter() - t_))
-        sim3.new_round()
-        sim3.tally()
-        rr_g = sim3.count_votes()
-        gi = sim3.index_info()
-        gen = {"generate_ms": round(min(ts_), 4), "generate_device_ms": gi["generate_ms"], "records": my_records,
-               "records_per_s": round(my_records / (min(ts_) * 1e-3), 1),
-               "round_from_generator_ms": round(min(ts_) + ms_per_step, 4),
-               "decided": int(rr_g.decided), "cut_size": int(rr_g.cut_size), "votes_winner": int(rr_g.votes_winner),
-               "note": "generate_ms = host wall time of rapid_sim_generate (upload of the round's distinct alerts, index, keys, segmented sort, "
-                       "streams); generate_device_ms = keys + sort + streams on the device"}
-        del sim3
-    except Exception as e:  # (a measurement beside the line, not the line)
-        sys.stderr.write("generator not timed: %s\n" % str(e)[:200])
+    if not args.no_extras:
+        try:
+            sim3 = E.ClusterSimulation(eng)
+            out_g = {}
+            for form, boundary in (("resolved", False), ("boundary", True)):
+                ts_, dev_ = [], []
+                for k in range(3):
+                    t_ = time.perf_counter()
+                    sim3.generate(sc.batches, my_rx, seed=2 + k, trust_copies=True, boundary=boundary)
+                    eng.sync()
+                    ts_.append(1e3 * (time.perf_counter() - t_))
+                    dev_.append(sim3.index_info()["generate_ms"])
+                t_ = time.perf_counter()
+                sim3.tally()
+                rr_g = sim3.count_votes()
+                round_ms = 1e3 * (time.perf_counter() - t_)
+                kms = sim3.time_tally(5)
+                out_g[form] = {"generate_ms": round(min(ts_), 4), "generate_device_ms": round(min(dev_), 4),
+                               "records_per_s": round(my_records / (min(dev_) * 1e-3), 1),
+                               "bytes_written": int(my_records * (20 if boundary else 8)),
+                               "tally_kernel_ms": round(kms, 4), "round_after_generation_ms": round(round_ms, 4),
+                               "decided": int(rr_g.decided), "cut_size": int(rr_g.cut_size), "votes_winner": int(rr_g.votes_winner)}
+            gen = dict(out_g, records=my_records,
+                       note="generate_ms = host wall time of rapid_sim_generate (upload of the round's distinct alerts, index, lay-down); "
+                            "generate_device_ms = the lay-down kernels on the device; resolved: 8-byte records, tally<kDictResolved>; "
+                            "boundary: the 20-byte records a load would have been handed")
+            del sim3
+        except Exception as e:  # (a measurement beside the line, not the line)
+            sys.stderr.write("generator not timed: %s\n" % str(e)[:200])
 
-    # ---- one full round including decideViewChange: time-to-stable-cut = streams resident -> decided cut + new
-    # configuration id on the host: per-round index build + tally + vote count + apply cut (rings, tables, config id)
-    sim.load_streams(records, rec_off)
-    sim.set_alert_set(sc.batches.recs, trust_copies=True)
-    sim.index_info()  # "streams resident" includes the resolve pass of the records (reported as resolve_ms) ...
-    sim.new_round()   # ... but not the round's index: the round below builds it again
+    # ---- the PCIe-inclusive way in (never `value`): host records -> rapid_sim_load_streams (copy into the engine's buffer)
+    load_host_ms = None
+    if not args.no_extras and world == 1:
+        try:
+            sim4 = E.ClusterSimulation(eng)
+            t_ = time.perf_counter()
+            sim4.load_streams(records, rec_off)
+            eng.sync()
+            load_host_ms = 1e3 * (time.perf_counter() - t_)
+            del sim4
+        except Exception as e:
+            sys.stderr.write("host load not timed: %s\n" % str(e)[:200])
+
+    # ---- one full round including decideViewChange: time-to-stable-cut = a round's deliveries resident in HBM -> decided cut +
+    # new configuration id on the host: attach + declare + per-round index + tally + vote count + apply cut (rings, tables,
+    # configuration id)
     barrier()
     t2 = time.perf_counter()
+    fresh_round(1)
     rr_full, new_cfg = sim.round(apply=True)
     eng.sync()
     ttsc_ms = 1e3 * (time.perf_counter() - t2)
@@ -268,20 +272,19 @@ def main():
                    "%s: N=%d K=%d H=%d L=%d faults=%d receivers=%d%s" % (cfgname, n, K, H, L, len(sc.faulty), len(sc.receivers),
                                                                             " (shards %d..%d of 8 simulated)" % (0, world - 1) if cfgname == "C4" else ""),
                    "parallelism": "receivers sharded over %d GPU(s); per round ONE all-gather (RCCL) of the ranks' local vote counts, merged on every rank" % world,
-                   "alert_set": "the round's distinct alerts are declared and validated once against the view; the load pass found the "
-                                "current configuration id on every delivered record, so the deliveries are vouched for as copies "
-                                "(rapid_sim_trust_alert_copies, honoured on verified facts only); roofline.kernel_ms_filter_per_delivery "
+                   "step": "a FRESH round per step: one of %d resident stream sets (20-byte boundary records, %d MB each) attached in place, "
+                           "alert set declared, index + tally (the one pass over the records) + vote count; nothing is kept "
+                           "between steps" % (n_sets, int(my_records * 20 / 1e6)),
+                   "alert_set": "the round's distinct alerts are declared and validated once per round against the view and the "
+                                "deliveries are vouched for as copies (rapid_sim_trust_alert_copies); the configuration id of "
+                                "every delivered record is still compared by the kernel; roofline.kernel_ms_filter_per_delivery "
                                 "is the same kernel filtering every delivery",
                    "baseline_config": "BASELINE.json configs[3] (100,000 nodes, K=10, 1% crashes, 8 GPUs)" if cfgname == "C4" else
                                       "BASELINE.json configs[2] (10,000 nodes, K=10, 5% asymmetric one-way edge failures)"},
         "ms_per_step_min": round(1e3 * min(per_step), 4), "ms_per_step_median": round(1e3 * float(np.median(per_step)), 4),
-        "ms_per_step_without_index": round(1e3 * elapsed_noindex / args.steps, 4),
-        "value_without_index": round(tot_batches * args.steps / elapsed_noindex, 1),
         "n_ranks_seen": eng.comm_info()[1],
-        "load_split_ms": round(load_ms, 4) if load_ms is not None else None,
-        "resolve_ms": resolve_ms,
         "generated_streams": gen,
-        "round_from_boundary_ms": round(load_ms + (resolve_ms or 0.0) + ms_per_step, 4) if load_ms is not None else None,
+        "load_from_host_ms": round(load_host_ms, 3) if load_host_ms is not None else None,
         "alert_records_per_s": round(tot_records * args.steps / elapsed, 1),
         "time_to_stable_cut_ms": round(ttsc_ms, 3) if rr_full.decided else None,
         "decided": int(rr_full.decided), "cut_size": int(rr_full.cut_size), "votes_winner": int(rr_full.votes_winner),
@@ -343,18 +346,6 @@ def measure_traffic(cfgname):
                 "rocprofv3 --pmc FETCH_SIZE in this run, calibrated x%.3f on the stream probe (known byte count)" % factor
     except Exception as e:  # a measurement aid must not take the bench line down
         return None, "PMC pass failed: %s" % str(e)[:120]
-
-
-def traffic_from_profiles(cfgname, world):
-    """HBM bytes per tally launch from the committed rocprofv3 PMC pass (profiles/*_traffic.json, written by
-    scripts/pmc_traffic.py with the FETCH_SIZE correction of MI355X_MICROARCH.md); null if none was recorded."""
-    path = os.path.join(ROOT, "profiles", "tally_traffic_%s.json" % cfgname)
-    if world != 1 or not os.path.exists(path):
-        return None
-    try:
-        return json.load(open(path)).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
 
 
 def cpu_baseline(pop, K, H, L, cfg_id, obs, subj, member, records, rec_off, nb, budget_s):

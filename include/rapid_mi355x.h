@@ -151,38 +151,48 @@ int rapid_cd_clear(rapid_cd* cd);                                               
 
 /* ---- whole population: MembershipService.handleMessage(BatchedAlertMessage) at every receiver ---------
  * (R/MembershipService.java:300-354 with the filter of :644-675).  records = the receivers' delivered
- * streams back to back, rec_off[r]..rec_off[r+1] (in records) = receiver r; every receiver starts the round
+ * streams back to back, rec_off[r]..rec_off[r+1] (in records, rec_off[0] = 0) = receiver r; every receiver starts the round
  * with an empty detector and announcedProposal == false in the engine's current configuration.
- * The records are borrowed for the call and pass through ONE load pass into the engine's own layout: 8 bytes per record
- * that a tally launch reads -- {subject, core word = ring mask + edge status + end-of-batch} -- plus, beside them and read by
- * no tally launch, the subject again (4 B) and the configuration id (8 B).  The load pass compares every record's
- * configuration id with the view's current one and MARKS the verdict in the resident record (R/MembershipService.java:
- * 653-657 drops an alert of another configuration); if the view changes while the streams stay loaded the marks are
- * brought up to date from the retained ids before the next tally.  src is never read, as in R/MultiNodeCutDetector.java:101.
- * Before the first tally over a (stream set, alert set, view) the engine resolves every record's subject to its entry of
- * the round's index (slot, rings and status the index covers) in one more streaming pass -- every delivered alert is
- * mapped from node to slot exactly once, and the tally itself looks nothing up (rapid_sim_pass_times reports both passes). */
+ * The records stay what they are: 20-byte rapid_alert_records in device memory, read ONCE per round -- by the alert-tally
+ * kernel itself, which compares every record's configuration id with the view's current one (another id: dropped, :653-657),
+ * maps its subject to a slot of the round's index (tables in LDS; through L2 for populations whose tables do not fit) and
+ * tallies it, all on the record's way through the registers.  No other pass touches a delivered record, nothing about a
+ * stream is kept between rounds, and a view change needs no second look at the loaded streams.  src is never read, as in
+ * R/MultiNodeCutDetector.java:101.  A stream holds at most (2^32 - 2^20) / 20 records (RAPID_ECAPACITY).
+ * rapid_sim_load_streams: host records, copied into the engine's own device buffer (the PCIe transfer). */
 int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, const int64_t* rec_off,
                            int32_t n_receivers);
-/* same, records already on this device (`records_bytes` readable bytes covering them; borrowed for the call, split into
- * the engine's arrays like the host form); d_rec_off is a device pointer to n_receivers+1 int64 and IS borrowed until
- * the next load */
+/* same, records already on this device (`records_bytes` readable bytes covering them; borrowed for the call: copied device to
+ * device into the engine's buffer); d_rec_off is a device pointer to n_receivers+1 int64 and IS borrowed until the next load */
 int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64_t records_bytes,
                                   const int64_t* d_rec_off, int32_t n_receivers);
+/* same without any copy: the engine reads the caller's device buffers IN PLACE (both borrowed until the next load / attach /
+ * generate or the engine's destruction; 4-byte aligned; never written).  What a host that receives a round's deliveries into
+ * device memory calls once per round: attaching costs nothing, the round is index + tally + vote count. */
+int rapid_sim_attach_streams_device(rapid_engine* h, const void* d_records, uint64_t records_bytes,
+                                    const int64_t* d_rec_off, int32_t n_receivers);
 /* The delivered streams made ON THE DEVICE instead of loaded (rapid_sim_generate): alerts = the round's distinct
- * alerts in batch order, batch b = alerts[batch_off[b] .. batch_off[b + 1]) = one BatchedAlertMessage; every receiver gets
- * every batch exactly once (the fan-out of R/UnicastToAllBroadcaster.java:46-63), receiver r in the order of
- * key(r, b) = mix64(mix64(seed + receivers[r]) + b) ascending (mix64 = the splitmix64 finaliser; rapid_amd/scenarios.py:
- * deliver_hashed is the same statement on the host).  The records are written directly in the resident layout with their
- * subjects already resolved against the round's index -- the 20-byte records of the deliveries never exist, there is no load
- * pass and no resolve pass -- and `alerts` IS the declared alert set of the round (rapid_sim_set_alert_set is implied).
- * receivers[r] = node index of receiver r (only its value enters the order).  Late deliveries of an earlier configuration
- * are not generated (alerts whose own configuration id differs are marked and dropped like loaded ones).
+ * alerts in batch order, batch b = alerts[batch_off[b] .. batch_off[b + 1]) = one BatchedAlertMessage (never empty:
+ * RAPID_EINVAL); every receiver gets every batch exactly once (the fan-out of R/UnicastToAllBroadcaster.java:46-63), receiver
+ * r in an order of its own: position j holds batch perm(j), a seeded permutation of [0, n_batches) evaluated in place (a
+ * four-round Feistel network keyed by mix64(seed + receivers[r]), cycle-walked into range; csrc/index_kernels.h: gen_perm_at;
+ * rapid_amd/scenarios.py: hashed_order / deliver_hashed are the same statement on the host).  No keys, no sort, no bound on
+ * receivers x batches.  `alerts` IS the declared alert set of the round (rapid_sim_set_alert_set is implied and refused).
+ * batch_keep (optional, [n_batches]): batch b reaches receiver r only if a per-(r, b) 32-bit draw is <= batch_keep[b]
+ * (0xFFFFFFFF: every receiver) -- late deliveries of an earlier configuration (alerts of the set that carry another
+ * configuration id; dropped per delivery, R/MembershipService.java:653-657) and lossy links; the places of a batch that does
+ * not reach a receiver hold empty records (no ring number, no batch end), so every stream has batch_off[n_batches] records.
+ * format RAPID_GEN_RESOLVED: 8-byte records {the subject's entry of the round index, ring mask + status + batch end} -- the
+ * 20-byte records of the deliveries never exist, the tally looks nothing up; valid for the view they were generated in
+ * (after a view change: RAPID_ESTATE, generate again).  RAPID_GEN_BOUNDARY: the 20-byte records themselves, exactly what a
+ * load would have been handed (the synthetic input of a round, made where it is consumed).
  * rapid_sim_pass_times out[2] = the device time of the last generation. */
+#define RAPID_GEN_RESOLVED 0
+#define RAPID_GEN_BOUNDARY 1
 int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const int64_t* batch_off, int32_t n_batches,
-                       const int32_t* receivers, int32_t n_receivers, uint64_t seed);
-/* testing aid: subject (| 0x80000000 if the record carries another configuration id) and core word (ring mask, bit 14 DOWN,
- * bit 15 UP, bit 16 end of batch) of n resident records starting at `first` */
+                       const uint32_t* batch_keep, const int32_t* receivers, int32_t n_receivers, uint64_t seed, int32_t format);
+/* testing aid: n delivered records starting at `first` -- boundary records: subject and core word (ring mask, bit 14 DOWN,
+ * bit 15 UP, bit 16 end of batch); resolved records: the subject's dictionary entry and the core word */
 int rapid_debug_read_records(rapid_engine* h, int64_t first, int32_t n, uint32_t* subjects, uint32_t* core_words);
 /* Optional, after a load: declares the round's DISTINCT alerts (every delivered record is a byte-identical copy of
  * one of them, flags aside -- one AlertMessage is broadcast to all receivers, R/UnicastToAllBroadcaster.java:46-52).

@@ -110,18 +110,18 @@ struct rapid_engine {
     std::vector<long long> h_keys;
 
     // ---- simulated population ----
-    // delivered streams, resident split: d_core[i] = {dst, mask | status | flags}, d_cfg[i] = configuration id of record i;
-    // d_stage = bounded staging area for the 20-byte records on their way in
-    DevBuf<unsigned char> d_core, d_cfg, d_stage;
-    DevBuf<unsigned int> d_dstv;  // the subject of record i (| kCoreStale), kept beside d_core: the record's first dword holds the
-                                  // subject's resolved dictionary entry while core_state == kCoreEntries
-    enum { kCoreSubjects = 0, kCoreEntries = 1, kCoreUnknown = 2 };
-    int core_state = kCoreUnknown;
-    unsigned long long content_serial = 1, core_serial = 0;  // what the round index is built from (alert set, streams, view) / what d_core was resolved against
-    hipEvent_t ev_res0 = nullptr, ev_res1 = nullptr;
-    bool resolve_ms_pending = false;
-    float resolve_ms = 0.f;
-    unsigned long long records_bytes = 0;  // readable bytes at d_core.p (probes)
+    // The delivered streams = the records the tally reads, receiver after receiver (d_rec_off).  rec_fmt == kFmtBoundary: the
+    // 20-byte rapid_alert_records themselves, exactly as they crossed the boundary -- copied into d_records_own by
+    // rapid_sim_load_streams / _device, or borrowed in place (rapid_sim_attach_streams_device) -- read from HBM ONCE per round, by
+    // the tally kernel.  rec_fmt == kFmtResident: the 8-byte resolved records rapid_sim_generate writes into d_records_own.
+    DevBuf<unsigned char> d_records_own;
+    const unsigned char* d_records = nullptr;
+    int rec_fmt = rapid::kFmtBoundary;
+    unsigned long long records_bytes = 0;  // readable bytes at d_records
+    // generated streams carry entries of the round index of the view they were generated in (gen_cfg_id); gen_clean: every
+    // alert of the set carried that view's configuration id and named a registered node
+    long long gen_cfg_id = 0;
+    bool gen_clean = false;
     DevBuf<long long> d_rec_off_own;
     const long long* d_rec_off = nullptr;
     int n_receivers = 0;
@@ -135,13 +135,13 @@ struct rapid_engine {
     bool index_valid = false;
     long long n_records_total = 0;
     DevBuf<unsigned char> d_alert_set;  // the round's distinct alerts, if the host declared them
+    unsigned char* h_alert_stage = nullptr;  // pinned staging of rapid_sim_set_alert_set
+    size_t alert_stage_bytes = 0;
+    hipEvent_t ev_alert = nullptr;
+    bool alert_copy_pending = false;
     long long n_alert_set = -1;
     bool trusted = false, all_down = false;
-    bool trust_copies = false;  // the caller's request to skip the per-delivery configuration-id check (honoured only if verified at load)
-    // what split_records_kernel saw when the loaded streams passed through it: the configuration they were compared with and
-    // whether EVERY delivered record carried it (R/MembershipService.java:653-657 drops the others)
-    long long load_cfg_id = 0;
-    bool load_all_current = false, load_in_range = false;
+    bool trust_copies = false;  // the caller vouches that the deliveries are copies of the declared alerts (rapid_sim_trust_alert_copies)
     DevBuf<unsigned int> d_loadflags;
     DevBuf<unsigned int> d_adj;
     hipEvent_t ev_idx0 = nullptr, ev_idx1 = nullptr;  // around the round-index kernels; read lazily (rapid_sim_index_info)
@@ -154,10 +154,10 @@ struct rapid_engine {
     DevBuf<unsigned short> d_dict, d_decl, d_adj_off, d_trank;
     DevBuf<unsigned int> d_tbits, d_tent;  // compressed dictionary (index_build_block_kernel)
     DevBuf<unsigned int> d_entries;        // dict_entry per node for rounds whose tables stay in memory
-    DevBuf<unsigned long long> d_gen_keys, d_gen_skeys;  // rapid_sim_generate: delivery-order keys [receivers][batches], sorted
-    DevBuf<unsigned int> d_gen_vals, d_gen_perm;         // ... and the batch indices they carry
+    DevBuf<uint2> d_gen_res;          // rapid_sim_generate: the alert set resolved once ({entry, core word} per alert)
+    DevBuf<unsigned int> d_gen_keep;  // ... per-batch delivery thresholds
     DevBuf<long long> d_gen_boff;
-    DevBuf<int> d_gen_rx, d_gen_seg;
+    DevBuf<int> d_gen_rx;
     float generate_ms = 0.f;
     int n_touched = 0;
     int dict_mode = 3;  // rapid::kDictResolved (the product) / kDictDirect / kDictCompressed / kDictMemory (testing knobs)
@@ -442,7 +442,6 @@ int rebuild_view(rapid_engine* h) {
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
     lap("configuration id");
-    h->content_serial++;
     h->config_id = cfg;
     h->ring_member = h->member;
     h->ring_m = M;
@@ -562,11 +561,10 @@ int build_round_index(rapid_engine* h) {
     h->idxwork_clean_at = nullptr;  // dirty from here until the build kernel has answered
     const long long n_scan = h->n_alert_set >= 0 ? h->n_alert_set : h->n_records_total;
     const dim3 touch_grid((unsigned)std::min<long long>(h->num_cus * 8, (n_scan + 255) / 256));
-    if (n_scan > 0 && h->n_alert_set >= 0)
-        hipLaunchKernelGGL(rapid::index_touch_kernel<false>, touch_grid, dim3(256), 0, st, h->d_alert_set.p, nullptr, n_scan, N,
-                           (1u << K) - 1u, (long long)h->config_id, h->d_member.p, d_gmask, reinterpret_cast<unsigned int*>(d_info + 4));
-    else if (n_scan > 0)
-        hipLaunchKernelGGL(rapid::index_touch_kernel<true>, touch_grid, dim3(256), 0, st, h->d_core.p, h->d_dstv.p, n_scan, N,
+    // (nothing declared: the delivered boundary records themselves are the alert set -- one more pass over them, which a
+    // caller that knows the round's distinct alerts avoids with rapid_sim_set_alert_set; generated streams always declare)
+    if (n_scan > 0)
+        hipLaunchKernelGGL(rapid::index_touch_kernel, touch_grid, dim3(256), 0, st, h->n_alert_set >= 0 ? h->d_alert_set.p : h->d_records, n_scan, N,
                            (1u << K) - 1u, (long long)h->config_id, h->d_member.p, d_gmask, reinterpret_cast<unsigned int*>(d_info + 4));
     const int adj_cap = 65536;
     HIPCHK(h, h->d_adj.ensure((size_t)adj_cap + 1));
@@ -621,8 +619,8 @@ int build_round_index(rapid_engine* h) {
     // tally looks nothing up (kDictResolved).  The modes in which the tally itself maps node -> slot remain as cross-checks
     // behind the testing knob: bit 15 = look up in the tally, from the tables placed as described above.
     const bool no_direct = (h->force_exact & (128 | 256)) != 0 || info[7] == 0, no_lds = (h->force_exact & 256) != 0;  // info[7]: the build kernel's own verdict
-    if ((h->force_exact & (128 | 256 | 32768)) == 0)
-        h->dict_mode = rapid::kDictResolved;
+    if (h->rec_fmt == rapid::kFmtResident)
+        h->dict_mode = rapid::kDictResolved;  // generated records carry their subjects' entries
     else if (!no_direct && sh_direct + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
         h->dict_mode = rapid::kDictDirect;
     else if (!no_lds && compressed_ok && sh_comp + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
@@ -673,22 +671,22 @@ int build_round_index(rapid_engine* h) {
     return RAPID_OK;
 }
 
-// The instantiation without the per-delivery configuration-id check runs only on VERIFIED facts: either every delivered
-// record went through the validation pass itself (nothing declared: index_touch_kernel<true> saw them all), or the declared
-// alerts all pass the filter under the current view, the caller asked for it, and split_records_kernel found the current
-// configuration id on every record when the streams were loaded (and the view has not changed since).  What a delivered
-// record can then still get wrong -- subject range, UP / DOWN against the membership, rings the index was not built for --
-// is checked per delivery by the kernel (RAPID_EINVAL).  Testing knob bit 6: never.
+// kTrusted = a delivered record that fails the membership filter or names a ring the index was not built for is an ERROR of
+// the stream (RAPID_EINVAL) instead of being dropped per delivery.  It runs only on VERIFIED facts: either every delivered record
+// went through the validation pass itself (nothing declared: index_touch_kernel saw them all and none failed), or the declared
+// alerts all pass the filter under the current view and the caller vouches that the deliveries are copies of them.  The
+// configuration id is compared per delivery by the kernel either way (boundary records; another id: dropped, as
+// R/MembershipService.java:653-657 does); generated records rest on the alert set they were generated from.  Testing knob bit 6: never.
 bool tally_is_trusted(const rapid_engine* h) {
     if (!h->trusted || (h->force_exact & 64) != 0) return false;
     if (h->n_alert_set < 0) return true;
-    return h->trust_copies && h->load_all_current && h->load_in_range && h->load_cfg_id == h->config_id;
+    if (h->rec_fmt == rapid::kFmtResident) return h->trust_copies && h->gen_clean;
+    return h->trust_copies;
 }
 
 int launch_tally(rapid_engine* h) {
     rapid::TallyParams p;
-    p.core = h->d_core.p;
-    p.cfg = h->d_cfg.p;
+    p.core = h->d_records;
     p.rec_off = h->d_rec_off;
     p.n_receivers = h->n_receivers;
     p.n_nodes = h->n_nodes;
@@ -744,16 +742,17 @@ int launch_tally(rapid_engine* h) {
     // delivered records themselves) the caller vouches that the deliveries are copies of them; bit6 of the testing knob: never
     const bool trusted = tally_is_trusted(h);
     const size_t lds = (size_t)h->lds_bytes;
-    switch (h->dict_mode * 2 + (trusted ? 1 : 0)) {
-        case 0: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictMemory, false>), grid, block, lds, h->stream, p); break;
-        case 1: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictMemory, true>), grid, block, lds, h->stream, p); break;
-        case 2: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictDirect, false>), grid, block, lds, h->stream, p); break;
-        case 3: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictDirect, true>), grid, block, lds, h->stream, p); break;
-        case 4: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, false>), grid, block, lds, h->stream, p); break;
-        case 5: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictCompressed, true>), grid, block, lds, h->stream, p); break;
-        case 6: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictResolved, false>), grid, block, lds, h->stream, p); break;
-        case 7: hipLaunchKernelGGL((rapid::tally_population_kernel<rapid::kDictResolved, true>), grid, block, lds, h->stream, p); break;
-        default: return fail(h, RAPID_ESTATE, "no tally kernel for dictionary mode %d", h->dict_mode);
+    using namespace rapid;
+    switch ((h->rec_fmt == kFmtBoundary ? 0 : 8) + h->dict_mode * 2 + (trusted ? 1 : 0)) {
+        case 0: hipLaunchKernelGGL((tally_population_kernel<kDictMemory, false, kFmtBoundary>), grid, block, lds, h->stream, p); break;
+        case 1: hipLaunchKernelGGL((tally_population_kernel<kDictMemory, true, kFmtBoundary>), grid, block, lds, h->stream, p); break;
+        case 2: hipLaunchKernelGGL((tally_population_kernel<kDictDirect, false, kFmtBoundary>), grid, block, lds, h->stream, p); break;
+        case 3: hipLaunchKernelGGL((tally_population_kernel<kDictDirect, true, kFmtBoundary>), grid, block, lds, h->stream, p); break;
+        case 4: hipLaunchKernelGGL((tally_population_kernel<kDictCompressed, false, kFmtBoundary>), grid, block, lds, h->stream, p); break;
+        case 5: hipLaunchKernelGGL((tally_population_kernel<kDictCompressed, true, kFmtBoundary>), grid, block, lds, h->stream, p); break;
+        case 14: hipLaunchKernelGGL((tally_population_kernel<kDictResolved, false, kFmtResident>), grid, block, lds, h->stream, p); break;
+        case 15: hipLaunchKernelGGL((tally_population_kernel<kDictResolved, true, kFmtResident>), grid, block, lds, h->stream, p); break;
+        default: return fail(h, RAPID_ESTATE, "no tally kernel for record format %d, dictionary mode %d", h->rec_fmt, h->dict_mode);
     }
     return RAPID_OK;
 }
@@ -764,60 +763,24 @@ int prepare_tally(rapid_engine* h) {
     HIPCHK(h, h->d_errflags.ensure(2));
     HIPCHK(h, h->d_stats.ensure(stats_words(h)));
     HIPCHK(h, h->d_voteback.ensure((10 * 8 + ((size_t)h->max_cut + 1) * sizeof(int) + 7) / 8));  // launch_tally: vote_res
-    if (h->load_cfg_id != h->config_id) {
-        // The view changed while these streams stayed loaded: which records carry the engine's configuration id
-        // (R/MembershipService.java:653-657) is marked in the resident records themselves (tally_kernel.h: kCoreStale), so
-        // the marks are brought up to date -- one pass over the retained ids, once per view change.
-        HIPCHK(h, hipMemsetAsync(h->d_loadflags.p, 0, 8, h->stream));
-        const long long n = h->n_records_total;
-        if (n > 0)
-            hipLaunchKernelGGL(rapid::remark_records_kernel, dim3((unsigned)std::min<long long>((long long)h->num_cus * 16, (n + 255) / 256)), dim3(256), 0,
-                               h->stream, n, h->d_dstv.p, reinterpret_cast<const uint2*>(h->d_cfg.p), (long long)h->config_id, h->d_loadflags.p);
-        h->core_state = rapid_engine::kCoreUnknown;  // (the marks live in d_dstv; the records' first dwords follow below)
-        unsigned int load_flags[2] = {1u, 0u};
-        HIPCHK(h, hipMemcpyAsync(load_flags, h->d_loadflags.p, sizeof load_flags, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipGetLastError());
-        h->load_all_current = (load_flags[0] & 1u) == 0u;
-        h->load_cfg_id = h->config_id;
-        h->index_valid = false;  // (the undeclared index validates against the marks)
-    }
+    if (h->rec_fmt == rapid::kFmtResident && h->gen_cfg_id != h->config_id)
+        return fail(h, RAPID_ESTATE, "the view changed since these deliveries were generated: call rapid_sim_generate again");
     h->stats_fresh = false;
     if (!h->index_valid) {
         int rc = build_round_index(h);  // also zeroes the error flags and the launch statistics / pool words
         if (rc) return rc;
         h->stats_fresh = true;
     }
-    {
-        // The records' first dwords: the subjects' dictionary entries of THIS index (kDictResolved), or the subjects themselves
-        // (the cross-check modes).  One streaming pass per (stream set, alert set, view), not per round replayed on them.
-        const int want = h->dict_mode == rapid::kDictResolved ? rapid_engine::kCoreEntries : rapid_engine::kCoreSubjects;
-        const bool ok = h->core_state == want && (want == rapid_engine::kCoreSubjects || h->core_serial == h->content_serial);
-        if (!ok && h->n_records_total > 0) {
-            const long long n = h->n_records_total;
-            if (!h->ev_res0) {
-                HIPCHK(h, hipEventCreate(&h->ev_res0));
-                HIPCHK(h, hipEventCreate(&h->ev_res1));
-            }
-            HIPCHK(h, hipEventRecord(h->ev_res0, h->stream));
-            hipLaunchKernelGGL(rapid::resolve_records_kernel, dim3((unsigned)std::min<long long>((long long)h->num_cus * 16, (n + 255) / 256)), dim3(256), 0,
-                               h->stream, n, reinterpret_cast<uint2*>(h->d_core.p), h->d_dstv.p,
-                               want == rapid_engine::kCoreEntries ? h->d_entries.p : (const unsigned int*)nullptr, (unsigned int)h->n_nodes);
-            HIPCHK(h, hipEventRecord(h->ev_res1, h->stream));
-            h->resolve_ms_pending = true;
-        }
-        h->core_state = want;
-        h->core_serial = h->content_serial;
-    }
     if (!h->lds_attr_set) {  // once per engine: every instantiation may use the whole 160 KiB of LDS
-        const void* kernels[8] = {reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictResolved, false>),
-                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictResolved, true>),
-                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, false>),
-                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictMemory, true>),
-                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictDirect, false>),
-                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictDirect, true>),
-                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictCompressed, false>),
-                                  reinterpret_cast<const void*>(rapid::tally_population_kernel<rapid::kDictCompressed, true>)};
+        using namespace rapid;
+        const void* kernels[8] = {reinterpret_cast<const void*>(tally_population_kernel<kDictResolved, false, kFmtResident>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictResolved, true, kFmtResident>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictMemory, false, kFmtBoundary>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictMemory, true, kFmtBoundary>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictDirect, false, kFmtBoundary>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictDirect, true, kFmtBoundary>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictCompressed, false, kFmtBoundary>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictCompressed, true, kFmtBoundary>)};
         for (const void* k : kernels) HIPCHK(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         h->lds_attr_set = true;
     }
@@ -886,20 +849,19 @@ void rapid_engine_destroy(rapid_engine* h) {
     if (h->ev0) quiet(hipEventDestroy(h->ev0), "hipEventDestroy");
     if (h->ev1) quiet(hipEventDestroy(h->ev1), "hipEventDestroy");
     if (h->h_mail) quiet(hipHostFree(h->h_mail), "hipHostFree(mailbox)");
+    if (h->h_alert_stage) quiet(hipHostFree(h->h_alert_stage), "hipHostFree(alert staging)");
+    if (h->ev_alert) quiet(hipEventDestroy(h->ev_alert), "hipEventDestroy");
     if (h->stream) quiet(hipStreamDestroy(h->stream), "hipStreamDestroy");
     h->d_blob.release(); h->d_host_off.release(); h->d_ports.release(); h->d_keys.release();
     h->d_hx_host0.release(); h->d_hx_port0.release(); h->d_member.release(); h->d_members.release();
     h->d_sort_keys.release(); h->d_sort_vals.release(); h->d_ring_skeys.release(); h->d_ring.release();
     h->d_pos.release(); h->d_obs.release(); h->d_subj.release();
     h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
-    h->d_q4_nodes.release(); h->d_q4_rows.release(); h->d_entries.release(); h->d_dstv.release();
-    h->d_gen_keys.release(); h->d_gen_skeys.release(); h->d_gen_vals.release(); h->d_gen_perm.release(); h->d_gen_boff.release(); h->d_gen_rx.release();
-    h->d_gen_seg.release();
-    if (h->ev_res0) (void)hipEventDestroy(h->ev_res0);
-    if (h->ev_res1) (void)hipEventDestroy(h->ev_res1);
+    h->d_q4_nodes.release(); h->d_q4_rows.release(); h->d_entries.release();
+    h->d_gen_res.release(); h->d_gen_keep.release(); h->d_gen_boff.release(); h->d_gen_rx.release();
     h->d_ids_hi2.release(); h->d_ids_lo2.release(); h->d_ids_new.release(); h->d_cfg_partial.release(); h->d_chunk_kept.release();
     h->d_joiners.release(); h->d_join_nodes.release(); h->d_join_vals.release(); h->d_join_keys.release(); h->d_join_skeys.release();
-    h->d_core.release(); h->d_cfg.release(); h->d_stage.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
+    h->d_records_own.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
     h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_idxblk.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release(); h->d_trank.release(); h->d_tbits.release(); h->d_tent.release();
     h->d_adj_off.release(); h->d_node_of_slot.release(); h->d_loadflags.release();
@@ -1311,44 +1273,10 @@ int rapid_cd_clear(rapid_cd* cd) {
 }
 
 // ------------------------------------------------------------------------------------------ population
-// 20-byte records (host or device memory) -> the resident split arrays.  Host records travel through a bounded staging
-// buffer, so a population's footprint is 16 B per delivered record + 256 MiB, not 36 B.
-static int load_split(rapid_engine* h, const unsigned char* src, bool src_on_device, long long n_rec) {
-    const size_t core_bytes = (((size_t)n_rec * 8 + 15) / 16) * 16 + 64;
-    HIPCHK(h, h->d_core.ensure(core_bytes));
-    HIPCHK(h, h->d_cfg.ensure(core_bytes));
-    HIPCHK(h, h->d_dstv.ensure((size_t)n_rec + 16));
-    h->core_state = rapid_engine::kCoreSubjects;  // (what the load pass writes)
-    const size_t tail = ((size_t)n_rec * 8 / 16) * 16;  // zeros behind the last record (the split pass below rewrites what it owns)
-    HIPCHK(h, hipMemsetAsync(h->d_core.p + tail, 0, core_bytes - tail, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->d_cfg.p + tail, 0, core_bytes - tail, h->stream));
-    HIPCHK(h, h->d_loadflags.ensure(2));
-    HIPCHK(h, hipMemsetAsync(h->d_loadflags.p, 0, 8, h->stream));
-    h->load_all_current = h->load_in_range = false;
-    h->load_cfg_id = h->config_id;
-    const long long chunk = 12ll << 20;  // records per staging round (240 MiB)
-    if (!src_on_device && n_rec > 0) HIPCHK(h, h->d_stage.ensure((size_t)std::min(chunk, n_rec) * 20 + 16));
-    for (long long at = 0; at < n_rec; at += chunk) {
-        const long long n = std::min(chunk, n_rec - at);
-        const unsigned char* from = src + (size_t)at * 20;
-        if (!src_on_device) {
-            HIPCHK(h, hipMemcpyAsync(h->d_stage.p, from, (size_t)n * 20, hipMemcpyHostToDevice, h->stream));
-            from = h->d_stage.p;
-        }
-        hipLaunchKernelGGL(rapid::split_records_kernel, dim3((unsigned)std::min<long long>((long long)h->num_cus * 16, (n + 255) / 256)),
-                           dim3(256), 0, h->stream, from, n, reinterpret_cast<uint2*>(h->d_core.p) + at, reinterpret_cast<uint2*>(h->d_cfg.p) + at,
-                           h->d_dstv.p + at, (long long)h->config_id, (unsigned int)h->n_nodes, h->d_loadflags.p);
-    }
-    unsigned int load_flags[2] = {1u, 0u};
-    HIPCHK(h, hipMemcpyAsync(load_flags, h->d_loadflags.p, sizeof load_flags, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipGetLastError());
-    h->load_all_current = h->view_built && (load_flags[0] & 1u) == 0u;  // every record carries the current configuration id
-    h->load_in_range = (load_flags[0] & 2u) == 0u;                      // ... and names a subject the registry knows
-    h->records_bytes = core_bytes - 48;
-    return RAPID_OK;
-}
-
+// The delivered streams stay what they are when they cross the boundary: 20-byte records, read once per round by the tally
+// kernel itself (tally_kernel.h: kFmtBoundary).  Loading = making them resident: a copy into the engine's own buffer (host
+// records: the PCIe transfer; device records: a device-to-device copy, because the caller's buffer is only borrowed for the
+// call), or no copy at all when the caller leaves them in place (rapid_sim_attach_streams_device).
 static void streams_replaced(rapid_engine* h, int n_receivers, long long n_rec) {
     h->n_receivers = n_receivers;
     h->n_records_total = n_rec;
@@ -1359,7 +1287,17 @@ static void streams_replaced(rapid_engine* h, int n_receivers, long long n_rec) 
     h->tallied = false;
     h->have_decision = false;
     h->tally_votes_valid = false;
-    h->content_serial++;
+}
+
+static int own_records(rapid_engine* h, const unsigned char* src, hipMemcpyKind kind, long long n_rec) {
+    const size_t bytes = (size_t)n_rec * 20;
+    HIPCHK(h, h->d_records_own.ensure(bytes + 64));
+    if (bytes) HIPCHK(h, hipMemcpyAsync(h->d_records_own.p, src, bytes, kind, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // (borrowed for the call)
+    h->d_records = h->d_records_own.p;
+    h->records_bytes = bytes;
+    h->rec_fmt = rapid::kFmtBoundary;
+    return RAPID_OK;
 }
 
 int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, const int64_t* rec_off,
@@ -1368,15 +1306,35 @@ int rapid_sim_load_streams(rapid_engine* h, const rapid_alert_record* records, c
     int rc = use_device(h);
     if (rc) return rc;
     const long long n_rec = rec_off[n_receivers];
-    if (n_rec < 0 || (n_rec > 0 && !records)) return fail(h, RAPID_EINVAL, "bad record stream");
-    for (int r = 0; r < n_receivers; ++r)
+    if (rec_off[0] != 0 || n_rec < 0 || (n_rec > 0 && !records)) return fail(h, RAPID_EINVAL, "bad record stream");
+    for (int r = 0; r < n_receivers; ++r) {
         if (rec_off[r + 1] < rec_off[r]) return fail(h, RAPID_EINVAL, "rec_off not monotone at %d", r);
+        if (rec_off[r + 1] - rec_off[r] > rapid::kMaxStreamRecords)
+            return fail(h, RAPID_ECAPACITY, "receiver %d: %lld records; at most %lld per stream", r, (long long)(rec_off[r + 1] - rec_off[r]), (long long)rapid::kMaxStreamRecords);
+    }
     HIPCHK(h, h->d_rec_off_own.ensure((size_t)n_receivers + 1));
     HIPCHK(h, hipMemcpyAsync(h->d_rec_off_own.p, rec_off, sizeof(long long) * ((size_t)n_receivers + 1), hipMemcpyHostToDevice,
                              h->stream));
-    if ((rc = load_split(h, reinterpret_cast<const unsigned char*>(records), false, n_rec))) return rc;
+    h->streams_loaded = false;  // (until the records are in place: a failing copy leaves no half-loaded streams behind)
+    if ((rc = own_records(h, reinterpret_cast<const unsigned char*>(records), hipMemcpyHostToDevice, n_rec))) return rc;
     h->d_rec_off = h->d_rec_off_own.p;
     streams_replaced(h, n_receivers, n_rec);
+    return RAPID_OK;
+}
+
+// d_rec_off as the caller's device array: its last entry and the per-stream bound are checked on a host copy
+static int check_device_offsets(rapid_engine* h, const int64_t* d_rec_off, int32_t n_receivers, uint64_t records_bytes, long long* n_rec_out) {
+    std::vector<long long> off((size_t)n_receivers + 1);
+    HIPCHK(h, hipMemcpy(off.data(), d_rec_off, sizeof(long long) * off.size(), hipMemcpyDeviceToHost));
+    const long long n_rec = off[(size_t)n_receivers];
+    if (off[0] != 0 || n_rec < 0 || (unsigned long long)n_rec * 20ull > records_bytes)
+        return fail(h, RAPID_EINVAL, "records_bytes=%llu does not cover %lld records", (unsigned long long)records_bytes, n_rec);
+    for (int r = 0; r < n_receivers; ++r) {
+        if (off[(size_t)r + 1] < off[(size_t)r]) return fail(h, RAPID_EINVAL, "rec_off not monotone at %d", r);
+        if (off[(size_t)r + 1] - off[(size_t)r] > rapid::kMaxStreamRecords)
+            return fail(h, RAPID_ECAPACITY, "receiver %d: %lld records; at most %lld per stream", r, off[(size_t)r + 1] - off[(size_t)r], (long long)rapid::kMaxStreamRecords);
+    }
+    *n_rec_out = n_rec;
     return RAPID_OK;
 }
 
@@ -1386,99 +1344,104 @@ int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64
     int rc = use_device(h);
     if (rc) return rc;
     long long n_rec = 0;
-    HIPCHK(h, hipMemcpy(&n_rec, reinterpret_cast<const long long*>(d_rec_off) + n_receivers, 8, hipMemcpyDeviceToHost));
-    if (n_rec < 0 || (unsigned long long)n_rec * 20ull > records_bytes + 0ull)
-        return fail(h, RAPID_EINVAL, "records_bytes=%llu does not cover %lld records", (unsigned long long)records_bytes, n_rec);
-    // the records are split into the engine's own arrays right here; the offsets stay where they are (borrowed)
-    if ((rc = load_split(h, static_cast<const unsigned char*>(d_records), true, n_rec))) return rc;
+    if ((rc = check_device_offsets(h, d_rec_off, n_receivers, records_bytes, &n_rec))) return rc;
+    h->streams_loaded = false;
+    if ((rc = own_records(h, static_cast<const unsigned char*>(d_records), hipMemcpyDeviceToDevice, n_rec))) return rc;
+    h->d_rec_off = reinterpret_cast<const long long*>(d_rec_off);  // the offsets stay where they are (borrowed until the next load)
+    streams_replaced(h, n_receivers, n_rec);
+    return RAPID_OK;
+}
+
+int rapid_sim_attach_streams_device(rapid_engine* h, const void* d_records, uint64_t records_bytes, const int64_t* d_rec_off,
+                                    int32_t n_receivers) {
+    if (!h || !d_rec_off || n_receivers < 0 || (!d_records && records_bytes)) return RAPID_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_records) & 3u) != 0u) return fail(h, RAPID_EINVAL, "records must be 4-byte aligned");
+    int rc = use_device(h);
+    if (rc) return rc;
+    long long n_rec = 0;
+    if ((rc = check_device_offsets(h, d_rec_off, n_receivers, records_bytes, &n_rec))) return rc;
+    h->d_records = static_cast<const unsigned char*>(d_records);  // nothing is copied, nothing is rewritten: the tally reads them in place
+    h->records_bytes = (unsigned long long)n_rec * 20ull;
+    h->rec_fmt = rapid::kFmtBoundary;
     h->d_rec_off = reinterpret_cast<const long long*>(d_rec_off);
     streams_replaced(h, n_receivers, n_rec);
     return RAPID_OK;
 }
 
-int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const int64_t* batch_off, int32_t n_batches, const int32_t* receivers,
-                       int32_t n_receivers, uint64_t seed) {
+int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const int64_t* batch_off, int32_t n_batches, const uint32_t* batch_keep,
+                       const int32_t* receivers, int32_t n_receivers, uint64_t seed, int32_t format) {
     if (!h || !batch_off || n_batches < 0 || n_receivers < 0 || (n_receivers > 0 && !receivers)) return RAPID_EINVAL;
+    if (format != RAPID_GEN_RESOLVED && format != RAPID_GEN_BOUNDARY) return fail(h, RAPID_EINVAL, "unknown record format %d", format);
     if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
     int rc = use_device(h);
     if (rc) return rc;
     const long long A = batch_off[n_batches];
     if (batch_off[0] != 0 || A < 0 || (A > 0 && !alerts)) return fail(h, RAPID_EINVAL, "bad batch offsets");
+    // (a BatchedAlertMessage is never empty: the reference's batcher only sends what it has queued, R/MembershipService.java:613-637;
+    // an empty batch would still end -- invalidateFailingEdges runs once per message, :330 -- and has no record to say so)
     for (int b = 0; b < n_batches; ++b)
-        if (batch_off[b + 1] < batch_off[b]) return fail(h, RAPID_EINVAL, "batch offsets not monotone at %d", b);
-    const long long RB = (long long)n_receivers * (long long)n_batches, total = (long long)n_receivers * A;
-    if (RB >= (1ll << 31)) return fail(h, RAPID_ECAPACITY, "%d receivers x %d batches: at most 2^31 deliveries per call", n_receivers, n_batches);
+        if (batch_off[b + 1] <= batch_off[b]) return fail(h, RAPID_EINVAL, "batch %d is empty or the offsets decrease", b);
+    if (A > rapid::kMaxStreamRecords) return fail(h, RAPID_ECAPACITY, "%lld alerts per receiver; at most %lld", A, (long long)rapid::kMaxStreamRecords);
+    const long long total = (long long)n_receivers * A;
+    const bool boundary = format == RAPID_GEN_BOUNDARY;
     hipStream_t st = h->stream;
     if (!h->ev0) {
         HIPCHK(h, hipEventCreate(&h->ev0));
         HIPCHK(h, hipEventCreate(&h->ev1));
     }
-    // the round's distinct alerts = the declared alert set; batches; receivers
+    // what the set itself says about the deliveries that will be copies of it (R/MembershipService.java:653-657)
+    bool clean = true;
+    for (long long i = 0; i < A; ++i) clean = clean && alerts[i].cfg_id == h->config_id && alerts[i].dst < (uint32_t)h->n_nodes;
+    // Nothing of the engine's stream state is committed before the generation has succeeded: a failure leaves "no streams loaded".
+    h->streams_loaded = false;
+    h->index_valid = false;
+    h->tallied = false;
     HIPCHK(h, h->d_alert_set.ensure((size_t)std::max<long long>(A, 1) * 20 + 16));
     HIPCHK(h, h->d_gen_boff.ensure((size_t)n_batches + 1));
     HIPCHK(h, h->d_gen_rx.ensure((size_t)std::max(n_receivers, 1)));
+    if (batch_keep) HIPCHK(h, h->d_gen_keep.ensure((size_t)std::max(n_batches, 1)));
     if (A) HIPCHK(h, hipMemcpyAsync(h->d_alert_set.p, alerts, (size_t)A * 20, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemcpyAsync(h->d_gen_boff.p, batch_off, sizeof(long long) * ((size_t)n_batches + 1), hipMemcpyHostToDevice, st));
     if (n_receivers) HIPCHK(h, hipMemcpyAsync(h->d_gen_rx.p, receivers, sizeof(int) * (size_t)n_receivers, hipMemcpyHostToDevice, st));
+    if (batch_keep && n_batches) HIPCHK(h, hipMemcpyAsync(h->d_gen_keep.p, batch_keep, sizeof(unsigned int) * (size_t)n_batches, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipStreamSynchronize(st));  // (borrowed inputs)
-    // resident arrays
-    const size_t core_bytes = (((size_t)total * 8 + 15) / 16) * 16 + 64;
-    HIPCHK(h, h->d_core.ensure(core_bytes));
-    HIPCHK(h, h->d_cfg.ensure(core_bytes));
-    HIPCHK(h, h->d_dstv.ensure((size_t)total + 16));
-    const size_t tail = ((size_t)total * 8 / 16) * 16;
-    HIPCHK(h, hipMemsetAsync(h->d_core.p + tail, 0, core_bytes - tail, st));
+    const size_t stride = boundary ? 20 : 8;
+    HIPCHK(h, h->d_records_own.ensure((size_t)total * stride + 64));
     HIPCHK(h, h->d_rec_off_own.ensure((size_t)n_receivers + 1));
-    HIPCHK(h, h->d_loadflags.ensure(2));
-    HIPCHK(h, hipMemsetAsync(h->d_loadflags.p, 0, 8, st));
     hipLaunchKernelGGL(rapid::gen_offsets_kernel, dim3(grid_for((long long)n_receivers + 1, 256)), dim3(256), 0, st, h->d_rec_off_own.p, n_receivers, A);
-    h->d_rec_off = h->d_rec_off_own.p;
-    streams_replaced(h, n_receivers, total);
-    h->n_alert_set = A;  // (streams_replaced forgets a declared set: this one is the streams' own)
-    h->records_bytes = core_bytes - 48;
-    h->load_cfg_id = h->config_id;
-    h->load_all_current = h->load_in_range = false;
-    // the round's index first: the records are written with their subjects already resolved
-    h->core_state = rapid_engine::kCoreUnknown;
-    h->index_valid = false;
+    h->n_receivers = n_receivers;
+    h->n_records_total = total;
+    h->n_alert_set = A;
+    h->rec_fmt = boundary ? rapid::kFmtBoundary : rapid::kFmtResident;
     HIPCHK(h, h->d_errflags.ensure(2));
     HIPCHK(h, h->d_stats.ensure(stats_words(h)));
     HIPCHK(h, h->d_voteback.ensure((10 * 8 + ((size_t)h->max_cut + 1) * sizeof(int) + 7) / 8));
-    if ((rc = build_round_index(h))) return rc;
-    const bool resolved = h->dict_mode == rapid::kDictResolved;
+    // resolved records carry entries of the round's index: built first, from the alert set
+    if (!boundary && (rc = build_round_index(h))) return rc;
     HIPCHK(h, hipEventRecord(h->ev0, st));
-    if (RB > 0 && A > 0) {
-        HIPCHK(h, h->d_gen_keys.ensure((size_t)RB));
-        HIPCHK(h, h->d_gen_skeys.ensure((size_t)RB));
-        HIPCHK(h, h->d_gen_vals.ensure((size_t)RB));
-        HIPCHK(h, h->d_gen_perm.ensure((size_t)RB));
-        HIPCHK(h, h->d_gen_seg.ensure((size_t)n_receivers + 1));
-        std::vector<int> seg((size_t)n_receivers + 1);
-        for (int r = 0; r <= n_receivers; ++r) seg[(size_t)r] = r * n_batches;
-        HIPCHK(h, hipMemcpyAsync(h->d_gen_seg.p, seg.data(), sizeof(int) * seg.size(), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(rapid::gen_keys_kernel, dim3((unsigned)std::min<long long>((long long)h->num_cus * 16, (RB + 255) / 256)), dim3(256), 0, st,
-                           h->d_gen_rx.p, n_receivers, n_batches, (unsigned long long)seed, h->d_gen_keys.p, h->d_gen_vals.p);
-        size_t tmp_bytes = 0;
-        HIPCHK(h, rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, h->d_gen_keys.p, h->d_gen_skeys.p, h->d_gen_vals.p, h->d_gen_perm.p,
-                                                      (unsigned int)RB, (unsigned int)n_receivers, h->d_gen_seg.p, h->d_gen_seg.p + 1, 0, 64, st));
-        HIPCHK(h, h->d_sort_tmp.ensure(tmp_bytes + 16));
-        HIPCHK(h, rocprim::segmented_radix_sort_pairs(h->d_sort_tmp.p, tmp_bytes, h->d_gen_keys.p, h->d_gen_skeys.p, h->d_gen_vals.p, h->d_gen_perm.p,
-                                                      (unsigned int)RB, (unsigned int)n_receivers, h->d_gen_seg.p, h->d_gen_seg.p + 1, 0, 64, st));
-        hipLaunchKernelGGL(rapid::gen_streams_kernel, dim3((unsigned)n_receivers), dim3(256), 0, st, h->d_alert_set.p, h->d_gen_boff.p, n_batches,
-                           h->d_gen_perm.p, A, reinterpret_cast<uint2*>(h->d_core.p), reinterpret_cast<uint2*>(h->d_cfg.p), h->d_dstv.p,
-                           (long long)h->config_id, (unsigned int)h->n_nodes, resolved ? h->d_entries.p : (const unsigned int*)nullptr, h->d_loadflags.p);
-        HIPCHK(h, hipStreamSynchronize(st));  // (`seg`)
+    if (total > 0) {
+        if (!boundary) {
+            HIPCHK(h, h->d_gen_res.ensure((size_t)A));
+            hipLaunchKernelGGL(rapid::gen_resolve_alerts_kernel, dim3(grid_for(A, 256)), dim3(256), 0, st, h->d_alert_set.p, A, (long long)h->config_id,
+                               (unsigned int)h->n_nodes, h->d_entries.p, h->d_gen_res.p);
+        }
+        hipLaunchKernelGGL(rapid::gen_streams_kernel, dim3((unsigned)n_receivers), dim3(256), 0, st, h->d_gen_res.p, h->d_alert_set.p, h->d_gen_boff.p,
+                           n_batches, batch_keep ? h->d_gen_keep.p : (const unsigned int*)nullptr, h->d_gen_rx.p, A, (unsigned long long)seed,
+                           h->d_records_own.p, boundary ? 1 : 0);
     }
     HIPCHK(h, hipEventRecord(h->ev1, st));
-    unsigned int load_flags[2] = {3u, 0u};
-    HIPCHK(h, hipMemcpyAsync(load_flags, h->d_loadflags.p, sizeof load_flags, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     HIPCHK(h, hipGetLastError());
     (void)hipEventElapsedTime(&h->generate_ms, h->ev0, h->ev1);
-    h->load_all_current = (load_flags[0] & 1u) == 0u;
-    h->load_in_range = (load_flags[0] & 2u) == 0u;
-    h->core_state = resolved ? rapid_engine::kCoreEntries : rapid_engine::kCoreSubjects;
-    h->core_serial = h->content_serial;
+    h->d_records = h->d_records_own.p;
+    h->records_bytes = (unsigned long long)total * stride;
+    h->d_rec_off = h->d_rec_off_own.p;
+    h->gen_cfg_id = h->config_id;
+    h->gen_clean = clean && batch_keep == nullptr;  // (an undelivered batch's places hold empty records: harmless, but not copies)
+    const bool index_valid = h->index_valid;
+    streams_replaced(h, n_receivers, total);
+    h->n_alert_set = A;  // (streams_replaced forgets a declared set: this one is the streams' own)
+    h->index_valid = index_valid;  // (resolved: the index the entries come from; rapid_sim_new_round builds it again -- same numbering)
     return RAPID_OK;
 }
 
@@ -1487,26 +1450,57 @@ int rapid_debug_read_records(rapid_engine* h, int64_t first, int32_t n, uint32_t
     if (!h->streams_loaded || first + n > h->n_records_total) return fail(h, RAPID_EINVAL, "records [%lld, %lld) not loaded", (long long)first, (long long)first + n);
     int rc = use_device(h);
     if (rc) return rc;
-    std::vector<uint32_t> both((size_t)n * 2);
-    HIPCHK(h, hipMemcpyAsync(subjects, h->d_dstv.p + first, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(both.data(), h->d_core.p + (size_t)first * 8, sizeof(uint32_t) * 2 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    const size_t stride = h->rec_fmt == rapid::kFmtBoundary ? 20 : 8;
+    std::vector<unsigned char> raw((size_t)n * stride);
+    if (n) HIPCHK(h, hipMemcpyAsync(raw.data(), h->d_records + (size_t)first * stride, raw.size(), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (int i = 0; i < n; ++i) core_words[i] = both[(size_t)2 * i + 1];
+    for (int i = 0; i < n; ++i) {
+        uint32_t w[5] = {0, 0, 0, 0, 0};
+        std::memcpy(w, raw.data() + (size_t)i * stride, stride);
+        if (h->rec_fmt == rapid::kFmtBoundary) {
+            subjects[i] = w[3];
+            core_words[i] = rapid::core_word(w[4]);
+        } else {
+            subjects[i] = w[0];  // the subject's dict_entry (tally_kernel.h)
+            core_words[i] = w[1];
+        }
+    }
     return RAPID_OK;
 }
 
 int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, int64_t n_alerts) {
     if (!h || n_alerts < 0 || (n_alerts > 0 && !alerts)) return RAPID_EINVAL;
     if (!h->streams_loaded) return fail(h, RAPID_ESTATE, "load the streams first");
+    if (h->rec_fmt == rapid::kFmtResident)
+        return fail(h, RAPID_ESTATE, "generated deliveries are copies of the alert set they were generated from (rapid_sim_generate declares it)");
     int rc = use_device(h);
     if (rc) return rc;
-    HIPCHK(h, h->d_alert_set.ensure((size_t)std::max<int64_t>(n_alerts, 1) * 20 + 16));
-    if (n_alerts)
-        HIPCHK(h, hipMemcpyAsync(h->d_alert_set.p, alerts, (size_t)n_alerts * 20, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // A round's alert set is new every round, so this call is on the round's path: the borrowed records go through a pinned
+    // staging buffer and an asynchronous copy on the engine's stream -- no stream synchronisation (the previous copy out of
+    // the staging buffer, if it is still in flight, is waited for through its event).
+    const size_t bytes = (size_t)n_alerts * 20;
+    HIPCHK(h, h->d_alert_set.ensure(std::max<size_t>(bytes, 20) + 16));
+    if (bytes > h->alert_stage_bytes) {
+        if (h->h_alert_stage) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            (void)hipHostFree(h->h_alert_stage);
+            h->h_alert_stage = nullptr;
+            h->alert_stage_bytes = 0;
+        }
+        const size_t want = bytes + bytes / 4 + 4096;
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_alert_stage), want, hipHostMallocDefault));
+        h->alert_stage_bytes = want;
+    }
+    if (!h->ev_alert) HIPCHK(h, hipEventCreateWithFlags(&h->ev_alert, hipEventDisableTiming));
+    if (bytes) {
+        if (h->alert_copy_pending) HIPCHK(h, hipEventSynchronize(h->ev_alert));
+        std::memcpy(h->h_alert_stage, alerts, bytes);
+        HIPCHK(h, hipMemcpyAsync(h->d_alert_set.p, h->h_alert_stage, bytes, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipEventRecord(h->ev_alert, h->stream));
+        h->alert_copy_pending = true;
+    }
     h->n_alert_set = n_alerts;
     h->index_valid = false;
-    h->content_serial++;
     return RAPID_OK;
 }
 
@@ -1993,20 +1987,21 @@ int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, in
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::dma_probe_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     unsigned int ring_off = 0;
     if (const char* e = getenv("RAPID_PROBE_RING_OFFSET")) ring_off = (unsigned int)atoi(e);
+    const unsigned long long rec_b = h->rec_fmt == rapid::kFmtBoundary ? 20ull : 8ull;
     auto launch = [&]() {
         (void)hipMemsetAsync(h->d_next.p, 0, 4, h->stream);
         (void)hipMemcpyAsync(h->d_next.p + 2, &ring_off, 4, hipMemcpyHostToDevice, h->stream);
         switch (variant) {
-            case 0: hipLaunchKernelGGL((rapid::stream_probe_kernel<2, 8>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
-            case 1: hipLaunchKernelGGL((rapid::stream_probe_kernel<4, 4>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
-            case 2: hipLaunchKernelGGL((rapid::stream_probe_kernel<8, 2>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
-            case 9: hipLaunchKernelGGL((rapid::dma_probe_kernel<6>), grid, block, (size_t)waves * 6 * 1024 + lds_pad, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
-            case 7: hipLaunchKernelGGL((rapid::dma_probe_kernel<4>), grid, block, (size_t)waves * 4 * 1024, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
-            case 8: hipLaunchKernelGGL((rapid::dma_probe_kernel<8>), grid, block, (size_t)waves * 8 * 1024, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
-            case 4: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 8>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
-            case 5: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 16>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
-            case 6: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 4>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
-            default: hipLaunchKernelGGL((rapid::stream_probe_kernel<2, 4>), grid, block, 0, h->stream, h->d_core.p, h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, 8ull); break;
+            case 0: hipLaunchKernelGGL((rapid::stream_probe_kernel<2, 8>), grid, block, 0, h->stream, const_cast<unsigned char*>(h->d_records), h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, rec_b); break;
+            case 1: hipLaunchKernelGGL((rapid::stream_probe_kernel<4, 4>), grid, block, 0, h->stream, const_cast<unsigned char*>(h->d_records), h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, rec_b); break;
+            case 2: hipLaunchKernelGGL((rapid::stream_probe_kernel<8, 2>), grid, block, 0, h->stream, const_cast<unsigned char*>(h->d_records), h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, rec_b); break;
+            case 9: hipLaunchKernelGGL((rapid::dma_probe_kernel<6>), grid, block, (size_t)waves * 6 * 1024 + lds_pad, h->stream, const_cast<unsigned char*>(h->d_records), h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, rec_b); break;
+            case 7: hipLaunchKernelGGL((rapid::dma_probe_kernel<4>), grid, block, (size_t)waves * 4 * 1024, h->stream, const_cast<unsigned char*>(h->d_records), h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, rec_b); break;
+            case 8: hipLaunchKernelGGL((rapid::dma_probe_kernel<8>), grid, block, (size_t)waves * 8 * 1024, h->stream, const_cast<unsigned char*>(h->d_records), h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, rec_b); break;
+            case 4: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 8>), grid, block, 0, h->stream, const_cast<unsigned char*>(h->d_records), h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, rec_b); break;
+            case 5: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 16>), grid, block, 0, h->stream, const_cast<unsigned char*>(h->d_records), h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, rec_b); break;
+            case 6: hipLaunchKernelGGL((rapid::stream_probe_kernel<1, 4>), grid, block, 0, h->stream, const_cast<unsigned char*>(h->d_records), h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, rec_b); break;
+            default: hipLaunchKernelGGL((rapid::stream_probe_kernel<2, 4>), grid, block, 0, h->stream, const_cast<unsigned char*>(h->d_records), h->records_bytes, h->d_rec_off, h->n_receivers, h->d_next.p, h->d_next.p + 1, rec_b); break;
         }
     };
     launch();
@@ -2030,13 +2025,8 @@ int rapid_sim_pass_times(rapid_engine* h, float out[4]) {
         if (hipEventSynchronize(h->ev_idx1) == hipSuccess) (void)hipEventElapsedTime(&h->index_ms, h->ev_idx0, h->ev_idx1);
         (void)hipGetLastError();
     }
-    if (h->resolve_ms_pending && h->ev_res0 && h->ev_res1) {
-        h->resolve_ms_pending = false;
-        if (hipEventSynchronize(h->ev_res1) == hipSuccess) (void)hipEventElapsedTime(&h->resolve_ms, h->ev_res0, h->ev_res1);
-        (void)hipGetLastError();
-    }
     out[0] = h->index_ms;
-    out[1] = h->resolve_ms;
+    out[1] = 0.f;  // (there is no resolve pass any more: a delivered record is read once, by the tally)
     out[2] = h->generate_ms;
     out[3] = 0.f;
     return RAPID_OK;

@@ -1,9 +1,9 @@
-// Per-round index over the loaded alert streams (built once per rapid_sim_load_streams / view change, NOT part of
-// the timed tally): which subjects does this round's alert set name at all, which of them can ever reach the L
-// watermark ("hot"), a dense slot numbering (hot subjects first, ascending node index), and the adjacency among
-// hot subjects along the K-ring monitoring graph -- the only (observer, subject, ring) triples for which
-// MultiNodeCutDetector.invalidateFailingEdges (R/MultiNodeCutDetector.java:137-164) can ever apply an implicit
-// report at any receiver, because both ends need >= L explicit reports (R/MultiNodeCutDetector.java:104-107, 153).
+// Per-round index over the round's alert set (rebuilt every round: part of every timed step of bench.py): which subjects does
+// this round's alert set name at all, which of them can ever reach the L watermark ("hot"), a dense slot numbering (hot
+// subjects first, ascending node index), and the adjacency among hot subjects along the K-ring monitoring graph -- the only
+// (observer, subject, ring) triples for which MultiNodeCutDetector.invalidateFailingEdges (R/MultiNodeCutDetector.java:137-164)
+// can ever apply an implicit report at any receiver, because both ends need >= L explicit reports
+// (R/MultiNodeCutDetector.java:104-107, 153).  Also here: the kernels of rapid_sim_generate.
 //
 // The index is a SUPERSET construction: it ignores the per-alert filter (configuration id, UP/DOWN vs membership),
 // so it can only make more subjects "touched"/"hot" than a receiver will see, never fewer.
@@ -16,29 +16,19 @@
 namespace rapid {
 
 // gmask[dst] |= ring_mask over every record given (the round's distinct alert set if the host declared one, else
-// every delivered record).  After the first few thousand records nearly every bit is already set, so the (possibly
-// stale, L1-cached) pre-test avoids almost all atomics.  Also validates the records once: vflags bit0 is set if ANY
-// record fails the filter of R/MembershipService.java:644-675 under the current view (or names a node out of range
-// or no ring), bit1 if any record is an UP alert.
-// Two record sources: the round's declared alert set as it crossed the boundary (20-byte records), or -- when nothing was
-// declared -- every delivered record of the resident streams (subject array + core word).
-template <bool kSplit>
-__global__ void index_touch_kernel(const unsigned char* records, const unsigned int* dstv, long long n_records, int n_nodes,
-                                   unsigned int kmask, long long cfg_id, const unsigned char* member, unsigned int* gmask,
-                                   unsigned int* vflags) {
+// every delivered record -- 20-byte boundary records either way).  After the first few thousand records nearly every bit is
+// already set, so the (possibly stale, L1-cached) pre-test avoids almost all atomics.  Also validates the records once:
+// vflags bit0 is set if ANY record fails the filter of R/MembershipService.java:644-675 under the current view (or names a
+// node out of range or no ring), bit1 if any record is an UP alert.
+__global__ void index_touch_kernel(const unsigned char* records, long long n_records, int n_nodes, unsigned int kmask, long long cfg_id,
+                                   const unsigned char* member, unsigned int* gmask, unsigned int* vflags) {
     const long long stride = (long long)gridDim.x * blockDim.x;
     const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
     unsigned int f = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
-        unsigned int dst, cw;  // cw: the resident core word (tally_kernel.h: core_word)
-        bool current;          // the record carries the engine's configuration id
-        if (kSplit) {  // the id was compared when the record became resident (kCoreStale); the subject from its own array
-            const unsigned int d = dstv[i];  // (the record's first dword may hold the subject's resolved entry instead)
-            dst = d & ~kCoreStale, cw = reinterpret_cast<const uint2*>(records)[i].y, current = (d & kCoreStale) == 0u;
-        } else {
-            const unsigned int* w = reinterpret_cast<const unsigned int*>(records + i * 20);
-            dst = w[3], cw = core_word(w[4]), current = w[0] == cfg_lo && w[1] == cfg_hi;
-        }
+        const unsigned int* w = reinterpret_cast<const unsigned int*>(records + i * 20);
+        const unsigned int dst = w[3], cw = core_word(w[4]);  // (tally_kernel.h: core_word)
+        const bool current = w[0] == cfg_lo && w[1] == cfg_hi;  // the record carries the engine's configuration id
         const unsigned int bits = cw & kmask;
         const bool down = (cw & kCoreDown) != 0u;
         if (dst < (unsigned)n_nodes && bits != 0u && (bits & ~gmask[dst]) != 0u) atomicOr(&gmask[dst], bits);
@@ -47,36 +37,6 @@ __global__ void index_touch_kernel(const unsigned char* records, const unsigned 
         f |= (ok ? 0u : 1u) | (down ? 0u : 2u);
     }
     if (f) atomicOr(vflags, f);
-}
-
-// The boundary hands over 20-byte records (include/rapid_mi355x.h); resident they are split: core[i] = {dst, core word
-// (tally_kernel.h: core_word -- ring mask, the status as two bits, the batch end in the sign bit)}, cfg[i] = configuration
-// id.  One pass at load time; 16-byte granules of the source are not aligned with records, so each thread reads its
-// record's five dwords.
-//
-// Every configuration id passes through this kernel anyway, so it is compared with the view's current one right here
-// (R/MembershipService.java:653-657 drops an alert of another configuration): load_flags bit0 = some delivered record
-// carries another id, bit1 = some record names a subject >= n_nodes.  The engine selects the tally instantiation that skips
-// the per-delivery id check only for a load whose flags stayed clear (engine.hip: launch_tally) -- the caller's promise
-// costs no traffic to verify.
-__global__ void split_records_kernel(const unsigned char* records, long long n_records, uint2* core, uint2* cfg, unsigned int* dstv,
-                                     long long cfg_id, unsigned int n_nodes, unsigned int* load_flags) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
-    unsigned int other = 0u, range = 0u;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
-        const unsigned int* w = reinterpret_cast<const unsigned int*>(records + i * 20);
-        const unsigned int c0 = w[0], c1 = w[1];
-        other |= (c0 ^ cfg_lo) | (c1 ^ cfg_hi);
-        range |= w[3] >= n_nodes ? 1u : 0u;
-        cfg[i] = make_uint2(c0, c1);
-        // (a subject index that would collide with the mark is no node of any view: kept out of range for good)
-        const unsigned int d = (w[3] >= kCoreStale ? kCoreStale - 1u : w[3]) | (((c0 ^ cfg_lo) | (c1 ^ cfg_hi)) != 0u ? kCoreStale : 0u);
-        dstv[i] = d;  // kept beside the record: its first dword is overwritten when the subjects are resolved to their entries
-        core[i] = make_uint2(d, core_word(w[4]));
-    }
-    const unsigned int f = (__ballot(other != 0u) != 0ull ? 1u : 0u) | (__ballot(range != 0u) != 0ull ? 2u : 0u);
-    if (f != 0u && (threadIdx.x & 63u) == 0u) atomicOr(load_flags, f);
 }
 
 // node -> dict_entry for rounds whose tables stay in memory (tally_kernel.h: RoundIndex::entries): what the tally's direct mode
@@ -91,36 +51,6 @@ __global__ void dict_entries_kernel(const unsigned short* dict, const unsigned s
         e = dict_entry((unsigned int)decl[i], sl);
     }
     entries[i] = e;
-}
-
-// The first dword of every resident record <- the dict_entry of its subject (entries != nullptr: kDictResolved; a stale or
-// unknown subject gets the poison entry at entries[n_nodes]) or the subject itself again (entries == nullptr: the modes that
-// look the subject up in the tally).  4 B read + 4 B written per record + a gather that hits the caches (most records name
-// one of the round's hot subjects); once per (stream set, round index), not per launch of the tally.
-__global__ void resolve_records_kernel(long long n_records, uint2* core, const unsigned int* dstv, const unsigned int* entries, unsigned int n_nodes) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
-        const unsigned int d = dstv[i];
-        uint2 r = core[i];  // (whole records are rewritten: a store of every other dword leaves half-written lines behind)
-        r.x = entries == nullptr ? d : entries[d < n_nodes ? d : n_nodes];  // (the stale mark makes d >= n_nodes)
-        core[i] = r;
-    }
-}
-
-// The view changed while streams stayed loaded: the same comparison against the new configuration id, over the retained ids
-// (8 B per record read, 4 B rewritten; once per view change, and only if the streams are tallied again at all).
-__global__ void remark_records_kernel(long long n_records, unsigned int* dstv, const uint2* cfg, long long cfg_id, unsigned int* load_flags) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
-    unsigned int other = 0u;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_records; i += stride) {
-        const uint2 c = cfg[i];
-        const unsigned int stale = ((c.x ^ cfg_lo) | (c.y ^ cfg_hi)) != 0u ? kCoreStale : 0u;
-        other |= stale;
-        const unsigned int old = dstv[i];
-        if (((old ^ stale) & kCoreStale) != 0u) dstv[i] = (old & ~kCoreStale) | stale;
-    }
-    if (__ballot(other != 0u) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(load_flags, 1u);
 }
 
 // Dictionary format (built by index_build_block_kernel below).  Slot numbering: the hot subjects (>= L distinct rings
@@ -461,68 +391,156 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
 // ---- rapid_sim_generate: the delivered streams made on the device ----------------------------------------------------
 // Every receiver gets every BatchedAlertMessage of the round exactly once, in a receiver-specific seeded order (the
 // reference's fan-out: UnicastToAllBroadcaster.java:46-63 sends each batch to all members; arrival order differs per
-// receiver -- paper Fig.11 methodology).  The order of receiver r = the batches sorted by
-//     key(r, b) = mix64(mix64(seed + node index of r) + b)            (ties, never seen, by b: the sort is stable)
-// (rapid_amd/scenarios.py: deliver_hashed states the same on the host).  gen_keys_kernel writes the keys, one segmented radix
-// sort orders every receiver's batches, and gen_streams_kernel -- one workgroup per receiver -- lays the batches down back to
-// back directly in the RESIDENT layout (core = {entry or subject, core word}, subject array, configuration ids): the 20-byte
-// records of a round's deliveries never exist, neither on the host nor on the device.
-__device__ inline unsigned long long gen_mix64(unsigned long long x) {  // splitmix64 finaliser (== mix64 of tally_kernel.h)
+// receiver -- paper Fig.11 methodology).  The order is a seeded PERMUTATION evaluated in place, not a sort: position j of
+// receiver r holds batch perm_r(j), a four-round alternating Feistel network over the smallest bit width that covers the
+// batch count, walked until it lands inside [0, n_batches) (cycle walking: a bijection on a power-of-two domain restricted to
+// a subset is a bijection of the subset), keyed by mix64(seed + node index of r).  Any position is computed in O(1) by
+// itself, so one workgroup per receiver lays the stream down tile by tile with nothing but an exclusive scan of the batch
+// lengths in delivery order in between -- no keys in memory, no sort, no limit on receivers x batches.
+// (rapid_amd/scenarios.py: hashed_order / deliver_hashed state the same on the host.)
+// keep != nullptr: batch b reaches receiver r only if (uint32)(mix64(keepk_r + b) >> 32) <= keep[b] -- late deliveries of an
+// earlier configuration (R/MembershipService.java:653-657 drops them) and lossy links reach SOME receivers; the places of an
+// undelivered batch hold empty records (no ring, no batch end: what the zeros behind a stream's end are), so that every
+// stream keeps its fixed length and no second pass has to count.
+__host__ __device__ inline unsigned long long gen_mix64(unsigned long long x) {  // splitmix64 finaliser (== mix64 of tally_kernel.h)
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
-__global__ void gen_keys_kernel(const int* receivers, int n_receivers, int n_batches, unsigned long long seed, unsigned long long* keys,
-                                unsigned int* vals) {
-    const long long total = (long long)n_receivers * n_batches;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const int r = (int)(t / n_batches);
-        const unsigned int b = (unsigned int)(t - (long long)r * n_batches);
-        keys[t] = gen_mix64(gen_mix64(seed + (unsigned long long)(unsigned int)receivers[r]) + (unsigned long long)b);
-        vals[t] = b;
-    }
+__host__ __device__ inline unsigned int gen_mix32(unsigned int x) {  // murmur3's 32-bit finaliser
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    return x ^ (x >> 16);
 }
+struct GenPerm {
+    unsigned int rk[4];        // round keys
+    unsigned long long keepk;  // key of the per-batch delivery draw
+    unsigned int n;            // batches
+    unsigned int a;            // bits of the right half; the left half has w - a
+    unsigned int mask_r, mask_l;
+};
+__host__ __device__ inline GenPerm gen_perm_make(unsigned long long seed, unsigned int receiver_node, unsigned int n_batches) {
+    GenPerm g;
+    const unsigned long long key = gen_mix64(seed + (unsigned long long)receiver_node);
+    for (int i = 0; i < 4; ++i) g.rk[i] = (unsigned int)(gen_mix64(key + (unsigned long long)(i + 1)) >> 32);
+    g.keepk = gen_mix64(key ^ 0xD1B54A32D192ED03ull);
+    g.n = n_batches;
+    unsigned int w = 2;
+    while (w < 32u && (1ull << w) < (unsigned long long)n_batches) ++w;
+    g.a = w >> 1;
+    g.mask_r = (1u << g.a) - 1u;
+    g.mask_l = (unsigned int)((1ull << (w - g.a)) - 1ull);
+    return g;
+}
+__host__ __device__ inline unsigned int gen_perm_at(const GenPerm& g, unsigned int j) {  // j < n -> the batch delivered j-th
+    if (g.n <= 1u) return 0u;
+    unsigned int x = j;
+    do {
+        unsigned int r = x & g.mask_r, l = x >> g.a;
+        l ^= gen_mix32(r + g.rk[0]) & g.mask_l;
+        r ^= gen_mix32(l + g.rk[1]) & g.mask_r;
+        l ^= gen_mix32(r + g.rk[2]) & g.mask_l;
+        r ^= gen_mix32(l + g.rk[3]) & g.mask_r;
+        x = (l << g.a) | r;
+    } while (x >= g.n);
+    return x;
+}
+__host__ __device__ inline bool gen_delivered(const GenPerm& g, const unsigned int* keep, unsigned int b) {
+    return keep == nullptr || (unsigned int)(gen_mix64(g.keepk + (unsigned long long)b) >> 32) <= keep[b];
+}
+
+// The round's distinct alerts, resolved once per generation: res[a] = {dict_entry of alert a's subject, its core word without
+// the batch end}; an alert of another configuration id or about an unknown node gets the poison entry entries[n_nodes]
+// (dropped by the per-delivery filter; engine.hip: gen_clean).
+__global__ void gen_resolve_alerts_kernel(const unsigned char* alerts, long long n_alerts, long long cfg_id, unsigned int n_nodes,
+                                          const unsigned int* entries, uint2* res) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_alerts) return;
+    const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
+    const unsigned int* w = reinterpret_cast<const unsigned int*>(alerts + i * 20);
+    const bool current = w[0] == cfg_lo && w[1] == cfg_hi;
+    const unsigned int d = current && w[3] < n_nodes ? w[3] : n_nodes;
+    res[i] = make_uint2(entries[d], core_word(w[4]) & ~kCoreEob);
+}
+
 // grid = receivers, block = 256.  alerts = the round's distinct alerts (20-byte records) in batch order, boff[b] .. boff[b + 1]
-// = batch b; perm[r][j] = the j-th batch receiver r gets; every receiver gets all n_alerts records: rec_off[r] = r * n_alerts.
-// entries != nullptr: the first dword of a record is its subject's dict_entry (kDictResolved), else the subject itself.
-__global__ __launch_bounds__(256) void gen_streams_kernel(const unsigned char* alerts, const long long* boff, int n_batches, const unsigned int* perm,
-                                                          long long n_alerts, uint2* core, uint2* cfg, unsigned int* dstv, long long cfg_id,
-                                                          unsigned int n_nodes, const unsigned int* entries, unsigned int* load_flags) {
+// = batch b (never empty); every receiver's stream has n_alerts records: rec_off[r] = r * n_alerts.  boundary == 0: 8-byte
+// resident records {entry, core word} from res[]; else the 20-byte boundary records themselves (flags bit 0 = the batch end).
+// A batch ends with its last alert, whatever the flags of the set say.
+constexpr int kGenTile = 1024;  // deliveries per tile: four per thread
+__global__ __launch_bounds__(256) void gen_streams_kernel(const uint2* res, const unsigned char* alerts, const long long* boff, int n_batches,
+                                                          const unsigned int* keep, const int* receivers, long long n_alerts,
+                                                          unsigned long long seed, unsigned char* out, int boundary) {
+    __shared__ unsigned int s_start[kGenTile + 1];  // first output record of delivery i of the tile (relative to the tile)
+    __shared__ unsigned int s_first[kGenTile];      // first alert of its batch; 0xFFFFFFFF: not delivered to this receiver
     __shared__ int s_wave[16];
     const int r = (int)blockIdx.x, t = (int)threadIdx.x;
-    const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
-    const long long base = (long long)r * n_alerts;
-    long long carry = 0;
-    unsigned int other = 0u, range = 0u;
-    for (int j0 = 0; j0 < n_batches; j0 += (int)blockDim.x) {
-        const int j = j0 + t;
-        long long b0 = 0;
-        int len = 0;
-        if (j < n_batches) {
-            const unsigned int b = perm[(long long)r * n_batches + j];
-            b0 = boff[b];
-            len = (int)(boff[b + 1] - b0);
+    const GenPerm g = gen_perm_make(seed, (unsigned int)receivers[r], (unsigned int)n_batches);
+    long long at = (long long)r * n_alerts;
+    for (int j0 = 0; j0 < n_batches; j0 += kGenTile) {
+        unsigned int first[4];
+        int len[4], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = j0 + 4 * t + i;
+            first[i] = 0xFFFFFFFFu;
+            len[i] = 0;
+            if (j < n_batches) {
+                const unsigned int b = gen_perm_at(g, (unsigned int)j);
+                const long long b0 = boff[b];
+                len[i] = (int)(boff[b + 1] - b0);
+                if (gen_delivered(g, keep, b)) first[i] = (unsigned int)b0;
+            }
+            sum += len[i];
         }
         int total = 0;
-        const long long at = base + carry + block_exclusive_scan(len, s_wave, &total);
-        carry += total;
-        for (int k = 0; k < len; ++k) {
-            const unsigned int* w = reinterpret_cast<const unsigned int*>(alerts + (b0 + k) * 20);
-            const unsigned int c0 = w[0], c1 = w[1];
-            other |= (c0 ^ cfg_lo) | (c1 ^ cfg_hi);
-            range |= w[3] >= n_nodes ? 1u : 0u;
-            const unsigned int d = (w[3] >= kCoreStale ? kCoreStale - 1u : w[3]) | (((c0 ^ cfg_lo) | (c1 ^ cfg_hi)) != 0u ? kCoreStale : 0u);
-            // (a batch ends with its last alert, whatever the flags of the set say)
-            const unsigned int word = (core_word(w[4]) & ~kCoreEob) | (k == len - 1 ? kCoreEob : 0u);
-            dstv[at + k] = d;
-            cfg[at + k] = make_uint2(c0, c1);
-            core[at + k] = make_uint2(entries == nullptr ? d : entries[d < n_nodes ? d : n_nodes], word);
+        int base = block_exclusive_scan(sum, s_wave, &total);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s_start[4 * t + i] = (unsigned int)base;
+            s_first[4 * t + i] = first[i];
+            base += len[i];
         }
+        if (t == (int)blockDim.x - 1) s_start[kGenTile] = (unsigned int)total;
+        __syncthreads();
+        for (int o = t; o < total; o += (int)blockDim.x) {
+            int lo = 0, hi = kGenTile;  // the delivery that output record o belongs to: the last one that starts at or before o
+#pragma unroll
+            for (int step = 0; step < 10; ++step) {
+                const int mid = (lo + hi) >> 1;
+                const bool le = s_start[mid] <= (unsigned int)o;
+                lo = le ? mid : lo;
+                hi = le ? hi : mid;
+            }
+            const unsigned int k = (unsigned int)o - s_start[lo], f = s_first[lo];
+            const bool last = (unsigned int)o + 1u == s_start[lo + 1];
+            const long long i_out = at + o;
+            if (boundary == 0) {
+                uint2 v = make_uint2(0u, 0u);
+                if (f != 0xFFFFFFFFu) {
+                    v = res[f + k];
+                    v.y |= last ? kCoreEob : 0u;
+                }
+                reinterpret_cast<uint2*>(out)[i_out] = v;
+            } else {
+                unsigned int w[5] = {0u, 0u, 0u, 0u, 0u};
+                if (f != 0xFFFFFFFFu) {
+                    const unsigned int* src = reinterpret_cast<const unsigned int*>(alerts + (long long)(f + k) * 20);
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) w[q] = src[q];
+                    w[4] = (w[4] & ~0x01000000u) | (last ? 0x01000000u : 0u);
+                }
+                unsigned int* dst = reinterpret_cast<unsigned int*>(out + i_out * 20);
+#pragma unroll
+                for (int q = 0; q < 5; ++q) dst[q] = w[q];
+            }
+        }
+        at += total;
+        __syncthreads();
     }
-    const unsigned int f = (__ballot(other != 0u) != 0ull ? 1u : 0u) | (__ballot(range != 0u) != 0ull ? 2u : 0u);
-    if (f != 0u && (threadIdx.x & 63u) == 0u) atomicOr(load_flags, f);
 }
 __global__ void gen_offsets_kernel(long long* rec_off, int n_receivers, long long n_alerts) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);

@@ -57,6 +57,7 @@ namespace rapid {
 
 constexpr int kWave = 64;
 constexpr int kRecBytes = 20;   // a rapid_alert_record as it crosses the boundary
+constexpr long long kMaxStreamRecords = ((1ll << 32) - (1ll << 20)) / 20;  // one receiver's stream is addressed with 32-bit byte offsets
 constexpr int kCoreBytes = 8;   // what a tally launch reads per delivered record: {the subject's dictionary entry (or, in the cross-check
                                 // modes, its node index), core word} -- beside them, read by no launch: the subject again and the
                                 // configuration id (src is never read: R/MultiNodeCutDetector.java:101)
@@ -65,7 +66,6 @@ constexpr int kCoreBytes = 8;   // what a tally launch reads per delivered recor
 #endif
 constexpr int kQ = RAPID_QUARTERS;        // quarters (64 records each) per window
 constexpr int kWin = kQ * kWave;          // 256 records = 5 KiB of stream per window
-constexpr int kQuarterBytes = kWave * kCoreBytes;
 static_assert(kQ >= 1 && kQ <= 16, "window size");
 constexpr int kScratchWords = (kQ + 1) * kWave;  // carried quarter + window, one decoded word per record
 #ifndef RAPID_UNDO_CAP
@@ -471,14 +471,40 @@ __device__ inline void exact_batch_end(const D& d, RxScalars& s, const unsigned 
 // that still fails the membership filter or names a ring the index was not built for is then an ERROR of the stream (sticky
 // flag, RAPID_EINVAL) instead of being dropped per delivery.
 // --------------------------------------------------------------------------------------------------------------
-struct Window {  // the resident core entries of kQ x 64 records, lane l of quarter q = record 64 q + l
-    unsigned int w3[kQ], w4[kQ];  // subject (| kCoreStale); core word
+// Two record formats reach the kernel (TallyParams::core points at either):
+//   kFmtBoundary -- the 20-byte rapid_alert_record exactly as it crosses the C ABI (SURVEY 8d's unit): {configuration id, src, dst,
+//       ring mask | status | flags}.  THE product path of loaded streams: a delivered record is read from HBM once, by this
+//       kernel, and by nothing else -- the configuration-id check of R/MembershipService.java:653-657, the conversion to the core
+//       word and the node -> slot lookup (tables in LDS, or through L2 for populations whose tables do not fit) all happen on
+//       the record's way through the registers.  Lane l of quarter q loads {cfg id} and {dst, word} of record 64 q + l with two
+//       buffer_load_dwordx2 at a lane stride of 20 B (a quarter is 1,280 contiguous bytes; src shares their cache lines and is
+//       never loaded into a register: R/MultiNodeCutDetector.java:101 never reads it);
+//   kFmtResident -- 8 bytes {the subject's dict_entry, core word}: what rapid_sim_generate writes when the round's deliveries
+//       are made on the device (the subjects are resolved while the records are laid down: kDictResolved, no lookup here).
+enum { kFmtResident = 0, kFmtBoundary = 1 };
+template <int kFmt>
+struct WindowT {  // kQ x 64 records in flight, lane l of quarter q = record 64 q + l
+    unsigned int w3[kQ], w4[kQ];  // resident: dict_entry (or subject); core word
+};
+template <>
+struct WindowT<kFmtBoundary> {
+    unsigned int c0[kQ], c1[kQ], w3[kQ], w4[kQ];  // configuration id (low, high); dst; dword 4 of the boundary record
 };
 enum { kApplied = 0, kWitnessFails = 1, kNotFastable = 2 };  // outcome of a fast-window attempt
 
-template <int kDictMode, bool kTrusted>
+#ifndef RAPID_SETS
+#define RAPID_SETS 3
+#endif
+#ifndef RAPID_SETS_BOUNDARY
+#define RAPID_SETS_BOUNDARY 2
+#endif
+
+template <int kDictMode, bool kTrusted, int kFmt = kFmtResident>
 __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kernel(TallyParams p) {
+    static_assert(kFmt == kFmtResident || kDictMode != kDictResolved, "a boundary record carries its subject, not an entry");
     constexpr bool kTablesInLds = kDictMode == kDictDirect;
+    constexpr int kStride = kFmt == kFmtBoundary ? kRecBytes : kCoreBytes;  // bytes from one record to the next
+    constexpr unsigned int kQuarterB = (unsigned int)(kWave * kStride);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = (int)(threadIdx.x & 63u);
     const int wave = (int)(threadIdx.x >> 6);
@@ -585,7 +611,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     int n_applied = 0;
     unsigned int sink = 0u;  // stream-only mode: keeps the loads alive
 
-    typedef Window Win;
+    typedef WindowT<kFmt> Win;
+    struct Rec {  // a window as the paths below see it, whatever the format it arrived in
+        unsigned int w3[kQ], w4[kQ];  // subject (resident: its dict_entry, or the subject | kCoreStale); core word (core_word)
+    };
     struct Stream {  // a receiver's delivered records
         const unsigned char* base;
         unsigned int bytes;
@@ -599,17 +628,47 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             reinterpret_cast<const unsigned char*>(((unsigned long long)uniform((unsigned int)(b >> 32)) << 32) | (unsigned long long)uniform((unsigned int)b)),
             uniform(st.bytes));
 #pragma unroll
-        for (int q = 0; q < kQ; ++q) stream_load2(rsrc, voff, (unsigned int)(q * kQuarterBytes), W.w3[q], W.w4[q]);
+        for (int q = 0; q < kQ; ++q) {
+            if constexpr (kFmt == kFmtBoundary) {
+                stream_load2(rsrc, voff, (unsigned int)q * kQuarterB, W.c0[q], W.c1[q]);
+                stream_load2(rsrc, voff, (unsigned int)q * kQuarterB + 12u, W.w3[q], W.w4[q]);
+            } else {
+                stream_load2(rsrc, voff, (unsigned int)q * kQuarterB, W.w3[q], W.w4[q]);
+            }
+        }
+    };
+    // A window OPENED: subject and core word per record.  Resident records are stored that way.  A boundary record becomes one
+    // here, on its way through the registers: the configuration-id comparison of R/MembershipService.java:653-657 (another id:
+    // the alert is dropped -- its rings and status are cleared, its batch end stays, a batch ends whether or not its last alert
+    // is dropped), the status byte as two bits, the batch-end flag in bit 16 (core_word).  An alert without ring numbers does
+    // nothing in the reference (aggregateForProposal(AlertMessage) iterates over them, R/MultiNodeCutDetector.java:76-82) and is
+    // cleared the same way -- which also makes the zeros behind a stream's end the empty record they are in the resident format.
+    const unsigned int cfg_lo = (unsigned int)(unsigned long long)p.cfg_id, cfg_hi = (unsigned int)((unsigned long long)p.cfg_id >> 32);
+    auto open = [&](const Win& c) -> Rec {
+        Rec x;
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) {
+            if constexpr (kFmt == kFmtBoundary) {
+                const unsigned int other = (c.c0[q] ^ cfg_lo) | (c.c1[q] ^ cfg_hi);
+                const unsigned int raw = c.w4[q];
+                const unsigned int rings = raw & kCoreRings;
+                const unsigned int live = other == 0u ? rings : 0u;
+                const unsigned int eobw = (raw >> 8) & kCoreEob;
+                const unsigned int full = rings | ((raw & 0x00FF0000u) != 0u ? kCoreDown : kCoreUp) | eobw;
+                x.w3[q] = c.w3[q];
+                x.w4[q] = live != 0u ? full : eobw;
+            } else {
+                x.w3[q] = c.w3[q];
+                x.w4[q] = c.w4[q];
+            }
+        }
+        return x;
     };
     auto make_stream = [&](long long rec0, long long rec1) -> Stream {
         Stream st;
-        st.base = p.core + (unsigned long long)rec0 * kCoreBytes;
-        st.bytes = (unsigned int)((rec1 - rec0) * kCoreBytes);
+        st.base = p.core + (unsigned long long)rec0 * kStride;
+        st.bytes = (unsigned int)((rec1 - rec0) * kStride);
         return st;
-    };
-    auto uniform64 = [&](long long v) -> long long {  // a vector load of a wave-uniform address: back into SGPRs
-        return (long long)(((unsigned long long)uniform((unsigned int)((unsigned long long)v >> 32)) << 32) |
-                           (unsigned long long)uniform((unsigned int)(unsigned long long)v));
     };
 
     // ---- per record: the subject's dictionary entry, and the record's EFFECTIVE core word ----
@@ -668,7 +727,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     //   built for -- is ONE AND with the entry, collected in `uncovered` (sticky error, results void);
     //   otherwise: stale or unknown subject (the poison entry), empty ring list, UP / DOWN against the membership per delivery.
     unsigned int uncovered = 0u;  // per lane: what delivered reports name that the index was not built for
-    auto effective = [&](const Win& c, int q, const Look& k) -> unsigned int {
+    auto effective = [&](const Rec& c, int q, const Look& k) -> unsigned int {
         const unsigned int w = c.w4[q];
         if (kTrusted) {
             uncovered |= w & k.entry;
@@ -687,7 +746,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         unsigned int slot, bits;
         bool down;
     };
-    auto decode_rec = [&](const Win& c, int q) -> Dec {
+    auto decode_rec = [&](const Rec& c, int q) -> Dec {
         const Look k = lookup(c.w3[q]);
         const unsigned int w = effective(c, q, k);
         Dec r;
@@ -716,17 +775,15 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // all requested (a window that is being tallied has kSets - 1 successors in flight -- with one, a wave would wait out a
     // whole memory latency per window as soon as a window's tally is shorter than that, which it is since the fast window
     // shrank to ~100 instructions: 15 waves x 2 KiB per CU are not enough bytes in flight for 8 TB/s).  Three sets of 8 registers.
-#ifndef RAPID_SETS
-#define RAPID_SETS 3
-#endif
-    constexpr int kSets = RAPID_SETS;  // (2: measurement builds)
+    // (boundary records: two sets of 16 registers -- 10 KiB of stream in flight per wave against 6 KiB of the resident format)
+    constexpr int kSets = kFmt == kFmtBoundary ? RAPID_SETS_BOUNDARY : RAPID_SETS;
     static_assert(kSets >= 2 && kSets <= 6, "window sets");
-    constexpr unsigned int kWinBytes = (unsigned int)(kWin * kCoreBytes);
+    constexpr unsigned int kWinBytes = (unsigned int)(kWin * kStride);
     Win S[kSets];
     Stream rsrc;
     rsrc.base = p.core;
     rsrc.bytes = 0u;
-    const unsigned int lane_off = (unsigned int)lane * (unsigned int)kCoreBytes;  // this lane's byte offset inside a quarter
+    const unsigned int lane_off = (unsigned int)lane * (unsigned int)kStride;  // this lane's byte offset inside a quarter
     if (p.stagger > 0 && (wave & 1) != 0) {  // every other wave starts late (see TallyParams::stagger)
         for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
@@ -902,12 +959,13 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         auto slot_word = [&](unsigned int so) -> unsigned int* {  // the state word of the slot whose doubled number is `so`
             return reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(d.st) + 2u * so);
         };
-        auto fast_try = [&](const Win& c) -> int {
+        auto fast_try = [&](const Win& cw) -> int {
 #ifdef RAPID_PROBE_STREAM  // measurement builds only (results are void): what the turn loop costs with the tally taken out
 #pragma unroll
-            for (int q = 0; q < kQ; ++q) sink ^= c.w3[q] ^ c.w4[q];
+            for (int q = 0; q < kQ; ++q) sink ^= cw.w3[q] ^ cw.w4[q];
             return kApplied;
 #endif
+            const Rec c = open(cw);
             unsigned int so[kQ], w[kQ];
             // (everything that can stay in vector registers does: the CU's waves share ONE scalar pipe, and it is the busiest
             // unit of this kernel.  "Does the window say anything about the witness" is a running minimum of slot ^ witness,
@@ -982,7 +1040,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         // nothing crosses H anywhere in the window and the reference cannot emit.  The window's entrants (each crossing of
         // L is seen by exactly one lane, whatever the order of the atomics) are in preProposal from here on with a bound
         // below H: the first witnesses.
-        auto cold_window = [&](const Win& c) -> bool {
+        auto cold_window = [&](const Win& cw) -> bool {
+            const Rec c = open(cw);
             const unsigned long long mEl = wave_ballot((c.w4[kQ - 1] & kCoreEob) != 0u);
             if (mEl == 0ull) return false;
             const int ncl = kWave - __clzll((long long)mEl);
@@ -1148,7 +1207,8 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         };
         // ---- SLOW window: the carried records and the window, decoded into the scratch list, go through the careful and
         // the exact path.  Everything is consumed: no carry afterwards.
-        auto slow_window = [&](const Win& c, int w) {
+        auto slow_window = [&](const Win& cw, int w) {
+            const Rec c = open(cw);
             flush_pending();
             fold_batches();
             const int base_rec = w * kWin;
@@ -1331,7 +1391,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
                 if (!claimed && w + kClaimAhead >= nwin) claim();
                 if ((p.flags & 32) != 0) {  // measurement aid: stream the records through the registers without tallying them
 #pragma unroll
-                    for (int q = 0; q < kQ; ++q) sink ^= cur.w3[q] ^ cur.w4[q];
+                    for (int q = 0; q < kQ; ++q) {
+                        sink ^= cur.w3[q] ^ cur.w4[q];
+                        if constexpr (kFmt == kFmtBoundary) sink ^= cur.c0[q] ^ cur.c1[q];
+                    }
                     next_general();
                     continue;
                 }

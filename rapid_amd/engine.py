@@ -303,26 +303,39 @@ class ClusterSimulation:
                                                          self.n_receivers))
 
     def load_streams_device(self, d_records_ptr, records_bytes, d_rec_off_ptr, n_receivers, keepalive=None):
+        """20-byte records already in device memory, copied into the engine's buffer (the offsets stay borrowed)."""
         self._keep = keepalive
         self.n_receivers = n_receivers
         self.e._check(self.e._lib.rapid_sim_load_streams_device(self.e._h, d_records_ptr, records_bytes, d_rec_off_ptr,
                                                                 n_receivers))
 
-    def generate(self, batches, receivers, seed, trust_copies=False):
+    def attach_streams_device(self, d_records_ptr, records_bytes, d_rec_off_ptr, n_receivers, keepalive=None):
+        """20-byte records in device memory, tallied IN PLACE (rapid_sim_attach_streams_device): nothing is copied; both
+        buffers stay borrowed until the next load / attach / generate -- `keepalive` holds them."""
+        self._keep = keepalive
+        self.n_receivers = n_receivers
+        self.e._check(self.e._lib.rapid_sim_attach_streams_device(self.e._h, d_records_ptr, records_bytes, d_rec_off_ptr,
+                                                                  n_receivers))
+
+    def generate(self, batches, receivers, seed, trust_copies=False, keep=None, boundary=False):
         """The round's deliveries made on the device (rapid_sim_generate): every receiver gets every batch of `batches`
         (scenarios.BatchSet) once, in the order scenarios.deliver_hashed states on the host; `batches.recs` is the declared
-        alert set of the round."""
+        alert set of the round.  keep: per-batch 32-bit delivery thresholds (None: every batch reaches every receiver).
+        boundary: write the 20-byte boundary records instead of resolved 8-byte ones."""
         recs = np.ascontiguousarray(batches.recs, dtype=ALERT_DTYPE)
         off = np.ascontiguousarray(batches.off, dtype=np.int64)
         rx = np.ascontiguousarray(receivers, dtype=np.int32)
+        kp = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint32)
+        assert kp is None or len(kp) == len(off) - 1
         self.n_receivers = len(rx)
-        self.e._check(self.e._lib.rapid_sim_generate(self.e._h, _addr(recs) if len(recs) else None, _addr(off), len(off) - 1,
-                                                     _addr(rx) if len(rx) else None, len(rx), C.c_uint64(int(seed) & ((1 << 64) - 1))))
+        self.e._check(self.e._lib.rapid_sim_generate(self.e._h, _addr(recs) if len(recs) else None, _addr(off), len(off) - 1, _addr(kp),
+                                                     _addr(rx) if len(rx) else None, len(rx), C.c_uint64(int(seed) & ((1 << 64) - 1)),
+                                                     1 if boundary else 0))
         if trust_copies:
             self.e._check(self.e._lib.rapid_sim_trust_alert_copies(self.e._h, 1))
 
     def read_records(self, first, n):
-        """Testing aid: (subjects, core words) of n resident records."""
+        """Testing aid: (subjects -- or, of generated resolved records, their dictionary entries --, core words) of n records."""
         subj = np.zeros(max(n, 1), dtype=np.uint32)
         words = np.zeros(max(n, 1), dtype=np.uint32)
         self.e._check(self.e._lib.rapid_debug_read_records(self.e._h, C.c_int64(int(first)), int(n), _addr(subj), _addr(words)))
@@ -428,13 +441,12 @@ class ClusterSimulation:
         keys = ("hot_subjects", "adjacency_entries", "waves_per_workgroup", "workgroups", "lds_bytes_per_workgroup",
                 "alerts_prevalidated", "dict_mode", "alert_set_declared")
         out = {k: int(v) for k, v in zip(keys, info)}
-        # dict_mode: 3 = the records carry their subjects' resolved entries (no lookup in the tally); 0 = tables in memory,
-        # 1 = direct tables in LDS, 2 = compressed tables in LDS (cross-check modes)
+        # dict_mode -- where the tally maps a boundary record's subject to its slot: 1 = direct tables in LDS, 2 = compressed
+        # tables in LDS, 0 = tables in memory (through L2); 3 = nowhere: generated records carry their subjects' entries
         out["tables_in_lds"] = int(out["dict_mode"] in (1, 2))
         out["index_build_ms"] = round(ms.value, 4)
         t = np.zeros(4, dtype=np.float32)
         self.e._check(self.e._lib.rapid_sim_pass_times(self.e._h, _addr(t)))
-        out["resolve_ms"] = round(float(t[1]), 4)
         out["generate_ms"] = round(float(t[2]), 4)
         return out
 

@@ -239,30 +239,92 @@ def mix64(x):
     return x ^ (x >> np.uint64(31))
 
 
-def hashed_order(seed, receiver, n_batches):
-    """The order in which rapid_sim_generate delivers the round's batches to `receiver` (its node index): ascending
-    key(r, b) = mix64(mix64(seed + r) + b), ties by b."""
+def mix32(x):
+    """murmur3's 32-bit finaliser on uint32 arrays (== gen_mix32 on the device)."""
+    x = np.asarray(x, dtype=np.uint32)
     with np.errstate(over="ignore"):
-        k0 = mix64(np.uint64(int(seed) & _M64) + np.uint64(int(receiver) & 0xFFFFFFFF))
-        keys = mix64(k0 + np.arange(n_batches, dtype=np.uint64))
-    return np.argsort(keys, kind="stable")
+        x = x ^ (x >> np.uint32(16))
+        x = x * np.uint32(0x85EBCA6B)
+        x = x ^ (x >> np.uint32(13))
+        x = x * np.uint32(0xC2B2AE35)
+    return x ^ (x >> np.uint32(16))
 
 
-def deliver_hashed(batches, receivers, seed):
+def _perm_keys(seed, receiver):
+    with np.errstate(over="ignore"):
+        key = mix64(np.uint64(int(seed) & _M64) + np.uint64(int(receiver) & 0xFFFFFFFF))
+        rk = [np.uint32(int(mix64(key + np.uint64(i + 1))) >> 32) for i in range(4)]
+        keepk = mix64(key ^ np.uint64(0xD1B54A32D192ED03))
+    return rk, keepk
+
+
+def hashed_order(seed, receiver, n_batches):
+    """The order in which rapid_sim_generate delivers the round's batches to `receiver` (its node index): position j holds
+    batch perm(j), a four-round alternating Feistel network over the smallest bit width covering n_batches, keyed by
+    mix64(seed + receiver), walked until it lands below n_batches (csrc/index_kernels.h: gen_perm_at)."""
+    n = int(n_batches)
+    if n <= 1:
+        return np.zeros(n, dtype=np.int64)
+    rk, _ = _perm_keys(seed, receiver)
+    w = 2
+    while (1 << w) < n:
+        w += 1
+    a = w >> 1
+    mask_r, mask_l = np.uint32((1 << a) - 1), np.uint32((1 << (w - a)) - 1)
+    x = np.arange(n, dtype=np.uint32)
+    out = np.zeros(n, dtype=np.int64)
+    todo = np.arange(n)
+    with np.errstate(over="ignore"):
+        while len(todo):
+            r, l = x & mask_r, x >> np.uint32(a)
+            l = l ^ (mix32(r + rk[0]) & mask_l)
+            r = r ^ (mix32(l + rk[1]) & mask_r)
+            l = l ^ (mix32(r + rk[2]) & mask_l)
+            r = r ^ (mix32(l + rk[3]) & mask_r)
+            x = (l << np.uint32(a)) | r
+            done = x < n
+            out[todo[done]] = x[done]
+            todo, x = todo[~done], x[~done]
+    return out
+
+
+def delivered_mask(seed, receiver, keep):
+    """Which batches reach `receiver` under the per-batch thresholds `keep` (uint32; None: all) -- gen_delivered on the device."""
+    if keep is None:
+        return None
+    keep = np.asarray(keep, dtype=np.uint32)
+    _, keepk = _perm_keys(seed, receiver)
+    with np.errstate(over="ignore"):
+        draw = (mix64(keepk + np.arange(len(keep), dtype=np.uint64)) >> np.uint64(32)).astype(np.uint32)
+    return draw <= keep
+
+
+def deliver_hashed(batches, receivers, seed, keep=None):
     """The host statement of rapid_sim_generate: every receiver gets every batch once, in hashed_order; the batch end is on
-    the last record of every batch.  Returns (records, rec_off[R+1], batches_per_receiver[R]) like deliver()."""
+    the last record of every batch.  keep: per-batch delivery thresholds -- the places of a batch that does not reach a
+    receiver hold EMPTY records (all zero: no ring, no batch end), so every stream has the same length.
+    Returns (records, rec_off[R+1], batches_per_receiver[R]) like deliver()."""
     B = batches.n_batches
     blen = np.diff(batches.off)
+    assert (blen > 0).all(), "a BatchedAlertMessage is never empty"
     R = len(receivers)
     A = int(batches.off[-1])
-    out = []
-    for r in receivers:
+    base = batches.recs.copy()
+    base["flags"] = 0
+    base["flags"][batches.off[1:] - 1] = FLAG_LAST_IN_BATCH  # a batch ends with its last alert, whatever the set's flags say
+    out, nb = [], np.full(R, B, dtype=np.int32)
+    for i, r in enumerate(receivers):
         perm = hashed_order(seed, int(r), B)
         lens = blen[perm]
         starts = np.repeat(batches.off[perm] - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens)
-        out.append(batches.recs[starts + np.arange(A, dtype=np.int64)])
+        recs = base[starts + np.arange(A, dtype=np.int64)]
+        got = delivered_mask(seed, int(r), keep)
+        if got is not None:
+            recs[np.repeat(~got[perm], lens)] = np.zeros(1, dtype=ALERT_DTYPE)
+            nb[i] = int(got.sum())
+        out.append(recs)
     records = np.concatenate(out) if out else np.zeros(0, dtype=ALERT_DTYPE)
-    return records, np.arange(R + 1, dtype=np.int64) * A, np.full(R, B, dtype=np.int32)
+    return records, np.arange(R + 1, dtype=np.int64) * A, nb
 
 
 @dataclass

@@ -22,5 +22,5 @@ sim.set_alert_set(sc.batches.recs, trust_copies=True)
 ms = sim.time_tally(reps)
 st = sim.stats()
 probe = sim.stream_probe(0, 16, reps)
-print("workload", name, "records", len(sc.records), "stream_bytes", 8 * len(sc.records), "tally_ms", round(ms, 4), "GB/s",
+print("workload", name, "records", len(sc.records), "stream_bytes", 20 * len(sc.records), "tally_ms", round(ms, 4), "GB/s",
       round(20 * len(sc.records) / ms / 1e6, 1), "probe_ms", round(probe, 4), st, sim.index_info())

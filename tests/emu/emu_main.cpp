@@ -139,7 +139,8 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
                   const unsigned int* pairs, int n_hot, int n_adj, int* emit_batch, int* num_proposals,
                   int* prop_count, unsigned long long* fingerprint, int* props, int prop_cap, unsigned long long* stats,
                   int flags, int waves, int grid, int tables_in_lds, unsigned long long seed, const unsigned int* tbits,
-                  const unsigned short* trank, const unsigned int* tent, int n_touched, unsigned long long* vote_res_out) {
+                  const unsigned short* trank, const unsigned int* tent, int n_touched, unsigned long long* vote_res_out, int fmt) {
+    // fmt: 0 = resident records (split / resolved below), 1 = the 20-byte boundary records themselves (kFmtBoundary)
     // tables_in_lds: 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS, 3 = no dictionary: the
     // records carry their subjects' entries (kDictResolved, what resolve_records_kernel leaves in the first dword)
     const int lds = rapid::tally_shared_bytes(tables_in_lds, n_nodes, n_touched, n_hot, n_adj) + waves * rapid::tally_wave_bytes(n_hot) +
@@ -159,8 +160,9 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
         core[2 * i] = (w[3] >= rapid::kCoreStale ? rapid::kCoreStale - 1u : w[3]) | (stale ? rapid::kCoreStale : 0u);
         core[2 * i + 1] = rapid::core_word(w[4]);
     }
-    p.core = reinterpret_cast<const unsigned char*>(core.data());
+    p.core = fmt == 1 ? records : reinterpret_cast<const unsigned char*>(core.data());
     p.cfg = reinterpret_cast<const unsigned char*>(cfgs.data());
+    if (fmt == 1 && tables_in_lds == 3) return -6;  // a boundary record carries its subject, not an entry
     p.rec_off = rec_off;
     p.n_receivers = n_receivers;
     p.n_nodes = n_nodes;
@@ -229,6 +231,17 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
         std::memset(smem, 0xCD, sizeof(smem));  // poison: the kernel must initialise what it reads
         const bool trusted = (flags & 256) != 0;  // emulator-only selector of the kTrusted instantiation
         auto run = [&](auto kern) { emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { kern(p); }, seed + (unsigned)b); };
+        if (fmt == 1) {
+            switch (tables_in_lds * 2 + (trusted ? 1 : 0)) {
+                case 0: run(rapid::tally_population_kernel<rapid::kDictMemory, false, rapid::kFmtBoundary>); break;
+                case 1: run(rapid::tally_population_kernel<rapid::kDictMemory, true, rapid::kFmtBoundary>); break;
+                case 2: run(rapid::tally_population_kernel<rapid::kDictDirect, false, rapid::kFmtBoundary>); break;
+                case 3: run(rapid::tally_population_kernel<rapid::kDictDirect, true, rapid::kFmtBoundary>); break;
+                case 4: run(rapid::tally_population_kernel<rapid::kDictCompressed, false, rapid::kFmtBoundary>); break;
+                default: run(rapid::tally_population_kernel<rapid::kDictCompressed, true, rapid::kFmtBoundary>); break;
+            }
+            continue;
+        }
         switch (tables_in_lds * 2 + (trusted ? 1 : 0)) {
             case 0: run(rapid::tally_population_kernel<rapid::kDictMemory, false>); break;
             case 1: run(rapid::tally_population_kernel<rapid::kDictMemory, true>); break;
@@ -291,8 +304,8 @@ extern "C" int emu_index_run(const unsigned char* alerts, long long n_alerts, in
     const int touch_grid = (int)std::max<long long>(1, std::min<long long>(8, (n_alerts + 255) / 256));
     for (int b = 0; b < touch_grid && n_alerts > 0; ++b)
         emu::run_block((unsigned)b, (unsigned)touch_grid, 256u, [&] {
-            rapid::index_touch_kernel<false>(alerts, nullptr, n_alerts, n_nodes, (1u << K) - 1u, cfg_id, member, gmask,
-                                             reinterpret_cast<unsigned int*>(info + 4));
+            rapid::index_touch_kernel(alerts, n_alerts, n_nodes, (1u << K) - 1u, cfg_id, member, gmask,
+                                      reinterpret_cast<unsigned int*>(info + 4));
         }, seed + 100 + (unsigned)b);
     std::vector<int> blk;
     int n_chunks = 0;
@@ -325,28 +338,22 @@ extern "C" int emu_index_run(const unsigned char* alerts, long long n_alerts, in
     return 0;
 }
 
-// rapid_sim_generate's kernels (index_kernels.h): keys, (std::stable_sort for the device's segmented radix sort), streams laid
-// down in the resident layout.  core_out = [n][2] dwords, cfg_out = [n][2], dstv_out = [n]; entries may be null (subjects).
-extern "C" int emu_generate(const unsigned char* alerts, const long long* boff, int n_batches, const int* receivers, int n_receivers,
-                            unsigned long long seed, long long cfg_id, int n_nodes, const unsigned int* entries, unsigned int* core_out,
-                            unsigned int* cfg_out, unsigned int* dstv_out, long long* rec_off_out, unsigned int* flags_out, unsigned long long sd) {
-    const long long RB = (long long)n_receivers * n_batches, A = boff[n_batches];
-    std::vector<unsigned long long> keys((size_t)std::max<long long>(RB, 1));
-    std::vector<unsigned int> vals((size_t)std::max<long long>(RB, 1)), perm((size_t)std::max<long long>(RB, 1));
-    for (unsigned b = 0; b < 3u; ++b)
-        emu::run_block(b, 3u, 256u, [&] { rapid::gen_keys_kernel(receivers, n_receivers, n_batches, seed, keys.data(), vals.data()); }, sd + b);
-    for (int r = 0; r < n_receivers; ++r) {
-        std::vector<int> order(n_batches);
-        for (int i = 0; i < n_batches; ++i) order[i] = i;
-        const unsigned long long* k = keys.data() + (size_t)r * n_batches;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return k[a] < k[b]; });
-        for (int i = 0; i < n_batches; ++i) perm[(size_t)r * n_batches + i] = vals[(size_t)r * n_batches + order[i]];
+// rapid_sim_generate's kernels (index_kernels.h): the alert set resolved once, then one workgroup per receiver lays its stream
+// down (the seeded permutation evaluated in place).  boundary == 0: out = [n][2] dwords {entry, core word}, entries =
+// [n_nodes + 1] dict_entry per node (the poison entry last); else out = the 20-byte records.  keep: per-batch thresholds or null.
+extern "C" int emu_generate(const unsigned char* alerts, const long long* boff, int n_batches, const unsigned int* keep, const int* receivers,
+                            int n_receivers, unsigned long long seed, long long cfg_id, int n_nodes, const unsigned int* entries,
+                            unsigned char* out, int boundary, long long* rec_off_out, unsigned long long sd) {
+    const long long A = boff[n_batches];
+    std::vector<uint2> res((size_t)std::max<long long>(A, 1));
+    if (!boundary) {
+        const unsigned g = (unsigned)std::max<long long>(1, (A + 255) / 256);
+        for (unsigned b = 0; b < g; ++b)
+            emu::run_block(b, g, 256u, [&] { rapid::gen_resolve_alerts_kernel(alerts, A, cfg_id, (unsigned int)n_nodes, entries, res.data()); }, sd + b);
     }
-    flags_out[0] = flags_out[1] = 0u;
     for (int r = 0; r < n_receivers; ++r)
         emu::run_block((unsigned)r, (unsigned)n_receivers, 256u, [&] {
-            rapid::gen_streams_kernel(alerts, boff, n_batches, perm.data(), A, reinterpret_cast<uint2*>(core_out), reinterpret_cast<uint2*>(cfg_out), dstv_out,
-                                      cfg_id, (unsigned int)n_nodes, entries, flags_out);
+            rapid::gen_streams_kernel(res.data(), alerts, boff, n_batches, keep, receivers, A, seed, out, boundary);
         }, sd + 100 + (unsigned)r);
     const unsigned g = (unsigned)((n_receivers + 1 + 255) / 256);
     for (unsigned b = 0; b < g; ++b) emu::run_block(b, g, 256u, [&] { rapid::gen_offsets_kernel(rec_off_out, n_receivers, A); }, sd + 900 + b);

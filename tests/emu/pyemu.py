@@ -118,13 +118,15 @@ def validate_alerts(records, n_nodes, K, cfg_id, member):
 
 
 def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_cap=None, force_exact=0, seed=1, waves=3,
-          grid=2, tables_in_lds=1, trusted=False, declared=None, pool=False):
+          grid=2, tables_in_lds=1, trusted=False, declared=None, pool=False, fmt=None):
     """`declared`: build the round index from these records (the round's distinct alert set) instead of the delivered
     ones; the call then returns (results ..., covered) with covered = False if the kernel found a delivered report that
     the declared set does not contain.  pool: only the first deal (grid x waves receivers) is static, the rest is claimed
     from the kernel's common pool."""
     if pool:
         force_exact = force_exact | 512
+    if fmt is None:  # the product's pairing: 20-byte boundary records are looked up by the tally (tables_in_lds 0 / 1 / 2), resident
+        fmt = 0 if tables_in_lds == 3 else 1  # 8-byte records (what the generator writes) carry their subjects' entries (3)
     L_ = lib()
     recs = np.ascontiguousarray(records)
     raw = np.zeros(((recs.nbytes + 15) // 16) * 16 + 32, dtype=np.uint8)
@@ -149,7 +151,7 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
                           p(ix["dict"]), p(ix["decl"]), p(ix["node_of_slot"]), p(ix["adj_off"]), p(ix["adj"]),
                           ix["n_hot"], ix["n_adj"], p(emit), p(nprop), p(pcount), p(fp), p(props), prop_cap, p(stats),
                           force_exact, waves, grid, tables_in_lds, C.c_ulonglong(seed), p(ix["tbits"]), p(ix["trank"]), p(ix["tent"]),
-                          ix["n_touched"], p(vote_res))
+                          ix["n_touched"], p(vote_res), int(fmt))
     # the vote statistics the kernel gathers next to the proposals (TallyParams::vote_res) against the results themselves
     voters = np.flatnonzero(pcount != 0)
     assert int(vote_res[2]) == len(voters), (vote_res, len(voters))
@@ -293,8 +295,20 @@ def ids_merge(old, new, seed=1):
     return list(zip(out_h[:n].tolist(), out_l[:n].tolist()))
 
 
-def generate(batches, receivers, seed, cfg_id, n_nodes):
-    """rapid_sim_generate's kernels under the emulator -> (subjects, core words, configuration ids [n][2], rec_off, load flags)."""
+def dict_entries(ix, n_nodes):
+    """dict_entry per node + the poison entry (index_kernels.h: dict_entries_kernel) from build_round_index's tables."""
+    n_hot = ix["n_hot"]
+    d, decl = ix["dict"][:n_nodes].astype(np.uint32), ix["decl"][:n_nodes].astype(np.uint32)
+    sl = d & 0x3FFF
+    sl = np.where(sl == 0x3FFF, n_hot + (np.arange(n_nodes, dtype=np.uint32) & 63), sl).astype(np.uint32)
+    e = ((~decl) & 0x3FFF) | np.where((decl >> 15) != 0, 1 << 15, 1 << 14).astype(np.uint32) | (sl << 17)
+    return np.concatenate([e.astype(np.uint32), np.array([0xFFFF | (n_hot << 17)], dtype=np.uint32)])
+
+
+def generate(batches, receivers, seed, cfg_id, n_nodes, entries=None, keep=None, boundary=False):
+    """rapid_sim_generate's kernels under the emulator.  boundary: -> (records as ALERT_DTYPE, rec_off); else
+    -> (entries, core words, rec_off) of the resolved 8-byte records (`entries` = dict_entries(...) of the round's index)."""
+    from rapid_amd.scenarios import ALERT_DTYPE
     L_ = lib()
     recs = np.ascontiguousarray(batches.recs)
     raw = np.concatenate([recs.view(np.uint8).reshape(-1), np.zeros(32, dtype=np.uint8)])
@@ -302,15 +316,18 @@ def generate(batches, receivers, seed, cfg_id, n_nodes):
     rx = np.ascontiguousarray(receivers, dtype=np.int32)
     R, A = len(rx), int(off[-1])
     n = R * A
-    core = np.zeros(2 * n + 2, dtype=np.uint32)
-    cfg = np.zeros(2 * n + 2, dtype=np.uint32)
-    dstv = np.zeros(n + 1, dtype=np.uint32)
+    out = np.full(n * (20 if boundary else 8) + 8, 0xEE, dtype=np.uint8)
     rec_off = np.zeros(R + 1, dtype=np.int64)
-    flags = np.zeros(2, dtype=np.uint32)
-    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    kp = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint32)
+    ent = None if entries is None else np.ascontiguousarray(entries, dtype=np.uint32)
+    assert boundary or ent is not None
+    p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
     L_.emu_generate.restype = C.c_int
-    rc = L_.emu_generate(p(raw), p(off), len(off) - 1, p(rx), R, C.c_ulonglong(int(seed) & ((1 << 64) - 1)), C.c_longlong(cfg_id), n_nodes, None,
-                         p(core), p(cfg), p(dstv), p(rec_off), p(flags), C.c_ulonglong(3))
+    rc = L_.emu_generate(p(raw), p(off), len(off) - 1, p(kp), p(rx), R, C.c_ulonglong(int(seed) & ((1 << 64) - 1)), C.c_longlong(cfg_id), n_nodes,
+                         p(ent), p(out), 1 if boundary else 0, p(rec_off), C.c_ulonglong(3))
     assert rc == 0, rc
-    core = core[: 2 * n].reshape(n, 2)
-    return dstv[:n], core[:, 1].copy(), core[:, 0].copy(), cfg[: 2 * n].reshape(n, 2), rec_off, flags
+    assert (out[n * (20 if boundary else 8):] == 0xEE).all()  # nothing written behind the last stream
+    if boundary:
+        return out[: n * 20].view(ALERT_DTYPE).copy(), rec_off
+    core = out[: n * 8].view(np.uint32).reshape(n, 2)
+    return core[:, 0].copy(), core[:, 1].copy(), rec_off

@@ -574,11 +574,12 @@ def test_full_size_c3_against_fast_oracle(E):
         assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
         for r in range(0, len(fe), 97):
             assert sorted(sim.proposal(r)) == fpp[fo[r]:fo[r + 1]].tolist()
-        # bench.py's own form of the round: the distinct alerts declared (index built from the set, not from the streams) and
-        # the per-delivery configuration-id check waived on the load pass's verdict -- the instantiation `value` is measured with
+        # bench.py's own form of the round: the distinct alerts declared (index built from the set, not from the streams), the
+        # deliveries vouched for as copies, the 20-byte records tallied where they lie with the tables in LDS -- the
+        # instantiation `value` is measured with
         sim_b, res_b = run_population(E, eng, sc.records, sc.rec_off, alert_set=sc.batches.recs, trust=True)
         info_b = sim_b.index_info()
-        assert info_b["alerts_prevalidated"] == 1 and info_b["alert_set_declared"] == 1 and info_b["dict_mode"] == 3
+        assert info_b["alerts_prevalidated"] == 1 and info_b["alert_set_declared"] == 1 and info_b["dict_mode"] == 1
         assert all(np.array_equal(a_, b_) for a_, b_ in zip((emit, nprop, pcount, fp), res_b))
         for r in range(0, len(fe), 997):
             assert sorted(sim_b.proposal(r)) == fpp[fo[r]:fo[r + 1]].tolist()
@@ -827,9 +828,9 @@ def test_sharded_vote_count_merges_the_ranks_local_answers(E):
 
 def test_streams_handed_over_in_device_memory(E):
     """rapid_sim_load_streams_device: the 20-byte records already sit in device memory (as a producer on the same GPU
-    would leave them; here allocated through the HIP runtime the library itself uses) -- split into the engine's resident
-    arrays by the same pass as the host form, with the same results; the record buffer may be released right after the
-    call, the offsets stay borrowed."""
+    would leave them; here allocated through the HIP runtime the library itself uses) -- copied into the engine's buffer,
+    with the same results as the host form; the record buffer may be released right after the call, the offsets stay
+    borrowed.  rapid_sim_attach_streams_device: the same records tallied IN PLACE, nothing copied (both buffers borrowed)."""
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")
     hip.hipMalloc.argtypes, hip.hipMemcpy.argtypes, hip.hipFree.argtypes = [C.POINTER(C.c_void_p), C.c_size_t], [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int], [C.c_void_p]
@@ -862,8 +863,24 @@ def test_streams_handed_over_in_device_memory(E):
     assert all(np.array_equal(a, b) for a, b in zip(want, got))
     rr = sim.count_votes()
     assert (rr.decided, rr.votes_winner, rr.cut_size) == (rr0.decided, rr0.votes_winner, rr0.cut_size) and rr.decided == 1
+    # in place: the engine reads the caller's buffer (at a 4-byte aligned, not 16-byte aligned, address)
+    pad = np.zeros(12, dtype=np.uint8)
+    d_rec2 = to_device(np.concatenate([pad, raw]))
+    sim.attach_streams_device(d_rec2.value + 12, raw.nbytes, d_off.value, len(sc.rec_off) - 1)
+    for declared in (False, True):
+        if declared:
+            sim.set_alert_set(sc.batches.recs, trust_copies=True)
+        sim.new_round()
+        sim.tally()
+        assert all(np.array_equal(a, b) for a, b in zip(want, sim.results())), declared
+        rr = sim.count_votes()
+        assert (rr.decided, rr.votes_winner, rr.cut_size) == (rr0.decided, rr0.votes_winner, rr0.cut_size)
+    with pytest.raises(E.IllegalArgumentException):
+        sim.attach_streams_device(d_rec2.value + 13, raw.nbytes, d_off.value, len(sc.rec_off) - 1)  # not 4-byte aligned
+    with pytest.raises(E.IllegalArgumentException):
+        sim.attach_streams_device(d_rec2.value + 12, raw.nbytes - 20, d_off.value, len(sc.rec_off) - 1)  # does not cover the records
     eng.close()
-    assert hip.hipFree(d_off) == 0
+    assert hip.hipFree(d_off) == 0 and hip.hipFree(d_rec2) == 0
 
 
 
@@ -964,12 +981,13 @@ def test_tables_in_memory_mode_vs_faithful_oracle(E, name, n, f, K, H, L):
     oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, np.concatenate(parts), sub_off, nthreads=8)
     want_fp = proposal_fingerprints(oo, op, oe >= 0)
     sim0, ref = run_population(E, eng, sc.records, sc.rec_off)
-    assert sim0.index_info()["dict_mode"] == 3  # the product: the records carry their subjects' resolved entries
-    # the cross-check modes, in which the tally looks the subject up itself -- 32768: from the tables where they fit best
-    # (direct, in LDS), 128: compressed tables in LDS, 256: tables in memory; alone: the pre-validated instantiation (every
-    # delivered alert passes the filter); | 64: per-delivery filter; | 1: exact path
+    assert sim0.index_info()["dict_mode"] == 1  # the product at this size: the 20-byte records looked up in direct tables in LDS
+    # where the tally looks a record's subject up -- nothing: the tables where they fit best (direct, in LDS), 128: compressed
+    # tables in LDS, 256: tables in memory (through L2); alone: the pre-validated instantiation (every delivered alert passes
+    # the filter); | 64: per-delivery filter; | 1: exact path
     # 4096: the round index built by several workgroups (count / assign / adjacency), the form of populations >= 40,000 nodes
-    for mode_knob, mode in ((32768, 1), (128, 2), (256, 0), (4096, 3), (4096 | 128, 2), (4096 | 256, 0), (0, 3)):
+    # (such a round never has direct tables)
+    for mode_knob, mode in ((0, 1), (128, 2), (256, 0), (4096, 2), (4096 | 128, 2), (4096 | 256, 0)):
       for kw in (dict(force_exact=mode_knob), dict(force_exact=mode_knob | 64), dict(force_exact=mode_knob, alert_set=sc.batches.recs),
                  dict(force_exact=mode_knob | 64, alert_set=sc.batches.recs), dict(force_exact=mode_knob | 1)):
         sim, res = run_population(E, eng, sc.records, sc.rec_off, **kw)
@@ -994,12 +1012,9 @@ def test_c4_shaped_shard_against_fast_oracle(E):
     fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=16)
     for kw in (dict(), dict(alert_set=sc.batches.recs)):
         sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off, **kw)
-        assert sim.index_info()["dict_mode"] == 3
+        assert sim.index_info()["dict_mode"] == 2  # 400 KB of plain tables do not fit the LDS, the compressed form does
         assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
         assert np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
-    # the cross-check modes at this size: 2 x 200 KB of plain tables do not fit the LDS, the compressed form does ...
-    sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off, force_exact=32768)
-    assert sim.index_info()["dict_mode"] == 2 and np.array_equal(emit, fe) and np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
     sim, (emit, nprop, pcount, fp) = run_population(E, eng, sc.records, sc.rec_off, force_exact=256)  # ... and from memory
     assert sim.index_info()["dict_mode"] == 0 and np.array_equal(emit, fe) and np.array_equal(fp, proposal_fingerprints(fo, fpp, fe >= 0))
     assert np.all(fe >= 0) and sorted(sim.proposal(0)) == sc.faulty.tolist()
@@ -1028,7 +1043,7 @@ def test_c4_full_shard_against_fast_oracle(E):
     want_fp = proposal_fingerprints(fo, fpp, fe >= 0)
     sim, (emit, nprop, pcount, fp) = run_population(E, eng, records, rec_off, alert_set=sc0.batches.recs, trust=True)
     info = sim.index_info()
-    assert info["alerts_prevalidated"] == 1 and info["dict_mode"] == 3
+    assert info["alerts_prevalidated"] == 1 and info["dict_mode"] == 2
     assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
     assert np.array_equal(fp, want_fp)
     assert np.all(fe >= 0) and np.all(pcount == len(sc0.faulty))
@@ -1112,11 +1127,13 @@ def test_streaming_rounds_with_stale_records_and_the_observer_cache(E):
 
 
 def test_streams_generated_on_the_device(E):
-    """rapid_sim_generate: the round's deliveries made on the device -- every receiver gets every batch once, in the
-    order of mix64(mix64(seed + receiver) + batch) -- directly in the resident layout, subjects already resolved.  Against the
-    host statement scenarios.deliver_hashed: the resident records themselves (subjects, core words) are equal; the tally over
-    the generated streams equals the tally over the same streams loaded through the boundary, and the oracle fed those
-    records; the round decides the same cut.  No load pass and no resolve pass run for generated streams."""
+    """rapid_sim_generate: the round's deliveries made on the device -- every receiver gets every batch once, in a
+    seeded permutation of its own evaluated in place (no keys, no sort).  Against the host statement scenarios.deliver_hashed:
+    the 20-byte boundary records are equal byte for byte; the resolved 8-byte records hold the subjects' dictionary entries and
+    the core words; the tally over either equals the tally over the host's records loaded through the boundary, and the
+    oracle fed those records; the round decides the same cut.  Per-batch delivery thresholds: late batches of the previous
+    configuration reach some receivers only, their places are empty records elsewhere."""
+    from tests.emu import pyemu
     K, H, L = 10, 9, 4
     for n, n_crash, n_join, seed in ((2000, 20, 0, 2), (1500, 30, 12, 977)):
         pop = S.Population.make(n + 40)
@@ -1126,40 +1143,100 @@ def test_streams_generated_on_the_device(E):
         sc = S.build_churn_scenario(obs, member, cfg, n_crash, n_join, H, L, materialise=False)
         rx = sc.receivers
         want, want_off, nb = S.deliver_hashed(sc.batches, rx, seed)
-        sim = E.ClusterSimulation(eng)
-        sim.generate(sc.batches, rx, seed)
-        info = sim.index_info()
-        assert info["dict_mode"] == 3 and info["alert_set_declared"] == 1 and info["resolve_ms"] == 0.0
         A = int(sc.batches.off[-1])
-        for first in (0, A - 7, (len(rx) // 2) * A + 3, len(want) - 1000):
-            first = max(0, first)
-            m = min(1000, len(want) - first)
-            dst, words = sim.read_records(first, m)
-            seg = want[first:first + m]
-            assert np.array_equal(dst, seg["dst"])
-            assert np.array_equal(words, (seg["ring_mask"].astype(np.uint32) & 0x3FFF) | np.where(seg["status"] != 0, 1 << 14, 1 << 15).astype(np.uint32)
-                                  | ((seg["flags"].astype(np.uint32) & 1) << 16))
-        sim.tally()
-        got = sim.results()
-        rr = sim.count_votes()
-        cut = sim.decided_cut() if rr.decided else None
         fe, fn, fo, fpp = O.fast_sim_run(pop.n, K, H, L, cfg, obs, subj, member, want, want_off, nthreads=16)
-        assert np.array_equal(got[0], fe) and np.array_equal(got[1], fn) and np.array_equal(got[2], np.diff(fo))
-        assert np.array_equal(got[3], proposal_fingerprints(fo, fpp, fe >= 0))
         sim2, ref = run_population(E, eng, want, want_off, alert_set=sc.batches.recs)
-        assert all(np.array_equal(a, b) for a, b in zip(ref, got))
         rr2 = sim2.count_votes()
-        assert (rr.decided, rr.votes_winner, rr.cut_size) == (rr2.decided, rr2.votes_winner, rr2.cut_size) and rr.decided == 1
-        assert cut == sim2.decided_cut() and sorted(cut) == sc.faulty.tolist()
-        # the per-delivery filter and a cross-check mode on generated streams (generated again: the knob decides what the
-        # records' first dwords hold)
-        for knob in (64, 32768):
-            sim.set_force_exact(knob)
-            sim.generate(sc.batches, rx, seed)
+        assert np.array_equal(ref[0], fe) and np.array_equal(ref[1], fn) and np.array_equal(ref[2], np.diff(fo))
+        assert np.array_equal(ref[3], proposal_fingerprints(fo, fpp, fe >= 0))
+        ix = pyemu.build_round_index(sc.batches.recs, pop.n, K, L, np.asarray(obs), member)
+        entries = pyemu.dict_entries(ix, pop.n)
+        sim = E.ClusterSimulation(eng)
+        for boundary in (True, False):
+            sim.generate(sc.batches, rx, seed, boundary=boundary)
+            info = sim.index_info()
+            assert info["dict_mode"] == (1 if boundary else 3) and info["alert_set_declared"] == 1
+            for first in (0, A - 7, (len(rx) // 2) * A + 3, len(want) - 1000):
+                first = max(0, first)
+                m = min(1000, len(want) - first)
+                dst, words = sim.read_records(first, m)
+                seg = want[first:first + m]
+                assert np.array_equal(dst, seg["dst"] if boundary else entries[seg["dst"]]), boundary
+                assert np.array_equal(words, (seg["ring_mask"].astype(np.uint32) & 0x3FFF) | np.where(seg["status"] != 0, 1 << 14, 1 << 15).astype(np.uint32)
+                                      | ((seg["flags"].astype(np.uint32) & 1) << 16))
+            for knob in (0, 64):  # the per-delivery filter, too
+                sim.set_force_exact(knob)
+                sim.new_round()
+                sim.tally()
+                assert all(np.array_equal(a, b) for a, b in zip(ref, sim.results())), (boundary, knob)
+            sim.set_force_exact(0)
+            rr = sim.count_votes()
+            assert (rr.decided, rr.votes_winner, rr.cut_size) == (rr2.decided, rr2.votes_winner, rr2.cut_size) and rr.decided == 1
+            assert sim.decided_cut() == sim2.decided_cut() and sorted(sim.decided_cut()) == sc.faulty.tolist()
+        with pytest.raises(E.RapidError):
+            sim.set_alert_set(sc.batches.recs)  # the set the deliveries were generated from IS the declared one
+        # late deliveries: a copy of a fifth of the batches, carrying the previous configuration id, each reaching about a tenth
+        # of the receivers; nothing of the round itself is lost, so every receiver's outcome is the one above -- except the
+        # number of batches it had seen when it announced
+        nb_ = sc.batches.n_batches
+        late = np.arange(0, nb_, 5)
+        lrecs = np.concatenate([sc.batches.recs[sc.batches.off[b]:sc.batches.off[b + 1]] for b in late])
+        lrecs["cfg_id"] = cfg - 1
+        loff = np.cumsum([0] + [int(sc.batches.off[b + 1] - sc.batches.off[b]) for b in late])
+        both = S.BatchSet(np.concatenate([sc.batches.recs, lrecs]), np.concatenate([sc.batches.off, sc.batches.off[-1] + loff[1:]]).astype(np.int64),
+                          np.concatenate([sc.batches.sender, sc.batches.sender[late]]))
+        keep = np.concatenate([np.full(nb_, 0xFFFFFFFF, dtype=np.uint32), np.full(len(late), 0xFFFFFFFF // 10, dtype=np.uint32)])
+        want_l, want_l_off, nb_l = S.deliver_hashed(both, rx, seed + 1, keep=keep)
+        assert nb_ < nb_l.min() and nb_l.max() < nb_ + len(late) and abs(nb_l.mean() - nb_ - len(late) / 10) < 0.03 * len(late)
+        fe_l, fn_l, fo_l, fpp_l = O.fast_sim_run(pop.n, K, H, L, cfg, obs, subj, member, want_l, want_l_off, nthreads=16)
+        assert np.array_equal(np.diff(fo_l), np.diff(fo)) and np.array_equal(fpp_l, fpp)
+        for boundary in (True, False):
+            sim.generate(both, rx, seed + 1, keep=keep, boundary=boundary)
             sim.tally()
-            assert all(np.array_equal(a, b) for a, b in zip(ref, sim.results())), knob
-        sim.set_force_exact(0)
+            got = sim.results()
+            assert np.array_equal(got[0], fe_l) and np.array_equal(got[1], fn_l) and np.array_equal(got[2], np.diff(fo_l))
+            assert np.array_equal(got[3], proposal_fingerprints(fo_l, fpp_l, fe_l >= 0))
+            if boundary:
+                dst, words = sim.read_records(0, 3 * int(both.off[-1]))
+                assert np.array_equal(dst, want_l["dst"][: len(dst)])
+        # a view change: resolved deliveries belong to the view they were generated in
+        rr = sim.count_votes()
+        sim.apply_cut(sim.decided_cut())
+        with pytest.raises(E.RapidError):
+            sim.tally()
+        with pytest.raises(E.IllegalArgumentException):  # a BatchedAlertMessage is never empty
+            sim.generate(S.BatchSet(sc.batches.recs, np.concatenate([sc.batches.off[:1], sc.batches.off]), np.concatenate([[0], sc.batches.sender])), rx, 1)
         eng.close()
+
+
+def test_generated_streams_at_full_size(E):
+    """rapid_sim_generate at BASELINE configs[2]'s full size (N = 10,000, C3b: 9,487 receivers x 4,343 batches = 93.7 M
+    records): EVERY receiver's outcome against the optimised CPU formulation fed scenarios.deliver_hashed's records, for the
+    resolved and the boundary form; the round decides the closed fault set."""
+    n, K, H, L = 10000, 10, 9, 4
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_scenario("C3b", subj, cfg, materialise=False)
+    want, want_off, nb = S.deliver_hashed(sc.batches, sc.receivers, 2)
+    fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, want, want_off, nthreads=64)
+    want_fp = proposal_fingerprints(fo, fpp, fe >= 0)
+    sim = E.ClusterSimulation(eng)
+    for boundary in (False, True):
+        sim.generate(sc.batches, sc.receivers, 2, trust_copies=True, boundary=boundary)
+        assert sim.index_info()["alerts_prevalidated"] == 1
+        sim.tally()
+        emit, nprop, pcount, fp = sim.results()
+        assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo)) and np.array_equal(fp, want_fp)
+        rr = sim.count_votes()
+        assert rr.decided == 1 and sorted(sim.decided_cut()) == sc.faulty.tolist()
+        for r in (0, len(fe) // 2, len(fe) - 1):
+            A = int(sc.batches.off[-1])
+            dst, words = sim.read_records(r * A, 2000)
+            if boundary:
+                assert np.array_equal(dst, want["dst"][r * A: r * A + 2000])
+    eng.close()
 
 
 def test_q4_stale_observer_cache_is_reported_through_the_c_abi(E):

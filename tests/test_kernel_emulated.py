@@ -444,11 +444,18 @@ def test_identifiers_merged_on_the_device():
         assert pyemu.ids_merge(old, new) == sorted(ids)
 
 
+def _core_words(recs):
+    return (recs["ring_mask"].astype(np.uint32) & 0x3FFF) | np.where(recs["status"] != 0, 1 << 14, 1 << 15).astype(np.uint32) | \
+        ((recs["flags"].astype(np.uint32) & 1) << 16)
+
+
 def test_streams_generated_on_the_device_equal_the_host_statement():
-    """rapid_sim_generate (gen_keys / gen_streams kernels, emulated; std::stable_sort for the device's segmented radix sort)
-    against scenarios.deliver_hashed: the same records in the same order for every receiver, in the resident layout -- subject,
-    core word (ring mask, DOWN / UP bits, end of batch on the last alert of every batch), configuration id, uniform
-    offsets; an alert of another configuration in the set is marked (and flagged), as the load pass marks it."""
+    """rapid_sim_generate (gen_resolve_alerts / gen_streams kernels, emulated) against scenarios.deliver_hashed: the same records
+    in the same order for every receiver -- as 20-byte boundary records (byte for byte) and as resolved 8-byte records (the
+    subject's dictionary entry of the round's index, ring mask + status + the batch end on the last alert of every batch);
+    an alert of another configuration in the set resolves to the poison entry; with per-batch delivery thresholds the places
+    of the batches that do not reach a receiver hold empty records; and the generated records, tallied, give what the host's
+    records give on the oracle."""
     n, K, H, L = 300, 10, 9, 4
     pop = S.Population.make(n)
     reg, view = oracle_view(pop, K, list(range(0, n - 20)))
@@ -456,32 +463,46 @@ def test_streams_generated_on_the_device_equal_the_host_statement():
     cfg = view.getCurrentConfigurationId()
     sc = S.build_churn_scenario(obs, member, cfg, 10, 8, H, L, materialise=False)
     rx = sc.receivers[::17]
-    for seed, stale_at in ((2, None), (12345678901234567, 3)):
+    rng = np.random.default_rng(4)
+    for seed, stale_at, with_keep in ((2, None, False), (12345678901234567, 3, False), (99, None, True)):
         bs = sc.batches
         if stale_at is not None:
             recs = bs.recs.copy()
             recs["cfg_id"][stale_at] = cfg + 1
             bs = S.BatchSet(recs, bs.off, bs.sender)
-        want, want_off, nb = S.deliver_hashed(bs, rx, seed)
-        dst, words, first, cfgs, rec_off, flags = pyemu.generate(bs, rx, seed, cfg, n)
-        assert np.array_equal(rec_off, want_off) and len(dst) == len(want)
-        stale = want["cfg_id"] != cfg
-        assert np.array_equal(dst, want["dst"] | np.where(stale, np.uint32(1 << 31), np.uint32(0)))
-        assert np.array_equal(first, dst)  # (no entries given: the first dword is the subject)
-        w = (want["ring_mask"].astype(np.uint32) & 0x3FFF) | np.where(want["status"] != 0, 1 << 14, 1 << 15).astype(np.uint32) | \
-            ((want["flags"].astype(np.uint32) & 1) << 16)
-        assert np.array_equal(words, w)
-        assert np.array_equal(cfgs.view(np.int64).reshape(-1), want["cfg_id"])
-        assert int(flags[0]) == (1 if stale.any() else 0)
-        # every receiver got every batch once, and two receivers got them in different orders
+        keep = None
+        if with_keep:
+            keep = np.where(rng.random(bs.n_batches) < 0.3, rng.integers(0, 1 << 32, size=bs.n_batches), 0xFFFFFFFF).astype(np.uint32)
+            keep[0] = 0  # (practically never delivered)
+        want, want_off, nb = S.deliver_hashed(bs, rx, seed, keep=keep)
         A = int(bs.off[-1])
-        assert all(sorted(want["src"][r * A:(r + 1) * A].tolist()) == sorted(bs.recs["src"].tolist()) for r in range(len(rx)))
-        assert not np.array_equal(want["src"][:A], want["src"][A:2 * A])
+        got, rec_off = pyemu.generate(bs, rx, seed, cfg, n, keep=keep, boundary=True)
+        assert np.array_equal(rec_off, want_off)
+        assert got.tobytes() == want.tobytes()
+        ix = pyemu.build_round_index(bs.recs, n, K, L, np.asarray(obs), member)
+        entries = pyemu.dict_entries(ix, n)
+        ent, words, rec_off = pyemu.generate(bs, rx, seed, cfg, n, entries=entries, keep=keep)
+        assert np.array_equal(rec_off, want_off)
+        empty = (want["ring_mask"] == 0) & (want["cfg_id"] == 0)
+        stale = (want["cfg_id"] != cfg) & ~empty
+        assert stale.any() == (stale_at is not None) and empty.any() == with_keep
+        assert np.array_equal(words, np.where(empty, 0, _core_words(want)).astype(np.uint32))
+        want_ent = np.where(empty, 0, np.where(stale, entries[n], entries[np.minimum(want["dst"], n)])).astype(np.uint32)
+        assert np.array_equal(ent, want_ent)
+        if keep is None:
+            # every receiver got every batch once, and two receivers got them in different orders
+            assert all(sorted(want["src"][r * A:(r + 1) * A].tolist()) == sorted(bs.recs["src"].tolist()) for r in range(len(rx)))
+            assert not np.array_equal(want["src"][:A], want["src"][A:2 * A])
+        else:
+            assert nb.min() < bs.n_batches and int((want["flags"] & 1).sum()) == int(nb.sum())
+        # the generated streams through the emulated tally (boundary records, tables looked up) = the oracle on the host's records
+        _check(got, rec_off, n, K, H, L, cfg, obs, subj, member, seed=int(seed) & 0xFFFF)
 
 
 def test_generator_edge_cases_and_the_late_delivery_model():
-    """One batch / one receiver / single-alert batches through the emulated generator; and scenarios.deliver's late deliveries:
-    additional whole batches carrying the previous configuration id -- every batch of the round still arrives exactly once."""
+    """One batch / one receiver / single-alert batches / a tile boundary through the emulated generator; and
+    scenarios.deliver's late deliveries: additional whole batches carrying the previous configuration id -- every batch of the
+    round still arrives exactly once."""
     n, K, H, L = 60, 10, 9, 4
     pop = S.Population.make(n)
     reg, view = oracle_view(pop, K)
@@ -489,11 +510,17 @@ def test_generator_edge_cases_and_the_late_delivery_model():
     cfg = view.getCurrentConfigurationId()
     sc = S.build_churn_scenario(obs, member, cfg, 3, 0, H, L, materialise=False)
     one = S.BatchSet(sc.batches.recs[: sc.batches.off[1]].copy(), sc.batches.off[:2].copy(), sc.batches.sender[:1].copy())
-    for bs, rx in ((one, sc.receivers[:1]), (one, sc.receivers[:5]), (sc.batches, sc.receivers[:1])):
+    # more batches than one tile of the lay-down (1,024 deliveries), of one to three alerts each
+    lens = np.random.default_rng(1).integers(1, 4, size=1100)
+    big = np.zeros(int(lens.sum()), dtype=S.ALERT_DTYPE)
+    big["cfg_id"], big["dst"], big["ring_mask"], big["status"] = cfg, np.arange(len(big)) % n, 1 + (np.arange(len(big)) % 7), S.DOWN
+    big["src"] = np.repeat(np.arange(1100), lens)
+    many = S.BatchSet(big, np.concatenate([[0], np.cumsum(lens)]).astype(np.int64), np.arange(1100, dtype=np.int32))
+    for bs, rx in ((one, sc.receivers[:1]), (one, sc.receivers[:5]), (sc.batches, sc.receivers[:1]), (many, sc.receivers[:3])):
         want, want_off, nb = S.deliver_hashed(bs, rx, 7)
-        dst, words, first, cfgs, rec_off, flags = pyemu.generate(bs, rx, 7, cfg, n)
-        assert np.array_equal(dst, want["dst"]) and np.array_equal(rec_off, want_off) and int(flags[0]) == 0
-        assert np.array_equal((words >> 16) & 1, want["flags"] & 1)
+        got, rec_off = pyemu.generate(bs, rx, 7, cfg, n, boundary=True)
+        assert got.tobytes() == want.tobytes() and np.array_equal(rec_off, want_off)
+        assert int((got["flags"] & 1).sum()) == bs.n_batches * len(rx)
     # late deliveries
     recs, off, nb = S.deliver(sc.batches, sc.receivers[:6], 2, stale_cfg=cfg - 1, stale_rate=0.25)
     B = sc.batches.n_batches
