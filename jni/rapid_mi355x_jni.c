@@ -221,21 +221,33 @@ JNIEXPORT void JNICALL Java_com_vrg_rapid_NativeCutEngine_simSetAlertSet(JNIEnv*
     CHECK(h, rapid_sim_set_alert_set(ENGINE(h), (const rapid_alert_record*)(*env)->GetDirectBufferAddress(env, alerts), n));
 }
 
-/* void simGenerate(long h, ByteBuffer alerts, long[] batchOff, int[] receivers, long seed): the round's deliveries made on the
- * device (rapid_sim_generate); `alerts` = the round's distinct alerts, packed, in batch order (a direct buffer) */
+/* void simGenerate(long h, ByteBuffer alerts, long[] batchOff, int[] batchKeep, int[] receivers, long seed, boolean boundary): the
+ * round's deliveries made on the device (rapid_sim_generate); `alerts` = the round's distinct alerts, packed, in batch order (a
+ * direct buffer); batchKeep = per-batch delivery thresholds as unsigned 32-bit values (null: every batch reaches every receiver) */
 JNIEXPORT void JNICALL Java_com_vrg_rapid_NativeCutEngine_simGenerate(JNIEnv* env, jobject self, jlong h, jobject alerts, jlongArray batchOff,
-                                                                      jintArray receivers, jlong seed) {
+                                                                      jintArray batchKeep, jintArray receivers, jlong seed, jboolean boundary) {
     (void)self;
     const jsize nb = (*env)->GetArrayLength(env, batchOff), nr = (*env)->GetArrayLength(env, receivers);
     jlong* off = (*env)->GetLongArrayElements(env, batchOff, NULL);
     jint* rx = (*env)->GetIntArrayElements(env, receivers, NULL);
+    jint* keep = batchKeep != NULL ? (*env)->GetIntArrayElements(env, batchKeep, NULL) : NULL;
     int rc = RAPID_EINVAL;
-    if (off != NULL && rx != NULL && nb >= 1)
+    if (off != NULL && rx != NULL && nb >= 1 && (batchKeep == NULL || (keep != NULL && (*env)->GetArrayLength(env, batchKeep) == nb - 1)))
         rc = rapid_sim_generate(ENGINE(h), (const rapid_alert_record*)(*env)->GetDirectBufferAddress(env, alerts), (const int64_t*)off, (int32_t)(nb - 1),
-                                (const int32_t*)rx, (int32_t)nr, (uint64_t)seed);
+                                (const uint32_t*)keep, (const int32_t*)rx, (int32_t)nr, (uint64_t)seed, boundary ? RAPID_GEN_BOUNDARY : RAPID_GEN_RESOLVED);
+    if (keep != NULL) (*env)->ReleaseIntArrayElements(env, batchKeep, keep, JNI_ABORT);
     if (rx != NULL) (*env)->ReleaseIntArrayElements(env, receivers, rx, JNI_ABORT);
     if (off != NULL) (*env)->ReleaseLongArrayElements(env, batchOff, off, JNI_ABORT);
     CHECK(h, rc);
+}
+
+/* void simAttachStreams(long h, long dRecords, long recordsBytes, long dRecOff, int nReceivers): a round's deliveries that already
+ * lie in device memory (addresses as handed out by the producer on the same GPU), tallied in place (rapid_sim_attach_streams_device) */
+JNIEXPORT void JNICALL Java_com_vrg_rapid_NativeCutEngine_simAttachStreams(JNIEnv* env, jobject self, jlong h, jlong dRecords, jlong recordsBytes,
+                                                                           jlong dRecOff, jint nReceivers) {
+    (void)self;
+    CHECK(h, rapid_sim_attach_streams_device(ENGINE(h), (const void*)(intptr_t)dRecords, (uint64_t)recordsBytes, (const int64_t*)(intptr_t)dRecOff,
+                                             (int32_t)nReceivers));
 }
 
 /* -> {decided, cutSize, votesWinner, quorum, newConfigId} */

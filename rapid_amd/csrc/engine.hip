@@ -122,6 +122,8 @@ struct rapid_engine {
     // alert of the set carried that view's configuration id and named a registered node
     long long gen_cfg_id = 0;
     bool gen_clean = false;
+    DevBuf<unsigned int> d_stream_flag;   // offsets check of an attached stream set (index_kernels.h: offsets_check_kernel)
+    bool offsets_on_device_only = false;  // attached: n_records_total is an upper bound until total_records() has fetched it
     DevBuf<long long> d_rec_off_own;
     const long long* d_rec_off = nullptr;
     int n_receivers = 0;
@@ -233,6 +235,8 @@ bool valid_khl(int K, int H, int L) {
 }
 
 inline unsigned grid_for(long long n, int block) { return (unsigned)((n + block - 1) / block); }
+
+int total_records_fwd(rapid_engine* h, long long* n);  // (defined with the stream-loading calls below)
 
 int use_device(rapid_engine* h) {
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
@@ -530,8 +534,14 @@ static int await_mail(rapid_engine* h, int word_index, unsigned int want) {
 // launch statistics [workgroups][8] + the pool words of launch_tally, sized for the largest grid a launch can have
 static size_t stats_words(const rapid_engine* h) { return (size_t)8 * (size_t)std::max(h->num_cus, 1) * 4 + 8; }
 
+bool tally_is_trusted(const rapid_engine* h);
+
 int build_round_index(rapid_engine* h) {
     const int N = h->n_nodes, K = h->cfg.K, L = h->cfg.L;
+    if (h->n_alert_set < 0 && h->offsets_on_device_only) {  // nothing declared: the pass over the delivered records needs their number
+        long long n_rec = 0;
+        if (int rc = total_records_fwd(h, &n_rec)) return rc;
+    }
     hipStream_t st = h->stream;
     {
         const int rc = ensure_mailbox(h);
@@ -646,7 +656,7 @@ int build_round_index(rapid_engine* h) {
     int best_w = 1;
     long long best_blocks = 0;
     double best_cost = 1e300;
-    int w_cap = rapid::kMaxWavesPerBlock;
+    int w_cap = rapid::tally_max_waves(h->dict_mode, tally_is_trusted(h), h->rec_fmt);  // (what decides the instantiation is known by now)
     if (const char* e = getenv("RAPID_TALLY_WAVES")) w_cap = std::max(1, std::min(w_cap, atoi(e)));  // profiling knob
     const double sat = 7.0;
     for (int w = 1; w <= w_cap; ++w) {
@@ -702,6 +712,7 @@ int launch_tally(rapid_engine* h) {
     p.idx.n_touched = h->n_touched;
     p.idx.entries = h->d_entries.p;
     p.error_flags = h->d_errflags.p;
+    p.stream_flag = h->offsets_on_device_only || h->d_stream_flag.p ? h->d_stream_flag.p : nullptr;
     p.idx.node_of_slot = h->d_node_of_slot.p;
     p.idx.smask = h->d_adj_off.p;  // (the buffers keep their round-1 names: per-slot masks, flat triple list)
     p.idx.pairs = h->d_adj.p;
@@ -863,7 +874,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_joiners.release(); h->d_join_nodes.release(); h->d_join_vals.release(); h->d_join_keys.release(); h->d_join_skeys.release();
     h->d_records_own.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
-    h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_idxblk.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release(); h->d_trank.release(); h->d_tbits.release(); h->d_tent.release();
+    h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_idxblk.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release(); h->d_stream_flag.release(); h->d_trank.release(); h->d_tbits.release(); h->d_tent.release();
     h->d_adj_off.release(); h->d_node_of_slot.release(); h->d_loadflags.release();
     h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release(); h->d_voteback.release(); h->d_gather.release();
     (void)hipGetLastError();
@@ -1297,6 +1308,8 @@ static int own_records(rapid_engine* h, const unsigned char* src, hipMemcpyKind 
     h->d_records = h->d_records_own.p;
     h->records_bytes = bytes;
     h->rec_fmt = rapid::kFmtBoundary;
+    h->offsets_on_device_only = false;
+    if (h->d_stream_flag.p) HIPCHK(h, hipMemsetAsync(h->d_stream_flag.p, 0, 8, h->stream));  // (these offsets were checked on the host)
     return RAPID_OK;
 }
 
@@ -1358,13 +1371,41 @@ int rapid_sim_attach_streams_device(rapid_engine* h, const void* d_records, uint
     if ((reinterpret_cast<uintptr_t>(d_records) & 3u) != 0u) return fail(h, RAPID_EINVAL, "records must be 4-byte aligned");
     int rc = use_device(h);
     if (rc) return rc;
-    long long n_rec = 0;
-    if ((rc = check_device_offsets(h, d_rec_off, n_receivers, records_bytes, &n_rec))) return rc;
-    h->d_records = static_cast<const unsigned char*>(d_records);  // nothing is copied, nothing is rewritten: the tally reads them in place
-    h->records_bytes = (unsigned long long)n_rec * 20ull;
+    // On the round's path: nothing is copied, nothing is waited for.  The offsets are checked where they are, by a kernel ahead
+    // of the round's own on the engine's stream; offsets that fail are followed by no launch, and the round's results come back
+    // as RAPID_EINVAL (rapid_sim_results / rapid_sim_count_votes / rapid_sim_round).
+    HIPCHK(h, h->d_stream_flag.ensure(2));
+    HIPCHK(h, hipMemsetAsync(h->d_stream_flag.p, 0, 8, h->stream));
+    hipLaunchKernelGGL(rapid::offsets_check_kernel, dim3(grid_for((long long)n_receivers + 1, 256)), dim3(256), 0, h->stream,
+                       reinterpret_cast<const long long*>(d_rec_off), n_receivers, (unsigned long long)records_bytes, (long long)rapid::kMaxStreamRecords,
+                       h->d_stream_flag.p);
+    h->d_records = static_cast<const unsigned char*>(d_records);  // the tally reads them in place
+    h->records_bytes = (unsigned long long)records_bytes;
     h->rec_fmt = rapid::kFmtBoundary;
     h->d_rec_off = reinterpret_cast<const long long*>(d_rec_off);
-    streams_replaced(h, n_receivers, n_rec);
+    h->offsets_on_device_only = true;
+    streams_replaced(h, n_receivers, (long long)(records_bytes / 20));  // (an upper bound until somebody needs the count: total_records())
+    return RAPID_OK;
+}
+
+// The number of delivered records of the loaded streams: known on the host, except for an attached set whose offsets were
+// never copied -- fetched (one synchronising 8-byte copy) by the few paths that need it: an undeclared alert set, the probes.
+static int total_records(rapid_engine* h, long long* n);
+namespace {
+int total_records_fwd(rapid_engine* h, long long* n) { return total_records(h, n); }
+}  // namespace
+static int total_records(rapid_engine* h, long long* n) {
+    if (h->offsets_on_device_only) {
+        long long last = 0;
+        unsigned int bad = 0;
+        HIPCHK(h, hipMemcpyAsync(&last, h->d_rec_off + h->n_receivers, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(&bad, h->d_stream_flag.p, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (bad) return fail(h, RAPID_EINVAL, "the attached stream offsets are not ascending from 0, exceed a stream's capacity or run past records_bytes");
+        h->n_records_total = last;
+        h->offsets_on_device_only = false;
+    }
+    *n = h->n_records_total;
     return RAPID_OK;
 }
 
@@ -1436,6 +1477,8 @@ int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const 
     h->d_records = h->d_records_own.p;
     h->records_bytes = (unsigned long long)total * stride;
     h->d_rec_off = h->d_rec_off_own.p;
+    h->offsets_on_device_only = false;
+    if (h->d_stream_flag.p) HIPCHK(h, hipMemsetAsync(h->d_stream_flag.p, 0, 8, st));
     h->gen_cfg_id = h->config_id;
     h->gen_clean = clean && batch_keep == nullptr;  // (an undelivered batch's places hold empty records: harmless, but not copies)
     const bool index_valid = h->index_valid;
@@ -1506,6 +1549,7 @@ int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, i
 
 int rapid_sim_trust_alert_copies(rapid_engine* h, int32_t on) {
     if (!h) return RAPID_EINVAL;
+    if (h->trust_copies != (on != 0)) h->index_valid = false;  // (another instantiation, maybe another launch geometry)
     h->trust_copies = on != 0;
     return RAPID_OK;
 }
@@ -1541,6 +1585,8 @@ static int check_tally_errors(rapid_engine* h) {
     unsigned int flags[2] = {0u, 0u};
     HIPCHK(h, hipMemcpyAsync(flags, h->d_errflags.p, sizeof flags, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (flags[0] & 2u)
+        return fail(h, RAPID_EINVAL, "the attached stream offsets are not ascending from 0, exceed a stream's capacity or run past records_bytes");
     if (flags[0] & 1u)
         return fail(h, RAPID_EINVAL, "a delivered alert names a subject / ring that the declared alert set does not contain "
                                     "(rapid_sim_set_alert_set must be given every distinct alert of the loaded streams)");
@@ -1602,6 +1648,8 @@ int rapid_sim_proposal(rapid_engine* h, int32_t receiver, int32_t* out, int32_t 
 // proposals share the winning bucket, count again with the next salt.
 constexpr int kVoteNextSalt = 1;
 static int decode_vote_answer(rapid_engine* h, const unsigned long long* hres, const int* href, rapid_round_result* out) {
+    if ((unsigned int)hres[8] & 2u)
+        return fail(h, RAPID_EINVAL, "the attached stream offsets are not ascending from 0, exceed a stream's capacity or run past records_bytes");
     if ((unsigned int)hres[8] & 1u)
         return fail(h, RAPID_EINVAL, "a delivered alert names a subject / ring that the declared alert set does not contain "
                                     "(rapid_sim_set_alert_set must be given every distinct alert of the loaded streams)");
@@ -2068,7 +2116,7 @@ int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, in
 
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on) {
     if (!h) return RAPID_EINVAL;
-    if (((h->force_exact ^ on) & (128 | 256 | 4096 | 8192 | 32768)) != 0) h->index_valid = false;  // the launch geometry depends on where the dictionary lives
+    if (((h->force_exact ^ on) & (64 | 128 | 256 | 4096)) != 0) h->index_valid = false;  // the launch geometry depends on the instantiation and on where the dictionary lives
     h->force_exact = on;
     return RAPID_OK;
 }

@@ -39,6 +39,22 @@ __global__ void index_touch_kernel(const unsigned char* records, long long n_rec
     if (f) atomicOr(vflags, f);
 }
 
+// The offsets of an attached stream set (rapid_sim_attach_streams_device), checked where they are -- no copy to the host, no
+// synchronisation on the round's path: rec_off[0] == 0, ascending, no stream longer than max_stream records, the last one
+// inside the records buffer.  A violation sets *flag; the tally then follows none of them (tally_kernel.h: stream_flag).
+__global__ void offsets_check_kernel(const long long* rec_off, int n_receivers, unsigned long long records_bytes, long long max_stream,
+                                     unsigned int* flag) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i > n_receivers) return;
+    bool bad = false;
+    if (i == 0) bad = rec_off[0] != 0 || rec_off[n_receivers] < 0 || (unsigned long long)rec_off[n_receivers] * 20ull > records_bytes;
+    if (i < n_receivers) {
+        const long long a = rec_off[i], b = rec_off[i + 1];
+        bad = bad || b < a || b - a > max_stream;
+    }
+    if (bad) atomicOr(flag, 1u);
+}
+
 // node -> dict_entry for rounds whose tables stay in memory (tally_kernel.h: RoundIndex::entries): what the tally's direct mode
 // assembles while it stages its tables in LDS, written out once per round; entries[n_nodes] = the poison entry.
 __global__ void dict_entries_kernel(const unsigned short* dict, const unsigned short* decl, int n_nodes, int n_hot, unsigned int* entries) {
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(1024) void index_assign_kernel(const unsigned int* 
             const int r = lane == 0 ? pt : pt + __popcll(tch & 0xFFFFFFFFull);
             trank[w] = (unsigned short)(r > 65535 ? 65535 : r);
         }
-        if (is_touched && my_rank < tent_cap) tent[my_rank] = (dcl << 16) | slot;
+        if (is_touched && my_rank < tent_cap) tent[my_rank] = dict_entry(dcl, slot);
         ph += __popcll(hots);
         pt += __popcll(tch);
     }
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
             const int b = __ffs((int)bits) - 1;
             bits &= bits - 1u;
             const int n = w * 32 + b;
-            if (tfits) tent[rk] = ((unsigned int)decl[n] << 16) | ((unsigned int)dict[n] & 0x3FFFu);
+            if (tfits) tent[rk] = dict_entry((unsigned int)decl[n], (unsigned int)dict[n] & 0x3FFFu);
             ++rk;
         }
     }

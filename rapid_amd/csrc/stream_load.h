@@ -38,14 +38,29 @@ __device__ __forceinline__ stream_rsrc_t stream_make_rsrc(const void* base, unsi
 
 // Two dwords at byte offset lane_off + imm of the stream (imm: wave-uniform, a compile-time constant at every call
 // site); non-temporal (every byte of a stream is read once).
-__device__ __forceinline__ void stream_load2(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int imm, unsigned int& a,
-                                             unsigned int& b) {
 #ifndef RAPID_STREAM_AUX
 #define RAPID_STREAM_AUX 2
 #endif
-    const stream_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_off, (int)imm, RAPID_STREAM_AUX);
+template <int kAux = RAPID_STREAM_AUX>
+__device__ __forceinline__ void stream_load2(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int imm, unsigned int& a,
+                                             unsigned int& b) {
+    const stream_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_off, (int)imm, kAux);
     a = v.x;
     b = v.y;
+}
+
+// Four dwords / one dword, same addressing (measurement variants of the boundary-record loads).
+typedef unsigned int stream_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_load4(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int imm, unsigned int& a, unsigned int& b,
+                                             unsigned int& c, unsigned int& d) {
+    const stream_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)imm, RAPID_STREAM_AUX);
+    a = v.x;
+    b = v.y;
+    c = v.z;
+    d = v.w;
+}
+__device__ __forceinline__ void stream_load1(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int imm, unsigned int& a) {
+    a = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)lane_off, (int)imm, RAPID_STREAM_AUX);
 }
 
 // A 64-bit word of a read-only table at a wave-uniform address, through the scalar cache (s_load, counted by lgkmcnt):

@@ -135,7 +135,7 @@ struct RoundIndex {
     const unsigned short* decl;     // [n_nodes] rings the round's alert set names for the node (all rings for a hot one) | member << 15
     // the same two tables in compressed form, for populations whose direct tables do not fit the LDS: a node is TOUCHED if
     // the round's alert set names it at all; tbits = one bit per node, trank[w] = touched nodes before word w,
-    // tent[rank] = (decl entry) << 16 | slot (kNoSlot: touched but not hot)
+    // tent[rank] = dict_entry(decl entry, slot) of the rank-th touched node (slot kNoSlot: touched but not hot)
     const unsigned int* tbits;      // [(n_nodes + 31) / 32]
     const unsigned short* trank;    // [(n_nodes + 31) / 32]
     const unsigned int* tent;       // [n_touched]
@@ -173,7 +173,10 @@ struct TallyParams {
     int* props;                       // [R][prop_cap] ascending node index
     int prop_cap;
     unsigned long long* stats;        // [workgroups][8], accumulated over launches
-    unsigned int* error_flags;        // sticky: bit0 = a delivered report is not covered by the index (see RoundIndex::decl)
+    unsigned int* error_flags;        // sticky: bit0 = a delivered report is not covered by the index (see RoundIndex::decl),
+                                      // bit1 = the attached stream offsets are not usable (stream_flag)
+    const unsigned int* stream_flag;  // != 0: the offsets check of an attached stream set failed (index_kernels.h: offsets_check_kernel):
+                                      // no stream is read, the results are void (RAPID_EINVAL when they are asked for); nullptr: checked on the host
     int waves_per_block;
     // Receivers [0, n_static) are dealt to the workgroups statically (n_static is a multiple of the grid size); the rest
     // is a common pool claimed through pool[0] by waves whose workgroup has worked off its own deal -- workgroups do not
@@ -498,9 +501,25 @@ enum { kApplied = 0, kWitnessFails = 1, kNotFastable = 2 };  // outcome of a fas
 #ifndef RAPID_SETS_BOUNDARY
 #define RAPID_SETS_BOUNDARY 2
 #endif
+// cache policy of the two loads of a boundary record (0 = default, 2 = nt).  Both touch the same cache lines: with nt the second
+// one fetches them from L2 again (measured, scripts/micro/boundary_shapes.hip: 5.4 TB/s against 6.1 TB/s for this shape;
+// the kernel: 0.436 -> 0.383 ms on C3b), whereas a resident 8-byte record is loaded once and streams best with nt
+#ifndef RAPID_BOUNDARY_AUX_A
+#define RAPID_BOUNDARY_AUX_A 0
+#endif
+#ifndef RAPID_BOUNDARY_AUX_B
+#define RAPID_BOUNDARY_AUX_B 0
+#endif
+
+// Waves per workgroup an instantiation may be launched with (= its register budget: 16 waves per CU leave 128 VGPRs per wave).
+// The per-delivery filter over compressed tables on boundary records needs a few more than that: twelve waves (168 VGPRs)
+// instead of spills inside the window loop.
+__host__ __device__ constexpr int tally_max_waves(int dict_mode, bool trusted, int fmt) {
+    return (fmt == kFmtBoundary && dict_mode == kDictCompressed && !trusted) ? 12 : kMaxWavesPerBlock;
+}
 
 template <int kDictMode, bool kTrusted, int kFmt = kFmtResident>
-__global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kernel(TallyParams p) {
+__global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) void tally_population_kernel(TallyParams p) {
     static_assert(kFmt == kFmtResident || kDictMode != kDictResolved, "a boundary record carries its subject, not an entry");
     constexpr bool kTablesInLds = kDictMode == kDictDirect;
     constexpr int kStride = kFmt == kFmtBoundary ? kRecBytes : kCoreBytes;  // bytes from one record to the next
@@ -533,8 +552,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         trank = l_rank;
         tent = l_ent;
     }
-    const unsigned short* const dict = p.idx.dict;
-    const unsigned short* const decl = p.idx.decl;
     const unsigned int* entries = nullptr;  // direct mode: dict_entry per node, [n_nodes] = where out-of-range subjects are sent
     if (kTablesInLds) {
         unsigned int* const l_ent = reinterpret_cast<unsigned int*>(smem);
@@ -620,6 +637,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         unsigned int bytes;
     };
     // one window of the stream `st` starting at this lane's byte offset `voff`: kQ wave instructions, nothing waited for
+    const unsigned int cfg_lo_ = (unsigned int)(unsigned long long)p.cfg_id, cfg_hi_ = (unsigned int)((unsigned long long)p.cfg_id >> 32);
     auto load_window = [&](const Stream& st, unsigned int voff, Win& W) {
         // declared wave-uniform right here (it is: every lane computes it from the wave's receiver index), so that the
         // descriptor is in SGPRs whatever the compiler concluded about the loops it travelled through
@@ -630,8 +648,18 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #pragma unroll
         for (int q = 0; q < kQ; ++q) {
             if constexpr (kFmt == kFmtBoundary) {
-                stream_load2(rsrc, voff, (unsigned int)q * kQuarterB, W.c0[q], W.c1[q]);
+#if defined(RAPID_BOUNDARY_X4)  // measurement variant: 16 + 4 bytes per record (src travels into a register nobody reads)
+                unsigned int src_;
+                stream_load4(rsrc, voff, (unsigned int)q * kQuarterB, W.c0[q], W.c1[q], src_, W.w3[q]);
+                stream_load1(rsrc, voff, (unsigned int)q * kQuarterB + 16u, W.w4[q]);
+#elif defined(RAPID_PROBE_NO_CFG)  // measurement only (results void for streams with late deliveries): the ids are not loaded
+                W.c0[q] = cfg_lo_;
+                W.c1[q] = cfg_hi_;
                 stream_load2(rsrc, voff, (unsigned int)q * kQuarterB + 12u, W.w3[q], W.w4[q]);
+#else
+                stream_load2<RAPID_BOUNDARY_AUX_A>(rsrc, voff, (unsigned int)q * kQuarterB, W.c0[q], W.c1[q]);
+                stream_load2<RAPID_BOUNDARY_AUX_B>(rsrc, voff, (unsigned int)q * kQuarterB + 12u, W.w3[q], W.w4[q]);
+#endif
             } else {
                 stream_load2(rsrc, voff, (unsigned int)q * kQuarterB, W.w3[q], W.w4[q]);
             }
@@ -643,7 +671,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // is dropped), the status byte as two bits, the batch-end flag in bit 16 (core_word).  An alert without ring numbers does
     // nothing in the reference (aggregateForProposal(AlertMessage) iterates over them, R/MultiNodeCutDetector.java:76-82) and is
     // cleared the same way -- which also makes the zeros behind a stream's end the empty record they are in the resident format.
-    const unsigned int cfg_lo = (unsigned int)(unsigned long long)p.cfg_id, cfg_hi = (unsigned int)((unsigned long long)p.cfg_id >> 32);
+    const unsigned int cfg_lo = cfg_lo_, cfg_hi = cfg_hi_;
     auto open = [&](const Win& c) -> Rec {
         Rec x;
 #pragma unroll
@@ -676,7 +704,6 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     // entry behind the table (nothing about it is covered, and it has a dummy slot).
     struct Look {
         unsigned int entry;
-        bool in;         // subject in range (direct mode: always true, see above)
         bool untouched;  // compressed mode: the round's alert set never names the node -- its membership is not in the tables
     };
     const unsigned int n_nodes_u = (unsigned int)(p.n_nodes > 0 ? p.n_nodes : 0);
@@ -684,39 +711,29 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
         Look k;
         k.untouched = false;
         if (kTablesInLds) {
-            k.in = true;
             k.entry = entries[min(w3, n_nodes_u)];
             return k;
         }
         if (kDictMode == kDictResolved) {  // the record carries its subject's entry (poison for a stale or unknown subject)
-            k.in = true;
             k.entry = w3;
             return k;
         }
         if (kDictMode == kDictMemory) {
-            k.in = true;
             k.entry = p.idx.entries[min(w3, n_nodes_u)];
             return k;
         }
-        k.in = w3 <= node_last && p.n_nodes > 0;
+        // kDictCompressed: bit test + rank -- two independent LDS reads -- then the entry of a touched node (its dict_entry, written
+        // by the index build; a touched node that is not hot carries kNoSlot there and gets this lane's dummy slot).  A node the
+        // alert set never names has no entry: a valid report about it is exactly what the coverage check exists for.
+        const bool in = w3 <= node_last && p.n_nodes > 0;
         const unsigned int idx = min(w3, node_last);
-        unsigned int sl, dm;
-        if (kDictMode == kDictCompressed) {
-            // bit test + rank: two independent LDS reads, then the entry of a touched node.  A node the alert set never
-            // names has no entry: a valid report about it is exactly what the coverage check exists for.
-            const unsigned int word = tbits[idx >> 5], before = (unsigned int)trank[idx >> 5];
-            const unsigned int bit = idx & 31u;
-            const bool touched = ((word >> bit) & 1u) != 0u;
-            const unsigned int ent = touched ? tent[before + (unsigned int)__popc(word & ((1u << bit) - 1u))] : kNoSlot;
-            dm = ent >> 16;
-            sl = ent & kSlotMask;
-            k.untouched = sl == kNoSlot && (dm & 0x3FFFu) == 0u;
-        } else {
-            sl = (unsigned int)dict[idx] & kSlotMask;
-            dm = (unsigned int)decl[idx];
-        }
-        if (sl == kNoSlot) sl = my_dummy;
-        k.entry = k.in ? dict_entry(dm, sl) : (kEntryPoison | (my_dummy << 17));
+        const unsigned int word = tbits[idx >> 5], before = (unsigned int)trank[idx >> 5];
+        const unsigned int bit = idx & 31u;
+        const bool touched = ((word >> bit) & 1u) != 0u;
+        unsigned int e = touched ? tent[before + (unsigned int)__popc(word & ((1u << bit) - 1u))] : (kCoreRings | kCoreDown | (kNoSlot << 17));
+        if ((e >> 17) == kNoSlot) e = (e & 0x1FFFFu) | (my_dummy << 17);
+        k.untouched = in && !touched;
+        k.entry = in ? e : (kEntryPoison | (my_dummy << 17));
         return k;
     };
     // effective: filterAlertMessages (R/MembershipService.java:644-675) applied to record (q, lane) of a window, branch-free:
@@ -733,7 +750,9 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
             uncovered |= w & k.entry;
             return w;
         }
-        const unsigned int bad0 = (k.in ? 0u : 1u) | ((w & kCoreRings) == 0u ? 1u : 0u);  // (k.in: false for a stale record, too)
+        // (a subject out of range has the poison entry: BOTH status bits, so whatever status the report carries fails below; a
+        // record of another configuration arrives with its rings cleared -- open() -- or, resident, with the poison entry)
+        const unsigned int bad0 = (w & kCoreRings) == 0u ? 1u : 0u;
         // (the membership of a node the alert set never names is not in the compressed tables: such a report is
         // not tallied, and flagged if it is otherwise valid)
         const unsigned int bad = bad0 | (w & k.entry & (kCoreDown | kCoreUp)) | (k.untouched ? 1u : 0u);
@@ -771,6 +790,10 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
     const int n_blocks = (int)gridDim.x;
     int r = uniform(wave * n_blocks + (int)blockIdx.x);  // the first deal: claim number `wave` of this workgroup
     if (r >= p.n_static) r = p.n_receivers;              // (the host sizes the static part so that this never takes pool work away)
+    if (p.stream_flag != nullptr && uniform(*p.stream_flag) != 0u) {  // offsets that failed their check are not followed
+        if (threadIdx.x == 0 && blockIdx.x == 0) stream_flag_or(p.error_flags, 2u);
+        r = p.n_receivers;
+    }
     // The stream runs kSets windows ahead of the tally: S[0] is the window about to be tallied, S[1 ..] the ones behind it,
     // all requested (a window that is being tallied has kSets - 1 successors in flight -- with one, a wave would wait out a
     // whole memory latency per window as soon as a window's tally is shorter than that, which it is since the fast window
@@ -977,8 +1000,7 @@ __global__ __launch_bounds__(kMaxWavesPerBlock * 64) void tally_population_kerne
 #ifdef RAPID_PROBE_NO_LOOKUP
                 Look k;
                 k.entry = (c.w3[q] & 0xFFu) << 17;
-                k.in = true;
-                k.untouched = false;
+                    k.untouched = false;
 #else
                 const Look k = lookup(c.w3[q]);
 #endif

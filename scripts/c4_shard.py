@@ -1,5 +1,6 @@
 """BASELINE configs[3] (N = 100,000, K = 10, 1 % crashed) as ONE of eight ranks sees it: its shard of the receivers on one
-MI355X, dictionary in memory.  Prints the tally kernel time of both instantiations, the roofline fraction and a round.
+MI355X, the 20-byte records tallied where they lie (compressed tables in LDS).  Prints the tally kernel time of both
+instantiations, the roofline fraction on the 20 B per record, and a whole round.
     python scripts/c4_shard.py [ranks=8] [reps=10]"""
 import json
 import os
@@ -37,9 +38,7 @@ for tag, declare in (("filter_per_delivery", False), ("alert_set_declared", True
         sim.set_alert_set(sc.batches.recs, trust_copies=True)
     ms = min(sim.time_tally(reps) for _ in range(2))
     info = sim.index_info()
-    res_b = 8 if declare else 16  # resident bytes per record the kernel reads (core only / core + configuration id)
     out[tag] = {"kernel_ms": round(ms, 4), "GBps": round(nbytes / ms / 1e6, 1), "frac_of_8TBps": round(nbytes / ms / 1e6 / 8000, 4),
-                "resident_GBps": round(res_b * len(records) / ms / 1e6, 1), "resident_frac_of_8TBps": round(res_b * len(records) / ms / 1e6 / 8000, 4),
                 "dict_mode": info["dict_mode"], "waves_per_workgroup": info["waves_per_workgroup"],
                 "index_build_ms": round(info["index_build_ms"], 4)}
 t = time.perf_counter()

@@ -197,6 +197,7 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     static unsigned int error_flags[2];
     error_flags[0] = error_flags[1] = 0u;
     p.error_flags = error_flags;
+    p.stream_flag = nullptr;
     p.idx.node_of_slot = node_of_slot;
     p.idx.smask = smask;
     p.idx.pairs = pairs;

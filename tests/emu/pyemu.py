@@ -69,7 +69,8 @@ def build_round_index(records, n_nodes, K, L, obs, member):
     per_word = padded.reshape(n_words, 32).sum(axis=1)
     trank = np.concatenate([[0], np.cumsum(per_word)[:-1]]).astype(np.uint16)
     tn = np.flatnonzero(touched)
-    tent = ((decl[tn].astype(np.uint32) << 16) | (dict_[tn].astype(np.uint32) & 0x3FFF)).astype(np.uint32)
+    dt, st = decl[tn].astype(np.uint32), dict_[tn].astype(np.uint32) & 0x3FFF  # tally_kernel.h: dict_entry(decl entry, slot)
+    tent = (((~dt) & 0x3FFF) | np.where((dt >> 15) != 0, 1 << 15, 1 << 14).astype(np.uint32) | (st << 17)).astype(np.uint32)
     tent = np.concatenate([tent, np.zeros(1, dtype=np.uint32)])
     pad = np.zeros(8, dtype=np.uint16)  # the kernel stages both tables 16 bytes at a time: allocated with slack, as on the device
     dict_, decl = np.concatenate([dict_.astype(np.uint16), pad]), np.concatenate([np.asarray(decl).astype(np.uint16), pad])

@@ -14,6 +14,7 @@ inline stream_rsrc_t stream_make_rsrc(const void* base, unsigned int bytes) {
     return stream_rsrc_t{static_cast<const unsigned char*>(base), bytes};
 }
 
+template <int kAux = 2>
 inline void stream_load2(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int imm, unsigned int& a, unsigned int& b) {
     const unsigned long long off = (unsigned long long)lane_off + (unsigned long long)imm;
     a = 0u;
@@ -21,6 +22,19 @@ inline void stream_load2(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int
     // the hardware checks every dword on its own
     if (rsrc.base != nullptr && off + 4ull <= rsrc.bytes) std::memcpy(&a, rsrc.base + off, 4);
     if (rsrc.base != nullptr && off + 8ull <= rsrc.bytes) std::memcpy(&b, rsrc.base + off + 4, 4);
+}
+
+inline void stream_load1(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int imm, unsigned int& a) {
+    const unsigned long long off = (unsigned long long)lane_off + (unsigned long long)imm;
+    a = 0u;
+    if (rsrc.base != nullptr && off + 4ull <= rsrc.bytes) std::memcpy(&a, rsrc.base + off, 4);
+}
+inline void stream_load4(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int imm, unsigned int& a, unsigned int& b, unsigned int& c,
+                         unsigned int& d) {
+    stream_load1(rsrc, lane_off, imm, a);
+    stream_load1(rsrc, lane_off, imm + 4u, b);
+    stream_load1(rsrc, lane_off, imm + 8u, c);
+    stream_load1(rsrc, lane_off, imm + 12u, d);
 }
 
 inline long long stream_scalar_load(const long long* p) { return *p; }

@@ -1,6 +1,6 @@
 """The compiler's verdict on the hot kernels, checked on the CPU: rapid_amd._native.build() keeps hipcc's per-kernel resource
-report next to the library, and the tally kernel must not spill.  Its six instantiations sit between 89 and 125 VGPRs
-under a budget of 128 (16 waves per CU), so an innocent-looking edit can push one over: the reloads then land inside the
+report next to the library, and the tally kernel must not spill.  Its eight instantiations sit between 86 and 133 VGPRs
+under budgets of 128 (16 waves per CU) and 168 (12), so an innocent-looking edit can push one over: the reloads then land inside the
 receiver loop, count against vmcnt like stream loads, and cost ~20 % (measured in round 2: 0.42 -> 0.52 ms on C3b for the
 per-delivery-filter kernels) without any test failing."""
 import json
@@ -24,8 +24,11 @@ def test_tally_kernels_fit_the_register_file_without_scratch():
     assert len(tally) == 8, sorted(tally)
     for name, r in tally.items():
         assert r["ScratchSize [bytes/lane]"] == 0, (name, r)
-        assert r["VGPRs"] <= 128, (name, r)          # 16 waves per CU = 4 per SIMD
-        assert r["Occupancy [waves/SIMD]"] >= 4, (name, r)
+        # 16 waves per CU = 4 per SIMD = 128 VGPRs; the per-delivery filter over compressed tables on boundary records is
+        # launched with at most 12 (tally_kernel.h: tally_max_waves): 3 per SIMD = 168
+        twelve = "tally_population_kernelILi2ELb0ELi1E" in name
+        assert r["VGPRs"] <= (168 if twelve else 128), (name, r)
+        assert r["Occupancy [waves/SIMD]"] >= (3 if twelve else 4), (name, r)
 
 
 def test_every_other_kernel_of_the_path_is_scratch_free_too():
@@ -38,15 +41,16 @@ def test_every_other_kernel_of_the_path_is_scratch_free_too():
 
 # (dictionary mode, trusted, record format): 0 / 1 / 2 = tables in memory / direct in LDS / compressed in LDS over 20-byte boundary
 # records (format 1); 3 = resolved 8-byte records (format 0)
-EXPECTED_VGPRS = {}
+EXPECTED_VGPRS = {(0, False, 1): 123, (0, True, 1): 104, (1, False, 1): 118, (1, True, 1): 102, (2, False, 1): 133, (2, True, 1): 114,
+                  (3, False, 0): 90, (3, True, 0): 86}
 
 
 def test_register_allocation_of_the_tally_kernel_is_the_measured_one():
     """A canary, not a law: changes that leave every result identical can still cost 20-30 % -- in round 2 once through
     spills after an edit of the table-staging loop, once because a rewrite of that loop left a table pointer aimed at global
     memory instead of its LDS copy (89 -> 93 VGPRs, 0.214 -> 0.285 ms on C3b) -- while every parity test stayed green.
-    These are the counts of the build whose timings are in profiles/r03_*; if they move, time the tally kernel on a GPU
-    (scripts/pool_ab.py prints it in seconds) before accepting the new numbers here."""
+    These are the counts of the build whose timings are in profiles/r04_*; if they move, time the tally kernel on a GPU
+    (scripts/ab_variants.py prints it in seconds) before accepting the new numbers here."""
     res = resources()
     got = {}
     for name, r in res.items():

@@ -877,8 +877,22 @@ def test_streams_handed_over_in_device_memory(E):
         assert (rr.decided, rr.votes_winner, rr.cut_size) == (rr0.decided, rr0.votes_winner, rr0.cut_size)
     with pytest.raises(E.IllegalArgumentException):
         sim.attach_streams_device(d_rec2.value + 13, raw.nbytes, d_off.value, len(sc.rec_off) - 1)  # not 4-byte aligned
-    with pytest.raises(E.IllegalArgumentException):
-        sim.attach_streams_device(d_rec2.value + 12, raw.nbytes - 20, d_off.value, len(sc.rec_off) - 1)  # does not cover the records
+    # offsets that run past the records, or are not ascending: checked on the device, ahead of the round's kernels, without
+    # a copy to the host -- no stream is read, and the round's results come back as IllegalArgumentException
+    bad_off = np.ascontiguousarray(sc.rec_off, dtype=np.int64).copy()
+    bad_off[3], bad_off[4] = bad_off[4], bad_off[3]
+    d_bad = to_device(bad_off)
+    for args in ((d_rec2.value + 12, raw.nbytes - 20, d_off.value), (d_rec2.value + 12, raw.nbytes, d_bad.value)):
+        sim.attach_streams_device(*args, len(sc.rec_off) - 1)
+        sim.tally()
+        with pytest.raises(E.IllegalArgumentException):
+            sim.results()
+        with pytest.raises(E.IllegalArgumentException):
+            sim.count_votes()
+    sim.attach_streams_device(d_rec2.value + 12, raw.nbytes, d_off.value, len(sc.rec_off) - 1)  # ... and a good set afterwards is fine
+    sim.tally()
+    assert all(np.array_equal(a, b) for a, b in zip(want, sim.results()))
+    assert hip.hipFree(d_bad) == 0
     eng.close()
     assert hip.hipFree(d_off) == 0 and hip.hipFree(d_rec2) == 0
 
@@ -932,15 +946,15 @@ def test_declared_alert_set_that_does_not_cover_the_streams_is_rejected(E):
     assert all(np.array_equal(a, b) for a, b in zip(res2, res2b))
     fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, bad, sc.rec_off, nthreads=8)
     assert np.array_equal(res2[0], fe) and np.array_equal(res2[2], np.diff(fo))
-    # The request not to re-check the configuration id per delivery is honoured on verified facts only: ONE delivered copy
-    # with another configuration id (a late delivery, R/MembershipService.java:653-657) is seen by the load pass, the tally
-    # runs the per-delivery filter, and the record is dropped as the reference drops it -- same results as without the
-    # request, as without any declaration, and as the oracle fed the same bytes
+    # Late deliveries are no breach of the promise: the kernel compares the configuration id of EVERY delivered record on its
+    # way through the registers, whatever the instantiation, and drops a record of another configuration as the reference
+    # drops it (R/MembershipService.java:653-657) -- same results with the request, without it, without any declaration, and
+    # as the oracle fed the same bytes
     late = sc.records.copy()
     k = int(np.flatnonzero(np.isin(late["dst"], sc.faulty))[11])
     late["cfg_id"][k] = cfg + 5
     sim, res_t = run_population(E, eng, late, sc.rec_off, alert_set=sc.batches.recs, trust=True)
-    assert sim.index_info()["alerts_prevalidated"] == 0  # the fast instantiation was NOT selected
+    assert sim.index_info()["alerts_prevalidated"] == 1
     sim, res_u = run_population(E, eng, late, sc.rec_off, alert_set=sc.batches.recs, trust=False)
     sim, res_n = run_population(E, eng, late, sc.rec_off)
     fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, late, sc.rec_off, nthreads=8)
@@ -1187,7 +1201,7 @@ def test_streams_generated_on_the_device(E):
                           np.concatenate([sc.batches.sender, sc.batches.sender[late]]))
         keep = np.concatenate([np.full(nb_, 0xFFFFFFFF, dtype=np.uint32), np.full(len(late), 0xFFFFFFFF // 10, dtype=np.uint32)])
         want_l, want_l_off, nb_l = S.deliver_hashed(both, rx, seed + 1, keep=keep)
-        assert nb_ < nb_l.min() and nb_l.max() < nb_ + len(late) and abs(nb_l.mean() - nb_ - len(late) / 10) < 0.03 * len(late)
+        assert nb_ <= nb_l.min() and nb_l.max() < nb_ + len(late) and abs(nb_l.mean() - nb_ - len(late) / 10) < 0.03 * len(late)
         fe_l, fn_l, fo_l, fpp_l = O.fast_sim_run(pop.n, K, H, L, cfg, obs, subj, member, want_l, want_l_off, nthreads=16)
         assert np.array_equal(np.diff(fo_l), np.diff(fo)) and np.array_equal(fpp_l, fpp)
         for boundary in (True, False):
@@ -1356,9 +1370,9 @@ def test_streaming_rounds_at_one_million_nodes(E):
             assert 0 < int((sc.records["cfg_id"] != cfg).sum()) < len(sc.records) // 50  # the late deliveries are there
         assert guard.check_round(view, sc.faulty[:: 50]) == []  # Q4 (sampled: the guard is host-side bookkeeping)
         sim.load_streams(sc.records, sc.rec_off)
-        sim.set_alert_set(sc.batches.recs, trust_copies=True)  # asked for; honoured only in round 0 (no late deliveries there)
+        sim.set_alert_set(sc.batches.recs, trust_copies=True)  # (late deliveries of the previous configuration are dropped per delivery either way)
         sim.tally()
-        assert sim.index_info()["alerts_prevalidated"] == (1 if rnd == 0 else 0)
+        assert sim.index_info()["alerts_prevalidated"] == 1
         emit, nprop, pcount, fp = sim.results()
         fe, fn, fo, fpp = O.fast_sim_run(pop.n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off, nthreads=64)
         assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
