@@ -170,15 +170,13 @@ def main():
     st = sim.stats()
     consumed = st["records_consumed"] // (args.kernel_reps + 1)
     index = sim.index_info()
-    kern_filter_ms, probe_ms = None, None
+    kern_filter_ms = None
     if not args.no_extras:
         # the same kernel with the per-delivery filter forced on (the instantiation that runs when the round's alerts do not
         # all validate against the view, or deliveries are not vouched for)
         sim.set_force_exact(64)
         kern_filter_ms = sim.time_tally(args.kernel_reps)
         sim.set_force_exact(0)
-        # what the memory system delivers for the SAME records with no processing (measurement probe)
-        probe_ms = sim.stream_probe(0, 16, 5)
     traffic, traffic_source = (None, "not measured at %d ranks" % world)
     if world == 1 and rank == 0 and not args.no_pmc:
         traffic, traffic_source = measure_traffic(cfgname)
@@ -197,8 +195,14 @@ def main():
                 "traffic_over_bytes": round(traffic / (rec_b * consumed), 3) if traffic else None,
                 "kernel_ms_filter_per_delivery": round(kern_filter_ms, 4) if kern_filter_ms else None,
                 "frac_filter_per_delivery": round(rec_b * consumed / (kern_filter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern_filter_ms else None,
-                "stream_probe_gbs": round(rec_b * my_records / (probe_ms * 1e-3) / 1e9, 1) if probe_ms else None,
                 "passes_over_a_delivered_record": 1}
+
+    if world > 1:  # every rank's own tally kernel: duration and roofline fraction (the line's `roofline` is rank 0's)
+        mine = torch.tensor([kern_ms, float(consumed)], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        roofline["per_rank"] = [{"rank": i, "kernel_ms": round(float(t[0]), 4), "records_consumed": int(t[1]),
+                                 "frac": round(rec_b * float(t[1]) / (float(t[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for i, t in enumerate(allr)]
 
     # ---- the same round's deliveries GENERATED on the device (rapid_sim_generate): every receiver gets every batch in a seeded
     # permutation of its own, written directly as resolved 8-byte records (the 20-byte records never exist; the tally reads 8 B

@@ -191,9 +191,6 @@ int rapid_sim_attach_streams_device(rapid_engine* h, const void* d_records, uint
 #define RAPID_GEN_BOUNDARY 1
 int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const int64_t* batch_off, int32_t n_batches,
                        const uint32_t* batch_keep, const int32_t* receivers, int32_t n_receivers, uint64_t seed, int32_t format);
-/* testing aid: n delivered records starting at `first` -- boundary records: subject and core word (ring mask, bit 14 DOWN,
- * bit 15 UP, bit 16 end of batch); resolved records: the subject's dictionary entry and the core word */
-int rapid_debug_read_records(rapid_engine* h, int64_t first, int32_t n, uint32_t* subjects, uint32_t* core_words);
 /* Optional, after a load: declares the round's DISTINCT alerts (every delivered record is a byte-identical copy of
  * one of them, flags aside -- one AlertMessage is broadcast to all receivers, R/UnicastToAllBroadcaster.java:46-52).
  * The per-round index (which subjects can reach the L watermark at all, their adjacency) and the one-time validation
@@ -412,16 +409,32 @@ int rapid_sim_stats(rapid_engine* h, uint64_t stats[8]);
 /* average duration (ms) of the tally kernel over `reps` back-to-back launches, HIP events on the engine stream */
 int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg);
 /* the per-round index of the loaded streams (built on demand): info = {hot subjects, adjacency entries, waves per
- * workgroup, workgroups, LDS bytes per workgroup, alerts pre-validated (0/1), where node -> slot is looked up (3 = nowhere in
- * the tally: the resident records carry their subjects' resolved entries -- the product; the cross-check modes of the testing
- * knob: 0 = tables in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS), alert set declared (0/1)};
- * index_ms = device time of the last index build */
+ * workgroup, workgroups, LDS bytes per workgroup, alerts pre-validated (0/1), where the tally maps a record's subject to its
+ * slot (boundary records: 1 = direct tables in LDS, 2 = compressed tables in LDS, 0 = tables in memory, read through L2 --
+ * chosen by what fits the LDS next to the receivers' detector state; 3 = nowhere: generated resolved records carry their
+ * subjects' entries), alert set declared (0/1)}; index_ms = device time of the last index build */
 int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms);
-/* device time (ms) of the passes a stream set goes through once, outside the per-round step: out[0] = the last index build,
- * out[1] = the last resolve pass (every resident record's subject -> its dictionary entry of the current round index; runs
- * when streams, alert set or view changed since the records were last resolved), out[2] = the last rapid_sim_generate,
- * out[3] = 0 */
+/* device times (ms): out[0] = the last index build, out[1] = 0 (there is no resolve pass: a delivered record is read once, by
+ * the tally), out[2] = the last rapid_sim_generate, out[3] = 0 */
 int rapid_sim_pass_times(rapid_engine* h, float out[4]);
+/* testing / measurement knob, a bit set (0 = normal): 1 = every window through the exact sequential path, 8 = careful
+ * path only (no cold / fast windows), 64 = never the pre-validated instantiation (per-delivery filter), 128 = never direct
+ * tables, 256 = tables in memory, 512 = sharded vote count always through the histogram all-reduces (never the all-gather +
+ * merge of the ranks' local counts), 1024 = every receiver dealt to the workgroups statically (no common pool for the last
+ * eighth), 2048 = the vote count never uses the statistics the tally kernel gathers (always a counting pass), 4096 = the
+ * round index built by several workgroups (the form of populations >= 40,000 nodes) whatever the size, 16384 = a view change
+ * sorts all K rings again instead of compacting / merging the old ones, 32 = measurement only: stream the records through
+ * the registers without tallying them (results are meaningless).  Every bit selects another PRODUCT path or instantiation
+ * (all of them parity-tested); none adds code that the default does not ship. */
+int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);
+
+/* ---- TEST BUILD ONLY (librapid_mi355x_test.so = the same sources compiled with -DRAPID_TEST_BUILD): testing aids and
+ * measurement probes.  The product library librapid_mi355x.so does not export them, contains no probe kernel and reads no
+ * environment variable. ---- */
+#ifdef RAPID_TEST_BUILD
+/* testing aid: n delivered records starting at `first` -- boundary records: subject and core word (ring mask, bit 14 DOWN,
+ * bit 15 UP, bit 16 end of batch); resolved records: the subject's dictionary entry and the core word */
+int rapid_debug_read_records(rapid_engine* h, int64_t first, int32_t n, uint32_t* subjects, uint32_t* core_words);
 /* measurement probe (not a product path): stream the loaded records with the tally kernel's access pattern and no
  * processing.  Register loads: variant 0 = 2 KiB tiles x 8 in flight, 1: 4 KiB x 4, 2: 8 KiB x 2, 3: 2 KiB x 4,
  * 4: 1 KiB x 8, 5: 1 KiB x 16, 6: 1 KiB x 4; LDS-DMA loads (the tally kernel's path): 7: 1 KiB x 4, 8: 1 KiB x 8,
@@ -429,23 +442,14 @@ int rapid_sim_pass_times(rapid_engine* h, float out[4]);
 int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, int32_t reps, float* ms_avg);
 /* measurement aid: the tally kernel's counters per workgroup ([rows][8], the rows rapid_sim_stats sums) */
 int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, int32_t* rows_out);
-/* testing / measurement knob, a bit set (0 = normal): 1 = every window through the exact sequential path, 8 = careful
- * path only (no cold / fast windows), 64 = never trust the pre-validation of the alert set (per-delivery filter), 32768 = the
- * tally looks every subject up itself instead of reading resolved records, from tables placed where they fit best (direct
- * in LDS, else compressed in LDS, else in memory) -- the cross-check of the product's resolve pass; 128 = the same, never
- * direct tables; 256 = the same, tables in memory; 512 = sharded vote count always through the histogram all-reduces (never
- * the all-gather + merge of the ranks' local counts), 1024 = every receiver dealt to the workgroups statically (no common
- * pool for the last eighth), 2048 = the vote count never uses the statistics the tally kernel gathers (always a counting
- * pass), 4096 = the round index built by several workgroups (the form of populations >= 40,000 nodes) whatever the size,
- * 16384 = a view change sorts all K rings again instead of compacting / merging the old ones, 32 = measurement only: stream
- * the records through the registers without tallying them (results are meaningless) */
-int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);
 /* testing aids for the sharded vote count (one GPU standing in for n ranks): the answer block this engine's voters
  * contribute to rapid_sim_count_votes' all-gather (out == NULL: only *seg_bytes), and the device-side merge of n_ranks such
  * blocks laid end to end, as every rank runs it after the all-gather.  *status = 1: merged, *out filled like
  * rapid_sim_count_votes fills it; 2: the voters disagree somewhere and the general (histogram) count would run. */
 int rapid_debug_vote_segment(rapid_engine* h, void* out, int64_t cap_bytes, int64_t* seg_bytes);
 int rapid_debug_vote_merge(rapid_engine* h, const void* segments, int32_t n_ranks, rapid_round_result* out, int32_t* status);
+
+#endif /* RAPID_TEST_BUILD */
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,9 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAPID_MI355X_LIB") or os.path.join(_HERE, "librapid_mi355x.so")  # override: profiling builds
+# the TEST build: the same sources with -DRAPID_TEST_BUILD -- plus the rapid_debug_* entry points, the probe kernels and the
+# environment knobs of the measurement scripts.  Only tests/ and scripts/ load it (use_test_build()).
+TEST_LIB_PATH = os.path.join(_HERE, "librapid_mi355x_test.so")
 SRC_DIR = os.path.join(_HERE, "csrc")
 SOURCES = ["engine.hip", "host_abi.cpp", "tally_kernel.h", "stream_load.h", "lds_dma.h", "index_kernels.h", "view_kernels.h", "vote_kernels.h", "wire.h", "consensus.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rapid_mi355x.h")
@@ -53,38 +56,48 @@ def hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def needs_build():
-    if not os.path.exists(LIB_PATH):
+def _stale(path):
+    if not os.path.exists(path):
         return True
     srcs = [os.path.join(SRC_DIR, s) for s in SOURCES] + [HEADER]
     if not all(os.path.exists(s) for s in srcs):
         return False  # sources absent (binary-only snapshot): use what is there
-    return os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)
+    return os.path.getmtime(path) < max(os.path.getmtime(s) for s in srcs)
+
+
+def needs_build():
+    return _stale(LIB_PATH) or _stale(TEST_LIB_PATH)
 
 
 RESOURCES_PATH = os.path.join(os.path.dirname(LIB_PATH), "librapid_mi355x.resources.json")
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 cross-compiles without a GPU (about a minute).  The compiler's per-kernel resource
-    report (VGPRs, scratch bytes per lane, LDS) is kept next to the library: tests/test_build.py reads it, because a
-    tally kernel that starts spilling is a silent 20 % regression, not a build failure."""
+    """hipcc --offload-arch=gfx950 cross-compiles without a GPU (about a minute): the product library and, in parallel, the test
+    build.  The compiler's per-kernel resource report of the PRODUCT (VGPRs, scratch bytes per lane, LDS) is kept next to the
+    library: tests/test_build.py reads it, because a tally kernel that starts spilling is a silent 20 % regression, not a
+    build failure."""
     if not force and not needs_build():
         return LIB_PATH
-    tmp = "%s.tmp%d" % (LIB_PATH, os.getpid())  # concurrent builders (pytest-xdist workers) must not share the output file
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + SRC_DIR,
-           "-Rpass-analysis=kernel-resource-usage",
-           os.path.join(SRC_DIR, "engine.hip"), os.path.join(SRC_DIR, "host_abi.cpp"), "-o", tmp, "-lrccl"]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stderr)
-        raise subprocess.CalledProcessError(r.returncode, cmd)
-    with open(tmp + ".json", "w") as f:
-        json.dump(parse_resource_remarks(r.stderr), f, indent=1, sort_keys=True)
-    os.replace(tmp + ".json", RESOURCES_PATH)
-    os.replace(tmp, LIB_PATH)
+    jobs = []
+    for out, defs in ((LIB_PATH, []), (TEST_LIB_PATH, ["-DRAPID_TEST_BUILD"])):
+        tmp = "%s.tmp%d" % (out, os.getpid())  # concurrent builders (pytest-xdist workers) must not share the output file
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + SRC_DIR] + defs + \
+              ["-Rpass-analysis=kernel-resource-usage",
+               os.path.join(SRC_DIR, "engine.hip"), os.path.join(SRC_DIR, "host_abi.cpp"), "-o", tmp, "-lrccl"]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((out, tmp, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    for out, tmp, cmd, proc in jobs:
+        _, err = proc.communicate()
+        if proc.returncode != 0:
+            sys.stderr.write(err)
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        if out == LIB_PATH:
+            with open(tmp + ".json", "w") as f:
+                json.dump(parse_resource_remarks(err), f, indent=1, sort_keys=True)
+            os.replace(tmp + ".json", RESOURCES_PATH)
+        os.replace(tmp, out)
     return LIB_PATH
 
 
@@ -146,9 +159,6 @@ def _signatures():
         "rapid_device_count": (i32, []),
         "rapid_engine_comm_info": (i32, [vp, pi32, pi32]),
         "rapid_sim_new_round": (i32, [vp]),
-        "rapid_debug_block_stats": (i32, [vp, p, i32, pi32]),
-        "rapid_debug_vote_segment": (i32, [vp, p, i64, pi64]),
-        "rapid_debug_vote_merge": (i32, [vp, p, i32, p, pi32]),
         "rapid_sim_trust_alert_copies": (i32, [vp, i32]),
         "rapid_view_build": (i32, [vp, p, p, p, p, p, i32, p, i32, p, p, i32]),
         "rapid_view_register_endpoints": (i32, [vp, p, p, p, p, p, i32, pi32]),
@@ -177,7 +187,6 @@ def _signatures():
         "rapid_sim_set_alert_set": (i32, [vp, p, i64]),
         "rapid_sim_attach_streams_device": (i32, [vp, p, u64, p, i32]),
         "rapid_sim_generate": (i32, [vp, p, p, i32, p, p, i32, u64, i32]),
-        "rapid_debug_read_records": (i32, [vp, i64, i32, p, p]),
         "rapid_sim_tally": (i32, [vp]),
         "rapid_sim_results": (i32, [vp, p, p, p, p, i32]),
         "rapid_sim_proposal": (i32, [vp, i32, p, i32, pi32]),
@@ -222,11 +231,34 @@ def _signatures():
         "rapid_sim_set_force_exact": (i32, [vp, i32]),
         "rapid_sim_index_info": (i32, [vp, p, C.POINTER(C.c_float)]),
         "rapid_sim_pass_times": (i32, [vp, p]),
+    }
+
+
+def _test_signatures():
+    """the entry points only the test build exports (include/rapid_mi355x.h, section RAPID_TEST_BUILD)"""
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    p, pi32, pi64 = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    return {
+        "rapid_debug_block_stats": (i32, [vp, p, i32, pi32]),
+        "rapid_debug_vote_segment": (i32, [vp, p, i64, pi64]),
+        "rapid_debug_vote_merge": (i32, [vp, p, i32, p, pi32]),
+        "rapid_debug_read_records": (i32, [vp, i64, i32, p, p]),
         "rapid_debug_stream_probe": (i32, [vp, i32, i32, i32, C.POINTER(C.c_float)]),
     }
 
 
 SIGNATURES = _signatures()
+TEST_SIGNATURES = _test_signatures()
+
+
+def _load(path, with_test_symbols):
+    L = C.CDLL(path)
+    sigs = dict(SIGNATURES, **TEST_SIGNATURES) if with_test_symbols else SIGNATURES
+    for name, (res, args) in sigs.items():
+        f = getattr(L, name)  # AttributeError here == the library does not export a declared symbol
+        f.restype = res
+        f.argtypes = args
+    return L
 
 
 def lib():
@@ -236,10 +268,26 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RapidError(EDEVICE, "librapid_mi355x.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
-    L = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        f = getattr(L, name)  # AttributeError here == the library does not export a declared symbol
-        f.restype = res
-        f.argtypes = args
-    _lib = L
-    return L
+    # (a profiling build named by RAPID_MI355X_LIB is a test build: it carries the debug entry points, too)
+    is_test = os.path.basename(LIB_PATH) != "librapid_mi355x.so"
+    _lib = _load(LIB_PATH, is_test)
+    return _lib
+
+
+def use_test_build():
+    """Engines created from now on come from librapid_mi355x_test.so (tests/ and scripts/ that need rapid_debug_* or the probes).
+    Returns the previous library path; use_library(path) switches back."""
+    if os.environ.get("RAPID_MI355X_LIB"):  # a profiling build chosen by the environment is built with -DRAPID_TEST_BUILD already
+        return LIB_PATH
+    return use_library(TEST_LIB_PATH)
+
+
+def use_library(path):
+    global _lib, LIB_PATH
+    prev = LIB_PATH
+    if path != LIB_PATH:
+        if not os.path.exists(path):
+            raise RapidError(EDEVICE, "%s is not built" % path)
+        LIB_PATH = path
+        _lib = None
+    return prev

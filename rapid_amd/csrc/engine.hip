@@ -32,6 +32,14 @@
 
 namespace {
 
+// Measurement knobs read from the environment exist in the TEST build only (-DRAPID_TEST_BUILD: librapid_mi355x_test.so, the
+// same sources plus the rapid_debug_* entry points and the probe kernels); the product library reads no environment variable.
+#ifdef RAPID_TEST_BUILD
+inline const char* env_knob(const char* name) { return getenv(name); }
+#else
+inline const char* env_knob(const char*) { return nullptr; }
+#endif
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -284,10 +292,51 @@ static int sort_rings(rapid_engine* h, unsigned long long* keys_in, unsigned lon
     return RAPID_OK;
 }
 
+// Every buffer a view change can need, at the size the engine's capacity (n_max) allows: a view change -- on the path from a
+// decided cut to the next configuration id -- then never allocates or frees device memory (an allocation inside
+// rapid_apply_cut was measured at up to 190 ms against 4.5 ms for the change itself).  identifiersSeen is the exception: it
+// is never pruned (R/MembershipView.java:167-201) and grows past any bound in the end; it starts at twice the capacity.
+int presize_view(rapid_engine* h) {
+    const size_t K = (size_t)h->cfg.K, N = (size_t)h->cfg.n_max, km = K * N;
+    const size_t J = N / 4 + 2, kj = K * J;  // a change with more joiners than a quarter of the view sorts afresh (rebuild_view)
+    HIPCHK(h, h->d_member.ensure(N));
+    HIPCHK(h, h->d_members.ensure(N));
+    HIPCHK(h, h->d_sort_keys.ensure(km));
+    HIPCHK(h, h->d_sort_vals.ensure(km));
+    HIPCHK(h, h->d_ring_skeys.ensure(km));
+    HIPCHK(h, h->d_ring.ensure(km));
+    HIPCHK(h, h->d_pos.ensure(km));
+    HIPCHK(h, h->d_obs.ensure(km));
+    HIPCHK(h, h->d_subj.ensure(km));
+    HIPCHK(h, h->d_cfg_out.ensure(1));
+    HIPCHK(h, h->d_chunk_kept.ensure(K * ((N + rapid::kRingChunk - 1) / rapid::kRingChunk + 1)));
+    HIPCHK(h, h->d_joiners.ensure(J));
+    HIPCHK(h, h->d_join_keys.ensure(kj));
+    HIPCHK(h, h->d_join_skeys.ensure(kj));
+    HIPCHK(h, h->d_join_vals.ensure(kj));
+    HIPCHK(h, h->d_join_nodes.ensure(kj));
+    HIPCHK(h, h->d_seg_off.ensure(K + 1));
+    HIPCHK(h, h->d_ids_new.ensure(2 * N));
+    HIPCHK(h, h->d_ids_hi.ensure(2 * N));
+    HIPCHK(h, h->d_ids_lo.ensure(2 * N));
+    HIPCHK(h, h->d_ids_hi2.ensure(2 * N));
+    HIPCHK(h, h->d_ids_lo2.ensure(2 * N));
+    HIPCHK(h, h->d_cfg_partial.ensure(2 * 512));
+    HIPCHK(h, h->d_loadflags.ensure(2));
+    // the library sort's scratch: for all K rings at full size, and for the joiners of one change
+    size_t tmp_full = 0, tmp_join = 0;
+    HIPCHK(h, rocprim::segmented_radix_sort_pairs(nullptr, tmp_full, h->d_sort_keys.p, h->d_ring_skeys.p, h->d_sort_vals.p, h->d_ring.p, (unsigned int)km,
+                                                  (unsigned int)K, h->d_seg_off.p, h->d_seg_off.p + 1, 0, 64, h->stream));
+    HIPCHK(h, rocprim::segmented_radix_sort_pairs(nullptr, tmp_join, h->d_join_keys.p, h->d_join_skeys.p, h->d_join_vals.p, h->d_join_nodes.p, (unsigned int)kj,
+                                                  (unsigned int)K, h->d_seg_off.p, h->d_seg_off.p + 1, 0, 64, h->stream));
+    HIPCHK(h, h->d_sort_tmp.ensure(std::max(tmp_full, tmp_join) + 16));
+    return RAPID_OK;
+}
+
 int rebuild_view(rapid_engine* h) {
     const int K = h->cfg.K, N = h->n_nodes;
     hipStream_t st = h->stream;
-    const bool timing = getenv("RAPID_TIME_VIEW") != nullptr;  // profiling knob: where a view change spends its time (stderr)
+    const bool timing = env_knob("RAPID_TIME_VIEW") != nullptr;  // profiling knob: where a view change spends its time (stderr)
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!timing) return;
@@ -657,7 +706,7 @@ int build_round_index(rapid_engine* h) {
     long long best_blocks = 0;
     double best_cost = 1e300;
     int w_cap = rapid::tally_max_waves(h->dict_mode, tally_is_trusted(h), h->rec_fmt);  // (what decides the instantiation is known by now)
-    if (const char* e = getenv("RAPID_TALLY_WAVES")) w_cap = std::max(1, std::min(w_cap, atoi(e)));  // profiling knob
+    if (const char* e = env_knob("RAPID_TALLY_WAVES")) w_cap = std::max(1, std::min(w_cap, atoi(e)));  // profiling knob
     const double sat = 7.0;
     for (int w = 1; w <= w_cap; ++w) {
         if (sh + w * per_wave + rapid::kBlockStatsBytes > lds_max) break;
@@ -675,7 +724,7 @@ int build_round_index(rapid_engine* h) {
     h->lds_bytes = sh + best_w * per_wave + rapid::kBlockStatsBytes;
     const long long want = ((long long)h->n_receivers + best_w - 1) / best_w;
     int blocks_per_cu = 1;
-    if (const char* e = getenv("RAPID_TALLY_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::min(4, atoi(e)));  // profiling knob
+    if (const char* e = env_knob("RAPID_TALLY_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, std::min(4, atoi(e)));  // profiling knob
     h->grid_blocks = (int)std::max<long long>(1, std::min<long long>(want, (long long)h->num_cus * blocks_per_cu));
     h->index_valid = true;
     return RAPID_OK;
@@ -728,7 +777,7 @@ int launch_tally(rapid_engine* h) {
     p.waves_per_block = h->waves_per_block;
     p.flags = h->force_exact & (1 | 4 | 8 | 32);
     p.stagger = 0;
-    if (const char* e = getenv("RAPID_TALLY_STAGGER")) p.stagger = std::max(0, std::min(64, atoi(e)));  // profiling knob
+    if (const char* e = env_knob("RAPID_TALLY_STAGGER")) p.stagger = std::max(0, std::min(64, atoi(e)));  // profiling knob
     // The last eighth of the receivers is not dealt to the workgroups but left in a common pool (tally_kernel.h: n_static),
     // once a population is at least two rounds of the launch; testing knob bit 10: everything dealt statically.
     p.n_static = h->n_receivers;
@@ -739,7 +788,7 @@ int launch_tally(rapid_engine* h) {
     h->tally_votes_valid = true;
     {
         const long long slots = (long long)h->grid_blocks * h->waves_per_block;
-        const char* e = getenv("RAPID_POOL_EIGHTHS");  // measurement knob: size of the pool in eighths of the population
+        const char* e = env_knob("RAPID_POOL_EIGHTHS");  // measurement knob: size of the pool in eighths of the population
         const int eighths = e ? std::max(0, std::min(7, atoi(e))) : 1;
         if ((h->force_exact & 1024) == 0 && eighths > 0 && (long long)h->n_receivers >= 2 * slots) {
             long long ns = ((long long)h->n_receivers * (8 - eighths) / 8 / h->grid_blocks) * h->grid_blocks;
@@ -849,7 +898,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     // unrelated later call (rocPRIM checks hipGetLastError after its launches) to trip over
     auto quiet = [](hipError_t e, const char* what) {
         if (e != hipSuccess) {
-            if (getenv("RAPID_DEBUG")) fprintf(stderr, "rapid_engine_destroy: %s: %s\n", what, hipGetErrorString(e));
+            if (env_knob("RAPID_DEBUG")) fprintf(stderr, "rapid_engine_destroy: %s: %s\n", what, hipGetErrorString(e));
             (void)hipGetLastError();
         }
     };
@@ -894,6 +943,7 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
     int rc = use_device(h);
     if (rc) return rc;
     const int K = h->cfg.K;
+    if ((rc = presize_view(h))) return rc;
     h->n_nodes = n_nodes;
     h->id_hi.assign(id_hi, id_hi + n_nodes);
     h->id_lo.assign(id_lo, id_lo + n_nodes);
@@ -1488,6 +1538,7 @@ int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const 
     return RAPID_OK;
 }
 
+#ifdef RAPID_TEST_BUILD
 int rapid_debug_read_records(rapid_engine* h, int64_t first, int32_t n, uint32_t* subjects, uint32_t* core_words) {
     if (!h || first < 0 || n < 0 || !subjects || !core_words) return RAPID_EINVAL;
     if (!h->streams_loaded || first + n > h->n_records_total) return fail(h, RAPID_EINVAL, "records [%lld, %lld) not loaded", (long long)first, (long long)first + n);
@@ -1510,6 +1561,8 @@ int rapid_debug_read_records(rapid_engine* h, int64_t first, int32_t n, uint32_t
     }
     return RAPID_OK;
 }
+
+#endif  // RAPID_TEST_BUILD
 
 int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, int64_t n_alerts) {
     if (!h || n_alerts < 0 || (n_alerts > 0 && !alerts)) return RAPID_EINVAL;
@@ -1832,6 +1885,7 @@ int rapid_sim_decided_cut(rapid_engine* h, int32_t* out, int32_t cap, int32_t* n
     return copy_list(h, h->decided_cut.data(), (int)h->decided_cut.size(), out, cap, n_out);
 }
 
+#ifdef RAPID_TEST_BUILD
 // Testing aids for the sharded count: what this engine's voters contribute to the all-gather, and the merge of n such
 // contributions exactly as rapid_sim_count_votes runs it after its all-gather (one GPU stands in for n ranks).
 int rapid_debug_vote_segment(rapid_engine* h, void* out, int64_t cap_bytes, int64_t* seg_bytes) {
@@ -1881,6 +1935,8 @@ int rapid_debug_vote_merge(rapid_engine* h, const void* segments, int32_t n_rank
     const int verdict = decode_vote_answer(h, hres, reinterpret_cast<const int*>(hres + res_words), out);
     return verdict == kVoteNextSalt ? fail(h, RAPID_ESTATE, "merged answer is impure") : verdict;
 }
+
+#endif  // RAPID_TEST_BUILD
 
 int rapid_apply_cut(rapid_engine* h, const int32_t* cut, int32_t n, int64_t* new_config_id) {
     if (!h || n < 0 || (n > 0 && !cut)) return RAPID_EINVAL;
@@ -2015,6 +2071,7 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg) {
     return RAPID_OK;
 }
 
+#ifdef RAPID_TEST_BUILD
 // Measurement probe: streams the loaded records with the tally kernel's access pattern and no processing.
 // variant: 0 = 2 KiB tiles x 8 in flight, 1 = 4 KiB x 4, 2 = 8 KiB x 2, 3 = 2 KiB x 4; waves = waves per block.
 int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, int32_t reps, float* ms_avg) {
@@ -2027,14 +2084,14 @@ int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, in
     if (!h->ev1) HIPCHK(h, hipEventCreate(&h->ev1));
     const hipEvent_t e0 = h->ev0, e1 = h->ev1;
     int per_cu = 16;  // waves per CU
-    if (const char* e = getenv("RAPID_PROBE_WAVES_PER_CU")) per_cu = std::max(1, std::min(32, atoi(e)));
+    if (const char* e = env_knob("RAPID_PROBE_WAVES_PER_CU")) per_cu = std::max(1, std::min(32, atoi(e)));
     const dim3 grid((unsigned)h->num_cus * (unsigned)std::max(1, per_cu / waves)), block((unsigned)waves * 64u);
     size_t lds_pad = 0;
-    if (const char* e = getenv("RAPID_PROBE_LDS_PAD")) lds_pad = (size_t)atoi(e);
+    if (const char* e = env_knob("RAPID_PROBE_LDS_PAD")) lds_pad = (size_t)atoi(e);
     if (lds_pad > 0)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::dma_probe_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     unsigned int ring_off = 0;
-    if (const char* e = getenv("RAPID_PROBE_RING_OFFSET")) ring_off = (unsigned int)atoi(e);
+    if (const char* e = env_knob("RAPID_PROBE_RING_OFFSET")) ring_off = (unsigned int)atoi(e);
     const unsigned long long rec_b = h->rec_fmt == rapid::kFmtBoundary ? 20ull : 8ull;
     auto launch = [&]() {
         (void)hipMemsetAsync(h->d_next.p, 0, 4, h->stream);
@@ -2063,6 +2120,8 @@ int rapid_debug_stream_probe(rapid_engine* h, int32_t variant, int32_t waves, in
     *ms_avg = ms / (float)reps;
     return RAPID_OK;
 }
+
+#endif  // RAPID_TEST_BUILD
 
 int rapid_sim_pass_times(rapid_engine* h, float out[4]) {
     if (!h || !out) return RAPID_EINVAL;
@@ -2102,6 +2161,7 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
     return RAPID_OK;
 }
 
+#ifdef RAPID_TEST_BUILD
 int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, int32_t* rows_out) {
     if (!h || !rows_out || cap_rows < 0 || (cap_rows > 0 && !out)) return RAPID_EINVAL;
     int rc = use_device(h);
@@ -2113,6 +2173,8 @@ int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, in
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RAPID_OK;
 }
+
+#endif  // RAPID_TEST_BUILD
 
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on) {
     if (!h) return RAPID_EINVAL;

@@ -50,7 +50,9 @@
 
 #include <type_traits>
 
-#include <lds_dma.h>
+#ifdef RAPID_TEST_BUILD
+#include <lds_dma.h>  // (the LDS-DMA stream probe)
+#endif
 #include <stream_load.h>
 
 namespace rapid {
@@ -1663,6 +1665,7 @@ __global__ __launch_bounds__(64) void cd_instance_kernel(CdParams p) {
     }
 }
 
+#ifdef RAPID_TEST_BUILD
 // --------------------------------------------------------------------------------------------------------------
 // Measurement probe (not part of the product path): the same access pattern as the tally kernel -- one wave per
 // receiver stream, TILE-byte tiles of 16 B/lane loads, DEPTH tiles in flight -- with no processing, to separate
@@ -1743,5 +1746,7 @@ __global__ __launch_bounds__(1024) void dma_probe_kernel(const unsigned char* re
     wait_dma<0>();
     if (reinterpret_cast<unsigned int*>(smem)[threadIdx.x] == 0x12345678u) sink[0] = 1u;
 }
+
+#endif  // RAPID_TEST_BUILD
 
 }  // namespace rapid

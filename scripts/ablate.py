@@ -2,6 +2,9 @@ import sys, time, json
 import numpy as np
 sys.path.insert(0, '/root/repo')
 from rapid_amd import engine as E, scenarios as S
+from rapid_amd import _native as _N  # noqa: E402
+
+_N.use_test_build()  # measurement aids: environment knobs, probes and rapid_debug_* exist in the test build only
 n,K,H,L=10000,10,9,4
 pop=S.Population.make(n)
 eng=E.Engine(n_max=n,K=K,H=H,L=L)

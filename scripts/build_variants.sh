@@ -4,7 +4,7 @@ set -eu
 cd "$(dirname "$0")/.."
 while [ $# -ge 2 ]; do
   tag=$1; defs=$2; shift 2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC $defs -Irapid_amd/csrc rapid_amd/csrc/engine.hip rapid_amd/csrc/host_abi.cpp \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DRAPID_TEST_BUILD $defs -Irapid_amd/csrc rapid_amd/csrc/engine.hip rapid_amd/csrc/host_abi.cpp \
       -o rapid_amd/librapid_mi355x_$tag.so -lrccl &
 done
 wait

@@ -5,6 +5,9 @@ import sys
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np  # noqa: E402
 from rapid_amd import engine as E, scenarios as S  # noqa: E402
+from rapid_amd import _native as _N  # noqa: E402
+
+_N.use_test_build()  # measurement aids: environment knobs, probes and rapid_debug_* exist in the test build only
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C3b"
 spec = S.CONFIGS[name]

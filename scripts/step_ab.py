@@ -9,6 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rapid_amd import engine as E  # noqa: E402
 from rapid_amd import scenarios as S  # noqa: E402
+from rapid_amd import _native as _N  # noqa: E402
+
+_N.use_test_build()  # measurement aids: environment knobs, probes and rapid_debug_* exist in the test build only
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C3b"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50

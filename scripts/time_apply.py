@@ -5,6 +5,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rapid_amd import engine as E, scenarios as S  # noqa: E402
+from rapid_amd import _native as _N  # noqa: E402
+
+_N.use_test_build()  # measurement aids: environment knobs, probes and rapid_debug_* exist in the test build only
 
 n_mem = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 spare = n_mem // 50 + 64

@@ -16,19 +16,34 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
+    """-> (the entry points of the product library, the ones only the test build exports: the header's RAPID_TEST_BUILD section)"""
     text = open(os.path.join(ROOT, "include", "rapid_mi355x.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rapid_[a-z0-9_]+)\s*\(", text)))
+    a, b = text.index("#ifdef RAPID_TEST_BUILD"), text.index("#endif", text.index("#ifdef RAPID_TEST_BUILD"))
+    find = lambda t: sorted(set(re.findall(r"\b(rapid_[a-z0-9_]+)\s*\(", t)))
+    return find(text[:a] + text[b:]), find(text[a:b])
+
+
+def exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("rapid_")}
 
 
 def test_library_exports_every_declared_symbol():
+    """The product library exports exactly what the header declares outside its RAPID_TEST_BUILD section -- no testing aid, no
+    probe -- and holds no probe kernel and no getenv; the test build exports both sections."""
     N.build()
-    L = C.CDLL(N.LIB_PATH)
-    names = declared_symbols()
-    assert len(names) >= 40
-    for name in names:
-        assert hasattr(L, name), "missing export: " + name
-    assert set(names) == set(N.SIGNATURES), set(names) ^ set(N.SIGNATURES)
+    product, test_only = declared_symbols()
+    assert len(product) >= 40 and len(test_only) >= 5
+    assert set(product) == set(N.SIGNATURES), set(product) ^ set(N.SIGNATURES)
+    assert set(test_only) == set(N.TEST_SIGNATURES), set(test_only) ^ set(N.TEST_SIGNATURES)
+    assert exported(N.LIB_PATH) == set(product), exported(N.LIB_PATH) ^ set(product)
+    assert exported(N.TEST_LIB_PATH) == set(product) | set(test_only)
+    blob = open(N.LIB_PATH, "rb").read()
+    for needle in (b"stream_probe_kernel", b"dma_probe_kernel", b"rapid_debug_", b"RAPID_TALLY_WAVES", b"RAPID_POOL_EIGHTHS", b"RAPID_TIME_VIEW"):
+        assert needle not in blob, needle
+    assert b"stream_probe_kernel" in open(N.TEST_LIB_PATH, "rb").read()
 
 
 def test_record_layout():

@@ -22,6 +22,16 @@ def E():
     return engine
 
 
+@pytest.fixture()
+def test_build():
+    """The tests that use rapid_debug_* (reading delivered records back, one GPU standing in for several ranks) run on
+    librapid_mi355x_test.so -- the same sources plus those entry points; every other test runs on the product library."""
+    from rapid_amd import _native as N
+    prev = N.use_test_build()
+    yield
+    N.use_library(prev)
+
+
 def make_engine(E, pop, K, H, L, members=None, **kw):
     eng = E.Engine(n_max=pop.n, K=K, H=H, L=L, **kw)
     view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo, members=members)
@@ -725,7 +735,7 @@ def test_vote_count_through_a_one_rank_communicator(E):
             assert a["votes_total"] == a["votes_winner"] + 10 == len(sc.rec_off) - 1
 
 
-def test_sharded_vote_count_merges_the_ranks_local_answers(E):
+def test_sharded_vote_count_merges_the_ranks_local_answers(E, test_build):
     """The merge every rank runs after the all-gather of rapid_sim_count_votes (vote_merge_kernel), with one GPU standing in
     for three ranks: the receivers of a round are cut into three shards, each shard is tallied and counted on its own
     (rapid_debug_vote_segment = what the rank would contribute), and the merged answer must be the answer of the whole
@@ -884,8 +894,12 @@ def test_streams_handed_over_in_device_memory(E):
     d_bad = to_device(bad_off)
     for args in ((d_rec2.value + 12, raw.nbytes - 20, d_off.value), (d_rec2.value + 12, raw.nbytes, d_bad.value)):
         sim.attach_streams_device(*args, len(sc.rec_off) - 1)
+        with pytest.raises(E.IllegalArgumentException):  # nothing declared: the pass over the delivered records asks for their number
+            sim.tally()
+        sim.attach_streams_device(*args, len(sc.rec_off) - 1)
+        sim.set_alert_set(sc.batches.recs, trust_copies=True)  # declared: nothing on the host looks at the offsets ...
         sim.tally()
-        with pytest.raises(E.IllegalArgumentException):
+        with pytest.raises(E.IllegalArgumentException):        # ... the kernels did
             sim.results()
         with pytest.raises(E.IllegalArgumentException):
             sim.count_votes()
@@ -1140,7 +1154,7 @@ def test_streaming_rounds_with_stale_records_and_the_observer_cache(E):
     assert np.array_equal(m2, om2) and np.array_equal(s2, os2) and np.array_equal(o2, oo2)
 
 
-def test_streams_generated_on_the_device(E):
+def test_streams_generated_on_the_device(E, test_build):
     """rapid_sim_generate: the round's deliveries made on the device -- every receiver gets every batch once, in a
     seeded permutation of its own evaluated in place (no keys, no sort).  Against the host statement scenarios.deliver_hashed:
     the 20-byte boundary records are equal byte for byte; the resolved 8-byte records hold the subjects' dictionary entries and
@@ -1223,7 +1237,7 @@ def test_streams_generated_on_the_device(E):
         eng.close()
 
 
-def test_generated_streams_at_full_size(E):
+def test_generated_streams_at_full_size(E, test_build):
     """rapid_sim_generate at BASELINE configs[2]'s full size (N = 10,000, C3b: 9,487 receivers x 4,343 batches = 93.7 M
     records): EVERY receiver's outcome against the optimised CPU formulation fed scenarios.deliver_hashed's records, for the
     resolved and the boundary form; the round decides the closed fault set."""
