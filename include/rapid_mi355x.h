@@ -123,19 +123,25 @@ int rapid_view_config_id(rapid_engine* h, int64_t* id_out);                     
 /* whole tables, row-major [n_nodes][K] (observers of members = ring successors; rows of non-members hold
  * their expected observers; subjects rows of non-members are -1) -- what the scenario generators consume */
 int rapid_view_tables(rapid_engine* h, int32_t* observers, int32_t* subjects, uint8_t* member, int32_t n_nodes);
-/* Quirk Q4 of the reference, made visible to the host (R/MembershipView.java:143-152, 181-195, 210-224): getObserversOf is
- * memoised per node, and ringAdd / ringDelete drop only the entries of the changed node's ring predecessors -- an entry can
- * survive a view change that moves its node's observers (the ring minimum changes: the maximum's successor wraps to it).
- * The only reader on this path is invalidateFailingEdges (R/MultiNodeCutDetector.java:147-149), which asks for the observers
- * of the subjects in preProposal -- members the round's alerts name on >= L rings.  The engine always tallies from the
- * fresh tables, so its results are the reference's unless some receiver may hold a stale entry for such a subject.
- * hot[0..n): the subjects this round's alerts name on >= L rings (the caller's alert set knows them; non-members and
- * duplicates are skipped).  For each: if it was hot in an earlier configuration and has not left the view since, its
- * observers of that time are compared with today's; differing ones are written to out (capacity cap, *n_out = how many
- * there are: 0 = the quirk cannot fire at any receiver in this round).  Members seen for the first time are remembered
- * with today's observers; rapid_apply_cut / rapid_view_ring_delete forget a node that leaves (its entry dies with it,
- * :187-191).  Conservative in one direction only: it may name a subject no receiver actually cached. */
+/* Quirk Q4 of the reference, reproduced (R/MembershipView.java:143-152, 181-195, 210-224): getObserversOf is memoised per node,
+ * and ringAdd / ringDelete drop only the entries of the changed node's ring predecessors -- an entry survives a view change that
+ * moves its node's observers when the ring minimum changes (the maximum's successor wraps to it).  The only reader on this path
+ * is invalidateFailingEdges (R/MultiNodeCutDetector.java:147-149), which asks for the observers of the MEMBERS in preProposal
+ * -- members the round's alerts name on >= L rings ("hot").  The engine keeps the same memo on the device: a hot member's
+ * observers are memoised from today's table the first round it is hot since its entry was last dropped, the round index reads
+ * hot members' observers from the memo, and rapid_apply_cut / rapid_view_ring_add / _delete drop exactly the entries the Java
+ * drops.  A stale entry therefore stays stale as long as the reference's does, and the tally applies the implicit reports the
+ * reference would apply (tests provoke the quirk and compare with the oracle's faithful cache).  One memo per engine: the
+ * population shares the view object, as the oracle's does; a real deployment has one cache per node, filled when THAT node first
+ * had the subject in its preProposal -- a hot subject that no receiver ever had in preProposal at a batch end is memoised here
+ * and not there.
+ * rapid_view_q4_emulation(h, 0) switches the memo off: the index always reads today's observers (the round-3 behaviour).
+ * rapid_view_q4_at_risk reports: for hot[0..n) (non-members and duplicates skipped) a member without an entry gets one (what its
+ * first getObserversOf does), a member whose memoised observers differ from today's is written to out (capacity cap, *n_out =
+ * how many there are; 0 = the quirk is not live for any of them).  rapid_sim_index_info's info[7] bit 1 says the same about the
+ * round index that was last built. */
 int rapid_view_q4_at_risk(rapid_engine* h, const int32_t* hot, int32_t n, int32_t* out, int32_t cap, int32_t* n_out);
+int rapid_view_q4_emulation(rapid_engine* h, int32_t on);
 
 /* ---- MultiNodeCutDetector, one instance (R/MultiNodeCutDetector.java) ---------------------------------
  * State lives on the GPU; every call runs the exact sequential kernel on one wavefront.
@@ -412,7 +418,8 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg);
  * workgroup, workgroups, LDS bytes per workgroup, alerts pre-validated (0/1), where the tally maps a record's subject to its
  * slot (boundary records: 1 = direct tables in LDS, 2 = compressed tables in LDS, 0 = tables in memory, read through L2 --
  * chosen by what fits the LDS next to the receivers' detector state; 3 = nowhere: generated resolved records carry their
- * subjects' entries), alert set declared (0/1)}; index_ms = device time of the last index build */
+ * subjects' entries), bit 0: alert set declared, bit 1: a hot member's memoised observers are stale in this round (Q4 is
+ * live)}; index_ms = device time of the last index build */
 int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms);
 /* device times (ms): out[0] = the last index build, out[1] = 0 (there is no resolve pass: a delivered record is read once, by
  * the tally), out[2] = the last rapid_sim_generate, out[3] = 0 */

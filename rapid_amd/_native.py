@@ -176,6 +176,7 @@ def _signatures():
         "rapid_view_config_id": (i32, [vp, pi64]),
         "rapid_view_tables": (i32, [vp, p, p, p, i32]),
         "rapid_view_q4_at_risk": (i32, [vp, p, i32, p, i32, pi32]),
+        "rapid_view_q4_emulation": (i32, [vp, i32]),
         "rapid_cd_create": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
         "rapid_cd_destroy": (None, [vp]),
         "rapid_cd_aggregate": (i32, [vp, p, i32, p, i32, p, pi32]),

@@ -108,9 +108,14 @@ struct rapid_engine {
     int ring_m = 0;                              // their length
     int n_ids_dev = 0;
 
-    // Q4 (rapid_view_q4_at_risk): member -> its observers when it was first hot, until it leaves the view
-    std::unordered_map<int, std::vector<int>> q4_cached;
+    // Q4: the reference's memoised getObserversOf (R/MembershipView.java:210-224) on the device -- d_q4_rows[node][K] is what a
+    // member's observers were when it was first hot since its entry was last dropped, d_q4_valid[node] says whether an entry
+    // exists; the round index reads hot members' observers from here (index_kernels.h), rebuild_view drops what ringAdd /
+    // ringDelete drop.  q4_emulate == false: the index always reads today's table.
     DevBuf<int> d_q4_nodes, d_q4_rows;
+    DevBuf<unsigned char> d_q4_valid, d_q4_flag;
+    bool q4_emulate = true;
+    bool q4_live = false;  // the last index build found a hot member whose memoised observers are not today's
 
     // host mirrors of the tables (filled lazily after a rebuild)
     bool host_tables_valid = false;
@@ -323,6 +328,8 @@ int presize_view(rapid_engine* h) {
     HIPCHK(h, h->d_ids_lo2.ensure(2 * N));
     HIPCHK(h, h->d_cfg_partial.ensure(2 * 512));
     HIPCHK(h, h->d_loadflags.ensure(2));
+    HIPCHK(h, h->d_q4_rows.ensure(km));
+    HIPCHK(h, h->d_q4_valid.ensure(N));
     // the library sort's scratch: for all K rings at full size, and for the joiners of one change
     size_t tmp_full = 0, tmp_join = 0;
     HIPCHK(h, rocprim::segmented_radix_sort_pairs(nullptr, tmp_full, h->d_sort_keys.p, h->d_ring_skeys.p, h->d_sort_vals.p, h->d_ring.p, (unsigned int)km,
@@ -358,31 +365,26 @@ int rebuild_view(rapid_engine* h) {
             if (now && !was) joiners.push_back(n);
             if (was && !now) {
                 ++removed;
-                if (!h->q4_cached.empty()) gone.push_back(n);
+                gone.push_back(n);
             }
         }
     }
-    // Q4 bookkeeping (rapid_view_q4_at_risk), only while something is memoised: ringDelete drops the entries of the node and
-    // of its ring predecessors (TreeSet.lower, no wrap-around) -- read off the tables of the view that is about to change
-    auto q4_drop_lower = [&](const std::vector<int>& nodes) -> int {
-        if (nodes.empty() || h->q4_cached.empty() || !h->d_subj.p || !h->d_pos.p) return RAPID_OK;
+    // Q4: ringDelete drops the memoised observers of the node itself and of its ring predecessors (TreeSet.lower, no
+    // wrap-around) -- read off the tables of the view that is about to change; ringAdd those of the joiner's new predecessors
+    // (further down, off the new tables)
+    auto q4_drop = [&](const std::vector<int>& nodes, int self) -> int {
+        if (nodes.empty() || !h->d_subj.p || !h->d_pos.p || !h->d_q4_valid.p) return RAPID_OK;
         const size_t m = nodes.size();
-        std::vector<int> preds(m * (size_t)K);
         HIPCHK(h, h->d_q4_nodes.ensure(m));
-        HIPCHK(h, h->d_q4_rows.ensure(m * (size_t)K));
         HIPCHK(h, hipMemcpyAsync(h->d_q4_nodes.p, nodes.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(rapid::gather_lower_kernel, dim3(grid_for((long long)m * K, 256)), dim3(256), 0, st, h->d_subj.p, h->d_pos.p, h->d_q4_nodes.p, (int)m,
-                           N, K, h->d_q4_rows.p);
-        HIPCHK(h, hipMemcpyAsync(preds.data(), h->d_q4_rows.p, sizeof(int) * m * (size_t)K, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipStreamSynchronize(st));
-        for (int q : preds)
-            if (q >= 0) h->q4_cached.erase(q);
+        hipLaunchKernelGGL(rapid::q4_invalidate_kernel, dim3(grid_for((long long)m * K, 256)), dim3(256), 0, st, h->d_subj.p, h->d_pos.p, h->d_q4_nodes.p,
+                           (int)m, N, K, h->d_q4_valid.p, self);
+        HIPCHK(h, hipStreamSynchronize(st));  // (`nodes` is the caller's)
         return RAPID_OK;
     };
-    if (!gone.empty()) {
-        int rc = q4_drop_lower(gone);
+    if (have_rings && !gone.empty()) {
+        int rc = q4_drop(gone, 1);  // (:181-195)
         if (rc) return rc;
-        for (int n : gone) h->q4_cached.erase(n);  // (:187-191)
     }
     h->n_members = M;
     lap("host scan + q4");
@@ -455,7 +457,7 @@ int rebuild_view(rapid_engine* h) {
 
     lap("tables");
     if (have_rings && !joiners.empty()) {  // ringAdd drops the entries of the joiner's new ring predecessors (:143-152)
-        int rc = q4_drop_lower(joiners);
+        int rc = q4_drop(joiners, 0);
         if (rc) return rc;
     }
 
@@ -642,7 +644,8 @@ int build_round_index(rapid_engine* h) {
                        h->d_tent.p, tent_cap, d_info, reinterpret_cast<volatile int*>(h->d_mail),
                        ((h->force_exact & (128 | 256 | 8192)) != 0 || chunked) ? -1 : 160 * 1024 - rapid::kBlockStatsBytes,  // (lds_max below)
                        h->d_stats.p, (int)stats_words(h), h->d_errflags.p, (int)++h->mail_seq,
-                       chunked ? h->d_idxblk.p : nullptr, n_chunks);
+                       chunked ? h->d_idxblk.p : nullptr, n_chunks, h->q4_emulate ? h->d_q4_rows.p : (int*)nullptr,
+                       h->q4_emulate ? h->d_q4_valid.p : (unsigned char*)nullptr);
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipGetLastError());
     if (int rc = await_mail(h, 15, h->mail_seq)) return rc;
@@ -651,6 +654,7 @@ int build_round_index(rapid_engine* h) {
     int info[8];
     std::memcpy(info, h->h_mail, sizeof info);  // written by the kernel into host-mapped memory
     h->index_ms_pending = true;  // the events are read when somebody asks (no wait for them here)
+    h->q4_live = (info[2] & 4) != 0;
     if (info[2] & 1) return fail(h, RAPID_ECAPACITY, "the round has %d hot subjects; at most 16318 are supported", info[0]);
     if (info[2] & 2)
         return fail(h, RAPID_ECAPACITY, "hot adjacency has %d entries; at most 65535 are supported", info[3]);
@@ -917,7 +921,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_sort_keys.release(); h->d_sort_vals.release(); h->d_ring_skeys.release(); h->d_ring.release();
     h->d_pos.release(); h->d_obs.release(); h->d_subj.release();
     h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
-    h->d_q4_nodes.release(); h->d_q4_rows.release(); h->d_entries.release();
+    h->d_q4_nodes.release(); h->d_q4_rows.release(); h->d_q4_valid.release(); h->d_q4_flag.release(); h->d_entries.release();
     h->d_gen_res.release(); h->d_gen_keep.release(); h->d_gen_boff.release(); h->d_gen_rx.release();
     h->d_ids_hi2.release(); h->d_ids_lo2.release(); h->d_ids_new.release(); h->d_cfg_partial.release(); h->d_chunk_kept.release();
     h->d_joiners.release(); h->d_join_nodes.release(); h->d_join_vals.release(); h->d_join_keys.release(); h->d_join_skeys.release();
@@ -976,7 +980,7 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
         h->n_ids_dev = (int)ni;
     }
     h->ids_pending.clear();
-    h->q4_cached.clear();  // a new MembershipView object: nothing memoised
+    HIPCHK(h, hipMemsetAsync(h->d_q4_valid.p, 0, (size_t)h->cfg.n_max, h->stream));  // a new MembershipView object: nothing memoised
 
     for (int i = 0; i < n_nodes; ++i)
         if (host_off[i + 1] < host_off[i]) return fail(h, RAPID_EINVAL, "hostname offsets must not decrease (entry %d)", i);
@@ -1172,7 +1176,6 @@ int rapid_view_q4_at_risk(rapid_engine* h, const int32_t* hot, int32_t n, int32_
     if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
     int rc = use_device(h);
     if (rc) return rc;
-    const int K = h->cfg.K;
     std::vector<int> nodes;
     nodes.reserve((size_t)n);
     for (int i = 0; i < n; ++i) {
@@ -1182,31 +1185,32 @@ int rapid_view_q4_at_risk(rapid_engine* h, const int32_t* hot, int32_t n, int32_
     std::sort(nodes.begin(), nodes.end());
     nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
     *n_out = 0;
-    if (nodes.empty()) return RAPID_OK;
+    // (a view of one member has no observers: computeObserversOf returns the empty list, :240-242 -- nothing to go stale)
+    if (nodes.empty() || h->n_members <= 1) return RAPID_OK;
     const size_t m = nodes.size();
-    std::vector<int> rows(m * (size_t)K);
+    std::vector<unsigned char> flag(m);
     HIPCHK(h, h->d_q4_nodes.ensure(m));
-    HIPCHK(h, h->d_q4_rows.ensure(m * (size_t)K));
+    HIPCHK(h, h->d_q4_flag.ensure(m));
     HIPCHK(h, hipMemcpyAsync(h->d_q4_nodes.p, nodes.data(), sizeof(int) * m, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(rapid::gather_rows_kernel, dim3(grid_for((long long)m * K, 256)), dim3(256), 0, h->stream, h->d_obs.p, h->d_q4_nodes.p, (int)m, K,
-                       h->d_q4_rows.p);
-    HIPCHK(h, hipMemcpyAsync(rows.data(), h->d_q4_rows.p, sizeof(int) * m * (size_t)K, hipMemcpyDeviceToHost, h->stream));
+    hipLaunchKernelGGL(rapid::q4_check_kernel, dim3(grid_for((long long)m, 256)), dim3(256), 0, h->stream, h->d_q4_nodes.p, (int)m, h->d_member.p, h->d_obs.p,
+                       h->cfg.K, h->d_q4_rows.p, h->d_q4_valid.p, h->d_q4_flag.p);
+    HIPCHK(h, hipMemcpyAsync(flag.data(), h->d_q4_flag.p, m, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     int at_risk = 0;
-    for (size_t i = 0; i < m; ++i) {
-        // (a view of one member has no observers: computeObserversOf returns the empty list, :240-242)
-        std::vector<int> fresh;
-        if (h->n_members > 1) fresh.assign(rows.begin() + (long)(i * (size_t)K), rows.begin() + (long)((i + 1) * (size_t)K));
-        auto it = h->q4_cached.find(nodes[i]);
-        if (it == h->q4_cached.end()) {
-            h->q4_cached.emplace(nodes[i], std::move(fresh));
-        } else if (it->second != fresh) {
+    for (size_t i = 0; i < m; ++i)
+        if (flag[i]) {
             if (at_risk < cap) out[at_risk] = nodes[i];
             ++at_risk;
         }
-    }
     *n_out = at_risk;
     if (at_risk > cap) return fail(h, RAPID_ECAPACITY, "%d subjects at risk, capacity %d", at_risk, cap);
+    return RAPID_OK;
+}
+
+int rapid_view_q4_emulation(rapid_engine* h, int32_t on) {
+    if (!h) return RAPID_EINVAL;
+    if (h->q4_emulate != (on != 0)) h->index_valid = false;
+    h->q4_emulate = on != 0;
     return RAPID_OK;
 }
 
@@ -2151,7 +2155,7 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
     info[4] = h->lds_bytes;
     info[5] = tally_is_trusted(h) ? 1 : 0;
     info[6] = h->dict_mode;  // 3 = resolved records (no lookup in the tally); 0 / 1 / 2 = tables in memory / direct in LDS / compressed in LDS
-    info[7] = h->n_alert_set >= 0 ? 1 : 0;
+    info[7] = (h->n_alert_set >= 0 ? 1 : 0) | (h->q4_live ? 2 : 0);
     if (h->index_ms_pending && h->ev_idx0 && h->ev_idx1) {
         h->index_ms_pending = false;
         if (hipEventSynchronize(h->ev_idx1) == hipSuccess) (void)hipEventElapsedTime(&h->index_ms, h->ev_idx0, h->ev_idx1);

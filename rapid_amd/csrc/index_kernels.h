@@ -229,7 +229,7 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
                                                                  volatile int* info_out, int direct_budget,
                                                                  unsigned long long* zero_words, int n_zero_words,
                                                                  unsigned int* zero_flags, int seq, const int* blk_counts,
-                                                                 int n_chunks) {
+                                                                 int n_chunks, int* q4_rows, unsigned char* q4_valid) {
     __shared__ int s_wave[16];
     __shared__ int s_pre_hot, s_pre_touched;
     const int T = (int)blockDim.x, t = (int)threadIdx.x;
@@ -306,25 +306,45 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     __syncthreads();
     const int n_hot = min(n_hot_all, 16318);
     // ---- the hot adjacency as a flat list: thread t owns a contiguous chunk of the hot slots ----
+    // Quirk Q4 of the reference, reproduced (q4_valid != nullptr): invalidateFailingEdges asks getObserversOf(subject) for the
+    // MEMBERS in preProposal (R/MultiNodeCutDetector.java:147-149), and that call is memoised per node
+    // (R/MembershipView.java:210-224) with an invalidation that misses a change of the ring minimum (:143-152, 181-195).  A hot
+    // member's row is therefore read from the memo q4_rows -- written from today's table the first time the member is hot since
+    // its entry was last dropped (engine.hip: rebuild_view drops what ringAdd / ringDelete drop) -- and a stale row stays
+    // stale exactly as long as the Java's does.  Joiners go through getExpectedObserversOf, which is not memoised: fresh.
     const int per2 = (n_hot + T - 1) / T;
     const int b2 = min(n_hot, t * per2), e2 = min(n_hot, b2 + per2);
     int mine = 0;
+    bool stale = false;
+    auto observers_of = [&](int node) -> const int* {
+        if (q4_valid == nullptr || member[node] == 0) return obs + (long long)node * K;
+        int* const row = q4_rows + (long long)node * K;
+        if (q4_valid[node] == 0) {  // (this thread owns the node: one slot, one thread)
+            for (int k = 0; k < K; ++k) row[k] = obs[(long long)node * K + k];
+            q4_valid[node] = 1;
+        }
+        return row;
+    };
     for (int e = b2; e < e2; ++e) {
         const int node = node_of_slot[e];
+        const int* const row = observers_of(node);
         for (int k = 0; k < K; ++k) {
-            const int o = obs[node * K + k];
-            if (o >= 0 && (int)(dict[o] & 0x3FFF) < n_hot) ++mine;
+            const int o = row[k];
+            stale = stale || o != obs[(long long)node * K + k];
+            if (o >= 0 && o < n_nodes && (int)(dict[o] & 0x3FFF) < n_hot) ++mine;
         }
     }
+    if (stale) atomicOr(reinterpret_cast<unsigned int*>(&info[2]), 4u);  // (info[2] bit 2: some hot member's memoised observers are not today's -- the quirk is live in this round)
     int total = 0;
     int at = block_exclusive_scan(mine, s_wave, &total);
     const bool fits = total <= 65535 && total <= adj_cap;
     for (int e = b2; e < e2; ++e) {
         const int node = node_of_slot[e];
+        const int* const row = observers_of(node);
         unsigned int am = 0u;
         for (int k = 0; k < K; ++k) {
-            const int o = obs[node * K + k];
-            const int eo = o >= 0 ? (int)(dict[o] & 0x3FFF) : 0x3FFF;
+            const int o = row[k];
+            const int eo = o >= 0 && o < n_nodes ? (int)(dict[o] & 0x3FFF) : 0x3FFF;
             if (eo < n_hot) {  // a hot node observes e on ring k (for a joiner: one of its expected observers)
                 if (fits) pairs[at] = (unsigned int)e | ((unsigned int)eo << 14) | ((unsigned int)k << 28);
                 ++at;
@@ -390,7 +410,7 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     if (t == 0) {
         info[0] = n_hot_all;
         info[1] = n_hot_all;
-        info[2] = (n_hot_all > 16318 ? 1 : 0) | (fits ? 0 : 2);  // 64 slot numbers are kept for the tally kernel's dummy slots
+        info[2] = (info[2] & 4) | (n_hot_all > 16318 ? 1 : 0) | (fits ? 0 : 2);  // 64 slot numbers are kept for the tally kernel's dummy slots
         info[3] = total;
         for (int i = 0; i < 8; ++i) info_out[i] = info[i];  // info[4] was written by the touch pass
         // the host does not wait for the stream: it polls this word of the mapped page (what it reads afterwards was written

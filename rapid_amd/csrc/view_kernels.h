@@ -333,6 +333,39 @@ __global__ void gather_lower_kernel(const int* subj, const int* pos, const int* 
     preds[t] = pos[(long long)k * n_nodes + node] > 0 ? subj[(long long)node * K + k] : -1;
 }
 
+// The memoised observers of the reference (Q4; index_kernels.h reads them for hot members): valid[node] = 0 for what
+// ringAdd / ringDelete of nodes[i] drop -- the node's ring predecessors WITHOUT wrap-around (TreeSet.lower) and, self != 0, the
+// node's own entry (R/MembershipView.java:143-152, 181-195).  subj / pos: the tables of the view the predecessors are taken from.
+__global__ void q4_invalidate_kernel(const int* subj, const int* pos, const int* nodes, int n, int n_nodes, int K, unsigned char* valid, int self) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n * K) return;
+    const int i = (int)(t / K), k = (int)(t - (long long)i * K);
+    const int node = nodes[i];
+    if (self != 0 && k == 0) valid[node] = 0;
+    if (pos[(long long)k * n_nodes + node] > 0) {
+        const int pred = subj[(long long)node * K + k];
+        if (pred >= 0 && pred < n_nodes) valid[pred] = 0;
+    }
+}
+// rapid_view_q4_at_risk: for every member among nodes[] -- memoise today's observers if nothing is memoised (what the first
+// getObserversOf does), else flag[i] = the memo differs from today's table
+__global__ void q4_check_kernel(const int* nodes, int n, const unsigned char* member, const int* obs, int K, int* rows, unsigned char* valid,
+                                unsigned char* flag) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const int node = nodes[i];
+    flag[i] = 0;
+    if (member[node] == 0) return;
+    if (valid[node] == 0) {
+        for (int k = 0; k < K; ++k) rows[(long long)node * K + k] = obs[(long long)node * K + k];
+        valid[node] = 1;
+        return;
+    }
+    bool differs = false;
+    for (int k = 0; k < K; ++k) differs = differs || rows[(long long)node * K + k] != obs[(long long)node * K + k];
+    flag[i] = differs ? 1 : 0;
+}
+
 // ---- configuration id -------------------------------------------------------------------------------------------
 // hash = 1; for id in sorted ids: hash = hash*37 + xx0(high); hash = hash*37 + xx0(low);
 //           for ep in ring 0:     hash = hash*37 + xx0(hostname); hash = hash*37 + xx0(port)

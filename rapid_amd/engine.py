@@ -139,6 +139,11 @@ class MembershipView:
         self.e.n_nodes += len(hostnames)
         return first.value
 
+    def setObserverCacheEmulation(self, on):
+        """Quirk Q4 (stale cachedObservers, R/MembershipView.java:143-152, 181-195): reproduced by default; False = the round
+        index always reads today's observers."""
+        self.e._check(self.e._lib.rapid_view_q4_emulation(self.e._h, 1 if on else 0))
+
     def isSafeToJoin(self, node, node_id):
         s = C.c_int32(0)
         self.e._check(self.e._lib.rapid_view_is_safe_to_join(self.e._h, node, int(node_id[0]), int(node_id[1]), C.byref(s)))
@@ -441,6 +446,8 @@ class ClusterSimulation:
         keys = ("hot_subjects", "adjacency_entries", "waves_per_workgroup", "workgroups", "lds_bytes_per_workgroup",
                 "alerts_prevalidated", "dict_mode", "alert_set_declared")
         out = {k: int(v) for k, v in zip(keys, info)}
+        out["q4_live"] = (out["alert_set_declared"] >> 1) & 1  # a hot member's memoised observers are stale in this round (quirk Q4)
+        out["alert_set_declared"] &= 1
         # dict_mode -- where the tally maps a boundary record's subject to its slot: 1 = direct tables in LDS, 2 = compressed
         # tables in LDS, 0 = tables in memory (through L2); 3 = nowhere: generated records carry their subjects' entries
         out["tables_in_lds"] = int(out["dict_mode"] in (1, 2))

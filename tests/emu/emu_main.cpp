@@ -298,7 +298,7 @@ extern "C" int emu_index_run(const unsigned char* alerts, long long n_alerts, in
                              const unsigned char* member, const int* obs, int chunked, int direct_budget, unsigned short* dict,
                              unsigned short* decl, int* node_of_slot, unsigned short* smask, unsigned int* pairs, int adj_cap,
                              unsigned int* tbits, unsigned short* trank, unsigned int* tent, int tent_cap, int* info_out,
-                             unsigned long long seed) {
+                             unsigned long long seed, int* q4_rows, unsigned char* q4_valid) {
     std::vector<unsigned int> work((size_t)n_nodes + 8, 0u);
     unsigned int* gmask = work.data();
     int* info = reinterpret_cast<int*>(work.data() + n_nodes);
@@ -329,7 +329,7 @@ extern "C" int emu_index_run(const unsigned char* alerts, long long n_alerts, in
     emu::run_block(0u, 1u, 1024u, [&] {
         rapid::index_build_block_kernel(gmask, member, obs, n_nodes, K, L, dict, decl, node_of_slot, smask, pairs, adj_cap, tbits, trank, tent,
                                         tent_cap, info, mail, chunked ? -1 : direct_budget, zero_words, 64, zero_flags, 4242,
-                                        chunked ? blk.data() : nullptr, n_chunks);
+                                        chunked ? blk.data() : nullptr, n_chunks, q4_rows, q4_valid);
     }, seed + 400);
     for (int i = 0; i < 8; ++i) info_out[i] = mail[i];
     if (mail[15] != 4242) return -2;                       // the sequence word behind the answer

@@ -1267,8 +1267,8 @@ def test_generated_streams_at_full_size(E, test_build):
     eng.close()
 
 
-def test_q4_stale_observer_cache_is_reported_through_the_c_abi(E):
-    """rapid_view_q4_at_risk against the oracle's faithful cachedObservers (R/MembershipView.java:143-152, 181-195, 210-224).
+def test_q4_stale_observer_cache_is_reproduced_and_reported(E):
+    """The reference's memoised getObserversOf, kept on the device, and rapid_view_q4_at_risk against the oracle's faithful cachedObservers (R/MembershipView.java:143-152, 181-195, 210-224).
     A subject that was hot once (its observers memoised) and stays in the view: (1) an unrelated removal changes nothing;
     (2) removing its successor on a ring drops its entry in the Java as well (lower(successor) == subject): no risk, and the
     entry is re-created from today's observers; (3) removing the ring MINIMUM while the subject is that ring's MAXIMUM changes
@@ -1315,6 +1315,34 @@ def test_q4_stale_observer_cache_is_reported_through_the_c_abi(E):
     assert view.getObserversOf(x)[0] == int(view.getRing(0)[0]) != m0
     assert oview.getObserversOf(x) != oview.computeObserversOf(x) == view.getObserversOf(x)    # the reference reads the stale list
     assert guard.check_round(view, [x, int(ring0[1])]) == [x]
+    # ... and the quirk DECIDES a round, on the device as in the reference: m0 (gone) is reported UP on every ring, x DOWN on
+    # eight rings other than ring 0; invalidateFailingEdges finds m0 as x's ring-0 observer in the stale memo, credits x with
+    # the implicit report, and every receiver proposes {x, m0}.  Against the faithful oracle carrying its cache; with the memo
+    # switched off (today's observers) x stays one report short of H and nobody proposes.
+    from tests.test_kernel_emulated import _q4_round
+    cfg = view.getCurrentConfigurationId()
+    assert cfg == oview.getCurrentConfigurationId()
+    alerts, records, rec_off, _, _, _ = _q4_round(oview, x, m0, n, K, cfg, n_receivers=40)
+    oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, records, rec_off, prewarm_observers=False)
+    assert np.all(oe >= 0)
+    for declared in (False, True):
+        sim.load_streams(records, rec_off)
+        if declared:
+            sim.set_alert_set(alerts, trust_copies=True)
+        sim.tally()
+        emit, nprop, pcount, fp = sim.results()
+        assert sim.index_info()["q4_live"] == 1
+        assert np.array_equal(emit, oe) and np.array_equal(nprop, on) and np.array_equal(pcount, np.diff(oo))
+        assert np.array_equal(fp, proposal_fingerprints(oo, op, oe >= 0)) and sorted(sim.proposal(0)) == sorted([x, m0])
+    view.setObserverCacheEmulation(False)
+    sim.new_round()
+    sim.tally()
+    emit, nprop, pcount, fp = sim.results()
+    assert sim.index_info()["q4_live"] == 0 and np.all(emit == -1) and np.all(pcount == 0)
+    view.setObserverCacheEmulation(True)
+    sim.new_round()
+    sim.tally()
+    assert np.array_equal(sim.results()[0], oe)
     # ... until x itself leaves the view: its entry dies with it
     cut([x])
     assert guard.check_round(view, [x]) == []

@@ -535,3 +535,90 @@ def test_generator_edge_cases_and_the_late_delivery_model():
         key = lambda a: sorted(zip(a["src"].tolist(), a["dst"].tolist(), a["ring_mask"].tolist()))
         assert key(cur) == key(sc.batches.recs)
         assert int((seg["flags"] & 1).sum()) == B + n_late  # whole batches, each with its end
+
+
+def _q4_scene():
+    """A view in which the reference's memoised observers of a member are STALE (quirk Q4, R/MembershipView.java:143-152,
+    181-195): x is the maximum of ring 0 and was queried (getObserversOf memoised: its ring-0 observer is the ring minimum m0,
+    by wrap-around); then m0 leaves -- ringDelete drops the entries of m0's predecessors without wrap-around, and x, the
+    maximum, is not one of them -- so the memo keeps naming m0.  -> (pop, oracle view, x, m0, stale row, K, H, L)"""
+    K, H, L = 10, 9, 4
+    for n in range(300, 340):
+        pop = S.Population.make(n)
+        reg, oview = oracle_view(pop, K)
+        ring0 = oview.getRing(0)
+        x, m0 = int(ring0[-1]), int(ring0[0])
+        # m0 must not be x's direct successor on another ring (its removal would drop x's entry legitimately)
+        if m0 in oview.getObserversOf(x)[1:]:
+            continue
+        assert oview.getObserversOf(x)[0] == m0
+        oview.ringDelete(m0)
+        stale, fresh = oview.getObserversOf(x), oview.computeObserversOf(x)
+        assert stale[0] == m0 and fresh[0] == int(oview.getRing(0)[0]) != m0 and stale[1:] == fresh[1:]
+        return pop, oview, x, m0, stale, K, H, L
+    raise AssertionError("no population with the scene found")
+
+
+def _q4_round(oview, x, m0, n, K, cfg, n_receivers=6, seed=3):
+    """Alerts under which the stale entry decides the outcome: m0, gone from the view, is reported UP by its expected observers
+    on every ring (a joiner in the making: it enters preProposal / proposal), x is reported DOWN on eight rings other than
+    ring 0 -- one short of H = 9.  The reference's invalidateFailingEdges asks for x's observers, gets the stale list, finds m0
+    (in proposal) as x's ring-0 observer and credits x with the implicit report: x reaches H and is proposed.  With today's
+    observers x's ring-0 observer is the new ring minimum, which nobody reports: x stays at eight and blocks every proposal."""
+    obs, subj, member = oview.tables(n)
+    recs = []
+    for k in range(K):
+        recs.append(S_alert(int(obs[m0, k]), m0, S.UP, cfg, k))          # expected observers of the non-member m0
+    for k in range(1, 9):
+        recs.append(S_alert(int(obs[x, k]), x, S.DOWN, cfg, k))          # x's (fresh == memoised, on these rings) observers
+    alerts = np.concatenate(recs)
+    alerts["flags"] = 1  # every alert its own BatchedAlertMessage
+    rng = np.random.default_rng(seed)
+    parts = [alerts[rng.permutation(len(alerts))] for _ in range(n_receivers)]
+    off = np.arange(n_receivers + 1, dtype=np.int64) * len(alerts)
+    return alerts, np.concatenate(parts), off, obs, subj, member
+
+
+def S_alert(src, dst, status, cfg, ring):
+    a = np.zeros(1, dtype=S.ALERT_DTYPE)
+    a["src"], a["dst"], a["status"], a["cfg_id"], a["ring_mask"] = src, dst, status, cfg, 1 << ring
+    return a
+
+
+def test_q4_stale_observer_memo_decides_a_round_as_in_the_reference():
+    """Quirk Q4 reproduced: the faithful oracle with its observer cache as the view changes left it, against the emulated tally
+    over a round index whose row for the stale member is the MEMOISED one -- equal; over today's table -- different (nobody
+    proposes).  And the index kernel itself, given the memo arrays: a hot member without an entry is memoised from today's
+    table, a hot member with a stale entry is read from the memo and the round is marked (info[2] bit 2)."""
+    pop, oview, x, m0, stale, K, H, L = _q4_scene()
+    n = pop.n
+    cfg = oview.getCurrentConfigurationId()
+    alerts, records, rec_off, obs, subj, member = _q4_round(oview, x, m0, n, K, cfg)
+    oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, records, rec_off, prewarm_observers=False)
+    assert np.all(oe >= 0) and all(sorted(op[oo[r]:oo[r + 1]].tolist()) == sorted([x, m0]) for r in range(len(oe)))
+    # (the oracle's tables() go through getObserversOf: they ARE the memoised rows; today's row of x comes from computeObserversOf)
+    obs_memo = np.asarray(obs).copy()
+    assert obs_memo[x].tolist() == stale
+    obs = obs_memo.copy()
+    obs[x] = oview.computeObserversOf(x)
+    for trusted in (False, True):
+        emit, nprop, pcount, fpr, props, stats = pyemu.tally(records, rec_off, n, K, H, L, cfg, obs_memo, subj, member, trusted=trusted)
+        assert np.array_equal(emit, oe) and np.array_equal(nprop, on) and np.array_equal(pcount, np.diff(oo))
+        assert all(props[r, : pcount[r]].tolist() == sorted([x, m0]) for r in range(len(oe)))
+        emit_f, _, pcount_f, *_ = pyemu.tally(records, rec_off, n, K, H, L, cfg, obs, subj, member, trusted=trusted)
+        assert np.all(emit_f == -1) and np.all(pcount_f == 0)  # today's observers: x never reaches H
+    # the index kernels with the memo
+    want_memo = pyemu.build_round_index(alerts, n, K, L, obs_memo, member)
+    want_fresh = pyemu.build_round_index(alerts, n, K, L, np.asarray(obs), member)
+    assert want_memo["n_adj"] == want_fresh["n_adj"] + 1
+    for chunked in (False, True):
+        rows, valid = np.full((n, K), -7, dtype=np.int32), np.zeros(n, dtype=np.uint8)
+        got = pyemu.index_run(alerts, n, K, L, cfg, obs, member, chunked=chunked, q4=(rows, valid))
+        assert got["info"][2] == 0 and np.array_equal(got["pairs"][: want_fresh["n_adj"]], want_fresh["adj"][: want_fresh["n_adj"]])
+        assert valid[x] == 1 and rows[x].tolist() == np.asarray(obs)[x].tolist() and valid[m0] == 0 and valid.sum() == 1  # members only
+        rows[x] = stale
+        got = pyemu.index_run(alerts, n, K, L, cfg, obs, member, chunked=chunked, q4=(rows, valid))
+        assert got["info"][2] == 4 and got["info"][3] == want_memo["n_adj"]
+        assert np.array_equal(got["pairs"][: want_memo["n_adj"]], want_memo["adj"][: want_memo["n_adj"]])
+        assert np.array_equal(got["smask"][: want_memo["n_hot"]], want_memo["adj_off"][: want_memo["n_hot"]])
+        assert rows[x].tolist() == stale  # a stale entry stays what it is
