@@ -269,9 +269,14 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RapidError(EDEVICE, "librapid_mi355x.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
-    # (a profiling build named by RAPID_MI355X_LIB is a test build: it carries the debug entry points, too)
-    is_test = os.path.basename(LIB_PATH) != "librapid_mi355x.so"
-    _lib = _load(LIB_PATH, is_test)
+    # (a profiling / variant build is usually a test build: it carries the debug entry points, too)
+    if os.path.basename(LIB_PATH) != "librapid_mi355x.so":
+        try:
+            _lib = _load(LIB_PATH, True)
+            return _lib
+        except AttributeError:
+            pass
+    _lib = _load(LIB_PATH, False)
     return _lib
 
 

@@ -135,7 +135,6 @@ struct rapid_engine {
     // alert of the set carried that view's configuration id and named a registered node
     long long gen_cfg_id = 0;
     bool gen_clean = false;
-    DevBuf<unsigned int> d_stream_flag;   // offsets check of an attached stream set (index_kernels.h: offsets_check_kernel)
     bool offsets_on_device_only = false;  // attached: n_records_total is an upper bound until total_records() has fetched it
     DevBuf<long long> d_rec_off_own;
     const long long* d_rec_off = nullptr;
@@ -177,6 +176,7 @@ struct rapid_engine {
     int n_touched = 0;
     int dict_mode = 3;  // rapid::kDictResolved (the product) / kDictDirect / kDictCompressed / kDictMemory (testing knobs)
     bool lds_attr_set = false;
+    bool packed = false;  // the round's detector state: two slots per LDS word (tally_kernel.h: PackedSlotDetector)
     DevBuf<unsigned int> d_errflags;  // sticky per loaded stream set: bit0 = a delivered report is not covered by the declared alert set
     DevBuf<int> d_idxblk;  // per-workgroup hot / touched counts of the chunked index build
     DevBuf<int> d_node_of_slot, d_idxwork;  // d_idxwork = gmask[N] | info[8] of the round index build
@@ -668,7 +668,9 @@ int build_round_index(rapid_engine* h) {
 
     // ---- launch geometry: fill the CU's LDS with as many receiver-waves as possible ----
     const int lds_max = 160 * 1024;
-    const int per_wave = rapid::tally_wave_bytes(h->n_slots);
+    // rounds with thousands of hot subjects keep two slots per LDS word (the detector state decides how many receivers a CU holds)
+    h->packed = rapid::tally_wants_packed(h->n_hot);
+    const int per_wave = rapid::tally_wave_bytes(h->n_slots, h->packed);
     const int sh_direct = rapid::tally_shared_bytes(rapid::kDictDirect, N, h->n_touched, h->n_hot, h->n_adj);
     const int sh_comp = rapid::tally_shared_bytes(rapid::kDictCompressed, N, h->n_touched, h->n_hot, h->n_adj);
     const int sh_mem = rapid::tally_shared_bytes(rapid::kDictMemory, N, h->n_touched, h->n_hot, h->n_adj);  // (== kDictResolved: no tables)
@@ -684,6 +686,8 @@ int build_round_index(rapid_engine* h) {
     const bool no_direct = (h->force_exact & (128 | 256)) != 0 || info[7] == 0, no_lds = (h->force_exact & 256) != 0;  // info[7]: the build kernel's own verdict
     if (h->rec_fmt == rapid::kFmtResident)
         h->dict_mode = rapid::kDictResolved;  // generated records carry their subjects' entries
+    else if (h->packed)
+        h->dict_mode = rapid::kDictMemory;    // (the LDS goes to the receivers' state)
     else if (!no_direct && sh_direct + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
         h->dict_mode = rapid::kDictDirect;
     else if (!no_lds && compressed_ok && sh_comp + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
@@ -765,7 +769,7 @@ int launch_tally(rapid_engine* h) {
     p.idx.n_touched = h->n_touched;
     p.idx.entries = h->d_entries.p;
     p.error_flags = h->d_errflags.p;
-    p.stream_flag = h->offsets_on_device_only || h->d_stream_flag.p ? h->d_stream_flag.p : nullptr;
+    p.stream_bytes = h->records_bytes;
     p.idx.node_of_slot = h->d_node_of_slot.p;
     p.idx.smask = h->d_adj_off.p;  // (the buffers keep their round-1 names: per-slot masks, flat triple list)
     p.idx.pairs = h->d_adj.p;
@@ -807,7 +811,11 @@ int launch_tally(rapid_engine* h) {
     const bool trusted = tally_is_trusted(h);
     const size_t lds = (size_t)h->lds_bytes;
     using namespace rapid;
-    switch ((h->rec_fmt == kFmtBoundary ? 0 : 8) + h->dict_mode * 2 + (trusted ? 1 : 0)) {
+    switch ((h->packed ? 16 : 0) + (h->rec_fmt == kFmtBoundary ? 0 : 8) + h->dict_mode * 2 + (trusted ? 1 : 0)) {
+        case 16: hipLaunchKernelGGL((tally_population_kernel<kDictMemory, false, kFmtBoundary, true>), grid, block, lds, h->stream, p); break;
+        case 17: hipLaunchKernelGGL((tally_population_kernel<kDictMemory, true, kFmtBoundary, true>), grid, block, lds, h->stream, p); break;
+        case 30: hipLaunchKernelGGL((tally_population_kernel<kDictResolved, false, kFmtResident, true>), grid, block, lds, h->stream, p); break;
+        case 31: hipLaunchKernelGGL((tally_population_kernel<kDictResolved, true, kFmtResident, true>), grid, block, lds, h->stream, p); break;
         case 0: hipLaunchKernelGGL((tally_population_kernel<kDictMemory, false, kFmtBoundary>), grid, block, lds, h->stream, p); break;
         case 1: hipLaunchKernelGGL((tally_population_kernel<kDictMemory, true, kFmtBoundary>), grid, block, lds, h->stream, p); break;
         case 2: hipLaunchKernelGGL((tally_population_kernel<kDictDirect, false, kFmtBoundary>), grid, block, lds, h->stream, p); break;
@@ -837,7 +845,11 @@ int prepare_tally(rapid_engine* h) {
     }
     if (!h->lds_attr_set) {  // once per engine: every instantiation may use the whole 160 KiB of LDS
         using namespace rapid;
-        const void* kernels[8] = {reinterpret_cast<const void*>(tally_population_kernel<kDictResolved, false, kFmtResident>),
+        const void* kernels[12] = {reinterpret_cast<const void*>(tally_population_kernel<kDictResolved, false, kFmtResident, true>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictResolved, true, kFmtResident, true>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictMemory, false, kFmtBoundary, true>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictMemory, true, kFmtBoundary, true>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictResolved, false, kFmtResident>),
                                   reinterpret_cast<const void*>(tally_population_kernel<kDictResolved, true, kFmtResident>),
                                   reinterpret_cast<const void*>(tally_population_kernel<kDictMemory, false, kFmtBoundary>),
                                   reinterpret_cast<const void*>(tally_population_kernel<kDictMemory, true, kFmtBoundary>),
@@ -927,7 +939,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_joiners.release(); h->d_join_nodes.release(); h->d_join_vals.release(); h->d_join_keys.release(); h->d_join_skeys.release();
     h->d_records_own.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
-    h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_idxblk.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release(); h->d_stream_flag.release(); h->d_trank.release(); h->d_tbits.release(); h->d_tent.release();
+    h->d_alert_set.release(); h->d_next.release(); h->d_idxwork.release(); h->d_idxblk.release(); h->d_adj.release(); h->d_dict.release(); h->d_decl.release(); h->d_errflags.release(); h->d_trank.release(); h->d_tbits.release(); h->d_tent.release();
     h->d_adj_off.release(); h->d_node_of_slot.release(); h->d_loadflags.release();
     h->d_hist.release(); h->d_winner.release(); h->d_mm.release(); h->d_mismatch.release(); h->d_ref.release(); h->d_voteback.release(); h->d_gather.release();
     (void)hipGetLastError();
@@ -1363,7 +1375,6 @@ static int own_records(rapid_engine* h, const unsigned char* src, hipMemcpyKind 
     h->records_bytes = bytes;
     h->rec_fmt = rapid::kFmtBoundary;
     h->offsets_on_device_only = false;
-    if (h->d_stream_flag.p) HIPCHK(h, hipMemsetAsync(h->d_stream_flag.p, 0, 8, h->stream));  // (these offsets were checked on the host)
     return RAPID_OK;
 }
 
@@ -1425,14 +1436,10 @@ int rapid_sim_attach_streams_device(rapid_engine* h, const void* d_records, uint
     if ((reinterpret_cast<uintptr_t>(d_records) & 3u) != 0u) return fail(h, RAPID_EINVAL, "records must be 4-byte aligned");
     int rc = use_device(h);
     if (rc) return rc;
-    // On the round's path: nothing is copied, nothing is waited for.  The offsets are checked where they are, by a kernel ahead
-    // of the round's own on the engine's stream; offsets that fail are followed by no launch, and the round's results come back
-    // as RAPID_EINVAL (rapid_sim_results / rapid_sim_count_votes / rapid_sim_round).
-    HIPCHK(h, h->d_stream_flag.ensure(2));
-    HIPCHK(h, hipMemsetAsync(h->d_stream_flag.p, 0, 8, h->stream));
-    hipLaunchKernelGGL(rapid::offsets_check_kernel, dim3(grid_for((long long)n_receivers + 1, 256)), dim3(256), 0, h->stream,
-                       reinterpret_cast<const long long*>(d_rec_off), n_receivers, (unsigned long long)records_bytes, (long long)rapid::kMaxStreamRecords,
-                       h->d_stream_flag.p);
+    // On the round's path: nothing is copied, nothing is launched, nothing is waited for.  The offsets are checked where they are,
+    // by the wave of the tally kernel that is about to follow them (tally_kernel.h: TallyParams::stream_bytes): offsets that do
+    // not lie inside the records are not followed, and the round's results come back as RAPID_EINVAL (rapid_sim_results /
+    // rapid_sim_count_votes / rapid_sim_round).
     h->d_records = static_cast<const unsigned char*>(d_records);  // the tally reads them in place
     h->records_bytes = (unsigned long long)records_bytes;
     h->rec_fmt = rapid::kFmtBoundary;
@@ -1451,11 +1458,10 @@ int total_records_fwd(rapid_engine* h, long long* n) { return total_records(h, n
 static int total_records(rapid_engine* h, long long* n) {
     if (h->offsets_on_device_only) {
         long long last = 0;
-        unsigned int bad = 0;
         HIPCHK(h, hipMemcpyAsync(&last, h->d_rec_off + h->n_receivers, 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipMemcpyAsync(&bad, h->d_stream_flag.p, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (bad) return fail(h, RAPID_EINVAL, "the attached stream offsets are not ascending from 0, exceed a stream's capacity or run past records_bytes");
+        if (last < 0 || (unsigned long long)last * 20ull > h->records_bytes)
+            return fail(h, RAPID_EINVAL, "the attached stream offsets run past records_bytes");
         h->n_records_total = last;
         h->offsets_on_device_only = false;
     }
@@ -1532,7 +1538,6 @@ int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const 
     h->records_bytes = (unsigned long long)total * stride;
     h->d_rec_off = h->d_rec_off_own.p;
     h->offsets_on_device_only = false;
-    if (h->d_stream_flag.p) HIPCHK(h, hipMemsetAsync(h->d_stream_flag.p, 0, 8, st));
     h->gen_cfg_id = h->config_id;
     h->gen_clean = clean && batch_keep == nullptr;  // (an undelivered batch's places hold empty records: harmless, but not copies)
     const bool index_valid = h->index_valid;
@@ -1643,7 +1648,7 @@ static int check_tally_errors(rapid_engine* h) {
     HIPCHK(h, hipMemcpyAsync(flags, h->d_errflags.p, sizeof flags, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (flags[0] & 2u)
-        return fail(h, RAPID_EINVAL, "the attached stream offsets are not ascending from 0, exceed a stream's capacity or run past records_bytes");
+        return fail(h, RAPID_EINVAL, "a receiver's stream offsets do not lie inside the attached records (not ascending, longer than a stream's capacity, or past records_bytes)");
     if (flags[0] & 1u)
         return fail(h, RAPID_EINVAL, "a delivered alert names a subject / ring that the declared alert set does not contain "
                                     "(rapid_sim_set_alert_set must be given every distinct alert of the loaded streams)");
@@ -1706,7 +1711,7 @@ int rapid_sim_proposal(rapid_engine* h, int32_t receiver, int32_t* out, int32_t 
 constexpr int kVoteNextSalt = 1;
 static int decode_vote_answer(rapid_engine* h, const unsigned long long* hres, const int* href, rapid_round_result* out) {
     if ((unsigned int)hres[8] & 2u)
-        return fail(h, RAPID_EINVAL, "the attached stream offsets are not ascending from 0, exceed a stream's capacity or run past records_bytes");
+        return fail(h, RAPID_EINVAL, "a receiver's stream offsets do not lie inside the attached records (not ascending, longer than a stream's capacity, or past records_bytes)");
     if ((unsigned int)hres[8] & 1u)
         return fail(h, RAPID_EINVAL, "a delivered alert names a subject / ring that the declared alert set does not contain "
                                     "(rapid_sim_set_alert_set must be given every distinct alert of the loaded streams)");

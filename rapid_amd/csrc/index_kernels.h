@@ -39,22 +39,6 @@ __global__ void index_touch_kernel(const unsigned char* records, long long n_rec
     if (f) atomicOr(vflags, f);
 }
 
-// The offsets of an attached stream set (rapid_sim_attach_streams_device), checked where they are -- no copy to the host, no
-// synchronisation on the round's path: rec_off[0] == 0, ascending, no stream longer than max_stream records, the last one
-// inside the records buffer.  A violation sets *flag; the tally then follows none of them (tally_kernel.h: stream_flag).
-__global__ void offsets_check_kernel(const long long* rec_off, int n_receivers, unsigned long long records_bytes, long long max_stream,
-                                     unsigned int* flag) {
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i > n_receivers) return;
-    bool bad = false;
-    if (i == 0) bad = rec_off[0] != 0 || rec_off[n_receivers] < 0 || (unsigned long long)rec_off[n_receivers] * 20ull > records_bytes;
-    if (i < n_receivers) {
-        const long long a = rec_off[i], b = rec_off[i + 1];
-        bad = bad || b < a || b - a > max_stream;
-    }
-    if (bad) atomicOr(flag, 1u);
-}
-
 // node -> dict_entry for rounds whose tables stay in memory (tally_kernel.h: RoundIndex::entries): what the tally's direct mode
 // assembles while it stages its tables in LDS, written out once per round; entries[n_nodes] = the poison entry.
 __global__ void dict_entries_kernel(const unsigned short* dict, const unsigned short* decl, int n_nodes, int n_hot, unsigned int* entries) {
@@ -316,43 +300,62 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     const int b2 = min(n_hot, t * per2), e2 = min(n_hot, b2 + per2);
     int mine = 0;
     bool stale = false;
-    auto observers_of = [&](int node) -> const int* {
-        if (q4_valid == nullptr || member[node] == 0) return obs + (long long)node * K;
-        int* const row = q4_rows + (long long)node * K;
-        if (q4_valid[node] == 0) {  // (this thread owns the node: one slot, one thread)
-            for (int k = 0; k < K; ++k) row[k] = obs[(long long)node * K + k];
-            q4_valid[node] = 1;
+    // One slot's K observers -> their slots, as K INDEPENDENT loads twice over (rows, then dictionary entries): this kernel is one
+    // workgroup living on memory latency, and a loop over the rings with a dependent pair of loads per ring costs 2 K round trips
+    // per slot and pass (two thirds of the kernel's 30 us at C3b) where two suffice.
+    constexpr int kKMax = 14;  // RAPID_MAX_K
+    auto slot_edges = [&](int e, unsigned int (&eo)[kKMax]) -> unsigned int {
+        const int node = node_of_slot[e];
+        const bool use_memo = q4_valid != nullptr && member[node] != 0;
+        const bool have = use_memo && q4_valid[node] != 0;
+        const int* const today = obs + (long long)node * K;
+        int* const memo = q4_rows + (long long)node * K;
+        int o[kKMax], td[kKMax];
+#pragma unroll
+        for (int k = 0; k < kKMax; ++k) td[k] = k < K ? today[k] : -1;
+        if (have) {
+#pragma unroll
+            for (int k = 0; k < kKMax; ++k) {
+                o[k] = k < K ? memo[k] : -1;
+                stale = stale || o[k] != td[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kKMax; ++k) o[k] = td[k];
+            if (use_memo) {  // the first time this member is hot since its entry was dropped (this thread owns the node: one slot, one thread)
+#pragma unroll
+                for (int k = 0; k < kKMax; ++k)
+                    if (k < K) memo[k] = td[k];
+                q4_valid[node] = 1;
+            }
         }
-        return row;
+        unsigned int am = 0u;
+#pragma unroll
+        for (int k = 0; k < kKMax; ++k) eo[k] = (o[k] >= 0 && o[k] < n_nodes) ? ((unsigned int)dict[o[k]] & 0x3FFFu) : 0x3FFFu;
+#pragma unroll
+        for (int k = 0; k < kKMax; ++k) am |= (int)eo[k] < n_hot ? 1u << k : 0u;  // a hot node observes e on ring k (for a joiner: one of its expected observers)
+        return am;
     };
     for (int e = b2; e < e2; ++e) {
-        const int node = node_of_slot[e];
-        const int* const row = observers_of(node);
-        for (int k = 0; k < K; ++k) {
-            const int o = row[k];
-            stale = stale || o != obs[(long long)node * K + k];
-            if (o >= 0 && o < n_nodes && (int)(dict[o] & 0x3FFF) < n_hot) ++mine;
-        }
+        unsigned int eo[kKMax];
+        mine += __popc(slot_edges(e, eo));
     }
     if (stale) atomicOr(reinterpret_cast<unsigned int*>(&info[2]), 4u);  // (info[2] bit 2: some hot member's memoised observers are not today's -- the quirk is live in this round)
     int total = 0;
     int at = block_exclusive_scan(mine, s_wave, &total);
     const bool fits = total <= 65535 && total <= adj_cap;
     for (int e = b2; e < e2; ++e) {
-        const int node = node_of_slot[e];
-        const int* const row = observers_of(node);
-        unsigned int am = 0u;
-        for (int k = 0; k < K; ++k) {
-            const int o = row[k];
-            const int eo = o >= 0 && o < n_nodes ? (int)(dict[o] & 0x3FFF) : 0x3FFF;
-            if (eo < n_hot) {  // a hot node observes e on ring k (for a joiner: one of its expected observers)
-                if (fits) pairs[at] = (unsigned int)e | ((unsigned int)eo << 14) | ((unsigned int)k << 28);
+        unsigned int eo[kKMax];
+        const unsigned int am = slot_edges(e, eo);
+#pragma unroll
+        for (int k = 0; k < kKMax; ++k) {
+            if ((am >> k) & 1u) {
+                if (fits) pairs[at] = (unsigned int)e | (eo[k] << 14) | ((unsigned int)k << 28);
                 ++at;
-                am |= 1u << k;
             }
         }
         smask[e] = (unsigned short)am;
-        if (am != 0u) dict[node] |= (unsigned short)0x4000;  // only this thread touches dict[node] after the barrier above
+        if (am != 0u) dict[node_of_slot[e]] |= (unsigned short)0x4000;  // only this thread touches dict[node] after the barrier above
     }
     __threadfence_block();
     __syncthreads();  // dict[] is final (adjacency flags included)

@@ -70,6 +70,10 @@ __device__ __forceinline__ long long stream_scalar_load(const long long* p) {
     return *reinterpret_cast<const __attribute__((address_space(4))) long long*>(reinterpret_cast<unsigned long long>(p));
 }
 
+__device__ __forceinline__ unsigned int stream_scalar_load32(const unsigned int* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) unsigned int*>(reinterpret_cast<unsigned long long>(p));
+}
+
 // Stores the wait-count pass does not see (see above).  The address is per lane; inactive lanes store nothing.
 __device__ __forceinline__ void stream_store(int* p, int v) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void stream_store(unsigned long long* p, unsigned long long v) {

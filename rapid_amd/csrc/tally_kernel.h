@@ -176,9 +176,12 @@ struct TallyParams {
     int prop_cap;
     unsigned long long* stats;        // [workgroups][8], accumulated over launches
     unsigned int* error_flags;        // sticky: bit0 = a delivered report is not covered by the index (see RoundIndex::decl),
-                                      // bit1 = the attached stream offsets are not usable (stream_flag)
-    const unsigned int* stream_flag;  // != 0: the offsets check of an attached stream set failed (index_kernels.h: offsets_check_kernel):
-                                      // no stream is read, the results are void (RAPID_EINVAL when they are asked for); nullptr: checked on the host
+                                      // bit1 = a receiver's stream offsets do not lie inside the records (stream_bytes)
+    // Readable bytes at `core`.  The offsets of an attached stream set are the caller's device array and are checked HERE, by the
+    // wave that is about to follow them -- nothing is copied to the host and no kernel runs ahead of this one: a stream whose
+    // offsets are not 0 <= rec_off[r] <= rec_off[r + 1], longer than kMaxStreamRecords, or past stream_bytes is not read at all
+    // (the receiver gets "no proposal") and the round's results are void (RAPID_EINVAL when they are asked for).
+    unsigned long long stream_bytes;
     int waves_per_block;
     // Receivers [0, n_static) are dealt to the workgroups statically (n_static is a multiple of the grid size); the rest
     // is a common pool claimed through pool[0] by waves whose workgroup has worked off its own deal -- workgroups do not
@@ -223,16 +226,27 @@ __host__ __device__ inline int tally_dict_bytes(int mode, int n_nodes, int n_tou
 }
 // slot -> node (read once per proposed node, when a receiver's proposal is written) stays in memory when a round has so
 // many hot subjects that the LDS is better spent on receivers: C5's ~15,000 hot subjects per round at N = 10^6
-constexpr int kSlotNodesInLdsMax = 4096;
+// ... and so do the per-slot masks of the rings on which a hot observer watches the slot (read by cold windows, sweeps and the
+// choice of a witness, never by a fast window).  RAPID_SLOT_TABLES_LDS_MAX: the emulator builds a variant with 8, so that the
+// small populations of its tests run the tables-in-memory code.
+#ifndef RAPID_SLOT_TABLES_LDS_MAX
+#define RAPID_SLOT_TABLES_LDS_MAX 4096
+#endif
+constexpr int kSlotNodesInLdsMax = RAPID_SLOT_TABLES_LDS_MAX;
 __host__ __device__ inline int tally_shared_bytes(int mode, int n_nodes, int n_touched, int n_hot, int n_adj) {
-    return tally_dict_bytes(mode, n_nodes, n_touched) + align16((n_adj + 1) * 4) + align16((n_hot + kDummySlots) * 2) +
-           (n_hot <= kSlotNodesInLdsMax ? align16(n_hot * 4) : 0);
+    return tally_dict_bytes(mode, n_nodes, n_touched) + align16((n_adj + 1) * 4) +
+           (n_hot <= kSlotNodesInLdsMax ? align16((n_hot + kDummySlots) * 2) + align16(n_hot * 4) : 0);
 }
 // per-workgroup statistics accumulator at the very end of the dynamic LDS segment
 constexpr int kBlockStatsBytes = 112;  // eight counters, the workgroup's claim counter, four vote accumulators
-__host__ __device__ inline int tally_wave_bytes(int n_slots) {
-    return align16((n_slots + kDummySlots) * 4) + kScratchWords * 4 + kUndoCap * 4;
+// packed: two slots per LDS word (PackedSlotDetector) -- rounds with thousands of hot subjects, where the detector state decides
+// how many receivers a CU holds (C5: 15,000 hot subjects = 60 KB per receiver as 32-bit words)
+__host__ __device__ inline int tally_state_bytes(int n_slots, bool packed) { return align16((n_slots + kDummySlots) * (packed ? 2 : 4)); }
+__host__ __device__ inline int tally_wave_bytes(int n_slots, bool packed = false) {
+    return tally_state_bytes(n_slots, packed) + kScratchWords * 4 + kUndoCap * 4;
 }
+// rounds with more hot subjects than the per-slot tables' LDS limit run packed (and with their dictionary in memory)
+__host__ __device__ inline bool tally_wants_packed(int n_hot) { return n_hot > kSlotNodesInLdsMax; }
 
 // ---- small wave helpers ---------------------------------------------------------------------------------------
 // A receiver is owned by ONE wavefront; that wave's LDS operations execute in program order, so cross-lane
@@ -298,6 +312,39 @@ struct SlotDetector {
     __device__ __forceinline__ unsigned int or_bits(int i, unsigned int bits) const { return atomicOr(&st[i], bits); }
     __device__ __forceinline__ void clear_bits(int i, unsigned int bits) const { atomicAnd(&st[i], ~bits); }
     __device__ __forceinline__ void sync() const { wave_lds_fence(); }
+    // the fast window's application: the WHOLE core word into the slot whose doubled number is `so` (= entry >> 16), nothing returned
+    __device__ __forceinline__ void fast_or(unsigned int so, unsigned int core) const {
+        (void)atomicOr(reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(st) + 2u * so), core);
+    }
+    __device__ __forceinline__ void attach(unsigned char* base) { st = reinterpret_cast<unsigned int*>(base); }
+};
+
+// Two slots per LDS word: bits 0..13 = rings reported, bit 14 = already flushed into an emitted proposal, in each half.  Reads
+// and plain stores are 16-bit LDS accesses; the order-free ORs go to the containing word with the ring bits shifted into the
+// slot's half -- three more vector instructions per quarter of a fast window than the 32-bit layout, for half the LDS.
+struct PackedSlotDetector {
+    static constexpr unsigned int kFlushed = 1u << 14;
+    unsigned short* st16;
+    unsigned int* st32;
+    int n_scan;
+    int H, L;
+    unsigned int kmask;
+    __device__ __forceinline__ unsigned int load(int i) const { return st16[i]; }
+    __device__ __forceinline__ void store(int i, unsigned int v) const { st16[i] = (unsigned short)v; }
+    __device__ __forceinline__ int count(unsigned int m) const { return __popc(m & kmask); }
+    __device__ __forceinline__ unsigned int or_bits(int i, unsigned int bits) const {
+        const int sh = (i & 1) * 16;
+        return (atomicOr(&st32[i >> 1], bits << sh) >> sh) & 0xFFFFu;
+    }
+    __device__ __forceinline__ void clear_bits(int i, unsigned int bits) const { atomicAnd(&st32[i >> 1], ~(bits << ((i & 1) * 16))); }
+    __device__ __forceinline__ void sync() const { wave_lds_fence(); }
+    __device__ __forceinline__ void fast_or(unsigned int so, unsigned int core) const {  // so = 2 x slot: the word at byte (so & ~3), the half (so & 2)
+        (void)atomicOr(reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(st32) + (so & ~3u)), (core & kCoreRings) << ((so & 2u) << 3));
+    }
+    __device__ __forceinline__ void attach(unsigned char* base) {
+        st16 = reinterpret_cast<unsigned short*>(base);
+        st32 = reinterpret_cast<unsigned int*>(base);
+    }
 };
 
 // Global-memory flavour (one MultiNodeCutDetector instance, rapid_cd_*): indices are node indices, the implicit
@@ -520,8 +567,9 @@ __host__ __device__ constexpr int tally_max_waves(int dict_mode, bool trusted, i
     return (fmt == kFmtBoundary && dict_mode == kDictCompressed && !trusted) ? 12 : kMaxWavesPerBlock;
 }
 
-template <int kDictMode, bool kTrusted, int kFmt = kFmtResident>
+template <int kDictMode, bool kTrusted, int kFmt = kFmtResident, bool kPacked = false>
 __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) void tally_population_kernel(TallyParams p) {
+    static_assert(!kPacked || kDictMode == kDictMemory || kDictMode == kDictResolved, "packed detector state: dictionary in memory, or none");
     static_assert(kFmt == kFmtResident || kDictMode != kDictResolved, "a boundary record carries its subject, not an entry");
     constexpr bool kTablesInLds = kDictMode == kDictDirect;
     constexpr int kStride = kFmt == kFmtBoundary ? kRecBytes : kCoreBytes;  // bytes from one record to the next
@@ -570,6 +618,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
     }
     // the hot adjacency (flat list of triples, count first) and the per-slot masks, copied from the round index
     unsigned int* const l_pairs = reinterpret_cast<unsigned int*>(smem + dict_bytes);
+    const bool slot_tables_in_lds = n_hot <= kSlotNodesInLdsMax;  // the per-slot masks and slot -> node
     unsigned short* const l_smask = reinterpret_cast<unsigned short*>(smem + dict_bytes + pairs_bytes);
     int* const l_nos = reinterpret_cast<int*>(smem + dict_bytes + pairs_bytes + align16((n_hot + kDummySlots) * 2));
     if (threadIdx.x == 0) l_pairs[0] = (unsigned int)p.idx.n_adj;
@@ -577,25 +626,37 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
         // ONE loop on purpose: with three separate copy loops here the register allocation of the whole kernel changes
         // (the per-delivery-filter instantiations go from 116-125 VGPRs to 128 + 104-148 B of scratch per lane, whose
         // reloads sit inside the receiver loop: 0.42 -> 0.52 ms on C3b); tests/test_build.py checks the scratch size.
-        const int n_stage = p.idx.n_adj > n_hot + kDummySlots ? p.idx.n_adj : n_hot + kDummySlots;
+        const int n_slot_tab = slot_tables_in_lds ? n_hot + kDummySlots : 0;
+        const int n_stage = p.idx.n_adj > n_slot_tab ? p.idx.n_adj : n_slot_tab;
         for (int i = (int)threadIdx.x; i < n_stage; i += (int)blockDim.x) {
             if (i < p.idx.n_adj) l_pairs[1 + i] = p.idx.pairs[i];
-            if (i < n_hot) {
-                l_smask[i] = p.idx.smask[i];
-                if (n_hot <= kSlotNodesInLdsMax) l_nos[i] = p.idx.node_of_slot[i];
-            } else if (i < n_hot + kDummySlots) {
-                l_smask[i] = 0;
+            if (slot_tables_in_lds) {
+                if (i < n_hot) {
+                    l_smask[i] = p.idx.smask[i];
+                    l_nos[i] = p.idx.node_of_slot[i];
+                } else if (i < n_hot + kDummySlots) {
+                    l_smask[i] = 0;
+                }
             }
         }
     }
     const unsigned int* const pairs = l_pairs;
-    const unsigned short* const smask = l_smask;
-    const bool nos_in_lds = n_hot <= kSlotNodesInLdsMax;  // (two typed pointers, not one generic one: a flat load would cost the precise wait counts)
+    // (two typed pointers each, not one generic one: a flat load would cost the precise wait counts)
+    const bool nos_in_lds = slot_tables_in_lds;
+    auto smask_of = [&](unsigned int slot) -> unsigned int {  // rings on which a hot observer watches the slot (a dummy slot: none)
+        if (slot_tables_in_lds) return (unsigned int)l_smask[slot];
+        return slot < (unsigned int)n_hot ? (unsigned int)p.idx.smask[slot] : 0u;
+    };
+    auto smask_uniform = [&](int slot) -> unsigned int {  // the same for a wave-uniform slot: through the scalar cache when the table is in memory
+        if (slot_tables_in_lds) return uniform((unsigned int)l_smask[slot]);
+        const unsigned int w = stream_scalar_load32(reinterpret_cast<const unsigned int*>(p.idx.smask) + (slot >> 1));
+        return (w >> ((slot & 1) * 16)) & 0xFFFFu;
+    };
     // The launch statistics are summed per workgroup in LDS and stored once per workgroup: thousands of waves adding to
     // the same eight global words at the end of their lives queue up behind each other in one L2 channel -- measured:
     // 0.13 ms of a 0.63 ms kernel, and every stream that crosses that channel waits with them.
     unsigned long long* const block_stats =
-        reinterpret_cast<unsigned long long*>(smem + shared_bytes + (int)(blockDim.x >> 6) * tally_wave_bytes(n_hot));
+        reinterpret_cast<unsigned long long*>(smem + shared_bytes + (int)(blockDim.x >> 6) * tally_wave_bytes(n_hot, kPacked));
     unsigned int* const block_claims = reinterpret_cast<unsigned int*>(block_stats + 8);  // receivers claimed by this workgroup
     if (threadIdx.x < 8u) block_stats[threadIdx.x] = 0ull;
     unsigned long long* const block_votes = block_stats + 10;  // [4], see TallyParams::vote_acc
@@ -607,13 +668,14 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
     __syncthreads();
 
     // ---- this wave's private LDS ----
-    const int state_bytes = align16((n_hot + kDummySlots) * 4);
-    unsigned char* const mine = smem + shared_bytes + wave * tally_wave_bytes(n_hot);
+    const int state_bytes = tally_state_bytes(n_hot, kPacked);
+    unsigned char* const mine = smem + shared_bytes + wave * tally_wave_bytes(n_hot, kPacked);
     unsigned int* const scratch = reinterpret_cast<unsigned int*>(mine + state_bytes);
     unsigned int* const undo = scratch + kScratchWords;
 
-    SlotDetector d;
-    d.st = reinterpret_cast<unsigned int*>(mine);
+    typedef typename std::conditional<kPacked, PackedSlotDetector, SlotDetector>::type Det;
+    Det d;
+    d.attach(mine);
     d.n_scan = n_hot;
     d.H = p.H;
     d.L = p.L;
@@ -693,6 +755,13 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
             }
         }
         return x;
+    };
+    // (see TallyParams::stream_bytes) -> the stream's length in records; 0 and the error flag for offsets that cannot be followed
+    auto checked_length = [&](long long rec0, long long rec1) -> int {
+        const bool ok = rec0 >= 0 && rec1 >= rec0 && rec1 - rec0 <= kMaxStreamRecords &&
+                        (unsigned long long)rec1 * (unsigned long long)kStride <= p.stream_bytes;
+        if (!ok && lane == 0) stream_flag_or(p.error_flags, 2u);
+        return ok ? (int)(rec1 - rec0) : 0;
     };
     auto make_stream = [&](long long rec0, long long rec1) -> Stream {
         Stream st;
@@ -792,10 +861,6 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
     const int n_blocks = (int)gridDim.x;
     int r = uniform(wave * n_blocks + (int)blockIdx.x);  // the first deal: claim number `wave` of this workgroup
     if (r >= p.n_static) r = p.n_receivers;              // (the host sizes the static part so that this never takes pool work away)
-    if (p.stream_flag != nullptr && uniform(*p.stream_flag) != 0u) {  // offsets that failed their check are not followed
-        if (threadIdx.x == 0 && blockIdx.x == 0) stream_flag_or(p.error_flags, 2u);
-        r = p.n_receivers;
-    }
     // The stream runs kSets windows ahead of the tally: S[0] is the window about to be tallied, S[1 ..] the ones behind it,
     // all requested (a window that is being tallied has kSets - 1 successors in flight -- with one, a wave would wait out a
     // whole memory latency per window as soon as a window's tally is shorter than that, which it is since the fast window
@@ -815,8 +880,8 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
     int nrec = 0;
     if (r < p.n_receivers) {
         const long long rec0 = stream_scalar_load(p.rec_off + r), rec1 = stream_scalar_load(p.rec_off + r + 1);
-        nrec = (int)(rec1 - rec0);
-        rsrc = make_stream(rec0, rec1);
+        nrec = checked_length(rec0, rec1);
+        rsrc = make_stream(rec0, rec0 + nrec);
 #pragma unroll
         for (int i = 0; i < kSets; ++i) load_window(rsrc, lane_off + (unsigned int)i * kWinBytes, S[i]);
     }
@@ -879,7 +944,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
         auto set_witness = [&]() {
             witness = ci < ncand ? lane_value((int)candv, ci) : -1;
             witness_so = witness >= 0 ? 2u * (unsigned int)witness : 0xFFFFFFFFu;
-            wmask = witness >= 0 ? uniform((unsigned int)smask[witness]) : 0u;
+            wmask = witness >= 0 ? smask_uniform(witness) : 0u;
             wave_lds_fence();
             wstate = witness >= 0 ? uniform(d.load(witness)) : 0u;
         };
@@ -901,7 +966,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
                 const int ca = d.count(ma), cb = d.count(mb);
                 const bool prea = ina && ca >= d.L && ca < d.H, preb = inb && cb >= d.L && cb < d.H;
                 run += __popcll(wave_ballot(prea)) + __popcll(wave_ballot(preb));
-                const unsigned int ama = prea ? (unsigned int)smask[ia] : 0u, amb = preb ? (unsigned int)smask[ib] : 0u;
+                const unsigned int ama = prea ? smask_of((unsigned int)ia) : 0u, amb = preb ? smask_of((unsigned int)ib) : 0u;
                 const int bounda = d.count(ma | ama), boundb = d.count(mb | amb);
                 const unsigned int keya = (prea && bounda < d.H) ? ((unsigned int)bounda << 16) | (unsigned int)ia : 0xFFFFFFFFu;
                 const unsigned int keyb = (preb && boundb < d.H) ? ((unsigned int)boundb << 16) | (unsigned int)ib : 0xFFFFFFFFu;
@@ -981,9 +1046,6 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
         // branch: nothing is applied unless the certificate holds, the last quarter holds a batch end (the records after
         // it are carried into the next window) and no first DOWN report would switch the implicit invalidation on inside
         // the window.
-        auto slot_word = [&](unsigned int so) -> unsigned int* {  // the state word of the slot whose doubled number is `so`
-            return reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned char*>(d.st) + 2u * so);
-        };
         auto fast_try = [&](const Win& cw) -> int {
 #ifdef RAPID_PROBE_STREAM  // measurement builds only (results are void): what the turn loop costs with the tally taken out
 #pragma unroll
@@ -1043,10 +1105,10 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
 #pragma unroll
             for (int q = 0; q < kQ; ++q) sink ^= so[q] ^ w[q];
 #else
-            (void)atomicOr(slot_word(carry_so), carry_w);
+            d.fast_or(carry_so, carry_w);
 #pragma unroll
-            for (int q = 0; q < kQ - 1; ++q) (void)atomicOr(slot_word(so[q]), w[q]);
-            (void)atomicOr(slot_word(so[kQ - 1]), inl ? w[kQ - 1] : 0u);
+            for (int q = 0; q < kQ - 1; ++q) d.fast_or(so[q], w[q]);
+            d.fast_or(so[kQ - 1], inl ? w[kQ - 1] : 0u);
 #endif
             vbatch += nbv;
             carry_so = so[kQ - 1];
@@ -1087,9 +1149,9 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
                 old[q] = 0u;
                 if (rb[q] != 0u) old[q] = d.or_bits((int)e[q].slot, rb[q]);
             }
-            bool high = cb != 0u && d.count(oldc | cb | (unsigned int)smask[cs]) >= d.H;
+            bool high = cb != 0u && d.count(oldc | cb | smask_of(cs)) >= d.H;
 #pragma unroll
-            for (int q = 0; q < kQ; ++q) high = high || (rb[q] != 0u && d.count(old[q] | rb[q] | (unsigned int)smask[e[q].slot]) >= d.H);
+            for (int q = 0; q < kQ; ++q) high = high || (rb[q] != 0u && d.count(old[q] | rb[q] | smask_of(e[q].slot)) >= d.H);
             if (wave_ballot(high) != 0ull) {  // roll back: every lane clears exactly the bits it set
                 if ((cb & ~oldc) != 0u) d.clear_bits((int)cs, cb & ~oldc);
 #pragma unroll
@@ -1474,8 +1536,8 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
         int nrec_next = 0;
         if (r_next < p.n_receivers) {
             const long long rec0 = next0, rec1 = next1;
-            nrec_next = (int)(rec1 - rec0);
-            rsrc = make_stream(rec0, rec1);
+            nrec_next = checked_length(rec0, rec1);
+            rsrc = make_stream(rec0, rec0 + nrec_next);
 #pragma unroll
             for (int i = 0; i < kSets; ++i) load_window(rsrc, lane_off + (unsigned int)i * kWinBytes, S[i]);
         }
@@ -1488,7 +1550,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
             int* const out = p.props + (long long)r * p.prop_cap;
             for (int i0 = 0; i0 < n_hot; i0 += kWave) {
                 const int i = i0 + lane;
-                const bool take = i < n_hot && (d.load(i) & SlotDetector::kFlushed) != 0;
+                const bool take = i < n_hot && (d.load(i) & Det::kFlushed) != 0;
                 const unsigned long long mk = wave_ballot(take);
                 const int idx = count + __popcll(mk & lanes_lt(lane));
                 if (take) {

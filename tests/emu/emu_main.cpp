@@ -129,7 +129,7 @@ using rapid::smem;
 
 extern "C" {
 int emu_window_records() { return rapid::kWin; }
-int emu_tally_wave_bytes(int n_slots) { return rapid::tally_wave_bytes(n_slots); }
+int emu_tally_wave_bytes(int n_slots, int packed) { return rapid::tally_wave_bytes(n_slots, packed != 0); }
 int emu_tally_shared_bytes(int mode, int n_nodes, int n_touched, int n_hot, int n_adj) { return rapid::tally_shared_bytes(mode, n_nodes, n_touched, n_hot, n_adj); }
 
 // Runs the population kernel: `grid` persistent workgroups of `waves` waves, one workgroup at a time.
@@ -139,18 +139,19 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
                   const unsigned int* pairs, int n_hot, int n_adj, int* emit_batch, int* num_proposals,
                   int* prop_count, unsigned long long* fingerprint, int* props, int prop_cap, unsigned long long* stats,
                   int flags, int waves, int grid, int tables_in_lds, unsigned long long seed, const unsigned int* tbits,
-                  const unsigned short* trank, const unsigned int* tent, int n_touched, unsigned long long* vote_res_out, int fmt) {
+                  const unsigned short* trank, const unsigned int* tent, int n_touched, unsigned long long* vote_res_out, int fmt, int packed) {
+    // packed: two slots per LDS word (PackedSlotDetector); only with the dictionary in memory (0) or none (3)
+    if (packed && tables_in_lds != 0 && tables_in_lds != 3) return -9;
     // fmt: 0 = resident records (split / resolved below), 1 = the 20-byte boundary records themselves (kFmtBoundary)
     // tables_in_lds: 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS, 3 = no dictionary: the
     // records carry their subjects' entries (kDictResolved, what resolve_records_kernel leaves in the first dword)
-    const int lds = rapid::tally_shared_bytes(tables_in_lds, n_nodes, n_touched, n_hot, n_adj) + waves * rapid::tally_wave_bytes(n_hot) +
+    const int lds = rapid::tally_shared_bytes(tables_in_lds, n_nodes, n_touched, n_hot, n_adj) + waves * rapid::tally_wave_bytes(n_hot, packed != 0) +
                     rapid::kBlockStatsBytes;
     if (lds > (int)sizeof(smem)) return -5;
     rapid::TallyParams p;
     // the 20-byte records as the boundary hands them over -> the split resident form (what engine.hip's
     // split_records_kernel produces); exactly sized, so that a read past a stream's end is caught by the bounds model
-    const long long n_rec_all = rec_off[n_receivers];
-    (void)records_bytes;
+    const long long n_rec_all = std::min<long long>(std::max<long long>(rec_off[n_receivers], 0), (long long)(records_bytes / 20ull));  // (records_bytes: what the caller really holds)
     std::vector<unsigned int> core((size_t)n_rec_all * 2 + 2), cfgs((size_t)n_rec_all * 2 + 2);
     for (long long i = 0; i < n_rec_all; ++i) {
         unsigned int w[5];
@@ -197,7 +198,7 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     static unsigned int error_flags[2];
     error_flags[0] = error_flags[1] = 0u;
     p.error_flags = error_flags;
-    p.stream_flag = nullptr;
+    p.stream_bytes = fmt == 1 ? (unsigned long long)n_rec_all * 20ull : (unsigned long long)n_rec_all * 8ull;
     p.idx.node_of_slot = node_of_slot;
     p.idx.smask = smask;
     p.idx.pairs = pairs;
@@ -232,6 +233,16 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
         std::memset(smem, 0xCD, sizeof(smem));  // poison: the kernel must initialise what it reads
         const bool trusted = (flags & 256) != 0;  // emulator-only selector of the kTrusted instantiation
         auto run = [&](auto kern) { emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { kern(p); }, seed + (unsigned)b); };
+        if (packed) {
+            if (fmt == 1) {
+                if (trusted) run(rapid::tally_population_kernel<rapid::kDictMemory, true, rapid::kFmtBoundary, true>);
+                else run(rapid::tally_population_kernel<rapid::kDictMemory, false, rapid::kFmtBoundary, true>);
+            } else {
+                if (trusted) run(rapid::tally_population_kernel<rapid::kDictResolved, true, rapid::kFmtResident, true>);
+                else run(rapid::tally_population_kernel<rapid::kDictResolved, false, rapid::kFmtResident, true>);
+            }
+            continue;
+        }
         if (fmt == 1) {
             switch (tables_in_lds * 2 + (trusted ? 1 : 0)) {
                 case 0: run(rapid::tally_population_kernel<rapid::kDictMemory, false, rapid::kFmtBoundary>); break;

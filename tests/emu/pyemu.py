@@ -120,7 +120,7 @@ def validate_alerts(records, n_nodes, K, cfg_id, member):
 
 
 def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_cap=None, force_exact=0, seed=1, waves=3,
-          grid=2, tables_in_lds=1, trusted=False, declared=None, pool=False, fmt=None):
+          grid=2, tables_in_lds=1, trusted=False, declared=None, pool=False, fmt=None, packed=False):
     """`declared`: build the round index from these records (the round's distinct alert set) instead of the delivered
     ones; the call then returns (results ..., covered) with covered = False if the kernel found a delivered report that
     the declared set does not contain.  pool: only the first deal (grid x waves receivers) is static, the rest is claimed
@@ -149,11 +149,11 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     stats = np.zeros((grid, 8), dtype=np.uint64)  # one row per workgroup, as the kernel writes them
     vote_res = np.zeros(10, dtype=np.uint64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    rc = L_.emu_tally_run(p(raw), C.c_ulonglong((raw.nbytes // 16) * 16), p(rec_off), R, n_nodes, K, H, L, C.c_longlong(cfg_id),
+    rc = L_.emu_tally_run(p(raw), C.c_ulonglong(recs.nbytes), p(rec_off), R, n_nodes, K, H, L, C.c_longlong(cfg_id),
                           p(ix["dict"]), p(ix["decl"]), p(ix["node_of_slot"]), p(ix["adj_off"]), p(ix["adj"]),
                           ix["n_hot"], ix["n_adj"], p(emit), p(nprop), p(pcount), p(fp), p(props), prop_cap, p(stats),
                           force_exact, waves, grid, tables_in_lds, C.c_ulonglong(seed), p(ix["tbits"]), p(ix["trank"]), p(ix["tent"]),
-                          ix["n_touched"], p(vote_res), int(fmt))
+                          ix["n_touched"], p(vote_res), int(fmt), 1 if packed else 0)
     # the vote statistics the kernel gathers next to the proposals (TallyParams::vote_res) against the results themselves
     voters = np.flatnonzero(pcount != 0)
     assert int(vote_res[2]) == len(voters), (vote_res, len(voters))

@@ -38,6 +38,7 @@ inline void stream_load4(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int
 }
 
 inline long long stream_scalar_load(const long long* p) { return *p; }
+inline unsigned int stream_scalar_load32(const unsigned int* p) { return *p; }
 inline void stream_store(int* p, int v) { *p = v; }
 inline void stream_store(unsigned long long* p, unsigned long long v) { *p = v; }
 

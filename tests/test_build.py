@@ -20,8 +20,8 @@ def test_tally_kernels_fit_the_register_file_without_scratch():
     res = resources()
     tally = {k: v for k, v in res.items() if "tally_population_kernel" in k}
     # {20-byte boundary records looked up in memory / direct tables / compressed tables, resolved 8-byte records of the generator}
-    # x {filter per delivery, trusted copies}
-    assert len(tally) == 8, sorted(tally)
+    # x {filter per delivery, trusted copies} + {in memory, resolved} x {filter, trusted} with two slots per LDS word
+    assert len(tally) == 12, sorted(tally)
     for name, r in tally.items():
         assert r["ScratchSize [bytes/lane]"] == 0, (name, r)
         # 16 waves per CU = 4 per SIMD = 128 VGPRs; the per-delivery filter over compressed tables on boundary records is
@@ -39,10 +39,9 @@ def test_every_other_kernel_of_the_path_is_scratch_free_too():
     assert not spilling, spilling
 
 
-# (dictionary mode, trusted, record format): 0 / 1 / 2 = tables in memory / direct in LDS / compressed in LDS over 20-byte boundary
-# records (format 1); 3 = resolved 8-byte records (format 0)
-EXPECTED_VGPRS = {(0, False, 1): 123, (0, True, 1): 104, (1, False, 1): 118, (1, True, 1): 102, (2, False, 1): 133, (2, True, 1): 114,
-                  (3, False, 0): 90, (3, True, 0): 86}
+# (dictionary mode, trusted, record format, packed): 0 / 1 / 2 = tables in memory / direct in LDS / compressed in LDS over 20-byte
+# boundary records (format 1); 3 = resolved 8-byte records (format 0); packed = two slots per LDS word
+EXPECTED_VGPRS = {(0, False, 1, False): 124, (0, False, 1, True): 121, (0, True, 1, False): 110, (0, True, 1, True): 110, (1, False, 1, False): 120, (1, True, 1, False): 110, (2, False, 1, False): 134, (2, True, 1, False): 116, (3, False, 0, False): 96, (3, False, 0, True): 102, (3, True, 0, False): 92, (3, True, 0, True): 94}
 
 
 def test_register_allocation_of_the_tally_kernel_is_the_measured_one():
@@ -55,6 +54,6 @@ def test_register_allocation_of_the_tally_kernel_is_the_measured_one():
     got = {}
     for name, r in res.items():
         if "tally_population_kernel" in name:
-            t = name.split("tally_population_kernelILi")[1]  # <dictionary mode>ELb<trusted>ELi<record format>EEEv...
-            got[(int(t[0]), t[4] == "1", int(t[8]))] = r["VGPRs"]
+            t = name.split("tally_population_kernelILi")[1]  # <dictionary mode>ELb<trusted>ELi<record format>ELb<packed>EEEv...
+            got[(int(t[0]), t[4] == "1", int(t[8]), t[12] == "1")] = r["VGPRs"]
     assert got == EXPECTED_VGPRS, got

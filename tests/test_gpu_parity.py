@@ -894,8 +894,9 @@ def test_streams_handed_over_in_device_memory(E):
     d_bad = to_device(bad_off)
     for args in ((d_rec2.value + 12, raw.nbytes - 20, d_off.value), (d_rec2.value + 12, raw.nbytes, d_bad.value)):
         sim.attach_streams_device(*args, len(sc.rec_off) - 1)
-        with pytest.raises(E.IllegalArgumentException):  # nothing declared: the pass over the delivered records asks for their number
-            sim.tally()
+        with pytest.raises(E.IllegalArgumentException):  # nothing declared: the pass over the delivered records asks for their
+            sim.tally()                                  # number (a count past the records: here); else the kernel's check
+            sim.results()
         sim.attach_streams_device(*args, len(sc.rec_off) - 1)
         sim.set_alert_set(sc.batches.recs, trust_copies=True)  # declared: nothing on the host looks at the offsets ...
         sim.tally()
@@ -1338,7 +1339,10 @@ def test_q4_stale_observer_cache_is_reproduced_and_reported(E):
     sim.new_round()
     sim.tally()
     emit, nprop, pcount, fp = sim.results()
-    assert sim.index_info()["q4_live"] == 0 and np.all(emit == -1) and np.all(pcount == 0)
+    # (x, one report short of H, is never proposed and blocks the proposal -- except at a receiver that has m0 complete before
+    # x reaches L, which proposes m0 alone with or without the memo)
+    assert sim.index_info()["q4_live"] == 0 and np.all(pcount <= 1) and np.array_equal(emit >= 0, np.diff(oo) == 1)
+    assert int((emit >= 0).sum()) < len(emit) // 4 and all(sim.proposal(int(r)) == [m0] for r in np.flatnonzero(emit >= 0))
     view.setObserverCacheEmulation(True)
     sim.new_round()
     sim.tally()

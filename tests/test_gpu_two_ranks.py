@@ -56,8 +56,8 @@ WORKER = COMMON + textwrap.dedent("""
     sys.path.insert(0, %(root)r)
     import torch
     import torch.distributed as dist
-    from rapid_amd import engine as E, parallel as P, _native as N
-    N.use_test_build()   # (rapid_debug_vote_segment / _merge)
+    from rapid_amd import engine as E, parallel as P, _native as NATIVE
+    NATIVE.use_test_build()   # (rapid_debug_vote_segment / _merge)
     rank, world = int(sys.argv[1]), int(sys.argv[2])
     dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=world)
     pop = S.Population.make(N)

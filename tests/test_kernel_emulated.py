@@ -76,6 +76,7 @@ def test_random_adversarial_streams(seed):
         recs.append(random_stream(rng, n_nodes, K, member, cfg, n_rec, hot, p_eob=float(rng.choice([0.02, 0.3, 1.0]))))
         off.append(off[-1] + n_rec)
     _check(np.concatenate(recs), np.array(off), n_nodes, K, H, L, cfg, obs, subj, member, seed=seed)
+    _check(np.concatenate(recs), np.array(off), n_nodes, K, H, L, cfg, obs, subj, member, seed=seed, tables_in_lds=0 if seed % 2 else 3, packed=True)
 
 
 @pytest.mark.parametrize("name,n,f,K,H,L", [("C1", 50, 1, 3, 3, 1), ("C2", 300, 12, 10, 9, 4),
@@ -130,6 +131,10 @@ def test_other_dictionary_placements(mode):
         off.append(off[-1] + n_rec)
     _check(np.concatenate(recs), np.array(off), n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode)
     _check(np.concatenate(recs), np.array(off), n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode, pool=True)
+    if mode in (0, 3):  # ... and with two slots per LDS word (PackedSlotDetector: the state of rounds with thousands of hot subjects)
+        _check(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode, packed=True)
+        _check(np.concatenate(recs), np.array(off), n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode, packed=True)
+        _check(np.concatenate(recs), np.array(off), n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode, packed=True, pool=True, waves=2, grid=3)
 
 
 def test_receivers_claimed_from_the_common_pool():
@@ -606,7 +611,9 @@ def test_q4_stale_observer_memo_decides_a_round_as_in_the_reference():
         assert np.array_equal(emit, oe) and np.array_equal(nprop, on) and np.array_equal(pcount, np.diff(oo))
         assert all(props[r, : pcount[r]].tolist() == sorted([x, m0]) for r in range(len(oe)))
         emit_f, _, pcount_f, *_ = pyemu.tally(records, rec_off, n, K, H, L, cfg, obs, subj, member, trusted=trusted)
-        assert np.all(emit_f == -1) and np.all(pcount_f == 0)  # today's observers: x never reaches H
+        # today's observers: x never reaches H and blocks the proposal (a receiver that has m0 complete before x reaches L
+        # proposes m0 alone, with or without the memo)
+        assert np.all(pcount_f <= 1) and np.array_equal(emit_f >= 0, np.diff(oo) == 1) and not np.array_equal(emit_f, oe)
     # the index kernels with the memo
     want_memo = pyemu.build_round_index(alerts, n, K, L, obs_memo, member)
     want_fresh = pyemu.build_round_index(alerts, n, K, L, np.asarray(obs), member)
@@ -622,3 +629,29 @@ def test_q4_stale_observer_memo_decides_a_round_as_in_the_reference():
         assert np.array_equal(got["pairs"][: want_memo["n_adj"]], want_memo["adj"][: want_memo["n_adj"]])
         assert np.array_equal(got["smask"][: want_memo["n_hot"]], want_memo["adj_off"][: want_memo["n_hot"]])
         assert rows[x].tolist() == stale  # a stale entry stays what it is
+
+
+def test_stream_offsets_that_cannot_be_followed_void_the_round():
+    """The offsets of an attached stream set are checked by the wave that is about to follow them (TallyParams::stream_bytes): a
+    stream whose offsets descend, or run past the records, is not read -- the emulator's bounds model would catch a read -- and
+    the launch reports it (error flag bit 1 -> RAPID_EINVAL on the device path)."""
+    n, K, H, L = 40, 5, 4, 2
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K)
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    rng = np.random.default_rng(5)
+    lens = [30, 300, 12, 700, 64]
+    parts = [random_stream(rng, n, K, member, cfg, m, [1, 2, 3, 4, 5]) for m in lens]
+    records, off = np.concatenate(parts), np.cumsum([0] + lens)
+    for bad in ("descending", "past the end"):
+        boff = off.copy()
+        if bad == "descending":
+            boff[2], boff[3] = boff[3], boff[2]
+        else:
+            boff[-1] += 5
+        for mode in (1, 3):
+            *res, covered = pyemu.tally(records, boff, n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode, declared=records)
+            assert not covered, (bad, mode)
+    *res, covered = pyemu.tally(records, off, n, K, H, L, cfg, obs, subj, member, declared=records)
+    assert covered
