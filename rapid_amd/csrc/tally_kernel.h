@@ -735,16 +735,17 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
     // is dropped), the status byte as two bits, the batch-end flag in bit 16 (core_word).  An alert without ring numbers does
     // nothing in the reference (aggregateForProposal(AlertMessage) iterates over them, R/MultiNodeCutDetector.java:76-82) and is
     // cleared the same way -- which also makes the zeros behind a stream's end the empty record they are in the resident format.
-    const unsigned int cfg_lo = cfg_lo_, cfg_hi = cfg_hi_;
+    const unsigned long long cfg64 = (unsigned long long)p.cfg_id;
     auto open = [&](const Win& c) -> Rec {
         Rec x;
 #pragma unroll
         for (int q = 0; q < kQ; ++q) {
             if constexpr (kFmt == kFmtBoundary) {
-                const unsigned int other = (c.c0[q] ^ cfg_lo) | (c.c1[q] ^ cfg_hi);
+                // (one 64-bit compare instead of two exclusive-ors, an or and a 32-bit compare)
+                const bool current = (((unsigned long long)c.c1[q] << 32) | (unsigned long long)c.c0[q]) == cfg64;
                 const unsigned int raw = c.w4[q];
                 const unsigned int rings = raw & kCoreRings;
-                const unsigned int live = other == 0u ? rings : 0u;
+                const unsigned int live = current ? rings : 0u;
                 const unsigned int eobw = (raw >> 8) & kCoreEob;
                 const unsigned int full = rings | ((raw & 0x00FF0000u) != 0u ? kCoreDown : kCoreUp) | eobw;
                 x.w3[q] = c.w3[q];

@@ -885,6 +885,16 @@ def test_streams_handed_over_in_device_memory(E):
         assert all(np.array_equal(a, b) for a, b in zip(want, sim.results())), declared
         rr = sim.count_votes()
         assert (rr.decided, rr.votes_winner, rr.cut_size) == (rr0.decided, rr0.votes_winner, rr0.cut_size)
+    # ... and the round's distinct alerts declared where they lie, too (rapid_sim_set_alert_set_device)
+    d_al = to_device(np.ascontiguousarray(sc.batches.recs).view(np.uint8).reshape(-1))
+    sim.attach_streams_device(d_rec2.value + 12, raw.nbytes, d_off.value, len(sc.rec_off) - 1)
+    sim.set_alert_set_device(d_al.value, len(sc.batches.recs), trust_copies=True)
+    sim.tally()
+    info = sim.index_info()
+    assert info["alert_set_declared"] == 1 and info["alerts_prevalidated"] == 1
+    assert all(np.array_equal(a, b) for a, b in zip(want, sim.results()))
+    with pytest.raises(E.IllegalArgumentException):
+        sim.set_alert_set_device(d_al.value + 2, len(sc.batches.recs))
     with pytest.raises(E.IllegalArgumentException):
         sim.attach_streams_device(d_rec2.value + 13, raw.nbytes, d_off.value, len(sc.rec_off) - 1)  # not 4-byte aligned
     # offsets that run past the records, or are not ascending: checked on the device, ahead of the round's kernels, without
@@ -909,7 +919,7 @@ def test_streams_handed_over_in_device_memory(E):
     assert all(np.array_equal(a, b) for a, b in zip(want, sim.results()))
     assert hip.hipFree(d_bad) == 0
     eng.close()
-    assert hip.hipFree(d_off) == 0 and hip.hipFree(d_rec2) == 0
+    assert hip.hipFree(d_off) == 0 and hip.hipFree(d_rec2) == 0 and hip.hipFree(d_al) == 0
 
 
 
