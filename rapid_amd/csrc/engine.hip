@@ -427,7 +427,7 @@ int rebuild_view(rapid_engine* h) {
             HIPCHK(h, hipStreamSynchronize(st));  // (`joiners` goes out of scope)
         }
         hipLaunchKernelGGL(rapid::ring_scatter_kernel, dim3((unsigned)(K * n_chunks)), dim3(rapid::kRingChunk), 0, st, h->d_ring.p, h->d_ring_skeys.p,
-                           m_old, n_chunks, h->d_member.p, h->d_chunk_kept.p, h->d_join_skeys.p, J, h->d_sort_vals.p, h->d_sort_keys.p, M);
+                           m_old, n_chunks, h->d_member.p, h->d_chunk_kept.p, h->d_join_skeys.p, h->d_join_nodes.p, J, h->d_sort_vals.p, h->d_sort_keys.p, M);
         if (J > 0)
             hipLaunchKernelGGL(rapid::ring_join_kernel, dim3(grid_for((long long)K * J * 64, 256)), dim3(256), 0, st, h->d_ring.p, h->d_ring_skeys.p,
                                m_old, n_chunks, h->d_member.p, h->d_chunk_kept.p, h->d_join_skeys.p, h->d_join_nodes.p, J, K, h->d_sort_vals.p,

@@ -182,11 +182,17 @@ __global__ void ring_tables_kernel(const int* ring, const unsigned long long* ri
 //   ring_join_kernel     joiner j of ring k          ->  new position j + (survivors with a smaller key)
 constexpr int kRingChunk = 1024;
 
-__device__ inline int lower_bound_u64(const unsigned long long* a, int n, unsigned long long key) {
+// A ring is ordered by (key, node index): two endpoints with the same 64-bit ring key -- one chance in 2^64 per pair; the
+// reference's TreeSet would silently refuse the second one, R/MembershipView.java:123-141 with the comparator of :562-587 -- stand in
+// the order of their node indices, which is what the stable sort of a full build produces (members are handed to it in ascending
+// node order).  The merge below uses the same total order on both sides, so the incremental and the full path cannot disagree.
+// elements of (keys[], nodes[]) -- sorted by that order -- that are smaller than (key, node)
+__device__ inline int lower_bound_key_node(const unsigned long long* keys, const int* nodes, int n, unsigned long long key, int node) {
     int lo = 0, hi = n;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (a[mid] < key) lo = mid + 1; else hi = mid;
+        const unsigned long long km = keys[mid];
+        if (km < key || (km == key && nodes[mid] < node)) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
@@ -220,8 +226,8 @@ __device__ inline int ring_chunks_before(const int* chunk_kept_k, int c, int* s_
 
 __global__ __launch_bounds__(kRingChunk) void ring_scatter_kernel(const int* ring_in, const unsigned long long* skeys_in, int m_old, int n_chunks,
                                                                   const unsigned char* member, const int* chunk_kept,
-                                                                  const unsigned long long* join_skeys, int n_join, int* ring_out,
-                                                                  unsigned long long* skeys_out, int m_new) {
+                                                                  const unsigned long long* join_skeys, const int* join_nodes, int n_join,
+                                                                  int* ring_out, unsigned long long* skeys_out, int m_new) {
     __shared__ int s_acc;
     __shared__ int s_wave[kRingChunk / 64];
     const int k = (int)blockIdx.x / n_chunks, c = (int)blockIdx.x - k * n_chunks;
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(kRingChunk) void ring_scatter_kernel(const int* rin
     int before = base + __popcll(b & ((1ull << lane) - 1ull));
     for (int i = 0; i < wv; ++i) before += s_wave[i];
     if (keep) {
-        const int at = before + (n_join > 0 ? lower_bound_u64(join_skeys + (long long)k * n_join, n_join, key) : 0);
+        const int at = before + (n_join > 0 ? lower_bound_key_node(join_skeys + (long long)k * n_join, join_nodes + (long long)k * n_join, n_join, key, node) : 0);
         if (at < m_new) {
             ring_out[(long long)k * m_new + at] = node;
             skeys_out[(long long)k * m_new + at] = key;
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void ring_join_kernel(const int* ring_in, cons
     const int k = (int)(w / n_join), j = (int)(w - (long long)k * n_join);
     const unsigned long long key = join_skeys[w];
     const int* rk = ring_in + (long long)k * m_old;
-    const int p = lower_bound_u64(skeys_in + (long long)k * m_old, m_old, key);  // old positions with a smaller key: [0, p)
+    const int p = lower_bound_key_node(skeys_in + (long long)k * m_old, rk, m_old, key, join_nodes[w]);  // old positions that sort before the joiner: [0, p)
     const int c = p / kRingChunk;
     int kept = 0;
     for (int i = lane; i < c; i += 64) kept += chunk_kept[(long long)k * n_chunks + i];

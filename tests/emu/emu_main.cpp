@@ -511,7 +511,7 @@ extern "C" int emu_view_build(const unsigned char* blob, const int* host_off, co
         }
         for (int b = 0; b < K * n_chunks; ++b)
             emu::run_block((unsigned)b, (unsigned)(K * n_chunks), (unsigned)rapid::kRingChunk, [&] {
-                rapid::ring_scatter_kernel(ring_out, sk2.data(), n_members, n_chunks, keep, chunk_kept.data(), jskeys.data(), J, ring2_out, sk3.data(), m_new);
+                rapid::ring_scatter_kernel(ring_out, sk2.data(), n_members, n_chunks, keep, chunk_kept.data(), jskeys.data(), jnodes.data(), J, ring2_out, sk3.data(), m_new);
             }, seed + 6000 + (unsigned)b);
         if (J > 0)
             launch((long long)K * J * 64, 256u, [&] {
@@ -521,6 +521,32 @@ extern "C" int emu_view_build(const unsigned char* blob, const int* host_off, co
         for (int k = 0; k < K; ++k)  // the new rings are sorted by key
             for (int i = 1; i < m_new; ++i)
                 if (sk3[(size_t)k * m_new + i - 1] >= sk3[(size_t)k * m_new + i]) return -12;
+    }
+    return 0;
+}
+
+// The incremental ring merge on hand-made keys (ONE ring): old ring (ring_in, skeys_in) sorted by (key, node), member[] = who
+// stays or joins, joiners (join_nodes, join_skeys) sorted the same way -> the new ring.  Lets a test force EQUAL ring keys, which
+// the 64-bit hashes of real endpoints never produce.
+extern "C" int emu_ring_merge(const int* ring_in, const unsigned long long* skeys_in, int m_old, const unsigned char* member, const int* join_nodes,
+                              const unsigned long long* join_skeys, int n_join, int* ring_out, unsigned long long* skeys_out, int m_new,
+                              unsigned long long seed) {
+    const int n_chunks = (std::max(m_old, 1) + rapid::kRingChunk - 1) / rapid::kRingChunk;
+    std::vector<int> chunk_kept((size_t)n_chunks, -1);
+    for (int b = 0; b < n_chunks; ++b)
+        emu::run_block((unsigned)b, (unsigned)n_chunks, (unsigned)rapid::kRingChunk, [&] {
+            rapid::ring_count_kernel(ring_in, m_old, n_chunks, member, chunk_kept.data());
+        }, seed + (unsigned)b);
+    for (int b = 0; b < n_chunks; ++b)
+        emu::run_block((unsigned)b, (unsigned)n_chunks, (unsigned)rapid::kRingChunk, [&] {
+            rapid::ring_scatter_kernel(ring_in, skeys_in, m_old, n_chunks, member, chunk_kept.data(), join_skeys, join_nodes, n_join, ring_out, skeys_out, m_new);
+        }, seed + 100 + (unsigned)b);
+    if (n_join > 0) {
+        const unsigned grid = (unsigned)(((long long)n_join * 64 + 255) / 256);
+        for (unsigned b = 0; b < grid; ++b)
+            emu::run_block(b, grid, 256u, [&] {
+                rapid::ring_join_kernel(ring_in, skeys_in, m_old, n_chunks, member, chunk_kept.data(), join_skeys, join_nodes, n_join, 1, ring_out, skeys_out, m_new);
+            }, seed + 200 + b);
     }
     return 0;
 }

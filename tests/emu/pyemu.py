@@ -281,6 +281,25 @@ def view_build(hostnames, ports, id_hi, id_lo, K, members, keep=None, seed=1):
     return out
 
 
+def ring_merge(ring, keys, member, join_nodes, join_keys, seed=1):
+    """ring_count / ring_scatter / ring_join on ONE ring with hand-made (possibly equal) keys: old ring and joiners, each sorted by
+    (key, node); member[node] = stays or joins -> (new ring, its keys)."""
+    L_ = lib()
+    ring = np.ascontiguousarray(np.concatenate([ring, [0]]), dtype=np.int32)
+    keys = np.ascontiguousarray(np.concatenate([np.asarray(keys, dtype=np.uint64), np.zeros(1, dtype=np.uint64)]))
+    jn = np.ascontiguousarray(np.concatenate([join_nodes, [0]]), dtype=np.int32)
+    jk = np.ascontiguousarray(np.concatenate([np.asarray(join_keys, dtype=np.uint64), np.zeros(1, dtype=np.uint64)]))
+    member = np.ascontiguousarray(np.concatenate([np.asarray(member, dtype=np.uint8), [0]]), dtype=np.uint8)
+    m_old, J = len(ring) - 1, len(jn) - 1
+    m_new = int(member[ring[:m_old]].sum()) + J
+    out_r, out_k = np.full(m_new + 1, -1, dtype=np.int32), np.zeros(m_new + 1, dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L_.emu_ring_merge.restype = C.c_int
+    rc = L_.emu_ring_merge(p(ring), p(keys), m_old, p(member), p(jn), p(jk), J, p(out_r), p(out_k), m_new, C.c_ulonglong(seed))
+    assert rc == 0, rc
+    return out_r[:m_new], out_k[:m_new]
+
+
 def ids_merge(old, new, seed=1):
     """ids_merge_kernel: two lists of (high, low) NodeIds sorted the way identifiersSeen is -> the merged list."""
     L_ = lib()

@@ -655,3 +655,25 @@ def test_stream_offsets_that_cannot_be_followed_void_the_round():
             assert not covered, (bad, mode)
     *res, covered = pyemu.tally(records, off, n, K, H, L, cfg, obs, subj, member, declared=records)
     assert covered
+
+
+def test_ring_merge_orders_equal_keys_by_node_index():
+    """Two endpoints with the same 64-bit ring key (one chance in 2^64 per pair; the reference's TreeSet would refuse the second,
+    R/MembershipView.java:123-141) stand in the order of their node indices -- what the stable sort of a full build produces -- on
+    both sides of the incremental merge (ring_scatter_kernel / ring_join_kernel): keys drawn from a handful of values, so that
+    survivors tie with survivors, joiners with joiners and joiners with survivors, across chunk boundaries."""
+    rng = np.random.default_rng(5)
+    for n, m_old, J, n_keys in ((3000, 2500, 300, 40), (200, 150, 50, 3), (64, 1, 40, 2), (2200, 2100, 0, 7)):
+        perm = rng.permutation(n)
+        old, join = perm[:m_old], perm[m_old:m_old + J]
+        key = rng.integers(0, n_keys, size=n).astype(np.uint64) * np.uint64(0x1111111111111111)
+        order = lambda nodes: np.array(sorted(nodes.tolist(), key=lambda v: (int(key[v]), v)), dtype=np.int32)
+        ring = order(old)
+        member = np.zeros(n, dtype=np.uint8)
+        stay = old[rng.random(m_old) < 0.8]
+        member[stay] = 1
+        member[join] = 1
+        jn = order(join)
+        want = order(np.concatenate([stay, join]))
+        got_r, got_k = pyemu.ring_merge(ring, key[ring], member, jn, key[jn], seed=int(n))
+        assert np.array_equal(got_r, want) and np.array_equal(got_k, key[want])
