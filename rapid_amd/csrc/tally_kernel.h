@@ -567,11 +567,22 @@ __host__ __device__ constexpr int tally_max_waves(int dict_mode, bool trusted, i
     return (fmt == kFmtBoundary && dict_mode == kDictCompressed && !trusted) ? 12 : kMaxWavesPerBlock;
 }
 
+// RAPID_WAVES_PER_EU (measurement knob): asks the compiler for a register budget that lets that many waves share a SIMD (5: 96
+// VGPRs -- two workgroups of ten waves per CU instead of one of fifteen)
+#ifdef RAPID_WAVES_PER_EU
+#define RAPID_TALLY_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RAPID_WAVES_PER_EU, RAPID_WAVES_PER_EU)))
+#else
+#define RAPID_TALLY_OCCUPANCY
+#endif
 template <int kDictMode, bool kTrusted, int kFmt = kFmtResident, bool kPacked = false>
-__global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) void tally_population_kernel(TallyParams p) {
+__global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RAPID_TALLY_OCCUPANCY void tally_population_kernel(TallyParams p) {
     static_assert(!kPacked || kDictMode == kDictMemory || kDictMode == kDictResolved, "packed detector state: dictionary in memory, or none");
     static_assert(kFmt == kFmtResident || kDictMode != kDictResolved, "a boundary record carries its subject, not an entry");
     constexpr bool kTablesInLds = kDictMode == kDictDirect;
+#ifndef RAPID_LEAN_OPEN
+#define RAPID_LEAN_OPEN 1
+#endif
+    constexpr bool kLeanOpen = RAPID_LEAN_OPEN != 0 && kFmt == kFmtBoundary && kTrusted;  // (see fast_try)
     constexpr int kStride = kFmt == kFmtBoundary ? kRecBytes : kCoreBytes;  // bytes from one record to the next
     constexpr unsigned int kQuarterB = (unsigned int)(kWave * kStride);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1053,29 +1064,53 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
             for (int q = 0; q < kQ; ++q) sink ^= cw.w3[q] ^ cw.w4[q];
             return kApplied;
 #endif
-            const Rec c = open(cw);
             unsigned int so[kQ], w[kQ];
             // (everything that can stay in vector registers does: the CU's waves share ONE scalar pipe, and it is the busiest
             // unit of this kernel.  "Does the window say anything about the witness" is a running minimum of slot ^ witness,
             // looked at once; the batch ends are counted per lane by adding upper halves.)
             unsigned int wdiff = carry_so ^ witness_so;
             unsigned int nbv = 0u;  // batch ends in the window (none among the lanes that will be carried, by the choice of ncl)
+            unsigned long long mEl;
+            if constexpr (kLeanOpen) {
+                // Boundary records of a vouched-for round, straight from the loaded dwords (no Rec in between): the alerts were
+                // validated when the set was declared (index_touch_kernel: current configuration, a ring named, status against the
+                // membership) and the deliveries are copies of them, so the only thing a delivered record can still be is LATE --
+                // another configuration id: dropped whole, R/MembershipService.java:653-657.  A window taken here lies inside the
+                // stream (its last window always goes the slow way), so no lane sees the zeros behind the end.  The batch end stays
+                // out of the word that is applied (nobody reads it there): counted from the flags byte, and looked for in the last
+                // quarter's flags.  Five vector instructions per quarter less than open() + effective().
 #pragma unroll
-            for (int q = 0; q < kQ; ++q) {
+                for (int q = 0; q < kQ; ++q) {
+                    const Look k = lookup(cw.w3[q]);
+                    const unsigned int raw = cw.w4[q];
+                    const bool current = (((unsigned long long)cw.c1[q] << 32) | (unsigned long long)cw.c0[q]) == cfg64;
+                    const unsigned int full = (raw & kCoreRings) | ((raw & 0x00FF0000u) != 0u ? kCoreDown : kCoreUp);
+                    w[q] = current ? full : 0u;
+                    uncovered |= w[q] & k.entry;
+                    so[q] = k.entry >> 16;
+                    wdiff = min(wdiff, so[q] ^ witness_so);
+                    nbv += (raw >> 24) & 1u;
+                }
+                mEl = wave_ballot((cw.w4[kQ - 1] & 0x01000000u) != 0u);
+            } else {
+                const Rec c = open(cw);
+#pragma unroll
+                for (int q = 0; q < kQ; ++q) {
 #ifdef RAPID_PROBE_NO_LOOKUP
-                Look k;
-                k.entry = (c.w3[q] & 0xFFu) << 17;
+                    Look k;
+                    k.entry = (c.w3[q] & 0xFFu) << 17;
                     k.untouched = false;
 #else
-                const Look k = lookup(c.w3[q]);
+                    const Look k = lookup(c.w3[q]);
 #endif
-                w[q] = effective(c, q, k);
-                so[q] = k.entry >> 16;
-                wdiff = min(wdiff, so[q] ^ witness_so);
-                nbv += c.w4[q] >> 16;
+                    w[q] = effective(c, q, k);
+                    so[q] = k.entry >> 16;
+                    wdiff = min(wdiff, so[q] ^ witness_so);
+                    nbv += c.w4[q] >> 16;
+                }
+                mEl = wave_ballot((c.w4[kQ - 1] & kCoreEob) != 0u);
             }
             const unsigned long long mW = wave_ballot(wdiff == 0u);
-            const unsigned long long mEl = wave_ballot((c.w4[kQ - 1] & kCoreEob) != 0u);
             const int ncl = kWave - __clzll((long long)mEl);  // lanes of the last quarter up to its last batch end (0: none)
             const bool inl = lane < ncl;
             unsigned int wadd = 0u;  // what the window reports about the witness (rare: ten reports in a whole stream)
@@ -1397,7 +1432,11 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
                     swept = true;
                     sweep();
                 }
-                if (lean_ok && !need_sweep && (cold || witness >= 0)) {
+#ifndef RAPID_COLD_IN_TURN
+#define RAPID_COLD_IN_TURN 1
+#endif
+                constexpr bool kColdInTurn = RAPID_COLD_IN_TURN != 0;  // (0: a stream's first, cold windows go through the general iteration)
+                if (lean_ok && !need_sweep && ((kColdInTurn && cold) || (!cold && witness >= 0))) {
                     const int w_end = nwin - 1;  // the stream's last window goes the slow way
                     const int w_first = w;
                     RAPID_T0(tl0);
@@ -1419,7 +1458,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) vo
                         for (int i = 0; i < kSets; ++i) {
                             bool advance = false;
                             if (n_ok == i && w + i < w_end) {
-                                if (cold) {  // (the first windows of a stream: until a subject reaches L there is no witness to be had)
+                                if (kColdInTurn && cold) {  // (the first windows of a stream: until a subject reaches L there is no witness to be had)
                                     advance = cold_window(S[i]);
                                 } else if (witness >= 0) {
                                     int st_ = fast_try(S[i]);

@@ -29,6 +29,10 @@ if os.environ.get("RAPID_AB_ONLY"):  # comma-separated subset of the variants
     libs = {k: v for k, v in libs.items() if k in keep}
 
 
+# environment knobs that belong to a variant (read by the test build when the round's launch geometry is chosen)
+VARIANT_ENV = {"occ5": {"RAPID_TALLY_WAVES": "10", "RAPID_TALLY_BLOCKS_PER_CU": "2"}}
+
+
 def use(path):
     """Point the loader at another build: engines created from now on come from it (each .so carries its own kernels)."""
     N._lib = None
@@ -51,6 +55,9 @@ reference = None
 for rnd in range(rounds):
     for tag, path in libs.items():
         use(path)
+        for k in ("RAPID_TALLY_WAVES", "RAPID_TALLY_BLOCKS_PER_CU"):
+            os.environ.pop(k, None)
+        os.environ.update(VARIANT_ENV.get(tag.split("-")[0], {}))
         eng = E.Engine(n_max=n, K=K, H=H, L=L)
         E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
         sim = E.ClusterSimulation(eng)
