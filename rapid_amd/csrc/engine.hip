@@ -196,6 +196,7 @@ struct rapid_engine {
     unsigned long long* h_pinned = nullptr;  // pinned staging for the vote read-back (sharded populations)
     // host-mapped mailbox the kernels write their small answers into (no copy enqueued, the host reads it after a
     // synchronisation): [0, 64) the round index's info[8], [64, ...) the vote count's res[] + representative list
+    bool idx_lds_attr_set = false;
     unsigned char* h_mail = nullptr;
     unsigned int mail_seq = 0;  // sequence numbers of the answers polled from the mailbox
     unsigned char* d_mail = nullptr;
@@ -603,6 +604,7 @@ int build_round_index(rapid_engine* h) {
     HIPCHK(h, h->d_dict.ensure((size_t)N + 8));  // (+ 8: the tally kernel stages them 16 bytes at a time)
     HIPCHK(h, h->d_decl.ensure((size_t)N + 40));  // (the index build reads it 64 bytes at a time)
     HIPCHK(h, h->d_node_of_slot.ensure((size_t)N));
+    HIPCHK(h, h->d_entries.ensure((size_t)N + 8));  // (+ 8: staged 16 bytes at a time)
     HIPCHK(h, h->d_adj_off.ensure((size_t)N + 1));
     const int tent_cap = 16384;  // touched nodes the compressed dictionary can hold (64 KiB of LDS)
     HIPCHK(h, h->d_tbits.ensure((size_t)(N + 31) / 32 + 1));
@@ -614,6 +616,26 @@ int build_round_index(rapid_engine* h) {
     if (!h->ev_idx1) HIPCHK(h, hipEventCreate(&h->ev_idx1));
     const hipEvent_t e0 = h->ev_idx0, e1 = h->ev_idx1;
     HIPCHK(h, hipEventRecord(e0, st));
+    const int adj_cap = 65536;
+    HIPCHK(h, h->d_adj.ensure((size_t)adj_cap + 1));
+    // A declared alert set over a population whose per-node tables fit one workgroup's LDS: the whole index in ONE launch
+    // (index_kernels.h: index_fused_kernel -- the alert set read once, everything else computed in LDS, the tables written out);
+    // testing knob bit 17: the two-kernel form (touch + one workgroup) whatever the size, as a cross-check.
+    const bool chunked = N >= rapid::kIndexChunkedMin || (h->force_exact & 4096) != 0;
+    const bool fused = h->n_alert_set >= 0 && N <= rapid::kIndexFusedMaxNodes && !chunked && (h->force_exact & 131072) == 0;
+    if (fused) {
+        if (!h->idx_lds_attr_set) {
+            HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::index_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          rapid::index_fused_lds_bytes(rapid::kIndexFusedMaxNodes)));  // (next to its few static words: below the CU's 160 KiB)
+            h->idx_lds_attr_set = true;
+        }
+        hipLaunchKernelGGL(rapid::index_fused_kernel, dim3(1), dim3(1024), (size_t)rapid::index_fused_lds_bytes(N), st, h->d_alerts, (long long)h->n_alert_set,
+                           (long long)h->config_id, h->d_member.p, h->d_obs.p, N, K, L, h->d_dict.p, h->d_decl.p, h->d_node_of_slot.p, h->d_adj_off.p,
+                           h->d_adj.p, adj_cap, h->d_tbits.p, h->d_trank.p, h->d_tent.p, tent_cap, reinterpret_cast<volatile int*>(h->d_mail),
+                           (h->force_exact & (128 | 256 | 8192)) != 0 ? -1 : 160 * 1024 - rapid::kBlockStatsBytes, h->d_stats.p, (int)stats_words(h),
+                           h->d_errflags.p, (int)++h->mail_seq, h->q4_emulate ? h->d_q4_rows.p : (int*)nullptr,
+                           h->q4_emulate ? h->d_q4_valid.p : (unsigned char*)nullptr, h->d_entries.p);
+    } else {
     // gmask | info live in one allocation; the touch pass (whole GPU), then everything else in one workgroup, which leaves
     // info[] in host-mapped memory and the work area, the launch statistics and the error flags zeroed: no memset, no
     // copy, and the host polls the mapped page for the answer instead of waiting for the stream
@@ -628,11 +650,8 @@ int build_round_index(rapid_engine* h) {
     if (n_scan > 0)
         hipLaunchKernelGGL(rapid::index_touch_kernel, touch_grid, dim3(256), 0, st, h->n_alert_set >= 0 ? h->d_alerts : h->d_records, n_scan, N,
                            (1u << K) - 1u, (long long)h->config_id, h->d_member.p, d_gmask, reinterpret_cast<unsigned int*>(d_info + 4));
-    const int adj_cap = 65536;
-    HIPCHK(h, h->d_adj.ensure((size_t)adj_cap + 1));
     // large populations: the walk over the nodes in several workgroups (two more launches, a tenth of the latency); testing
     // knob bit 12: also for small ones.  Such a round never has direct tables (kIndexChunkedMin nodes do not fit the LDS).
-    const bool chunked = N >= rapid::kIndexChunkedMin || (h->force_exact & 4096) != 0;
     const int n_chunks = chunked ? (N + rapid::kIndexChunk - 1) / rapid::kIndexChunk : 0;
     if (chunked) {
         HIPCHK(h, h->d_idxblk.ensure((size_t)2 * (size_t)std::max(n_chunks, 1)));
@@ -647,11 +666,14 @@ int build_round_index(rapid_engine* h) {
                        h->d_stats.p, (int)stats_words(h), h->d_errflags.p, (int)++h->mail_seq,
                        chunked ? h->d_idxblk.p : nullptr, n_chunks, h->q4_emulate ? h->d_q4_rows.p : (int*)nullptr,
                        h->q4_emulate ? h->d_q4_valid.p : (unsigned char*)nullptr);
+    }
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipGetLastError());
     if (int rc = await_mail(h, 15, h->mail_seq)) return rc;
-    h->idxwork_clean_at = h->d_idxwork.p;
-    h->idxwork_clean_n = N;
+    if (!fused) {
+        h->idxwork_clean_at = h->d_idxwork.p;
+        h->idxwork_clean_n = N;
+    }
     int info[8];
     std::memcpy(info, h->h_mail, sizeof info);  // written by the kernel into host-mapped memory
     h->index_ms_pending = true;  // the events are read when somebody asks (no wait for them here)
@@ -696,8 +718,8 @@ int build_round_index(rapid_engine* h) {
     else
         h->dict_mode = rapid::kDictMemory;
     h->tables_in_lds = h->dict_mode == rapid::kDictDirect || h->dict_mode == rapid::kDictCompressed;
-    if (h->dict_mode == rapid::kDictMemory || h->dict_mode == rapid::kDictResolved) {
-        HIPCHK(h, h->d_entries.ensure((size_t)N + 1));
+    // (the one-launch index has written them already; compressed tables hold their own entries)
+    if (!fused && h->dict_mode != rapid::kDictCompressed) {
         hipLaunchKernelGGL(rapid::dict_entries_kernel, dim3(grid_for((long long)N + 1, 256)), dim3(256), 0, st, h->d_dict.p, h->d_decl.p, N, h->n_hot,
                            h->d_entries.p);
     }

@@ -427,6 +427,267 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     if (t < 8) info[t] = 0;
 }
 
+// ---- a declared alert set over a population of up to kIndexFusedMaxNodes nodes: the whole index in ONE launch ----------------
+// The round index is on every round's path, ahead of the tally, and as two kernels (touch, then one workgroup) it lived on
+// dependent memory round trips: the per-node ring masks written by atomics of the touch pass and read back by the build, the
+// dictionary written to memory and read back entry by entry for the adjacency, every table walked twice -- ~45 us at N = 10^4
+// against a tally of 380 us.  Here ONE workgroup keeps everything it computes in LDS (per node: the rings the alert set names
+// -> the declared mask, the dictionary entry, the member flag: 5 bytes) and touches memory three times: the alert set and
+// the member flags (independent loads, one round trip), the observer rows of the hot subjects (one round trip), and the
+// finished tables written out (stores).  Same outputs, bit for bit, as index_touch_kernel + index_build_block_kernel
+// (tests/test_kernel_emulated.py compares them); the global work area of the two-kernel form is not touched.
+constexpr int kIndexFusedMaxNodes = 24576;
+constexpr int kIndexFusedNosLds = 4096;  // slot -> node for the first slots in LDS (the rest is read back from memory)
+__host__ __device__ inline int index_fused_lds_bytes(int n_nodes) {
+    const int n2 = (n_nodes + 1) & ~1;
+    return 2 * align16(n2 * 2 + 64) + align16(n_nodes + 1) + kIndexFusedNosLds * 4;
+}
+
+__global__ __launch_bounds__(1024) void index_fused_kernel(const unsigned char* alerts, long long n_alerts, long long cfg_id,
+                                                           const unsigned char* member, const int* obs, int n_nodes, int K, int L,
+                                                           unsigned short* dict, unsigned short* decl, int* node_of_slot,
+                                                           unsigned short* smask, unsigned int* pairs, int adj_cap, unsigned int* tbits,
+                                                           unsigned short* trank, unsigned int* tent, int tent_cap, volatile int* info_out,
+                                                           int direct_budget, unsigned long long* zero_words, int n_zero_words,
+                                                           unsigned int* zero_flags, int seq, int* q4_rows, unsigned char* q4_valid,
+                                                           unsigned int* entries) {
+    __shared__ int s_wave[16];
+    __shared__ unsigned int s_flags, s_stale;
+    unsigned char* const lds = dynamic_lds();
+    const int T = (int)blockDim.x, t = (int)threadIdx.x;
+    const int n2 = (n_nodes + 1) & ~1;
+    const int tab_bytes = align16(n2 * 2 + 64);  // (+ 64: the compressed tables read a word's 32 entries as four 16-byte loads)
+    unsigned short* const l_decl = reinterpret_cast<unsigned short*>(lds);  // first the rings the alert set names, then the declared mask | member << 15
+    unsigned int* const l_decl32 = reinterpret_cast<unsigned int*>(lds);
+    unsigned short* const l_dict = reinterpret_cast<unsigned short*>(lds + tab_bytes);
+    unsigned char* const l_mem = lds + 2 * tab_bytes;
+    int* const l_nos = reinterpret_cast<int*>(lds + 2 * tab_bytes + align16(n_nodes + 1));
+    const unsigned int cfg_lo = (unsigned int)(unsigned long long)cfg_id, cfg_hi = (unsigned int)((unsigned long long)cfg_id >> 32);
+    const unsigned int kmask = (1u << K) - 1u;
+
+    // ---- the alert set and the member flags: all loads of the first batch are in flight before anything waits ----
+    constexpr int kAB = 8;
+    unsigned int a_c0[kAB], a_c1[kAB], a_dst[kAB], a_w4[kAB];
+    auto load_alerts = [&](long long i0) {
+#pragma unroll
+        for (int j = 0; j < kAB; ++j) {
+            const long long i = i0 + (long long)j * T + t;
+            a_c0[j] = a_c1[j] = a_w4[j] = 0u;
+            a_dst[j] = 0xFFFFFFFFu;
+            if (i < n_alerts) {
+                const unsigned int* w = reinterpret_cast<const unsigned int*>(alerts + i * 20);
+                a_c0[j] = w[0];
+                a_c1[j] = w[1];
+                a_dst[j] = w[3];
+                a_w4[j] = w[4];
+            }
+        }
+    };
+    load_alerts(0);
+    for (int n = t; n < n_nodes; n += T) l_mem[n] = member[n];
+    for (int i = t; i < tab_bytes / 4; i += T) l_decl32[i] = 0u;
+    for (int i = t; i < n_zero_words; i += T) zero_words[i] = 0ull;  // (see index_build_block_kernel)
+    if (t < 2 && zero_flags != nullptr) zero_flags[t] = 0u;
+    if (t == 0) {
+        s_flags = 0u;
+        s_stale = 0u;
+    }
+    __syncthreads();
+    unsigned int f = 0u;
+    for (long long i0 = 0; i0 < n_alerts; i0 += (long long)kAB * T) {
+        if (i0 > 0) load_alerts(i0);
+#pragma unroll
+        for (int j = 0; j < kAB; ++j) {
+            if (i0 + (long long)j * T + t >= n_alerts) continue;
+            const unsigned int dst = a_dst[j], cw = core_word(a_w4[j]);
+            const bool current = a_c0[j] == cfg_lo && a_c1[j] == cfg_hi, inr = dst < (unsigned int)n_nodes;
+            const unsigned int bits = cw & kmask;
+            const bool down = (cw & kCoreDown) != 0u;
+            if (inr && bits != 0u) atomicOr(&l_decl32[dst >> 1], bits << ((dst & 1u) * 16u));  // (whatever the filter says: a superset, as in index_touch_kernel)
+            const bool ok = current && inr && bits != 0u && ((l_mem[inr ? dst : 0u] != 0) == down);
+            f |= (ok ? 0u : 1u) | (down ? 0u : 2u);
+        }
+    }
+    if (f) atomicOr(&s_flags, f);
+    __syncthreads();
+
+    // ---- slots (ascending node order), dictionary, declared ring masks: wave w owns a contiguous range of nodes ----
+    const int lane = t & 63, wv = t >> 6, nw = T >> 6;
+    const int per_wave_nodes = ((n_nodes + nw * 64 - 1) / (nw * 64)) * 64;
+    const int beg = min(n_nodes, wv * per_wave_nodes), end = min(n_nodes, beg + per_wave_nodes);
+    int nh = 0;
+    for (int n0 = beg; n0 < end; n0 += 64) {
+        const int n = n0 + lane;
+        const unsigned int g = n < end ? (unsigned int)l_decl[n] : 0u;
+        nh += __popcll(__ballot(__popc(g) >= L));
+    }
+    int n_hot_all = 0;
+    int ph = block_exclusive_scan(lane == 0 ? nh : 0, s_wave, &n_hot_all);
+    ph = __shfl(ph, 0, 64);
+    for (int n0 = beg; n0 < end; n0 += 64) {
+        const int n = n0 + lane;
+        const bool in = n < end;
+        const unsigned int g = in ? (unsigned int)l_decl[n] : 0u;
+        const unsigned int mem = (in && l_mem[n] != 0) ? 0x8000u : 0u;
+        const bool hot = in && __popc(g) >= L;
+        const unsigned long long hots = __ballot(hot);
+        const int mine_slot = ph + __popcll(hots & ((1ull << lane) - 1ull));
+        ph += __popcll(hots);
+        unsigned int slot = 0x3FFFu;
+        if (hot && mine_slot < 16319) {
+            slot = (unsigned int)mine_slot;
+            node_of_slot[mine_slot] = n;
+            if (mine_slot < kIndexFusedNosLds) l_nos[mine_slot] = n;
+        }
+        if (in) {
+            l_dict[n] = (unsigned short)(slot | mem);
+            l_decl[n] = (unsigned short)((slot != 0x3FFFu ? 0x3FFFu : (g & 0x3FFFu)) | mem);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int n_hot = min(n_hot_all, 16318);
+
+    // ---- the hot adjacency (see index_build_block_kernel; quirk Q4: a hot member's row comes from the memo) ----
+    const int per2 = (n_hot + T - 1) / T;
+    const int b2 = min(n_hot, t * per2), e2 = min(n_hot, b2 + per2);
+    int mine = 0;
+    bool stale = false;
+    constexpr int kKMax = 14;
+    auto node_of = [&](int e) -> int { return e < kIndexFusedNosLds ? l_nos[e] : node_of_slot[e]; };
+    auto slot_edges = [&](int e, unsigned int (&eo)[kKMax]) -> unsigned int {
+        const int node = node_of(e);
+        const bool use_memo = q4_valid != nullptr && l_mem[node] != 0;
+        const int* const today = obs + (long long)node * K;
+        int* const memo = q4_rows + (long long)node * K;
+        int o[kKMax], td[kKMax], mm[kKMax];
+        // (today's row, the memo flag and the memoised row are requested together: one round trip, not three)
+        const bool have = use_memo && q4_valid[node] != 0;
+#pragma unroll
+        for (int k = 0; k < kKMax; ++k) td[k] = k < K ? today[k] : -1;
+#pragma unroll
+        for (int k = 0; k < kKMax; ++k) mm[k] = (use_memo && k < K) ? memo[k] : -1;
+        if (have) {
+#pragma unroll
+            for (int k = 0; k < kKMax; ++k) {
+                o[k] = mm[k];
+                stale = stale || o[k] != td[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kKMax; ++k) o[k] = td[k];
+        }
+        unsigned int am = 0u;
+#pragma unroll
+        for (int k = 0; k < kKMax; ++k) eo[k] = (o[k] >= 0 && o[k] < n_nodes) ? ((unsigned int)l_dict[o[k]] & 0x3FFFu) : 0x3FFFu;
+#pragma unroll
+        for (int k = 0; k < kKMax; ++k) am |= (int)eo[k] < n_hot ? 1u << k : 0u;
+        return am;
+    };
+    // (a thread owns at most a few slots: their edges are kept between the counting and the writing pass when it owns one)
+    unsigned int eo1[kKMax];
+    unsigned int am1 = 0u;
+    for (int e = b2; e < e2; ++e) {
+        unsigned int eo[kKMax];
+        const unsigned int am = slot_edges(e, eo);
+        mine += __popc(am);
+        if (e == b2) {
+            am1 = am;
+#pragma unroll
+            for (int k = 0; k < kKMax; ++k) eo1[k] = eo[k];
+        }
+    }
+    if (stale) atomicOr(&s_stale, 1u);
+    int total = 0;
+    int at = block_exclusive_scan(mine, s_wave, &total);
+    const bool fits = total <= 65535 && total <= adj_cap;
+    for (int e = b2; e < e2; ++e) {
+        unsigned int eo[kKMax];
+        unsigned int am = am1;
+        if (e == b2) {
+#pragma unroll
+            for (int k = 0; k < kKMax; ++k) eo[k] = eo1[k];
+        } else {
+            am = slot_edges(e, eo);
+        }
+        const int node = node_of(e);
+        if (q4_valid != nullptr && l_mem[node] != 0 && q4_valid[node] == 0) {  // the first time this member is hot since its entry was dropped
+            const int* const today = obs + (long long)node * K;
+            for (int k = 0; k < K; ++k) q4_rows[(long long)node * K + k] = today[k];
+            q4_valid[node] = 1;
+        }
+#pragma unroll
+        for (int k = 0; k < kKMax; ++k) {
+            if ((am >> k) & 1u) {
+                if (fits) pairs[at] = (unsigned int)e | (eo[k] << 14) | ((unsigned int)k << 28);
+                ++at;
+            }
+        }
+        smask[e] = (unsigned short)am;
+        if (am != 0u) l_dict[node] |= (unsigned short)0x4000;  // (only this thread touches the node's entry after the barrier above)
+    }
+    __syncthreads();  // l_dict is final (adjacency flags included)
+
+    // ---- the compressed form of the tables, when the direct ones will not fit the tally's LDS (see index_build_block_kernel) ----
+    const bool direct_fits = direct_budget >= 0 &&
+                             tally_shared_bytes(kDictDirect, n_nodes, 0, n_hot, total) + 8 * tally_wave_bytes(n_hot) <= direct_budget;
+    const int n_words = direct_fits ? 0 : (n_nodes + 31) / 32;
+    const int perw = (n_words + T - 1) / T;
+    const int w0 = min(n_words, t * perw), w1 = min(n_words, w0 + perw);
+    int cnt = 0;
+    for (int w = w0; w < w1; ++w) {
+        unsigned int bits = 0u;
+        const int valid = min(32, n_nodes - w * 32);
+        for (int b = 0; b < valid; ++b)
+            if (((unsigned int)l_decl[w * 32 + b] & 0x3FFFu) != 0u) bits |= 1u << b;
+        tbits[w] = bits;
+        cnt += __popc(bits);
+    }
+    int n_touched = 0;
+    int rk = block_exclusive_scan(cnt, s_wave, &n_touched);
+    const bool tfits = n_touched <= 65535 && n_touched <= tent_cap;
+    for (int w = w0; w < w1; ++w) {
+        trank[w] = (unsigned short)(rk > 65535 ? 65535 : rk);
+        const int valid = min(32, n_nodes - w * 32);
+        for (int b = 0; b < valid; ++b) {
+            const int n = w * 32 + b;
+            if (((unsigned int)l_decl[n] & 0x3FFFu) == 0u) continue;
+            if (tfits) tent[rk] = dict_entry((unsigned int)l_decl[n], (unsigned int)l_dict[n] & 0x3FFFu);
+            ++rk;
+        }
+    }
+    // ---- the finished per-node tables, written out two entries at a time ----
+    if (t == 0 && (n_nodes & 1) != 0) l_dict[n_nodes] = 0;  // (the odd entry behind the last node: written, read by nobody)
+    __syncthreads();
+    for (int i = t; i < n2 / 2; i += T) {
+        reinterpret_cast<unsigned int*>(dict)[i] = reinterpret_cast<const unsigned int*>(l_dict)[i];
+        reinterpret_cast<unsigned int*>(decl)[i] = l_decl32[i];
+    }
+    // ... and the 32-bit entries the tally stages (or gathers from): what dict_entries_kernel writes behind the other forms
+    for (int i = t; i <= n_nodes; i += T) {
+        unsigned int e = kEntryPoison | ((unsigned int)n_hot_all << 17);
+        if (i < n_nodes) {
+            unsigned int sl = (unsigned int)l_dict[i] & kSlotMask;
+            if (sl == kNoSlot) sl = (unsigned int)n_hot_all + ((unsigned int)i & (unsigned int)(kDummySlots - 1));
+            e = dict_entry((unsigned int)l_decl[i], sl);
+        }
+        entries[i] = e;
+    }
+    __syncthreads();
+    if (t == 0) {
+        info_out[0] = n_hot_all;
+        info_out[1] = n_hot_all;
+        info_out[2] = (s_stale != 0u ? 4 : 0) | (n_hot_all > 16318 ? 1 : 0) | (fits ? 0 : 2);
+        info_out[3] = total;
+        info_out[4] = (int)s_flags;
+        info_out[5] = n_touched;
+        info_out[6] = tfits && !direct_fits ? 1 : 0;
+        info_out[7] = direct_fits ? 1 : 0;
+        __threadfence_system();
+        info_out[15] = seq;
+    }
+}
+
 // ---- rapid_sim_generate: the delivered streams made on the device ----------------------------------------------------
 // Every receiver gets every BatchedAlertMessage of the round exactly once, in a receiver-specific seeded order (the
 // reference's fan-out: UnicastToAllBroadcaster.java:46-63 sends each batch to all members; arrival order differs per

@@ -142,9 +142,10 @@ struct RoundIndex {
     const unsigned short* trank;    // [(n_nodes + 31) / 32]
     const unsigned int* tent;       // [n_touched]
     int n_touched;
-    // populations whose tables stay in memory: ONE gather per record instead of two -- dict_entry per node, [n_nodes] = the
-    // entry out-of-range subjects are sent to (built by dict_entries_kernel once per round; the entries of the round's hot
-    // subjects, all that most records ever ask for, stay in the caches)
+    // dict_entry per node, [n_nodes] = the entry out-of-range subjects are sent to (written once per round by the index:
+    // index_fused_kernel, or dict_entries_kernel behind the other forms; 16-byte aligned).  Direct mode: copied into LDS at the
+    // head of the launch.  Tables in memory: ONE gather per record (the entries of the round's hot subjects, all that most
+    // records ever ask for, stay in the caches).
     const unsigned int* entries;
     const int* node_of_slot;        // [n_hot]
     // the hot adjacency: pairs[a] = subject slot | observer slot << 14 | ring << 28 for every (subject, ring, observer) triple
@@ -247,6 +248,12 @@ __host__ __device__ inline int tally_wave_bytes(int n_slots, bool packed = false
 }
 // rounds with more hot subjects than the per-slot tables' LDS limit run packed (and with their dictionary in memory)
 __host__ __device__ inline bool tally_wants_packed(int n_hot) { return n_hot > kSlotNodesInLdsMax; }
+
+// the workgroup's dynamic LDS segment (every `extern __shared__` array of a kernel is the same memory)
+__device__ __forceinline__ unsigned char* dynamic_lds() {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    return smem;
+}
 
 // ---- small wave helpers ---------------------------------------------------------------------------------------
 // A receiver is owned by ONE wavefront; that wave's LDS operations execute in program order, so cross-lane
@@ -615,16 +622,28 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
     }
     const unsigned int* entries = nullptr;  // direct mode: dict_entry per node, [n_nodes] = where out-of-range subjects are sent
     if (kTablesInLds) {
+        // The round index leaves the finished entries in memory (RoundIndex::entries); they are copied 16 bytes at a time, four
+        // copies per thread in flight: ONE memory round trip for up to 15,360 nodes.  (Assembled here from the index's two 16-bit
+        // tables, entry by entry, the staging of 10^4 nodes was eleven dependent round trips at the head of every launch --
+        // ~15 us during which no wave of the workgroup streams.)
         unsigned int* const l_ent = reinterpret_cast<unsigned int*>(smem);
-        for (int i = (int)threadIdx.x; i <= p.n_nodes; i += (int)blockDim.x) {
-            unsigned int e = kEntryPoison | ((unsigned int)n_hot << 17);
-            if (i < p.n_nodes) {
-                unsigned int sl = (unsigned int)p.idx.dict[i] & kSlotMask;
-                if (sl == kNoSlot) sl = (unsigned int)n_hot + ((unsigned int)i & (unsigned int)(kDummySlots - 1));
-                e = dict_entry((unsigned int)p.idx.decl[i], sl);
+        const int n_ent = p.n_nodes + 1, n_quads = n_ent / 4;
+        const uint4* const src4 = reinterpret_cast<const uint4*>(p.idx.entries);
+        uint4* const dst4 = reinterpret_cast<uint4*>(l_ent);
+        for (int base = 0; base < n_quads; base += 4 * (int)blockDim.x) {
+            uint4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = base + j * (int)blockDim.x + (int)threadIdx.x;
+                v[j] = i < n_quads ? src4[i] : make_uint4(0u, 0u, 0u, 0u);
             }
-            l_ent[i] = e;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = base + j * (int)blockDim.x + (int)threadIdx.x;
+                if (i < n_quads) dst4[i] = v[j];
+            }
         }
+        for (int i = 4 * n_quads + (int)threadIdx.x; i < n_ent; i += (int)blockDim.x) l_ent[i] = p.idx.entries[i];
         entries = l_ent;
     }
     // the hot adjacency (flat list of triples, count first) and the per-slot masks, copied from the round index

@@ -309,10 +309,29 @@ extern "C" int emu_index_run(const unsigned char* alerts, long long n_alerts, in
                              const unsigned char* member, const int* obs, int chunked, int direct_budget, unsigned short* dict,
                              unsigned short* decl, int* node_of_slot, unsigned short* smask, unsigned int* pairs, int adj_cap,
                              unsigned int* tbits, unsigned short* trank, unsigned int* tent, int tent_cap, int* info_out,
-                             unsigned long long seed, int* q4_rows, unsigned char* q4_valid) {
+                             unsigned long long seed, int* q4_rows, unsigned char* q4_valid, unsigned int* entries_out) {
     std::vector<unsigned int> work((size_t)n_nodes + 8, 0u);
     unsigned int* gmask = work.data();
     int* info = reinterpret_cast<int*>(work.data() + n_nodes);
+    static unsigned long long zero_words[64];
+    static unsigned int zero_flags[2];
+    for (auto& z : zero_words) z = ~0ull;
+    zero_flags[0] = zero_flags[1] = 7u;
+    int mail[16];
+    for (int& m : mail) m = -1;
+    if (chunked == 2) {  // the whole index in one launch (index_fused_kernel): declared alert set, tables in LDS
+        if (rapid::index_fused_lds_bytes(n_nodes) > (int)sizeof(smem)) return -6;
+        std::memset(smem, 0xCD, sizeof(smem));
+        emu::run_block(0u, 1u, 1024u, [&] {
+            rapid::index_fused_kernel(alerts, n_alerts, cfg_id, member, obs, n_nodes, K, L, dict, decl, node_of_slot, smask, pairs, adj_cap, tbits, trank,
+                                      tent, tent_cap, mail, direct_budget, zero_words, 64, zero_flags, 4242, q4_rows, q4_valid, entries_out);
+        }, seed + 400);
+        for (int i = 0; i < 8; ++i) info_out[i] = mail[i];
+        if (mail[15] != 4242) return -2;
+        for (auto z : zero_words) if (z != 0ull) return -3;
+        if (zero_flags[0] != 0u || zero_flags[1] != 0u) return -4;
+        return 0;
+    }
     const int touch_grid = (int)std::max<long long>(1, std::min<long long>(8, (n_alerts + 255) / 256));
     for (int b = 0; b < touch_grid && n_alerts > 0; ++b)
         emu::run_block((unsigned)b, (unsigned)touch_grid, 256u, [&] {
@@ -331,12 +350,6 @@ extern "C" int emu_index_run(const unsigned char* alerts, long long n_alerts, in
                 rapid::index_assign_kernel(gmask, member, n_nodes, L, blk.data(), dict, decl, node_of_slot, tbits, trank, tent, tent_cap);
             }, seed + 300 + (unsigned)b);
     }
-    static unsigned long long zero_words[64];
-    static unsigned int zero_flags[2];
-    for (auto& z : zero_words) z = ~0ull;
-    zero_flags[0] = zero_flags[1] = 7u;
-    int mail[16];
-    for (int& m : mail) m = -1;
     emu::run_block(0u, 1u, 1024u, [&] {
         rapid::index_build_block_kernel(gmask, member, obs, n_nodes, K, L, dict, decl, node_of_slot, smask, pairs, adj_cap, tbits, trank, tent,
                                         tent_cap, info, mail, chunked ? -1 : direct_budget, zero_words, 64, zero_flags, 4242,

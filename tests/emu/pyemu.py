@@ -78,7 +78,7 @@ def build_round_index(records, n_nodes, K, L, obs, member):
                 adj=adj, n_hot=n_hot, n_adj=len(pairs))
 
 
-def index_run(records, n_nodes, K, L, cfg_id, obs, member, chunked=False, direct_budget=-1, seed=1, q4=None):
+def index_run(records, n_nodes, K, L, cfg_id, obs, member, chunked=False, direct_budget=-1, seed=1, q4=None, fused=False):
     """Runs the round-index KERNELS (rapid_amd/csrc/index_kernels.h: touch, then one workgroup -- or count / assign / one
     workgroup, the form of large populations) under the emulator.  -> dict shaped like build_round_index's, plus `info`
     (the eight words the host reads from the mailbox)."""
@@ -94,13 +94,14 @@ def index_run(records, n_nodes, K, L, cfg_id, obs, member, chunked=False, direct
                node_of_slot=np.full(n_nodes + 1, -7, dtype=np.int32), smask=np.full(n_nodes + 1, 0xEEEE, dtype=np.uint16),
                pairs=np.zeros(adj_cap + 1, dtype=np.uint32), tbits=np.full(n_words + 1, 0xEEEEEEEE, dtype=np.uint32),
                trank=np.full(n_words + 1, 0xEEEE, dtype=np.uint16), tent=np.full(tent_cap, 0xEEEEEEEE, dtype=np.uint32),
-               info=np.zeros(8, dtype=np.int32))
+               info=np.zeros(8, dtype=np.int32), entries=np.full(n_nodes + 1, 0xEEEEEEEE, dtype=np.uint32))
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     L_.emu_index_run.restype = C.c_int
-    rc = L_.emu_index_run(p(raw), C.c_longlong(len(recs)), n_nodes, K, L, C.c_longlong(cfg_id), p(member), p(obs), 1 if chunked else 0,
+    rc = L_.emu_index_run(p(raw), C.c_longlong(len(recs)), n_nodes, K, L, C.c_longlong(cfg_id), p(member), p(obs), 2 if fused else (1 if chunked else 0),
                           direct_budget, p(out["dict"]), p(out["decl"]), p(out["node_of_slot"]), p(out["smask"]), p(out["pairs"]), adj_cap,
                           p(out["tbits"]), p(out["trank"]), p(out["tent"]), tent_cap, p(out["info"]), C.c_ulonglong(seed),
-                          None if q4 is None else p(q4[0]), None if q4 is None else p(q4[1]))  # q4 = (rows int32 [n][K], valid uint8 [n]): the memo
+                          None if q4 is None else p(q4[0]), None if q4 is None else p(q4[1]),  # q4 = (rows int32 [n][K], valid uint8 [n]): the memo
+                          p(out["entries"]))  # (written by the one-launch form only)
     assert rc == 0, rc
     return out
 

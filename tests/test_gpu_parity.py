@@ -1026,7 +1026,8 @@ def test_tables_in_memory_mode_vs_faithful_oracle(E, name, n, f, K, H, L):
     # the filter); | 64: per-delivery filter; | 1: exact path
     # 4096: the round index built by several workgroups (count / assign / adjacency), the form of populations >= 40,000 nodes
     # (such a round never has direct tables)
-    for mode_knob, mode in ((0, 1), (128, 2), (256, 0), (4096, 2), (4096 | 128, 2), (4096 | 256, 0)):
+    # 131072: a declared alert set indexed by the two-kernel form (touch + one workgroup) instead of the one-launch form
+    for mode_knob, mode in ((0, 1), (128, 2), (256, 0), (4096, 2), (4096 | 128, 2), (4096 | 256, 0), (131072, 1), (131072 | 128, 2)):
       for kw in (dict(force_exact=mode_knob), dict(force_exact=mode_knob | 64), dict(force_exact=mode_knob, alert_set=sc.batches.recs),
                  dict(force_exact=mode_knob | 64, alert_set=sc.batches.recs), dict(force_exact=mode_knob | 1)):
         sim, res = run_population(E, eng, sc.records, sc.rec_off, **kw)

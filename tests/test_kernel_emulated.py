@@ -270,9 +270,11 @@ def test_declared_alert_set_must_cover_the_delivered_streams():
 
 
 @pytest.mark.parametrize("n,n_out,n_crash,n_join,chunked", [(300, 30, 10, 12, False), (300, 30, 10, 12, True), (9000, 60, 120, 40, True),
-                                                            (17000, 40, 200, 30, True)])
+                                                            (17000, 40, 200, 30, True), (300, 30, 10, 12, "fused"), (301, 0, 25, 0, "fused"),
+                                                            (9000, 60, 120, 40, "fused"), (17000, 40, 200, 30, "fused")])
 def test_round_index_kernels_match_their_host_statement(n, n_out, n_crash, n_join, chunked):
-    """The kernels that build the per-round index (rapid_amd/csrc/index_kernels.h), emulated: the one-workgroup form and the
+    """The kernels that build the per-round index (rapid_amd/csrc/index_kernels.h), emulated: the one-launch form of a declared
+    alert set (index_fused_kernel: everything in one workgroup's LDS), the two-kernel form (touch, then one workgroup) and the
     form of large populations (nodes walked by workgroups of 8,192: count, assign, then one workgroup for the adjacency)
     must produce, entry for entry, what pyemu.build_round_index states in numpy -- the statement every emulated tally test
     already runs on: slots ascending by node, dictionary and declared masks, the hot adjacency triples and per-slot masks,
@@ -285,7 +287,9 @@ def test_round_index_kernels_match_their_host_statement(n, n_out, n_crash, n_joi
     sc = S.build_churn_scenario(obs, member, cfg, n_crash, n_join, H, L, receivers=[0])
     alerts = sc.batches.recs
     want = pyemu.build_round_index(alerts, n, K, L, np.asarray(obs), member)
-    got = pyemu.index_run(alerts, n, K, L, cfg, obs, member, chunked=chunked)
+    fused = chunked == "fused"
+    chunked = chunked is True
+    got = pyemu.index_run(alerts, n, K, L, cfg, obs, member, chunked=chunked, fused=fused)
     nh, na, nt = want["n_hot"], want["n_adj"], want["n_touched"]
     assert (int(got["info"][0]), int(got["info"][1]), int(got["info"][3]), int(got["info"][5])) == (nh, nh, na, nt)
     assert got["info"][2] == 0 and got["info"][6] == 1 and got["info"][7] == 0
@@ -297,8 +301,10 @@ def test_round_index_kernels_match_their_host_statement(n, n_out, n_crash, n_joi
     nw = (n + 31) // 32
     assert np.array_equal(got["tbits"][:nw], want["tbits"]) and np.array_equal(got["trank"][:nw], want["trank"])
     assert np.array_equal(got["tent"][:nt], want["tent"][:nt])
+    if fused:  # ... and the 32-bit entries the tally stages, which the other forms leave to dict_entries_kernel
+        assert np.array_equal(got["entries"], pyemu.dict_entries(want, n))
     if not chunked:  # with room for the direct tables the one-workgroup form skips the compressed ones and says so
-        lean = pyemu.index_run(alerts, n, K, L, cfg, obs, member, direct_budget=160 * 1024)
+        lean = pyemu.index_run(alerts, n, K, L, cfg, obs, member, direct_budget=160 * 1024, fused=fused)
         assert lean["info"][7] == 1 and lean["info"][6] == 0 and np.array_equal(lean["dict"][:n], want["dict"][:n])
         assert np.array_equal(lean["pairs"][:na], want["adj"][:na]) and (lean["tbits"][:nw] == 0xEEEEEEEE).all()
 
@@ -618,13 +624,13 @@ def test_q4_stale_observer_memo_decides_a_round_as_in_the_reference():
     want_memo = pyemu.build_round_index(alerts, n, K, L, obs_memo, member)
     want_fresh = pyemu.build_round_index(alerts, n, K, L, np.asarray(obs), member)
     assert want_memo["n_adj"] == want_fresh["n_adj"] + 1
-    for chunked in (False, True):
+    for chunked, fused in ((False, False), (True, False), (False, True)):
         rows, valid = np.full((n, K), -7, dtype=np.int32), np.zeros(n, dtype=np.uint8)
-        got = pyemu.index_run(alerts, n, K, L, cfg, obs, member, chunked=chunked, q4=(rows, valid))
+        got = pyemu.index_run(alerts, n, K, L, cfg, obs, member, chunked=chunked, fused=fused, q4=(rows, valid))
         assert got["info"][2] == 0 and np.array_equal(got["pairs"][: want_fresh["n_adj"]], want_fresh["adj"][: want_fresh["n_adj"]])
         assert valid[x] == 1 and rows[x].tolist() == np.asarray(obs)[x].tolist() and valid[m0] == 0 and valid.sum() == 1  # members only
         rows[x] = stale
-        got = pyemu.index_run(alerts, n, K, L, cfg, obs, member, chunked=chunked, q4=(rows, valid))
+        got = pyemu.index_run(alerts, n, K, L, cfg, obs, member, chunked=chunked, fused=fused, q4=(rows, valid))
         assert got["info"][2] == 4 and got["info"][3] == want_memo["n_adj"]
         assert np.array_equal(got["pairs"][: want_memo["n_adj"]], want_memo["adj"][: want_memo["n_adj"]])
         assert np.array_equal(got["smask"][: want_memo["n_hot"]], want_memo["adj_off"][: want_memo["n_hot"]])
