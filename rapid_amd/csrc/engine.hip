@@ -751,6 +751,10 @@ int build_round_index(rapid_engine* h) {
             best_blocks = blocks;
         }
     }
+    if (const char* e = env_knob("RAPID_TALLY_WAVES_EXACT")) {  // profiling knob: this many waves, whatever the cost model says
+        const int w = atoi(e);
+        if (w >= 1 && w <= w_cap && sh + w * per_wave + rapid::kBlockStatsBytes <= lds_max) best_w = w;
+    }
     h->waves_per_block = best_w;
     h->lds_bytes = sh + best_w * per_wave + rapid::kBlockStatsBytes;
     const long long want = ((long long)h->n_receivers + best_w - 1) / best_w;

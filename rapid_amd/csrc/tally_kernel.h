@@ -611,11 +611,26 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
         unsigned int* l_bits = reinterpret_cast<unsigned int*>(smem);
         unsigned short* l_rank = reinterpret_cast<unsigned short*>(smem + align16(n_words * 4));
         unsigned int* l_ent = reinterpret_cast<unsigned int*>(smem + align16(n_words * 4) + align16(n_words * 2));
-        for (int i = (int)threadIdx.x; i < n_words; i += (int)blockDim.x) {
-            l_bits[i] = p.idx.tbits[i];
-            l_rank[i] = p.idx.trank[i];
-        }
-        for (int i = (int)threadIdx.x; i < p.idx.n_touched; i += (int)blockDim.x) l_ent[i] = p.idx.tent[i];
+        // (four copies per thread in flight, as for the direct tables below: the three tables of 10^5 nodes arrive in two or three
+        // round trips instead of ten)
+        auto stage32 = [&](unsigned int* dst, const unsigned int* src, int n) {
+            for (int base = 0; base < n; base += 4 * (int)blockDim.x) {
+                unsigned int v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = base + j * (int)blockDim.x + (int)threadIdx.x;
+                    v[j] = i < n ? src[i] : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = base + j * (int)blockDim.x + (int)threadIdx.x;
+                    if (i < n) dst[i] = v[j];
+                }
+            }
+        };
+        stage32(l_bits, p.idx.tbits, n_words);
+        stage32(reinterpret_cast<unsigned int*>(l_rank), reinterpret_cast<const unsigned int*>(p.idx.trank), (n_words + 1) / 2);  // (two ranks per word)
+        stage32(l_ent, p.idx.tent, p.idx.n_touched);
         tbits = l_bits;
         trank = l_rank;
         tent = l_ent;

@@ -162,6 +162,11 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
     const int* ref_list;
     unsigned long long cand;
     bool have = true;
+    // (this kernel is a chain of memory round trips, not bandwidth: the receiver's own count and fingerprint are requested
+    // together with the candidate's index, before anything depends on it, and the lists are compared four steps at a time)
+    const bool in_range = r < n_receivers;
+    const int my_count = in_range ? prop_count[r] : 0;
+    const unsigned long long my_fp = in_range ? fp[r] : 0ull;
     if (rep_in_res) {
         const unsigned int rep = (unsigned int)res[0];
         have = rep < (unsigned int)n_receivers;
@@ -173,12 +178,22 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
         ref_n = ref[0];
         ref_list = ref + 1;
     }
-    const bool voter = have && r < n_receivers && prop_count[r] != 0 && fp[r] == cand;
+    const bool voter = have && in_range && my_count != 0 && my_fp == cand;
     if (voter) {
-        bool bad = prop_count[r] != ref_n;
+        bool bad = my_count != ref_n;
         if (!bad) {
             const int* mine = props + (long long)r * prop_cap;
-            for (int i = lane; i < ref_n; i += 64) bad |= mine[i] != ref_list[i];
+            for (int i0 = 0; i0 < ref_n; i0 += 256) {
+                int a[4], b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = i0 + 64 * j + lane;
+                    a[j] = i < ref_n ? mine[i] : 0;
+                    b[j] = i < ref_n ? ref_list[i] : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bad |= a[j] != b[j];
+            }
         }
         const unsigned long long any_bad = __ballot(bad);
         if (lane == 0) {

@@ -24,6 +24,7 @@ sc = S.build_scenario(name, subj, view.getCurrentConfigurationId())
 nbytes = 20 * len(sc.records)
 for w in waves:
     os.environ["RAPID_TALLY_WAVES"] = str(w)
+    os.environ["RAPID_TALLY_WAVES_EXACT"] = str(w)  # (exactly that many, not the cost model's choice below the cap)
     sim = E.ClusterSimulation(eng)
     sim.load_streams(sc.records, sc.rec_off)
     sim.set_alert_set(sc.batches.recs, trust_copies=True)
