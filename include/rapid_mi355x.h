@@ -435,7 +435,8 @@ int rapid_sim_pass_times(rapid_engine* h, float out[4]);
  * eighth), 2048 = the vote count never uses the statistics the tally kernel gathers (always a counting pass), 4096 = the
  * round index built by several workgroups (the form of populations >= 40,000 nodes) whatever the size, 16384 = a view change
  * sorts all K rings again instead of compacting / merging the old ones, 131072 = the round index of a declared alert set built
- * by the two-kernel form (touch pass + one workgroup) instead of the one-launch form, 32 = measurement only: stream the records through
+ * by the two-kernel form (touch pass + one workgroup) instead of the one-launch form, 262144 = the vote verification compares the
+ * voters' node lists instead of their slot bitmaps, 32 = measurement only: stream the records through
  * the registers without tallying them (results are meaningless).  Every bit selects another PRODUCT path or instantiation
  * (all of them parity-tested); none adds code that the default does not ship. */
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);

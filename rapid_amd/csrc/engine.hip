@@ -101,6 +101,8 @@ struct rapid_engine {
     DevBuf<unsigned long long> d_cfg_partial;
     DevBuf<int> d_chunk_kept, d_joiners, d_join_nodes, d_join_vals;   // incremental view change (view_kernels.h)
     DevBuf<unsigned long long> d_join_keys, d_join_skeys;
+    DevBuf<unsigned long long> d_bitmaps;  // [receivers][bitmap_words]: the voters' proposals over the round's hot slots (launch_tally)
+    int bitmap_words = 0;
     DevBuf<unsigned char> d_sort_tmp;
     DevBuf<int> d_seg_off;                       // [K + 1] ring boundaries inside the [K][M] sort buffers
     std::vector<int> seg_host;                   // its host copy (lives as long as the async upload needs it)
@@ -163,6 +165,7 @@ struct rapid_engine {
     bool index_ms_pending = false;
     const int* idxwork_clean_at = nullptr;  // the index work area is known to be all zero for this allocation and node count
     int idxwork_clean_n = -1;
+    bool tally_bitmaps_valid = false;  // d_bitmaps holds the voters' proposals of the last tally launch as slot bitmaps (TallyParams::bitmaps)
     bool tally_votes_valid = false;  // d_voteback holds the vote statistics of the last tally launch (tally_kernel.h: vote_res)
     bool stats_fresh = false;  // the statistics were zeroed by the index build of this very call
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // timing events, created once (no create / destroy per call, nothing to leak on an error path)
@@ -821,6 +824,12 @@ int launch_tally(rapid_engine* h) {
     p.vote_acc = h->d_stats.p + (size_t)8 * (size_t)h->grid_blocks + 1;
     p.vote_res = h->d_voteback.p;
     h->tally_votes_valid = true;
+    // the voters' proposals as bitmaps over the round's hot slots, for the verification that follows (grown when a round needs more)
+    p.bitmap_words = (h->n_hot + 63) / 64;
+    HIPCHK(h, h->d_bitmaps.ensure((size_t)std::max(h->n_receivers, 1) * (size_t)std::max(p.bitmap_words, 1)));
+    p.bitmaps = h->d_bitmaps.p;
+    h->tally_bitmaps_valid = true;
+    h->bitmap_words = p.bitmap_words;
     {
         const long long slots = (long long)h->grid_blocks * h->waves_per_block;
         const char* e = env_knob("RAPID_POOL_EIGHTHS");  // measurement knob: size of the pool in eighths of the population
@@ -963,6 +972,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_q4_nodes.release(); h->d_q4_rows.release(); h->d_q4_valid.release(); h->d_q4_flag.release(); h->d_entries.release();
     h->d_gen_res.release(); h->d_gen_keep.release(); h->d_gen_boff.release(); h->d_gen_rx.release();
     h->d_ids_hi2.release(); h->d_ids_lo2.release(); h->d_ids_new.release(); h->d_cfg_partial.release(); h->d_chunk_kept.release();
+    h->d_bitmaps.release();
     h->d_joiners.release(); h->d_join_nodes.release(); h->d_join_vals.release(); h->d_join_keys.release(); h->d_join_skeys.release();
     h->d_records_own.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
@@ -1847,10 +1857,12 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
                 hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st,
                                    h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
             // (published "to" the block itself: the last workgroup completes res[] and, from_tally, copies the list into ref[])
-            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * 64, 1024))), dim3(1024), 0, st,
+            const bool by_bits = from_tally && h->tally_bitmaps_valid && (h->force_exact & 262144) == 0;  // (the voters' bitmaps of the same launch: 64 bytes per receiver instead of a list)
+            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * (by_bits ? 1 : 64), 1024))), dim3(1024), 0, st,
                                h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, d_res,
                                (int)res_words, reinterpret_cast<unsigned int*>(d_res + 9), reinterpret_cast<volatile unsigned long long*>(d_res),
-                               nullptr, 0u, from_tally ? 1 : 0, h->d_errflags.p);
+                               nullptr, 0u, from_tally ? 1 : 0, h->d_errflags.p, by_bits ? h->d_bitmaps.p : (const unsigned long long*)nullptr,
+                               h->bitmap_words);
             NCCLCHK(h, ncclAllGather(d_res, h->d_gather.p, seg_words, ncclUint64, h->comm, st));  // the round's one collective
             hipLaunchKernelGGL(rapid::vote_merge_kernel, dim3(1), dim3(256), 0, st, h->d_gather.p, h->n_ranks, (int)seg_words,
                                (int)res_words, h->max_cut, (long long)out->quorum, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
@@ -1871,12 +1883,13 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
                 hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st,
                                    h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
             from_tally_used = from_tally;
-            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * 64, 1024))), dim3(1024), 0, st,
+            const bool by_bits = from_tally && h->tally_bitmaps_valid && (h->force_exact & 262144) == 0;  // (the voters' bitmaps of the same launch: 64 bytes per receiver instead of a list)
+            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * (by_bits ? 1 : 64), 1024))), dim3(1024), 0, st,
                                h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, d_res,
                                (int)res_words, reinterpret_cast<unsigned int*>(d_res + 9),
                                reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
                                reinterpret_cast<volatile unsigned int*>(h->d_mail) + 14, ++h->mail_seq, from_tally ? 1 : 0,
-                               h->d_errflags.p);
+                               h->d_errflags.p, by_bits ? h->d_bitmaps.p : (const unsigned long long*)nullptr, h->bitmap_words);
         } else {
             HIPCHK(h, hipMemsetAsync(h->d_hist.p, 0, HB * 8, st));
             HIPCHK(h, hipMemsetAsync(h->d_mm.p, 0, 64, st));

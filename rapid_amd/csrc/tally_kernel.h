@@ -200,6 +200,12 @@ struct TallyParams {
     // nullptr: not gathered.
     unsigned long long* vote_acc;
     unsigned long long* vote_res;
+    // bitmaps[r * bitmap_words + i] = which of the hot slots 64 i .. 64 i + 63 receiver r proposes (written for receivers that
+    // announce; bitmap_words = ceil(n_hot / 64)): the proposal in the round's own slot numbering, 64 bytes per receiver at C3b
+    // instead of a 2 KB node list -- what the fast-round verification compares element for element (vote_kernels.h).  nullptr:
+    // not written.
+    unsigned long long* bitmaps;
+    int bitmap_words;
     // Every other wave of a workgroup starts `stagger` x 8,128 cycles late.  All receivers of a round cost the same and all
     // waves start together, so without it the waves of a launch move in step: everybody streams (the memory system
     // saturated), then everybody tallies the end of a stream and writes results (the memory system idle).
@@ -1622,10 +1628,12 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
         if (emit_batch >= 0) {
             wave_lds_fence();
             int* const out = p.props + (long long)r * p.prop_cap;
+            unsigned long long* const bm = p.bitmaps != nullptr ? p.bitmaps + (long long)r * p.bitmap_words : nullptr;
             for (int i0 = 0; i0 < n_hot; i0 += kWave) {
                 const int i = i0 + lane;
                 const bool take = i < n_hot && (d.load(i) & Det::kFlushed) != 0;
                 const unsigned long long mk = wave_ballot(take);
+                if (bm != nullptr && lane == 0) stream_store(bm + (i0 >> 6), mk);
                 const int idx = count + __popcll(mk & lanes_lt(lane));
                 if (take) {
                     const int node = nos_in_lds ? l_nos[i] : p.idx.node_of_slot[i];

@@ -139,11 +139,16 @@ __global__ void vote_prepare_ref_kernel(const unsigned long long* mm, unsigned l
 // publish != nullptr (population held by one rank): the LAST workgroup to finish copies the round's answer --
 // res[0 .. res_words) and ref[0 .. 1 + size] -- into host-mapped memory, so the host reads it after synchronising
 // without a copy being enqueued; done[0] counts the finished workgroups and is left at zero.
+// bits != nullptr (only with rep_in_res: the tally kernel wrote every voter's proposal as a bitmap over the round's hot slots,
+// tally_kernel.h: TallyParams::bitmaps): the comparison runs on the bitmaps -- bits_words 64-bit words per receiver, equal
+// bitmaps <=> equal node lists (slot -> node is injective within a round), 64 bytes per receiver at C3b instead of a 2 KB list
+// (19 MB re-read by 594 workgroups -> 0.6 MB by ten) -- with ONE THREAD per receiver (launch ceil(R / block) workgroups).
 __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop_count, const int* props, int prop_cap,
                                    int n_receivers, const unsigned long long* mm, const int* ref,
                                    unsigned long long* mismatch, const unsigned long long* res, int res_words,
                                    unsigned int* done, volatile unsigned long long* publish, volatile unsigned int* seq_out,
-                                   unsigned int seq, int rep_in_res, const unsigned int* tally_errors) {
+                                   unsigned int seq, int rep_in_res, const unsigned int* tally_errors,
+                                   const unsigned long long* bits = nullptr, int bits_words = 0) {
     __shared__ unsigned int s_bad, s_seen, s_last;
     if (threadIdx.x == 0) {
         s_bad = 0u;
@@ -151,8 +156,9 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
         s_last = 0u;
     }
     __syncthreads();
-    const int r = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const int lane = (int)(threadIdx.x & 63u);
+    const bool by_bits = bits != nullptr && rep_in_res != 0;
+    const int r = by_bits ? (int)(blockIdx.x * blockDim.x + threadIdx.x) : (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = by_bits ? 0 : (int)(threadIdx.x & 63u);
     // The proposal the voters are compared with.  After a counting kernel: the winning bucket's only fingerprint mm[0] and
     // the representative's list it copied out (ref[0] = size, ref[1..]).  rep_in_res -- no counting kernel ran, res[] came
     // from the tally kernel (tally_kernel.h: vote_res): the CANDIDATE is the proposal of the lowest voter res[0], read in
@@ -167,8 +173,9 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
     const bool in_range = r < n_receivers;
     const int my_count = in_range ? prop_count[r] : 0;
     const unsigned long long my_fp = in_range ? fp[r] : 0ull;
+    unsigned int rep = 0u;
     if (rep_in_res) {
-        const unsigned int rep = (unsigned int)res[0];
+        rep = (unsigned int)res[0];
         have = rep < (unsigned int)n_receivers;
         cand = have ? fp[rep] : 0ull;
         ref_n = have ? prop_count[rep] : 0;
@@ -179,7 +186,28 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
         ref_list = ref + 1;
     }
     const bool voter = have && in_range && my_count != 0 && my_fp == cand;
-    if (voter) {
+    if (by_bits) {
+        bool bad = false;
+        if (voter) {
+            const unsigned long long* const mine = bits + (long long)r * bits_words;
+            const unsigned long long* const cnd = bits + (long long)rep * bits_words;
+            for (int i0 = 0; i0 < bits_words; i0 += 8) {
+                unsigned long long a[8], b[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    a[j] = i0 + j < bits_words ? mine[i0 + j] : 0ull;
+                    b[j] = i0 + j < bits_words ? cnd[i0 + j] : 0ull;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bad |= a[j] != b[j];
+            }
+        }
+        const unsigned long long m_seen = __ballot(voter), m_bad = __ballot(voter && bad);
+        if ((threadIdx.x & 63u) == 0u) {
+            if (m_bad) atomicAdd(&s_bad, (unsigned int)__popcll(m_bad));
+            if (m_seen) atomicAdd(&s_seen, (unsigned int)__popcll(m_seen));
+        }
+    } else if (voter) {
         bool bad = my_count != ref_n;
         if (!bad) {
             const int* mine = props + (long long)r * prop_cap;

@@ -1,6 +1,6 @@
 """One round = new_round + tally + count_votes (bench.py's step), timed in one process under different knobs of
 rapid_sim_set_force_exact (0 = product; 2048 = vote count with its own counting pass; 1024 = no common pool; 131072 = round
-index by the two-kernel form):
+index by the two-kernel form; 262144 = vote verification on node lists instead of slot bitmaps):
     python scripts/step_ab.py [config] [steps]"""
 import os
 import sys
@@ -27,7 +27,7 @@ sim = E.ClusterSimulation(eng)
 sim.load_streams(sc.records, sc.rec_off)
 sim.set_alert_set(sc.batches.recs, trust_copies=True)
 for rnd in range(3):
-    for knob in (0, 131072, 2048, 1024, 0):
+    for knob in (0, 262144, 131072, 2048, 1024, 0):
         sim.set_force_exact(knob)
         for _ in range(5):
             sim.new_round(); sim.tally(); rr = sim.count_votes()

@@ -225,6 +225,11 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     for (int i = 0; i < 10; ++i) vote_res[i] = 0xDEADull;
     p.vote_acc = vote_acc;
     p.vote_res = vote_res;
+    // the voters' proposals as bitmaps over the hot slots (TallyParams::bitmaps), poisoned: a voter's words must all be written
+    const int bitmap_words = (n_hot + 63) / 64;
+    std::vector<unsigned long long> bitmaps((size_t)std::max(n_receivers, 1) * (size_t)std::max(bitmap_words, 1), 0xA5A5A5A5A5A5A5A5ull);
+    p.bitmaps = bitmaps.data();
+    p.bitmap_words = bitmap_words;
     if ((flags & 512) != 0 && n_receivers > grid * waves) {
         p.n_static = grid * waves;
         p.pool = pool;
@@ -270,6 +275,19 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     if (vote_res_out != nullptr)
         for (int i = 0; i < 10; ++i) vote_res_out[i] = vote_res[i];
     if (pool[0] != 0u || pool[1] != 0u) return -7;  // the last workgroup must leave the pool words zeroed for the next launch
+    // every voter's bitmap names exactly its proposal: as many bits as the proposal has nodes, and (up to the list's capacity)
+    // the same nodes in the same order
+    for (int r = 0; r < n_receivers; ++r) {
+        if (prop_count[r] == 0) continue;
+        int at = 0;
+        for (int i = 0; i < bitmap_words * 64; ++i) {
+            if (((bitmaps[(size_t)r * bitmap_words + (i >> 6)] >> (i & 63)) & 1ull) == 0ull) continue;
+            if (i >= n_hot) return -10;
+            if (at < prop_cap && props[(long long)r * prop_cap + at] != node_of_slot[i]) return -10;
+            ++at;
+        }
+        if (prop_count[r] > 0 ? at != prop_count[r] : at <= prop_cap) return -10;
+    }
     return error_flags[0] != 0u ? -1 : 0;
 }
 
@@ -394,9 +412,11 @@ extern "C" int emu_generate(const unsigned char* alerts, const long long* boff, 
 
 extern "C" {
 // mode 0: vote_count_local_kernel + vote_verify_kernel; mode 1: res[] as the tally kernel leaves it (lowest voter, voters) +
-// vote_verify_kernel with the candidate read in place.  block[] = res[10] followed by ref[1 + prop_cap] (as published).
+// vote_verify_kernel with the candidate read in place; mode 2: as mode 1, the comparison on the voters' bitmaps (bits[],
+// bits_words per receiver, one thread per receiver).  block[] = res[10] followed by ref[1 + prop_cap] (as published).
 int emu_vote_settle(const unsigned long long* fp, const int* prop_count, const int* props, int prop_cap, int n_receivers,
-                    unsigned long long salt, int mode, unsigned long long* block, unsigned long long seed) {
+                    unsigned long long salt, int mode, unsigned long long* block, unsigned long long seed,
+                    const unsigned long long* bits, int bits_words) {
     const int res_words = 10;
     std::vector<unsigned long long> dev((size_t)res_words + (size_t)(prop_cap + 2) / 2 + 1, 0ull);
     unsigned long long* res = dev.data();
@@ -414,12 +434,14 @@ int emu_vote_settle(const unsigned long long* fp, const int* prop_count, const i
         res[0] = rep;
         res[2] = voters;
     }
-    const int grid = std::max(1, (n_receivers * 64 + 1023) / 1024);
+    const bool by_bits = mode == 2;
+    const int grid = std::max(1, (n_receivers * (by_bits ? 1 : 64) + 1023) / 1024);
     unsigned int seq_word = 0u;
     for (int b = 0; b < grid; ++b)
         emu::run_block((unsigned)b, (unsigned)grid, 1024u, [&] {
             rapid::vote_verify_kernel(fp, prop_count, props, prop_cap, n_receivers, res + 4, ref, res + 6, res, res_words,
-                                      reinterpret_cast<unsigned int*>(res + 9), block, &seq_word, 77u, mode, errs);
+                                      reinterpret_cast<unsigned int*>(res + 9), block, &seq_word, 77u, mode != 0 ? 1 : 0, errs,
+                                      by_bits ? bits : nullptr, bits_words);
         }, seed + 10 + (unsigned)b);
     if (seq_word != 77u) return -2;
     if (res[9] != 0ull) return -3;  // the packed counter is left at zero

@@ -14,7 +14,11 @@ def lib():
     global _LIB
     if _LIB is None:
         variant = os.environ.get("RAPID_EMU_VARIANT", "")  # "q1" / "q2": smaller windows; "ubsan": sanitizer build
-        subprocess.check_call(["make", "-C", _HERE, "-s", "VARIANT=" + variant], stderr=subprocess.DEVNULL)
+        import fcntl
+        os.makedirs(os.path.join(_HERE, "_build"), exist_ok=True)
+        with open(os.path.join(_HERE, "_build", ".lock"), "w") as lk:  # one builder at a time (pytest-xdist workers)
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-C", _HERE, "-s", "VARIANT=" + variant], stderr=subprocess.DEVNULL)
         _LIB = C.CDLL(os.path.join(_HERE, "_build", "libtally_emu%s.so" % ("_" + variant if variant else "")))
     return _LIB
 
@@ -201,7 +205,7 @@ class CdInstance:
 RES_WORDS = 10
 
 
-def vote_settle(fp, prop_count, props, mode, salt=0, seed=1):
+def vote_settle(fp, prop_count, props, mode, salt=0, seed=1, bits=None):
     """vote_count_local_kernel + vote_verify_kernel (mode 0) or vote_verify_kernel on the statistics the tally kernel leaves
     (mode 1: candidate = the lowest voter's proposal) under the emulator.  -> (res[10] as published, ref list or None if it
     overflowed)."""
@@ -213,7 +217,12 @@ def vote_settle(fp, prop_count, props, mode, salt=0, seed=1):
     block = np.zeros(RES_WORDS + (cap + 2) // 2 + 1, dtype=np.uint64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     L_.emu_vote_settle.restype = C.c_int
-    rc = L_.emu_vote_settle(p(fp), p(prop_count), p(props), cap, R, C.c_ulonglong(salt), mode, p(block), C.c_ulonglong(seed))
+    # mode 2: the comparison on bits[R, words] (the voters' proposals as bitmaps over the round's hot slots)
+    if bits is not None:
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        assert mode == 2 and bits.shape[0] == R
+    rc = L_.emu_vote_settle(p(fp), p(prop_count), p(props), cap, R, C.c_ulonglong(salt), mode, p(block), C.c_ulonglong(seed),
+                            p(bits) if bits is not None else None, int(bits.shape[1]) if bits is not None else 0)
     assert rc == 0, rc
     ref = block[RES_WORDS:].view(np.int32)
     n = int(ref[0])

@@ -723,7 +723,8 @@ def test_vote_count_through_a_one_rank_communicator(E):
 
     for case in ("crash", "churn", "noquorum", "conflict", "dissent"):
         a, sc = run(False, case)
-        for with_comm, knob in ((True, 0), (True, 512), (False, 2048)):  # 2048: count without the statistics the tally kernel gathers
+        # 2048: count without the statistics the tally kernel gathers; 262144: verification on the node lists instead of the slot bitmaps
+        for with_comm, knob in ((True, 0), (True, 512), (False, 2048), (False, 262144), (True, 262144)):
             b, _ = run(with_comm, case, knob)
             for k in ("decided", "cut_size", "quorum", "votes_total", "votes_winner", "membership", "cut", "new_cfg"):
                 assert a.get(k) == b.get(k), (case, knob, k, a.get(k), b.get(k))

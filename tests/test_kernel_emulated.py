@@ -366,6 +366,24 @@ def test_vote_kernels_settle_a_round(seed):
                 props2[forged, 0] += 1
                 res2, _ = pyemu.vote_settle(fp, pcount, props2, mode=1)
                 assert int(res2[6]) == 1 and int(res2[7]) == int(counts[lead])
+        # the same settled on the voters' bitmaps (what the tally kernel writes beside the lists: one bit per hot slot, the
+        # slot numbering = the rank of a node among the round's proposed nodes), 9 and 1 words per receiver
+        nodes = sorted({x for c in cuts for x in c})
+        slot = {x: i for i, x in enumerate(nodes)}
+        for words in (1, 9):
+            bits = np.zeros((R, words), dtype=np.uint64)
+            spread = (words * 64) // max(len(nodes), 1)
+            for r in voters:
+                for x in cuts[int(which[r])]:
+                    b = slot[x] * max(spread, 1)
+                    bits[r, b >> 6] |= np.uint64(1 << (b & 63))
+            res3, ref3 = pyemu.vote_settle(fp, pcount, props, mode=2, bits=bits)
+            assert ref3 == ref1 and res3.tolist() == res1.tolist()
+            if len(voters) >= 3 and which[int(voters[-1])] == lead:
+                bits2 = bits.copy()
+                bits2[int(voters[-1]), words - 1] ^= np.uint64(1 << 63)
+                res4, _ = pyemu.vote_settle(fp, pcount, props, mode=2, bits=bits2)
+                assert int(res4[6]) == 1 and int(res4[7]) == int(counts[lead])
 
 
 @pytest.mark.parametrize("seed", range(8))
