@@ -1072,6 +1072,15 @@ int rapid_view_register_endpoints(rapid_engine* h, const uint8_t* hostnames, con
     if (rc) return rc;
     const int K = h->cfg.K, n_old = h->n_nodes, n_nodes = n_old + n_new;
     const int base = h->reg_off[(size_t)n_old];
+    // Device memory first (the one step that fails for an ordinary reason -- no memory left), the host-side registry after it:
+    // a call that returns an error has registered nothing.
+    const size_t blob_bytes = h->reg_blob.size() + (size_t)(host_off[n_new] - host_off[0]);
+    HIPCHK(h, h->d_blob.ensure(std::max<size_t>(blob_bytes, 1)));
+    HIPCHK(h, h->d_host_off.ensure((size_t)n_nodes + 1));
+    HIPCHK(h, h->d_ports.ensure((size_t)n_nodes));
+    HIPCHK(h, h->d_keys.ensure((size_t)K * n_nodes));
+    HIPCHK(h, h->d_hx_host0.ensure((size_t)n_nodes));
+    HIPCHK(h, h->d_hx_port0.ensure((size_t)n_nodes));
     h->reg_blob.insert(h->reg_blob.end(), hostnames + host_off[0], hostnames + host_off[n_new]);
     for (int i = 1; i <= n_new; ++i) h->reg_off.push_back(base + (host_off[i] - host_off[0]));
     h->reg_ports.insert(h->reg_ports.end(), ports, ports + n_new);
@@ -1081,19 +1090,26 @@ int rapid_view_register_endpoints(rapid_engine* h, const uint8_t* hostnames, con
     h->n_nodes = n_nodes;
     // the ring keys are laid out [K][n_nodes]: with another stride they are computed again for everybody (a few us per
     // ten thousand endpoints), and the rings are sorted afresh -- the members and their order are the same
-    const size_t blob_bytes = h->reg_blob.size();
-    HIPCHK(h, h->d_blob.ensure(std::max<size_t>(blob_bytes, 1)));
-    HIPCHK(h, h->d_host_off.ensure((size_t)n_nodes + 1));
-    HIPCHK(h, h->d_ports.ensure((size_t)n_nodes));
-    HIPCHK(h, h->d_keys.ensure((size_t)K * n_nodes));
-    HIPCHK(h, h->d_hx_host0.ensure((size_t)n_nodes));
-    HIPCHK(h, h->d_hx_port0.ensure((size_t)n_nodes));
-    HIPCHK(h, hipMemcpyAsync(h->d_blob.p, h->reg_blob.data(), blob_bytes, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_host_off.p, h->reg_off.data(), sizeof(int) * ((size_t)n_nodes + 1), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_ports.p, h->reg_ports.data(), sizeof(int) * (size_t)n_nodes, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(rapid::ring_keys_kernel, dim3(grid_for((long long)K * n_nodes, 256)), dim3(256), 0, h->stream,
-                       h->d_blob.p, h->d_host_off.p, h->d_ports.p, n_nodes, K, h->d_keys.p, h->d_hx_host0.p, h->d_hx_port0.p);
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    auto upload = [&]() -> int {
+        HIPCHK(h, hipMemcpyAsync(h->d_blob.p, h->reg_blob.data(), blob_bytes, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_host_off.p, h->reg_off.data(), sizeof(int) * ((size_t)n_nodes + 1), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_ports.p, h->reg_ports.data(), sizeof(int) * (size_t)n_nodes, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(rapid::ring_keys_kernel, dim3(grid_for((long long)K * n_nodes, 256)), dim3(256), 0, h->stream,
+                           h->d_blob.p, h->d_host_off.p, h->d_ports.p, n_nodes, K, h->d_keys.p, h->d_hx_host0.p, h->d_hx_port0.p);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return RAPID_OK;
+    };
+    if ((rc = upload())) {  // (a device fault: the registry goes back to where it was; the key table may be half rewritten, so the view has to be built again)
+        h->reg_blob.resize((size_t)base);
+        h->reg_off.resize((size_t)n_old + 1);
+        h->reg_ports.resize((size_t)n_old);
+        h->id_hi.resize((size_t)n_old);
+        h->id_lo.resize((size_t)n_old);
+        h->member.resize((size_t)n_old);
+        h->n_nodes = n_old;
+        h->view_built = false;
+        return rc;
+    }
     h->host_tables_valid = false;
     h->ring_member.clear();
     h->ring_m = 0;
