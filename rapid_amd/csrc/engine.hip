@@ -697,9 +697,9 @@ int build_round_index(rapid_engine* h) {
     // rounds with thousands of hot subjects keep two slots per LDS word (the detector state decides how many receivers a CU holds)
     h->packed = rapid::tally_wants_packed(h->n_hot);
     const int per_wave = rapid::tally_wave_bytes(h->n_slots, h->packed);
-    const int sh_direct = rapid::tally_shared_bytes(rapid::kDictDirect, N, h->n_touched, h->n_hot, h->n_adj);
-    const int sh_comp = rapid::tally_shared_bytes(rapid::kDictCompressed, N, h->n_touched, h->n_hot, h->n_adj);
-    const int sh_mem = rapid::tally_shared_bytes(rapid::kDictMemory, N, h->n_touched, h->n_hot, h->n_adj);  // (== kDictResolved: no tables)
+    const int sh_direct = rapid::tally_shared_bytes(rapid::kDictDirect, N, h->n_touched, h->n_hot, h->n_adj, h->packed);
+    const int sh_comp = rapid::tally_shared_bytes(rapid::kDictCompressed, N, h->n_touched, h->n_hot, h->n_adj, h->packed);
+    const int sh_mem = rapid::tally_shared_bytes(rapid::kDictMemory, N, h->n_touched, h->n_hot, h->n_adj, h->packed);  // (== kDictResolved: no tables)
     if (sh_mem + per_wave + rapid::kBlockStatsBytes > lds_max)
         return fail(h, RAPID_ECAPACITY, "%d subjects need %d B of LDS per receiver (max %d)", h->n_slots,
                     sh_mem + per_wave + rapid::kBlockStatsBytes, lds_max);

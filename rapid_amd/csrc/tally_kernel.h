@@ -240,9 +240,11 @@ __host__ __device__ inline int tally_dict_bytes(int mode, int n_nodes, int n_tou
 #define RAPID_SLOT_TABLES_LDS_MAX 4096
 #endif
 constexpr int kSlotNodesInLdsMax = RAPID_SLOT_TABLES_LDS_MAX;
-__host__ __device__ inline int tally_shared_bytes(int mode, int n_nodes, int n_touched, int n_hot, int n_adj) {
+// (the per-slot tables are in LDS exactly when the detector state is not packed: the property of the INSTANTIATION, so that no
+// access to them has to choose between an LDS and a memory pointer at run time -- see l_smask in the kernel)
+__host__ __device__ inline int tally_shared_bytes(int mode, int n_nodes, int n_touched, int n_hot, int n_adj, bool packed = false) {
     return tally_dict_bytes(mode, n_nodes, n_touched) + align16((n_adj + 1) * 4) +
-           (n_hot <= kSlotNodesInLdsMax ? align16((n_hot + kDummySlots) * 2) + align16(n_hot * 4) : 0);
+           (!packed ? align16((n_hot + kDummySlots) * 2) + align16(n_hot * 4) : 0);
 }
 // per-workgroup statistics accumulator at the very end of the dynamic LDS segment
 constexpr int kBlockStatsBytes = 112;  // eight counters, the workgroup's claim counter, four vote accumulators
@@ -260,6 +262,24 @@ __device__ __forceinline__ unsigned char* dynamic_lds() {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     return smem;
 }
+
+// A pointer into the workgroup's LDS that carries its address space in its type (see the per-slot tables of the tally kernel).
+// tests/emu/ compiles these headers with g++, where there is one address space: a plain pointer.
+#if defined(__clang__) && defined(__HIP__)
+template <class T>
+using lds_ptr = __attribute__((address_space(3))) T*;
+template <class T>
+__device__ __forceinline__ lds_ptr<T> to_lds(void* generic) {  // (the low half of a generic LDS address is the offset in the segment)
+    return (lds_ptr<T>)(unsigned long long)generic;
+}
+#else
+template <class T>
+using lds_ptr = T*;
+template <class T>
+inline lds_ptr<T> to_lds(void* generic) {
+    return static_cast<T*>(generic);
+}
+#endif
 
 // ---- small wave helpers ---------------------------------------------------------------------------------------
 // A receiver is owned by ONE wavefront; that wave's LDS operations execute in program order, so cross-lane
@@ -608,7 +628,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
     // into a word nobody reads, so the fast window needs neither a "hot?" test nor an execution mask per record.
     const int dict_bytes = tally_dict_bytes(kDictMode, p.n_nodes, p.idx.n_touched);
     const int pairs_bytes = align16((p.idx.n_adj + 1) * 4);
-    const int shared_bytes = tally_shared_bytes(kDictMode, p.n_nodes, p.idx.n_touched, n_hot, p.idx.n_adj);
+    const int shared_bytes = tally_shared_bytes(kDictMode, p.n_nodes, p.idx.n_touched, n_hot, p.idx.n_adj, kPacked);
     const unsigned int* tbits = p.idx.tbits;
     const unsigned short* trank = p.idx.trank;
     const unsigned int* tent = p.idx.tent;
@@ -669,9 +689,18 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
     }
     // the hot adjacency (flat list of triples, count first) and the per-slot masks, copied from the round index
     unsigned int* const l_pairs = reinterpret_cast<unsigned int*>(smem + dict_bytes);
-    const bool slot_tables_in_lds = n_hot <= kSlotNodesInLdsMax;  // the per-slot masks and slot -> node
-    unsigned short* const l_smask = reinterpret_cast<unsigned short*>(smem + dict_bytes + pairs_bytes);
-    int* const l_nos = reinterpret_cast<int*>(smem + dict_bytes + pairs_bytes + align16((n_hot + kDummySlots) * 2));
+    constexpr bool slot_tables_in_lds = !kPacked;  // the per-slot masks and slot -> node (tally_shared_bytes)
+    // Where the two per-slot tables live is a property of the instantiation (in LDS unless the detector state is packed), and the
+    // LDS copies are read through pointers that SAY they point into the LDS (lds_ptr).  Chosen at run time through generic
+    // pointers, "in LDS ? l_smask[slot] : p.idx.smask[slot]" is merged by the compiler into ONE load through a selected pointer
+    // -- a FLAT load, which returns out of order with everything else and is waited for with s_waitcnt vmcnt(0); kept apart as
+    // two loads under a run-time branch, the wait-count pass still waits with vmcnt(0) before the LDS read (its destination MAY be
+    // the pending target of the other branch's load).  Either way every sweep, cold window, choice of a witness and every 64
+    // slots of a proposal being written waited for the two windows of the stream in flight and for the stores of the previous
+    // 64 slots -- a memory latency each, 11 % of a receiver's cycles in the proposal loop alone (C3b,
+    // profiles/r04_phase_timers_out_c3b.txt).
+    lds_ptr<unsigned short> const l_smask = to_lds<unsigned short>(smem + dict_bytes + pairs_bytes);
+    lds_ptr<int> const l_nos = to_lds<int>(smem + dict_bytes + pairs_bytes + align16((n_hot + kDummySlots) * 2));
     if (threadIdx.x == 0) l_pairs[0] = (unsigned int)p.idx.n_adj;
     {
         // ONE loop on purpose: with three separate copy loops here the register allocation of the whole kernel changes
@@ -692,8 +721,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
         }
     }
     const unsigned int* const pairs = l_pairs;
-    // (two typed pointers each, not one generic one: a flat load would cost the precise wait counts)
-    const bool nos_in_lds = slot_tables_in_lds;
+    constexpr bool nos_in_lds = slot_tables_in_lds;
     auto smask_of = [&](unsigned int slot) -> unsigned int {  // rings on which a hot observer watches the slot (a dummy slot: none)
         if (slot_tables_in_lds) return (unsigned int)l_smask[slot];
         return slot < (unsigned int)n_hot ? (unsigned int)p.idx.smask[slot] : 0u;

@@ -145,7 +145,7 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     // fmt: 0 = resident records (split / resolved below), 1 = the 20-byte boundary records themselves (kFmtBoundary)
     // tables_in_lds: 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS, 3 = no dictionary: the
     // records carry their subjects' entries (kDictResolved, what resolve_records_kernel leaves in the first dword)
-    const int lds = rapid::tally_shared_bytes(tables_in_lds, n_nodes, n_touched, n_hot, n_adj) + waves * rapid::tally_wave_bytes(n_hot, packed != 0) +
+    const int lds = rapid::tally_shared_bytes(tables_in_lds, n_nodes, n_touched, n_hot, n_adj, packed != 0) + waves * rapid::tally_wave_bytes(n_hot, packed != 0) +
                     rapid::kBlockStatsBytes;
     if (lds > (int)sizeof(smem)) return -5;
     rapid::TallyParams p;
