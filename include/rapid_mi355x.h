@@ -423,7 +423,9 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg);
  * slot (boundary records: 1 = direct tables in LDS, 2 = compressed tables in LDS, 0 = tables in memory, read through L2 --
  * chosen by what fits the LDS next to the receivers' detector state; 3 = nowhere: generated resolved records carry their
  * subjects' entries), bit 0: alert set declared, bit 1: a hot member's memoised observers are stale in this round (Q4 is
- * live)}; index_ms = device time of the last index build */
+ * live)}; index_ms = device time of the last index build that was timed: a call that asks (index_ms != NULL) has the
+ * NEXT build bracketed by timing events -- this call's own if the index is stale; 0 before the
+ * first timed build.  Rounds nobody asks about carry no timing events. */
 int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms);
 /* device times (ms): out[0] = the last index build, out[1] = 0 (there is no resolve pass: a delivered record is read once, by
  * the tally), out[2] = the last rapid_sim_generate, out[3] = 0 */

@@ -163,6 +163,9 @@ struct rapid_engine {
     DevBuf<unsigned int> d_adj;
     hipEvent_t ev_idx0 = nullptr, ev_idx1 = nullptr;  // around the round-index kernels; read lazily (rapid_sim_index_info)
     bool index_ms_pending = false;
+    bool time_index = false;  // somebody has asked for the index build's device time: the NEXT build is bracketed by events (two more
+                              // packets in the queue of every round otherwise, for a number nobody reads)
+    bool vote_lds_attr_set = false;
     const int* idxwork_clean_at = nullptr;  // the index work area is known to be all zero for this allocation and node count
     int idxwork_clean_n = -1;
     bool tally_bitmaps_valid = false;  // d_bitmaps holds the voters' proposals of the last tally launch as slot bitmaps (TallyParams::bitmaps)
@@ -615,10 +618,13 @@ int build_round_index(rapid_engine* h) {
     HIPCHK(h, h->d_tent.ensure((size_t)tent_cap));
     unsigned int* const d_gmask = reinterpret_cast<unsigned int*>(h->d_idxwork.p);
     int* const d_info = h->d_idxwork.p + (size_t)N;
-    if (!h->ev_idx0) HIPCHK(h, hipEventCreate(&h->ev_idx0));
-    if (!h->ev_idx1) HIPCHK(h, hipEventCreate(&h->ev_idx1));
-    const hipEvent_t e0 = h->ev_idx0, e1 = h->ev_idx1;
-    HIPCHK(h, hipEventRecord(e0, st));
+    const bool timed = h->time_index;  // (asked for since the last build: this one is bracketed by events)
+    h->time_index = false;
+    if (timed) {
+        if (!h->ev_idx0) HIPCHK(h, hipEventCreate(&h->ev_idx0));
+        if (!h->ev_idx1) HIPCHK(h, hipEventCreate(&h->ev_idx1));
+        HIPCHK(h, hipEventRecord(h->ev_idx0, st));
+    }
     const int adj_cap = 65536;
     HIPCHK(h, h->d_adj.ensure((size_t)adj_cap + 1));
     // A declared alert set over a population whose per-node tables fit one workgroup's LDS: the whole index in ONE launch
@@ -670,7 +676,7 @@ int build_round_index(rapid_engine* h) {
                        chunked ? h->d_idxblk.p : nullptr, n_chunks, h->q4_emulate ? h->d_q4_rows.p : (int*)nullptr,
                        h->q4_emulate ? h->d_q4_valid.p : (unsigned char*)nullptr);
     }
-    HIPCHK(h, hipEventRecord(e1, st));
+    if (timed) HIPCHK(h, hipEventRecord(h->ev_idx1, st));
     HIPCHK(h, hipGetLastError());
     if (int rc = await_mail(h, 15, h->mail_seq)) return rc;
     if (!fused) {
@@ -679,7 +685,7 @@ int build_round_index(rapid_engine* h) {
     }
     int info[8];
     std::memcpy(info, h->h_mail, sizeof info);  // written by the kernel into host-mapped memory
-    h->index_ms_pending = true;  // the events are read when somebody asks (no wait for them here)
+    h->index_ms_pending = timed;  // the events are read when somebody asks (no wait for them here)
     h->q4_live = (info[2] & 4) != 0;
     if (info[2] & 1) return fail(h, RAPID_ECAPACITY, "the round has %d hot subjects; at most 16318 are supported", info[0]);
     if (info[2] & 2)
@@ -1854,9 +1860,11 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
     bool merged = h->comm && R <= 262144 && (h->force_exact & 512) == 0;
     const size_t seg_words = (back_bytes + 7) / 8;
     if (merged) HIPCHK(h, h->d_gather.ensure(seg_words * (size_t)h->n_ranks));
-    if (local || merged)
+    if ((local || merged) && !h->vote_lds_attr_set) {  // once per engine
         HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::vote_count_local_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, rapid::kVoteBuckets * 4 + 1024));
+        h->vote_lds_attr_set = true;
+    }
 
     // Everything below is enqueued on the engine stream and read back with ONE synchronisation per salt:
     // histogram -> (all-reduce) -> winner -> min/max of the winning bucket -> (all-reduce) -> representative list
@@ -2223,6 +2231,7 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
     if (!h || !info) return RAPID_EINVAL;
     int rc = use_device(h);
     if (rc) return rc;
+    if (index_ms) h->time_index = true;  // (the next build is timed: this call's own if the index is stale)
     if ((rc = prepare_tally(h))) return rc;  // builds the index if it is stale
     info[0] = h->n_hot;
     info[1] = h->n_adj;

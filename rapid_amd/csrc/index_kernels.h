@@ -216,6 +216,7 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
                                                                  int n_chunks, int* q4_rows, unsigned char* q4_valid) {
     __shared__ int s_wave[16];
     __shared__ int s_pre_hot, s_pre_touched;
+    __shared__ int s_pub[8];  // the answer on its way to the host-mapped page
     const int T = (int)blockDim.x, t = (int)threadIdx.x;
     const bool prebuilt = blk_counts != nullptr;  // index_count_kernel + index_assign_kernel did everything that is per node
     if (t == 0) {
@@ -415,11 +416,16 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
         info[1] = n_hot_all;
         info[2] = (info[2] & 4) | (n_hot_all > 16318 ? 1 : 0) | (fits ? 0 : 2);  // 64 slot numbers are kept for the tally kernel's dummy slots
         info[3] = total;
-        for (int i = 0; i < 8; ++i) info_out[i] = info[i];  // info[4] was written by the touch pass
-        // the host does not wait for the stream: it polls this word of the mapped page (what it reads afterwards was written
-        // before the fence; the zeroing above is ordered before the tally kernel by the stream)
+        for (int i = 0; i < 8; ++i) s_pub[i] = info[i];  // info[4] was written by the touch pass
+    }
+    __syncthreads();
+    if (t < 64) {
+        // the host does not wait for the stream: it polls the last word of the mapped page (what it reads afterwards was written
+        // before the fence; the zeroing below is ordered before the tally kernel by the stream).  Eight lanes, one store
+        // instruction: see index_fused_kernel.
+        if (t < 8) info_out[t] = s_pub[t];
         __threadfence_system();
-        info_out[15] = seq;
+        if (t == 0) info_out[15] = seq;
     }
     // leave the work area as the next round's touch pass needs it (all zero): nobody reads gmask[] / info[] after this point
     __syncthreads();
@@ -674,17 +680,22 @@ __global__ __launch_bounds__(1024) void index_fused_kernel(const unsigned char* 
         entries[i] = e;
     }
     __syncthreads();
-    if (t == 0) {
-        info_out[0] = n_hot_all;
-        info_out[1] = n_hot_all;
-        info_out[2] = (s_stale != 0u ? 4 : 0) | (n_hot_all > 16318 ? 1 : 0) | (fits ? 0 : 2);
-        info_out[3] = total;
-        info_out[4] = (int)s_flags;
-        info_out[5] = n_touched;
-        info_out[6] = tfits && !direct_fits ? 1 : 0;
-        info_out[7] = direct_fits ? 1 : 0;
+    // The answer goes into the host-mapped page the host polls.  Eight lanes store the eight words with ONE instruction: a volatile
+    // store to that page is waited for before the next one is issued -- nine stores in a row by one thread were nine round trips
+    // over the host link at the tail of a kernel the whole round waits for.
+    if (t < 64) {
+        if (t < 8) {
+            const int v = t <= 1 ? n_hot_all
+                        : t == 2 ? ((s_stale != 0u ? 4 : 0) | (n_hot_all > 16318 ? 1 : 0) | (fits ? 0 : 2))
+                        : t == 3 ? total
+                        : t == 4 ? (int)s_flags
+                        : t == 5 ? n_touched
+                        : t == 6 ? (tfits && !direct_fits ? 1 : 0)
+                                 : (direct_fits ? 1 : 0);
+            info_out[t] = v;
+        }
         __threadfence_system();
-        info_out[15] = seq;
+        if (t == 0) info_out[15] = seq;
     }
 }
 

@@ -252,7 +252,9 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
     __syncthreads();
     if (publish != nullptr && s_last != 0u) {
         int n = (ref_n < 0 || ref_n > prop_cap) ? 0 : ref_n;
-        volatile int* const pref = reinterpret_cast<volatile int*>(publish + res_words);
+        // (ordinary stores, made visible by the fence below ahead of the one word the host polls: see vote_merge_kernel)
+        unsigned long long* const out = const_cast<unsigned long long*>(publish);
+        int* const pref = reinterpret_cast<int*>(out + res_words);
         if (threadIdx.x == 0) pref[0] = ref_n;
         for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) pref[1 + i] = ref_list[i];
         for (int i = (int)threadIdx.x; i < res_words; i += (int)blockDim.x) {
@@ -266,7 +268,7 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
                 if (i == 4) v = cand;
                 if (i == 5) v = ~cand;
             }
-            publish[i] = v;
+            out[i] = v;
         }
         __threadfence_system();
         __syncthreads();
@@ -475,22 +477,26 @@ __global__ __launch_bounds__(256) void vote_merge_kernel(const unsigned long lon
         }
     }
     differ = __syncthreads_or(differ);
-    volatile int* const pref = reinterpret_cast<volatile int*>(publish + res_words);
+    // (the answer block is written with ordinary stores -- a volatile store to the host-mapped page is waited for before the next
+    // one is issued, eleven round trips over the host link from one thread -- and made visible by the fence below, ahead of the
+    // one word the host polls)
+    unsigned long long* const out = const_cast<unsigned long long*>(publish);
+    int* const pref = reinterpret_cast<int*>(out + res_words);
     for (int i = (int)threadIdx.x; i < n; i += (int)blockDim.x) pref[1 + i] = lref[1 + i];
     if (threadIdx.x == 0) {
         const unsigned long long* lres = lead < 0 ? gathered : gathered + (long long)lead * seg_words;
         const bool ok = s_simple != 0 && differ == 0;
         pref[0] = s_overflow ? -1 : n;
-        publish[0] = lead < 0 ? 0ull : lres[0];
-        publish[1] = s_votes;
-        publish[2] = s_voters;
-        publish[3] = lead < 0 ? 0ull : (s_votes == s_voters ? 1ull : 2ull);
-        publish[4] = lead < 0 ? 0ull : lres[4];
-        publish[5] = lead < 0 ? ~0ull : lres[5];
-        publish[6] = 0ull;
-        publish[7] = s_votes;
-        publish[8] = s_err;
-        publish[9] = ok ? 1ull : 2ull;
+        out[0] = lead < 0 ? 0ull : lres[0];
+        out[1] = s_votes;
+        out[2] = s_voters;
+        out[3] = lead < 0 ? 0ull : (s_votes == s_voters ? 1ull : 2ull);
+        out[4] = lead < 0 ? 0ull : lres[4];
+        out[5] = lead < 0 ? ~0ull : lres[5];
+        out[6] = 0ull;
+        out[7] = s_votes;
+        out[8] = s_err;
+        out[9] = ok ? 1ull : 2ull;
     }
     __threadfence_system();
     __syncthreads();
