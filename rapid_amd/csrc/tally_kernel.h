@@ -234,8 +234,8 @@ __host__ __device__ inline int tally_dict_bytes(int mode, int n_nodes, int n_tou
 // slot -> node (read once per proposed node, when a receiver's proposal is written) stays in memory when a round has so
 // many hot subjects that the LDS is better spent on receivers: C5's ~15,000 hot subjects per round at N = 10^6
 // ... and so do the per-slot masks of the rings on which a hot observer watches the slot (read by cold windows, sweeps and the
-// choice of a witness, never by a fast window).  RAPID_SLOT_TABLES_LDS_MAX: the emulator builds a variant with 8, so that the
-// small populations of its tests run the tables-in-memory code.
+// choice of a witness, never by a fast window).  RAPID_SLOT_TABLES_LDS_MAX hot subjects is where a round goes over to the packed
+// detector state (tally_wants_packed), and the packed instantiations are the ones that read the per-slot tables from memory.
 #ifndef RAPID_SLOT_TABLES_LDS_MAX
 #define RAPID_SLOT_TABLES_LDS_MAX 4096
 #endif

@@ -1,9 +1,10 @@
 """The tally kernel's window size is a compile-time constant (RAPID_QUARTERS x 64 records, csrc/tally_kernel.h); the
 small populations of the emulated tests hold only a few hundred records per receiver, so the emulated kernel tests are
-re-run on builds with 64- and 128-record windows (every stream then spans many cold / fast / slow windows and carries) and
-on the sanitizer build, in a child process (the emulator library is chosen once per process).  `slotmem`: the per-slot tables
-(masks of the rings on which a hot observer watches a slot, slot -> node) read from memory -- the code of rounds with more than
-4,096 hot subjects -- at the emulator's population sizes."""
+re-run on builds with 64-, 128- and 192-record windows (every stream then spans many cold / fast / slow windows and carries)
+and on the sanitizer build, in a child process (the emulator library is chosen once per process).  (The per-slot tables --
+masks of the rings on which a hot observer watches a slot, slot -> node -- are read from memory by the instantiations with the
+packed detector state, the code of rounds with more than 4,096 hot subjects: tests/test_kernel_emulated.py runs those at the
+emulator's population sizes in every build.)"""
 import os
 import subprocess
 import sys
@@ -13,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("variant", ["q1", "q2", "slotmem", "ubsan"])
+@pytest.mark.parametrize("variant", ["q1", "q2", "q3", "ubsan"])
 def test_emulated_kernel_tests_on_variant(variant):
     env = {**os.environ, "RAPID_EMU_VARIANT": variant}
     # (the window-size variants change the tally kernel only: the index / vote / view kernel tests of that file run once, in
