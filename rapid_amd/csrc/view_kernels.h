@@ -382,7 +382,8 @@ __global__ void q4_check_kernel(const int* nodes, int n, const unsigned char* me
 // the configuration id itself.
 __global__ void config_id_kernel(const long long* ids_hi, const long long* ids_lo, int n_ids, const int* ring0,
                                  int n_members, const unsigned long long* hx_host0, const unsigned long long* hx_port0,
-                                 long long* out, unsigned long long* partial) {
+                                 long long* out, unsigned long long* partial, volatile unsigned int* seq_out = nullptr,
+                                 unsigned int seq = 0u) {
     RAPID_DYNAMIC_LDS(smem_raw);
     unsigned long long* sv = reinterpret_cast<unsigned long long*>(smem_raw);
     unsigned long long* sm = sv + blockDim.x;
@@ -424,6 +425,10 @@ __global__ void config_id_kernel(const long long* ids_hi, const long long* ids_l
     if (t == 0) {
         if (gridDim.x == 1) {
             out[0] = (long long)(1ull * sm[0] + sv[0]);
+            if (seq_out != nullptr) {  // `out` is in host-mapped memory and the host polls seq_out instead of waiting for the stream
+                __threadfence_system();
+                *seq_out = seq;
+            }
         } else {
             partial[2 * blockIdx.x] = sv[0];
             partial[2 * blockIdx.x + 1] = sm[0];
@@ -432,11 +437,16 @@ __global__ void config_id_kernel(const long long* ids_hi, const long long* ids_l
 }
 
 // the workgroups' (v, m) pairs, in order, applied to h = 1 (one wavefront; a few hundred pairs)
-__global__ void config_id_final_kernel(const unsigned long long* partial, int n_pairs, long long* out) {
+__global__ void config_id_final_kernel(const unsigned long long* partial, int n_pairs, long long* out, volatile unsigned int* seq_out = nullptr,
+                                       unsigned int seq = 0u) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     unsigned long long h = 1ull;
     for (int i = 0; i < n_pairs; ++i) h = h * partial[2 * i + 1] + partial[2 * i];
     out[0] = (long long)h;
+    if (seq_out != nullptr) {  // (see config_id_kernel)
+        __threadfence_system();
+        *seq_out = seq;
+    }
 }
 
 }  // namespace rapid
