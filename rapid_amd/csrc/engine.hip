@@ -107,6 +107,11 @@ struct rapid_engine {
     DevBuf<int> d_seg_off;                       // [K + 1] ring boundaries inside the [K][M] sort buffers
     std::vector<int> seg_host;                   // its host copy (lives as long as the async upload needs it)
     std::vector<uint8_t> ring_member;            // member flags the device rings were built from (empty: no rings yet)
+    // nodes whose member flag was set or cleared since then (a superset, repeats allowed), as long as changed_valid: a view change
+    // then costs the host what the change is, not a walk over the whole registry (10^6 nodes: 1 ms of a 2.4 ms view change)
+    std::vector<int> changed;
+    bool changed_valid = false;
+    DevBuf<int> d_gone;                          // the nodes that left, for the kernels of a view change
     int ring_m = 0;                              // their length
     int n_ids_dev = 0;
 
@@ -348,6 +353,7 @@ int presize_view(rapid_engine* h) {
     HIPCHK(h, h->d_q4_rows.ensure(km));
     HIPCHK(h, h->d_q4_valid.ensure(N));
     HIPCHK(h, h->d_q4_nodes.ensure(N));
+    HIPCHK(h, h->d_gone.ensure(N));
     {
         // member flags (N) | nodes that left (4 N) | nodes that came (4 N) | members, for a sort from scratch (4 N) | new NodeIds (16 N)
         const size_t need = ((size_t)29 * N + 64 + 4095) & ~(size_t)4095;
@@ -389,15 +395,28 @@ int rebuild_view(rapid_engine* h) {
     const bool have_rings = h->ring_m > 0 && h->ring_member.size() == (size_t)N;
     std::vector<int> joiners, gone;
     int removed = 0, M = 0;
-    for (int n = 0; n < N; ++n) {
-        const bool now = h->member[(size_t)n] != 0;
-        M += now ? 1 : 0;
-        if (have_rings) {
-            const bool was = h->ring_member[(size_t)n] != 0;
+    const bool by_list = have_rings && h->changed_valid;  // (the device's member flags are then the ones the rings were built from)
+    if (by_list) {
+        std::sort(h->changed.begin(), h->changed.end());
+        h->changed.erase(std::unique(h->changed.begin(), h->changed.end()), h->changed.end());
+        for (const int n : h->changed) {  // ascending, like the walk below
+            const bool now = h->member[(size_t)n] != 0, was = h->ring_member[(size_t)n] != 0;
             if (now && !was) joiners.push_back(n);
-            if (was && !now) {
-                ++removed;
-                gone.push_back(n);
+            if (was && !now) gone.push_back(n);
+        }
+        removed = (int)gone.size();
+        M = h->ring_m - removed + (int)joiners.size();
+    } else {
+        for (int n = 0; n < N; ++n) {
+            const bool now = h->member[(size_t)n] != 0;
+            M += now ? 1 : 0;
+            if (have_rings) {
+                const bool was = h->ring_member[(size_t)n] != 0;
+                if (now && !was) joiners.push_back(n);
+                if (was && !now) {
+                    ++removed;
+                    gone.push_back(n);
+                }
             }
         }
     }
@@ -416,24 +435,35 @@ int rebuild_view(rapid_engine* h) {
     long long* const stage_ids = reinterpret_cast<long long*>(stage_members + N);
     std::memcpy(stage_gone, gone.data(), sizeof(int) * gone.size());
     std::memcpy(stage_join, joiners.data(), sizeof(int) * joiners.size());
-    auto q4_drop = [&](const int* staged, size_t m, int self) -> int {
+    auto q4_drop = [&](const int* d_nodes, size_t m, int self) -> int {
         if (m == 0 || !h->d_subj.p || !h->d_pos.p || !h->d_q4_valid.p) return RAPID_OK;
-        HIPCHK(h, h->d_q4_nodes.ensure(m));
-        HIPCHK(h, hipMemcpyAsync(h->d_q4_nodes.p, staged, sizeof(int) * m, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(rapid::q4_invalidate_kernel, dim3(grid_for((long long)m * K, 256)), dim3(256), 0, st, h->d_subj.p, h->d_pos.p, h->d_q4_nodes.p,
+        hipLaunchKernelGGL(rapid::q4_invalidate_kernel, dim3(grid_for((long long)m * K, 256)), dim3(256), 0, st, h->d_subj.p, h->d_pos.p, d_nodes,
                            (int)m, N, K, h->d_q4_valid.p, self);
         return RAPID_OK;
     };
+    const int J = (int)joiners.size();
     if (have_rings && !gone.empty()) {
-        int rc = q4_drop(stage_gone, gone.size(), 1);  // (:181-195)
+        HIPCHK(h, h->d_gone.ensure(gone.size()));
+        HIPCHK(h, hipMemcpyAsync(h->d_gone.p, stage_gone, sizeof(int) * gone.size(), hipMemcpyHostToDevice, st));
+        int rc = q4_drop(h->d_gone.p, gone.size(), 1);  // (:181-195)
         if (rc) return rc;
+    }
+    if (have_rings && J > 0) {
+        HIPCHK(h, h->d_joiners.ensure((size_t)J));
+        HIPCHK(h, hipMemcpyAsync(h->d_joiners.p, stage_join, sizeof(int) * (size_t)J, hipMemcpyHostToDevice, st));
     }
     h->n_members = M;
     lap("host scan + q4");
 
     HIPCHK(h, h->d_member.ensure((size_t)N));
-    std::memcpy(stage_member, h->member.data(), (size_t)N);
-    HIPCHK(h, hipMemcpyAsync(h->d_member.p, stage_member, (size_t)N, hipMemcpyHostToDevice, st));
+    if (by_list) {  // the flags on the device are patched where they changed
+        if (removed > 0 || J > 0)
+            hipLaunchKernelGGL(rapid::member_patch_kernel, dim3(grid_for((long long)std::max(removed, J), 256)), dim3(256), 0, st, h->d_member.p,
+                               removed > 0 ? h->d_gone.p : (const int*)nullptr, removed, J > 0 ? h->d_joiners.p : (const int*)nullptr, J);
+    } else {
+        std::memcpy(stage_member, h->member.data(), (size_t)N);
+        HIPCHK(h, hipMemcpyAsync(h->d_member.p, stage_member, (size_t)N, hipMemcpyHostToDevice, st));
+    }
     const size_t km = (size_t)K * (size_t)std::max(M, 1);
     HIPCHK(h, h->d_sort_keys.ensure(km));  // (DevBuf::ensure does not keep contents: the rings themselves are only grown where
     HIPCHK(h, h->d_sort_vals.ensure(km));  //  they are about to be written from scratch)
@@ -442,7 +472,6 @@ int rebuild_view(rapid_engine* h) {
     HIPCHK(h, h->d_subj.ensure((size_t)K * N));
     HIPCHK(h, h->d_cfg_out.ensure(1));
 
-    const int J = (int)joiners.size();
     // incremental while the change is small against the view (a decided cut); a view that is mostly new is sorted afresh
     const bool incremental = have_rings && M > 0 && (long long)J * 4 <= (long long)h->ring_m && (h->force_exact & 16384) == 0;
     if (incremental && (removed > 0 || J > 0)) {
@@ -456,12 +485,10 @@ int rebuild_view(rapid_engine* h) {
                            h->d_member.p, h->d_chunk_kept.p);
         if (J > 0) {
             const size_t kj = (size_t)K * J;
-            HIPCHK(h, h->d_joiners.ensure((size_t)J));
             HIPCHK(h, h->d_join_keys.ensure(kj));
             HIPCHK(h, h->d_join_skeys.ensure(kj));
             HIPCHK(h, h->d_join_vals.ensure(kj));
             HIPCHK(h, h->d_join_nodes.ensure(kj));
-            HIPCHK(h, hipMemcpyAsync(h->d_joiners.p, stage_join, sizeof(int) * (size_t)J, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(rapid::ring_gather_kernel, dim3(grid_for((long long)kj, 256)), dim3(256), 0, st, h->d_keys.p, h->d_joiners.p, J, N, K,
                                h->d_join_keys.p, h->d_join_vals.p);
             int rc = sort_rings(h, h->d_join_keys.p, h->d_join_skeys.p, h->d_join_vals.p, h->d_join_nodes.p, J);
@@ -497,7 +524,7 @@ int rebuild_view(rapid_engine* h) {
 
     lap("tables");
     if (have_rings && !joiners.empty()) {  // ringAdd drops the entries of the joiner's new ring predecessors (:143-152)
-        int rc = q4_drop(stage_join, joiners.size(), 0);
+        int rc = q4_drop(h->d_joiners.p, joiners.size(), 0);
         if (rc) return rc;
     }
 
@@ -550,7 +577,14 @@ int rebuild_view(rapid_engine* h) {
     std::memcpy(&cfg, h->h_mail + 32, 8);
     lap("configuration id");
     h->config_id = cfg;
-    h->ring_member = h->member;
+    if (by_list) {
+        for (const int n : gone) h->ring_member[(size_t)n] = 0;
+        for (const int n : joiners) h->ring_member[(size_t)n] = 1;
+    } else {
+        h->ring_member = h->member;
+    }
+    h->changed.clear();
+    h->changed_valid = true;
     h->ring_m = M;
     h->host_tables_valid = false;
     h->tallied = false;
@@ -1034,6 +1068,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_gen_res.release(); h->d_gen_keep.release(); h->d_gen_boff.release(); h->d_gen_rx.release();
     h->d_ids_hi2.release(); h->d_ids_lo2.release(); h->d_ids_new.release(); h->d_cfg_partial.release(); h->d_chunk_kept.release();
     h->d_bitmaps.release();
+    h->d_gone.release();
     h->d_joiners.release(); h->d_join_nodes.release(); h->d_join_vals.release(); h->d_join_keys.release(); h->d_join_skeys.release();
     h->d_records_own.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
@@ -1114,6 +1149,8 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
     h->view_built = true;
     h->streams_loaded = false;
     h->ring_member.clear();  // new endpoints, new ring keys: nothing to compact from
+    h->changed.clear();
+    h->changed_valid = false;
     h->ring_m = 0;
     return rebuild_view(h);
 }
@@ -1175,6 +1212,8 @@ int rapid_view_register_endpoints(rapid_engine* h, const uint8_t* hostnames, con
     }
     h->host_tables_valid = false;
     h->ring_member.clear();
+    h->changed.clear();
+    h->changed_valid = false;
     h->ring_m = 0;
     return rebuild_view(h);  // loaded streams stay loaded (their indices are still valid); the per-round index is rebuilt
 }
@@ -1201,6 +1240,7 @@ int rapid_view_ring_add(rapid_engine* h, int32_t node, int64_t id_hi, int64_t id
     if (seen) return fail(h, RAPID_EUUID_SEEN, "identifier of node %d already seen", node);  // :127-129
     if (h->member[(size_t)node]) return fail(h, RAPID_ENODE_EXISTS, "node %d already in ring", node);          // :133-135
     h->member[(size_t)node] = 1;
+    h->changed.push_back(node);
     h->id_hi[(size_t)node] = id_hi;
     h->id_lo[(size_t)node] = id_lo;
     h->ids_pending.push_back(id);
@@ -1213,6 +1253,7 @@ int rapid_view_ring_delete(rapid_engine* h, int32_t node) {
     if ((rc = use_device(h))) return rc;
     if (!h->member[(size_t)node]) return fail(h, RAPID_ENODE_MISSING, "node %d not in ring", node);  // :172-174
     h->member[(size_t)node] = 0;  // identifiersSeen is never pruned (:167-201)
+    h->changed.push_back(node);
     return rebuild_view(h);
 }
 
@@ -2090,26 +2131,36 @@ int rapid_apply_cut(rapid_engine* h, const int32_t* cut, int32_t n, int64_t* new
     if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
     int rc = use_device(h);
     if (rc) return rc;
-    // validate first so that a failing call leaves the view untouched
-    std::vector<uint8_t> mem = h->member;
+    // A failing call leaves the view untouched: the flags are set / cleared in place -- the cost of the call is the cut's, not the
+    // registry's -- and put back if the cut does not validate
+    for (int i = 0; i < n; ++i)
+        if (cut[i] < 0 || cut[i] >= h->n_nodes) return fail(h, RAPID_EINVAL, "node index %d out of range", cut[i]);
     std::vector<std::pair<int64_t, int64_t>> added;
     for (int i = 0; i < n; ++i) {
         const int node = cut[i];
-        if (node < 0 || node >= h->n_nodes) return fail(h, RAPID_EINVAL, "node index %d out of range", node);
-        if (mem[(size_t)node]) {
-            mem[(size_t)node] = 0;  // ringDelete (R/MembershipService.java:399-400)
+        if (h->member[(size_t)node]) {
+            h->member[(size_t)node] = 0;  // ringDelete (R/MembershipService.java:399-400)
         } else {
             added.push_back({h->id_hi[(size_t)node], h->id_lo[(size_t)node]});
-            mem[(size_t)node] = 1;  // ringAdd (R/MembershipService.java:404-407)
+            h->member[(size_t)node] = 1;  // ringAdd (R/MembershipService.java:404-407)
         }
     }
+    auto undo = [&]() {  // (in reverse: a node named twice goes back through both of its states)
+        for (int i = n - 1; i >= 0; --i) h->member[(size_t)cut[i]] ^= 1;
+    };
     if (!added.empty()) {  // ringAdd :127-129: an identifier seen before -- in an earlier configuration, or earlier in this cut
         std::sort(added.begin(), added.end());
         bool seen = std::adjacent_find(added.begin(), added.end()) != added.end();
-        if (!seen && (rc = ids_seen_any(h, added, &seen))) return rc;
-        if (seen) return fail(h, RAPID_EUUID_SEEN, "the identifier of a joiner in the cut was already seen");
+        if (!seen && (rc = ids_seen_any(h, added, &seen))) {
+            undo();
+            return rc;
+        }
+        if (seen) {
+            undo();
+            return fail(h, RAPID_EUUID_SEEN, "the identifier of a joiner in the cut was already seen");
+        }
     }
-    h->member.swap(mem);
+    h->changed.insert(h->changed.end(), cut, cut + n);
     h->ids_pending.insert(h->ids_pending.end(), added.begin(), added.end());
     rc = rebuild_view(h);  // new rings, tables, configuration id; cutDetection.clear() == fresh state next tally
     if (rc) return rc;

@@ -372,6 +372,14 @@ __global__ void q4_check_kernel(const int* nodes, int n, const unsigned char* me
     flag[i] = differs ? 1 : 0;
 }
 
+// A view change's member flags, patched where they changed (the nodes that left: 0, the nodes that came: 1) -- the flags on the
+// device are the ones the rings were built from, and the change is a few thousand nodes of a million.
+__global__ void member_patch_kernel(unsigned char* member, const int* gone, int n_gone, const int* joined, int n_joined) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < n_gone) member[gone[i]] = 0;
+    if (i < n_joined) member[joined[i]] = 1;
+}
+
 // ---- configuration id -------------------------------------------------------------------------------------------
 // hash = 1; for id in sorted ids: hash = hash*37 + xx0(high); hash = hash*37 + xx0(low);
 //           for ep in ring 0:     hash = hash*37 + xx0(hostname); hash = hash*37 + xx0(port)
