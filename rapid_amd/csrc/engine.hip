@@ -435,17 +435,19 @@ int rebuild_view(rapid_engine* h) {
     long long* const stage_ids = reinterpret_cast<long long*>(stage_members + N);
     std::memcpy(stage_gone, gone.data(), sizeof(int) * gone.size());
     std::memcpy(stage_join, joiners.data(), sizeof(int) * joiners.size());
-    auto q4_drop = [&](const int* d_nodes, size_t m, int self) -> int {
+    bool gone_cleared = false;  // the member flags of the nodes that left were cleared by the kernel that drops their memo entries
+    auto q4_drop = [&](const int* d_nodes, size_t m, int self, bool clear_members) -> int {
         if (m == 0 || !h->d_subj.p || !h->d_pos.p || !h->d_q4_valid.p) return RAPID_OK;
         hipLaunchKernelGGL(rapid::q4_invalidate_kernel, dim3(grid_for((long long)m * K, 256)), dim3(256), 0, st, h->d_subj.p, h->d_pos.p, d_nodes,
-                           (int)m, N, K, h->d_q4_valid.p, self);
+                           (int)m, N, K, h->d_q4_valid.p, self, clear_members ? h->d_member.p : (unsigned char*)nullptr);
+        gone_cleared = gone_cleared || clear_members;
         return RAPID_OK;
     };
     const int J = (int)joiners.size();
     if (have_rings && !gone.empty()) {
         HIPCHK(h, h->d_gone.ensure(gone.size()));
         HIPCHK(h, hipMemcpyAsync(h->d_gone.p, stage_gone, sizeof(int) * gone.size(), hipMemcpyHostToDevice, st));
-        int rc = q4_drop(h->d_gone.p, gone.size(), 1);  // (:181-195)
+        int rc = q4_drop(h->d_gone.p, gone.size(), 1, by_list && h->d_member.p != nullptr);  // (:181-195)
         if (rc) return rc;
     }
     if (have_rings && J > 0) {
@@ -457,9 +459,10 @@ int rebuild_view(rapid_engine* h) {
 
     HIPCHK(h, h->d_member.ensure((size_t)N));
     if (by_list) {  // the flags on the device are patched where they changed
-        if (removed > 0 || J > 0)
-            hipLaunchKernelGGL(rapid::member_patch_kernel, dim3(grid_for((long long)std::max(removed, J), 256)), dim3(256), 0, st, h->d_member.p,
-                               removed > 0 ? h->d_gone.p : (const int*)nullptr, removed, J > 0 ? h->d_joiners.p : (const int*)nullptr, J);
+        const int n_clear = gone_cleared ? 0 : removed;
+        if (n_clear > 0 || J > 0)
+            hipLaunchKernelGGL(rapid::member_patch_kernel, dim3(grid_for((long long)std::max(n_clear, J), 256)), dim3(256), 0, st, h->d_member.p,
+                               n_clear > 0 ? h->d_gone.p : (const int*)nullptr, n_clear, J > 0 ? h->d_joiners.p : (const int*)nullptr, J);
     } else {
         std::memcpy(stage_member, h->member.data(), (size_t)N);
         HIPCHK(h, hipMemcpyAsync(h->d_member.p, stage_member, (size_t)N, hipMemcpyHostToDevice, st));
@@ -524,7 +527,7 @@ int rebuild_view(rapid_engine* h) {
 
     lap("tables");
     if (have_rings && !joiners.empty()) {  // ringAdd drops the entries of the joiner's new ring predecessors (:143-152)
-        int rc = q4_drop(h->d_joiners.p, joiners.size(), 0);
+        int rc = q4_drop(h->d_joiners.p, joiners.size(), 0, false);
         if (rc) return rc;
     }
 
@@ -559,6 +562,8 @@ int rebuild_view(rapid_engine* h) {
     {
         const int T = 1024;
         const long long total = 2ll * h->n_ids_dev + 2ll * M;
+        // (one workgroup for everything was tried for small views -- one launch instead of two -- and is slower: forty dependent
+        // hashes per thread against ten)
         const int G = (int)std::max<long long>(1, std::min<long long>(512, total / 8192));
         HIPCHK(h, h->d_cfg_partial.ensure((size_t)2 * G));
         // The configuration id is written straight into the host-mapped page (bytes 32..39, sequence word 10) by whichever kernel

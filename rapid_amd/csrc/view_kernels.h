@@ -342,11 +342,15 @@ __global__ void gather_lower_kernel(const int* subj, const int* pos, const int* 
 // The memoised observers of the reference (Q4; index_kernels.h reads them for hot members): valid[node] = 0 for what
 // ringAdd / ringDelete of nodes[i] drop -- the node's ring predecessors WITHOUT wrap-around (TreeSet.lower) and, self != 0, the
 // node's own entry (R/MembershipView.java:143-152, 181-195).  subj / pos: the tables of the view the predecessors are taken from.
-__global__ void q4_invalidate_kernel(const int* subj, const int* pos, const int* nodes, int n, int n_nodes, int K, unsigned char* valid, int self) {
+// member_clear != nullptr: nodes[] are the nodes that leave in this view change, and their member flags on the device are cleared
+// on the way (what member_patch_kernel would do in a launch of its own).
+__global__ void q4_invalidate_kernel(const int* subj, const int* pos, const int* nodes, int n, int n_nodes, int K, unsigned char* valid, int self,
+                                     unsigned char* member_clear = nullptr) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)n * K) return;
     const int i = (int)(t / K), k = (int)(t - (long long)i * K);
     const int node = nodes[i];
+    if (member_clear != nullptr && k == 0) member_clear[node] = 0;
     if (self != 0 && k == 0) valid[node] = 0;
     if (pos[(long long)k * n_nodes + node] > 0) {
         const int pred = subj[(long long)node * K + k];
