@@ -1158,6 +1158,18 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
                     so[q] = k.entry >> 16;
                     wdiff = min(wdiff, so[q] ^ witness_so);
                     nbv += (raw >> 24) & 1u;
+                    // measurement builds only (profiles/r04_ab_sensitivity_c3b.txt): work ADDED to the fast window, results unchanged
+#ifdef RAPID_PROBE_DUP_LOOKUP  // a second gather per record
+                    sink ^= lookup(cw.w3[q] ^ 1u).entry;
+#endif
+#ifdef RAPID_PROBE_VALU_N  // 3 N more dependent vector instructions per quarter
+                    {
+                        unsigned int x_ = raw;
+#pragma unroll
+                        for (int i_ = 0; i_ < RAPID_PROBE_VALU_N; ++i_) x_ = (x_ ^ (x_ >> 7)) + 0x9E3779B9u;
+                        sink ^= x_;
+                    }
+#endif
                 }
                 mEl = wave_ballot((cw.w4[kQ - 1] & 0x01000000u) != 0u);
             } else {
@@ -1213,6 +1225,10 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
 #pragma unroll
             for (int q = 0; q < kQ - 1; ++q) d.fast_or(so[q], w[q]);
             d.fast_or(so[kQ - 1], inl ? w[kQ - 1] : 0u);
+#ifdef RAPID_PROBE_DUP_OR  // measurement builds only: a second OR per record, into this lane's dummy slot (results unchanged)
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) d.fast_or(2u * my_dummy, w[q] ^ (so[q] & 1u));
+#endif
 #endif
             vbatch += nbv;
             carry_so = so[kQ - 1];
