@@ -612,6 +612,10 @@ int ensure_host_tables(rapid_engine* h) {
     HIPCHK(h, hipMemcpyAsync(h->h_keys.data(), h->d_keys.p, sizeof(long long) * K * N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->host_tables_valid = true;
+    if (!h->host_keys0_valid) {  // (the ring-0 keys came along: no copy of their own later)
+        h->h_keys0.assign(h->h_keys.begin(), h->h_keys.begin() + N);
+        h->host_keys0_valid = true;
+    }
     return RAPID_OK;
 }
 
