@@ -112,6 +112,7 @@ struct rapid_engine {
     std::vector<int> changed;
     bool changed_valid = false;
     DevBuf<int> d_gone;                          // the nodes that left, for the kernels of a view change
+    DevBuf<unsigned short> d_edges, d_edge_mask; // index_edges_kernel: every hot slot's observer slots and ring mask (large populations)
     int ring_m = 0;                              // their length
     int n_ids_dev = 0;
 
@@ -764,6 +765,12 @@ int build_round_index(rapid_engine* h) {
         hipLaunchKernelGGL(rapid::index_count_kernel, dim3((unsigned)n_chunks), dim3(1024), 0, st, d_gmask, N, L, h->d_idxblk.p);
         hipLaunchKernelGGL(rapid::index_assign_kernel, dim3((unsigned)n_chunks), dim3(1024), 0, st, d_gmask, h->d_member.p, N, L,
                            h->d_idxblk.p, h->d_dict.p, h->d_decl.p, h->d_node_of_slot.p, h->d_tbits.p, h->d_trank.p, h->d_tent.p, tent_cap);
+        // the hot adjacency slot by slot, one thread each (and the work area cleared by many workgroups instead of one)
+        HIPCHK(h, h->d_edges.ensure((size_t)16384 * rapid::kIndexEdgeStride));
+        HIPCHK(h, h->d_edge_mask.ensure(16384));
+        hipLaunchKernelGGL(rapid::index_edges_kernel, dim3(64), dim3(256), 0, st, h->d_idxblk.p, n_chunks, h->d_node_of_slot.p, h->d_member.p, h->d_obs.p,
+                           N, K, h->d_dict.p, h->q4_emulate ? h->d_q4_rows.p : (int*)nullptr, h->q4_emulate ? h->d_q4_valid.p : (unsigned char*)nullptr,
+                           h->d_edges.p, h->d_edge_mask.p, d_info, d_gmask);
     }
     hipLaunchKernelGGL(rapid::index_build_block_kernel, dim3(1), dim3(1024), 0, st, d_gmask, h->d_member.p, h->d_obs.p, N, K, L,
                        h->d_dict.p, h->d_decl.p, h->d_node_of_slot.p, h->d_adj_off.p, h->d_adj.p, adj_cap, h->d_tbits.p, h->d_trank.p,
@@ -771,7 +778,8 @@ int build_round_index(rapid_engine* h) {
                        ((h->force_exact & (128 | 256 | 8192)) != 0 || chunked) ? -1 : 160 * 1024 - rapid::kBlockStatsBytes,  // (lds_max below)
                        h->d_stats.p, (int)stats_words(h), h->d_errflags.p, (int)++h->mail_seq,
                        chunked ? h->d_idxblk.p : nullptr, n_chunks, h->q4_emulate ? h->d_q4_rows.p : (int*)nullptr,
-                       h->q4_emulate ? h->d_q4_valid.p : (unsigned char*)nullptr);
+                       h->q4_emulate ? h->d_q4_valid.p : (unsigned char*)nullptr, chunked ? h->d_edges.p : (const unsigned short*)nullptr,
+                       chunked ? h->d_edge_mask.p : (const unsigned short*)nullptr);
     }
     if (timed) HIPCHK(h, hipEventRecord(h->ev_idx1, st));
     HIPCHK(h, hipGetLastError());
@@ -1078,6 +1086,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_ids_hi2.release(); h->d_ids_lo2.release(); h->d_ids_new.release(); h->d_cfg_partial.release(); h->d_chunk_kept.release();
     h->d_bitmaps.release();
     h->d_gone.release();
+    h->d_edges.release(); h->d_edge_mask.release();
     h->d_joiners.release(); h->d_join_nodes.release(); h->d_join_vals.release(); h->d_join_keys.release(); h->d_join_skeys.release();
     h->d_records_own.release(); h->d_rec_off_own.release(); h->d_emit.release(); h->d_nprop.release();
     h->d_pcount.release(); h->d_props.release(); h->d_fp.release(); h->d_stats.release();
@@ -1991,11 +2000,12 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
                                    h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
             // (published "to" the block itself: the last workgroup completes res[] and, from_tally, copies the list into ref[])
             const bool by_bits = from_tally && h->tally_bitmaps_valid && (h->force_exact & 262144) == 0;  // (the voters' bitmaps of the same launch: 64 bytes per receiver instead of a list)
-            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * (by_bits ? 1 : 64), 1024))), dim3(1024), 0, st,
+            const int bits_wave = by_bits && h->bitmap_words > 16 ? 1 : 0;  // (bitmaps of more than 128 bytes: a wave per receiver)
+            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * (by_bits && !bits_wave ? 1 : 64), 1024))), dim3(1024), 0, st,
                                h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, d_res,
                                (int)res_words, reinterpret_cast<unsigned int*>(d_res + 9), reinterpret_cast<volatile unsigned long long*>(d_res),
                                nullptr, 0u, from_tally ? 1 : 0, h->d_errflags.p, by_bits ? h->d_bitmaps.p : (const unsigned long long*)nullptr,
-                               h->bitmap_words);
+                               h->bitmap_words, bits_wave);
             NCCLCHK(h, ncclAllGather(d_res, h->d_gather.p, seg_words, ncclUint64, h->comm, st));  // the round's one collective
             hipLaunchKernelGGL(rapid::vote_merge_kernel, dim3(1), dim3(256), 0, st, h->d_gather.p, h->n_ranks, (int)seg_words,
                                (int)res_words, h->max_cut, (long long)out->quorum, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
@@ -2017,12 +2027,13 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
                                    h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
             from_tally_used = from_tally;
             const bool by_bits = from_tally && h->tally_bitmaps_valid && (h->force_exact & 262144) == 0;  // (the voters' bitmaps of the same launch: 64 bytes per receiver instead of a list)
-            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * (by_bits ? 1 : 64), 1024))), dim3(1024), 0, st,
+            const int bits_wave = by_bits && h->bitmap_words > 16 ? 1 : 0;  // (bitmaps of more than 128 bytes: a wave per receiver)
+            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * (by_bits && !bits_wave ? 1 : 64), 1024))), dim3(1024), 0, st,
                                h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, d_res,
                                (int)res_words, reinterpret_cast<unsigned int*>(d_res + 9),
                                reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
                                reinterpret_cast<volatile unsigned int*>(h->d_mail) + 14, ++h->mail_seq, from_tally ? 1 : 0,
-                               h->d_errflags.p, by_bits ? h->d_bitmaps.p : (const unsigned long long*)nullptr, h->bitmap_words);
+                               h->d_errflags.p, by_bits ? h->d_bitmaps.p : (const unsigned long long*)nullptr, h->bitmap_words, bits_wave);
         } else {
             HIPCHK(h, hipMemsetAsync(h->d_hist.p, 0, HB * 8, st));
             HIPCHK(h, hipMemsetAsync(h->d_mm.p, 0, 64, st));

@@ -196,6 +196,64 @@ __global__ __launch_bounds__(1024) void index_assign_kernel(const unsigned int* 
 }
 
 
+// The hot adjacency of a LARGE population (the form of index_count_kernel / index_assign_kernel), slot by slot and in parallel: one
+// thread per hot slot works out which of its K observers are hot (today's row or the memo of quirk Q4 -> the observers'
+// dictionary entries: three dependent, scattered reads per slot into tables of tens of megabytes) and leaves the K observer
+// slots and their ring mask where index_build_block_kernel only has to count and lay them down.  As the single workgroup's own
+// work -- fifteen slots per thread, one after the other, twice -- this chain was 0.89 ms of a 2.7 ms round at 10^6 nodes and
+// 15,000 hot subjects.  The launch also clears the touch pass's work area (nobody reads it after index_assign_kernel), 4 MB
+// that the single workgroup used to clear at its end.
+constexpr int kIndexEdgeStride = 14;  // RAPID_MAX_K observer slots per hot slot
+__global__ __launch_bounds__(256) void index_edges_kernel(const int* blk_counts, int n_chunks, const int* node_of_slot, const unsigned char* member,
+                                                          const int* obs, int n_nodes, int K, const unsigned short* dict, int* q4_rows,
+                                                          unsigned char* q4_valid, unsigned short* edges, unsigned short* edge_mask, int* info,
+                                                          unsigned int* gmask) {
+    __shared__ int s_hot;
+    if (threadIdx.x == 0) s_hot = 0;
+    __syncthreads();
+    for (int b = (int)threadIdx.x; b < n_chunks; b += (int)blockDim.x) atomicAdd(&s_hot, blk_counts[2 * b]);
+    __syncthreads();
+    const int n_hot = min(s_hot, 16318);
+    const long long gsz = (long long)gridDim.x * blockDim.x, gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long n = gid; n < n_nodes; n += gsz) gmask[n] = 0u;
+    const int e = (int)gid;
+    if (e >= n_hot) return;
+    const int node = node_of_slot[e];
+    const bool use_memo = q4_valid != nullptr && member[node] != 0;
+    const bool have = use_memo && q4_valid[node] != 0;
+    const int* const today = obs + (long long)node * K;
+    int* const memo = q4_rows + (long long)node * K;
+    int o[kIndexEdgeStride], td[kIndexEdgeStride];
+    bool stale = false;
+#pragma unroll
+    for (int k = 0; k < kIndexEdgeStride; ++k) td[k] = k < K ? today[k] : -1;
+    if (have) {
+#pragma unroll
+        for (int k = 0; k < kIndexEdgeStride; ++k) {
+            o[k] = k < K ? memo[k] : -1;
+            stale = stale || o[k] != td[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kIndexEdgeStride; ++k) o[k] = td[k];
+        if (use_memo) {  // the first time this member is hot since its entry was dropped (one slot, one thread)
+#pragma unroll
+            for (int k = 0; k < kIndexEdgeStride; ++k)
+                if (k < K) memo[k] = td[k];
+            q4_valid[node] = 1;
+        }
+    }
+    unsigned int am = 0u;
+#pragma unroll
+    for (int k = 0; k < kIndexEdgeStride; ++k) {
+        const unsigned int eo = (o[k] >= 0 && o[k] < n_nodes) ? ((unsigned int)dict[o[k]] & 0x3FFFu) : 0x3FFFu;
+        edges[(long long)e * kIndexEdgeStride + k] = (unsigned short)eo;
+        am |= (int)eo < n_hot ? 1u << k : 0u;
+    }
+    edge_mask[e] = (unsigned short)am;
+    if (stale) atomicOr(reinterpret_cast<unsigned int*>(&info[2]), 4u);  // (see index_build_block_kernel)
+}
+
 // The whole index after the touch pass in ONE workgroup (the round's hot set is a few hundred to a few thousand
 // subjects): slot numbering + dictionary + declared masks, then the hot adjacency.  One launch and one read-back of
 // info[] instead of six launches and two synchronisations, and no atomics: the list of a hot slot e is built by the
@@ -213,7 +271,10 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
                                                                  volatile int* info_out, int direct_budget,
                                                                  unsigned long long* zero_words, int n_zero_words,
                                                                  unsigned int* zero_flags, int seq, const int* blk_counts,
-                                                                 int n_chunks, int* q4_rows, unsigned char* q4_valid) {
+                                                                 int n_chunks, int* q4_rows, unsigned char* q4_valid,
+                                                                 const unsigned short* edges = nullptr, const unsigned short* edge_mask = nullptr) {
+    // edges != nullptr (with blk_counts): index_edges_kernel has worked out every hot slot's observer slots and ring mask (and
+    // cleared the work area): what is left here is to count them and lay the triples down
     __shared__ int s_wave[16];
     __shared__ int s_pre_hot, s_pre_touched;
     __shared__ int s_pub[8];  // the answer on its way to the host-mapped page
@@ -338,6 +399,10 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
         return am;
     };
     for (int e = b2; e < e2; ++e) {
+        if (edges != nullptr) {
+            mine += __popc((unsigned int)edge_mask[e]);
+            continue;
+        }
         unsigned int eo[kKMax];
         mine += __popc(slot_edges(e, eo));
     }
@@ -347,7 +412,14 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     const bool fits = total <= 65535 && total <= adj_cap;
     for (int e = b2; e < e2; ++e) {
         unsigned int eo[kKMax];
-        const unsigned int am = slot_edges(e, eo);
+        unsigned int am;
+        if (edges != nullptr) {
+            am = (unsigned int)edge_mask[e];
+#pragma unroll
+            for (int k = 0; k < kKMax; ++k) eo[k] = (unsigned int)edges[(long long)e * kIndexEdgeStride + k];
+        } else {
+            am = slot_edges(e, eo);
+        }
 #pragma unroll
         for (int k = 0; k < kKMax; ++k) {
             if ((am >> k) & 1u) {
@@ -428,8 +500,10 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
         if (t == 0) info_out[15] = seq;
     }
     // leave the work area as the next round's touch pass needs it (all zero): nobody reads gmask[] / info[] after this point
+    // (index_edges_kernel has cleared gmask[] already where it ran: 4 MB at 10^6 nodes are not one workgroup's job)
     __syncthreads();
-    for (int n = t; n < n_nodes; n += T) gmask[n] = 0u;
+    if (edges == nullptr)
+        for (int n = t; n < n_nodes; n += T) gmask[n] = 0u;
     if (t < 8) info[t] = 0;
 }
 

@@ -148,7 +148,10 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
                                    unsigned long long* mismatch, const unsigned long long* res, int res_words,
                                    unsigned int* done, volatile unsigned long long* publish, volatile unsigned int* seq_out,
                                    unsigned int seq, int rep_in_res, const unsigned int* tally_errors,
-                                   const unsigned long long* bits = nullptr, int bits_words = 0) {
+                                   const unsigned long long* bits = nullptr, int bits_words = 0, int bits_wave = 0) {
+    // bits_wave != 0 (rounds with thousands of hot slots: bitmaps of kilobytes): a WAVE per receiver walks the bitmap, 512
+    // bytes at a time (launch ceil(R * 64 / block) workgroups) -- one thread per receiver put all of a 10^6-node round's 1,024
+    // bitmaps of 1.9 KB through one workgroup: 0.2 ms
     __shared__ unsigned int s_bad, s_seen, s_last;
     if (threadIdx.x == 0) {
         s_bad = 0u;
@@ -157,8 +160,9 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
     }
     __syncthreads();
     const bool by_bits = bits != nullptr && rep_in_res != 0;
-    const int r = by_bits ? (int)(blockIdx.x * blockDim.x + threadIdx.x) : (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const int lane = by_bits ? 0 : (int)(threadIdx.x & 63u);
+    const bool thread_per_rx = by_bits && bits_wave == 0;
+    const int r = thread_per_rx ? (int)(blockIdx.x * blockDim.x + threadIdx.x) : (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = thread_per_rx ? 0 : (int)(threadIdx.x & 63u);
     // The proposal the voters are compared with.  After a counting kernel: the winning bucket's only fingerprint mm[0] and
     // the representative's list it copied out (ref[0] = size, ref[1..]).  rep_in_res -- no counting kernel ran, res[] came
     // from the tally kernel (tally_kernel.h: vote_res): the CANDIDATE is the proposal of the lowest voter res[0], read in
@@ -186,7 +190,28 @@ __global__ void vote_verify_kernel(const unsigned long long* fp, const int* prop
         ref_list = ref + 1;
     }
     const bool voter = have && in_range && my_count != 0 && my_fp == cand;
-    if (by_bits) {
+    if (by_bits && bits_wave != 0) {
+        bool bad = false;
+        if (voter) {  // (the same for all lanes of the wave: they asked about the same receiver)
+            const unsigned long long* const mine = bits + (long long)r * bits_words;
+            const unsigned long long* const cnd = bits + (long long)rep * bits_words;
+            for (int i0 = lane; i0 < bits_words; i0 += 256) {
+                unsigned long long a[4], b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = i0 + 64 * j < bits_words ? mine[i0 + 64 * j] : 0ull;
+                    b[j] = i0 + 64 * j < bits_words ? cnd[i0 + 64 * j] : 0ull;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bad |= a[j] != b[j];
+            }
+        }
+        const bool wave_bad = __ballot(voter && bad) != 0ull;
+        if (lane == 0 && voter) {
+            atomicAdd(&s_seen, 1u);
+            if (wave_bad) atomicAdd(&s_bad, 1u);
+        }
+    } else if (by_bits) {
         bool bad = false;
         if (voter) {
             const unsigned long long* const mine = bits + (long long)r * bits_words;

@@ -368,10 +368,21 @@ extern "C" int emu_index_run(const unsigned char* alerts, long long n_alerts, in
                 rapid::index_assign_kernel(gmask, member, n_nodes, L, blk.data(), dict, decl, node_of_slot, tbits, trank, tent, tent_cap);
             }, seed + 300 + (unsigned)b);
     }
+    std::vector<unsigned short> edges, edge_mask;
+    if (chunked) {  // the hot adjacency slot by slot (index_edges_kernel), as the engine launches it: 64 workgroups of 256
+        edges.assign((size_t)16384 * rapid::kIndexEdgeStride, 0xEEEE);
+        edge_mask.assign(16384, 0xEEEE);
+        for (int b = 0; b < 64; ++b)
+            emu::run_block((unsigned)b, 64u, 256u, [&] {
+                rapid::index_edges_kernel(blk.data(), n_chunks, node_of_slot, member, obs, n_nodes, K, dict, q4_rows, q4_valid, edges.data(),
+                                          edge_mask.data(), info, gmask);
+            }, seed + 350 + (unsigned)b);
+    }
     emu::run_block(0u, 1u, 1024u, [&] {
         rapid::index_build_block_kernel(gmask, member, obs, n_nodes, K, L, dict, decl, node_of_slot, smask, pairs, adj_cap, tbits, trank, tent,
                                         tent_cap, info, mail, chunked ? -1 : direct_budget, zero_words, 64, zero_flags, 4242,
-                                        chunked ? blk.data() : nullptr, n_chunks, q4_rows, q4_valid);
+                                        chunked ? blk.data() : nullptr, n_chunks, q4_rows, q4_valid, chunked ? edges.data() : nullptr,
+                                        chunked ? edge_mask.data() : nullptr);
     }, seed + 400);
     for (int i = 0; i < 8; ++i) info_out[i] = mail[i];
     if (mail[15] != 4242) return -2;                       // the sequence word behind the answer
@@ -434,14 +445,14 @@ int emu_vote_settle(const unsigned long long* fp, const int* prop_count, const i
         res[0] = rep;
         res[2] = voters;
     }
-    const bool by_bits = mode == 2;
-    const int grid = std::max(1, (n_receivers * (by_bits ? 1 : 64) + 1023) / 1024);
+    const bool by_bits = mode == 2 || mode == 3, bits_wave = mode == 3;  // 3: the comparison on bitmaps with a wave per receiver
+    const int grid = std::max(1, (n_receivers * (by_bits && !bits_wave ? 1 : 64) + 1023) / 1024);
     unsigned int seq_word = 0u;
     for (int b = 0; b < grid; ++b)
         emu::run_block((unsigned)b, (unsigned)grid, 1024u, [&] {
             rapid::vote_verify_kernel(fp, prop_count, props, prop_cap, n_receivers, res + 4, ref, res + 6, res, res_words,
                                       reinterpret_cast<unsigned int*>(res + 9), block, &seq_word, 77u, mode != 0 ? 1 : 0, errs,
-                                      by_bits ? bits : nullptr, bits_words);
+                                      by_bits ? bits : nullptr, bits_words, bits_wave ? 1 : 0);
         }, seed + 10 + (unsigned)b);
     if (seq_word != 77u) return -2;
     if (res[9] != 0ull) return -3;  // the packed counter is left at zero

@@ -220,7 +220,7 @@ def vote_settle(fp, prop_count, props, mode, salt=0, seed=1, bits=None):
     # mode 2: the comparison on bits[R, words] (the voters' proposals as bitmaps over the round's hot slots)
     if bits is not None:
         bits = np.ascontiguousarray(bits, dtype=np.uint64)
-        assert mode == 2 and bits.shape[0] == R
+        assert mode in (2, 3) and bits.shape[0] == R
     rc = L_.emu_vote_settle(p(fp), p(prop_count), p(props), cap, R, C.c_ulonglong(salt), mode, p(block), C.c_ulonglong(seed),
                             p(bits) if bits is not None else None, int(bits.shape[1]) if bits is not None else 0)
     assert rc == 0, rc

@@ -370,20 +370,21 @@ def test_vote_kernels_settle_a_round(seed):
         # slot numbering = the rank of a node among the round's proposed nodes), 9 and 1 words per receiver
         nodes = sorted({x for c in cuts for x in c})
         slot = {x: i for i, x in enumerate(nodes)}
-        for words in (1, 9):
+        for words in (1, 9, 300):
             bits = np.zeros((R, words), dtype=np.uint64)
             spread = (words * 64) // max(len(nodes), 1)
             for r in voters:
                 for x in cuts[int(which[r])]:
                     b = slot[x] * max(spread, 1)
                     bits[r, b >> 6] |= np.uint64(1 << (b & 63))
-            res3, ref3 = pyemu.vote_settle(fp, pcount, props, mode=2, bits=bits)
-            assert ref3 == ref1 and res3.tolist() == res1.tolist()
-            if len(voters) >= 3 and which[int(voters[-1])] == lead:
-                bits2 = bits.copy()
-                bits2[int(voters[-1]), words - 1] ^= np.uint64(1 << 63)
-                res4, _ = pyemu.vote_settle(fp, pcount, props, mode=2, bits=bits2)
-                assert int(res4[6]) == 1 and int(res4[7]) == int(counts[lead])
+            for mode in (2, 3):  # a thread per receiver / a wave per receiver
+                res3, ref3 = pyemu.vote_settle(fp, pcount, props, mode=mode, bits=bits)
+                assert ref3 == ref1 and res3.tolist() == res1.tolist()
+                if len(voters) >= 3 and which[int(voters[-1])] == lead:
+                    bits2 = bits.copy()
+                    bits2[int(voters[-1]), words - 1] ^= np.uint64(1 << 63)
+                    res4, _ = pyemu.vote_settle(fp, pcount, props, mode=mode, bits=bits2)
+                    assert int(res4[6]) == 1 and int(res4[7]) == int(counts[lead])
 
 
 @pytest.mark.parametrize("seed", range(8))
