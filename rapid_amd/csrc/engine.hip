@@ -357,7 +357,7 @@ int presize_view(rapid_engine* h) {
     HIPCHK(h, h->d_gone.ensure(N));
     {
         // member flags (N) | nodes that left (4 N) | nodes that came (4 N) | members, for a sort from scratch (4 N) | new NodeIds (16 N)
-        const size_t need = ((size_t)29 * N + 64 + 4095) & ~(size_t)4095;
+        const size_t need = ((size_t)29 * N + 256 + 4095) & ~(size_t)4095;  // (+ 256: each part starts on a 16-byte boundary)
         if (h->vstage_bytes < need) {
             if (h->h_vstage) {
                 HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -428,12 +428,14 @@ int rebuild_view(rapid_engine* h) {
     // that came | members | new NodeIds): the copies are asynchronous, the block lives as long as the engine, and the one wait of
     // a view change is for the configuration id at its end.  (Each upload used to come out of a local vector and was followed
     // by a stream synchronisation so that the vector could go: five waits of ~20-40 us around kernels of a few us each.)
-    if (!h->h_vstage || h->vstage_bytes < (size_t)29 * (size_t)N + 64) return fail(h, RAPID_ESTATE, "view buffers are not sized (rapid_view_build first)");
+    if (!h->h_vstage || h->vstage_bytes < (size_t)29 * (size_t)N + 256) return fail(h, RAPID_ESTATE, "view buffers are not sized (rapid_view_build first)");
+    const size_t a16 = 15, n4 = ((size_t)N * 4 + a16) & ~a16;  // (bytes of N ints, rounded up to 16)
     unsigned char* const stage_member = h->h_vstage;
-    int* const stage_gone = reinterpret_cast<int*>(h->h_vstage + (((size_t)N + 15) & ~(size_t)15));
-    int* const stage_join = stage_gone + N;
-    int* const stage_members = stage_join + N;
-    long long* const stage_ids = reinterpret_cast<long long*>(stage_members + N);
+    unsigned char* const stage_lists = h->h_vstage + (((size_t)N + a16) & ~a16);
+    int* const stage_gone = reinterpret_cast<int*>(stage_lists);
+    int* const stage_join = reinterpret_cast<int*>(stage_lists + n4);
+    int* const stage_members = reinterpret_cast<int*>(stage_lists + 2 * n4);
+    long long* const stage_ids = reinterpret_cast<long long*>(stage_lists + 3 * n4);  // 16 N bytes
     std::memcpy(stage_gone, gone.data(), sizeof(int) * gone.size());
     std::memcpy(stage_join, joiners.data(), sizeof(int) * joiners.size());
     bool gone_cleared = false;  // the member flags of the nodes that left were cleared by the kernel that drops their memo entries
