@@ -477,6 +477,25 @@ int emu_vote_merge(const unsigned long long* gathered, int n_ranks, int seg_word
 #include <algorithm>
 #include <numeric>
 
+// The two small kernels of a view change that touch per-node flags (view_kernels.h): q4_invalidate_kernel -- the memo entries that
+// ringAdd / ringDelete of nodes[] drop, with the member flags of nodes that leave cleared on the way -- and member_patch_kernel.
+extern "C" int emu_view_flags(const int* subj, const int* pos, const int* nodes, int n, int n_nodes, int K, unsigned char* valid, int self,
+                              unsigned char* member_clear, unsigned char* member, const int* gone, int n_gone, const int* joined, int n_joined,
+                              unsigned long long seed) {
+    if (n > 0) {
+        const unsigned grid = (unsigned)(((long long)n * K + 255) / 256);
+        for (unsigned b = 0; b < grid; ++b)
+            emu::run_block(b, grid, 256u, [&] { rapid::q4_invalidate_kernel(subj, pos, nodes, n, n_nodes, K, valid, self, member_clear); }, seed + b);
+    }
+    const int m = n_gone > n_joined ? n_gone : n_joined;
+    if (m > 0) {
+        const unsigned grid = (unsigned)((m + 255) / 256);
+        for (unsigned b = 0; b < grid; ++b)
+            emu::run_block(b, grid, 256u, [&] { rapid::member_patch_kernel(member, gone, n_gone, joined, n_joined); }, seed + 1000 + b);
+    }
+    return 0;
+}
+
 extern "C" int emu_view_build(const unsigned char* blob, const int* host_off, const int* ports, int n_nodes, int K, const int* members,
                               int n_members, const long long* ids_hi_sorted, const long long* ids_lo_sorted, int n_ids,
                               const unsigned char* keep /* nullable: members kept by a removal-only change */, long long* keys_out,

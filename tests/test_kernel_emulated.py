@@ -702,3 +702,39 @@ def test_ring_merge_orders_equal_keys_by_node_index():
         want = order(np.concatenate([stay, join]))
         got_r, got_k = pyemu.ring_merge(ring, key[ring], member, jn, key[jn], seed=int(n))
         assert np.array_equal(got_r, want) and np.array_equal(got_k, key[want])
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_view_change_flag_kernels(seed):
+    """q4_invalidate_kernel (what ringAdd / ringDelete drop from the observer memo, R/MembershipView.java:143-152, 181-195: the node's
+    own entry when it leaves, and its ring predecessors WITHOUT wrap-around; the member flags of nodes that leave cleared on the way)
+    and member_patch_kernel, emulated, against their statement in numpy."""
+    import ctypes as C
+    rng = np.random.default_rng(5100 + seed)
+    n_nodes, K = int(rng.integers(5, 400)), int(rng.integers(3, 11))
+    subj = rng.integers(-1, n_nodes, size=(n_nodes, K)).astype(np.int32)   # ring predecessors (-1: none)
+    pos = rng.integers(0, 3, size=(K, n_nodes)).astype(np.int32)          # position in ring k (0: the ring minimum, no predecessor below it)
+    nodes = rng.choice(n_nodes, size=int(rng.integers(0, n_nodes // 2 + 1)), replace=False).astype(np.int32)
+    valid0 = rng.integers(0, 2, size=n_nodes).astype(np.uint8)
+    member0 = rng.integers(0, 2, size=n_nodes).astype(np.uint8)
+    rest = np.setdiff1d(np.arange(n_nodes), nodes)
+    joined = rng.choice(rest, size=int(rng.integers(0, len(rest) // 2 + 1)), replace=False).astype(np.int32) if len(rest) else np.zeros(0, np.int32)
+    L_ = pyemu.lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for self_flag, clear in ((1, True), (0, False), (1, False)):
+        valid, member = valid0.copy(), member0.copy()
+        gone = np.zeros(0, np.int32) if clear else nodes  # (cleared by the memo kernel, or by the patch kernel)
+        rc = L_.emu_view_flags(p(subj), p(pos), p(nodes) if len(nodes) else None, len(nodes), n_nodes, K, p(valid), self_flag,
+                               p(member) if clear else None, p(member), p(gone) if len(gone) else None, len(gone),
+                               p(joined) if len(joined) else None, len(joined), C.c_ulonglong(seed))
+        assert rc == 0
+        want_valid, want_member = valid0.copy(), member0.copy()
+        for node in nodes.tolist():
+            if self_flag:
+                want_valid[node] = 0
+            for k in range(K):
+                if pos[k, node] > 0 and 0 <= subj[node, k] < n_nodes:
+                    want_valid[subj[node, k]] = 0
+        want_member[nodes] = 0
+        want_member[joined] = 1
+        assert np.array_equal(valid, want_valid) and np.array_equal(member, want_member), (self_flag, clear)
