@@ -19,8 +19,14 @@ def test_emulated_kernel_tests_on_variant(variant):
     env = {**os.environ, "RAPID_EMU_VARIANT": variant}
     # (the window-size variants change the tally kernel only: the index / vote / view kernel tests of that file run once, in
     # the default build -- except under the sanitizer, where everything runs)
-    only = [] if variant == "ubsan" else ["-k", "not (round_index or vote_ or view_kernels)"]
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernel_emulated.py", "-x", "-q", "-p", "no:cacheprovider"] + only,
+    only = [] if variant == "ubsan" else ["-k", "not (round_index or vote_ or view_kernels or view_change)"]
+    # (the child run spreads over a few workers where pytest-xdist is there: the variants are most of the CPU suite's wall time)
+    try:
+        import xdist  # noqa: F401
+        workers = ["-n", str(max(1, min(4, (os.cpu_count() or 2) // 2)))]
+    except ImportError:
+        workers = []
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernel_emulated.py", "-x", "-q", "-p", "no:cacheprovider"] + workers + only,
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
