@@ -20,8 +20,8 @@ boundary -- over the kernel's own duration (HIP events on the engine's stream, b
 PMC-measured HBM traffic of the same launch and must agree.  `ms_per_step` is the mean the contract asks for;
 `ms_per_step_min` / `_median` over the same steps are reported next to it.
 
-Launch: `python bench.py --gpus 1` or, for N > 1,
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
+Launch: `python bench.py --gpus N` (for N > 1 the process turns itself into the launcher of its N ranks: self_launch) or, as the
+driver does, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
 The simulated receivers are sharded across ranks (strong scaling of ONE cluster); the only data-path collective is
 the per-round RCCL all-gather of the ranks' local vote counts inside librapid_mi355x.so (the histogram all-reduces of
 the general count only run for a round whose voters disagree).
@@ -59,14 +59,53 @@ def parse():
     return ap.parse_args()
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch_command(gpus, argv, port):
+    """The command line and environment `python3 bench.py --gpus N` turns itself into when nobody launched its ranks: one process
+    per GPU under torch.distributed.run on this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve).
+    HSA_ENABLE_IPC_MODE_LEGACY=0: the ranks' RCCL communicator inside librapid_mi355x.so maps its peers' buffers through
+    hipIpcGetMemHandle, and this platform's host driver only supports the dmabuf form of it -- with the legacy form the
+    communicator's setup fails with "hipIpcGetMemHandle: invalid argument" (tests/test_gpu_multi.py sets the same)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    return cmd, env
+
+
+def self_launch(args, execve=os.execve, device_count=None):
+    """Replaces this process by the launcher of its ranks (the fan-out of the reference being replaced: one unicast per member,
+    R/UnicastToAllBroadcaster.java:46-52, R/FastPaxos.java:104 -- here one rank per GPU).  Exits non-zero when the node does not
+    have the devices asked for: a line from fewer ranks than --gpus would be a wrong line."""
+    if device_count is None:
+        from rapid_amd import engine as E
+        device_count = E.device_count
+    have = device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py: --gpus %d but %d gfx950 device(s) are visible" % (args.gpus, have))
+    cmd, env = self_launch_command(args.gpus, sys.argv[1:], free_port())
+    sys.stdout.flush()
+    sys.stderr.flush()
+    execve(cmd[0], cmd, env)
+    raise SystemExit("bench.py: could not start %s" % " ".join(cmd))  # (execve returned: only the mocked one of the tests does)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            self_launch(args)  # `python3 bench.py --gpus N`: this process becomes the launcher of its N ranks (does not return)
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    # (every rank, however it was launched: RCCL's peer mappings need the dmabuf form of hipIpcGetMemHandle here -- see self_launch_command)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 

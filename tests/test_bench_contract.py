@@ -57,3 +57,42 @@ def test_cpu_baseline_leg_on_a_small_sample():
     for d in (base, opt):
         assert set(d) == {"value", "unit", "cores", "kind", "sample"} and d["kind"] == "port" and d["unit"] == "alert-batches/s" and d["value"] > 0
     assert base["cores"] == 1 and opt["cores"] == (os.cpu_count() or 1)
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
+    """`python3 bench.py --gpus N` with WORLD_SIZE unset: the process replaces itself by torch.distributed.run with one rank per GPU
+    (the exec is mocked here), rendezvous on 127.0.0.1 with a free port, the original flags passed through, dmabuf IPC selected;
+    fewer visible devices than ranks asked for is a non-zero exit, not a line from fewer ranks."""
+    import pytest
+
+    import bench
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2", "--config", "C4"])
+    args = bench.parse()
+    seen = {}
+
+    def fake_execve(path, cmd, env):
+        seen.update(path=path, cmd=cmd, env=env)
+
+    with pytest.raises(SystemExit):  # (the mocked exec returns)
+        bench.self_launch(args, execve=fake_execve, device_count=lambda: 8)
+    cmd = seen["cmd"]
+    assert seen["path"] == sys.executable and cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 <= int(cmd[cmd.index("--master-port") + 1]) <= 65535
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2", "--config", "C4"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(args, execve=fake_execve, device_count=lambda: 1)
+    assert "4" in str(e.value) and "1" in str(e.value)
+    # main() takes that path exactly when nobody launched the ranks
+    called = []
+    monkeypatch.setattr(bench, "self_launch", lambda a: called.append(a.gpus) or (_ for _ in ()).throw(SystemExit(0)))
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert called == [4]
+    monkeypatch.setenv("WORLD_SIZE", "2")  # launched, but with another number of ranks: refused, not re-launched
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert called == [4] and "WORLD_SIZE=2" in str(e.value)

@@ -5,7 +5,7 @@ visible.  (tests/test_gpu_two_ranks.py covers what ONE GPU can: two processes ex
    quorum -- through rapid_sim_count_votes itself: every rank settles its own voters, ONE ncclAllGather moves the answer blocks,
    every rank merges (the conflict falls back to the all-reduce of the vote histogram): decision, cut, votes and the
    configuration id after applying the cut are equal on both ranks and equal to ONE engine holding the whole population.
-2. `bench.py --gpus 2` under torch.distributed.run, strong (C3b at a reduced N) and weak (`--config C4`: shards 0 and 1 of the
+2. the plain `python bench.py --gpus 2` (it launches its two ranks itself), strong (C3b at a reduced N) and weak (`--config C4`: shards 0 and 1 of the
    eight): one JSON line, n_ranks_seen == 2, the contract's fields present."""
 import json
 import os
@@ -123,10 +123,9 @@ def test_vote_count_over_a_two_rank_rccl_communicator():
 @pytest.mark.skipif(not _two_devices(), reason="needs two gfx950 devices")
 @pytest.mark.parametrize("extra", [["--n", "3000"], ["--config", "C4"]])
 def test_bench_runs_on_two_ranks(extra):
-    port = free_port()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", "--no-extras"] + extra
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # the plain command: bench.py starts its own ranks (bench.self_launch: torch.distributed.run, one rank per GPU, dmabuf IPC)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-pmc", "--no-extras"] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
