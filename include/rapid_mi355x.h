@@ -209,10 +209,11 @@ int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const 
  * next call that reads results (rapid_sim_results, rapid_sim_count_votes, rapid_sim_round, rapid_sim_proposal) return
  * RAPID_EINVAL: the round's results are void, the set was wrong. */
 int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, int64_t n_alerts);
-/* same, the distinct alerts already in device memory (4-byte aligned; borrowed until the next load / attach / generate or
- * declaration; never written): read in place by the round index -- what a host that receives a round's deliveries into device
+/* same, the distinct alerts already in device memory (`alerts_bytes` readable bytes covering them: n_alerts * 20 > alerts_bytes is
+ * RAPID_EINVAL; 4-byte aligned; borrowed until the next load / attach / generate or declaration; never written): read in place by
+ * the round index -- what a host that receives a round's deliveries into device
  * memory (rapid_sim_attach_streams_device) declares them with: no copy, no synchronisation on the round's path */
-int rapid_sim_set_alert_set_device(rapid_engine* h, const void* d_alerts, int64_t n_alerts);
+int rapid_sim_set_alert_set_device(rapid_engine* h, const void* d_alerts, uint64_t alerts_bytes, int64_t n_alerts);
 /* Opt-in, per loaded stream set (a load resets it): asks the tally to treat a delivered record that fails the filter of
  * R/MembershipService.java:644-675 as an ERROR of the stream (RAPID_EINVAL, results void) instead of dropping it per delivery
  * -- the instantiation without the per-delivery filter, a few instructions per record cheaper (both read the same 8 B per

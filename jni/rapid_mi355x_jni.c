@@ -221,10 +221,16 @@ JNIEXPORT void JNICALL Java_com_vrg_rapid_NativeCutEngine_simSetAlertSet(JNIEnv*
     CHECK(h, rapid_sim_set_alert_set(ENGINE(h), (const rapid_alert_record*)(*env)->GetDirectBufferAddress(env, alerts), n));
 }
 
-/* void simSetAlertSetDevice(long h, long dAlerts, long n): the round's distinct alerts already in device memory, read in place */
-JNIEXPORT void JNICALL Java_com_vrg_rapid_NativeCutEngine_simSetAlertSetDevice(JNIEnv* env, jobject self, jlong h, jlong dAlerts, jlong n) {
+/* void simSetAlertSetDevice(long h, long dAlerts, long alertsBytes, long n): the round's distinct alerts already in device memory
+ * (alertsBytes readable bytes covering them), read in place */
+JNIEXPORT void JNICALL Java_com_vrg_rapid_NativeCutEngine_simSetAlertSetDevice(JNIEnv* env, jobject self, jlong h, jlong dAlerts, jlong alertsBytes,
+                                                                               jlong n) {
     (void)self;
-    CHECK(h, rapid_sim_set_alert_set_device(ENGINE(h), (const void*)(intptr_t)dAlerts, (int64_t)n));
+    if (alertsBytes < 0) {
+        throw_iae(env, "alertsBytes < 0");
+        return;
+    }
+    CHECK(h, rapid_sim_set_alert_set_device(ENGINE(h), (const void*)(intptr_t)dAlerts, (uint64_t)alertsBytes, (int64_t)n));
 }
 
 /* void simGenerate(long h, ByteBuffer alerts, long[] batchOff, int[] batchKeep, int[] receivers, long seed, boolean boundary): the

@@ -186,7 +186,7 @@ def _signatures():
         "rapid_sim_load_streams": (i32, [vp, p, p, i32]),
         "rapid_sim_load_streams_device": (i32, [vp, p, u64, p, i32]),
         "rapid_sim_set_alert_set": (i32, [vp, p, i64]),
-        "rapid_sim_set_alert_set_device": (i32, [vp, p, i64]),
+        "rapid_sim_set_alert_set_device": (i32, [vp, p, u64, i64]),
         "rapid_sim_attach_streams_device": (i32, [vp, p, u64, p, i32]),
         "rapid_sim_generate": (i32, [vp, p, p, i32, p, p, i32, u64, i32]),
         "rapid_sim_tally": (i32, [vp]),

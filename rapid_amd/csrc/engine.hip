@@ -166,6 +166,7 @@ struct rapid_engine {
     unsigned char* h_vstage = nullptr;       // pinned staging of a view change's uploads (member flags, the nodes that left / came, new
     size_t vstage_bytes = 0;                 // NodeIds): sized from n_max by presize_view, so that rebuild_view never waits for a copy
     size_t alert_stage_bytes = 0;
+    bool vstage_busy = false;  // asynchronous copies out of h_vstage may still be in flight (cleared when a view change's last kernel has answered)
     hipEvent_t ev_alert = nullptr;
     bool alert_copy_pending = false;
     long long n_alert_set = -1;
@@ -429,6 +430,14 @@ int rebuild_view(rapid_engine* h) {
     // a view change is for the configuration id at its end.  (Each upload used to come out of a local vector and was followed
     // by a stream synchronisation so that the vector could go: five waits of ~20-40 us around kernels of a few us each.)
     if (!h->h_vstage || h->vstage_bytes < (size_t)29 * (size_t)N + 256) return fail(h, RAPID_ESTATE, "view buffers are not sized (rapid_view_build first)");
+    // The staging block is written with plain memcpy: the previous view change's copies out of it are known to be done when that
+    // change got as far as its configuration id.  One that returned early (a device error on the way) may have left copies in
+    // flight: waited for here, on that rare path only.
+    if (h->vstage_busy) {
+        HIPCHK(h, hipStreamSynchronize(st));
+        h->vstage_busy = false;
+    }
+    h->vstage_busy = true;
     const size_t a16 = 15, n4 = ((size_t)N * 4 + a16) & ~a16;  // (bytes of N ints, rounded up to 16)
     unsigned char* const stage_member = h->h_vstage;
     unsigned char* const stage_lists = h->h_vstage + (((size_t)N + a16) & ~a16);
@@ -581,6 +590,7 @@ int rebuild_view(rapid_engine* h) {
         HIPCHK(h, hipGetLastError());
         if ((rc_mail = await_mail(h, 10, seq))) return rc_mail;
     }
+    h->vstage_busy = false;  // (the kernel that answered runs behind every copy of this change on the stream)
     long long cfg = 0;
     std::memcpy(&cfg, h->h_mail + 32, 8);
     lap("configuration id");
@@ -599,6 +609,25 @@ int rebuild_view(rapid_engine* h) {
     h->have_decision = false;
     h->index_valid = false;
     return RAPID_OK;
+}
+
+// A view change that failed on the way (a device error inside rebuild_view) may have patched the device's member flags and
+// swapped the rings while ring_member / ring_m still describe the old ones: nothing incremental may be built on that.  The next
+// change sorts the rings afresh from the host's member flags; if the identifiers of the change were already merged on the device
+// the view has to be built again (rapid_view_build) -- the set cannot be un-merged.
+void view_change_failed(rapid_engine* h, int n_ids_before) {
+    h->changed.clear();
+    h->changed_valid = false;
+    h->ring_member.clear();
+    h->ring_m = 0;
+    h->host_tables_valid = false;
+    h->index_valid = false;
+    h->tallied = false;
+    h->have_decision = false;
+    if (h->n_ids_dev != n_ids_before) {
+        h->view_built = false;
+        h->err += " (the identifiers of the failed change are merged already: build the view again)";
+    }
 }
 
 int ensure_host_tables(rapid_engine* h) {
@@ -1109,10 +1138,17 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
     if (!hostnames || !host_off || !ports || !id_hi || !id_lo || n_nodes <= 0 || n_nodes > h->cfg.n_max || n_members < 0 ||
         (n_members > 0 && !members) || n_extra < 0 || (n_extra > 0 && (!extra_id_hi || !extra_id_lo)) || host_off[0] < 0)
         return fail(h, RAPID_EINVAL, "bad arguments to rapid_view_build (n_nodes=%d, n_max=%d)", n_nodes, h->cfg.n_max);
+    // everything that can be wrong with the arguments is found before the engine's state is touched: a call that returns
+    // RAPID_EINVAL leaves a previously built view as it was
+    for (int i = 0; i < n_members; ++i)
+        if (members[i] < 0 || members[i] >= n_nodes) return fail(h, RAPID_EINVAL, "member index %d out of range", members[i]);
+    for (int i = 0; i < n_nodes; ++i)
+        if (host_off[i + 1] < host_off[i]) return fail(h, RAPID_EINVAL, "hostname offsets must not decrease (entry %d)", i);
     int rc = use_device(h);
     if (rc) return rc;
     const int K = h->cfg.K;
     if ((rc = presize_view(h))) return rc;
+    h->view_built = false;  // (until the new view stands: a device error below leaves "no view", not a mixture of two)
     h->n_nodes = n_nodes;
     h->id_hi.assign(id_hi, id_hi + n_nodes);
     h->id_lo.assign(id_lo, id_lo + n_nodes);
@@ -1121,7 +1157,6 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
     ids.reserve((size_t)n_members + (size_t)n_extra);
     for (int i = 0; i < n_members; ++i) {
         const int m = members[i];
-        if (m < 0 || m >= n_nodes) return fail(h, RAPID_EINVAL, "member index %d out of range", m);
         h->member[(size_t)m] = 1;  // Set semantics, like TreeSet.addAll (R/MembershipView.java:82-85)
         ids.push_back({id_hi[m], id_lo[m]});
     }
@@ -1147,8 +1182,6 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
     h->ids_pending.clear();
     HIPCHK(h, hipMemsetAsync(h->d_q4_valid.p, 0, (size_t)h->cfg.n_max, h->stream));  // a new MembershipView object: nothing memoised
 
-    for (int i = 0; i < n_nodes; ++i)
-        if (host_off[i + 1] < host_off[i]) return fail(h, RAPID_EINVAL, "hostname offsets must not decrease (entry %d)", i);
     const size_t blob_bytes = (size_t)host_off[n_nodes];
     h->reg_blob.assign(hostnames, hostnames + blob_bytes);
     h->reg_off.assign(host_off, host_off + n_nodes + 1);
@@ -1166,13 +1199,14 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
                        h->d_blob.p, h->d_host_off.p, h->d_ports.p, n_nodes, K, h->d_keys.p, h->d_hx_host0.p, h->d_hx_port0.p);
     h->host_keys0_valid = false;
     HIPCHK(h, hipStreamSynchronize(h->stream));  // borrowed inputs may go away after the call
-    h->view_built = true;
     h->streams_loaded = false;
     h->ring_member.clear();  // new endpoints, new ring keys: nothing to compact from
     h->changed.clear();
     h->changed_valid = false;
     h->ring_m = 0;
-    return rebuild_view(h);
+    if ((rc = rebuild_view(h))) return rc;
+    h->view_built = true;
+    return RAPID_OK;
 }
 
 int rapid_view_register_endpoints(rapid_engine* h, const uint8_t* hostnames, const int32_t* host_off, const int32_t* ports,
@@ -1259,12 +1293,22 @@ int rapid_view_ring_add(rapid_engine* h, int32_t node, int64_t id_hi, int64_t id
     if ((rc = ids_seen_any(h, {id}, &seen))) return rc;
     if (seen) return fail(h, RAPID_EUUID_SEEN, "identifier of node %d already seen", node);  // :127-129
     if (h->member[(size_t)node]) return fail(h, RAPID_ENODE_EXISTS, "node %d already in ring", node);          // :133-135
+    const int64_t old_hi = h->id_hi[(size_t)node], old_lo = h->id_lo[(size_t)node];
+    const int n_ids_before = h->n_ids_dev;
+    const size_t pending_before = h->ids_pending.size();
     h->member[(size_t)node] = 1;
     h->changed.push_back(node);
     h->id_hi[(size_t)node] = id_hi;
     h->id_lo[(size_t)node] = id_lo;
     h->ids_pending.push_back(id);
-    return rebuild_view(h);
+    if ((rc = rebuild_view(h))) {  // the node is not added: flags and identifier as before, the rings sorted afresh by the next change
+        h->member[(size_t)node] = 0;
+        h->id_hi[(size_t)node] = old_hi;
+        h->id_lo[(size_t)node] = old_lo;
+        if (h->ids_pending.size() > pending_before) h->ids_pending.resize(pending_before);
+        view_change_failed(h, n_ids_before);
+    }
+    return rc;
 }
 
 int rapid_view_ring_delete(rapid_engine* h, int32_t node) {
@@ -1274,7 +1318,11 @@ int rapid_view_ring_delete(rapid_engine* h, int32_t node) {
     if (!h->member[(size_t)node]) return fail(h, RAPID_ENODE_MISSING, "node %d not in ring", node);  // :172-174
     h->member[(size_t)node] = 0;  // identifiersSeen is never pruned (:167-201)
     h->changed.push_back(node);
-    return rebuild_view(h);
+    if ((rc = rebuild_view(h))) {
+        h->member[(size_t)node] = 1;
+        view_change_failed(h, h->n_ids_dev);
+    }
+    return rc;
 }
 
 int rapid_view_observers(rapid_engine* h, int32_t node, int32_t* out, int32_t cap, int32_t* n_out) {
@@ -1729,9 +1777,11 @@ int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const 
 #ifdef RAPID_TEST_BUILD
 int rapid_debug_read_records(rapid_engine* h, int64_t first, int32_t n, uint32_t* subjects, uint32_t* core_words) {
     if (!h || first < 0 || n < 0 || !subjects || !core_words) return RAPID_EINVAL;
-    if (!h->streams_loaded || first + n > h->n_records_total) return fail(h, RAPID_EINVAL, "records [%lld, %lld) not loaded", (long long)first, (long long)first + n);
     int rc = use_device(h);
     if (rc) return rc;
+    long long n_loaded = 0;  // (the delivered count, not the size of an attached buffer)
+    if (h->streams_loaded && (rc = total_records(h, &n_loaded))) return rc;
+    if (!h->streams_loaded || first + n > n_loaded) return fail(h, RAPID_EINVAL, "records [%lld, %lld) not loaded", (long long)first, (long long)first + n);
     const size_t stride = h->rec_fmt == rapid::kFmtBoundary ? 20 : 8;
     std::vector<unsigned char> raw((size_t)n * stride);
     if (n) HIPCHK(h, hipMemcpyAsync(raw.data(), h->d_records + (size_t)first * stride, raw.size(), hipMemcpyDeviceToHost, h->stream));
@@ -1789,9 +1839,11 @@ int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, i
     return RAPID_OK;
 }
 
-int rapid_sim_set_alert_set_device(rapid_engine* h, const void* d_alerts, int64_t n_alerts) {
+int rapid_sim_set_alert_set_device(rapid_engine* h, const void* d_alerts, uint64_t alerts_bytes, int64_t n_alerts) {
     if (!h || n_alerts < 0 || (n_alerts > 0 && !d_alerts)) return RAPID_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_alerts) & 3u) != 0u) return fail(h, RAPID_EINVAL, "alerts must be 4-byte aligned");
+    if ((unsigned long long)n_alerts > alerts_bytes / 20ull)  // (the index kernel would read past the caller's allocation)
+        return fail(h, RAPID_EINVAL, "alerts_bytes=%llu does not cover %lld alerts", (unsigned long long)alerts_bytes, (long long)n_alerts);
     if (!h->streams_loaded) return fail(h, RAPID_ESTATE, "load the streams first");
     if (h->rec_fmt == rapid::kFmtResident)
         return fail(h, RAPID_ESTATE, "generated deliveries are copies of the alert set they were generated from (rapid_sim_generate declares it)");
@@ -2153,8 +2205,8 @@ int rapid_apply_cut(rapid_engine* h, const int32_t* cut, int32_t n, int64_t* new
     if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
     int rc = use_device(h);
     if (rc) return rc;
-    // A failing call leaves the view untouched: the flags are set / cleared in place -- the cost of the call is the cut's, not the
-    // registry's -- and put back if the cut does not validate
+    // A failing call leaves the membership untouched: the flags are set / cleared in place -- the cost of the call is the cut's, not
+    // the registry's -- and put back if the cut does not validate or the device fails on the way (view_change_failed)
     for (int i = 0; i < n; ++i)
         if (cut[i] < 0 || cut[i] >= h->n_nodes) return fail(h, RAPID_EINVAL, "node index %d out of range", cut[i]);
     std::vector<std::pair<int64_t, int64_t>> added;
@@ -2182,10 +2234,17 @@ int rapid_apply_cut(rapid_engine* h, const int32_t* cut, int32_t n, int64_t* new
             return fail(h, RAPID_EUUID_SEEN, "the identifier of a joiner in the cut was already seen");
         }
     }
+    const int n_ids_before = h->n_ids_dev;
+    const size_t pending_before = h->ids_pending.size();
     h->changed.insert(h->changed.end(), cut, cut + n);
     h->ids_pending.insert(h->ids_pending.end(), added.begin(), added.end());
     rc = rebuild_view(h);  // new rings, tables, configuration id; cutDetection.clear() == fresh state next tally
-    if (rc) return rc;
+    if (rc) {  // (a device error on the way: the membership goes back to what it was and nothing is built on half-changed rings)
+        undo();
+        if (h->ids_pending.size() > pending_before) h->ids_pending.resize(pending_before);
+        view_change_failed(h, n_ids_before);
+        return rc;
+    }
     if (new_config_id) *new_config_id = h->config_id;
     return RAPID_OK;
 }

@@ -491,13 +491,17 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
         for (int i = 0; i < 8; ++i) s_pub[i] = info[i];  // info[4] was written by the touch pass
     }
     __syncthreads();
-    if (t < 64) {
-        // the host does not wait for the stream: it polls the last word of the mapped page (what it reads afterwards was written
-        // before the fence; the zeroing below is ordered before the tally kernel by the stream).  Eight lanes, one store
-        // instruction: see index_fused_kernel.
-        if (t < 8) info_out[t] = s_pub[t];
+    // the host does not wait for the stream: it polls the last word of the mapped page (what it reads afterwards was written
+    // before the sequence word; the zeroing below is ordered before the tally kernel by the stream).  Eight lanes, one store
+    // instruction -- see index_fused_kernel, also for why every storing lane fences and a barrier stands before the sequence word.
+    if (t < 8) {
+        info_out[t] = s_pub[t];
         __threadfence_system();
-        if (t == 0) info_out[15] = seq;
+    }
+    __syncthreads();
+    if (t == 0) {
+        __threadfence_system();
+        info_out[15] = seq;
     }
     // leave the work area as the next round's touch pass needs it (all zero): nobody reads gmask[] / info[] after this point
     // (index_edges_kernel has cleared gmask[] already where it ran: 4 MB at 10^6 nodes are not one workgroup's job)
@@ -757,19 +761,24 @@ __global__ __launch_bounds__(1024) void index_fused_kernel(const unsigned char* 
     // The answer goes into the host-mapped page the host polls.  Eight lanes store the eight words with ONE instruction: a volatile
     // store to that page is waited for before the next one is issued -- nine stores in a row by one thread were nine round trips
     // over the host link at the tail of a kernel the whole round waits for.
-    if (t < 64) {
-        if (t < 8) {
-            const int v = t <= 1 ? n_hot_all
-                        : t == 2 ? ((s_stale != 0u ? 4 : 0) | (n_hot_all > 16318 ? 1 : 0) | (fits ? 0 : 2))
-                        : t == 3 ? total
-                        : t == 4 ? (int)s_flags
-                        : t == 5 ? n_touched
-                        : t == 6 ? (tfits && !direct_fits ? 1 : 0)
-                                 : (direct_fits ? 1 : 0);
-            info_out[t] = v;
-        }
+    // Ordering: a thread's fence orders that thread's own stores only, so each of the eight storing lanes fences its word, the
+    // workgroup barrier orders all of that before lane 0, and lane 0 publishes the sequence word behind a fence of its own -- the
+    // release pattern vote_verify_kernel uses, not an assumption about the lanes of a wave moving in lock step.
+    if (t < 8) {
+        const int v = t <= 1 ? n_hot_all
+                    : t == 2 ? ((s_stale != 0u ? 4 : 0) | (n_hot_all > 16318 ? 1 : 0) | (fits ? 0 : 2))
+                    : t == 3 ? total
+                    : t == 4 ? (int)s_flags
+                    : t == 5 ? n_touched
+                    : t == 6 ? (tfits && !direct_fits ? 1 : 0)
+                             : (direct_fits ? 1 : 0);
+        info_out[t] = v;
         __threadfence_system();
-        if (t == 0) info_out[15] = seq;
+    }
+    __syncthreads();
+    if (t == 0) {
+        __threadfence_system();
+        info_out[15] = seq;
     }
 }
 

@@ -353,10 +353,12 @@ class ClusterSimulation:
         self.e._check(self.e._lib.rapid_sim_set_alert_set(self.e._h, _addr(alerts) if len(alerts) else None, len(alerts)))
         self.e._check(self.e._lib.rapid_sim_trust_alert_copies(self.e._h, 1 if trust_copies else 0))
 
-    def set_alert_set_device(self, d_alerts_ptr, n_alerts, trust_copies=False, keepalive=None):
-        """The round's distinct alerts, already in device memory (rapid_sim_set_alert_set_device): read in place."""
+    def set_alert_set_device(self, d_alerts_ptr, n_alerts, trust_copies=False, keepalive=None, alerts_bytes=None):
+        """The round's distinct alerts, already in device memory (rapid_sim_set_alert_set_device): read in place.
+        alerts_bytes: readable bytes at d_alerts_ptr (default: exactly the n_alerts records)."""
         self._keep_alerts = keepalive
-        self.e._check(self.e._lib.rapid_sim_set_alert_set_device(self.e._h, d_alerts_ptr, n_alerts))
+        nbytes = 20 * int(n_alerts) if alerts_bytes is None else int(alerts_bytes)
+        self.e._check(self.e._lib.rapid_sim_set_alert_set_device(self.e._h, d_alerts_ptr, nbytes, n_alerts))
         self.e._check(self.e._lib.rapid_sim_trust_alert_copies(self.e._h, 1 if trust_copies else 0))
 
     def tally(self):

@@ -896,6 +896,8 @@ def test_streams_handed_over_in_device_memory(E):
     assert all(np.array_equal(a, b) for a, b in zip(want, sim.results()))
     with pytest.raises(E.IllegalArgumentException):
         sim.set_alert_set_device(d_al.value + 2, len(sc.batches.recs))
+    with pytest.raises(E.IllegalArgumentException):  # more alerts than the buffer holds: refused on the host, not a fault in the index kernel
+        sim.set_alert_set_device(d_al.value, len(sc.batches.recs) + 1, alerts_bytes=20 * len(sc.batches.recs))
     with pytest.raises(E.IllegalArgumentException):
         sim.attach_streams_device(d_rec2.value + 13, raw.nbytes, d_off.value, len(sc.rec_off) - 1)  # not 4-byte aligned
     # offsets that run past the records, or are not ascending: checked on the device, ahead of the round's kernels, without
