@@ -1126,6 +1126,15 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
         // branch: nothing is applied unless the certificate holds, the last quarter holds a batch end (the records after
         // it are carried into the next window) and no first DOWN report would switch the implicit invalidation on inside
         // the window.
+#ifndef RAPID_LANE_DUMMY
+#define RAPID_LANE_DUMMY 0
+#endif
+        // (measurement knob, round 5) a report about a subject that is not hot goes to THIS LANE's dummy slot instead of the one its
+        // node index picks: 64 lanes, 64 dummy words, two per bank -- no two lanes of a quarter ever OR into the same dummy word
+        auto dummy_to_lane = [&](unsigned int so_raw) -> unsigned int {
+            if constexpr (RAPID_LANE_DUMMY != 0) return so_raw < 2u * (unsigned int)n_hot ? so_raw : 2u * my_dummy;
+            return so_raw;
+        };
         auto fast_try = [&](const Win& cw) -> int {
 #ifdef RAPID_PROBE_STREAM  // measurement builds only (results are void): what the turn loop costs with the tally taken out
 #pragma unroll
@@ -1155,7 +1164,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
                     const unsigned int full = (raw & kCoreRings) | ((raw & 0x00FF0000u) != 0u ? kCoreDown : kCoreUp);
                     w[q] = current ? full : 0u;
                     uncovered |= w[q] & k.entry;
-                    so[q] = k.entry >> 16;
+                    so[q] = dummy_to_lane(k.entry >> 16);
                     wdiff = min(wdiff, so[q] ^ witness_so);
                     nbv += (raw >> 24) & 1u;
                     // measurement builds only (profiles/r04_ab_sensitivity_c3b.txt): work ADDED to the fast window, results unchanged
@@ -1184,7 +1193,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
                     const Look k = lookup(c.w3[q]);
 #endif
                     w[q] = effective(c, q, k);
-                    so[q] = k.entry >> 16;
+                    so[q] = dummy_to_lane(k.entry >> 16);
                     wdiff = min(wdiff, so[q] ^ witness_so);
                     nbv += c.w4[q] >> 16;
                 }
@@ -1221,10 +1230,19 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
 #pragma unroll
             for (int q = 0; q < kQ; ++q) sink ^= so[q] ^ w[q];
 #else
+#if defined(RAPID_SKIP_DUMMY_OR)  // (measurement knob, round 5) no OR at all for reports about subjects that are not hot: an execution mask instead of dummy words
+            const unsigned int hot2_ = 2u * (unsigned int)n_hot;
+            if (carry_so < hot2_) d.fast_or(carry_so, carry_w);
+#pragma unroll
+            for (int q = 0; q < kQ - 1; ++q)
+                if (so[q] < hot2_) d.fast_or(so[q], w[q]);
+            if (so[kQ - 1] < hot2_) d.fast_or(so[kQ - 1], inl ? w[kQ - 1] : 0u);
+#else
             d.fast_or(carry_so, carry_w);
 #pragma unroll
             for (int q = 0; q < kQ - 1; ++q) d.fast_or(so[q], w[q]);
             d.fast_or(so[kQ - 1], inl ? w[kQ - 1] : 0u);
+#endif
 #ifdef RAPID_PROBE_DUP_OR  // measurement builds only: a second OR per record, into this lane's dummy slot (results unchanged)
 #pragma unroll
             for (int q = 0; q < kQ; ++q) d.fast_or(2u * my_dummy, w[q] ^ (so[q] & 1u));

@@ -383,6 +383,25 @@ def build_scenario(name, subj, cfg_id, seed_fault=1, seed_delivery=2, receivers=
     return sc
 
 
+def with_late_batches(batches, prev_cfg, rate, seed):
+    """The round's batch set plus `rate` x its batches as LATE DELIVERIES of the previous configuration ("stale-cfg
+    alerts from round r-1 are interleaved at rate 1 %"): seeded copies of whole BatchedAlertMessages whose alerts carry `prev_cfg`
+    and are dropped per delivery (R/MembershipService.java:653-657; their batch end still counts, :330).  They are additional
+    batches -- nothing of the current round is lost to them -- and, as members of the batch set, they fall at receiver-specific
+    places of every receiver's delivery order (rapid_sim_generate / deliver_hashed)."""
+    B = batches.n_batches
+    if prev_cfg is None or rate <= 0 or B == 0:
+        return batches
+    rng = np.random.Generator(np.random.PCG64([int(seed) & _M64, 4242]))
+    pick = np.sort(rng.integers(0, B, size=max(1, int(round(rate * B)))))
+    lens = np.diff(batches.off)[pick]
+    starts = np.repeat(batches.off[pick] - np.concatenate([[0], np.cumsum(lens)[:-1]]), lens)
+    late = batches.recs[starts + np.arange(int(lens.sum()), dtype=np.int64)].copy()
+    late["cfg_id"] = prev_cfg
+    off = np.concatenate([batches.off, batches.off[-1] + np.cumsum(lens)]).astype(np.int64)
+    return BatchSet(np.concatenate([batches.recs, late]), off, np.concatenate([batches.sender, batches.sender[pick]]))
+
+
 class StreamingChurn:
     """C5: rounds of continuous churn over one population (BASELINE configs[4]).  Every round takes the CURRENT
     view (observer table + membership, after the previous round's cut was applied), crashes `crash_frac` of the members
@@ -399,6 +418,23 @@ class StreamingChurn:
         self.round = 0
         self.prev_cfg = None
         self.ever_member = None  # identifiers are never pruned (quirk Q5): a node joins once
+
+    def next_round_batches(self, obs, member, cfg_id):
+        """The round WITHOUT materialised deliveries -- what rapid_sim_generate / rapid_sim_round_population take: the scenario
+        (receivers = every surviving member, batches = the round's own alerts) and the batch set to deliver (+ the late
+        deliveries of the previous configuration as additional batches).  -> (scenario, batch set to deliver)."""
+        is_member = np.asarray(member) != 0
+        self.ever_member = is_member.copy() if self.ever_member is None else (self.ever_member | is_member)
+        fresh = np.flatnonzero(~self.ever_member)
+        n_members = int(is_member.sum())
+        n_crash = max(1, int(round(self.crash_frac * n_members)))
+        n_join = min(len(fresh), int(round(self.join_frac * n_members)))
+        sc = build_churn_scenario(obs, member, cfg_id, n_crash, n_join, self.H, self.L, seed_fault=self.seed + 1000 * self.round,
+                                  materialise=False, eligible_joiners=fresh)
+        deliver_set = with_late_batches(sc.batches, self.prev_cfg, self.stale_rate, self.seed + 31 * self.round)
+        self.prev_cfg = cfg_id
+        self.round += 1
+        return sc, deliver_set
 
     def next_round(self, obs, member, cfg_id, receivers=None):
         is_member = np.asarray(member) != 0

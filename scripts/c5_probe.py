@@ -1,0 +1,70 @@
+"""What bounds the tally at BASELINE configs[4] (10^6 members, ~15,000 hot subjects per round)?  One churn round, its deliveries made
+on the device for a sample of receivers (20-byte boundary records, late deliveries of another configuration among them), and the
+tally kernel timed in every prepared build of the library (scripts/build_variants.sh): the product's kernel, the same without the
+dictionary gather (pnolook), without the detector's OR (pnoor), and streaming only (pstream) -- results of the probe builds are void.
+    python scripts/c5_probe.py [members=1000000] [receivers=1024] [reps=5]"""
+import glob
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rapid_amd import _native as N  # noqa: E402
+from rapid_amd import engine as E  # noqa: E402
+from rapid_amd import scenarios as S  # noqa: E402
+
+n_mem = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+n_rx = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+K, H, L = 10, 9, 4
+
+libs = {"default": N.TEST_LIB_PATH}
+for path in sorted(glob.glob(os.path.join(ROOT, "rapid_amd", "librapid_mi355x_*.so"))):
+    tag = os.path.basename(path)[len("librapid_mi355x_"):-3]
+    if tag not in ("test",) and not tag.startswith("timers"):
+        libs[tag] = path
+if os.environ.get("RAPID_AB_ONLY"):
+    libs = {k: v for k, v in libs.items() if k in os.environ["RAPID_AB_ONLY"].split(",")}
+
+t0 = time.time()
+pop = S.Population.make(n_mem + int(0.006 * n_mem) + 64)
+sc = deliver_set = None
+rx = None
+for tag, path in libs.items():
+    N._lib = None
+    N.LIB_PATH = path
+    eng = E.Engine(n_max=pop.n, K=K, H=H, L=L, max_cut=max(4096, int(0.02 * n_mem)))
+    view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo, members=np.arange(n_mem, dtype=np.int32))
+    if sc is None:
+        obs, subj, member = view.tables()
+        cfg = view.getCurrentConfigurationId()
+        st = S.StreamingChurn(H, L)
+        st.prev_cfg = cfg ^ 0x5A5A  # (a first round has no predecessor: any other id stands in for "the previous configuration")
+        sc, deliver_set = st.next_round_batches(obs, member, cfg)
+        rng = np.random.Generator(np.random.PCG64(11))
+        rx = np.sort(rng.permutation(sc.receivers)[:n_rx]).astype(np.int32)
+        print("setup %.1f s: %d members, %d alerts in %d batches (+ %d late), %d receivers" % (
+            time.time() - t0, n_mem, len(sc.batches.recs), sc.batches.n_batches, deliver_set.n_batches - sc.batches.n_batches, len(rx)), flush=True)
+    sim = E.ClusterSimulation(eng)
+    sim.generate(deliver_set, rx, seed=7, trust_copies=True, boundary=True)
+    n_rec = len(rx) * len(deliver_set.recs)
+    for knob, what in ((0, "as chosen"), (64, "filter per delivery")):
+        sim.set_force_exact(knob)
+        ms = sim.time_tally(reps)
+        info = sim.index_info(timed=False)
+        print("%-8s %-20s tally %.4f ms  %.3e records/s  %.1f %% of 8 TB/s on 20 B  (dict mode %d, %d waves x %d workgroups, %d hot, prevalidated %d)" % (
+            tag, what, ms, n_rec / ms * 1e3, 100 * 20 * n_rec / ms / 1e6 / 8000, info["dict_mode"], info["waves_per_workgroup"], info["workgroups"],
+            info["hot_subjects"], info["alerts_prevalidated"]), flush=True)
+    sim.set_force_exact(0)
+    if tag == "default":
+        sim.tally()
+        rr = sim.count_votes()
+        emit, nprop, pcount, fp = sim.results()
+        print("default: %d of %d receivers propose, %d distinct proposals, cut %s the round's fault set" % (
+            int((emit >= 0).sum()), len(emit), len(np.unique(fp[emit >= 0])),
+            "==" if sorted(sim.proposal(int(np.flatnonzero(emit >= 0)[0]))) == sc.faulty.tolist() else "!="), flush=True)
+    del sim
+    eng.close()

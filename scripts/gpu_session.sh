@@ -1,0 +1,40 @@
+#!/bin/bash
+# One `gpurun` call = one GPU session: scripts/gpu_session.sh <section> [<section> ...], sections run in the order given; everything a
+# section prints that is worth keeping goes to gpurun_out/ (merged back by gpurun), a short digest to stdout.
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash scripts/gpu_session.sh micro c5probe ab_c3b'
+# (round 4 kept one script per session, gpu_r04_a.sh ... _q.sh; their sections live here now.)
+set -u
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+R=$PWD
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+filter() { grep -v "^ROCm\|^Hostname\|^Librccl\|^RCCL\|^HIP\|amdgpu.ids"; }
+for section in "$@"; do
+  echo "==== $section"
+  case "$section" in
+    tests)        # the whole GPU suite, as the driver runs it
+      timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1; filter < gpurun_out/pytest_gpu.log | tail -4 ;;
+    tests:*)      # a subset: tests:<-k expression>
+      timeout 900 python -m pytest tests -m gpu -q -x -k "${section#tests:}" > gpurun_out/pytest_gpu_sub.log 2>&1; filter < gpurun_out/pytest_gpu_sub.log | tail -4 ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | filter | tail -2 ;;
+    bench)        # the driver's command
+      timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; python scripts/bench_digest.py gpurun_out/bench.json ;;
+    bench:*)      # bench:<config>[:extra flags]
+      IFS=: read -r _ cfg extra <<< "$section"
+      timeout 900 python bench.py --gpus 1 --config "$cfg" $extra > "gpurun_out/bench_$cfg.json" 2> "gpurun_out/bench_$cfg.err"; python scripts/bench_digest.py "gpurun_out/bench_$cfg.json"; tail -2 "gpurun_out/bench_$cfg.err" ;;
+    micro)        # scripts/micro/gather_rate.hip: what a table lookup costs by where the table lives
+      (cd scripts/micro && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 gather_rate.hip -o gather_rate 2>/dev/null; timeout 200 ./gather_rate) | tee gpurun_out/gather_rate.txt ;;
+    c5probe)      # the C5 tally kernel in every prepared build (what bounds it)
+      RAPID_AB_ONLY=${C5_ONLY:-default,pnolook,pnoor,pstream} timeout 600 python scripts/c5_probe.py 1000000 1024 5 2> gpurun_out/c5_probe.err | tee gpurun_out/c5_probe.txt; tail -2 gpurun_out/c5_probe.err ;;
+    ab_c3b)       # the C3b tally kernel in every prepared build, interleaved
+      RAPID_AB_ONLY=${AB_ONLY:-default,lanedummy,skipdummy} timeout 600 python scripts/ab_variants.py C3b 3 20 2> gpurun_out/ab_c3b.err | tee gpurun_out/ab_c3b.txt | tail -12; tail -2 gpurun_out/ab_c3b.err ;;
+    kstats)       # rocprofv3 kernel statistics of the bench command (driver form)
+      cd /tmp; rm -rf "$R/gpurun_out/prof_bench"
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_bench" -o bench -- python "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > "$R/gpurun_out/bench_traced.json" 2> "$R/gpurun_out/prof_bench.log"
+      cd "$R"; head -12 gpurun_out/prof_bench/bench_kernel_stats.csv | cut -c1-200 ;;
+    c5stream)     # BASELINE configs[4] rounds on a receiver sample (scripts/c5_stream.py)
+      timeout 600 python scripts/c5_stream.py 1000000 3 1024 > gpurun_out/c5_1m.jsonl 2> gpurun_out/c5.err; cut -c1-420 gpurun_out/c5_1m.jsonl; tail -2 gpurun_out/c5.err ;;
+    *) echo "unknown section $section" ;;
+  esac
+done
