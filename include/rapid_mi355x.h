@@ -261,6 +261,30 @@ int rapid_sim_decided_cut(rapid_engine* h, int32_t* out, int32_t cap, int32_t* n
 /* tally + vote count (+ apply, if decided and apply != 0): one full round; new_config_id may be NULL */
 int rapid_sim_round(rapid_engine* h, int32_t apply, rapid_round_result* out, int64_t* new_config_id);
 
+/* ---- one round over a population that does not fit one launch (BASELINE configs[4]: 10^6 receivers x ~1.5 x 10^5 deliveries) ------
+ * The receivers are taken TILE BY TILE: a tile's deliveries are made on the device from the round's alert set exactly as
+ * rapid_sim_generate makes them (same seeded per-receiver orders, same batch_keep draws: receiver i's stream does not depend on the
+ * tiling), the tile is tallied, and the fast-round votes are ACCUMULATED ACROSS THE TILES' LAUNCHES: the first voter's proposal is
+ * the round's candidate, every later voter that holds its fingerprint is compared with it bit for bit (as a bitmap over the round's
+ * hot slots; nothing is counted on fingerprints alone) and counted.  What R/FastPaxos.java:141-150 keeps per proposal is a count:
+ * a tile's delivered records and node lists are gone with the next tile; every receiver's announce batch, getNumProposals(),
+ * proposal size and fingerprint stay (rapid_sim_results with n_receivers = the whole population; rapid_sim_proposal for the
+ * receivers of the last tile).  The round index is built once; no stream synchronisation between tiles.  With a communicator
+ * every rank takes its own receivers this way and ONE all-gather at the end merges the ranks' accumulated answers (as
+ * rapid_sim_count_votes does for populations held in one launch).  If the candidate ends without a quorum although the voters are
+ * not unanimous, the exact plurality is owed: the receivers' fingerprints (summed over the ranks as a positional histogram) bound
+ * what any proposal can have; below the quorum nothing is decided, otherwise the tiles are taken once more with the proposal of
+ * the winning fingerprint as the candidate (the deliveries are a function of the seed: the same streams again).
+ * tile_receivers: receivers per launch (0 = sixteen waves' worth per CU); the tile's stream buffer -- tile_receivers x
+ * batch_off[n_batches] records of 8 (RAPID_GEN_RESOLVED) or 20 bytes (RAPID_GEN_BOUNDARY) -- is the only place a delivered record
+ * of the round ever exists.  The library makes the copies itself and vouches for them (rapid_sim_trust_alert_copies is implied).
+ * rapid_sim_round_tiled_info: out = {wall time of the last tiled round in ms, tiles launched, passes over the population (1, or 2
+ * after an exact-plurality pass), records delivered / 10^6}. */
+int rapid_sim_round_tiled(rapid_engine* h, const rapid_alert_record* alerts, const int64_t* batch_off, int32_t n_batches,
+                          const uint32_t* batch_keep, const int32_t* receivers, int32_t n_receivers, int32_t tile_receivers,
+                          uint64_t seed, int32_t format, rapid_round_result* out);
+int rapid_sim_round_tiled_info(rapid_engine* h, double out[4]);
+
 /* ---- decideViewChange (R/MembershipService.java:385-430) -----------------------------------------------
  * members in `cut` are removed (ringDelete), non-members are added (ringAdd with their registered NodeId);
  * rings, tables and the configuration id are rebuilt on the GPU; detector state of the population is cleared. */

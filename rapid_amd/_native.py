@@ -189,6 +189,8 @@ def _signatures():
         "rapid_sim_set_alert_set_device": (i32, [vp, p, u64, i64]),
         "rapid_sim_attach_streams_device": (i32, [vp, p, u64, p, i32]),
         "rapid_sim_generate": (i32, [vp, p, p, i32, p, p, i32, u64, i32]),
+        "rapid_sim_round_tiled": (i32, [vp, p, p, i32, p, p, i32, i32, u64, i32, C.POINTER(RoundResult)]),
+        "rapid_sim_round_tiled_info": (i32, [vp, p]),
         "rapid_sim_tally": (i32, [vp]),
         "rapid_sim_results": (i32, [vp, p, p, p, p, i32]),
         "rapid_sim_proposal": (i32, [vp, i32, p, i32, pi32]),

@@ -207,6 +207,13 @@ struct rapid_engine {
     bool tables_in_lds = true;
     int num_cus = 256;
 
+    // ---- a round taken tile by tile (rapid_sim_round_tiled) ----
+    long long out_base = 0;      // receiver offset of the running tile in the per-receiver result arrays (0 outside a tiled round)
+    int tiled_total = 0;         // receivers of the last tiled round (its per-receiver results cover all of them), 0: none
+    int tiled_last_base = 0, tiled_last_n = 0;  // the tile whose proposals are still resident (rapid_sim_proposal)
+    DevBuf<unsigned long long> d_vacc;  // vote accumulator: acc[8] | candidate bitmap | candidate list (vote_kernels.h)
+    double tiled_ms[4] = {0, 0, 0, 0};  // the last tiled round: total wall, tiles, passes, records delivered / 1e6
+
     // ---- votes ----
     DevBuf<unsigned long long> d_hist, d_winner, d_mm, d_mismatch, d_voteback, d_gather;
     DevBuf<int> d_ref;
@@ -723,6 +730,7 @@ static int await_mail(rapid_engine* h, int word_index, unsigned int want) {
 static size_t stats_words(const rapid_engine* h) { return (size_t)8 * (size_t)std::max(h->num_cus, 1) * 4 + 8; }
 
 bool tally_is_trusted(const rapid_engine* h);
+int ensure_tally_attrs(rapid_engine* h);
 
 int build_round_index(rapid_engine* h) {
     const int N = h->n_nodes, K = h->cfg.K, L = h->cfg.L;
@@ -881,7 +889,7 @@ int build_round_index(rapid_engine* h) {
     int best_w = 1;
     long long best_blocks = 0;
     double best_cost = 1e300;
-    int w_cap = rapid::tally_max_waves(h->dict_mode, tally_is_trusted(h), h->rec_fmt);  // (what decides the instantiation is known by now)
+    int w_cap = rapid::tally_max_waves(h->dict_mode, tally_is_trusted(h), h->rec_fmt, h->packed);  // (what decides the instantiation is known by now)
     if (const char* e = env_knob("RAPID_TALLY_WAVES")) w_cap = std::max(1, std::min(w_cap, atoi(e)));  // profiling knob
     const double sat = 7.0;
     for (int w = 1; w <= w_cap; ++w) {
@@ -947,10 +955,10 @@ int launch_tally(rapid_engine* h) {
     p.idx.pairs = h->d_adj.p;
     p.idx.n_hot = h->n_hot;
     p.idx.n_adj = h->n_adj;
-    p.emit_batch = h->d_emit.p;
-    p.num_proposals = h->d_nprop.p;
-    p.prop_count = h->d_pcount.p;
-    p.fingerprint = h->d_fp.p;
+    p.emit_batch = h->d_emit.p + h->out_base;  // (a tiled round: the running tile's place in the round's per-receiver results)
+    p.num_proposals = h->d_nprop.p + h->out_base;
+    p.prop_count = h->d_pcount.p + h->out_base;
+    p.fingerprint = h->d_fp.p + h->out_base;
     p.props = h->d_props.p;
     p.prop_cap = h->max_cut;
     p.stats = h->d_stats.p;  // [grid_blocks][8]
@@ -1021,6 +1029,18 @@ int prepare_tally(rapid_engine* h) {
         if (rc) return rc;
         h->stats_fresh = true;
     }
+    if (int rc = ensure_tally_attrs(h)) return rc;
+    const size_t R = (size_t)std::max(h->n_receivers, 1);
+    HIPCHK(h, h->d_emit.ensure(R));
+    HIPCHK(h, h->d_nprop.ensure(R));
+    HIPCHK(h, h->d_pcount.ensure(R));
+    HIPCHK(h, h->d_fp.ensure(R));
+    HIPCHK(h, h->d_props.ensure(R * (size_t)h->max_cut));
+    HIPCHK(h, h->d_next.ensure(4));
+    return RAPID_OK;
+}
+
+int ensure_tally_attrs(rapid_engine* h) {
     if (!h->lds_attr_set) {  // once per engine: every instantiation may use the whole 160 KiB of LDS
         using namespace rapid;
         const void* kernels[12] = {reinterpret_cast<const void*>(tally_population_kernel<kDictResolved, false, kFmtResident, true>),
@@ -1038,13 +1058,6 @@ int prepare_tally(rapid_engine* h) {
         for (const void* k : kernels) HIPCHK(h, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         h->lds_attr_set = true;
     }
-    const size_t R = (size_t)std::max(h->n_receivers, 1);
-    HIPCHK(h, h->d_emit.ensure(R));
-    HIPCHK(h, h->d_nprop.ensure(R));
-    HIPCHK(h, h->d_pcount.ensure(R));
-    HIPCHK(h, h->d_fp.ensure(R));
-    HIPCHK(h, h->d_props.ensure(R * (size_t)h->max_cut));
-    HIPCHK(h, h->d_next.ensure(4));
     return RAPID_OK;
 }
 
@@ -1116,6 +1129,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_gen_res.release(); h->d_gen_keep.release(); h->d_gen_boff.release(); h->d_gen_rx.release();
     h->d_ids_hi2.release(); h->d_ids_lo2.release(); h->d_ids_new.release(); h->d_cfg_partial.release(); h->d_chunk_kept.release();
     h->d_bitmaps.release();
+    h->d_vacc.release();
     h->d_gone.release();
     h->d_edges.release(); h->d_edge_mask.release();
     h->d_joiners.release(); h->d_join_nodes.release(); h->d_join_vals.release(); h->d_join_keys.release(); h->d_join_skeys.release();
@@ -1580,6 +1594,8 @@ int rapid_cd_clear(rapid_cd* cd) {
 // records: the PCIe transfer; device records: a device-to-device copy, because the caller's buffer is only borrowed for the
 // call), or no copy at all when the caller leaves them in place (rapid_sim_attach_streams_device).
 static void streams_replaced(rapid_engine* h, int n_receivers, long long n_rec) {
+    h->out_base = 0;
+    h->tiled_total = 0;
     h->n_receivers = n_receivers;
     h->n_records_total = n_rec;
     h->n_alert_set = -1;
@@ -1874,6 +1890,7 @@ int rapid_sim_tally(rapid_engine* h) {
     if (!h) return RAPID_EINVAL;
     int rc = use_device(h);
     if (rc) return rc;
+    if (h->tiled_total) return fail(h, RAPID_ESTATE, "the last round was taken tile by tile: load, attach or generate streams first");
     h->tally_votes_valid = false;  // (set again by the launch below; a call that launches nothing must not leave an older launch's statistics valid)
     if ((rc = prepare_tally(h))) return rc;
     if (!h->stats_fresh) HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * ((size_t)std::max(h->grid_blocks, 1) + 1), h->stream));
@@ -1937,13 +1954,21 @@ int rapid_sim_proposal(rapid_engine* h, int32_t receiver, int32_t* out, int32_t 
     if (receiver < 0 || receiver >= h->n_receivers) return fail(h, RAPID_EINVAL, "receiver out of range");
     int rc;
     if ((rc = use_device(h)) || (rc = ensure_host_keys0(h))) return rc;
+    // (after a tiled round the node lists of the LAST tile are what is still resident; every receiver's counts and fingerprint are)
+    int local = receiver;
+    if (h->tiled_total) {
+        if (receiver < h->tiled_last_base || receiver >= h->tiled_last_base + h->tiled_last_n)
+            return fail(h, RAPID_ESTATE, "receiver %d's proposal went with its tile; receivers [%d, %d) of the last tile are resident", receiver,
+                        h->tiled_last_base, h->tiled_last_base + h->tiled_last_n);
+        local = receiver - h->tiled_last_base;
+    }
     int cnt = 0;
     HIPCHK(h, hipMemcpyAsync(&cnt, h->d_pcount.p + receiver, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (cnt < 0) return fail(h, RAPID_ECAPACITY, "receiver %d's proposal exceeds max_cut=%d", receiver, h->max_cut);
     std::vector<int> v((size_t)cnt);
     if (cnt)
-        HIPCHK(h, hipMemcpy(v.data(), h->d_props.p + (size_t)receiver * h->max_cut, sizeof(int) * (size_t)cnt,
+        HIPCHK(h, hipMemcpy(v.data(), h->d_props.p + (size_t)local * h->max_cut, sizeof(int) * (size_t)cnt,
                             hipMemcpyDeviceToHost));
     sort_ring0(h, v);
     return copy_list(h, v.data(), cnt, out, cap, n_out);
@@ -2001,6 +2026,7 @@ static void begin_round_result(rapid_engine* h, rapid_round_result* out) {
 int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
     if (!h || !out) return RAPID_EINVAL;
     if (!h->tallied) return fail(h, RAPID_ESTATE, "no tally has run");
+    if (h->tiled_total) return fail(h, RAPID_ESTATE, "the votes of a tiled round are counted, tile by tile, by rapid_sim_round_tiled itself");
     int rc;
     // (the ring-0 keys for the order of a decided cut: a host copy that outlives view changes -- mirroring every table of the
     // view here cost the first round after each view change 0.12 ms at 10^4 nodes, and 200 MB of copies at 10^6)
@@ -2199,6 +2225,198 @@ int rapid_debug_vote_merge(rapid_engine* h, const void* segments, int32_t n_rank
 }
 
 #endif  // RAPID_TEST_BUILD
+
+// ---- a round over a population that does not fit one launch ------------------------------------------------------------------
+int rapid_sim_round_tiled(rapid_engine* h, const rapid_alert_record* alerts, const int64_t* batch_off, int32_t n_batches,
+                          const uint32_t* batch_keep, const int32_t* receivers, int32_t n_receivers, int32_t tile_receivers,
+                          uint64_t seed, int32_t format, rapid_round_result* out) {
+    if (!h || !out || !batch_off || n_batches < 0 || n_receivers < 0 || (n_receivers > 0 && !receivers) || tile_receivers < 0) return RAPID_EINVAL;
+    if (format != RAPID_GEN_RESOLVED && format != RAPID_GEN_BOUNDARY) return fail(h, RAPID_EINVAL, "unknown record format %d", format);
+    if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const long long A = batch_off[n_batches];
+    if (batch_off[0] != 0 || A < 0 || (A > 0 && !alerts)) return fail(h, RAPID_EINVAL, "bad batch offsets");
+    for (int b = 0; b < n_batches; ++b)
+        if (batch_off[b + 1] <= batch_off[b]) return fail(h, RAPID_EINVAL, "batch %d is empty or the offsets decrease", b);
+    if (A > rapid::kMaxStreamRecords) return fail(h, RAPID_ECAPACITY, "%lld alerts per receiver; at most %lld", A, (long long)rapid::kMaxStreamRecords);
+    if ((rc = ensure_host_keys0(h)) || (rc = ensure_mailbox(h))) return rc;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const bool boundary = format == RAPID_GEN_BOUNDARY;
+    const size_t stride = boundary ? 20 : 8;
+    hipStream_t st = h->stream;
+    const int R = n_receivers;
+    // a tile = the receivers of one launch: sixteen waves' worth per CU unless the caller says otherwise, bounded by what 2^31 bytes
+    // of boundary records hold (the tile's stream buffer is the only place a delivered record of this round ever exists)
+    long long T = tile_receivers > 0 ? tile_receivers : (long long)16 * h->num_cus;
+    T = std::max<long long>(1, std::min<long long>(T, std::max(R, 1)));
+    bool clean = true;
+    for (long long i = 0; i < A; ++i) clean = clean && alerts[i].cfg_id == h->config_id && alerts[i].dst < (uint32_t)h->n_nodes;
+    // nothing of the engine's stream state survives into the round, and a failure on the way leaves "no streams loaded"
+    h->streams_loaded = false;
+    h->index_valid = false;
+    h->tallied = false;
+    h->have_decision = false;
+    h->tiled_total = 0;
+    h->out_base = 0;
+    HIPCHK(h, h->d_alert_set.ensure((size_t)std::max<long long>(A, 1) * 20 + 16));
+    HIPCHK(h, h->d_gen_boff.ensure((size_t)n_batches + 1));
+    HIPCHK(h, h->d_gen_rx.ensure((size_t)std::max(R, 1)));
+    if (batch_keep) HIPCHK(h, h->d_gen_keep.ensure((size_t)std::max(n_batches, 1)));
+    if (A) HIPCHK(h, hipMemcpyAsync(h->d_alert_set.p, alerts, (size_t)A * 20, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemcpyAsync(h->d_gen_boff.p, batch_off, sizeof(long long) * ((size_t)n_batches + 1), hipMemcpyHostToDevice, st));
+    if (R) HIPCHK(h, hipMemcpyAsync(h->d_gen_rx.p, receivers, sizeof(int) * (size_t)R, hipMemcpyHostToDevice, st));
+    if (batch_keep && n_batches) HIPCHK(h, hipMemcpyAsync(h->d_gen_keep.p, batch_keep, sizeof(unsigned int) * (size_t)n_batches, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipStreamSynchronize(st));  // (borrowed inputs)
+    HIPCHK(h, h->d_records_own.ensure((size_t)T * (size_t)A * stride + 64));
+    HIPCHK(h, h->d_rec_off_own.ensure((size_t)T + 1));
+    hipLaunchKernelGGL(rapid::gen_offsets_kernel, dim3(grid_for(T + 1, 256)), dim3(256), 0, st, h->d_rec_off_own.p, (int)T, A);  // (the same for every tile)
+    h->d_records = h->d_records_own.p;
+    h->records_bytes = (unsigned long long)T * (unsigned long long)A * stride;
+    h->d_rec_off = h->d_rec_off_own.p;
+    h->offsets_on_device_only = false;
+    h->rec_fmt = boundary ? rapid::kFmtBoundary : rapid::kFmtResident;
+    h->n_receivers = (int)T;  // (what the launch geometry is chosen for)
+    h->n_records_total = T * A;
+    h->n_alert_set = A;
+    h->d_alerts = h->d_alert_set.p;
+    h->gen_cfg_id = h->config_id;
+    h->gen_clean = clean && batch_keep == nullptr;
+    // the deliveries are made here, by the library, from the declared alerts: it can vouch for them being copies itself
+    h->trust_copies = true;
+    HIPCHK(h, h->d_errflags.ensure(2));
+    HIPCHK(h, h->d_stats.ensure(stats_words(h)));
+    const size_t res_words = 10, ref_len = (size_t)h->max_cut + 1;
+    const size_t back_bytes = res_words * 8 + ref_len * sizeof(int), seg_words = (back_bytes + 7) / 8;
+    HIPCHK(h, h->d_voteback.ensure(seg_words));
+    if ((rc = build_round_index(h))) return rc;  // once per round: every tile is a launch over the same alert set (also zeroes flags / statistics)
+    if ((rc = ensure_tally_attrs(h))) return rc;
+    if (!boundary && A > 0) {
+        HIPCHK(h, h->d_gen_res.ensure((size_t)A));
+        hipLaunchKernelGGL(rapid::gen_resolve_alerts_kernel, dim3(grid_for(A, 256)), dim3(256), 0, st, h->d_alert_set.p, A, (long long)h->config_id,
+                           (unsigned int)h->n_nodes, h->d_entries.p, h->d_gen_res.p);
+    }
+    // per-receiver results for the whole population; node lists and bitmaps for one tile
+    const size_t Rz = (size_t)std::max(R, 1);
+    HIPCHK(h, h->d_emit.ensure(Rz));
+    HIPCHK(h, h->d_nprop.ensure(Rz));
+    HIPCHK(h, h->d_pcount.ensure(Rz));
+    HIPCHK(h, h->d_fp.ensure(Rz));
+    HIPCHK(h, h->d_props.ensure((size_t)T * (size_t)h->max_cut));
+    HIPCHK(h, h->d_next.ensure(4));
+    const int words = std::max((h->n_hot + 63) / 64, 1);
+    HIPCHK(h, h->d_bitmaps.ensure((size_t)T * (size_t)words));
+    const size_t acc_words = (size_t)rapid::kVoteAccWords + (size_t)words + ((size_t)h->max_cut + 1) / 2 + 1;
+    HIPCHK(h, h->d_vacc.ensure(acc_words));
+    unsigned long long* const acc = h->d_vacc.p;
+    unsigned long long* const acc_bits = acc + rapid::kVoteAccWords;
+    int* const acc_list = reinterpret_cast<int*>(acc_bits + words);
+    unsigned long long* const d_res = h->d_voteback.p;  // (the tally's per-launch vote statistics land here too, and are consumed tile by tile)
+    HIPCHK(h, h->d_gather.ensure(seg_words * (size_t)std::max(h->n_ranks, 1) + seg_words));
+    unsigned long long* const d_block = h->d_gather.p + seg_words * (size_t)std::max(h->n_ranks, 1);  // this rank's answer block
+    HIPCHK(h, h->d_hist.ensure((size_t)rapid::kVoteBuckets + 2));
+    HIPCHK(h, h->d_mm.ensure(8));
+    HIPCHK(h, h->d_winner.ensure(4));
+    begin_round_result(h, out);
+    unsigned long long* const hres = h->h_pinned;
+    const unsigned long long my_tag = ~(unsigned long long)h->rank;
+
+    unsigned long long target = 0ull;  // pass 0: the first voter's proposal is the candidate; a counting pass: the proposal with this fingerprint
+    int passes = 0, tiles = 0;
+    int verdict = RAPID_OK;
+    for (int pass = 0; pass < 3; ++pass) {
+        ++passes;
+        HIPCHK(h, hipMemsetAsync(acc, 0, acc_words * 8, st));
+        if (target != 0ull) HIPCHK(h, hipMemcpyAsync(acc + 6, &target, 8, hipMemcpyHostToDevice, st));  // (pageable, 8 bytes: staged by the runtime)
+        for (long long base = 0; base < R; base += T) {
+            const int n = (int)std::min<long long>(T, R - base);
+            ++tiles;
+            hipLaunchKernelGGL(rapid::gen_streams_kernel, dim3((unsigned)n), dim3(256), 0, st, h->d_gen_res.p, h->d_alert_set.p, h->d_gen_boff.p, n_batches,
+                               batch_keep ? h->d_gen_keep.p : (const unsigned int*)nullptr, h->d_gen_rx.p + base, A, (unsigned long long)seed,
+                               h->d_records_own.p, boundary ? 1 : 0);
+            h->n_receivers = n;
+            h->out_base = base;
+            if ((rc = launch_tally(h))) return rc;
+            hipLaunchKernelGGL(rapid::vote_acc_pick_kernel, dim3(1), dim3(1024), 0, st, d_res, h->d_fp.p + base, h->d_pcount.p + base, h->d_props.p, h->max_cut,
+                               h->d_bitmaps.p, words, n, h->d_errflags.p, acc, acc_bits, acc_list);
+            hipLaunchKernelGGL(rapid::vote_acc_count_kernel, dim3(std::max(1u, grid_for((long long)n * 64, 1024))), dim3(1024), 0, st, h->d_fp.p + base,
+                               h->d_pcount.p + base, h->d_bitmaps.p, words, n, acc, acc_bits);
+            h->tiled_last_base = (int)base;
+            h->tiled_last_n = n;
+        }
+        h->tally_votes_valid = false;
+        hipLaunchKernelGGL(rapid::vote_acc_finish_kernel, dim3(8), dim3(256), 0, st, acc, acc_list, h->max_cut, d_block, reinterpret_cast<int*>(d_block + res_words));
+        HIPCHK(h, hipGetLastError());
+        const unsigned long long* ans = nullptr;
+        bool settled = false;
+        if (h->comm) {  // the round's one collective: every rank's block to everybody, merged identically everywhere
+            NCCLCHK(h, ncclAllGather(d_block, h->d_gather.p, seg_words, ncclUint64, h->comm, st));
+            hipLaunchKernelGGL(rapid::vote_merge_kernel, dim3(1), dim3(256), 0, st, h->d_gather.p, h->n_ranks, (int)seg_words, (int)res_words, h->max_cut,
+                               (long long)out->quorum, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
+                               reinterpret_cast<volatile unsigned int*>(h->d_mail) + 14, ++h->mail_seq);
+            HIPCHK(h, hipGetLastError());
+            if ((rc = await_mail(h, 14, h->mail_seq))) return rc;
+            ans = reinterpret_cast<const unsigned long long*>(h->h_mail + 64);
+            settled = ans[9] == 1ull;
+        } else {
+            HIPCHK(h, hipMemcpyAsync(hres, d_block, back_bytes, hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+            ans = hres;
+            const unsigned long long votes = ans[1], voters = ans[2];
+            settled = voters == 0ull || votes == voters || (long long)votes >= (long long)out->quorum || ans[6] != 0ull;
+        }
+        if (settled) {
+            verdict = decode_vote_answer(h, ans, reinterpret_cast<const int*>(ans + res_words), out);
+            break;
+        }
+        // The candidate has no quorum and the voters are not unanimous: the exact plurality is owed (R/FastPaxos.java:141-150 counts
+        // every distinct proposal).  Every receiver's fingerprint is still here: their positional histogram (summed over the ranks)
+        // says how many votes the most popular proposal can have at most; below the quorum nothing is decided, whatever it is.
+        // Otherwise the tiles are taken once more with THAT proposal -- the one holding the winning bucket's fingerprint -- as the
+        // candidate, its voters verified bit for bit like the first candidate's.
+        unsigned long long win[4] = {0, 0, 0, 0}, mm[2] = {0, 0};
+        bool found = false;
+        for (unsigned long long salt = 0; salt < 4 && !found; ++salt) {
+            HIPCHK(h, hipMemsetAsync(h->d_hist.p, 0, ((size_t)rapid::kVoteBuckets + 2) * 8, st));
+            HIPCHK(h, hipMemsetAsync(h->d_mm.p, 0, 64, st));
+            if (R) hipLaunchKernelGGL(rapid::vote_histogram_kernel, dim3(grid_for(R, 256)), dim3(256), 0, st, h->d_fp.p, h->d_pcount.p, R, salt, h->d_hist.p);
+            if (h->comm) NCCLCHK(h, ncclAllReduce(h->d_hist.p, h->d_hist.p, (size_t)rapid::kVoteBuckets + 2, ncclUint64, ncclSum, h->comm, st));
+            hipLaunchKernelGGL(rapid::vote_winner_kernel, dim3(1), dim3(1024), 0, st, h->d_hist.p, h->d_winner.p);
+            if (R) hipLaunchKernelGGL(rapid::vote_bucket_minmax_kernel, dim3(grid_for(R, 256)), dim3(256), 0, st, h->d_fp.p, h->d_pcount.p, R, salt, h->d_winner.p, h->d_mm.p, my_tag);
+            if (h->comm) NCCLCHK(h, ncclAllReduce(h->d_mm.p, h->d_mm.p, 2, ncclUint64, ncclMax, h->comm, st));
+            HIPCHK(h, hipMemcpyAsync(win, h->d_winner.p, sizeof win, hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipMemcpyAsync(mm, h->d_mm.p, sizeof mm, hipMemcpyDeviceToHost, st));
+            HIPCHK(h, hipStreamSynchronize(st));
+            out->votes_total = (int64_t)win[2];
+            out->votes_winner = (int64_t)win[1];
+            out->distinct_local = (int32_t)std::min<unsigned long long>(win[3], 0x7FFFFFFFull);
+            if ((long long)win[1] < (long long)out->quorum) {  // no proposal can have a quorum
+                found = true;
+                target = 0ull;
+            } else if (mm[0] == ~mm[1]) {  // the winning bucket holds one fingerprint: the proposal to count
+                found = true;
+                target = mm[0];
+            }
+        }
+        if (!found) return fail(h, RAPID_ECOLLISION, "winning vote bucket stayed impure under 4 salts");
+        if (target == 0ull || pass == 2) break;  // undecided (pass 2 cannot get here with a quorum left uncounted)
+    }
+    h->out_base = 0;
+    h->n_receivers = R;
+    h->tiled_total = R;
+    h->tallied = true;
+    h->tiled_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    h->tiled_ms[1] = tiles;
+    h->tiled_ms[2] = passes;
+    h->tiled_ms[3] = (double)R * (double)A * passes / 1e6;
+    return verdict == kVoteNextSalt ? fail(h, RAPID_ECOLLISION, "the accumulated answer is impure") : verdict;
+}
+
+int rapid_sim_round_tiled_info(rapid_engine* h, double out[4]) {
+    if (!h || !out) return RAPID_EINVAL;
+    for (int i = 0; i < 4; ++i) out[i] = h->tiled_ms[i];
+    return RAPID_OK;
+}
 
 int rapid_apply_cut(rapid_engine* h, const int32_t* cut, int32_t n, int64_t* new_config_id) {
     if (!h || n < 0 || (n > 0 && !cut)) return RAPID_EINVAL;

@@ -583,6 +583,9 @@ enum { kApplied = 0, kWitnessFails = 1, kNotFastable = 2 };  // outcome of a fas
 #ifndef RAPID_SETS_BOUNDARY
 #define RAPID_SETS_BOUNDARY 2
 #endif
+#ifndef RAPID_SETS_PACKED
+#define RAPID_SETS_PACKED 4
+#endif
 // cache policy of the two loads of a boundary record (0 = default, 2 = nt).  Both touch the same cache lines: with nt the second
 // one fetches them from L2 again (measured, scripts/micro/boundary_shapes.hip: 5.4 TB/s against 6.1 TB/s for this shape;
 // the kernel: 0.436 -> 0.383 ms on C3b), whereas a resident 8-byte record is loaded once and streams best with nt
@@ -596,8 +599,12 @@ enum { kApplied = 0, kWitnessFails = 1, kNotFastable = 2 };  // outcome of a fas
 // Waves per workgroup an instantiation may be launched with (= its register budget: 16 waves per CU leave 128 VGPRs per wave).
 // The per-delivery filter over compressed tables on boundary records needs a few more than that: twelve waves (168 VGPRs)
 // instead of spills inside the window loop.
-__host__ __device__ constexpr int tally_max_waves(int dict_mode, bool trusted, int fmt) {
-    return (fmt == kFmtBoundary && dict_mode == kDictCompressed && !trusted) ? 12 : kMaxWavesPerBlock;
+// Packed detector state (rounds with thousands of hot subjects): the LDS holds a handful of receivers per CU whatever the register
+// budget, so those instantiations are compiled for eight waves per workgroup -- 256 VGPRs per wave -- and keep more windows of the
+// stream in flight per wave instead (RAPID_SETS_PACKED): with one or two waves per SIMD the bytes in flight are what a wave itself
+// has requested.
+__host__ __device__ constexpr int tally_max_waves(int dict_mode, bool trusted, int fmt, bool packed = false) {
+    return packed ? 8 : (fmt == kFmtBoundary && dict_mode == kDictCompressed && !trusted) ? 12 : kMaxWavesPerBlock;
 }
 
 // RAPID_WAVES_PER_EU (measurement knob): asks the compiler for a register budget that lets that many waves share a SIMD (5: 96
@@ -608,7 +615,7 @@ __host__ __device__ constexpr int tally_max_waves(int dict_mode, bool trusted, i
 #define RAPID_TALLY_OCCUPANCY
 #endif
 template <int kDictMode, bool kTrusted, int kFmt = kFmtResident, bool kPacked = false>
-__global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RAPID_TALLY_OCCUPANCY void tally_population_kernel(TallyParams p) {
+__global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked) * 64) RAPID_TALLY_OCCUPANCY void tally_population_kernel(TallyParams p) {
     static_assert(!kPacked || kDictMode == kDictMemory || kDictMode == kDictResolved, "packed detector state: dictionary in memory, or none");
     static_assert(kFmt == kFmtResident || kDictMode != kDictResolved, "a boundary record carries its subject, not an entry");
     constexpr bool kTablesInLds = kDictMode == kDictDirect;
@@ -946,7 +953,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
     // whole memory latency per window as soon as a window's tally is shorter than that, which it is since the fast window
     // shrank to ~100 instructions: 15 waves x 2 KiB per CU are not enough bytes in flight for 8 TB/s).  Three sets of 8 registers.
     // (boundary records: two sets of 16 registers -- 10 KiB of stream in flight per wave against 6 KiB of the resident format)
-    constexpr int kSets = kFmt == kFmtBoundary ? RAPID_SETS_BOUNDARY : RAPID_SETS;
+    constexpr int kSets = kPacked ? RAPID_SETS_PACKED : kFmt == kFmtBoundary ? RAPID_SETS_BOUNDARY : RAPID_SETS;
     static_assert(kSets >= 2 && kSets <= 6, "window sets");
     constexpr unsigned int kWinBytes = (unsigned int)(kWin * kStride);
     Win S[kSets];
@@ -1039,18 +1046,43 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt) * 64) RA
             wave_lds_fence();
             int run = 0;
             unsigned int best = 0xFFFFFFFFu;  // bound << 16 | slot
-            for (int i0 = 0; i0 < n_hot; i0 += 2 * kWave) {  // two slots per lane and step: two LDS round trips in flight, half the turns
-                const int ia = i0 + lane, ib = i0 + kWave + lane;
-                const bool ina = ia < n_hot, inb = ib < n_hot;
-                const unsigned int ma = ina ? d.load(ia) : 0u, mb = inb ? d.load(ib) : 0u;
-                const int ca = d.count(ma), cb = d.count(mb);
-                const bool prea = ina && ca >= d.L && ca < d.H, preb = inb && cb >= d.L && cb < d.H;
-                run += __popcll(wave_ballot(prea)) + __popcll(wave_ballot(preb));
-                const unsigned int ama = prea ? smask_of((unsigned int)ia) : 0u, amb = preb ? smask_of((unsigned int)ib) : 0u;
-                const int bounda = d.count(ma | ama), boundb = d.count(mb | amb);
-                const unsigned int keya = (prea && bounda < d.H) ? ((unsigned int)bounda << 16) | (unsigned int)ia : 0xFFFFFFFFu;
-                const unsigned int keyb = (preb && boundb < d.H) ? ((unsigned int)boundb << 16) | (unsigned int)ib : 0xFFFFFFFFu;
-                best = min(best, min(keya, keyb));
+            // Per-slot masks in memory (packed detector state: thousands of hot subjects): the masks of kSweepBatch steps are requested
+            // together and for every slot of the step, whether or not it turns out to be in preProposal -- coalesced 128-byte loads, all
+            // in flight at once.  Asked for slot by slot under the "in preProposal" mask, every step of the sweep waited out a memory
+            // round trip of its own: 118 dependent round trips per sweep at 15,000 hot subjects, ~95,000 cycles, 16 % of a receiver's
+            // time at 10^6 nodes (profiles/r05_c5_phase_before.txt).
+            constexpr int kSweepBatch = slot_tables_in_lds ? 1 : 4;
+            for (int i0 = 0; i0 < n_hot; i0 += 2 * kWave * kSweepBatch) {  // two slots per lane and step: two LDS round trips in flight, half the turns
+                unsigned int pre_a[kSweepBatch], pre_b[kSweepBatch];
+                if constexpr (!slot_tables_in_lds) {
+#pragma unroll
+                    for (int u = 0; u < kSweepBatch; ++u) {
+                        const int ia = i0 + u * 2 * kWave + lane, ib = ia + kWave;
+                        pre_a[u] = ia < n_hot ? (unsigned int)p.idx.smask[ia] : 0u;
+                        pre_b[u] = ib < n_hot ? (unsigned int)p.idx.smask[ib] : 0u;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kSweepBatch; ++u) {
+                    const int ia = i0 + u * 2 * kWave + lane, ib = ia + kWave;
+                    const bool ina = ia < n_hot, inb = ib < n_hot;
+                    const unsigned int ma = ina ? d.load(ia) : 0u, mb = inb ? d.load(ib) : 0u;
+                    const int ca = d.count(ma), cb = d.count(mb);
+                    const bool prea = ina && ca >= d.L && ca < d.H, preb = inb && cb >= d.L && cb < d.H;
+                    run += __popcll(wave_ballot(prea)) + __popcll(wave_ballot(preb));
+                    unsigned int ama, amb;
+                    if constexpr (slot_tables_in_lds) {
+                        ama = prea ? smask_of((unsigned int)ia) : 0u;
+                        amb = preb ? smask_of((unsigned int)ib) : 0u;
+                    } else {
+                        ama = prea ? pre_a[u] : 0u;
+                        amb = preb ? pre_b[u] : 0u;
+                    }
+                    const int bounda = d.count(ma | ama), boundb = d.count(mb | amb);
+                    const unsigned int keya = (prea && bounda < d.H) ? ((unsigned int)bounda << 16) | (unsigned int)ia : 0xFFFFFFFFu;
+                    const unsigned int keyb = (preb && boundb < d.H) ? ((unsigned int)boundb << 16) | (unsigned int)ib : 0xFFFFFFFFu;
+                    best = min(best, min(keya, keyb));
+                }
             }
             s.running = run;
             running_exact = !owed;  // with nothing owed the state here is the reference's

@@ -442,6 +442,123 @@ __global__ __launch_bounds__(1024) void vote_count_local_kernel(const unsigned l
     if (t == 0) ref[0] = n;
 }
 
+// ---- votes accumulated ACROSS LAUNCHES: a population taken tile by tile (rapid_sim_round_tiled; BASELINE configs[4]: 10^6 receivers
+// do not fit one launch, and the fast quorum N - floor((N-1)/4) needs three quarters of them) -------------------------------------
+// The round's accumulator lives in device memory for the whole round:
+//   acc[0] = a candidate proposal has been picked, acc[1] = verified votes for it, acc[2] = voters so far, acc[3] = voters that share
+//   the candidate's fingerprint but not its proposal (a collision: reported, never counted), acc[4] = the candidate's fingerprint,
+//   acc[5] = its size (-1: larger than prop_cap), acc[6] = the fingerprint the candidate must have (0: the first voter's proposal),
+//   acc[7] = the tally's sticky error word; then the candidate as a bitmap over the round's hot slots (acc_bits[bits_words]) and as
+//   a node list (acc_list[prop_cap]).
+// After every tile's tally: vote_acc_pick_kernel (one workgroup) adds the tile's voters and, while there is no candidate, takes the
+// tile's lowest voter (tile_res[0], gathered by the tally kernel itself) -- or, in a counting pass for a given fingerprint, the lowest
+// voter that holds it -- as the candidate; vote_acc_count_kernel then compares every voter of the tile that holds the candidate's
+// fingerprint with the candidate's BITMAP, word for word (slot -> node is injective within a round: equal bitmaps <=> equal
+// proposals; nothing is counted on fingerprints alone), one wave per receiver.  The tile's proposals are gone with the next tile;
+// what survives is the count -- which is all R/FastPaxos.java:141-150 keeps per proposal -- and every receiver's fingerprint
+// (for the exact plurality when the candidate has no quorum).
+constexpr int kVoteAccWords = 8;
+__global__ __launch_bounds__(1024) void vote_acc_pick_kernel(const unsigned long long* tile_res, const unsigned long long* fp, const int* prop_count,
+                                                             const int* props, int prop_cap, const unsigned long long* bits, int bits_words,
+                                                             int n_receivers, const unsigned int* tally_errors, unsigned long long* acc,
+                                                             unsigned long long* acc_bits, int* acc_list) {
+    __shared__ unsigned int s_rep;
+    const int t = (int)threadIdx.x, T = (int)blockDim.x;
+    const unsigned long long target = acc[6];
+    const bool have = acc[0] != 0ull;
+    if (t == 0) s_rep = 0xFFFFFFFFu;
+    __syncthreads();
+    if (!have) {
+        if (target == 0ull) {
+            if (t == 0 && tile_res[2] != 0ull) s_rep = (unsigned int)tile_res[0];
+        } else {  // the lowest voter of this tile that holds the wanted fingerprint
+            unsigned int best = 0xFFFFFFFFu;
+            for (int r = t; r < n_receivers; r += T)
+                if (prop_count[r] != 0 && fp[r] == target) best = min(best, (unsigned int)r);
+            if (best != 0xFFFFFFFFu) atomicMin(&s_rep, best);
+        }
+    }
+    __syncthreads();
+    const unsigned int rep = s_rep;
+    const bool pick = !have && rep < (unsigned int)n_receivers;
+    if (pick) {
+        const int n = prop_count[rep];
+        for (int i = t; i < bits_words; i += T) acc_bits[i] = bits[(long long)rep * bits_words + i];
+        for (int i = t; i < prop_cap; i += T) acc_list[i] = (n > 0 && i < n) ? props[(long long)rep * prop_cap + i] : 0;
+        if (t == 0) {
+            acc[4] = fp[rep];
+            acc[5] = (unsigned long long)(long long)(n < 0 ? -1 : n);
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        acc[2] += tile_res[2];
+        acc[7] |= (unsigned long long)tally_errors[0];
+        if (pick) {
+            __threadfence();
+            acc[0] = 1ull;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void vote_acc_count_kernel(const unsigned long long* fp, const int* prop_count, const unsigned long long* bits,
+                                                              int bits_words, int n_receivers, unsigned long long* acc,
+                                                              const unsigned long long* acc_bits) {
+    __shared__ unsigned int s_ok, s_bad;
+    if (threadIdx.x == 0) {
+        s_ok = 0u;
+        s_bad = 0u;
+    }
+    __syncthreads();
+    const int r = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63u);
+    const bool have = acc[0] != 0ull;
+    const unsigned long long cand = acc[4];
+    const bool voter = have && r < n_receivers && prop_count[r] != 0 && fp[r] == cand;
+    bool bad = false;
+    if (voter) {  // (the same for all lanes of the wave)
+        const unsigned long long* const mine = bits + (long long)r * bits_words;
+        for (int i0 = lane; i0 < bits_words; i0 += 256) {
+            unsigned long long a[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = i0 + 64 * j < bits_words ? mine[i0 + 64 * j] : 0ull;
+                b[j] = i0 + 64 * j < bits_words ? acc_bits[i0 + 64 * j] : 0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bad |= a[j] != b[j];
+        }
+    }
+    const bool wave_bad = __ballot(voter && bad) != 0ull;
+    if (lane == 0 && voter) atomicAdd(wave_bad ? &s_bad : &s_ok, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_ok) atomicAdd(&acc[1], (unsigned long long)s_ok);
+        if (s_bad) atomicAdd(&acc[3], (unsigned long long)s_bad);
+    }
+}
+
+// The round's answer block in the layout a rank contributes to the all-gather (res[res_words] + ref[1 + prop_cap]): what
+// vote_count_local_kernel + vote_verify_kernel leave for a population held in one launch.
+__global__ void vote_acc_finish_kernel(const unsigned long long* acc, const int* acc_list, int prop_cap, unsigned long long* res, int* ref) {
+    const long long n = (long long)acc[5];
+    const int len = acc[0] == 0ull ? 0 : (n < 0 ? -1 : (int)n);
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < prop_cap; i += (int)(gridDim.x * blockDim.x)) ref[1 + i] = i < len ? acc_list[i] : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long votes = acc[1], voters = acc[2], fpc = acc[0] != 0ull ? acc[4] : 0ull;
+        res[0] = 0ull;
+        res[1] = votes;
+        res[2] = voters;
+        res[3] = voters == 0ull ? 0ull : (votes == voters ? 1ull : 2ull);
+        res[4] = fpc;
+        res[5] = ~fpc;
+        res[6] = acc[3];
+        res[7] = votes;
+        res[8] = acc[7];
+        res[9] = 0ull;
+        ref[0] = len;
+    }
+}
+
 // Populations sharded over ranks: every rank settles its own voters first -- the candidate proposal (the winning bucket's
 // after a counting kernel, the lowest voter's when the statistics came from the tally kernel), its verified vote count
 // res[1] = res[7], the rank's voters res[2] -- ONE all-gather moves the ranks' answers (res[res_words] + ref[1 + prop_cap],

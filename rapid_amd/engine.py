@@ -339,6 +339,27 @@ class ClusterSimulation:
         if trust_copies:
             self.e._check(self.e._lib.rapid_sim_trust_alert_copies(self.e._h, 1))
 
+    def round_tiled(self, batches, receivers, seed, tile_receivers=0, keep=None, boundary=False):
+        """One round over a population that does not fit one launch (rapid_sim_round_tiled): the deliveries made tile by tile on
+        the device, every tile tallied, the fast-round votes accumulated across the tiles' launches.  -> RoundResult; afterwards
+        results() covers every receiver, decided_cut() the decision, proposal(r) the receivers of the last tile."""
+        recs = np.ascontiguousarray(batches.recs, dtype=ALERT_DTYPE)
+        off = np.ascontiguousarray(batches.off, dtype=np.int64)
+        rx = np.ascontiguousarray(receivers, dtype=np.int32)
+        kp = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint32)
+        assert kp is None or len(kp) == len(off) - 1
+        rr = RoundResult()
+        self.e._check(self.e._lib.rapid_sim_round_tiled(self.e._h, _addr(recs) if len(recs) else None, _addr(off), len(off) - 1, _addr(kp),
+                                                        _addr(rx) if len(rx) else None, len(rx), int(tile_receivers),
+                                                        C.c_uint64(int(seed) & ((1 << 64) - 1)), 1 if boundary else 0, C.byref(rr)))
+        self.n_receivers = len(rx)
+        return rr
+
+    def round_tiled_info(self):
+        t = np.zeros(4, dtype=np.float64)
+        self.e._check(self.e._lib.rapid_sim_round_tiled_info(self.e._h, _addr(t)))
+        return dict(wall_ms=float(t[0]), tiles=int(t[1]), passes=int(t[2]), records_delivered=int(round(t[3] * 1e6)))
+
     def read_records(self, first, n):
         """Testing aid: (subjects -- or, of generated resolved records, their dictionary entries --, core words) of n records."""
         subj = np.zeros(max(n, 1), dtype=np.uint32)

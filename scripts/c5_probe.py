@@ -49,16 +49,19 @@ for tag, path in libs.items():
         print("setup %.1f s: %d members, %d alerts in %d batches (+ %d late), %d receivers" % (
             time.time() - t0, n_mem, len(sc.batches.recs), sc.batches.n_batches, deliver_set.n_batches - sc.batches.n_batches, len(rx)), flush=True)
     sim = E.ClusterSimulation(eng)
-    sim.generate(deliver_set, rx, seed=7, trust_copies=True, boundary=True)
     n_rec = len(rx) * len(deliver_set.recs)
-    for knob, what in ((0, "as chosen"), (64, "filter per delivery")):
-        sim.set_force_exact(knob)
-        ms = sim.time_tally(reps)
-        info = sim.index_info(timed=False)
-        print("%-8s %-20s tally %.4f ms  %.3e records/s  %.1f %% of 8 TB/s on 20 B  (dict mode %d, %d waves x %d workgroups, %d hot, prevalidated %d)" % (
-            tag, what, ms, n_rec / ms * 1e3, 100 * 20 * n_rec / ms / 1e6 / 8000, info["dict_mode"], info["waves_per_workgroup"], info["workgroups"],
-            info["hot_subjects"], info["alerts_prevalidated"]), flush=True)
-    sim.set_force_exact(0)
+    for boundary in (True, False):
+        sim.generate(deliver_set, rx, seed=7, trust_copies=True, boundary=boundary)
+        rec_b = 20 if boundary else 8
+        for knob, what in ((0, "as chosen"), (64, "filter per delivery")):
+            sim.set_force_exact(knob)
+            ms = sim.time_tally(reps)
+            info = sim.index_info(timed=False)
+            print("%-8s %-9s %-20s tally %.4f ms  %.3e records/s  %.1f %% of 8 TB/s on %d B  (generated in %.3f ms; dict mode %d, %d waves x %d workgroups, %d hot, prevalidated %d)" % (
+                tag, "boundary" if boundary else "resolved", what, ms, n_rec / ms * 1e3, 100 * rec_b * n_rec / ms / 1e6 / 8000, rec_b, info["generate_ms"],
+                info["dict_mode"], info["waves_per_workgroup"], info["workgroups"], info["hot_subjects"], info["alerts_prevalidated"]), flush=True)
+        sim.set_force_exact(0)
+    sim.generate(deliver_set, rx, seed=7, trust_copies=True, boundary=True)
     if tag == "default":
         sim.tally()
         rr = sim.count_votes()

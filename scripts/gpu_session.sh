@@ -27,6 +27,8 @@ for section in "$@"; do
       (cd scripts/micro && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 gather_rate.hip -o gather_rate 2>/dev/null; timeout 200 ./gather_rate) | tee gpurun_out/gather_rate.txt ;;
     c5probe)      # the C5 tally kernel in every prepared build (what bounds it)
       RAPID_AB_ONLY=${C5_ONLY:-default,pnolook,pnoor,pstream} timeout 600 python scripts/c5_probe.py 1000000 1024 5 2> gpurun_out/c5_probe.err | tee gpurun_out/c5_probe.txt; tail -2 gpurun_out/c5_probe.err ;;
+    c5phase)      # event counters and phase timers of the C5 tally (needs rapid_amd/librapid_mi355x_timers.so)
+      timeout 600 python scripts/c5_phase.py 1000000 1024 2> gpurun_out/c5_phase.err | tee gpurun_out/c5_phase.txt; tail -2 gpurun_out/c5_phase.err ;;
     ab_c3b)       # the C3b tally kernel in every prepared build, interleaved
       RAPID_AB_ONLY=${AB_ONLY:-default,lanedummy,skipdummy} timeout 600 python scripts/ab_variants.py C3b 3 20 2> gpurun_out/ab_c3b.err | tee gpurun_out/ab_c3b.txt | tail -12; tail -2 gpurun_out/ab_c3b.err ;;
     kstats)       # rocprofv3 kernel statistics of the bench command (driver form)

@@ -1619,3 +1619,87 @@ def test_round_driven_by_the_failure_detector_and_batching_timers(E):
     assert 10_000 < out["time_to_stable_cut_ms"] < 12_500
     rr = sim.count_votes()
     assert rr.decided == 1 and sorted(sim.decided_cut()) == faulty.tolist()
+
+
+def test_round_taken_tile_by_tile_accumulates_the_votes(E, test_build):
+    """rapid_sim_round_tiled: a population taken tile by tile -- the deliveries of a tile made on the device, tallied, the fast-round
+    votes accumulated across the tiles' launches -- equals the same round held in ONE launch (rapid_sim_generate + tally +
+    count_votes, itself checked against the oracle above): every receiver's announce batch / getNumProposals() / size /
+    fingerprint, the decision, the cut, the votes; for tiles that do not divide the population, both record formats, late
+    deliveries among the batches.  And a round in which the LOWEST voter dissents while a quorum agrees: the first candidate ends
+    without a quorum, the fingerprints' histogram names the proposal that can have one, the tiles are taken once more for it."""
+    K, H, L = 10, 9, 4
+    n, n_crash, n_join, seed = 1500, 30, 12, 977
+    pop = S.Population.make(n + 40)
+    eng, view = make_engine(E, pop, K, H, L, members=list(range(n)))
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_churn_scenario(obs, member, cfg, n_crash, n_join, H, L, materialise=False)
+    rx = sc.receivers
+    both = S.with_late_batches(sc.batches, cfg - 1, 0.2, 5)
+    sim = E.ClusterSimulation(eng)
+    for batches in (sc.batches, both):
+        for boundary in (False, True):
+            sim.generate(batches, rx, seed, boundary=boundary, trust_copies=True)
+            sim.tally()
+            want = [a.copy() for a in sim.results()]
+            rr1 = sim.count_votes()
+            cut1 = sim.decided_cut()
+            assert rr1.decided == 1 and sorted(cut1) == sc.faulty.tolist()
+            for tile in (0, 256, 1000, 97):
+                rr = sim.round_tiled(batches, rx, seed, tile_receivers=tile, boundary=boundary)
+                got = sim.results()
+                assert all(np.array_equal(a, b) for a, b in zip(want, got)), (boundary, tile)
+                assert (rr.decided, rr.votes_winner, rr.votes_total, rr.cut_size, rr.quorum) == (1, rr1.votes_winner, rr1.votes_total, rr1.cut_size, rr1.quorum)
+                assert sim.decided_cut() == cut1
+                info = sim.round_tiled_info()
+                t = tile if tile else 16 * 256
+                assert info["passes"] == 1 and info["tiles"] == -(-len(rx) // min(t, len(rx))) and info["records_delivered"] == len(rx) * len(batches.recs)
+                last = len(rx) - 1
+                assert sorted(sim.proposal(last)) == sc.faulty.tolist()  # the last tile's node lists are resident ...
+                if tile and tile < len(rx):
+                    with pytest.raises(E.RapidError):                    # ... the others went with their tiles
+                        sim.proposal(0)
+                with pytest.raises(E.RapidError):  # the streams of a tiled round are gone: nothing to tally or count again
+                    sim.tally()
+                with pytest.raises(E.RapidError):
+                    sim.count_votes()
+    # ---- the lowest voter dissents, a quorum agrees ----
+    # one more "batch": a single alert naming a healthy member on all K rings (a legal AlertMessage with K ring numbers), which
+    # reaches nine receivers in ten; the others propose the cut without it.  The seed is chosen so that receiver 0 is one of them.
+    healthy = np.setdiff1d(np.flatnonzero(member != 0), sc.faulty)
+    extra = E.alert(int(healthy[5]), int(healthy[7]), E.DOWN, cfg, list(range(K)))
+    extra["flags"] = 1
+    bs = S.BatchSet(np.concatenate([sc.batches.recs, extra]), np.concatenate([sc.batches.off, [sc.batches.off[-1] + 1]]).astype(np.int64),
+                    np.concatenate([sc.batches.sender, [int(healthy[5])]]).astype(np.int32))
+    keep = np.full(bs.n_batches, 0xFFFFFFFF, dtype=np.uint32)
+    keep[-1] = int(0.9 * 0xFFFFFFFF)
+    s2 = next(s for s in range(100, 400) if not S.delivered_mask(s, int(rx[0]), keep)[-1])
+    minority = sum(1 for r in rx if not S.delivered_mask(s2, int(r), keep)[-1])
+    assert 0 < minority < len(rx) // 5
+    for boundary in (False, True):
+        sim.generate(bs, rx, s2, keep=keep, boundary=boundary)
+        sim.tally()
+        want = [a.copy() for a in sim.results()]
+        rr1 = sim.count_votes()
+        # (a receiver that hears of the extra subject only after it has announced proposes the plain cut, too: the majority is
+        # smaller than the receivers the batch reaches -- R/MembershipService.java:318-319 ignores what comes after the announcement)
+        assert rr1.decided == 1 and rr1.quorum <= rr1.votes_winner <= len(rx) - minority and sorted(sim.decided_cut()) == sorted(sc.faulty.tolist() + [int(healthy[7])])
+        cut1 = sim.decided_cut()
+        for tile in (0, 300):
+            rr = sim.round_tiled(bs, rx, s2, tile_receivers=tile, keep=keep, boundary=boundary)
+            assert all(np.array_equal(a, b) for a, b in zip(want, sim.results()))
+            assert (rr.decided, rr.votes_winner, rr.votes_total, rr.cut_size) == (1, rr1.votes_winner, rr1.votes_total, len(cut1)) and sim.decided_cut() == cut1
+            assert sim.round_tiled_info()["passes"] == 2
+    # ... and nobody has a quorum when four receivers in ten dissent: undecided, after ONE pass over the population
+    keep[-1] = int(0.5 * 0xFFFFFFFF)
+    rr = sim.round_tiled(bs, rx, s2, tile_receivers=300, keep=keep)
+    assert rr.decided == 0 and 0 < rr.votes_winner < rr.quorum and rr.votes_total == len(rx) and sim.round_tiled_info()["passes"] == 1
+    with pytest.raises(E.RapidError):
+        sim.decided_cut()
+    # an empty population, and misuse
+    rr = sim.round_tiled(sc.batches, rx[:0], seed)
+    assert rr.decided == 0 and rr.votes_total == 0
+    with pytest.raises(E.IllegalArgumentException):
+        sim.round_tiled(S.BatchSet(sc.batches.recs, np.concatenate([sc.batches.off[:1], sc.batches.off]), np.concatenate([[0], sc.batches.sender])), rx, 1)
+    eng.close()
