@@ -11,7 +11,8 @@
 // node across L, so membership of "proposal U preProposal" grows only through explicit reports; a pair
 // becomes applicable at the first batch end after BOTH endpoints crossed L, i.e. when the later of the
 // two is among the nodes that crossed L since the previous pass.  Pairs whose endpoints both crossed L
-// earlier were applied by an earlier pass and are duplicates (no-ops) now.
+// earlier were applied by an earlier pass and are duplicates (no-ops) now.  The same holds for a joiner in flux and its
+// expected observers: the pair is looked at when the later of the two crosses L.
 //
 // This file is validated against the faithful restatement (rapid_oracle.hpp) on randomised streams in
 // tests/test_oracle_fast.py, and is then used (a) as the full-size checker for the GPU kernels and
@@ -39,7 +40,19 @@ class FastCutReceiver {
     FastCutReceiver(int n_nodes, int K, int H, int L, int64_t cfg_id, const int32_t* obs, const int32_t* subj,
                     const uint8_t* member)
         : n_(n_nodes), K_(K), H_(H), L_(L), cfg_(cfg_id), obs_(obs), subj_(subj), member_(member),
-          mask_((size_t)n_nodes, 0), flushed_((size_t)n_nodes, 0) {}
+          mask_((size_t)n_nodes, 0), flushed_((size_t)n_nodes, 0) {
+        // who is an EXPECTED observer of which registered non-member (row j of the observer table for a non-member j holds its
+        // expected observers, R/MembershipView.java:292-322): sorted by observer, so that a node that has just entered
+        // proposal U preProposal finds the joiners it vouches for without a walk over all joiners (10^6-node rounds have 5,000)
+        for (int j = 0; j < n_nodes; ++j) {
+            if (member[j]) continue;
+            for (int k = 0; k < K; ++k) {
+                const int o = obs[(size_t)j * K + k];
+                if (o >= 0) rev_.push_back({o, j, k});
+            }
+        }
+        std::sort(rev_.begin(), rev_.end(), [](const Rev& a, const Rev& b) { return a.o != b.o ? a.o < b.o : (a.j != b.j ? a.j < b.j : a.k < b.k); });
+    }
 
     void reset() {
         for (int d : touched_) {
@@ -49,7 +62,6 @@ class FastCutReceiver {
         touched_.clear();
         pending_.clear();
         unflushedH_.clear();
-        joiners_.clear();
         proposal_.clear();
         inprog_ = 0;
         proposalCount_ = 0;
@@ -122,10 +134,7 @@ class FastCutReceiver {
     bool applyBit(int dst, int k) {
         uint16_t& m = mask_[(size_t)dst];
         if (m & (1u << k)) return false;
-        if (m == 0) {
-            touched_.push_back(dst);
-            if (!member_[dst]) joiners_.push_back(dst);
-        }
+        if (m == 0) touched_.push_back(dst);
         m = (uint16_t)(m | (1u << k));
         const int c = __builtin_popcount(m);
         if (c == L_) {
@@ -161,19 +170,16 @@ class FastCutReceiver {
                     if (o >= 0 && inAct(o)) cands.push_back({n, k, o});
                 }
             }
-            if (inAct(n) && member_[n]) {  // n as an observer of its (member) subjects
+            if (inAct(n) && member_[n]) {  // n as an observer of its (member) subjects ...
                 for (int k = 0; k < K_; ++k) {
                     const int s = subj_[(size_t)n * K_ + k];
                     if (s >= 0 && inPre(s)) cands.push_back({s, k, n});
                 }
-            }
-        }
-        // joiners in flux whose expected observers (predecessors) are in proposal U preProposal
-        for (int j : joiners_) {
-            if (!inPre(j)) continue;
-            for (int k = 0; k < K_; ++k) {
-                const int o = obs_[(size_t)j * K_ + k];
-                if (o >= 0 && inAct(o)) cands.push_back({j, k, o});
+                // ... and as an expected observer of joiners in flux (a joiner that crosses L itself is "the node in flux" above:
+                // its row of the observer table holds its expected observers)
+                auto it = std::lower_bound(rev_.begin(), rev_.end(), n, [](const Rev& a, int o) { return a.o < o; });
+                for (; it != rev_.end() && it->o == n; ++it)
+                    if (inPre(it->j)) cands.push_back({it->j, it->k, n});
             }
         }
         pending_.clear();
@@ -190,7 +196,9 @@ class FastCutReceiver {
     const uint8_t* member_;
     std::vector<uint16_t> mask_;
     std::vector<uint8_t> flushed_;
-    std::vector<int> touched_, pending_, unflushedH_, joiners_, proposal_;
+    struct Rev { int o, j, k; };
+    std::vector<Rev> rev_;
+    std::vector<int> touched_, pending_, unflushedH_, proposal_;
     int inprog_ = 0, proposalCount_ = 0, emitBatch_ = -1;
     bool seenDown_ = false, announced_ = false;
 };

@@ -1463,6 +1463,73 @@ def test_streaming_rounds_at_one_million_nodes(E):
     eng.close()
 
 
+def test_full_population_rounds_at_one_million_nodes(E):
+    """BASELINE configs[4] as complete, DECIDED rounds: N = 1,000,000 members, every one of the ~985,000 surviving members a
+    simulated receiver of ~150,000 deliveries (1.5 x 10^11 delivered alerts per round: they never exist at once --
+    rapid_sim_round_tiled makes a tile's deliveries on the device, tallies them and accumulates the fast-round votes across the
+    tiles' launches).  Three consecutive rounds of continuous churn (10,000 crash + 5,000 join per round, 1 % late deliveries of
+    the previous configuration from the second round on), each decided by the accumulated votes of the WHOLE population
+    (quorum N - floor((N-1)/4) = 750,001 in the first round), the decided cut applied, the next round in the new configuration:
+    * every receiver of one whole tile (1,024 receivers; another tile in every round) against the optimised oracle fed the host
+      statement of the same deliveries (scenarios.deliver_hashed): announce batch, getNumProposals, size, fingerprint of the
+      oracle's list;
+    * every receiver of the population: it announces, and its fingerprint is the checked tile's;
+    * the decided cut = the round's fault set; configuration id, membership size and sampled observer lists after every view
+      change against the oracle's MembershipView put through the same ringDelete / ringAdd sequence."""
+    K, H, L = 10, 9, 4
+    n_mem, spare, rounds, tile = 1000000, 16000, 3, 1024
+    pop = S.Population.make(n_mem + spare)
+    members = list(range(n_mem))
+    eng, view = make_engine(E, pop, K, H, L, members=members, max_cut=16384)
+    reg, oview = oracle_view(pop, K, members)
+    st = S.StreamingChurn(H, L)
+    sim = E.ClusterSimulation(eng)
+    for rnd in range(rounds):
+        obs, subj, member = view.tables()
+        cfg = view.getCurrentConfigurationId()
+        assert cfg == oview.getCurrentConfigurationId()
+        sc, deliver_set = st.next_round_batches(obs, member, cfg)
+        rx = sc.receivers
+        n_members = int((member != 0).sum())
+        assert len(rx) == n_members - len(sc.crashed) and len(sc.crashed) >= 9800 and len(sc.joiners) >= 4900
+        assert (deliver_set.n_batches > sc.batches.n_batches) == (rnd > 0)  # the late deliveries are there from the second round on
+        seed = 1000 + rnd
+        boundary = rnd == 1  # (one round on the 20-byte boundary records, the others on resolved 8-byte records)
+        rr = sim.round_tiled(deliver_set, rx, seed, tile_receivers=tile, boundary=boundary)
+        info = sim.round_tiled_info()
+        assert info["passes"] == 1 and info["tiles"] == -(-len(rx) // tile) and info["records_delivered"] == len(rx) * len(deliver_set.recs)
+        quorum = n_members - (n_members - 1) // 4
+        assert (rr.decided, rr.quorum, rr.membership_size, rr.cut_size) == (1, quorum, n_members, len(sc.faulty))
+        assert rr.votes_winner == rr.votes_total == len(rx) >= quorum  # unanimous: nothing of the round is lost to the late deliveries
+        cut = sim.decided_cut()
+        assert sorted(cut) == sc.faulty.tolist()
+        emit, nprop, pcount, fp = sim.results()
+        assert np.all(emit >= 0) and np.all(pcount == len(sc.faulty)) and np.all(nprop >= 1) and len(np.unique(fp)) == 1
+        # one whole tile against the oracle, 256 receivers at a time (a tile's 1.5 x 10^8 records are 3 GB on the host)
+        k = (3 + 411 * rnd) % (len(rx) // tile)
+        for lo in range(k * tile, (k + 1) * tile, 256):
+            part = rx[lo:lo + 256]
+            recs, off, _ = S.deliver_hashed(deliver_set, part, seed)
+            fe, fn, fo, fpp = O.fast_sim_run(pop.n, K, H, L, cfg, obs, subj, member, recs, off, nthreads=64)
+            sl = slice(lo, lo + 256)
+            assert np.array_equal(emit[sl], fe) and np.array_equal(nprop[sl], fn) and np.array_equal(pcount[sl], np.diff(fo))
+            assert np.array_equal(fp[sl], proposal_fingerprints(fo, fpp, fe >= 0))
+            assert sorted(fpp[fo[0]:fo[1]].tolist()) == sc.faulty.tolist()
+            del recs
+        new_cfg = sim.apply_cut(np.asarray(cut, dtype=np.int32))
+        is_member = member != 0
+        for node in cut:  # decideViewChange on the oracle's view (R/MembershipService.java:394-413)
+            if is_member[node]:
+                oview.ringDelete(int(node))
+            else:
+                oview.ringAdd(int(node), (int(pop.id_hi[node]), int(pop.id_lo[node])))
+        assert new_cfg == oview.getCurrentConfigurationId() == view.getCurrentConfigurationId()
+        assert view.getMembershipSize() == oview.getMembershipSize() == n_members - len(sc.crashed) + len(sc.joiners)
+        for s_ in (int(sc.joiners[0]), int(sc.joiners[-1]), int(rx[0]), int(rx[-1])):
+            assert view.getObserversOf(s_) == oview.computeObserversOf(s_)
+    eng.close()
+
+
 # ------------------------------------------------------------------ f3: serialized rapid.proto bytes -> device tally
 def test_wire_bytes_to_device_tally_with_joiners_unknown_at_start(E):
     """SURVEY 8f rank 3 end to end: a churn round as the reference puts it on the wire -- one serialized
