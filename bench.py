@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3b", help="C2 | C3a | C3b (headline: C3b = BASELINE configs[2], closed fault set) | C4 (BASELINE configs[3]: N = 100,000 in EIGHT "
-                         "shards, rank r simulates shard r -- weak scaling: --gpus 1 measures one shard, --gpus 8 the whole cluster)")
+                         "shards, rank r simulates shard r -- weak scaling: --gpus 1 measures one shard, --gpus 8 the whole cluster) | C5 "
+                         "(BASELINE configs[4]: N = 1,000,000, continuous churn, eight shards like C4; a step = one whole tiled round of the shard)")
     ap.add_argument("--n", type=int, default=None, help="override population size (testing only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -56,6 +57,7 @@ def parse():
     ap.add_argument("--stream-sets", type=int, default=2, help="resident stream sets (different delivery orders) the steps alternate between")
     ap.add_argument("--no-extras", action="store_true", help="skip the measurements beside the line (generator, per-delivery filter, probe)")
     ap.add_argument("--ttsc-trials", type=int, default=5, help="trials of the time-to-stable-cut measurement (the view is rebuilt between them)")
+    ap.add_argument("--tile", type=int, default=0, help="C5: receivers per launch of the tiled round (default 4096)")
     return ap.parse_args()
 
 
@@ -120,6 +122,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     cfgname = args.config
+    if cfgname == "C5":
+        return bench_c5(args, rank, world, local_rank, torch, dist, E, P, S)
     spec = dict(S.CONFIGS[cfgname])
     n = args.n or spec["n"]
     K, H, L = spec["K"], spec["H"], spec["L"]
@@ -358,6 +362,182 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     if out["n_ranks_seen"] != args.gpus:  # the communicator inside the library must span exactly the ranks asked for
+        raise SystemExit("bench.py: the engine's communicator sees %d rank(s), --gpus %d" % (out["n_ranks_seen"], args.gpus))
+
+
+def bench_c5(args, rank, world, local_rank, torch, dist, E, P, S):
+    """BASELINE configs[4]: 1,000,000 members, K = 10, continuous churn (every round 1 % of the members crash, 0.5 % join, 1 % late
+    deliveries of the previous configuration), 8 x MI355X.  The cluster is ALWAYS cut into eight shards of receivers and rank r
+    simulates shard r (weak scaling, like C4): --gpus 1 measures one shard, --gpus 8 the whole cluster -- the fast quorum of
+    750,001 votes exists only there.  A shard is ~123,000 receivers x ~150,000 deliveries = 1.8 x 10^10 delivered alerts per round
+    (370 GB as 20-byte records): they never exist at once.  One STEP = one whole round of the shard through rapid_sim_round_tiled:
+    per tile the deliveries are made on the device from the round's resident alert set (8-byte resolved records), tallied, and
+    the fast-round votes accumulated across the tiles' launches; one all-gather across the ranks at the end.  The generator is
+    INSIDE the timed step (a delivered record of this configuration exists nowhere else); the tally kernel alone is priced by
+    `roofline` on one resident tile of 20-byte boundary records, as for the other configurations."""
+    spec = dict(S.CONFIGS["C5"])
+    n_mem = args.n or spec["n"]
+    K, H, L = spec["K"], spec["H"], spec["L"]
+    shards = 8
+    if world > shards:
+        raise SystemExit("C5 is defined on %d shards; --gpus %d" % (shards, world))
+    t0 = time.time()
+    pop = S.Population.make(n_mem + int(0.006 * n_mem * 3) + 64)
+    eng = E.Engine(n_max=pop.n, K=K, H=H, L=L, device_id=local_rank, max_cut=max(4096, int(0.02 * n_mem)))
+    if world > 1:
+        uid = [E.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(uid[0], rank, world)
+    view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo, members=np.arange(n_mem, dtype=np.int32))
+    sim = E.ClusterSimulation(eng)
+    st = S.StreamingChurn(H, L)
+    tile = args.tile if args.tile > 0 else 4096
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    def next_round():
+        obs, subj, member = view.tables()
+        cfg = view.getCurrentConfigurationId()
+        sc, deliver_set = st.next_round_batches(obs, member, cfg)
+        lo, hi = P.shard_range(len(sc.receivers), rank, shards)
+        return sc, deliver_set, sc.receivers[lo:hi], cfg
+
+    # round 0 (untimed): the configuration the timed round's late deliveries come from.  Its cut is applied as decided by the
+    # round itself where all eight shards are present; a partial cluster applies the round's fault set (what the whole cluster
+    # decides: the first round loses nothing).
+    sc0, set0, rx0, cfg0 = next_round()
+    rr0 = sim.round_tiled(set0, rx0, seed=1000, tile_receivers=tile)
+    cut0 = sim.decided_cut() if rr0.decided else sc0.faulty.tolist()
+    assert sorted(cut0) == sc0.faulty.tolist(), "round 0 decided something else than its fault set"
+    sim.apply_cut(np.asarray(cut0, dtype=np.int32))
+    sc, deliver_set, my_rx, cfg_id = next_round()
+    setup_s = time.time() - t0
+    A = len(deliver_set.recs)
+    my_batches = len(my_rx) * deliver_set.n_batches
+    my_records = len(my_rx) * A
+
+    def step(i):
+        return sim.round_tiled(deliver_set, my_rx, seed=2000, tile_receivers=tile)
+
+    for i in range(args.warmup):
+        rr = step(i)
+    barrier()
+    per_step = []
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        ts = time.perf_counter()
+        rr = step(args.warmup + i)
+        per_step.append(time.perf_counter() - ts)
+    barrier()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        cnt = torch.tensor([my_batches, my_records], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        tot_batches, tot_records = int(cnt[0].item()), int(cnt[1].item())
+    else:
+        tot_batches, tot_records = my_batches, my_records
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = tot_batches * args.steps / elapsed
+    emit, nprop, pcount, fp = sim.results()
+    proposing = int((emit >= 0).sum())
+    distinct = int(len(np.unique(fp[emit >= 0])))
+    tiled = sim.round_tiled_info()
+
+    # ---- the tally kernel alone, on ONE resident tile (HIP events on the engine's stream, back-to-back launches): the 20-byte boundary
+    # records (SURVEY 8d's unit: `roofline`) and the resolved 8-byte records the timed rounds run on
+    tile_rx = my_rx[:min(len(my_rx), 1024)]
+    forms = {}
+    for form, boundary in (("boundary", True), ("resolved", False)):
+        sim.generate(deliver_set, tile_rx, seed=2000, trust_copies=True, boundary=boundary)
+        kms = sim.time_tally(args.kernel_reps)
+        stt = sim.stats()
+        consumed = stt["records_consumed"] // (args.kernel_reps + 1)
+        info = sim.index_info(timed=False)
+        rec_b = 20.0 if boundary else 8.0
+        forms[form] = {"kernel_ms": round(kms, 4), "records_consumed_per_launch": int(consumed), "bytes_per_record": int(rec_b),
+                       "records_per_s": round(consumed / (kms * 1e-3), 1), "achieved_GBps": round(rec_b * consumed / (kms * 1e-3) / 1e9, 1),
+                       "frac": round(rec_b * consumed / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "generate_device_ms": info["generate_ms"],
+                       "dict_mode": info["dict_mode"], "waves_per_workgroup": info["waves_per_workgroup"], "workgroups": info["workgroups"],
+                       "hot_subjects": info["hot_subjects"], "alerts_prevalidated": info["alerts_prevalidated"]}
+    b = forms["boundary"]
+    roofline = {"bound": "hbm", "achieved": b["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b["frac"], "traffic": None,
+                "traffic_source": "not measured for C5 (the C3b line carries the PMC pass)",
+                "kernel": "tally_population_kernel<%s, %s, kFmtBoundary, packed>" % ({0: "kDictMemory", 4: "kDictHashed"}.get(b["dict_mode"], "?"),
+                                                                                       "trusted" if b["alerts_prevalidated"] else "filter"),
+                "kernel_ms": b["kernel_ms"], "bytes_per_launch": int(20 * b["records_consumed_per_launch"]), "bytes_per_record": 20,
+                "records_consumed_per_launch": b["records_consumed_per_launch"], "tile_receivers": int(len(tile_rx)),
+                "resolved_records": forms["resolved"]}
+    if world > 1:
+        mine = torch.tensor([b["kernel_ms"], float(b["records_consumed_per_launch"])], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        roofline["per_rank"] = [{"rank": i, "kernel_ms": round(float(t[0]), 4), "records_consumed": int(t[1]),
+                                 "frac": round(20.0 * float(t[1]) / (float(t[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for i, t in enumerate(allr)]
+
+    # ---- one round + its view change: time-to-stable-cut (only a whole cluster decides; a partial one applies the fault set)
+    barrier()
+    t2 = time.perf_counter()
+    rr_full = sim.round_tiled(deliver_set, my_rx, seed=2000, tile_receivers=tile)
+    cut = sim.decided_cut() if rr_full.decided else None
+    t_round = 1e3 * (time.perf_counter() - t2)
+    t3 = time.perf_counter()
+    new_cfg = sim.apply_cut(np.asarray(cut if cut is not None else sc.faulty, dtype=np.int32))
+    t_apply = 1e3 * (time.perf_counter() - t3)
+    eng.sync()
+    if cut is not None and sorted(cut) != sc.faulty.tolist():
+        raise SystemExit("bench.py: the decided cut is not the round's fault set")
+
+    # ---- beside the line, one GPU only: the WHOLE population on this GPU, shard after shard (the votes of all ~985,000 receivers
+    # accumulated across ~240 launches): a decided round of BASELINE configs[4] without the other seven GPUs
+    whole = None
+    if world == 1 and not args.no_extras:
+        # (the view has moved on by one cut: the whole-population round runs in the NEXT configuration, with a round of its own)
+        sc2, set2, _, cfg2 = next_round()
+        t4 = time.perf_counter()
+        rr_w = sim.round_tiled(set2, sc2.receivers, seed=3000, tile_receivers=tile)
+        t_w = 1e3 * (time.perf_counter() - t4)
+        cut_w = sim.decided_cut() if rr_w.decided else []
+        whole = {"receivers": int(len(sc2.receivers)), "records_delivered": int(len(sc2.receivers)) * int(len(set2.recs)), "round_ms": round(t_w, 1),
+                 "records_per_s": round(len(sc2.receivers) * len(set2.recs) / (t_w * 1e-3), 1), "decided": int(rr_w.decided),
+                 "votes_winner": int(rr_w.votes_winner), "quorum": int(rr_w.quorum), "cut_size": int(rr_w.cut_size),
+                 "cut_is_the_fault_set": bool(sorted(cut_w) == sc2.faulty.tolist()), "tiles": sim.round_tiled_info()["tiles"]}
+        if not (rr_w.decided and whole["cut_is_the_fault_set"]):
+            raise SystemExit("bench.py: the whole-population round did not decide its fault set: %r" % whole)
+
+    out = {
+        "metric": "alert-batches/sec", "value": round(value, 1), "unit": "alert-batches/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic, deliveries made on the device inside the step",
+        "config": {"workload": "C5: N=%d K=%d H=%d L=%d, round of continuous churn: %d crash + %d join, %d alerts in %d batches (+ %d late "
+                               "batches of the previous configuration), %d receivers in the cluster (shards 0..%d of 8 simulated: %d receivers)"
+                               % (n_mem, K, H, L, len(sc.crashed), len(sc.joiners), len(sc.batches.recs), sc.batches.n_batches,
+                                  deliver_set.n_batches - sc.batches.n_batches, len(sc.receivers), world - 1, len(my_rx) if world == 1 else -1),
+                   "parallelism": "receivers in eight shards, rank r = shard r; per round ONE all-gather (RCCL) of the ranks' accumulated vote counts",
+                   "step": "one whole round of the shard, tile by tile (%d receivers per launch): deliveries generated on the device as 8-byte "
+                           "resolved records, tallied, votes accumulated across the launches" % tile,
+                   "baseline_config": "BASELINE.json configs[4] (1,000,000 nodes, K=10, streaming alert batches, continuous churn, 8 GPUs)"},
+        "ms_per_step_min": round(1e3 * min(per_step), 3), "ms_per_step_median": round(1e3 * float(np.median(per_step)), 3),
+        "n_ranks_seen": eng.comm_info()[1],
+        "alert_records_per_s": round(tot_records * args.steps / elapsed, 1),
+        "records_delivered_per_step": tot_records, "tiles_per_step": tiled["tiles"], "passes_per_step": tiled["passes"],
+        "time_to_stable_cut_ms": round(t_round + t_apply, 3) if rr_full.decided else None,
+        "round_ms": round(t_round, 3), "apply_cut_ms": round(t_apply, 3),
+        "decided": int(rr_full.decided), "cut_size": int(rr_full.cut_size), "votes_winner": int(rr_full.votes_winner), "votes_total": int(rr_full.votes_total),
+        "quorum": int(rr_full.quorum), "proposing": proposing, "distinct_proposals": distinct,
+        "whole_population_on_one_gpu": whole, "setup_s": round(setup_s, 1), "roofline": roofline,
+    }
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    if out["n_ranks_seen"] != args.gpus:
         raise SystemExit("bench.py: the engine's communicator sees %d rank(s), --gpus %d" % (out["n_ranks_seen"], args.gpus))
 
 

@@ -181,7 +181,8 @@ int rapid_sim_attach_streams_device(rapid_engine* h, const void* d_records, uint
  * alerts in batch order, batch b = alerts[batch_off[b] .. batch_off[b + 1]) = one BatchedAlertMessage (never empty:
  * RAPID_EINVAL); every receiver gets every batch exactly once (the fan-out of R/UnicastToAllBroadcaster.java:46-63), receiver
  * r in an order of its own: position j holds batch perm(j), a seeded permutation of [0, n_batches) evaluated in place (a
- * four-round Feistel network keyed by mix64(seed + receivers[r]), cycle-walked into range; csrc/index_kernels.h: gen_perm_at;
+ * four-round Feistel network on a mixed-radix domain that covers n_batches with less than its square root to spare, keyed by
+ * mix64(seed + receivers[r]), cycle-walked into range; csrc/index_kernels.h: gen_perm_at;
  * rapid_amd/scenarios.py: hashed_order / deliver_hashed are the same statement on the host).  No keys, no sort, no bound on
  * receivers x batches.  `alerts` IS the declared alert set of the round (rapid_sim_set_alert_set is implied and refused).
  * batch_keep (optional, [n_batches]): batch b reaches receiver r only if a per-(r, b) 32-bit draw is <= batch_keep[b]

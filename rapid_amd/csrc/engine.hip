@@ -191,6 +191,7 @@ struct rapid_engine {
     DevBuf<uint2> d_gen_res;          // rapid_sim_generate: the alert set resolved once ({entry, core word} per alert)
     DevBuf<unsigned int> d_gen_keep;  // ... per-batch delivery thresholds
     DevBuf<long long> d_gen_boff;
+    DevBuf<uint4> d_gen_bat;          // ... {first alert, length, the first alert's resolved record} per batch (gen_pack_batches_kernel)
     DevBuf<int> d_gen_rx;
     float generate_ms = 0.f;
     int n_touched = 0;
@@ -1126,7 +1127,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_pos.release(); h->d_obs.release(); h->d_subj.release();
     h->d_ids_hi.release(); h->d_ids_lo.release(); h->d_cfg_out.release(); h->d_sort_tmp.release();
     h->d_q4_nodes.release(); h->d_q4_rows.release(); h->d_q4_valid.release(); h->d_q4_flag.release(); h->d_entries.release();
-    h->d_gen_res.release(); h->d_gen_keep.release(); h->d_gen_boff.release(); h->d_gen_rx.release();
+    h->d_gen_res.release(); h->d_gen_keep.release(); h->d_gen_boff.release(); h->d_gen_rx.release(); h->d_gen_bat.release();
     h->d_ids_hi2.release(); h->d_ids_lo2.release(); h->d_ids_new.release(); h->d_cfg_partial.release(); h->d_chunk_kept.release();
     h->d_bitmaps.release();
     h->d_vacc.release();
@@ -1768,9 +1769,12 @@ int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const 
             hipLaunchKernelGGL(rapid::gen_resolve_alerts_kernel, dim3(grid_for(A, 256)), dim3(256), 0, st, h->d_alert_set.p, A, (long long)h->config_id,
                                (unsigned int)h->n_nodes, h->d_entries.p, h->d_gen_res.p);
         }
-        hipLaunchKernelGGL(rapid::gen_streams_kernel, dim3((unsigned)n_receivers), dim3(256), 0, st, h->d_gen_res.p, h->d_alert_set.p, h->d_gen_boff.p,
-                           n_batches, batch_keep ? h->d_gen_keep.p : (const unsigned int*)nullptr, h->d_gen_rx.p, A, (unsigned long long)seed,
-                           h->d_records_own.p, boundary ? 1 : 0);
+        HIPCHK(h, h->d_gen_bat.ensure((size_t)std::max(n_batches, 1)));
+        hipLaunchKernelGGL(rapid::gen_pack_batches_kernel, dim3(grid_for(n_batches, 256)), dim3(256), 0, st, h->d_gen_boff.p, n_batches,
+                           boundary ? (const uint2*)nullptr : h->d_gen_res.p, h->d_gen_bat.p);
+        hipLaunchKernelGGL(rapid::gen_streams_kernel, dim3(grid_for(n_receivers, rapid::kGenWavesPerBlock)), dim3(rapid::kGenWavesPerBlock * 64), 0, st,
+                           h->d_gen_res.p, h->d_alert_set.p, h->d_gen_bat.p, n_batches, batch_keep ? h->d_gen_keep.p : (const unsigned int*)nullptr,
+                           h->d_gen_rx.p, n_receivers, A, (unsigned long long)seed, h->d_records_own.p, boundary ? 1 : 0);
     }
     HIPCHK(h, hipEventRecord(h->ev1, st));
     HIPCHK(h, hipStreamSynchronize(st));
@@ -2296,6 +2300,9 @@ int rapid_sim_round_tiled(rapid_engine* h, const rapid_alert_record* alerts, con
         hipLaunchKernelGGL(rapid::gen_resolve_alerts_kernel, dim3(grid_for(A, 256)), dim3(256), 0, st, h->d_alert_set.p, A, (long long)h->config_id,
                            (unsigned int)h->n_nodes, h->d_entries.p, h->d_gen_res.p);
     }
+    HIPCHK(h, h->d_gen_bat.ensure((size_t)std::max(n_batches, 1)));
+    hipLaunchKernelGGL(rapid::gen_pack_batches_kernel, dim3(grid_for(n_batches, 256)), dim3(256), 0, st, h->d_gen_boff.p, n_batches,
+                       boundary ? (const uint2*)nullptr : h->d_gen_res.p, h->d_gen_bat.p);
     // per-receiver results for the whole population; node lists and bitmaps for one tile
     const size_t Rz = (size_t)std::max(R, 1);
     HIPCHK(h, h->d_emit.ensure(Rz));
@@ -2331,9 +2338,9 @@ int rapid_sim_round_tiled(rapid_engine* h, const rapid_alert_record* alerts, con
         for (long long base = 0; base < R; base += T) {
             const int n = (int)std::min<long long>(T, R - base);
             ++tiles;
-            hipLaunchKernelGGL(rapid::gen_streams_kernel, dim3((unsigned)n), dim3(256), 0, st, h->d_gen_res.p, h->d_alert_set.p, h->d_gen_boff.p, n_batches,
-                               batch_keep ? h->d_gen_keep.p : (const unsigned int*)nullptr, h->d_gen_rx.p + base, A, (unsigned long long)seed,
-                               h->d_records_own.p, boundary ? 1 : 0);
+            hipLaunchKernelGGL(rapid::gen_streams_kernel, dim3(grid_for(n, rapid::kGenWavesPerBlock)), dim3(rapid::kGenWavesPerBlock * 64), 0, st, h->d_gen_res.p,
+                               h->d_alert_set.p, h->d_gen_bat.p, n_batches, batch_keep ? h->d_gen_keep.p : (const unsigned int*)nullptr, h->d_gen_rx.p + base,
+                               n, A, (unsigned long long)seed, h->d_records_own.p, boundary ? 1 : 0);
             h->n_receivers = n;
             h->out_base = base;
             if ((rc = launch_tally(h))) return rc;

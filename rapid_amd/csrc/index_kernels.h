@@ -786,12 +786,15 @@ __global__ __launch_bounds__(1024) void index_fused_kernel(const unsigned char* 
 // Every receiver gets every BatchedAlertMessage of the round exactly once, in a receiver-specific seeded order (the
 // reference's fan-out: UnicastToAllBroadcaster.java:46-63 sends each batch to all members; arrival order differs per
 // receiver -- paper Fig.11 methodology).  The order is a seeded PERMUTATION evaluated in place, not a sort: position j of
-// receiver r holds batch perm_r(j), a four-round alternating Feistel network over the smallest bit width that covers the
-// batch count, walked until it lands inside [0, n_batches) (cycle walking: a bijection on a power-of-two domain restricted to
-// a subset is a bijection of the subset), keyed by mix64(seed + node index of r).  Any position is computed in O(1) by
-// itself, so one workgroup per receiver lays the stream down tile by tile with nothing but an exclusive scan of the batch
-// lengths in delivery order in between -- no keys in memory, no sort, no limit on receivers x batches.
-// (rapid_amd/scenarios.py: hashed_order / deliver_hashed state the same on the host.)
+// receiver r holds batch perm_r(j), a four-round alternating Feistel network on the mixed-radix domain [0, b) x [0, a) -- a = the
+// power of two at or above sqrt(n_batches), b = ceil(n_batches / a): the smallest such domain covers n_batches with less than a
+// positions to spare, so that "walk until it lands inside [0, n_batches)" (cycle walking: a bijection of a domain restricted to a
+// subset is a bijection of the subset) takes a second step for one position in several hundred.  (Round 4 ran the network on the
+// next power of two: up to half of the positions walked, and a wave walks as long as its unluckiest lane -- five to six network
+// evaluations per delivery at 1.4 x 10^5 batches, most of the generator's instructions.)  Keyed by mix64(seed + node index of r).
+// Any position is computed in O(1) by itself, so one WAVE per receiver lays the stream down 64 deliveries at a time with nothing
+// but a prefix sum of the batch lengths over its lanes in between -- no keys in memory, no sort, no barrier, no LDS, no limit on
+// receivers x batches.  (rapid_amd/scenarios.py: hashed_order / deliver_hashed state the same on the host.)
 // keep != nullptr: batch b reaches receiver r only if (uint32)(mix64(keepk_r + b) >> 32) <= keep[b] -- late deliveries of an
 // earlier configuration (R/MembershipService.java:653-657 drops them) and lossy links reach SOME receivers; the places of an
 // undelivered batch hold empty records (no ring, no batch end: what the zeros behind a stream's end are), so that every
@@ -813,8 +816,9 @@ struct GenPerm {
     unsigned int rk[4];        // round keys
     unsigned long long keepk;  // key of the per-batch delivery draw
     unsigned int n;            // batches
-    unsigned int a;            // bits of the right half; the left half has w - a
-    unsigned int mask_r, mask_l;
+    unsigned int s;            // the right half has s bits: a = 1 << s
+    unsigned int mask_r;       // a - 1
+    unsigned int b;            // radix of the left half: ceil(n / a)
 };
 __host__ __device__ inline GenPerm gen_perm_make(unsigned long long seed, unsigned int receiver_node, unsigned int n_batches) {
     GenPerm g;
@@ -822,23 +826,29 @@ __host__ __device__ inline GenPerm gen_perm_make(unsigned long long seed, unsign
     for (int i = 0; i < 4; ++i) g.rk[i] = (unsigned int)(gen_mix64(key + (unsigned long long)(i + 1)) >> 32);
     g.keepk = gen_mix64(key ^ 0xD1B54A32D192ED03ull);
     g.n = n_batches;
-    unsigned int w = 2;
-    while (w < 32u && (1ull << w) < (unsigned long long)n_batches) ++w;
-    g.a = w >> 1;
-    g.mask_r = (1u << g.a) - 1u;
-    g.mask_l = (unsigned int)((1ull << (w - g.a)) - 1ull);
+    unsigned int s = 1;
+    while (s < 16u && (1ull << (2 * s)) < (unsigned long long)n_batches) ++s;  // a * a >= n
+    g.s = s;
+    g.mask_r = (1u << s) - 1u;
+    g.b = (unsigned int)(((unsigned long long)n_batches + g.mask_r) >> s);
+    if (g.b == 0u) g.b = 1u;
     return g;
+}
+__host__ __device__ inline unsigned int gen_scale(unsigned int x, unsigned int b) {  // x in [0, 2^32) -> [0, b)
+    return (unsigned int)(((unsigned long long)x * (unsigned long long)b) >> 32);
 }
 __host__ __device__ inline unsigned int gen_perm_at(const GenPerm& g, unsigned int j) {  // j < n -> the batch delivered j-th
     if (g.n <= 1u) return 0u;
     unsigned int x = j;
     do {
-        unsigned int r = x & g.mask_r, l = x >> g.a;
-        l ^= gen_mix32(r + g.rk[0]) & g.mask_l;
-        r ^= gen_mix32(l + g.rk[1]) & g.mask_r;
-        l ^= gen_mix32(r + g.rk[2]) & g.mask_l;
-        r ^= gen_mix32(l + g.rk[3]) & g.mask_r;
-        x = (l << g.a) | r;
+        unsigned int r = x & g.mask_r, l = x >> g.s;
+        l += gen_scale(gen_mix32(r + g.rk[0]), g.b);
+        l -= l >= g.b ? g.b : 0u;
+        r = (r + gen_mix32(l + g.rk[1])) & g.mask_r;
+        l += gen_scale(gen_mix32(r + g.rk[2]), g.b);
+        l -= l >= g.b ? g.b : 0u;
+        r = (r + gen_mix32(l + g.rk[3])) & g.mask_r;
+        x = (l << g.s) | r;
     } while (x >= g.n);
     return x;
 }
@@ -860,80 +870,121 @@ __global__ void gen_resolve_alerts_kernel(const unsigned char* alerts, long long
     res[i] = make_uint2(entries[d], core_word(w[4]) & ~kCoreEob);
 }
 
-// grid = receivers, block = 256.  alerts = the round's distinct alerts (20-byte records) in batch order, boff[b] .. boff[b + 1]
-// = batch b (never empty); every receiver's stream has n_alerts records: rec_off[r] = r * n_alerts.  boundary == 0: 8-byte
-// resident records {entry, core word} from res[]; else the 20-byte boundary records themselves (flags bit 0 = the batch end).
-// A batch ends with its last alert, whatever the flags of the set say.
-constexpr int kGenTile = 1024;  // deliveries per tile: four per thread
-__global__ __launch_bounds__(256) void gen_streams_kernel(const uint2* res, const unsigned char* alerts, const long long* boff, int n_batches,
-                                                          const unsigned int* keep, const int* receivers, long long n_alerts,
-                                                          unsigned long long seed, unsigned char* out, int boundary) {
-    __shared__ unsigned int s_start[kGenTile + 1];  // first output record of delivery i of the tile (relative to the tile)
-    __shared__ unsigned int s_first[kGenTile];      // first alert of its batch; 0xFFFFFFFF: not delivered to this receiver
-    __shared__ int s_wave[16];
-    const int r = (int)blockIdx.x, t = (int)threadIdx.x;
+// bat[b] = {first alert of batch b, its length, the first alert's resolved record}: what a delivery needs to know about its batch
+// in ONE 16-byte gather -- and, for the nine batches in ten that hold a single alert, the record itself (res == nullptr, boundary
+// records: zeros there).  The generator is bound by the rate at which a CU turns scattered addresses into cache lines (2.65 x 10^11
+// scattered reads per second over the whole GPU, profiles/r05_gather_rate.txt): a second gather per delivery halves it.
+__global__ void gen_pack_batches_kernel(const long long* boff, int n_batches, const uint2* res, uint4* bat) {
+    const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (b >= n_batches) return;
+    const unsigned int f = (unsigned int)boff[b];
+    const uint2 r0 = res != nullptr ? res[f] : make_uint2(0u, 0u);
+    bat[b] = make_uint4(f, (unsigned int)(boff[b + 1] - boff[b]), r0.x, r0.y);
+}
+
+// ONE WAVE PER RECEIVER (a workgroup = kGenWavesPerBlock receivers; no barrier, no LDS): the wave walks its receiver's delivery
+// order kGenChunks x 64 deliveries at a time -- lane l of chunk u evaluates position j0 + 64 u + l of the permutation and gathers
+// its batch's {first alert, length} (all kGenChunks gathers in flight together), an inclusive scan over the lanes turns the
+// lengths into output positions, and the records go out: a batch of up to kGenLaneLoop alerts is written by its own lane, alert by
+// alert (consecutive lanes hold consecutive deliveries, so a step's stores fall into one contiguous stretch of the stream); a
+// chunk holding a longer batch is written record by record instead, every output record finding its delivery by a binary search
+// over the lanes' positions (six shuffles), whatever the lengths are.  alerts = the round's distinct alerts (20-byte records) in
+// batch order; every receiver's stream has n_alerts records: rec_off[r] = r * n_alerts.  boundary == 0: 8-byte resident records
+// {entry, core word} from res[]; else the 20-byte boundary records themselves (flags bit 0 = the batch end).  A batch ends with
+// its last alert, whatever the flags of the set say.  (Round 4: a workgroup per receiver, 1,024 deliveries per step between two
+// barriers, every output record found by a ten-step binary search in LDS: 1.8 - 2.5 ms per 1.5 x 10^8 records at 10^6 nodes.)
+constexpr int kGenWavesPerBlock = 4;
+constexpr int kGenChunks = 4;
+constexpr int kGenLaneLoop = 4;
+__global__ __launch_bounds__(kGenWavesPerBlock * 64) void gen_streams_kernel(const uint2* res, const unsigned char* alerts, const uint4* bat, int n_batches,
+                                                                             const unsigned int* keep, const int* receivers, int n_receivers,
+                                                                             long long n_alerts, unsigned long long seed, unsigned char* out,
+                                                                             int boundary) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const int r = (int)blockIdx.x * kGenWavesPerBlock + (int)(threadIdx.x >> 6);
+    if (r >= n_receivers) return;
     const GenPerm g = gen_perm_make(seed, (unsigned int)receivers[r], (unsigned int)n_batches);
-    long long at = (long long)r * n_alerts;
-    for (int j0 = 0; j0 < n_batches; j0 += kGenTile) {
-        unsigned int first[4];
-        int len[4], sum = 0;
+    long long at = (long long)r * n_alerts;  // the stream's next record
+    // record k of the batch whose first alert is f, `last`: it closes the batch; delivered == false: an empty record
+    // (r0 = the batch's first record as it came with the batch's table entry: resolved records only)
+    auto put = [&](long long i_out, unsigned int f, unsigned int k, bool last, bool delivered, uint2 r0) {
+        if (boundary == 0) {
+            uint2 v = make_uint2(0u, 0u);
+            if (delivered) {
+                v = k == 0u ? r0 : res[f + k];
+                v.y |= last ? kCoreEob : 0u;
+            }
+            reinterpret_cast<uint2*>(out)[i_out] = v;
+        } else {
+            unsigned int w[5] = {0u, 0u, 0u, 0u, 0u};
+            if (delivered) {
+                const unsigned int* src = reinterpret_cast<const unsigned int*>(alerts + (long long)(f + k) * 20);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = j0 + 4 * t + i;
-            first[i] = 0xFFFFFFFFu;
-            len[i] = 0;
+                for (int q = 0; q < 5; ++q) w[q] = src[q];
+                w[4] = (w[4] & ~0x01000000u) | (last ? 0x01000000u : 0u);
+            }
+            unsigned int* dst = reinterpret_cast<unsigned int*>(out + i_out * 20);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) dst[q] = w[q];
+        }
+    };
+    for (int j0 = 0; j0 < n_batches; j0 += 64 * kGenChunks) {
+        unsigned int first[kGenChunks], len[kGenChunks];
+        uint2 rec0[kGenChunks];
+        bool del[kGenChunks];
+#pragma unroll
+        for (int u = 0; u < kGenChunks; ++u) {
+            const int j = j0 + 64 * u + lane;
+            first[u] = 0u;
+            len[u] = 0u;
+            rec0[u] = make_uint2(0u, 0u);
+            del[u] = false;
             if (j < n_batches) {
                 const unsigned int b = gen_perm_at(g, (unsigned int)j);
-                const long long b0 = boff[b];
-                len[i] = (int)(boff[b + 1] - b0);
-                if (gen_delivered(g, keep, b)) first[i] = (unsigned int)b0;
+                const uint4 bt = bat[b];
+                first[u] = bt.x;
+                len[u] = bt.y;
+                rec0[u] = make_uint2(bt.z, bt.w);
+                del[u] = gen_delivered(g, keep, b);
             }
-            sum += len[i];
         }
-        int total = 0;
-        int base = block_exclusive_scan(sum, s_wave, &total);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            s_start[4 * t + i] = (unsigned int)base;
-            s_first[4 * t + i] = first[i];
-            base += len[i];
-        }
-        if (t == (int)blockDim.x - 1) s_start[kGenTile] = (unsigned int)total;
-        __syncthreads();
-        for (int o = t; o < total; o += (int)blockDim.x) {
-            int lo = 0, hi = kGenTile;  // the delivery that output record o belongs to: the last one that starts at or before o
-#pragma unroll
-            for (int step = 0; step < 10; ++step) {
-                const int mid = (lo + hi) >> 1;
-                const bool le = s_start[mid] <= (unsigned int)o;
-                lo = le ? mid : lo;
-                hi = le ? hi : mid;
+        for (int u = 0; u < kGenChunks; ++u) {
+            if (j0 + 64 * u >= n_batches) break;  // (wave-uniform)
+            int incl = (int)len[u];
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
             }
-            const unsigned int k = (unsigned int)o - s_start[lo], f = s_first[lo];
-            const bool last = (unsigned int)o + 1u == s_start[lo + 1];
-            const long long i_out = at + o;
-            if (boundary == 0) {
-                uint2 v = make_uint2(0u, 0u);
-                if (f != 0xFFFFFFFFu) {
-                    v = res[f + k];
-                    v.y |= last ? kCoreEob : 0u;
-                }
-                reinterpret_cast<uint2*>(out)[i_out] = v;
+            const int start = incl - (int)len[u];
+            const int total = __shfl(incl, 63, 64);
+            const bool any_long = __ballot(len[u] > (unsigned int)kGenLaneLoop) != 0ull;
+            if (!any_long) {
+                for (unsigned int k = 0; __ballot(len[u] > k) != 0ull; ++k)
+                    if (len[u] > k) put(at + start + (long long)k, first[u], k, k + 1u == len[u], del[u], rec0[u]);
             } else {
-                unsigned int w[5] = {0u, 0u, 0u, 0u, 0u};
-                if (f != 0xFFFFFFFFu) {
-                    const unsigned int* src = reinterpret_cast<const unsigned int*>(alerts + (long long)(f + k) * 20);
+                for (int o0 = 0; o0 < total; o0 += 64) {
+                    const int o = o0 + lane;
+                    int lo = 0;  // the last lane whose batch starts at or before output record o (lengths are >= 1 for real deliveries)
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) w[q] = src[q];
-                    w[4] = (w[4] & ~0x01000000u) | (last ? 0x01000000u : 0u);
+                    for (int step = 32; step > 0; step >>= 1) {
+                        const int mid = lo + step;
+                        const int s_mid = __shfl(start, mid & 63, 64);
+                        const int l_mid = __shfl((int)len[u], mid & 63, 64);
+                        if (mid < 64 && l_mid > 0 && s_mid <= o) lo = mid;
+                    }
+                    const int s_lo = __shfl(start, lo, 64);
+                    const unsigned int f_lo = (unsigned int)__shfl((int)first[u], lo, 64), n_lo = (unsigned int)__shfl((int)len[u], lo, 64);
+                    const int d_lo = __shfl(del[u] ? 1 : 0, lo, 64);
+                    const uint2 r_lo = make_uint2((unsigned int)__shfl((int)rec0[u].x, lo, 64), (unsigned int)__shfl((int)rec0[u].y, lo, 64));
+                    if (o < total) {
+                        const unsigned int k = (unsigned int)(o - s_lo);
+                        put(at + o, f_lo, k, k + 1u == n_lo, d_lo != 0, r_lo);
+                    }
                 }
-                unsigned int* dst = reinterpret_cast<unsigned int*>(out + i_out * 20);
-#pragma unroll
-                for (int q = 0; q < 5; ++q) dst[q] = w[q];
             }
+            at += total;
         }
-        at += total;
-        __syncthreads();
     }
 }
 __global__ void gen_offsets_kernel(long long* rec_off, int n_receivers, long long n_alerts) {

@@ -260,28 +260,35 @@ def _perm_keys(seed, receiver):
 
 def hashed_order(seed, receiver, n_batches):
     """The order in which rapid_sim_generate delivers the round's batches to `receiver` (its node index): position j holds
-    batch perm(j), a four-round alternating Feistel network over the smallest bit width covering n_batches, keyed by
-    mix64(seed + receiver), walked until it lands below n_batches (csrc/index_kernels.h: gen_perm_at)."""
+    batch perm(j), a four-round alternating Feistel network on [0, b) x [0, a) -- a = the power of two at or above
+    sqrt(n_batches), b = ceil(n_batches / a) --, keyed by mix64(seed + receiver), walked until it lands below n_batches
+    (csrc/index_kernels.h: gen_perm_at)."""
     n = int(n_batches)
     if n <= 1:
         return np.zeros(n, dtype=np.int64)
     rk, _ = _perm_keys(seed, receiver)
-    w = 2
-    while (1 << w) < n:
-        w += 1
-    a = w >> 1
-    mask_r, mask_l = np.uint32((1 << a) - 1), np.uint32((1 << (w - a)) - 1)
+    s = 1
+    while s < 16 and (1 << (2 * s)) < n:
+        s += 1
+    mask_r = np.uint32((1 << s) - 1)
+    b = np.uint32(max(1, (n + (1 << s) - 1) >> s))
+
+    def scale(x):  # [0, 2^32) -> [0, b)
+        return ((x.astype(np.uint64) * np.uint64(b)) >> np.uint64(32)).astype(np.uint32)
+
     x = np.arange(n, dtype=np.uint32)
     out = np.zeros(n, dtype=np.int64)
     todo = np.arange(n)
     with np.errstate(over="ignore"):
         while len(todo):
-            r, l = x & mask_r, x >> np.uint32(a)
-            l = l ^ (mix32(r + rk[0]) & mask_l)
-            r = r ^ (mix32(l + rk[1]) & mask_r)
-            l = l ^ (mix32(r + rk[2]) & mask_l)
-            r = r ^ (mix32(l + rk[3]) & mask_r)
-            x = (l << np.uint32(a)) | r
+            r, l = x & mask_r, x >> np.uint32(s)
+            l = l + scale(mix32(r + rk[0]))
+            l = np.where(l >= b, l - b, l)
+            r = (r + mix32(l + rk[1])) & mask_r
+            l = l + scale(mix32(r + rk[2]))
+            l = np.where(l >= b, l - b, l)
+            r = (r + mix32(l + rk[3])) & mask_r
+            x = (l << np.uint32(s)) | r
             done = x < n
             out[todo[done]] = x[done]
             todo, x = todo[~done], x[~done]

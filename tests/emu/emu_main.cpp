@@ -405,10 +405,16 @@ extern "C" int emu_generate(const unsigned char* alerts, const long long* boff, 
         for (unsigned b = 0; b < g; ++b)
             emu::run_block(b, g, 256u, [&] { rapid::gen_resolve_alerts_kernel(alerts, A, cfg_id, (unsigned int)n_nodes, entries, res.data()); }, sd + b);
     }
-    for (int r = 0; r < n_receivers; ++r)
-        emu::run_block((unsigned)r, (unsigned)n_receivers, 256u, [&] {
-            rapid::gen_streams_kernel(res.data(), alerts, boff, n_batches, keep, receivers, A, seed, out, boundary);
-        }, sd + 100 + (unsigned)r);
+    std::vector<uint4> bat((size_t)std::max(n_batches, 1));
+    {
+        const unsigned g = (unsigned)std::max(1, (n_batches + 255) / 256);
+        for (unsigned b = 0; b < g; ++b) emu::run_block(b, g, 256u, [&] { rapid::gen_pack_batches_kernel(boff, n_batches, boundary ? nullptr : res.data(), bat.data()); }, sd + 50 + b);
+    }
+    const unsigned gw = (unsigned)((n_receivers + rapid::kGenWavesPerBlock - 1) / rapid::kGenWavesPerBlock);
+    for (unsigned b = 0; b < gw; ++b)
+        emu::run_block(b, gw, (unsigned)rapid::kGenWavesPerBlock * 64u, [&] {
+            rapid::gen_streams_kernel(res.data(), alerts, bat.data(), n_batches, keep, receivers, n_receivers, A, seed, out, boundary);
+        }, sd + 100 + b);
     const unsigned g = (unsigned)((n_receivers + 1 + 255) / 256);
     for (unsigned b = 0; b < g; ++b) emu::run_block(b, g, 256u, [&] { rapid::gen_offsets_kernel(rec_off_out, n_receivers, A); }, sd + 900 + b);
     return 0;
