@@ -464,7 +464,10 @@ int rapid_sim_pass_times(rapid_engine* h, float out[4]);
  * round index built by several workgroups (the form of populations >= 40,000 nodes) whatever the size, 16384 = a view change
  * sorts all K rings again instead of compacting / merging the old ones, 131072 = the round index of a declared alert set built
  * by the two-kernel form (touch pass + one workgroup) instead of the one-launch form, 262144 = the vote verification compares the
- * voters' node lists instead of their slot bitmaps, 32 = measurement only: stream the records through
+ * voters' node lists instead of their slot bitmaps, 8192 = the packed detector state (two slots per LDS word: the form of rounds with
+ * more than 4,096 hot subjects) whatever the size, 1048576 = packed rounds over boundary records keep their dictionary in LDS as hashed
+ * buckets of one-byte remainders (exact; slots renumbered in hash order) instead of looking subjects up in memory, where the round
+ * is eligible (every named subject hot, at most 2^21 nodes), 32 = measurement only: stream the records through
  * the registers without tallying them (results are meaningless).  Every bit selects another PRODUCT path or instantiation
  * (all of them parity-tested); none adds code that the default does not ship. */
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);

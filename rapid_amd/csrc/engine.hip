@@ -188,6 +188,12 @@ struct rapid_engine {
     DevBuf<unsigned short> d_dict, d_decl, d_adj_off, d_trank;
     DevBuf<unsigned int> d_tbits, d_tent;  // compressed dictionary (index_build_block_kernel)
     DevBuf<unsigned int> d_entries;        // dict_entry per node for rounds whose tables stay in memory
+    // the hashed dictionary of packed rounds (index_hash_kernel): bucket bounds, remainders, member bits; the renumbered per-slot tables
+    DevBuf<unsigned short> d_hoff, d_hnew, d_smask2;
+    DevBuf<unsigned int> d_hrem, d_hmem, d_adj2;  // (d_hrem: bytes, allocated in whole dwords -- the tally stages it dword by dword)
+    DevBuf<int> d_nos2;
+    unsigned int hash_mul = 0;
+    bool hash_lds_attr_set = false;
     DevBuf<uint2> d_gen_res;          // rapid_sim_generate: the alert set resolved once ({entry, core word} per alert)
     DevBuf<unsigned int> d_gen_keep;  // ... per-batch delivery thresholds
     DevBuf<long long> d_gen_boff;
@@ -846,7 +852,7 @@ int build_round_index(rapid_engine* h) {
     // ---- launch geometry: fill the CU's LDS with as many receiver-waves as possible ----
     const int lds_max = 160 * 1024;
     // rounds with thousands of hot subjects keep two slots per LDS word (the detector state decides how many receivers a CU holds)
-    h->packed = rapid::tally_wants_packed(h->n_hot);
+    h->packed = rapid::tally_wants_packed(h->n_hot) || ((h->force_exact & 8192) != 0 && h->n_hot > 0);  // (testing knob bit 13: packed whatever the size)
     const int per_wave = rapid::tally_wave_bytes(h->n_slots, h->packed);
     const int sh_direct = rapid::tally_shared_bytes(rapid::kDictDirect, N, h->n_touched, h->n_hot, h->n_adj, h->packed);
     const int sh_comp = rapid::tally_shared_bytes(rapid::kDictCompressed, N, h->n_touched, h->n_hot, h->n_adj, h->packed);
@@ -861,8 +867,19 @@ int build_round_index(rapid_engine* h) {
     // tally looks nothing up (kDictResolved).  The modes in which the tally itself maps node -> slot remain as cross-checks
     // behind the testing knob: bit 15 = look up in the tally, from the tables placed as described above.
     const bool no_direct = (h->force_exact & (128 | 256)) != 0 || info[7] == 0, no_lds = (h->force_exact & 256) != 0;  // info[7]: the build kernel's own verdict
+    // Packed rounds over boundary records look their subjects up in memory (one dict_entry per node, gathered through L2).  Knob bit
+    // 20: in LDS instead, as hashed buckets of one-byte remainders (kDictHashed) -- when every named subject is hot (a miss is then a
+    // report the alert set does not cover, nothing else), the key fits kHashMaxKeyBits and at least three receivers still fit the
+    // CU next to it.  Exact and parity-tested, but no faster at 10^6 nodes (1.46 against 1.40 ms per 1.5 x 10^8 records): the exact
+    // lookup costs ~50 vector instructions per record where the gather costs the CU's address-coalescing time, and with one wave
+    // per SIMD neither hides behind anything (profiles/r05_c5_hashed_dictionary.txt) -- so it is not the default.
+    const int sh_hash = rapid::tally_shared_bytes(rapid::kDictHashed, N, h->n_hot, h->n_hot, h->n_adj, true);
+    const bool hash_ok = h->packed && h->rec_fmt == rapid::kFmtBoundary && h->n_hot > 0 && h->n_touched == h->n_hot && (h->force_exact & 1048576) != 0 &&
+                         rapid::hash_key_bits(N) <= rapid::kHashMaxKeyBits && sh_hash + 3 * per_wave + rapid::kBlockStatsBytes <= lds_max;
     if (h->rec_fmt == rapid::kFmtResident)
         h->dict_mode = rapid::kDictResolved;  // generated records carry their subjects' entries
+    else if (hash_ok)
+        h->dict_mode = rapid::kDictHashed;
     else if (h->packed)
         h->dict_mode = rapid::kDictMemory;    // (the LDS goes to the receivers' state)
     else if (!no_direct && sh_direct + 8 * per_wave + rapid::kBlockStatsBytes <= lds_max)
@@ -877,7 +894,42 @@ int build_round_index(rapid_engine* h) {
         hipLaunchKernelGGL(rapid::dict_entries_kernel, dim3(grid_for((long long)N + 1, 256)), dim3(256), 0, st, h->d_dict.p, h->d_decl.p, N, h->n_hot,
                            h->d_entries.p);
     }
-    const int sh = h->dict_mode == rapid::kDictDirect ? sh_direct : h->dict_mode == rapid::kDictCompressed ? sh_comp : sh_mem;
+    if (h->dict_mode == rapid::kDictHashed) {
+        // one more launch and one more answer to wait for (~20 us on a round of milliseconds): the hot subjects renumbered in the
+        // order the hashed lookup yields, the per-slot tables and the triples rewritten into their second buffers
+        const int nb = rapid::hash_buckets(N);
+        HIPCHK(h, h->d_hoff.ensure((size_t)nb + 4));
+        HIPCHK(h, h->d_hrem.ensure(((size_t)h->n_hot + rapid::kHashPad + 3) / 4 + 1));
+        HIPCHK(h, h->d_hmem.ensure(((size_t)h->n_hot + 31) / 32 + 1));
+        HIPCHK(h, h->d_hnew.ensure((size_t)h->n_hot + 1));
+        HIPCHK(h, h->d_nos2.ensure((size_t)N));
+        HIPCHK(h, h->d_smask2.ensure((size_t)N + 1));
+        HIPCHK(h, h->d_adj2.ensure((size_t)adj_cap + 1));
+        const size_t hl = (size_t)rapid::index_hash_lds_bytes(N, h->n_hot);
+        if (!h->hash_lds_attr_set) {
+            HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rapid::index_hash_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            h->hash_lds_attr_set = true;
+        }
+        bool hashed = false;
+        if (hl <= 96 * 1024) {
+            hipLaunchKernelGGL(rapid::index_hash_kernel, dim3(1), dim3(1024), hl, st, h->d_node_of_slot.p, h->d_adj_off.p, h->d_adj.p, h->n_hot, h->n_adj, N,
+                               h->d_member.p, h->d_hoff.p, reinterpret_cast<unsigned char*>(h->d_hrem.p), h->d_hmem.p, h->d_nos2.p, h->d_smask2.p, h->d_adj2.p,
+                               h->d_hnew.p, h->d_entries.p, h->d_dict.p, reinterpret_cast<volatile int*>(h->d_mail), (int)++h->mail_seq);
+            HIPCHK(h, hipGetLastError());
+            if (int rc = await_mail(h, 11, h->mail_seq)) return rc;
+            int ans[2];
+            std::memcpy(ans, h->h_mail + 48, sizeof ans);
+            hashed = ans[0] == 1;
+            if (hashed) {
+                h->hash_mul = rapid::hash_multiplier(ans[1]);
+                std::swap(h->d_node_of_slot, h->d_nos2);
+                std::swap(h->d_adj_off, h->d_smask2);
+                std::swap(h->d_adj, h->d_adj2);
+            }
+        }
+        if (!hashed) h->dict_mode = rapid::kDictMemory;  // (no multiplier keeps every bucket within its capacity: the dictionary stays in memory)
+    }
+    const int sh = h->dict_mode == rapid::kDictDirect ? sh_direct : h->dict_mode == rapid::kDictCompressed ? sh_comp : h->dict_mode == rapid::kDictHashed ? sh_hash : sh_mem;
     // Waves per CU (one workgroup per CU, its receivers claimed by its waves from a counter in LDS).  A CU's share of
     // the memory system is saturated by the stream loads of ~7 waves; with w waves a CU works through its n receivers in
     // floor(n / w) full rounds, each as long as w streams sharing the CU's bandwidth, plus a last round of the m
@@ -949,6 +1001,11 @@ int launch_tally(rapid_engine* h) {
     p.idx.tent = h->d_tent.p;
     p.idx.n_touched = h->n_touched;
     p.idx.entries = h->d_entries.p;
+    p.idx.hoff = h->d_hoff.p;
+    p.idx.hrem = reinterpret_cast<const unsigned char*>(h->d_hrem.p);
+    p.idx.hmem = h->d_hmem.p;
+    p.idx.hmul = h->hash_mul;
+    p.idx.hbits = rapid::hash_key_bits(h->n_nodes);
     p.error_flags = h->d_errflags.p;
     p.stream_bytes = h->records_bytes;
     p.idx.node_of_slot = h->d_node_of_slot.p;
@@ -999,6 +1056,8 @@ int launch_tally(rapid_engine* h) {
     const size_t lds = (size_t)h->lds_bytes;
     using namespace rapid;
     switch ((h->packed ? 16 : 0) + (h->rec_fmt == kFmtBoundary ? 0 : 8) + h->dict_mode * 2 + (trusted ? 1 : 0)) {
+        case 24: hipLaunchKernelGGL((tally_population_kernel<kDictHashed, false, kFmtBoundary, true>), grid, block, lds, h->stream, p); break;
+        case 25: hipLaunchKernelGGL((tally_population_kernel<kDictHashed, true, kFmtBoundary, true>), grid, block, lds, h->stream, p); break;
         case 16: hipLaunchKernelGGL((tally_population_kernel<kDictMemory, false, kFmtBoundary, true>), grid, block, lds, h->stream, p); break;
         case 17: hipLaunchKernelGGL((tally_population_kernel<kDictMemory, true, kFmtBoundary, true>), grid, block, lds, h->stream, p); break;
         case 30: hipLaunchKernelGGL((tally_population_kernel<kDictResolved, false, kFmtResident, true>), grid, block, lds, h->stream, p); break;
@@ -1044,7 +1103,9 @@ int prepare_tally(rapid_engine* h) {
 int ensure_tally_attrs(rapid_engine* h) {
     if (!h->lds_attr_set) {  // once per engine: every instantiation may use the whole 160 KiB of LDS
         using namespace rapid;
-        const void* kernels[12] = {reinterpret_cast<const void*>(tally_population_kernel<kDictResolved, false, kFmtResident, true>),
+        const void* kernels[14] = {reinterpret_cast<const void*>(tally_population_kernel<kDictHashed, false, kFmtBoundary, true>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictHashed, true, kFmtBoundary, true>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictResolved, false, kFmtResident, true>),
                                   reinterpret_cast<const void*>(tally_population_kernel<kDictResolved, true, kFmtResident, true>),
                                   reinterpret_cast<const void*>(tally_population_kernel<kDictMemory, false, kFmtBoundary, true>),
                                   reinterpret_cast<const void*>(tally_population_kernel<kDictMemory, true, kFmtBoundary, true>),
@@ -1131,6 +1192,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_ids_hi2.release(); h->d_ids_lo2.release(); h->d_ids_new.release(); h->d_cfg_partial.release(); h->d_chunk_kept.release();
     h->d_bitmaps.release();
     h->d_vacc.release();
+    h->d_hoff.release(); h->d_hnew.release(); h->d_smask2.release(); h->d_hrem.release(); h->d_hmem.release(); h->d_adj2.release(); h->d_nos2.release();
     h->d_gone.release();
     h->d_edges.release(); h->d_edge_mask.release();
     h->d_joiners.release(); h->d_join_nodes.release(); h->d_join_vals.release(); h->d_join_keys.release(); h->d_join_skeys.release();
@@ -2683,7 +2745,7 @@ int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, in
 
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on) {
     if (!h) return RAPID_EINVAL;
-    if (((h->force_exact ^ on) & (64 | 128 | 256 | 4096)) != 0) h->index_valid = false;  // the launch geometry depends on the instantiation and on where the dictionary lives
+    if (((h->force_exact ^ on) & (64 | 128 | 256 | 4096 | 8192 | 1048576)) != 0) h->index_valid = false;  // the launch geometry depends on the instantiation and on where the dictionary lives
     h->force_exact = on;
     return RAPID_OK;
 }

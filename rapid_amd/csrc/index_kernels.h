@@ -18,8 +18,8 @@ namespace rapid {
 // gmask[dst] |= ring_mask over every record given (the round's distinct alert set if the host declared one, else
 // every delivered record -- 20-byte boundary records either way).  After the first few thousand records nearly every bit is
 // already set, so the (possibly stale, L1-cached) pre-test avoids almost all atomics.  Also validates the records once:
-// vflags bit0 is set if ANY record fails the filter of R/MembershipService.java:644-675 under the current view (or names a
-// node out of range or no ring), bit1 if any record is an UP alert.
+// vflags bit0 is set if ANY record of the CURRENT configuration fails the rest of the filter of R/MembershipService.java:644-675
+// under the current view (or names a node out of range or no ring), bit1 if any record is an UP alert.
 __global__ void index_touch_kernel(const unsigned char* records, long long n_records, int n_nodes, unsigned int kmask, long long cfg_id,
                                    const unsigned char* member, unsigned int* gmask, unsigned int* vflags) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -32,8 +32,10 @@ __global__ void index_touch_kernel(const unsigned char* records, long long n_rec
         const unsigned int bits = cw & kmask;
         const bool down = (cw & kCoreDown) != 0u;
         if (dst < (unsigned)n_nodes && bits != 0u && (bits & ~gmask[dst]) != 0u) atomicOr(&gmask[dst], bits);
-        const bool ok = current && dst < (unsigned)n_nodes && bits != 0u &&
-                        ((member[dst < (unsigned)n_nodes ? dst : 0u] != 0) == down);
+        // (an alert of another configuration is not validated: whatever it says, every delivery that is a copy of it is dropped
+        // whole by the tally's configuration-id compare, R/MembershipService.java:653-657 -- late deliveries among a round's
+        // batches do not cost the round its pre-validated instantiation)
+        const bool ok = !current || (dst < (unsigned)n_nodes && bits != 0u && ((member[dst < (unsigned)n_nodes ? dst : 0u] != 0) == down));
         f |= (ok ? 0u : 1u) | (down ? 0u : 2u);
     }
     if (f) atomicOr(vflags, f);
@@ -511,6 +513,122 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
     if (t < 8) info[t] = 0;
 }
 
+// ---- the hashed dictionary of rounds with thousands of hot subjects (tally_kernel.h: kDictHashed) ---------------------------------
+// One workgroup, behind the index build of a round whose every named subject is hot.  The hot subjects are RENUMBERED: slot =
+// position in the order of (bucket, remainder) of the key x = (node * mul) mod 2^bits -- the order the dictionary's lookup yields
+// by itself (bucket's first slot + index of the matching remainder), so that no position -> slot table is needed.  Everything that
+// carries slot numbers follows: node_of_slot and smask (written in the new order into their second buffers), the triples (both
+// slot fields mapped), and the per-node tables in memory (entries[], dict[]: patched for the hot nodes, so that a launch that looks
+// subjects up in memory, or records resolved against entries[], agree with the renumbered tables).  The multiplier is the first
+// of kHashMultipliers under which no bucket holds more than kHashBucketCap keys (consecutive node indices -- joiners are registered
+// in a block -- spread evenly under a multiplicative hash; random ones fill buckets like balls into bins: 4,096 buckets, 15,000 keys,
+// a bucket of 17 once in 10^3 rounds); answer[0] = 1 and answer[1] = the multiplier's index, or answer[0] = 0: the host falls back
+// to the dictionary in memory.  mail: the host-mapped page, words 12 and 13, sequence word 11.
+constexpr int kHashTries = 4;
+__host__ __device__ inline unsigned int hash_multiplier(int i) {  // odd 24-bit constants (v_mul_u32_u24 territory)
+    return i == 0 ? 0x9E3779u : i == 1 ? 0x85EBCBu : i == 2 ? 0xC2B2AFu : 0x27D4EBu;
+}
+__global__ __launch_bounds__(1024) void index_hash_kernel(const int* node_of_slot, const unsigned short* smask, const unsigned int* pairs, int n_hot, int n_adj,
+                                                          int n_nodes, const unsigned char* member, unsigned short* hoff, unsigned char* hrem,
+                                                          unsigned int* hmem, int* node_of_slot_new, unsigned short* smask_new, unsigned int* pairs_new,
+                                                          unsigned short* new_of_old, unsigned int* entries, unsigned short* dict,
+                                                          volatile int* mail, int seq) {
+    unsigned char* const hash_lds = dynamic_lds();
+    __shared__ int s_wave[16];
+    __shared__ int s_max, s_choice;
+    const int T = (int)blockDim.x, t = (int)threadIdx.x;
+    const int bits = hash_key_bits(n_nodes), nb = 1 << (bits - kHashRemBits);
+    const unsigned int kmask = (1u << bits) - 1u;
+    unsigned int* const cnt = reinterpret_cast<unsigned int*>(hash_lds);              // [nb] keys per bucket, then the running cursor
+    unsigned int* const off = cnt + nb;                                                // [nb + 1] first slot per bucket
+    unsigned short* const byb = reinterpret_cast<unsigned short*>(off + nb + 1);      // [n_hot] old slots grouped by bucket (unordered inside)
+    if (t == 0) s_choice = -1;
+    __syncthreads();
+    for (int tr = 0; tr < kHashTries; ++tr) {
+        const unsigned int mul = hash_multiplier(tr);
+        for (int b = t; b < nb; b += T) cnt[b] = 0u;
+        if (t == 0) s_max = 0;
+        __syncthreads();
+        for (int i = t; i < n_hot; i += T) atomicAdd(&cnt[(((unsigned int)node_of_slot[i] * mul) & kmask) >> kHashRemBits], 1u);
+        __syncthreads();
+        int mx = 0;
+        for (int b = t; b < nb; b += T) mx = max(mx, (int)cnt[b]);
+        if (mx > 0) atomicMax(&s_max, mx);
+        __syncthreads();
+        if (s_max <= kHashBucketCap) {
+            if (t == 0) s_choice = tr;
+            __syncthreads();
+            break;
+        }
+        __syncthreads();
+    }
+    const int choice = s_choice;
+    if (choice >= 0) {
+        const unsigned int mul = hash_multiplier(choice);
+        // first slot of every bucket: an exclusive scan of the counts (each thread owns a contiguous run of buckets)
+        const int per = (nb + T - 1) / T, b0 = min(nb, t * per), b1 = min(nb, b0 + per);
+        int mine = 0;
+        for (int b = b0; b < b1; ++b) mine += (int)cnt[b];
+        int total = 0;
+        int at = block_exclusive_scan(mine, s_wave, &total);
+        for (int b = b0; b < b1; ++b) {
+            off[b] = (unsigned int)at;
+            at += (int)cnt[b];
+        }
+        if (t == 0) off[nb] = (unsigned int)total;
+        __syncthreads();
+        for (int b = t; b < nb; b += T) cnt[b] = 0u;  // (now the cursor inside the bucket)
+        __syncthreads();
+        for (int i = t; i < n_hot; i += T) {
+            const unsigned int b = (((unsigned int)node_of_slot[i] * mul) & kmask) >> kHashRemBits;
+            byb[off[b] + atomicAdd(&cnt[b], 1u)] = (unsigned short)i;
+        }
+        __syncthreads();
+        // a key's slot = its bucket's first slot + the keys of the bucket with a smaller remainder (distinct within a bucket)
+        for (int i = t; i < n_hot; i += T) {
+            const int node = node_of_slot[i];
+            const unsigned int x = ((unsigned int)node * mul) & kmask, b = x >> kHashRemBits, r = x & 255u;
+            int below = 0;
+            for (unsigned int j = off[b]; j < off[b + 1]; ++j) {
+                const unsigned int xo = ((unsigned int)node_of_slot[byb[j]] * mul) & kmask;
+                below += (xo & 255u) < r ? 1 : 0;
+            }
+            const unsigned int pos = off[b] + (unsigned int)below;
+            new_of_old[i] = (unsigned short)pos;
+            hrem[pos] = (unsigned char)r;
+            node_of_slot_new[pos] = node;
+            smask_new[pos] = smask[i];
+            entries[node] = (entries[node] & 0x1FFFFu) | (pos << 17);
+            dict[node] = (unsigned short)((dict[node] & 0xC000u) | pos);
+        }
+        for (int b = t; b <= nb; b += T) hoff[b] = (unsigned short)off[b];
+        for (int i = n_hot + t; i < n_hot + kHashPad; i += T) hrem[i] = 0;
+        for (int w = t; w < (n_hot + 31) / 32; w += T) hmem[w] = 0u;
+        __threadfence_block();
+        __syncthreads();
+        for (int i = t; i < n_hot; i += T)
+            if (member[node_of_slot[i]] != 0) atomicOr(&hmem[new_of_old[i] >> 5], 1u << (new_of_old[i] & 31u));
+        for (int a = t; a < n_adj; a += T) {
+            const unsigned int pr = pairs[a];
+            pairs_new[a] = (unsigned int)new_of_old[pr & 0x3FFFu] | ((unsigned int)new_of_old[(pr >> 14) & 0x3FFFu] << 14) | (pr & 0xF0000000u);
+        }
+    }
+    __syncthreads();
+    if (t < 2) {
+        mail[12 + t] = t == 0 ? (choice >= 0 ? 1 : 0) : choice;
+        __threadfence_system();
+    }
+    __syncthreads();
+    if (t == 0) {
+        __threadfence_system();
+        mail[11] = seq;
+    }
+}
+__host__ __device__ inline int index_hash_lds_bytes(int n_nodes, int n_hot) {
+    const int nb = hash_buckets(n_nodes);
+    return (2 * nb + 1) * 4 + ((n_hot + 1) & ~1) * 2 + 16;
+}
+
 // ---- a declared alert set over a population of up to kIndexFusedMaxNodes nodes: the whole index in ONE launch ----------------
 // The round index is on every round's path, ahead of the tally, and as two kernels (touch, then one workgroup) it lived on
 // dependent memory round trips: the per-node ring masks written by atomics of the touch pass and read back by the build, the
@@ -588,7 +706,7 @@ __global__ __launch_bounds__(1024) void index_fused_kernel(const unsigned char* 
             const unsigned int bits = cw & kmask;
             const bool down = (cw & kCoreDown) != 0u;
             if (inr && bits != 0u) atomicOr(&l_decl32[dst >> 1], bits << ((dst & 1u) * 16u));  // (whatever the filter says: a superset, as in index_touch_kernel)
-            const bool ok = current && inr && bits != 0u && ((l_mem[inr ? dst : 0u] != 0) == down);
+            const bool ok = !current || (inr && bits != 0u && ((l_mem[inr ? dst : 0u] != 0) == down));  // (see index_touch_kernel)
             f |= (ok ? 0u : 1u) | (down ? 0u : 2u);
         }
     }
@@ -823,7 +941,10 @@ struct GenPerm {
 __host__ __device__ inline GenPerm gen_perm_make(unsigned long long seed, unsigned int receiver_node, unsigned int n_batches) {
     GenPerm g;
     const unsigned long long key = gen_mix64(seed + (unsigned long long)receiver_node);
-    for (int i = 0; i < 4; ++i) g.rk[i] = (unsigned int)(gen_mix64(key + (unsigned long long)(i + 1)) >> 32);
+    g.rk[0] = (unsigned int)(gen_mix64(key + 1ull) >> 32);  // (spelled out: a loop over rk[] left the round keys in scratch memory)
+    g.rk[1] = (unsigned int)(gen_mix64(key + 2ull) >> 32);
+    g.rk[2] = (unsigned int)(gen_mix64(key + 3ull) >> 32);
+    g.rk[3] = (unsigned int)(gen_mix64(key + 4ull) >> 32);
     g.keepk = gen_mix64(key ^ 0xD1B54A32D192ED03ull);
     g.n = n_batches;
     unsigned int s = 1;
@@ -911,7 +1032,8 @@ __global__ __launch_bounds__(kGenWavesPerBlock * 64) void gen_streams_kernel(con
         if (boundary == 0) {
             uint2 v = make_uint2(0u, 0u);
             if (delivered) {
-                v = k == 0u ? r0 : res[f + k];
+                v = r0;  // (not `k == 0 ? r0 : res[f + k]`: a select between a register pair and memory is compiled as a select of ADDRESSES --
+                if (k != 0u) v = res[f + k];  //  r0 spilled to scratch memory so that it has one, and a flat load through the chosen pointer)
                 v.y |= last ? kCoreEob : 0u;
             }
             reinterpret_cast<uint2*>(out)[i_out] = v;
@@ -950,7 +1072,7 @@ __global__ __launch_bounds__(kGenWavesPerBlock * 64) void gen_streams_kernel(con
         }
 #pragma unroll
         for (int u = 0; u < kGenChunks; ++u) {
-            if (j0 + 64 * u >= n_batches) break;  // (wave-uniform)
+            if (j0 + 64 * u >= n_batches) continue;  // (wave-uniform; `continue`, so that the loop unrolls and first[] / len[] stay in registers)
             int incl = (int)len[u];
             for (int off = 1; off < 64; off <<= 1) {
                 const int o = __shfl_up(incl, off, 64);

@@ -147,6 +147,18 @@ struct RoundIndex {
     // head of the launch.  Tables in memory: ONE gather per record (the entries of the round's hot subjects, all that most
     // records ever ask for, stay in the caches).
     const unsigned int* entries;
+    // kDictHashed (rounds with thousands of hot subjects over populations of up to 2^21 nodes, every named subject hot): the hot
+    // subjects as an EXACT dictionary in ~1.7 bytes per key, small enough for the LDS next to the receivers' state.  A node's key is
+    // x = (node * hmul) mod 2^hbits (hmul odd: a bijection of the hbits-bit numbers; hbits covers n_nodes), its bucket x >> 8, its
+    // remainder x & 255; the slots are numbered by (bucket, remainder), hoff[b] = first slot of bucket b (hoff[buckets] = n_hot),
+    // hrem[slot] = the slot's remainder (one byte; 32 bytes of padding behind the last), hmem bit slot = the node is a member.
+    // A bucket holds at most kHashBucketCap keys (index_hash_kernel tries multipliers until that holds).  (bucket, remainder)
+    // determine the node, so a match is the node itself, never a look-alike.
+    const unsigned short* hoff;     // [hbuckets + 1]
+    const unsigned char* hrem;      // [n_hot + 32]
+    const unsigned int* hmem;       // [(n_hot + 31) / 32]
+    unsigned int hmul;
+    int hbits;
     const int* node_of_slot;        // [n_hot]
     // the hot adjacency: pairs[a] = subject slot | observer slot << 14 | ring << 28 for every (subject, ring, observer) triple
     // among hot slots -- one potential implicit report each (R/MultiNodeCutDetector.java:137-164); smask[slot] = the rings on
@@ -225,10 +237,20 @@ __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
 // GPU does that at memory speed, whereas the tally would do it 64 lanes at a time between two dependent LDS or L2 round
 // trips, and give 40 KB of LDS per workgroup (or, at 10^5 .. 10^6 nodes, its whole speed) for the tables.  The other three
 // modes read the subject's node index and look it up themselves; they stay as cross-checks (testing knobs bit 7 / 8).
-enum { kDictMemory = 0, kDictDirect = 1, kDictCompressed = 2, kDictResolved = 3 };
+enum { kDictMemory = 0, kDictDirect = 1, kDictCompressed = 2, kDictResolved = 3, kDictHashed = 4 };
+// the hashed dictionary's geometry: key bits (>= 10, covering n_nodes), one-byte remainders, at most kHashBucketCap keys per bucket
+constexpr int kHashRemBits = 8, kHashBucketCap = 16, kHashMaxKeyBits = 21, kHashPad = 32;
+__host__ __device__ inline int hash_key_bits(int n_nodes) {
+    int b = 10;
+    while (b < 31 && (1ll << b) < (long long)n_nodes) ++b;
+    return b;
+}
+__host__ __device__ inline int hash_buckets(int n_nodes) { return 1 << (hash_key_bits(n_nodes) - kHashRemBits); }
 __host__ __device__ inline int tally_dict_bytes(int mode, int n_nodes, int n_touched) {
     if (mode == kDictDirect) return align16((n_nodes + 1) * 4);  // one dict_entry per node + the entry out-of-range subjects are sent to
     if (mode == kDictCompressed) return align16(((n_nodes + 31) / 32) * 4) + align16(((n_nodes + 31) / 32) * 2) + align16(n_touched * 4);
+    if (mode == kDictHashed)  // (every named subject is hot in such a round: n_touched == n_hot)
+        return align16((hash_buckets(n_nodes) + 1) * 2) + align16(n_touched + kHashPad) + align16(((n_touched + 31) / 32) * 4);
     return 0;
 }
 // slot -> node (read once per proposed node, when a receiver's proposal is written) stays in memory when a round has so
@@ -616,7 +638,9 @@ __host__ __device__ constexpr int tally_max_waves(int dict_mode, bool trusted, i
 #endif
 template <int kDictMode, bool kTrusted, int kFmt = kFmtResident, bool kPacked = false>
 __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked) * 64) RAPID_TALLY_OCCUPANCY void tally_population_kernel(TallyParams p) {
-    static_assert(!kPacked || kDictMode == kDictMemory || kDictMode == kDictResolved, "packed detector state: dictionary in memory, or none");
+    static_assert(!kPacked || kDictMode == kDictMemory || kDictMode == kDictResolved || kDictMode == kDictHashed,
+                  "packed detector state: dictionary in memory, hashed in LDS, or none");
+    static_assert(kDictMode != kDictHashed || kFmt == kFmtBoundary, "the hashed dictionary maps the subjects of boundary records");
     static_assert(kFmt == kFmtResident || kDictMode != kDictResolved, "a boundary record carries its subject, not an entry");
     constexpr bool kTablesInLds = kDictMode == kDictDirect;
 #ifndef RAPID_LEAN_OPEN
@@ -667,6 +691,39 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
         tbits = l_bits;
         trank = l_rank;
         tent = l_ent;
+    }
+    // kDictHashed: bucket bounds, remainders and member bits, staged like the compressed tables (dword copies, four in flight)
+    const unsigned short* l_hoff = nullptr;
+    const unsigned char* l_hrem = nullptr;
+    const unsigned int* l_hmem = nullptr;
+    const unsigned int hmask = p.idx.hbits >= 32 ? 0xFFFFFFFFu : ((1u << p.idx.hbits) - 1u), hmul = p.idx.hmul;
+    if (kDictMode == kDictHashed) {
+        const int nb = hash_buckets(p.n_nodes);
+        const int w_off = (nb + 1 + 1) / 2, w_rem = (p.idx.n_touched + kHashPad + 3) / 4, w_mem = (p.idx.n_touched + 31) / 32;
+        unsigned int* const d_off = reinterpret_cast<unsigned int*>(smem);
+        unsigned int* const d_rem = reinterpret_cast<unsigned int*>(smem + align16((nb + 1) * 2));
+        unsigned int* const d_mem = reinterpret_cast<unsigned int*>(smem + align16((nb + 1) * 2) + align16(p.idx.n_touched + kHashPad));
+        auto stage32h = [&](unsigned int* dst, const unsigned int* src, int n) {
+            for (int base = 0; base < n; base += 4 * (int)blockDim.x) {
+                unsigned int v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = base + j * (int)blockDim.x + (int)threadIdx.x;
+                    v[j] = i < n ? src[i] : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = base + j * (int)blockDim.x + (int)threadIdx.x;
+                    if (i < n) dst[i] = v[j];
+                }
+            }
+        };
+        stage32h(d_off, reinterpret_cast<const unsigned int*>(p.idx.hoff), w_off);  // (the global tables are allocated in whole dwords)
+        stage32h(d_rem, reinterpret_cast<const unsigned int*>(p.idx.hrem), w_rem);
+        stage32h(d_mem, p.idx.hmem, w_mem);
+        l_hoff = reinterpret_cast<const unsigned short*>(d_off);
+        l_hrem = reinterpret_cast<const unsigned char*>(d_rem);
+        l_hmem = d_mem;
     }
     const unsigned int* entries = nullptr;  // direct mode: dict_entry per node, [n_nodes] = where out-of-range subjects are sent
     if (kTablesInLds) {
@@ -878,6 +935,38 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
         }
         if (kDictMode == kDictMemory) {
             k.entry = p.idx.entries[min(w3, n_nodes_u)];
+            return k;
+        }
+        if (kDictMode == kDictHashed) {
+            // bucket bounds (two 16-bit reads), the bucket's remainders -- sixteen bytes from its first slot on, fetched as five
+            // aligned dwords and shifted into place --, a bytewise compare with the key's remainder, the member bit of the slot
+            // that matched.  (x - 0x01010101) & ~x & 0x80808080 marks the zero bytes of x; its lowest mark is exact, and the
+            // first match is the only one: the remainders of a bucket are distinct.  A match past the bucket's own slots
+            // belongs to a later bucket: no match.
+            const bool in = w3 < n_nodes_u;
+            const unsigned int x = (w3 * hmul) & hmask;
+            const unsigned int b = in ? x >> kHashRemBits : 0u, r = x & 255u;
+            const unsigned int o0 = l_hoff[b], o1 = l_hoff[b + 1];
+            const unsigned int* const wp = reinterpret_cast<const unsigned int*>(l_hrem + (o0 & ~3u));
+            const unsigned int d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3], d4 = wp[4];
+            const unsigned int sh = (o0 & 3u) * 8u;
+            const unsigned int pat = r * 0x01010101u;
+            auto zero_marks = [&](unsigned int lo, unsigned int hi) -> unsigned int {
+                const unsigned int e = (unsigned int)((((unsigned long long)hi << 32) | (unsigned long long)lo) >> sh) ^ pat;
+                return (e - 0x01010101u) & ~e & 0x80808080u;
+            };
+            const unsigned int z0 = zero_marks(d0, d1), z1 = zero_marks(d1, d2), z2 = zero_marks(d2, d3), z3 = zero_marks(d3, d4);
+            const unsigned int idx = z0 != 0u   ? (unsigned int)(__ffs((int)z0) - 1) >> 3
+                                     : z1 != 0u ? 4u + ((unsigned int)(__ffs((int)z1) - 1) >> 3)
+                                     : z2 != 0u ? 8u + ((unsigned int)(__ffs((int)z2) - 1) >> 3)
+                                     : z3 != 0u ? 12u + ((unsigned int)(__ffs((int)z3) - 1) >> 3)
+                                                : 0xFFFFu;
+            const bool hit = in && idx < o1 - o0;
+            const unsigned int slot = hit ? o0 + idx : my_dummy;
+            const unsigned int mem = hit ? (l_hmem[slot >> 5] >> (slot & 31u)) & 1u : 0u;
+            // a hot node: every ring is declared; which status fails the membership filter follows from the member bit
+            k.entry = hit ? ((mem != 0u ? kCoreUp : kCoreDown) | (slot << 17)) : in ? (kCoreRings | kCoreDown | (my_dummy << 17)) : (kEntryPoison | (my_dummy << 17));
+            k.untouched = in && !hit;
             return k;
         }
         // kDictCompressed: bit test + rank -- two independent LDS reads -- then the entry of a touched node (its dict_entry, written

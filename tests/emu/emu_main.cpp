@@ -139,9 +139,11 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
                   const unsigned int* pairs, int n_hot, int n_adj, int* emit_batch, int* num_proposals,
                   int* prop_count, unsigned long long* fingerprint, int* props, int prop_cap, unsigned long long* stats,
                   int flags, int waves, int grid, int tables_in_lds, unsigned long long seed, const unsigned int* tbits,
-                  const unsigned short* trank, const unsigned int* tent, int n_touched, unsigned long long* vote_res_out, int fmt, int packed) {
-    // packed: two slots per LDS word (PackedSlotDetector); only with the dictionary in memory (0) or none (3)
-    if (packed && tables_in_lds != 0 && tables_in_lds != 3) return -9;
+                  const unsigned short* trank, const unsigned int* tent, int n_touched, unsigned long long* vote_res_out, int fmt, int packed,
+                  const unsigned short* hoff, const unsigned char* hrem, const unsigned int* hmem, unsigned int hmul) {
+    // packed: two slots per LDS word (PackedSlotDetector); only with the dictionary in memory (0), hashed in LDS (4) or none (3)
+    if (packed && tables_in_lds != 0 && tables_in_lds != 3 && tables_in_lds != 4) return -9;
+    if (tables_in_lds == 4 && (!packed || fmt != 1 || hoff == nullptr)) return -9;  // (the hashed dictionary: boundary records, packed state)
     // fmt: 0 = resident records (split / resolved below), 1 = the 20-byte boundary records themselves (kFmtBoundary)
     // tables_in_lds: 0 = dictionary in memory, 1 = direct tables in LDS, 2 = compressed tables in LDS, 3 = no dictionary: the
     // records carry their subjects' entries (kDictResolved, what resolve_records_kernel leaves in the first dword)
@@ -190,6 +192,11 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
         entries[(size_t)i] = e;
     }
     p.idx.entries = entries.data();
+    p.idx.hoff = hoff;
+    p.idx.hrem = hrem;
+    p.idx.hmem = hmem;
+    p.idx.hmul = hmul;
+    p.idx.hbits = rapid::hash_key_bits(n_nodes);
     if (tables_in_lds == 3)
         for (long long i = 0; i < n_rec_all; ++i) {
             const unsigned int d = core[2 * i];
@@ -239,7 +246,10 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
         const bool trusted = (flags & 256) != 0;  // emulator-only selector of the kTrusted instantiation
         auto run = [&](auto kern) { emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { kern(p); }, seed + (unsigned)b); };
         if (packed) {
-            if (fmt == 1) {
+            if (tables_in_lds == 4) {
+                if (trusted) run(rapid::tally_population_kernel<rapid::kDictHashed, true, rapid::kFmtBoundary, true>);
+                else run(rapid::tally_population_kernel<rapid::kDictHashed, false, rapid::kFmtBoundary, true>);
+            } else if (fmt == 1) {
                 if (trusted) run(rapid::tally_population_kernel<rapid::kDictMemory, true, rapid::kFmtBoundary, true>);
                 else run(rapid::tally_population_kernel<rapid::kDictMemory, false, rapid::kFmtBoundary, true>);
             } else {
@@ -389,6 +399,26 @@ extern "C" int emu_index_run(const unsigned char* alerts, long long n_alerts, in
     for (auto z : zero_words) if (z != 0ull) return -3;    // what the round's launches expect zeroed
     if (zero_flags[0] != 0u || zero_flags[1] != 0u) return -4;
     for (int n = 0; n < n_nodes + 8; ++n) if (work[(size_t)n] != 0u) return -5;  // the work area, left clean for the next round
+    return 0;
+}
+
+// index_hash_kernel: the hashed dictionary of a packed round + the renumbering of everything that carries slot numbers
+extern "C" unsigned int emu_hash_multiplier(int i) { return rapid::hash_multiplier(i); }
+extern "C" int emu_hash_build(const int* node_of_slot, const unsigned short* smask, const unsigned int* pairs, int n_hot, int n_adj, int n_nodes,
+                              const unsigned char* member, unsigned short* hoff, unsigned char* hrem, unsigned int* hmem, int* nos_new,
+                              unsigned short* smask_new, unsigned int* pairs_new, unsigned short* new_of_old, unsigned int* entries,
+                              unsigned short* dict, int* answer, unsigned long long seed) {
+    if (rapid::index_hash_lds_bytes(n_nodes, n_hot) > (int)sizeof(smem)) return -5;
+    static int mail[16];
+    for (int i = 0; i < 16; ++i) mail[i] = -1;
+    std::memset(smem, 0xCD, sizeof(smem));
+    emu::run_block(0, 1, 1024, [&] {
+        rapid::index_hash_kernel(node_of_slot, smask, pairs, n_hot, n_adj, n_nodes, member, hoff, hrem, hmem, nos_new, smask_new, pairs_new, new_of_old,
+                                 entries, dict, mail, 777);
+    }, seed);
+    if (mail[11] != 777) return -2;
+    answer[0] = mail[12];
+    answer[1] = mail[13];
     return 0;
 }
 

@@ -150,6 +150,11 @@ inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v)
     if (v > o) *p = v;
     return o;
 }
+inline int atomicMax(int* p, int v) {
+    const int o = *p;
+    if (v > o) *p = v;
+    return o;
+}
 inline unsigned atomicMin(unsigned* p, unsigned v) {
     const unsigned o = *p;
     if (v < o) *p = v;

@@ -120,7 +120,8 @@ def validate_alerts(records, n_nodes, K, cfg_id, member):
     inr = dst < n_nodes
     mem = np.asarray(member)[np.where(inr, dst, 0)] != 0
     down = r["status"] != 0
-    ok = (r["cfg_id"] == cfg_id) & inr & ((r["ring_mask"] & ((1 << K) - 1)) != 0) & (mem == down)
+    # (an alert of another configuration is not validated: its copies are dropped whole per delivery, index_kernels.h: index_touch_kernel)
+    ok = (r["cfg_id"] != cfg_id) | (inr & ((r["ring_mask"] & ((1 << K) - 1)) != 0) & (mem == down))
     return bool(ok.all()), bool(down.all())
 
 
@@ -154,11 +155,22 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     stats = np.zeros((grid, 8), dtype=np.uint64)  # one row per workgroup, as the kernel writes them
     vote_res = np.zeros(10, dtype=np.uint64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
+    hashed = None
+    if tables_in_lds == 4:  # the hashed dictionary of packed rounds: built by index_hash_kernel, which renumbers the slots
+        assert packed and ix["n_touched"] == ix["n_hot"], "kDictHashed: packed rounds whose every named subject is hot"
+        hashed = hash_build(ix, n_nodes, member, seed=seed)
+        ix = dict(ix, node_of_slot=hashed["node_of_slot"], adj_off=hashed["smask"], adj=hashed["pairs"])
     rc = L_.emu_tally_run(p(raw), C.c_ulonglong(recs.nbytes), p(rec_off), R, n_nodes, K, H, L, C.c_longlong(cfg_id),
                           p(ix["dict"]), p(ix["decl"]), p(ix["node_of_slot"]), p(ix["adj_off"]), p(ix["adj"]),
                           ix["n_hot"], ix["n_adj"], p(emit), p(nprop), p(pcount), p(fp), p(props), prop_cap, p(stats),
                           force_exact, waves, grid, tables_in_lds, C.c_ulonglong(seed), p(ix["tbits"]), p(ix["trank"]), p(ix["tent"]),
-                          ix["n_touched"], p(vote_res), int(fmt), 1 if packed else 0)
+                          ix["n_touched"], p(vote_res), int(fmt), 1 if packed else 0,
+                          p(hashed["hoff"]) if hashed else None, p(hashed["hrem"]) if hashed else None, p(hashed["hmem"]) if hashed else None,
+                          C.c_uint(hashed["mul"] if hashed else 0))
+    if hashed:  # (the kernel lists a proposal in slot order; slots are in hash order there: back to ascending node index)
+        for r in range(R):
+            if pcount[r] > 0:
+                props[r, : pcount[r]] = np.sort(props[r, : pcount[r]])
     # the vote statistics the kernel gathers next to the proposals (TallyParams::vote_res) against the results themselves
     voters = np.flatnonzero(pcount != 0)
     assert int(vote_res[2]) == len(voters), (vote_res, len(voters))
@@ -169,6 +181,69 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
         return emit, nprop, pcount, fp, props, stats.sum(axis=0), rc == 0
     assert rc == 0, rc
     return emit, nprop, pcount, fp, props, stats.sum(axis=0)
+
+
+def hash_key_bits(n_nodes):
+    b = 10
+    while (1 << b) < n_nodes:
+        b += 1
+    return b
+
+
+def hash_build(ix, n_nodes, member, seed=1):
+    """index_hash_kernel under the emulator, checked against its statement here: the hot nodes ordered by (bucket, remainder) of
+    x = (node * mul) mod 2^bits under the first multiplier that keeps every bucket within 16 keys; hoff / hrem / hmem; node_of_slot,
+    smask and the triples in the new numbering.  -> dict of the new tables + `mul`."""
+    L_ = lib()
+    n_hot, n_adj = ix["n_hot"], ix["n_adj"]
+    bits = hash_key_bits(n_nodes)
+    nb = 1 << (bits - 8)
+    nos = np.ascontiguousarray(ix["node_of_slot"], dtype=np.int32)
+    smask = np.ascontiguousarray(ix["adj_off"], dtype=np.uint16)
+    pairs = np.ascontiguousarray(ix["adj"], dtype=np.uint32)
+    member = np.ascontiguousarray(member, dtype=np.uint8)
+    entries = dict_entries(ix, n_nodes).copy()
+    dict_ = np.ascontiguousarray(ix["dict"], dtype=np.uint16).copy()
+    out = dict(hoff=np.full(nb + 4, 0xEEEE, dtype=np.uint16), hrem=np.full(n_hot + 32 + 8, 0xEE, dtype=np.uint8), hmem=np.full((n_hot + 31) // 32 + 1, 0xEEEEEEEE, dtype=np.uint32),
+               node_of_slot=np.full(n_hot + 1, -7, dtype=np.int32), smask=np.full(n_hot + 1, 0xEEEE, dtype=np.uint16),
+               pairs=np.zeros(max(n_adj, 1) + 1, dtype=np.uint32), new_of_old=np.full(n_hot + 1, 0xEEEE, dtype=np.uint16))
+    ans = np.zeros(2, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L_.emu_hash_build.restype = C.c_int
+    L_.emu_hash_multiplier.restype = C.c_uint
+    rc = L_.emu_hash_build(p(nos), p(smask), p(pairs), n_hot, n_adj, n_nodes, p(member), p(out["hoff"]), p(out["hrem"]), p(out["hmem"]), p(out["node_of_slot"]),
+                           p(out["smask"]), p(out["pairs"]), p(out["new_of_old"]), p(entries), p(dict_), p(ans), C.c_ulonglong(seed))
+    assert rc == 0 and ans[0] == 1, (rc, ans)
+    mul = int(L_.emu_hash_multiplier(int(ans[1])))
+    # the statement: keys, their order, the tables
+    x = (nos[:n_hot].astype(np.uint64) * np.uint64(mul)) & np.uint64((1 << bits) - 1)
+    order = np.argsort(x, kind="stable")  # (bucket, remainder) = the key itself; keys are distinct
+    new_of_old = np.empty(n_hot, dtype=np.int64)
+    new_of_old[order] = np.arange(n_hot)
+    counts = np.bincount((x >> np.uint64(8)).astype(np.int64), minlength=nb)
+    assert counts.max() <= 16
+    for t in range(int(ans[1])):  # an earlier multiplier was passed over only because a bucket overflowed under it
+        xt = (nos[:n_hot].astype(np.uint64) * np.uint64(int(L_.emu_hash_multiplier(t)))) & np.uint64((1 << bits) - 1)
+        assert np.bincount((xt >> np.uint64(8)).astype(np.int64), minlength=nb).max() > 16
+    assert np.array_equal(out["new_of_old"][:n_hot], new_of_old.astype(np.uint16))
+    assert np.array_equal(out["hoff"][: nb + 1], np.concatenate([[0], np.cumsum(counts)]).astype(np.uint16))
+    assert np.array_equal(out["hrem"][:n_hot], (x[order] & np.uint64(255)).astype(np.uint8)) and not out["hrem"][n_hot: n_hot + 32].any()
+    assert np.array_equal(out["node_of_slot"][:n_hot], nos[:n_hot][order]) and np.array_equal(out["smask"][:n_hot], smask[:n_hot][order])
+    mem_bits = member[nos[:n_hot][order]] != 0
+    want_mem = np.zeros((n_hot + 31) // 32, dtype=np.uint32)
+    for i in np.flatnonzero(mem_bits):
+        want_mem[i >> 5] |= np.uint32(1 << (int(i) & 31))
+    assert np.array_equal(out["hmem"][: len(want_mem)], want_mem)
+    pr = pairs[:n_adj].astype(np.int64)
+    want_pairs = new_of_old[pr & 0x3FFF] | (new_of_old[(pr >> 14) & 0x3FFF] << 14) | (pr & 0xF0000000)
+    assert np.array_equal(out["pairs"][:n_adj], want_pairs.astype(np.uint32))
+    e0 = dict_entries(ix, n_nodes)
+    hot_nodes = nos[:n_hot]
+    want_e = e0.copy()
+    want_e[hot_nodes] = (e0[hot_nodes] & 0x1FFFF) | (new_of_old.astype(np.uint32) << 17)
+    assert np.array_equal(entries, want_e)
+    out["mul"] = mul
+    return out
 
 
 class CdInstance:

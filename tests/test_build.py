@@ -21,14 +21,17 @@ def test_tally_kernels_fit_the_register_file_without_scratch():
     tally = {k: v for k, v in res.items() if "tally_population_kernel" in k}
     # {20-byte boundary records looked up in memory / direct tables / compressed tables, resolved 8-byte records of the generator}
     # x {filter per delivery, trusted copies} + {in memory, resolved} x {filter, trusted} with two slots per LDS word
-    assert len(tally) == 12, sorted(tally)
+    # ... + the hashed dictionary in LDS (mode 4) x {filter, trusted}, packed
+    assert len(tally) == 14, sorted(tally)
     for name, r in tally.items():
         assert r["ScratchSize [bytes/lane]"] == 0, (name, r)
         # 16 waves per CU = 4 per SIMD = 128 VGPRs; the per-delivery filter over compressed tables on boundary records is
-        # launched with at most 12 (tally_kernel.h: tally_max_waves): 3 per SIMD = 168
+        # launched with at most 12 (tally_kernel.h: tally_max_waves): 3 per SIMD = 168; the packed instantiations (a handful of
+        # receivers per CU whatever the registers: their LDS decides) with at most 8: 2 per SIMD = 256
         twelve = "tally_population_kernelILi2ELb0ELi1E" in name
-        assert r["VGPRs"] <= (168 if twelve else 128), (name, r)
-        assert r["Occupancy [waves/SIMD]"] >= (3 if twelve else 4), (name, r)
+        packed = name.split("tally_population_kernelILi")[1][12] == "1"
+        assert r["VGPRs"] <= (256 if packed else 168 if twelve else 128), (name, r)
+        assert r["Occupancy [waves/SIMD]"] >= (2 if packed else 3 if twelve else 4), (name, r)
 
 
 def test_every_other_kernel_of_the_path_is_scratch_free_too():
@@ -41,14 +44,15 @@ def test_every_other_kernel_of_the_path_is_scratch_free_too():
 
 # (dictionary mode, trusted, record format, packed): 0 / 1 / 2 = tables in memory / direct in LDS / compressed in LDS over 20-byte
 # boundary records (format 1); 3 = resolved 8-byte records (format 0); packed = two slots per LDS word
-EXPECTED_VGPRS = {(0, False, 1, False): 123, (0, False, 1, True): 120, (0, True, 1, False): 104, (0, True, 1, True): 108, (1, False, 1, False): 119, (1, True, 1, False): 103, (2, False, 1, False): 133, (2, True, 1, False): 114, (3, False, 0, False): 91, (3, False, 0, True): 98, (3, True, 0, False): 87, (3, True, 0, True): 91}
+# 4 = hashed buckets in LDS (packed rounds, opt-in).  The packed instantiations keep four windows of the stream in flight (round 5).
+EXPECTED_VGPRS = {(0, False, 1, False): 123, (0, False, 1, True): 166, (0, True, 1, False): 104, (0, True, 1, True): 159, (1, False, 1, False): 119, (1, True, 1, False): 103, (2, False, 1, False): 133, (2, True, 1, False): 114, (3, False, 0, False): 91, (3, False, 0, True): 125, (3, True, 0, False): 87, (3, True, 0, True): 118, (4, False, 1, True): 174, (4, True, 1, True): 167}
 
 
 def test_register_allocation_of_the_tally_kernel_is_the_measured_one():
     """A canary, not a law: changes that leave every result identical can still cost 20-30 % -- in round 2 once through
     spills after an edit of the table-staging loop, once because a rewrite of that loop left a table pointer aimed at global
     memory instead of its LDS copy (89 -> 93 VGPRs, 0.214 -> 0.285 ms on C3b) -- while every parity test stayed green.
-    These are the counts of the build whose timings are in profiles/r04_*; if they move, time the tally kernel on a GPU
+    These are the counts of the build whose timings are in profiles/r05_*; if they move, time the tally kernel on a GPU
     (scripts/ab_variants.py prints it in seconds) before accepting the new numbers here."""
     res = resources()
     got = {}

@@ -1463,6 +1463,61 @@ def test_streaming_rounds_at_one_million_nodes(E):
     eng.close()
 
 
+def test_hashed_dictionary_of_packed_rounds(E):
+    """Rounds with thousands of hot subjects keep the node -> slot dictionary in LDS as hashed buckets of one-byte remainders
+    (tally_kernel.h: kDictHashed; index_hash_kernel renumbers the hot subjects in hash order) next to the packed detector state.
+    Forced at a small population (testing knobs 8192: packed whatever the size, 1048576: the hashed dictionary): every receiver's outcome, the proposals in
+    ring-0 order, the decision and the cut equal the default instantiation's and the oracle's -- vouched-for copies and the
+    per-delivery filter, late deliveries of another configuration among the records, joiners and crashed members in one cut; the
+    same with the packed state and the dictionary in memory (the default of such rounds); a report of the current configuration
+    about a node the alert set does not name is an error of the stream, not a silently different tally."""
+    K, H, L = 10, 9, 4
+    n, n_out = 3000, 60
+    pop = S.Population.make(n + n_out)
+    eng, view = make_engine(E, pop, K, H, L, members=list(range(n)))
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_churn_scenario(obs, member, cfg, 40, 25, H, L)
+    sc = S.build_churn_scenario(obs, member, cfg, 40, 25, H, L, receivers=sc.receivers[::3])
+    late = sc.records.copy()
+    late["cfg_id"][::9] = cfg - 7  # late deliveries: dropped per delivery, whoever they name
+    late["dst"][::27] = np.arange(len(late["dst"][::27])) % pop.n
+    for records in (sc.records, late):
+        fe, fn, fo, fpp = O.fast_sim_run(pop.n, K, H, L, cfg, obs, subj, member, records, sc.rec_off, nthreads=8)
+        sim0, ref = run_population(E, eng, records, sc.rec_off, alert_set=sc.batches.recs)
+        assert sim0.index_info()["dict_mode"] == 1
+        assert np.array_equal(ref[0], fe) and np.array_equal(ref[1], fn) and np.array_equal(ref[2], np.diff(fo))
+        assert np.array_equal(ref[3], proposal_fingerprints(fo, fpp, fe >= 0))
+        rr0 = sim0.count_votes()
+        cut0 = sim0.decided_cut() if rr0.decided else None
+        props0 = [sim0.proposal(r) for r in range(0, len(fe), 37)]
+        HK = 8192 | 1048576
+        for knob, mode, trust in ((HK, 4, True), (HK | 64, 4, True), (HK, 4, False), (8192, 0, True)):
+            sim, res = run_population(E, eng, records, sc.rec_off, force_exact=knob, alert_set=sc.batches.recs, trust=trust)
+            info = sim.index_info()
+            assert info["dict_mode"] == mode and info["alerts_prevalidated"] == (1 if trust and not (knob & 64) else 0), (knob, info)
+            assert all(np.array_equal(a, b) for a, b in zip(ref, res)), (knob, trust)
+            assert [sim.proposal(r) for r in range(0, len(fe), 37)] == props0
+            rr = sim.count_votes()
+            assert (rr.decided, rr.votes_winner, rr.votes_total, rr.cut_size) == (rr0.decided, rr0.votes_winner, rr0.votes_total, rr0.cut_size)
+            assert (sim.decided_cut() if rr.decided else None) == cut0
+            sim.set_force_exact(0)
+    stray = sc.records.copy()
+    stray["dst"][11] = int(np.setdiff1d(np.flatnonzero(member != 0), sc.batches.recs["dst"])[3])
+    stray["status"][11] = 1
+    for trust in (True, False):
+        sim, _ = None, None
+        sim = E.ClusterSimulation(eng)
+        sim.set_force_exact(8192 | 1048576)
+        sim.load_streams(stray, sc.rec_off)
+        sim.set_alert_set(sc.batches.recs, trust_copies=trust)
+        sim.tally()
+        with pytest.raises(E.IllegalArgumentException):
+            sim.results()
+        sim.set_force_exact(0)
+    eng.close()
+
+
 def test_full_population_rounds_at_one_million_nodes(E):
     """BASELINE configs[4] as complete, DECIDED rounds: N = 1,000,000 members, every one of the ~985,000 surviving members a
     simulated receiver of ~150,000 deliveries (1.5 x 10^11 delivered alerts per round: they never exist at once --

@@ -131,6 +131,24 @@ def test_other_dictionary_placements(mode):
         off.append(off[-1] + n_rec)
     _check(np.concatenate(recs), np.array(off), n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode)
     _check(np.concatenate(recs), np.array(off), n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode, pool=True)
+    if mode == 0:  # ... the dictionary as hashed buckets of one-byte remainders in LDS (kDictHashed: packed rounds whose every named subject
+        # is hot), slots renumbered in hash order by index_hash_kernel; stale and uncovered reports among the deliveries
+        _check(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, tables_in_lds=4, packed=True)
+        _check(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, tables_in_lds=4, packed=True, pool=True, waves=2, grid=3)
+        late = sc.records.copy()
+        late["cfg_id"][::7] = cfg + 3  # late deliveries of another configuration: dropped per delivery, their subjects may be anybody
+        late["dst"][::21] = np.arange(len(late["dst"][::21])) % n
+        fe, fn, fo, fp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, late, sc.rec_off)
+        for trusted in (False, True):
+            emit, nprop, pcount, fpr, props, stats, covered = pyemu.tally(late, sc.rec_off, n, K, H, L, cfg, obs, subj, member, tables_in_lds=4, packed=True,
+                                                                          declared=sc.batches.recs, trusted=trusted)
+            assert covered and np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
+            assert np.array_equal(fpr, proposal_fingerprints(fo, fp, fe >= 0))
+        stray = sc.records.copy()  # a report of the CURRENT configuration about a node the alert set does not name: not covered
+        stray["dst"][5] = int(np.setdiff1d(np.arange(n), sc.batches.recs["dst"])[0])
+        stray["status"][5] = 1 if member[stray["dst"][5]] else 0
+        *_, covered = pyemu.tally(stray, sc.rec_off, n, K, H, L, cfg, obs, subj, member, tables_in_lds=4, packed=True, declared=sc.batches.recs)
+        assert not covered
     if mode in (0, 3):  # ... and with two slots per LDS word (PackedSlotDetector: the state of rounds with thousands of hot subjects)
         _check(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode, packed=True)
         _check(np.concatenate(recs), np.array(off), n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode, packed=True)
