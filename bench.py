@@ -58,6 +58,13 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the measurements beside the line (generator, per-delivery filter, probe)")
     ap.add_argument("--ttsc-trials", type=int, default=5, help="trials of the time-to-stable-cut measurement (the view is rebuilt between them)")
     ap.add_argument("--tile", type=int, default=0, help="C5: receivers per launch of the tiled round (default 4096)")
+    ap.add_argument("--seed-fault", type=int, default=1, help="SURVEY 8(d): seed of the fault set")
+    ap.add_argument("--seed-delivery", type=int, default=2, help="SURVEY 8(d): seed of the per-receiver delivery orders (stream set k uses seed + k)")
+    ap.add_argument("--reps", type=int, default=5, help="SURVEY 8(d) 'Seeds': repetitions with seed_fault + rep, seed_delivery + rep (rep 0 = the line itself; "
+                                                         "the others: one stream set, --rep-steps steps) + one run at H = 8, L = 2; 1 = none")
+    ap.add_argument("--rep-steps", type=int, default=10)
+    ap.add_argument("--parity-receivers", type=int, default=64, help="receivers per stream set checked against the oracle after the timed loop")
+    ap.add_argument("--no-parity", action="store_true")
     return ap.parse_args()
 
 
@@ -140,7 +147,7 @@ def main():
     view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
     obs, subj, member = view.tables()
     cfg_id = view.getCurrentConfigurationId()
-    sc = S.build_scenario(cfgname, subj, cfg_id, n=n, f=f, materialise=False)
+    sc = S.build_scenario(cfgname, subj, cfg_id, n=n, f=f, materialise=False, seed_fault=args.seed_fault)
     # C3b (default): ONE cluster, its receivers cut into `world` shards (strong scaling).  C4: the cluster BASELINE runs on eight
     # GPUs, always cut into eight shards -- every rank carries the same load whatever the number of ranks (weak scaling)
     shards = 8 if cfgname == "C4" else world
@@ -153,11 +160,13 @@ def main():
     # earlier rounds' benches and of tests/test_gpu_parity.py::test_full_size_c3_against_fast_oracle
     n_sets = max(1, args.stream_sets)
     sets = []
+    parity_samples = []  # per stream set: (receiver indices, their delivered records, offsets) for the untimed check against the oracle
     for k in range(n_sets):
-        recs_k, off_k, nb_k = S.deliver(sc.batches, my_rx, seed_delivery=2 + k)
+        recs_k, off_k, nb_k = S.deliver(sc.batches, my_rx, seed_delivery=args.seed_delivery + k)
         d_rec = torch.from_numpy(recs_k.view(np.uint8).reshape(-1)).cuda()
         d_off = torch.from_numpy(np.ascontiguousarray(off_k, dtype=np.int64)).cuda()
         sets.append((d_rec, d_off, len(off_k) - 1))
+        parity_samples.append(take_sample(recs_k, off_k, args.parity_receivers))
         if k == 0:
             records, rec_off, nb = recs_k, off_k, nb_k
         del recs_k
@@ -322,6 +331,54 @@ def main():
         ttsc_trials.append(t_k)
     ttsc_ms = float(np.median(ttsc_trials))
 
+    # ---- the line verifies itself (untimed): the decided cut is the scenario's fault set, and for EVERY stream set of the timed loop a
+    # sample of receivers -- announce batch, getNumProposals(), proposal size, fingerprint of the proposal -- equals the CPU
+    # restatement (oracle/fast_cut.hpp) fed the same delivered bytes.  A mismatch is a non-zero exit, not a line.
+    parity = None
+    if not args.no_parity:
+        view.build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)  # (the last time-to-stable-cut trial applied its cut: back to the round's view)
+        assert view.getCurrentConfigurationId() == cfg_id
+        parity = {"receivers_per_stream_set": int(len(parity_samples[0][0])), "stream_sets": n_sets, "checker": "oracle/fast_cut.hpp",
+                  "fields": ["emit_batch", "num_proposals", "proposal_size", "fingerprint"], "mismatches": 0}
+        for k in range(n_sets):
+            fresh_round(k)
+            sim.tally()
+            bad = parity_mismatches(sim.results(), parity_samples[k], pop.n, K, H, L, cfg_id, obs, subj, member)
+            parity["mismatches"] += bad
+        fresh_round(0)
+        rr_chk = None
+        if cfgname in ("C2", "C3b"):
+            sim.tally()
+            rr_chk = sim.count_votes()
+            cut_ok = bool(rr_chk.decided) and sorted(sim.decided_cut()) == sc.faulty.tolist()
+            if world == 1 or rr_chk.decided:
+                parity["decided_cut_is_the_fault_set"] = cut_ok
+                if not cut_ok:
+                    parity["mismatches"] += 1
+        if parity["mismatches"]:
+            sys.stderr.write("bench.py: PARITY MISMATCH %r\n" % parity)
+            raise SystemExit(3)
+
+    # ---- SURVEY 8(d) "Seeds": repetitions with seed_fault + rep, seed_delivery + rep (rep 0 is the line itself), and the H = 8, L = 2
+    # thresholds of the reference's own tests as one more -- each a fresh engine, one stream set, fewer steps, its own parity sample
+    repetitions = None
+    if world == 1 and args.reps > 1 and cfgname in ("C2", "C3a", "C3b") and not args.no_extras:
+        runs = [{"rep": 0, "seed_fault": args.seed_fault, "seed_delivery": args.seed_delivery, "ms_per_step": round(ms_per_step, 4),
+                 "time_to_stable_cut_ms": round(ttsc_ms, 3) if rr_full.decided else None, "decided": int(rr_full.decided), "cut_size": int(rr_full.cut_size)}]
+        for rep in range(1, args.reps):
+            runs.append(dict(light_run(E, S, torch, pop, K, H, L, cfgname, n, f, args.seed_fault + rep, args.seed_delivery + rep, local_rank, args), rep=rep))
+        # (the crash form of the fault set: closing an ingress-loss set under "two faulty observers" swallows the cluster)
+        h8 = dict(light_run(E, S, torch, pop, K, 8, 2, cfgname, n, f, args.seed_fault, args.seed_delivery, local_rank, args, kind="crash"),
+                  scenario="the same %d nodes crash (every healthy observer reports them), thresholds H=8 L=2 of the reference's own tests" % f)
+        ms = [r["ms_per_step"] for r in runs]
+        tt = [r["time_to_stable_cut_ms"] for r in runs if r["time_to_stable_cut_ms"] is not None]
+        repetitions = {"reps": len(runs), "ms_per_step": {"min": min(ms), "median": round(float(np.median(ms)), 4), "max": max(ms)},
+                       "time_to_stable_cut_ms": {"min": min(tt), "median": round(float(np.median(tt)), 3), "max": max(tt)} if tt else None,
+                       "runs": runs, "h8_l2": h8}
+        if any(r.get("parity_mismatches") for r in runs + [h8]):
+            sys.stderr.write("bench.py: PARITY MISMATCH in a repetition %r\n" % repetitions)
+            raise SystemExit(3)
+
     out = {
         "metric": "alert-batches/sec", "value": round(value, 1), "unit": "alert-batches/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
@@ -350,6 +407,7 @@ def main():
         "time_to_stable_cut_trials_ms": [round(t, 3) for t in ttsc_trials],  # (the headline is their median; the first is the cold one)
         "decided": int(rr_full.decided), "cut_size": int(rr_full.cut_size), "votes_winner": int(rr_full.votes_winner),
         "quorum": int(rr_full.quorum), "kernel_stats": st, "round_index": index, "setup_s": round(setup_s, 1),
+        "parity_checked": parity, "repetitions": repetitions,
         "roofline": roofline,
     }
 
@@ -539,6 +597,108 @@ def bench_c5(args, rank, world, local_rank, torch, dist, E, P, S):
         dist.destroy_process_group()
     if out["n_ranks_seen"] != args.gpus:
         raise SystemExit("bench.py: the engine's communicator sees %d rank(s), --gpus %d" % (out["n_ranks_seen"], args.gpus))
+
+
+def take_sample(records, rec_off, k):
+    """k receivers spread evenly over a stream set: (their indices, their delivered records back to back, offsets)."""
+    R = len(rec_off) - 1
+    idx = np.unique(np.linspace(0, max(R - 1, 0), num=min(k, R), dtype=np.int64)) if R else np.zeros(0, dtype=np.int64)
+    parts = [records[rec_off[r]:rec_off[r + 1]] for r in idx]
+    off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64)
+    return idx, (np.concatenate(parts) if parts else records[:0]).copy(), off
+
+
+def fingerprints_of(prop_off, props, emitted):
+    """The kernel's proposal fingerprint (tally_kernel.h: sum of mix64(node) + mix64(0x5EED + count), 0 reserved) of the oracle's lists."""
+    from rapid_amd.scenarios import mix64
+    out = np.zeros(len(prop_off) - 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = mix64(np.asarray(props, dtype=np.uint64))
+        csum = np.concatenate([[np.uint64(0)], np.cumsum(x, dtype=np.uint64)])
+        for r in np.flatnonzero(emitted):
+            cnt = int(prop_off[r + 1] - prop_off[r])
+            v = (csum[prop_off[r + 1]] - csum[prop_off[r]]) + mix64(np.uint64(0x5EED + cnt))
+            out[r] = v if v != 0 else np.uint64(1)
+    return out
+
+
+def parity_mismatches(results, sample, n_nodes, K, H, L, cfg_id, obs, subj, member):
+    """Receivers of the sample whose device results differ from oracle/fast_cut.hpp fed the same delivered records (the checker,
+    after the timed region: never the thing measured)."""
+    from oracle import pyoracle as O
+    idx, recs, off = sample
+    if len(idx) == 0:
+        return 0
+    emit, nprop, pcount, fp = results
+    fe, fn, fo, fpp = O.fast_sim_run(n_nodes, K, H, L, cfg_id, obs, subj, member, recs, off, nthreads=min(16, os.cpu_count() or 1))
+    want_fp = fingerprints_of(fo, fpp, fe >= 0)
+    bad = (emit[idx] != fe) | (nprop[idx] != fn) | (pcount[idx] != np.diff(fo)) | (fp[idx] != want_fp)
+    return int(bad.sum())
+
+
+def light_run(E, S, torch, pop, K, H, L, cfgname, n, f, seed_fault, seed_delivery, device_id, args, kind=None):
+    """One repetition beside the line: a fresh engine, the scenario under other seeds (or thresholds), ONE resident stream set, the
+    same fresh-round step, time-to-stable-cut, and the parity sample.  -> dict."""
+    eng = E.Engine(n_max=n, K=K, H=H, L=L, device_id=device_id)
+    view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
+    obs, subj, member = view.tables()
+    cfg_id = view.getCurrentConfigurationId()
+    sc = S.build_scenario(cfgname, subj, cfg_id, n=n, f=f, H=H, L=L, materialise=False, seed_fault=seed_fault, kind=kind)
+    recs, off, nb = S.deliver(sc.batches, sc.receivers, seed_delivery=seed_delivery)
+    sample = take_sample(recs, off, args.parity_receivers)
+    d_rec = torch.from_numpy(recs.view(np.uint8).reshape(-1)).cuda()
+    d_off = torch.from_numpy(np.ascontiguousarray(off, dtype=np.int64)).cuda()
+    alert_set = np.ascontiguousarray(sc.batches.recs)
+    d_al = torch.from_numpy(alert_set.view(np.uint8).reshape(-1).copy()).cuda()
+    n_rec = len(recs)
+    del recs
+    torch.cuda.synchronize()
+    sim = E.ClusterSimulation(eng)
+
+    def fresh():
+        sim.attach_streams_device(d_rec.data_ptr(), d_rec.numel(), d_off.data_ptr(), len(off) - 1, keepalive=(d_rec, d_off))
+        sim.set_alert_set_device(d_al.data_ptr(), len(alert_set), trust_copies=True, keepalive=d_al)
+
+    for _ in range(3):
+        fresh()
+        sim.tally()
+        sim.count_votes()
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.rep_steps):
+        fresh()
+        sim.tally()
+        rr = sim.count_votes()
+    eng.sync()
+    ms = 1e3 * (time.perf_counter() - t0) / max(args.rep_steps, 1)
+    fresh()
+    sim.tally()
+    bad = parity_mismatches(sim.results(), sample, pop.n, K, H, L, cfg_id, obs, subj, member) if not args.no_parity else 0
+    trials = []
+    for k in range(3):
+        if k > 0:
+            view.build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
+        eng.sync()
+        t1 = time.perf_counter()
+        fresh()
+        rr_full, new_cfg = sim.round(apply=True)
+        trials.append(1e3 * (time.perf_counter() - t1))
+        eng.sync()
+    cut_ok = None
+    if rr_full.decided:
+        cut_ok = sorted(sim.decided_cut()) == sc.faulty.tolist()
+        bad += 0 if cut_ok else 1
+    out = {"seed_fault": seed_fault, "seed_delivery": seed_delivery, "H": H, "L": L, "ms_per_step": round(ms, 4),
+           "alert_batches_per_s": round(float(nb.sum()) / (ms * 1e-3), 1), "records": int(n_rec), "faulty": int(len(sc.faulty)),
+           "time_to_stable_cut_ms": round(float(np.median(trials)), 3) if rr_full.decided else None, "decided": int(rr_full.decided),
+           "cut_size": int(rr_full.cut_size), "votes_winner": int(rr_full.votes_winner), "cut_is_the_fault_set": cut_ok,
+           "proposing": int((sim.results()[0] >= 0).sum()) if False else None, "parity_mismatches": int(bad)}
+    out.pop("proposing")
+    del sim
+    eng.close()
+    del d_rec, d_off, d_al
+    torch.cuda.empty_cache()
+    return out
 
 
 def measure_traffic(cfgname):

@@ -27,7 +27,7 @@ def test_json_line_names_every_contract_key():
     tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
     out = _dict_keys(tree, "out")
     assert CONTRACT_KEYS <= out, sorted(CONTRACT_KEYS - out)
-    assert {"time_to_stable_cut_ms", "n_ranks_seen"} <= out
+    assert {"time_to_stable_cut_ms", "n_ranks_seen", "parity_checked", "repetitions"} <= out
     assert ROOFLINE_KEYS <= _dict_keys(tree, "roofline")
 
 
@@ -96,3 +96,30 @@ def test_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert called == [4] and "WORLD_SIZE=2" in str(e.value)
+
+
+def test_the_line_verifies_itself_against_the_oracle():
+    """bench.py's untimed parity leg: a sample of receivers spread over a stream set, the kernel's fingerprint restated on the oracle's
+    lists, and the comparison itself -- clean results pass, a single wrong field of a single receiver is counted."""
+    import bench
+    from oracle import pyoracle as O
+    from rapid_amd import scenarios as S
+    from tests.helpers import oracle_view, proposal_fingerprints
+    n, K, H, L = 500, 10, 9, 4
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K, list(range(n)))
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_scenario("C2", subj, cfg, n=n, f=5, H=H, L=L)
+    idx, recs, off = bench.take_sample(sc.records, sc.rec_off, 24)
+    assert len(idx) == 24 and idx[0] == 0 and idx[-1] == len(sc.rec_off) - 2 and len(np.unique(idx)) == 24
+    for j, r in enumerate(idx):
+        assert np.array_equal(recs[off[j]:off[j + 1]], sc.records[sc.rec_off[r]:sc.rec_off[r + 1]])
+    fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off)
+    fp = proposal_fingerprints(fo, fpp, fe >= 0)
+    assert np.array_equal(bench.fingerprints_of(fo, fpp, fe >= 0), fp)
+    res = [fe.copy(), fn.copy(), np.diff(fo).astype(np.int32), fp.copy()]
+    assert bench.parity_mismatches(res, (idx, recs, off), n, K, H, L, cfg, obs, subj, member) == 0
+    res[3][idx[5]] ^= np.uint64(1)
+    res[0][idx[9]] += 1
+    assert bench.parity_mismatches(res, (idx, recs, off), n, K, H, L, cfg, obs, subj, member) == 2
