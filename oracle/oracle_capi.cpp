@@ -271,6 +271,15 @@ int orc_fr_decided(void* f, int32_t* out, int cap) {
 // configuration to the next; the run is then single-threaded (the cache is written while it is read).
 static int g_prewarm_observers = 1;
 void orc_sim_set_prewarm(int on) { g_prewarm_observers = on; }
+// Per-node observer caches (MembershipView::enablePerNodeCaches): receiver r of the next orc_sim_run calls is cluster node
+// receiver_nodes[r] and reads / fills THAT node's cache; nullptr: the view's one shared cache again.  Implies no prewarming.
+static const int32_t* g_receiver_nodes = nullptr;
+void orc_sim_set_receiver_nodes(void* view_p, const int32_t* receiver_nodes) {
+    g_receiver_nodes = receiver_nodes;
+    if (receiver_nodes != nullptr) static_cast<MembershipView*>(view_p)->enablePerNodeCaches(true);
+}
+void orc_view_per_node_caches(void* view_p, int on) { static_cast<MembershipView*>(view_p)->enablePerNodeCaches(on != 0); }
+int orc_view_node_has_cached(void* view_p, int node, int subject) { return static_cast<MembershipView*>(view_p)->nodeHasCached(node, subject) ? 1 : 0; }
 
 int orc_sim_run(void* view_p, int K, int H, int L, const int64_t* id_hi, const int64_t* id_lo, int n_ids,
                 const void* records, const int64_t* rec_off, int R, int snapshot_order, int nthreads,
@@ -282,7 +291,8 @@ int orc_sim_run(void* view_p, int K, int H, int L, const int64_t* id_hi, const i
     (void)view->getCurrentConfigurationId();
     for (int k = 0; k < K; ++k)
         for (int n = 0; n < n_ids; ++n) (void)view->ringKey(k, n);
-    if (g_prewarm_observers) {
+    view->selectNode(-1);
+    if (g_prewarm_observers && g_receiver_nodes == nullptr) {
         for (int n = 0; n < n_ids; ++n)
             if (view->isHostPresent(n)) (void)view->getObserversOf(n);
     } else {
@@ -295,6 +305,7 @@ int orc_sim_run(void* view_p, int K, int H, int L, const int64_t* id_hi, const i
     std::vector<std::vector<int>> props((size_t)R);
     auto work = [&](int r0, int r1) {
         for (int r = r0; r < r1; ++r) {
+            if (g_receiver_nodes != nullptr) view->selectNode(g_receiver_nodes[r]);  // this receiver's own cachedObservers
             MultiNodeCutDetector cd(K, H, L);
             cd.setSnapshotOrder((MultiNodeCutDetector::SnapshotOrder)snapshot_order);
             AlertBatchService svc(view, &cd);
@@ -327,6 +338,7 @@ int orc_sim_run(void* view_p, int K, int H, int L, const int64_t* id_hi, const i
             th.emplace_back(work, (int)((int64_t)R * t / nthreads), (int)((int64_t)R * (t + 1) / nthreads));
         for (auto& t : th) t.join();
     }
+    view->selectNode(-1);
     int64_t off = 0;
     for (int r = 0; r < R; ++r) {
         out_prop_off[r] = off;

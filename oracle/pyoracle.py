@@ -106,6 +106,9 @@ def lib():
     sig("orc_fr_vote", i32, [vp, i32, i64, pi32, i32])
     sig("orc_fr_decided", i32, [vp, pi32, i32])
     sig("orc_sim_set_prewarm", None, [i32])
+    sig("orc_sim_set_receiver_nodes", None, [vp, vp])
+    sig("orc_view_per_node_caches", None, [vp, i32])
+    sig("orc_view_node_has_cached", i32, [vp, i32, i32])
     sig("orc_sim_run", i32, [vp, i32, i32, i32, pi64, pi64, i32, vp, pi64, i32, i32, i32, pi32, pi32, pi64, pi32, i64])
     sig("orc_fast_sim_run", i32,
         [i32, i32, i32, i32, i64, pi32, pi32, C.POINTER(C.c_uint8), vp, pi64, i32, i32, pi32, pi32, pi64, pi32, i64])
@@ -164,6 +167,10 @@ class MembershipView:
     """MembershipView.java restated (oracle/rapid_oracle.hpp)."""
 
     CAP = 64
+
+    def nodeHasCached(self, node, subject):
+        """Per-node cache mode (sim_run(receiver_nodes=...)): does cluster node `node` hold a cachedObservers entry for `subject`?"""
+        return bool(lib().orc_view_node_has_cached(self._h, int(node), int(subject)))
 
     def __init__(self, registry, K, node_ids=None, endpoints=None):
         self.registry = registry
@@ -392,11 +399,16 @@ def _csr(off, vals, R):
     return [vals[off[r]: off[r + 1]].copy() for r in range(R)]
 
 
-def sim_run(view, K, H, L, id_hi, id_lo, records, rec_off, snapshot_order=0, nthreads=1, prewarm_observers=True):
+def sim_run(view, K, H, L, id_hi, id_lo, records, rec_off, snapshot_order=0, nthreads=1, prewarm_observers=True, receiver_nodes=None):
     """Faithful whole-population run: one AlertBatchService per receiver over a shared view.  prewarm_observers=False:
     the view's observer cache (quirk Q4) is only filled by what these receivers query, and survives into the next call
-    with whatever the view changes in between left of it (single-threaded)."""
+    with whatever the view changes in between left of it (single-threaded).  receiver_nodes (one cluster node per receiver):
+    every receiver reads and fills ITS OWN cachedObservers, as the nodes of a deployment do -- each holds its own MembershipView
+    object (R/MembershipView.java:49, 210-224); the caches persist in the view, per node, across calls and view changes."""
     lib().orc_sim_set_prewarm(1 if prewarm_observers else 0)
+    rx_nodes = None if receiver_nodes is None else np.ascontiguousarray(receiver_nodes, dtype=np.int32)
+    assert rx_nodes is None or len(rx_nodes) == len(rec_off) - 1
+    lib().orc_sim_set_receiver_nodes(view._h, None if rx_nodes is None else rx_nodes.ctypes.data)
     records = np.ascontiguousarray(records, dtype=ALERT_DTYPE)
     rec_off = np.ascontiguousarray(rec_off, dtype=np.int64)
     hi = np.ascontiguousarray(id_hi, dtype=np.int64)
@@ -415,7 +427,9 @@ def sim_run(view, K, H, L, id_hi, id_lo, records, rec_off, snapshot_order=0, nth
         if rc == ECAPACITY:
             cap = int(poff[R]) + 1
             continue
+        lib().orc_sim_set_receiver_nodes(view._h, None)
         _raise(rc)
+    lib().orc_sim_set_receiver_nodes(view._h, None)
     return emit, nprop, poff, props[: poff[R]].copy()
 
 

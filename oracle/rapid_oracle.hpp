@@ -174,7 +174,7 @@ class MembershipView {
             if (it != endpoints.end() && it != endpoints.begin()) affectedSubjects.insert(*std::prev(it));
         }
         allNodes_.insert(node);
-        for (int s : affectedSubjects) cachedObservers_.erase(s);
+        for (int s : affectedSubjects) eraseCached(s);
         identifiersSeen_.insert(nodeId);
         shouldUpdateConfigurationId_ = true;
     }
@@ -189,19 +189,39 @@ class MembershipView {
             if (it != endpoints.end() && it != endpoints.begin()) affectedSubjects.insert(*std::prev(it));
             if (it != endpoints.end()) endpoints.erase(it);
             comparators_[k].removeEndpoint(node);
-            cachedObservers_.erase(node);
+            eraseCached(node);
         }
         allNodes_.erase(node);
-        for (int s : affectedSubjects) cachedObservers_.erase(s);
+        for (int s : affectedSubjects) eraseCached(s);
         shouldUpdateConfigurationId_ = true;
     }
 
     // :210-224 (memoised, with the stale-entry behaviour of :143-152/:181-195 -- SURVEY quirk Q4)
     const std::vector<int>& getObserversOf(int node) const {
         if (!allNodes_.count(node)) throw NodeNotInRingException("node not in ring");
-        auto it = cachedObservers_.find(node);
-        if (it == cachedObservers_.end()) it = cachedObservers_.emplace(node, computeObserversOf(node)).first;
+        auto& cache = activeCache();
+        auto it = cache.find(node);
+        if (it == cache.end()) it = cache.emplace(node, computeObserversOf(node)).first;
         return it->second;
+    }
+
+    // ---- one cachedObservers PER NODE OF THE CLUSTER (test infrastructure for quirk Q4) ----
+    // In a deployment every node holds its own MembershipView object, hence its own cachedObservers (:49), filled by what THAT
+    // node asked for (MultiNodeCutDetector.java:147-149: the subjects in its preProposal at a batch end) and invalidated by the
+    // ringAdd / ringDelete every node applies alike.  The rings are the same at every node, so ONE ring structure stands for all
+    // of them here; with per-node caches enabled, selectNode(n) makes getObserversOf read and fill node n's cache, and a view
+    // change drops the affected entries from every node's cache.  selectNode(-1): back to the view's own (shared) cache.
+    void enablePerNodeCaches(bool on) {
+        perNode_ = on;
+        if (!on) {
+            nodeCaches_.clear();
+            active_ = -1;
+        }
+    }
+    void selectNode(int node) const { active_ = perNode_ ? node : -1; }
+    bool nodeHasCached(int node, int subject) const {
+        auto it = nodeCaches_.find(node);
+        return it != nodeCaches_.end() && it->second.count(subject) != 0;
     }
 
     // :234-257 (fresh computation, bypassing the cache; public here so tests can detect Q4 staleness)
@@ -317,7 +337,15 @@ class MembershipView {
     std::vector<AddressComparator> comparators_;
     std::vector<Ring> rings_;
     std::set<NodeId, NodeIdComparator> identifiersSeen_;
+    std::unordered_map<int, std::vector<int>>& activeCache() const { return (perNode_ && active_ >= 0) ? nodeCaches_[active_] : cachedObservers_; }
+    void eraseCached(int subject) {
+        cachedObservers_.erase(subject);
+        for (auto& kv : nodeCaches_) kv.second.erase(subject);
+    }
     mutable std::unordered_map<int, std::vector<int>> cachedObservers_;
+    mutable std::unordered_map<int, std::unordered_map<int, std::vector<int>>> nodeCaches_;  // per-node caches (Q4 test mode)
+    bool perNode_ = false;
+    mutable int active_ = -1;
     std::unordered_set<int> allNodes_;
     mutable int64_t currentConfigurationId_ = -1;
     mutable Configuration currentConfiguration_;
