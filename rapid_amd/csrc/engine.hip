@@ -24,6 +24,10 @@
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <rccl/rccl.h>
 
+#if !defined(RAPID_TEST_BUILD) && (defined(RAPID_MEASUREMENT_BUILD) || defined(RAPID_PHASE_TIMERS) || defined(RAPID_BLOCK_STAMPS) || defined(RAPID_TRACE))
+#error "measurement hooks (tally_probes.inc) are for test / measurement builds only: the product library is compiled without them"
+#endif
+
 #include "../../include/rapid_mi355x.h"
 #include "index_kernels.h"
 #include "tally_kernel.h"
@@ -201,7 +205,7 @@ struct rapid_engine {
     DevBuf<int> d_gen_rx;
     float generate_ms = 0.f;
     int n_touched = 0;
-    int dict_mode = 3;  // rapid::kDictResolved (the product) / kDictDirect / kDictCompressed / kDictMemory (testing knobs)
+    int dict_mode = 3;  // rapid::kDictDirect / kDictCompressed / kDictMemory / kDictHashed for boundary records, kDictResolved for generated resident ones
     bool lds_attr_set = false;
     bool packed = false;  // the round's detector state: two slots per LDS word (tally_kernel.h: PackedSlotDetector)
     DevBuf<unsigned int> d_errflags;  // sticky per loaded stream set: bit0 = a delivered report is not covered by the declared alert set
@@ -863,9 +867,6 @@ int build_round_index(rapid_engine* h) {
     // Where the node -> slot dictionary lives: in LDS as plain tables (4 B per node) when at least eight receivers still fit
     // next to them; else compressed (3 bits per node + 4 B per node the alert set names: 100,000 nodes in ~25 KB); else in
     // memory.  Testing knob: bit 7 = never direct, bit 8 = never in LDS at all.
-    // The product resolves every record's subject to its dictionary entry ONCE, in a streaming pass (prepare_tally), and the
-    // tally looks nothing up (kDictResolved).  The modes in which the tally itself maps node -> slot remain as cross-checks
-    // behind the testing knob: bit 15 = look up in the tally, from the tables placed as described above.
     const bool no_direct = (h->force_exact & (128 | 256)) != 0 || info[7] == 0, no_lds = (h->force_exact & 256) != 0;  // info[7]: the build kernel's own verdict
     // Packed rounds over boundary records look their subjects up in memory (one dict_entry per node, gathered through L2).  Knob bit
     // 20: in LDS instead, as hashed buckets of one-byte remainders (kDictHashed) -- when every named subject is hot (a miss is then a

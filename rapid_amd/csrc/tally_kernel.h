@@ -15,17 +15,21 @@
 //     (index_kernels.h builds the node->slot dictionary once per round; reports about other subjects can never change any
 //     receiver's outcome and only contribute to seenLinkDownEvents): bits 0..K-1 = rings reported, bit 16 = already
 //     flushed into an emitted proposal;
-//   * the delivered stream is read ONCE from HBM, straight into registers (stream_load.h), 8 bytes per record:
-//     core[i] = {the subject's DICTIONARY ENTRY, core word}.  The entry (dict_entry below: slot, rings the index was not
-//     built for, which edge status fails the membership filter) is written into the record by resolve_records_kernel
-//     once per (stream set, round index) -- the tally looks nothing up; the core word (core_word below) is the ring mask,
-//     the edge status as two bits and the end-of-batch mark, laid out against the entry so that "this delivery is not
-//     covered" is one AND and "apply it" is one ds_or of the whole word.  The configuration-id verdict of
-//     R/MembershipService.java:653-657 is marked in the record by the load pass (kCoreStale) and arrives as the poison
-//     entry: no launch reads the ids.  A WINDOW is kQ quarters of 64 records at fixed positions of the stream; lane l of
-//     quarter q owns record 64 q + l and loads it with one buffer_load_dwordx2 (lane stride 8 B: a quarter is 512
-//     contiguous bytes).  Three windows per wave are in flight (three register sets, each re-requested in place as soon
-//     as its window is applied), without a byte of LDS;
+//   * the delivered stream is read ONCE from HBM, straight into registers (stream_load.h), by this kernel and by nothing else
+//     (round 3 moved 68 bytes per record through a load / split pass, a resolve pass and the tally; since round 4 the record
+//     stays what it is when it crosses the C ABI).  kFmtBoundary -- the product path of loaded and attached streams -- reads the
+//     20-byte rapid_alert_record itself: lane l of quarter q loads {configuration id} and {dst, ring mask | status | flags} of
+//     record 64 q + l with two buffer_load_dwordx2 at a lane stride of 20 B (src shares their cache lines and never reaches a
+//     register: R/MultiNodeCutDetector.java:101 never reads it), and the record becomes {subject, core word} on its way
+//     through the registers (open()): the configuration-id compare of R/MembershipService.java:653-657, the status byte as
+//     two bits, the batch end in bit 16; the subject is then mapped to its DICTIONARY ENTRY (dict_entry below: slot, rings the
+//     index was not built for, which edge status fails the membership filter) by a lookup whose tables live in LDS (direct or
+//     compressed), in memory, or -- hashed -- in LDS again (kDictMode).  The core word (core_word below) is laid out against
+//     the entry so that "this delivery is not covered" is one AND and "apply it" is one ds_or of the whole word.
+//     kFmtResident -- what rapid_sim_generate writes when it resolves while it lays down -- is 8 bytes {entry, core word}
+//     and needs no lookup (kDictResolved).  A WINDOW is kQ quarters of 64 records at fixed positions of the stream; two
+//     windows of boundary records per wave are in flight (three of resident ones, four in the packed instantiations), each
+//     register set re-requested in place as soon as its window is applied, without a byte of LDS;
 //   * FAST window (the steady state): while a WITNESS exists -- a slot in preProposal that provably stays below H
 //     through the window even if it is credited with every implicit report it can ever get -- updatesInProgress
 //     stays >= 1, so the reference cannot emit inside the window (R/MultiNodeCutDetector.java:110-121) and the
@@ -83,9 +87,9 @@ constexpr int kDummySlots = RAPID_DUMMY_SLOTS;   // slots n_hot .. n_hot + 63: w
 static_assert((kDummySlots & (kDummySlots - 1)) == 0 && kDummySlots >= 1 && kDummySlots <= 64, "dummy slots");
 constexpr int kMaxWavesPerBlock = 16;
 
-// The RESIDENT core word of a delivered record (second dword of core[i]; the first is the subject's node index), written by
-// split_records_kernel from dword 4 of the boundary record {ring mask, status, flags}: the status as TWO bits, exactly
-// one of which is set in a real record and none in the zeros behind a stream's end, so that "this report fails the
+// The core word of a delivered record: dword 4 of the boundary record {ring mask, status, flags} converted on the record's way
+// through the registers (open() / core_word()), or stored as the second dword of a generated resident record: the status as TWO
+// bits, exactly one of which is set in a real record and none in the zeros behind a stream's end, so that "this report fails the
 // UP / DOWN filter for this subject" is one AND with the subject's dictionary entry; the batch end in bit 16 -- the low bit
 // of the word's upper half, which nothing else of the word reaches into: a lane counts the batch ends it has applied by
 // adding upper halves (one vector instruction per quarter; counting them in scalars took two more per quarter out of the one
@@ -94,11 +98,9 @@ constexpr unsigned int kCoreRings = 0x3FFFu;   // bits 0..13: ring mask (K <= 14
 constexpr unsigned int kCoreDown = 1u << 14;   // edgeStatus == DOWN
 constexpr unsigned int kCoreUp = 1u << 15;     // edgeStatus == UP
 constexpr unsigned int kCoreEob = 1u << 16;    // last record of its BatchedAlertMessage
-// ... and in the FIRST dword (the subject's node index) bit 31 marks a record whose configuration id is not the one the
-// engine is in (R/MembershipService.java:653-657 drops it): the id is compared where every id passes anyway -- when the
-// records are split at load time, and again by remark_records_kernel if the view changes while streams stay loaded -- so
-// no launch of the tally reads the configuration ids.  A marked subject is out of every node range: the record takes the
-// path of any report about an unknown node (dropped by the per-delivery filter, an error where deliveries are vouched for).
+// (bit 31 of a subject: what the CPU emulator's harness marks a record of another configuration with when it prepares resident
+// records by hand -- out of every node range, so that the record takes the path of any report about an unknown node.  The
+// kernels compare the configuration id of a boundary record themselves and never see the mark.)
 constexpr unsigned int kCoreStale = 1u << 31;
 __host__ __device__ inline unsigned int core_word(unsigned int boundary_dword4) {
     return (boundary_dword4 & kCoreRings) | ((boundary_dword4 & 0x00FF0000u) != 0u ? kCoreDown : kCoreUp) |
@@ -169,12 +171,12 @@ struct RoundIndex {
 };
 
 struct TallyParams {
-    // The delivered streams, resident (index_kernels.h: split_records_kernel, resolve_records_kernel, gen_streams_kernel):
-    // core[i] = {dict_entry of record i's subject (its node index | kCoreStale in the cross-check modes), core word}: 8 bytes,
-    // all a launch pulls from HBM per delivered record.  cfg[i] = its configuration id: not read by this kernel (the verdict
-    // of R/MembershipService.java:653-657 is marked in the record when it becomes resident).
-    const unsigned char* core;         // [n_records][8]
-    const unsigned char* cfg;          // [n_records][8]
+    // The delivered streams, receiver after receiver: kFmtBoundary -- the 20-byte rapid_alert_records exactly as they crossed the C
+    // ABI (loaded, attached in place, or generated), 20 bytes pulled from HBM per delivered record, once; kFmtResident -- the
+    // 8-byte {dict_entry of the subject, core word} records of rapid_sim_generate(RAPID_GEN_RESOLVED).  (cfg: unused by the
+    // kernels -- the emulator's harness keeps the configuration ids of hand-made resident records there.)
+    const unsigned char* core;         // [n_records][20 or 8]
+    const unsigned char* cfg;
     const long long* rec_off;          // [R+1], in records
     int n_receivers;
     int n_nodes;
@@ -230,13 +232,13 @@ __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
 // node + 4 B per touched node; or left in memory), the round's (subject, observer, ring) triples [count, triples ...], the per-slot masks of the rings on
 // which a hot observer watches the slot, and slot -> node.  Per wave: detector state (hot + dummy slots),
 // decoded-record scratch, undo list.
-// dictionary placement: where node -> (slot, declared rings, member) is looked up
-// kDictResolved -- the product's way: there is no lookup in the tally at all.  The first dword of a resident record holds the
-// subject's dict_entry itself, written by resolve_records_kernel (index_kernels.h) once per (stream set, round index): every
-// delivered record has to be mapped from node to slot exactly once, and a streaming pass over all records with the whole
-// GPU does that at memory speed, whereas the tally would do it 64 lanes at a time between two dependent LDS or L2 round
-// trips, and give 40 KB of LDS per workgroup (or, at 10^5 .. 10^6 nodes, its whole speed) for the tables.  The other three
-// modes read the subject's node index and look it up themselves; they stay as cross-checks (testing knobs bit 7 / 8).
+// dictionary placement: where node -> (slot, declared rings, member) is looked up, one instantiation each
+//   kDictDirect     one dict_entry per node in LDS, staged from the index's finished entries[] (the product path up to ~30,000 nodes)
+//   kDictCompressed one bit per node + rank + one entry per node the alert set names, in LDS (10^5 nodes in 25 KB)
+//   kDictMemory     entries[] gathered through L2 (rounds whose state leaves the LDS no room: the packed detector, 10^6 nodes)
+//   kDictHashed     the hot subjects as hashed buckets of one-byte remainders in LDS, exact (packed rounds; opt-in, see engine.hip)
+//   kDictResolved   no lookup: a generated resident record carries its subject's entry (rapid_sim_generate resolves each of the
+//                   round's distinct alerts once, while the deliveries are laid down)
 enum { kDictMemory = 0, kDictDirect = 1, kDictCompressed = 2, kDictResolved = 3, kDictHashed = 4 };
 // the hashed dictionary's geometry: key bits (>= 10, covering n_nodes), one-byte remainders, at most kHashBucketCap keys per bucket
 constexpr int kHashRemBits = 8, kHashBucketCap = 16, kHashMaxKeyBits = 21, kHashPad = 32;
@@ -341,14 +343,27 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {  // 
     return x ^ (x >> 31);
 }
 
-// Phase timers of the profiling build (-DRAPID_PHASE_TIMERS, scripts/phase_timers.sh): shader-clock cycles per phase,
-// summed over all waves, reported through the stats array instead of the usual counters.  Never in the product build.
-#ifdef RAPID_PHASE_TIMERS
-#define RAPID_T0(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
-#define RAPID_T1(acc, v) acc += __builtin_amdgcn_s_memtime() - (v)
+// Measurement builds hook into the kernels below through these macros and nothing else.  Their bodies -- phase timers, workgroup
+// time stamps, the emulator's trace lines -- live in tally_probes.inc, which only a build that says -DRAPID_MEASUREMENT_BUILD ever
+// sees (scripts/build_variants.sh; engine.hip refuses to compile the PRODUCT with it, tests/test_build.py checks both).  Here: the
+// empty defaults -- what librapid_mi355x.so and its test build are compiled with.  (The timing-only probes of rounds 4 and 5 --
+// the turn loop without its lookup, its OR, its configuration ids -- are gone from the source: what they measured is in
+// profiles/r04_ab_probes_c3b.txt, r04_ab_sensitivity_c3b.txt, r05_c5_probe_builds.txt, r05_ab_dummy_slots_c3b.txt.)
+#ifdef RAPID_MEASUREMENT_BUILD
+#include "tally_probes.inc"
 #else
-#define RAPID_T0(v)
-#define RAPID_T1(acc, v)
+#define RAPID_T0(v)                      // start of a timed phase
+#define RAPID_T1(acc, v)                 // end of it
+#define RAPID_HOOK_BLOCK_INIT()          // next to the zeroing of the workgroup's statistics
+#define RAPID_HOOK_KERNEL_LOCALS()       // a wave's own accumulators
+#define RAPID_HOOK_RECEIVER_BEGIN()      // first statement of a receiver
+#define RAPID_HOOK_TIGHT(n)              // n windows went through the steady-state loop
+#define RAPID_HOOK_RESULTS()             // lane 0, after the receiver's results were stored
+#define RAPID_HOOK_RECEIVER_END()        // last statement of a receiver
+#define RAPID_HOOK_STATS()               // after mine_stats[] was filled
+#define RAPID_HOOK_REDUCE(i) false       // true: the hook folded mine_stats[i] into block_stats[i] itself
+#define RAPID_HOOK_STATS_OUT(i) false    // true: the hook wrote block_stats[i] to p.stats itself
+#define RAPID_TRACE_LINE(...)            // a line of the emulator's trace
 #endif
 
 // ---- detector state accessors ---------------------------------------------------------------------------------
@@ -571,12 +586,13 @@ __device__ inline void exact_batch_end(const D& d, RxScalars& s, const unsigned 
 
 // --------------------------------------------------------------------------------------------------------------
 // Whole-population tally.  block = waves_per_block x 64; the workgroup's waves claim receivers from its deal (and the pool).
-// kDictMode: kDictResolved (the product) -- the records carry their subjects' dictionary entries; the other modes look the
-// subject up (tables in memory / direct in LDS / compressed in LDS) and exist as cross-checks.
-// kTrusted: the engine has verified that every declared alert passes the filter of R/MembershipService.java:644-675 under
-// the current view and that every delivered record carries the current configuration id and a known subject; a delivery
-// that still fails the membership filter or names a ring the index was not built for is then an ERROR of the stream (sticky
-// flag, RAPID_EINVAL) instead of being dropped per delivery.
+// kDictMode: where a boundary record's subject is mapped to its dictionary entry (see the list above tally_dict_bytes); the host picks
+// the one whose tables fit the LDS next to the receivers' state (engine.hip: build_round_index).
+// kTrusted: every declared alert of the current configuration passes the filter of R/MembershipService.java:644-675 under the current
+// view (checked by the round index) and the deliveries are vouched for as copies of them; the configuration id of every delivered
+// record is still compared here, and a delivery that fails the membership filter or names a ring the index was not built for is
+// an ERROR of the stream (sticky flag, RAPID_EINVAL) instead of being dropped per delivery.
+// kPacked: two slots per LDS word (rounds with thousands of hot subjects).
 // --------------------------------------------------------------------------------------------------------------
 // Two record formats reach the kernel (TallyParams::core points at either):
 //   kFmtBoundary -- the 20-byte rapid_alert_record exactly as it crosses the C ABI (SURVEY 8d's unit): {configuration id, src, dst,
@@ -804,9 +820,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
     if (threadIdx.x < 8u) block_stats[threadIdx.x] = 0ull;
     unsigned long long* const block_votes = block_stats + 10;  // [4], see TallyParams::vote_acc
     if (threadIdx.x >= 16u && threadIdx.x < 20u) block_votes[threadIdx.x - 16u] = 0ull;
-#if defined(RAPID_PHASE_TIMERS) && defined(RAPID_BLOCK_STAMPS)
-    if (threadIdx.x == 7u) block_stats[7] = ~0ull;
-#endif
+    RAPID_HOOK_BLOCK_INIT();
     if (threadIdx.x == 8u) *block_claims = blockDim.x >> 6;  // claims 0 .. waves - 1 are the first deal
     __syncthreads();
 
@@ -827,11 +841,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
     const unsigned int node_last = (unsigned int)(p.n_nodes > 0 ? p.n_nodes - 1 : 0);
     const unsigned int my_dummy = (unsigned int)(n_hot + (lane & (kDummySlots - 1)));  // tables in memory: this lane's dummy slot
     unsigned long long n_slow = 0, n_fast = 0, n_restart = 0, n_records = 0, n_pipe = 0, n_careful = 0, n_sweeps = 0;
-#ifdef RAPID_PHASE_TIMERS
-    unsigned long long t_total = 0, t_ensure = 0, t_lean = 0, t_careful = 0, t_out = 0, t_flush = 0, t_rx = 0, n_tight = 0;
-    RAPID_T0(t_kernel0);
-    const unsigned long long t_real_start = __builtin_amdgcn_s_memrealtime();
-#endif
+    RAPID_HOOK_KERNEL_LOCALS();
     int n_applied = 0;
     unsigned int sink = 0u;  // stream-only mode: keeps the loads alive
 
@@ -844,7 +854,6 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
         unsigned int bytes;
     };
     // one window of the stream `st` starting at this lane's byte offset `voff`: kQ wave instructions, nothing waited for
-    const unsigned int cfg_lo_ = (unsigned int)(unsigned long long)p.cfg_id, cfg_hi_ = (unsigned int)((unsigned long long)p.cfg_id >> 32);
     auto load_window = [&](const Stream& st, unsigned int voff, Win& W) {
         // declared wave-uniform right here (it is: every lane computes it from the wave's receiver index), so that the
         // descriptor is in SGPRs whatever the compiler concluded about the loops it travelled through
@@ -855,18 +864,8 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
 #pragma unroll
         for (int q = 0; q < kQ; ++q) {
             if constexpr (kFmt == kFmtBoundary) {
-#if defined(RAPID_BOUNDARY_X4)  // measurement variant: 16 + 4 bytes per record (src travels into a register nobody reads)
-                unsigned int src_;
-                stream_load4(rsrc, voff, (unsigned int)q * kQuarterB, W.c0[q], W.c1[q], src_, W.w3[q]);
-                stream_load1(rsrc, voff, (unsigned int)q * kQuarterB + 16u, W.w4[q]);
-#elif defined(RAPID_PROBE_NO_CFG)  // measurement only (results void for streams with late deliveries): the ids are not loaded
-                W.c0[q] = cfg_lo_;
-                W.c1[q] = cfg_hi_;
-                stream_load2(rsrc, voff, (unsigned int)q * kQuarterB + 12u, W.w3[q], W.w4[q]);
-#else
                 stream_load2<RAPID_BOUNDARY_AUX_A>(rsrc, voff, (unsigned int)q * kQuarterB, W.c0[q], W.c1[q]);
                 stream_load2<RAPID_BOUNDARY_AUX_B>(rsrc, voff, (unsigned int)q * kQuarterB + 12u, W.w3[q], W.w4[q]);
-#endif
             } else {
                 stream_load2(rsrc, voff, (unsigned int)q * kQuarterB, W.w3[q], W.w4[q]);
             }
@@ -1062,10 +1061,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
         for (int i = 0; i < kSets; ++i) load_window(rsrc, lane_off + (unsigned int)i * kWinBytes, S[i]);
     }
     while (r < p.n_receivers) {
-#ifdef RAPID_PHASE_TIMERS
-        const unsigned long long t_rx0 = __builtin_amdgcn_s_memtime();
-        const unsigned long long t_lean0 = t_lean, t_careful0 = t_careful, t_flush0 = t_flush;
-#endif
+        RAPID_HOOK_RECEIVER_BEGIN();
         const int nwin = (nrec + kWin - 1) / kWin;
         // The next receiver is claimed a few windows before the end of this one's stream, and the bounds of its stream are
         // loaded right then: both answers arrive with the stream's last windows instead of costing two memory round trips
@@ -1128,9 +1124,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
         // fast path: slots in [L, H) that stay below H even if they are given every implicit report they can ever get --
         // popc(state | smask) < H, so that a lagging state cannot hide their departure -- smallest bound first.
         auto sweep = [&]() {
-#ifdef RAPID_TRACE
-            if (lane == 0) fprintf(stderr, "R r=%d\n", r);
-#endif
+            RAPID_TRACE_LINE("R r=%d\n", r);
             RAPID_T0(ts0);
             wave_lds_fence();
             int run = 0;
@@ -1226,9 +1220,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
                 s.entered = true;
                 return;
             }
-#ifdef RAPID_TRACE
-            if (lane == 0) fprintf(stderr, "F r=%d\n", r);
-#endif
+            RAPID_TRACE_LINE("F r=%d\n", r);
             RAPID_T0(tf0);
             wave_lds_fence();
             int applied = 0;
@@ -1247,21 +1239,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
         // branch: nothing is applied unless the certificate holds, the last quarter holds a batch end (the records after
         // it are carried into the next window) and no first DOWN report would switch the implicit invalidation on inside
         // the window.
-#ifndef RAPID_LANE_DUMMY
-#define RAPID_LANE_DUMMY 0
-#endif
-        // (measurement knob, round 5) a report about a subject that is not hot goes to THIS LANE's dummy slot instead of the one its
-        // node index picks: 64 lanes, 64 dummy words, two per bank -- no two lanes of a quarter ever OR into the same dummy word
-        auto dummy_to_lane = [&](unsigned int so_raw) -> unsigned int {
-            if constexpr (RAPID_LANE_DUMMY != 0) return so_raw < 2u * (unsigned int)n_hot ? so_raw : 2u * my_dummy;
-            return so_raw;
-        };
         auto fast_try = [&](const Win& cw) -> int {
-#ifdef RAPID_PROBE_STREAM  // measurement builds only (results are void): what the turn loop costs with the tally taken out
-#pragma unroll
-            for (int q = 0; q < kQ; ++q) sink ^= cw.w3[q] ^ cw.w4[q];
-            return kApplied;
-#endif
             unsigned int so[kQ], w[kQ];
             // (everything that can stay in vector registers does: the CU's waves share ONE scalar pipe, and it is the busiest
             // unit of this kernel.  "Does the window say anything about the witness" is a running minimum of slot ^ witness,
@@ -1285,36 +1263,18 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
                     const unsigned int full = (raw & kCoreRings) | ((raw & 0x00FF0000u) != 0u ? kCoreDown : kCoreUp);
                     w[q] = current ? full : 0u;
                     uncovered |= w[q] & k.entry;
-                    so[q] = dummy_to_lane(k.entry >> 16);
+                    so[q] = k.entry >> 16;
                     wdiff = min(wdiff, so[q] ^ witness_so);
                     nbv += (raw >> 24) & 1u;
-                    // measurement builds only (profiles/r04_ab_sensitivity_c3b.txt): work ADDED to the fast window, results unchanged
-#ifdef RAPID_PROBE_DUP_LOOKUP  // a second gather per record
-                    sink ^= lookup(cw.w3[q] ^ 1u).entry;
-#endif
-#ifdef RAPID_PROBE_VALU_N  // 3 N more dependent vector instructions per quarter
-                    {
-                        unsigned int x_ = raw;
-#pragma unroll
-                        for (int i_ = 0; i_ < RAPID_PROBE_VALU_N; ++i_) x_ = (x_ ^ (x_ >> 7)) + 0x9E3779B9u;
-                        sink ^= x_;
-                    }
-#endif
                 }
                 mEl = wave_ballot((cw.w4[kQ - 1] & 0x01000000u) != 0u);
             } else {
                 const Rec c = open(cw);
 #pragma unroll
                 for (int q = 0; q < kQ; ++q) {
-#ifdef RAPID_PROBE_NO_LOOKUP
-                    Look k;
-                    k.entry = (c.w3[q] & 0xFFu) << 17;
-                    k.untouched = false;
-#else
                     const Look k = lookup(c.w3[q]);
-#endif
                     w[q] = effective(c, q, k);
-                    so[q] = dummy_to_lane(k.entry >> 16);
+                    so[q] = k.entry >> 16;
                     wdiff = min(wdiff, so[q] ^ witness_so);
                     nbv += c.w4[q] >> 16;
                 }
@@ -1341,34 +1301,14 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
             }
             const bool certified = __popc((wstate | wadd | wmask) & d.kmask) < d.H;
             if (!(fastable && certified)) {
-#ifdef RAPID_TRACE
-                if (lane == 0) fprintf(stderr, "W-fail r=%d witness=%d wcount=%d fastable=%d\n", r, witness, __popc((wstate | wadd) & d.kmask), (int)fastable);
-#endif
+                RAPID_TRACE_LINE("W-fail r=%d witness=%d wcount=%d fastable=%d\n", r, witness, __popc((wstate | wadd) & d.kmask), (int)fastable);
                 return fastable ? kWitnessFails : kNotFastable;
             }
             // whole core words are ORed in: the status and batch-end bits land in bits of the state word nobody reads
-#ifdef RAPID_PROBE_NO_OR
-#pragma unroll
-            for (int q = 0; q < kQ; ++q) sink ^= so[q] ^ w[q];
-#else
-#if defined(RAPID_SKIP_DUMMY_OR)  // (measurement knob, round 5) no OR at all for reports about subjects that are not hot: an execution mask instead of dummy words
-            const unsigned int hot2_ = 2u * (unsigned int)n_hot;
-            if (carry_so < hot2_) d.fast_or(carry_so, carry_w);
-#pragma unroll
-            for (int q = 0; q < kQ - 1; ++q)
-                if (so[q] < hot2_) d.fast_or(so[q], w[q]);
-            if (so[kQ - 1] < hot2_) d.fast_or(so[kQ - 1], inl ? w[kQ - 1] : 0u);
-#else
             d.fast_or(carry_so, carry_w);
 #pragma unroll
             for (int q = 0; q < kQ - 1; ++q) d.fast_or(so[q], w[q]);
             d.fast_or(so[kQ - 1], inl ? w[kQ - 1] : 0u);
-#endif
-#ifdef RAPID_PROBE_DUP_OR  // measurement builds only: a second OR per record, into this lane's dummy slot (results unchanged)
-#pragma unroll
-            for (int q = 0; q < kQ; ++q) d.fast_or(2u * my_dummy, w[q] ^ (so[q] & 1u));
-#endif
-#endif
             vbatch += nbv;
             carry_so = so[kQ - 1];
             carry_w = inl ? 0u : w[kQ - 1];
@@ -1578,9 +1518,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
             bool exact_next = false;  // the sub-chunk starts with the critical record: replay it record by record
             while (spos < send && emit_batch < 0 && !restart) {
                 n_careful++;
-#ifdef RAPID_TRACE
-                if (lane == 0) fprintf(stderr, "C r=%d w=%d spos=%d run=%d cap=%d\n", r, w, spos, s.running, careful_cap);
-#endif
+                RAPID_TRACE_LINE("C r=%d w=%d spos=%d run=%d cap=%d\n", r, w, spos, s.running, careful_cap);
                 decode_scratch();
                 if (exact_only || s.batch_emitted || exact_next) {
                     exact_next = false;
@@ -1719,9 +1657,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
                     }
                     voff = vturn + (unsigned int)kSets * kWinBytes;
                     RAPID_T1(t_ensure, tl0);
-#ifdef RAPID_PHASE_TIMERS
-                    n_tight += (unsigned long long)(w - w_first);
-#endif
+                    RAPID_HOOK_TIGHT(w - w_first);
                     n_fast += (unsigned long long)(w - w_first);
                     n_records += (unsigned long long)(w - w_first) * (unsigned long long)kWin;
                     if (w != w_first) swept = false;  // (another window now)
@@ -1833,7 +1769,6 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
             uncovered = 0u;
         }
         if (lane == 0) {
-#ifndef RAPID_PHASE_TIMERS
             stream_store(p.emit_batch + r, emit_batch);
             stream_store(p.num_proposals + r, s.proposal_count);
             stream_store(p.prop_count + r, count > p.prop_cap ? -1 : count);
@@ -1842,53 +1777,23 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
                 atomicAdd(&block_votes[2], 1ull);
                 atomicMax(&block_votes[3], ~(unsigned long long)(unsigned int)r);
             }
-#else
-            stream_store(p.emit_batch + r, emit_batch);
-            // profiling build: cycles spent on this receiver, in total and per phase
-            stream_store(p.fingerprint + r, ((__builtin_amdgcn_s_memtime() - t_rx0) & 0xFFFFFFFFull) | ((t_flush - t_flush0) << 32));
-            stream_store(p.num_proposals + r, (int)((t_careful - t_careful0) >> 4));
-            stream_store(p.prop_count + r, (int)((t_lean - t_lean0) >> 4));
-#endif
+            RAPID_HOOK_RESULTS();
         }
         wave_lds_fence();
         r = r_next;
         nrec = nrec_next;
         RAPID_T1(t_out, to0);
-#ifdef RAPID_PHASE_TIMERS
-        t_rx++;
-#endif
+        RAPID_HOOK_RECEIVER_END();
     }
     unsigned long long mine_stats[8];
-#ifdef RAPID_PHASE_TIMERS
-    RAPID_T1(t_total, t_kernel0);
-    mine_stats[0] = t_total; mine_stats[1] = t_ensure; mine_stats[2] = t_lean; mine_stats[3] = t_careful;
-    mine_stats[4] = t_out; mine_stats[5] = t_flush; mine_stats[6] = t_rx; mine_stats[7] = n_tight;
-#else
     mine_stats[0] = n_slow; mine_stats[1] = n_fast; mine_stats[2] = n_sweeps; mine_stats[3] = n_restart;
     mine_stats[4] = (unsigned long long)n_applied; mine_stats[5] = n_records; mine_stats[6] = n_pipe; mine_stats[7] = n_careful;
-#endif
-#if defined(RAPID_PHASE_TIMERS) && defined(RAPID_BLOCK_STAMPS)
-    // profiling build for scripts/block_times.py: [1] = when the workgroup's last wave finished, [7] = when its first wave got
-    // here after the tables were staged (constant-rate counter, 10 ns ticks) -- per workgroup through rapid_debug_block_stats
-    mine_stats[1] = __builtin_amdgcn_s_memrealtime();
-    mine_stats[7] = t_real_start;
+    RAPID_HOOK_STATS();
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i == 1)
-                atomicMax(&block_stats[i], mine_stats[i]);
-            else if (i == 7)
-                atomicMin(&block_stats[i], mine_stats[i]);
-            else
-                atomicAdd(&block_stats[i], mine_stats[i]);
-        }
+        for (int i = 0; i < 8; ++i)
+            if (!RAPID_HOOK_REDUCE(i)) atomicAdd(&block_stats[i], mine_stats[i]);
     }
-#else
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) atomicAdd(&block_stats[i], mine_stats[i]);
-    }
-#endif
     if ((p.flags & 32) != 0 && sink == 0x12345678u) block_stats[0] = 1ull;
     __syncthreads();
     if (threadIdx.x == 0 && p.pool != nullptr) {
@@ -1914,16 +1819,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
         }
     }
     // p.stats = [gridDim.x][8], accumulated over launches; one plain read-modify-write per workgroup and counter
-#if defined(RAPID_PHASE_TIMERS) && defined(RAPID_BLOCK_STAMPS)
-    if (threadIdx.x < 8u && p.stats != nullptr) {
-        if (threadIdx.x == 1u || threadIdx.x == 7u)
-            p.stats[(size_t)blockIdx.x * 8 + threadIdx.x] = block_stats[threadIdx.x];
-        else
-            p.stats[(size_t)blockIdx.x * 8 + threadIdx.x] += block_stats[threadIdx.x];
-    }
-#else
-    if (threadIdx.x < 8u && p.stats != nullptr) p.stats[(size_t)blockIdx.x * 8 + threadIdx.x] += block_stats[threadIdx.x];
-#endif
+    if (threadIdx.x < 8u && p.stats != nullptr && !RAPID_HOOK_STATS_OUT(threadIdx.x)) p.stats[(size_t)blockIdx.x * 8 + threadIdx.x] += block_stats[threadIdx.x];
 }
 
 // --------------------------------------------------------------------------------------------------------------

@@ -1,7 +1,8 @@
-"""What bounds the tally at BASELINE configs[4] (10^6 members, ~15,000 hot subjects per round)?  One churn round, its deliveries made
-on the device for a sample of receivers (20-byte boundary records, late deliveries of another configuration among them), and the
-tally kernel timed in every prepared build of the library (scripts/build_variants.sh): the product's kernel, the same without the
-dictionary gather (pnolook), without the detector's OR (pnoor), and streaming only (pstream) -- results of the probe builds are void.
+"""The tally at BASELINE configs[4] (10^6 members, ~15,000 hot subjects per round) on one tile: one churn round, its deliveries made on
+the device for a sample of receivers (late deliveries of another configuration among them) as 20-byte boundary records and as
+resolved 8-byte records, and the tally kernel timed in every prepared build of the library (scripts/build_variants.sh; RAPID_AB_ONLY
+picks).  (Round 5 also ran it over timing-only probe builds -- no dictionary gather, no OR, streaming only: profiles/
+r05_c5_probe_builds.txt; those probes are gone from the kernel source.)  RAPID_C5_KNOB=<bits>: rapid_sim_set_force_exact for the runs.
     python scripts/c5_probe.py [members=1000000] [receivers=1024] [reps=5]"""
 import glob
 import os
@@ -53,7 +54,8 @@ for tag, path in libs.items():
     for boundary in (True, False):
         sim.generate(deliver_set, rx, seed=7, trust_copies=True, boundary=boundary)
         rec_b = 20 if boundary else 8
-        for knob, what in ((0, "as chosen"), (64, "filter per delivery")):
+        base = int(os.environ.get("RAPID_C5_KNOB", "0"))
+        for knob, what in ((base, "as chosen"), (base | 64, "filter per delivery")):
             sim.set_force_exact(knob)
             ms = sim.time_tally(reps)
             info = sim.index_info(timed=False)

@@ -61,3 +61,24 @@ def test_register_allocation_of_the_tally_kernel_is_the_measured_one():
             t = name.split("tally_population_kernelILi")[1]  # <dictionary mode>ELb<trusted>ELi<record format>ELb<packed>EEEv...
             got[(int(t[0]), t[4] == "1", int(t[8]), t[12] == "1")] = r["VGPRs"]
     assert got == EXPECTED_VGPRS, got
+
+
+def test_product_is_compiled_without_measurement_hooks():
+    """The hot kernel's source holds hook POINTS and their empty defaults; the bodies (phase timers, time stamps, trace lines) live in
+    csrc/tally_probes.inc, which only -DRAPID_MEASUREMENT_BUILD pulls in -- and the product refuses that define: one stray -D must not
+    change what librapid_mi355x.so computes (several of round 4's probes voided the results)."""
+    import re
+    import subprocess
+    src = open(os.path.join(N.SRC_DIR, "tally_kernel.h")).read()
+    assert "RAPID_PROBE_" not in src and '#include "tally_probes.inc"' in src
+    body = src.split('#include "tally_probes.inc"', 1)[1]
+    for word in ("RAPID_PHASE_TIMERS", "RAPID_BLOCK_STAMPS", "RAPID_TRACE\b", "fprintf"):
+        assert not re.search(word, body), word
+    # the product's command line (rapid_amd/_native.py: build) carries no -D at all; the test build exactly one
+    native = open(os.path.join(os.path.dirname(N.SRC_DIR), "_native.py")).read()
+    assert re.findall(r'"-D[A-Z_]+"', native) == ['"-DRAPID_TEST_BUILD"']
+    # ... and a product translation unit that is handed a hook switch anyway does not compile
+    for define in ("-DRAPID_MEASUREMENT_BUILD", "-DRAPID_PHASE_TIMERS", "-DRAPID_TRACE"):
+        r = subprocess.run([N.hipcc(), "--offload-arch=gfx950", "-std=c++17", "-E", "--cuda-host-only", define, "-I" + N.SRC_DIR,
+                            os.path.join(N.SRC_DIR, "engine.hip"), "-o", os.devnull], capture_output=True, text=True)
+        assert r.returncode != 0 and "measurement hooks" in r.stderr, (define, r.stderr[-300:])
