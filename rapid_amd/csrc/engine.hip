@@ -30,6 +30,7 @@
 
 #include "../../include/rapid_mi355x.h"
 #include "index_kernels.h"
+#include "node_id_sort.h"
 #include "tally_kernel.h"
 #include "view_kernels.h"
 #include "vote_kernels.h"
@@ -115,6 +116,11 @@ struct rapid_engine {
     // then costs the host what the change is, not a walk over the whole registry (10^6 nodes: 1 ms of a 2.4 ms view change)
     std::vector<int> changed;
     bool changed_valid = false;
+    DevBuf<int> d_chunk_base, d_chunk_lb, d_nonmembers;  // ring_chunk_prep_kernel's answers; nonmember_list_kernel's list (count first)
+    DevBuf<unsigned int> d_idacc;                // ids_contains_publish_kernel: {answer, finished workgroups}
+    bool idacc_clean = false;
+    std::vector<unsigned int> change_stamp;      // per node: the view change that last listed it (a node named twice in one cut is listed once)
+    unsigned int change_epoch = 0;
     DevBuf<int> d_gone;                          // the nodes that left, for the kernels of a view change
     DevBuf<unsigned short> d_edges, d_edge_mask; // index_edges_kernel: every hot slot's observer slots and ring mask (large populations)
     int ring_m = 0;                              // their length
@@ -295,6 +301,8 @@ int use_device(rapid_engine* h) {
     return RAPID_OK;
 }
 
+int ensure_mailbox(rapid_engine* h);
+
 // Rebuilds rings, tables, state template and configuration id from the host member flags.
 // Is any of `ids` (sorted, distinct) among the identifiers seen so far?  A binary search per id in the device's sorted copy.
 static int ids_seen_any(rapid_engine* h, const std::vector<std::pair<int64_t, int64_t>>& ids, bool* any) {
@@ -307,6 +315,36 @@ static int ids_seen_any(rapid_engine* h, const std::vector<std::pair<int64_t, in
         flat[nn + i] = ids[i].second;
     }
     HIPCHK(h, h->d_ids_new.ensure(2 * nn));
+    if (nn <= 16384 && h->h_vstage != nullptr && h->vstage_bytes >= 16 * nn && !h->vstage_busy) {
+        // a cut's NodeIds: through the pinned staging block, answered into the mailbox (word 13 = 2 x the call's sequence number +
+        // the answer): no pageable copy, no stream synchronisation -- this check stands in front of every view change
+        if (int rc = ensure_mailbox(h)) return rc;
+        std::memcpy(h->h_vstage, flat.data(), 16 * nn);
+        h->vstage_busy = true;
+        HIPCHK(h, hipMemcpyAsync(h->d_ids_new.p, h->h_vstage, 16 * nn, hipMemcpyHostToDevice, h->stream));
+        const unsigned int seq = ++h->mail_seq & 0x3FFFFFFFu;
+        HIPCHK(h, h->d_idacc.ensure(2));
+        if (!h->idacc_clean) {
+            HIPCHK(h, hipMemsetAsync(h->d_idacc.p, 0, 8, h->stream));
+            h->idacc_clean = true;  // (the kernel's last workgroup leaves both words zero)
+        }
+        hipLaunchKernelGGL(rapid::ids_contains_publish_kernel, dim3(grid_for((long long)nn, 256)), dim3(256), 0, h->stream, h->d_ids_hi.p, h->d_ids_lo.p,
+                           h->n_ids_dev, h->d_ids_new.p, h->d_ids_new.p + nn, (int)nn, h->d_idacc.p, reinterpret_cast<volatile unsigned int*>(h->d_mail), 13, seq);
+        HIPCHK(h, hipGetLastError());
+        volatile unsigned int* const w = reinterpret_cast<volatile unsigned int*>(h->h_mail) + 13;
+        const auto t0 = std::chrono::steady_clock::now();
+        while ((*w >> 1) != seq) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {  // (a faulted kernel never answers)
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                HIPCHK(h, hipGetLastError());
+                if ((*w >> 1) != seq) return fail(h, RAPID_EDEVICE, "kernel finished without publishing its answer");
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        h->vstage_busy = false;  // (the kernel that answered ran behind the copy)
+        *any = (*w & 1u) != 0u;
+        return RAPID_OK;
+    }
     HIPCHK(h, h->d_loadflags.ensure(2));
     HIPCHK(h, hipMemsetAsync(h->d_loadflags.p, 0, 8, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_ids_new.p, flat.data(), 16 * nn, hipMemcpyHostToDevice, h->stream));
@@ -357,6 +395,9 @@ int presize_view(rapid_engine* h) {
     HIPCHK(h, h->d_subj.ensure(km));
     HIPCHK(h, h->d_cfg_out.ensure(1));
     HIPCHK(h, h->d_chunk_kept.ensure(K * ((N + rapid::kRingChunk - 1) / rapid::kRingChunk + 1)));
+    HIPCHK(h, h->d_chunk_base.ensure(K * ((N + rapid::kRingChunk - 1) / rapid::kRingChunk + 2)));
+    HIPCHK(h, h->d_chunk_lb.ensure(K * ((N + rapid::kRingChunk - 1) / rapid::kRingChunk + 2)));
+    HIPCHK(h, h->d_nonmembers.ensure(N + 1));
     HIPCHK(h, h->d_joiners.ensure(J));
     HIPCHK(h, h->d_join_keys.ensure(kj));
     HIPCHK(h, h->d_join_skeys.ensure(kj));
@@ -417,9 +458,17 @@ int rebuild_view(rapid_engine* h) {
     int removed = 0, M = 0;
     const bool by_list = have_rings && h->changed_valid;  // (the device's member flags are then the ones the rings were built from)
     if (by_list) {
-        std::sort(h->changed.begin(), h->changed.end());
-        h->changed.erase(std::unique(h->changed.begin(), h->changed.end()), h->changed.end());
-        for (const int n : h->changed) {  // ascending, like the walk below
+        // (in the order the cut names them: nothing below depends on the order of these two lists -- the joiners are sorted per ring
+        // by their keys on the device, the rest are per-node updates -- and sorting 15,000 node indices here was a third of the host's
+        // share of a view change at 10^6 members; a node the cut names twice is taken once)
+        if (h->change_stamp.size() < (size_t)N) h->change_stamp.resize((size_t)N, 0u);
+        if (++h->change_epoch == 0u) {
+            std::fill(h->change_stamp.begin(), h->change_stamp.end(), 0u);
+            h->change_epoch = 1u;
+        }
+        for (const int n : h->changed) {
+            if (h->change_stamp[(size_t)n] == h->change_epoch) continue;
+            h->change_stamp[(size_t)n] = h->change_epoch;
             const bool now = h->member[(size_t)n] != 0, was = h->ring_member[(size_t)n] != 0;
             if (now && !was) joiners.push_back(n);
             if (was && !now) gone.push_back(n);
@@ -463,26 +512,30 @@ int rebuild_view(rapid_engine* h) {
     int* const stage_join = reinterpret_cast<int*>(stage_lists + n4);
     int* const stage_members = reinterpret_cast<int*>(stage_lists + 2 * n4);
     long long* const stage_ids = reinterpret_cast<long long*>(stage_lists + 3 * n4);  // 16 N bytes
+    // the nodes that left and, right behind them, the nodes that came: one list on the device (ring_patch_kernel takes it whole)
     std::memcpy(stage_gone, gone.data(), sizeof(int) * gone.size());
-    std::memcpy(stage_join, joiners.data(), sizeof(int) * joiners.size());
+    std::memcpy(stage_gone + gone.size(), joiners.data(), sizeof(int) * joiners.size());
+    (void)stage_join;
     bool gone_cleared = false;  // the member flags of the nodes that left were cleared by the kernel that drops their memo entries
-    auto q4_drop = [&](const int* d_nodes, size_t m, int self, bool clear_members) -> int {
-        if (m == 0 || !h->d_subj.p || !h->d_pos.p || !h->d_q4_valid.p) return RAPID_OK;
-        hipLaunchKernelGGL(rapid::q4_invalidate_kernel, dim3(grid_for((long long)m * K, 256)), dim3(256), 0, st, h->d_subj.p, h->d_pos.p, d_nodes,
+    // (ring_now / m_now: the rings of the view the predecessors are taken from -- the old ones for the nodes that leave, the new ones
+    // for the joiners)
+    auto q4_drop = [&](const int* d_nodes, size_t m, int self, bool clear_members, const int* ring_now, int m_now) -> int {
+        if (m == 0 || !h->d_subj.p || !ring_now || !h->d_q4_valid.p) return RAPID_OK;
+        hipLaunchKernelGGL(rapid::q4_invalidate_kernel, dim3(grid_for((long long)m * K, 256)), dim3(256), 0, st, h->d_subj.p, ring_now, m_now, d_nodes,
                            (int)m, N, K, h->d_q4_valid.p, self, clear_members ? h->d_member.p : (unsigned char*)nullptr);
         gone_cleared = gone_cleared || clear_members;
         return RAPID_OK;
     };
     const int J = (int)joiners.size();
-    if (have_rings && !gone.empty()) {
-        HIPCHK(h, h->d_gone.ensure(gone.size()));
-        HIPCHK(h, hipMemcpyAsync(h->d_gone.p, stage_gone, sizeof(int) * gone.size(), hipMemcpyHostToDevice, st));
-        int rc = q4_drop(h->d_gone.p, gone.size(), 1, by_list && h->d_member.p != nullptr);  // (:181-195)
-        if (rc) return rc;
-    }
-    if (have_rings && J > 0) {
-        HIPCHK(h, h->d_joiners.ensure((size_t)J));
-        HIPCHK(h, hipMemcpyAsync(h->d_joiners.p, stage_join, sizeof(int) * (size_t)J, hipMemcpyHostToDevice, st));
+    const int* d_joined = nullptr;  // the joiners on the device: behind the nodes that left, in the same buffer
+    if (have_rings && (!gone.empty() || J > 0)) {
+        HIPCHK(h, h->d_gone.ensure(gone.size() + (size_t)J));
+        HIPCHK(h, hipMemcpyAsync(h->d_gone.p, stage_gone, sizeof(int) * (gone.size() + (size_t)J), hipMemcpyHostToDevice, st));
+        d_joined = h->d_gone.p + gone.size();
+        if (!gone.empty()) {
+            int rc = q4_drop(h->d_gone.p, gone.size(), 1, by_list && h->d_member.p != nullptr, h->d_ring.p, h->ring_m);  // (:181-195)
+            if (rc) return rc;
+        }
     }
     h->n_members = M;
     lap("host scan + q4");
@@ -492,7 +545,7 @@ int rebuild_view(rapid_engine* h) {
         const int n_clear = gone_cleared ? 0 : removed;
         if (n_clear > 0 || J > 0)
             hipLaunchKernelGGL(rapid::member_patch_kernel, dim3(grid_for((long long)std::max(n_clear, J), 256)), dim3(256), 0, st, h->d_member.p,
-                               n_clear > 0 ? h->d_gone.p : (const int*)nullptr, n_clear, J > 0 ? h->d_joiners.p : (const int*)nullptr, J);
+                               n_clear > 0 ? h->d_gone.p : (const int*)nullptr, n_clear, J > 0 ? d_joined : (const int*)nullptr, J);
     } else {
         std::memcpy(stage_member, h->member.data(), (size_t)N);
         HIPCHK(h, hipMemcpyAsync(h->d_member.p, stage_member, (size_t)N, hipMemcpyHostToDevice, st));
@@ -507,6 +560,7 @@ int rebuild_view(rapid_engine* h) {
 
     // incremental while the change is small against the view (a decided cut); a view that is mostly new is sorted afresh
     const bool incremental = have_rings && M > 0 && (long long)J * 4 <= (long long)h->ring_m && (h->force_exact & 16384) == 0;
+    bool tables_patched = false;
     if (incremental && (removed > 0 || J > 0)) {
         // Old ring k minus the removed nodes, merged with the joiners in the order of their ring-k keys
         // (R/MembershipView.java:123-201: each TreeSet loses / gains the endpoint, nothing else moves): three launches over
@@ -522,20 +576,45 @@ int rebuild_view(rapid_engine* h) {
             HIPCHK(h, h->d_join_skeys.ensure(kj));
             HIPCHK(h, h->d_join_vals.ensure(kj));
             HIPCHK(h, h->d_join_nodes.ensure(kj));
-            hipLaunchKernelGGL(rapid::ring_gather_kernel, dim3(grid_for((long long)kj, 256)), dim3(256), 0, st, h->d_keys.p, h->d_joiners.p, J, N, K,
+            hipLaunchKernelGGL(rapid::ring_gather_kernel, dim3(grid_for((long long)kj, 256)), dim3(256), 0, st, h->d_keys.p, d_joined, J, N, K,
                                h->d_join_keys.p, h->d_join_vals.p);
-            int rc = sort_rings(h, h->d_join_keys.p, h->d_join_skeys.p, h->d_join_vals.p, h->d_join_nodes.p, J);
-            if (rc) return rc;
+            if (J <= rapid::kJoinSortMax) {  // a cut's joiners: runs sorted in LDS, then every pair finds its place among the other runs (the library's sort: 0.27 ms of fixed cost)
+                hipLaunchKernelGGL(rapid::ring_sort_runs_kernel, dim3((unsigned)(K * ((J + rapid::kJoinRun - 1) / rapid::kJoinRun))), dim3(rapid::kJoinRun / 2), 0, st,
+                                   h->d_join_keys.p, h->d_join_vals.p, J);
+                hipLaunchKernelGGL(rapid::ring_merge_runs_kernel, dim3(grid_for((long long)kj, 256)), dim3(256), 0, st, h->d_join_keys.p, h->d_join_vals.p, J, K,
+                                   h->d_join_skeys.p, h->d_join_nodes.p);
+            } else {
+                int rc = sort_rings(h, h->d_join_keys.p, h->d_join_skeys.p, h->d_join_vals.p, h->d_join_nodes.p, J);
+                if (rc) return rc;
+            }
         }
+        HIPCHK(h, h->d_chunk_base.ensure((size_t)K * ((size_t)n_chunks + 1)));
+        HIPCHK(h, h->d_chunk_lb.ensure((size_t)K * ((size_t)n_chunks + 1)));
+        hipLaunchKernelGGL(rapid::ring_chunk_prep_kernel, dim3((unsigned)K), dim3(1024), 0, st, h->d_ring.p, h->d_ring_skeys.p, m_old, n_chunks, h->d_chunk_kept.p,
+                           h->d_join_skeys.p, h->d_join_nodes.p, J, h->d_chunk_base.p, h->d_chunk_lb.p);
         hipLaunchKernelGGL(rapid::ring_scatter_kernel, dim3((unsigned)(K * n_chunks)), dim3(rapid::kRingChunk), 0, st, h->d_ring.p, h->d_ring_skeys.p,
-                           m_old, n_chunks, h->d_member.p, h->d_chunk_kept.p, h->d_join_skeys.p, h->d_join_nodes.p, J, h->d_sort_vals.p, h->d_sort_keys.p, M);
+                           m_old, n_chunks, h->d_member.p, h->d_chunk_base.p, h->d_chunk_lb.p, h->d_join_skeys.p, h->d_join_nodes.p, J, h->d_sort_vals.p,
+                           h->d_sort_keys.p, M);
         if (J > 0)
             hipLaunchKernelGGL(rapid::ring_join_kernel, dim3(grid_for((long long)K * J * 64, 256)), dim3(256), 0, st, h->d_ring.p, h->d_ring_skeys.p,
-                               m_old, n_chunks, h->d_member.p, h->d_chunk_kept.p, h->d_join_skeys.p, h->d_join_nodes.p, J, K, h->d_sort_vals.p,
+                               m_old, n_chunks, h->d_member.p, h->d_chunk_base.p, h->d_join_skeys.p, h->d_join_nodes.p, J, K, h->d_sort_vals.p,
                                h->d_sort_keys.p, M);
         std::swap(h->d_ring, h->d_sort_vals);
         std::swap(h->d_ring_skeys, h->d_sort_keys);
         lap("rings: compact + merge");
+        // The tables follow the rings where the cut touched them: the old neighbours of the nodes that left, the joiners and their new
+        // neighbours, on every ring (ring_patch_kernel), then the rows of the non-members (their expected observers).  Two full
+        // passes over the K x M positions with scattered reads were 0.38 ms of a view change at 10^6 members.
+        if (by_list && M >= 2 && m_old >= 2) {
+            hipLaunchKernelGGL(rapid::ring_patch_kernel, dim3(grid_for((long long)(removed + J) * K, 256)), dim3(256), 0, st, h->d_gone.p, removed, J, h->d_ring.p,
+                               h->d_ring_skeys.p, M, h->d_keys.p, h->d_member.p, N, K, h->d_obs.p, h->d_subj.p);
+            HIPCHK(h, h->d_nonmembers.ensure((size_t)N + 1));
+            HIPCHK(h, hipMemsetAsync(h->d_nonmembers.p, 0, 4, st));
+            hipLaunchKernelGGL(rapid::nonmember_list_kernel, dim3(grid_for((long long)N, 1024)), dim3(1024), 0, st, h->d_member.p, N, h->d_nonmembers.p);
+            hipLaunchKernelGGL(rapid::ring_nonmember_rows_kernel, dim3((unsigned)std::min<long long>(4096, std::max<long long>(1, grid_for((long long)K * (N - M), 256)))),
+                               dim3(256), 0, st, h->d_ring.p, h->d_ring_skeys.p, M, h->d_keys.p, h->d_nonmembers.p, N, K, h->d_obs.p, h->d_subj.p);
+            tables_patched = true;
+        }
     } else if (M && !(incremental && removed == 0 && J == 0)) {
         HIPCHK(h, h->d_ring_skeys.ensure(km));
         HIPCHK(h, h->d_ring.ensure(km));
@@ -549,21 +628,23 @@ int rebuild_view(rapid_engine* h) {
         int rc = sort_rings(h, h->d_sort_keys.p, h->d_ring_skeys.p, h->d_sort_vals.p, h->d_ring.p, M);
         if (rc) return rc;
     }
-    if (M)
-        hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * M, 256)), dim3(256), 0, st, h->d_ring.p,
-                           h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 0);
-    hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * N, 256)), dim3(256), 0, st, h->d_ring.p,
-                       h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 1);
+    if (!tables_patched) {  // (a build, a change that sorted the rings afresh: every row from the rings; d_pos is this pass's scratch)
+        if (M)
+            hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * M, 256)), dim3(256), 0, st, h->d_ring.p,
+                               h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 0);
+        hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * N, 256)), dim3(256), 0, st, h->d_ring.p,
+                           h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 1);
+    }
 
     lap("tables");
     if (have_rings && !joiners.empty()) {  // ringAdd drops the entries of the joiner's new ring predecessors (:143-152)
-        int rc = q4_drop(h->d_joiners.p, joiners.size(), 0, false);
+        int rc = q4_drop(d_joined, joiners.size(), 0, false, h->d_ring.p, M);
         if (rc) return rc;
     }
 
     // identifiersSeen, sorted, on the device: everything again after a build; a cut's few new NodeIds are merged in
     if (!h->ids_pending.empty()) {
-        std::sort(h->ids_pending.begin(), h->ids_pending.end());
+        if (!std::is_sorted(h->ids_pending.begin(), h->ids_pending.end())) rapid::sort_node_ids(h->ids_pending);  // (a cut's arrive sorted)
         const size_t nn = h->ids_pending.size(), ni = (size_t)h->n_ids_dev + nn;
         std::vector<long long> overflow;  // (more new NodeIds than the capacity in nodes -- a fresh build registers extra ids: not staged)
         long long* flat = stage_ids;
@@ -604,7 +685,7 @@ int rebuild_view(rapid_engine* h) {
         const unsigned int seq = ++h->mail_seq;
         hipLaunchKernelGGL(rapid::config_id_kernel, dim3((unsigned)G), dim3(T), (size_t)T * 16, st, h->d_ids_hi.p, h->d_ids_lo.p,
                            h->n_ids_dev, h->d_ring.p, M, h->d_hx_host0.p, h->d_hx_port0.p, d_cfg, h->d_cfg_partial.p, d_seq, seq);
-        if (G > 1) hipLaunchKernelGGL(rapid::config_id_final_kernel, dim3(1), dim3(64), 0, st, h->d_cfg_partial.p, G, d_cfg, d_seq, seq);
+        if (G > 1) hipLaunchKernelGGL(rapid::config_id_final_kernel, dim3(1), dim3(512), 0, st, h->d_cfg_partial.p, G, d_cfg, d_seq, seq);
         HIPCHK(h, hipGetLastError());
         if ((rc_mail = await_mail(h, 10, seq))) return rc_mail;
     }
@@ -918,11 +999,11 @@ int build_round_index(rapid_engine* h) {
                                h->d_hnew.p, h->d_entries.p, h->d_dict.p, reinterpret_cast<volatile int*>(h->d_mail), (int)++h->mail_seq);
             HIPCHK(h, hipGetLastError());
             if (int rc = await_mail(h, 11, h->mail_seq)) return rc;
-            int ans[2];
-            std::memcpy(ans, h->h_mail + 48, sizeof ans);
-            hashed = ans[0] == 1;
+            int ans = 0;
+            std::memcpy(&ans, h->h_mail + 48, sizeof ans);  // (word 12: 1 + the multiplier's index, 0: none fits)
+            hashed = ans >= 1;
             if (hashed) {
-                h->hash_mul = rapid::hash_multiplier(ans[1]);
+                h->hash_mul = rapid::hash_multiplier(ans - 1);
                 std::swap(h->d_node_of_slot, h->d_nos2);
                 std::swap(h->d_adj_off, h->d_smask2);
                 std::swap(h->d_adj, h->d_adj2);
@@ -1193,6 +1274,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_ids_hi2.release(); h->d_ids_lo2.release(); h->d_ids_new.release(); h->d_cfg_partial.release(); h->d_chunk_kept.release();
     h->d_bitmaps.release();
     h->d_vacc.release();
+    h->d_idacc.release(); h->d_chunk_base.release(); h->d_chunk_lb.release(); h->d_nonmembers.release();
     h->d_hoff.release(); h->d_hnew.release(); h->d_smask2.release(); h->d_hrem.release(); h->d_hmem.release(); h->d_adj2.release(); h->d_nos2.release();
     h->d_gone.release();
     h->d_edges.release(); h->d_edge_mask.release();
@@ -2497,6 +2579,14 @@ int rapid_apply_cut(rapid_engine* h, const int32_t* cut, int32_t n, int64_t* new
     // the registry's -- and put back if the cut does not validate or the device fails on the way (view_change_failed)
     for (int i = 0; i < n; ++i)
         if (cut[i] < 0 || cut[i] >= h->n_nodes) return fail(h, RAPID_EINVAL, "node index %d out of range", cut[i]);
+    const bool timing = env_knob("RAPID_TIME_VIEW") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "apply_cut %-32s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count());
+        tp = t;
+    };
     std::vector<std::pair<int64_t, int64_t>> added;
     for (int i = 0; i < n; ++i) {
         const int node = cut[i];
@@ -2511,8 +2601,10 @@ int rapid_apply_cut(rapid_engine* h, const int32_t* cut, int32_t n, int64_t* new
         for (int i = n - 1; i >= 0; --i) h->member[(size_t)cut[i]] ^= 1;
     };
     if (!added.empty()) {  // ringAdd :127-129: an identifier seen before -- in an earlier configuration, or earlier in this cut
-        std::sort(added.begin(), added.end());
+        lap("flags");
+        rapid::sort_node_ids(added);
         bool seen = std::adjacent_find(added.begin(), added.end()) != added.end();
+        lap("joiners' identifiers sorted");
         if (!seen && (rc = ids_seen_any(h, added, &seen))) {
             undo();
             return rc;
@@ -2522,6 +2614,7 @@ int rapid_apply_cut(rapid_engine* h, const int32_t* cut, int32_t n, int64_t* new
             return fail(h, RAPID_EUUID_SEEN, "the identifier of a joiner in the cut was already seen");
         }
     }
+    lap("identifiers seen before?");
     const int n_ids_before = h->n_ids_dev;
     const size_t pending_before = h->ids_pending.size();
     h->changed.insert(h->changed.end(), cut, cut + n);
@@ -2533,6 +2626,7 @@ int rapid_apply_cut(rapid_engine* h, const int32_t* cut, int32_t n, int64_t* new
         view_change_failed(h, n_ids_before);
         return rc;
     }
+    lap("rebuild_view");
     if (new_config_id) *new_config_id = h->config_id;
     return RAPID_OK;
 }

@@ -522,8 +522,8 @@ __global__ __launch_bounds__(1024) void index_build_block_kernel(unsigned int* g
 // subjects up in memory, or records resolved against entries[], agree with the renumbered tables).  The multiplier is the first
 // of kHashMultipliers under which no bucket holds more than kHashBucketCap keys (consecutive node indices -- joiners are registered
 // in a block -- spread evenly under a multiplicative hash; random ones fill buckets like balls into bins: 4,096 buckets, 15,000 keys,
-// a bucket of 17 once in 10^3 rounds); answer[0] = 1 and answer[1] = the multiplier's index, or answer[0] = 0: the host falls back
-// to the dictionary in memory.  mail: the host-mapped page, words 12 and 13, sequence word 11.
+// a bucket of 17 once in 10^3 rounds); the answer is 1 + the multiplier's index, or 0: the host falls back
+// to the dictionary in memory.  mail: the host-mapped page, word 12 (0: no multiplier fits; 1 + the multiplier's index), sequence word 11.
 constexpr int kHashTries = 4;
 __host__ __device__ inline unsigned int hash_multiplier(int i) {  // odd 24-bit constants (v_mul_u32_u24 territory)
     return i == 0 ? 0x9E3779u : i == 1 ? 0x85EBCBu : i == 2 ? 0xC2B2AFu : 0x27D4EBu;
@@ -614,12 +614,8 @@ __global__ __launch_bounds__(1024) void index_hash_kernel(const int* node_of_slo
         }
     }
     __syncthreads();
-    if (t < 2) {
-        mail[12 + t] = t == 0 ? (choice >= 0 ? 1 : 0) : choice;
-        __threadfence_system();
-    }
-    __syncthreads();
     if (t == 0) {
+        mail[12] = choice + 1;
         __threadfence_system();
         mail[11] = seq;
     }

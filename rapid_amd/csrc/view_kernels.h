@@ -176,8 +176,9 @@ __global__ void ring_tables_kernel(const int* ring, const unsigned long long* ri
 // A decided cut removes some members and admits some joiners; everybody else keeps its place in every ring.  The new ring k
 // is therefore the old ring k without the removed nodes, merged with the (few) joiners sorted by their ring-k key -- a
 // stable compaction plus a merge by binary search, spread over workgroups of kRingChunk old positions, instead of sorting
-// all K x M keys again.  Three launches:
+// all K x M keys again.  Four launches:
 //   ring_count_kernel    chunk_kept[k][c] = survivors among the old positions of chunk c of ring k
+//   ring_chunk_prep_kernel  their exclusive scan per ring + the joiners before every chunk's first position
 //   ring_scatter_kernel  survivor at old position p  ->  new position (survivors before p) + (joiners with a smaller key)
 //   ring_join_kernel     joiner j of ring k          ->  new position j + (survivors with a smaller key)
 constexpr int kRingChunk = 1024;
@@ -212,26 +213,58 @@ __global__ __launch_bounds__(kRingChunk) void ring_count_kernel(const int* ring_
     if (threadIdx.x == 0) chunk_kept[blockIdx.x] = s_total;
 }
 
-// survivors before old position p of ring k: the chunks before p's chunk (block-wide sum, every thread gets it) ...
-__device__ inline int ring_chunks_before(const int* chunk_kept_k, int c, int* s_acc) {
-    if (threadIdx.x == 0) *s_acc = 0;
+// What every chunk's workgroup needs before it can place anything, worked out ONCE per ring instead of by each of the ~10^4
+// workgroups for itself (every one summed the counts of the chunks before it and ran two thirteen-step binary searches through memory
+// ahead of its first store: ~15 us of dependent round trips per workgroup, 150 us for the scatter of 10^7 positions):
+//   chunk_base[k][c] = survivors in the chunks before c (an exclusive scan of chunk_kept), chunk_base[k][n_chunks] = all survivors;
+//   chunk_lb[k][c]   = joiners of ring k that sort before the FIRST old position of chunk c, chunk_lb[k][n_chunks] = n_join: the
+//                      joiners before any position of chunk c lie in [chunk_lb[c], chunk_lb[c + 1]] (both sides are sorted).
+// grid = K, block = 1024.
+__global__ __launch_bounds__(1024) void ring_chunk_prep_kernel(const int* ring_in, const unsigned long long* skeys_in, int m_old, int n_chunks,
+                                                               const int* chunk_kept, const unsigned long long* join_skeys, const int* join_nodes, int n_join,
+                                                               int* chunk_base, int* chunk_lb) {
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    const int k = (int)blockIdx.x, t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int* const kept = chunk_kept + (long long)k * n_chunks;
+    int* const base = chunk_base + (long long)k * (n_chunks + 1);
+    int* const lb = chunk_lb + (long long)k * (n_chunks + 1);
+    if (t == 0) s_carry = 0;
     __syncthreads();
-    int mine = 0;
-    for (int i = (int)threadIdx.x; i < c; i += (int)blockDim.x) mine += chunk_kept_k[i];
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
-    if ((threadIdx.x & 63u) == 0u && mine != 0) atomicAdd(s_acc, mine);
-    __syncthreads();
-    return *s_acc;
+    for (int c0 = 0; c0 < n_chunks; c0 += 1024) {
+        const int c = c0 + t;
+        const int v = c < n_chunks ? kept[c] : 0;
+        int incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        int before = s_carry;
+        for (int i = 0; i < wv; ++i) before += s_wave[i];
+        if (c < n_chunks) base[c] = before + incl - v;
+        __syncthreads();
+        if (t == 1023) s_carry = before + incl;
+        __syncthreads();
+    }
+    if (t == 0) {
+        base[n_chunks] = s_carry;
+        lb[n_chunks] = n_join;
+    }
+    for (int c = t; c < n_chunks; c += 1024) {
+        const long long p = (long long)k * m_old + (long long)c * kRingChunk;
+        lb[c] = n_join > 0 ? lower_bound_key_node(join_skeys + (long long)k * n_join, join_nodes + (long long)k * n_join, n_join, skeys_in[p], ring_in[p]) : 0;
+    }
 }
 
 __global__ __launch_bounds__(kRingChunk) void ring_scatter_kernel(const int* ring_in, const unsigned long long* skeys_in, int m_old, int n_chunks,
-                                                                  const unsigned char* member, const int* chunk_kept,
+                                                                  const unsigned char* member, const int* chunk_base, const int* chunk_lb,
                                                                   const unsigned long long* join_skeys, const int* join_nodes, int n_join,
                                                                   int* ring_out, unsigned long long* skeys_out, int m_new) {
-    __shared__ int s_acc;
     __shared__ int s_wave[kRingChunk / 64];
     const int k = (int)blockIdx.x / n_chunks, c = (int)blockIdx.x - k * n_chunks;
-    const int base = ring_chunks_before(chunk_kept + (long long)k * n_chunks, c, &s_acc);
+    const int base = chunk_base[(long long)k * (n_chunks + 1) + c];
     const int p = c * kRingChunk + (int)threadIdx.x;
     int node = 0;
     unsigned long long key = 0ull;
@@ -241,6 +274,13 @@ __global__ __launch_bounds__(kRingChunk) void ring_scatter_kernel(const int* rin
         key = skeys_in[(long long)k * m_old + p];
         keep = member[node] != 0;
     }
+    // The joiners that sort before a position are a monotone function of the position (both sides are sorted by (key, node)): the
+    // answers of this chunk's and the next chunk's first positions (ring_chunk_prep_kernel) bound everybody's, and with a few thousand
+    // joiners among a million members the two are usually equal -- a thirteen-step binary search through memory per survivor
+    // shrinks to a search inside that interval.
+    const unsigned long long* const jk = join_skeys + (long long)k * n_join;
+    const int* const jn = join_nodes + (long long)k * n_join;
+    const int lo0 = chunk_lb[(long long)k * (n_chunks + 1) + c], hi0 = chunk_lb[(long long)k * (n_chunks + 1) + c + 1];
     const unsigned long long b = __ballot(keep);
     const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
     if (lane == 0) s_wave[wv] = __popcll(b);
@@ -248,7 +288,8 @@ __global__ __launch_bounds__(kRingChunk) void ring_scatter_kernel(const int* rin
     int before = base + __popcll(b & ((1ull << lane) - 1ull));
     for (int i = 0; i < wv; ++i) before += s_wave[i];
     if (keep) {
-        const int at = before + (n_join > 0 ? lower_bound_key_node(join_skeys + (long long)k * n_join, join_nodes + (long long)k * n_join, n_join, key, node) : 0);
+        const int lb = lo0 + (hi0 > lo0 ? lower_bound_key_node(jk + lo0, jn + lo0, hi0 - lo0, key, node) : 0);
+        const int at = before + lb;
         if (at < m_new) {
             ring_out[(long long)k * m_new + at] = node;
             skeys_out[(long long)k * m_new + at] = key;
@@ -258,7 +299,7 @@ __global__ __launch_bounds__(kRingChunk) void ring_scatter_kernel(const int* rin
 
 // one wavefront per (ring, joiner): grid = ceil(K * n_join / waves per block)
 __global__ __launch_bounds__(256) void ring_join_kernel(const int* ring_in, const unsigned long long* skeys_in, int m_old, int n_chunks,
-                                                        const unsigned char* member, const int* chunk_kept, const unsigned long long* join_skeys,
+                                                        const unsigned char* member, const int* chunk_base, const unsigned long long* join_skeys,
                                                         const int* join_nodes, int n_join, int K, int* ring_out, unsigned long long* skeys_out,
                                                         int m_new) {
     const int lane = (int)(threadIdx.x & 63u);
@@ -269,13 +310,172 @@ __global__ __launch_bounds__(256) void ring_join_kernel(const int* ring_in, cons
     const int* rk = ring_in + (long long)k * m_old;
     const int p = lower_bound_key_node(skeys_in + (long long)k * m_old, rk, m_old, key, join_nodes[w]);  // old positions that sort before the joiner: [0, p)
     const int c = p / kRingChunk;
+    // the survivors among the old positions of the joiner's own chunk before p: up to sixteen steps of 64 positions, every step's two
+    // dependent reads (the node at the position, its member flag) issued for all steps together -- two round trips, not thirty-two
     int kept = 0;
-    for (int i = lane; i < c; i += 64) kept += chunk_kept[(long long)k * n_chunks + i];
-    for (int i = c * kRingChunk + lane; i < p; i += 64) kept += member[rk[i]] != 0 ? 1 : 0;
+    int nodes_[kRingChunk / 64];
+#pragma unroll
+    for (int s_ = 0; s_ < kRingChunk / 64; ++s_) {
+        const int i = c * kRingChunk + s_ * 64 + lane;
+        nodes_[s_] = i < p ? rk[i] : -1;
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < kRingChunk / 64; ++s_) kept += (nodes_[s_] >= 0 && member[nodes_[s_]] != 0) ? 1 : 0;
     for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
+    kept += chunk_base[(long long)k * (n_chunks + 1) + min(c, n_chunks)];  // (the survivors of the chunks before the joiner's)
     if (lane == 0 && j + kept < m_new) {
         ring_out[(long long)k * m_new + j + kept] = join_nodes[w];
         skeys_out[(long long)k * m_new + j + kept] = key;
+    }
+}
+
+// The joiners of a cut, ring by ring, sorted by (sortable key, node), in two launches that use the whole GPU for a few thousand pairs:
+//   ring_sort_runs_kernel   every run of kJoinRun consecutive pairs of a ring is sorted in place in LDS (a bitonic network over the run);
+//   ring_merge_runs_kernel  every pair's final place = its index inside its run + the pairs of every OTHER run of its ring that sort
+//                           before it (a binary search per run; pairs are distinct -- a node joins once -- so the places are too).
+// (Measured at 10^6 members, 5,000 joiners x 10 rings: the library's segmented radix sort 0.27 ms of fixed launches and scans; one
+// workgroup per ring running a bitonic network over 8,192 padded pairs 109 us -- ten CUs busy, 246 idle; every pair counting its
+// predecessors among all of its ring's pairs 361 us -- J^2 comparisons are too many even spread over every CU;
+// profiles/r05_apply_1m_kernels.txt.)  n <= kJoinSortMax; beyond: the library sort.  keys / nodes: [K][n] as ring_gather_kernel
+// leaves them, in any order.
+constexpr int kJoinSortMax = 8192;
+constexpr int kJoinRun = 1024;
+__global__ __launch_bounds__(kJoinRun / 2) void ring_sort_runs_kernel(unsigned long long* keys, int* nodes, int n) {
+    __shared__ unsigned long long sk[kJoinRun];
+    __shared__ int sn[kJoinRun];
+    const int runs = (n + kJoinRun - 1) / kJoinRun;
+    const int k = (int)blockIdx.x / runs, r0 = ((int)blockIdx.x - k * runs) * kJoinRun;
+    const int cnt = min(kJoinRun, n - r0), T = (int)blockDim.x, t = (int)threadIdx.x;
+    unsigned long long* const gk = keys + (long long)k * n + r0;
+    int* const gn = nodes + (long long)k * n + r0;
+    for (int i = t; i < kJoinRun; i += T) {
+        sk[i] = i < cnt ? gk[i] : ~0ull;  // (padding sorts last: behind every real pair, whose node index is below INT_MAX)
+        sn[i] = i < cnt ? gn[i] : 0x7FFFFFFF;
+    }
+    __syncthreads();
+    for (int size = 2; size <= kJoinRun; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = t; i < kJoinRun / 2; i += T) {
+                const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;  // the i-th pair of positions at this stride
+                const bool up = (lo & size) == 0;
+                const unsigned long long ka = sk[lo], kb = sk[hi];
+                const int na = sn[lo], nb = sn[hi];
+                const bool a_after_b = ka > kb || (ka == kb && na > nb);
+                if (a_after_b == up) {
+                    sk[lo] = kb;
+                    sk[hi] = ka;
+                    sn[lo] = nb;
+                    sn[hi] = na;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = t; i < cnt; i += T) {
+        gk[i] = sk[i];
+        gn[i] = sn[i];
+    }
+}
+__global__ void ring_merge_runs_kernel(const unsigned long long* keys, const int* nodes, int n, int K, unsigned long long* keys_out, int* nodes_out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)K * n) return;
+    const int k = (int)(t / n), i = (int)(t - (long long)k * n);
+    const unsigned long long* const rk = keys + (long long)k * n;
+    const int* const rn = nodes + (long long)k * n;
+    const unsigned long long key = rk[i];
+    const int node = rn[i];
+    const int mine = i / kJoinRun;
+    int place = i - mine * kJoinRun;
+    for (int r0 = 0, r = 0; r0 < n; r0 += kJoinRun, ++r)
+        if (r != mine) place += lower_bound_key_node(rk + r0, rn + r0, min(kJoinRun, n - r0), key, node);
+    keys_out[(long long)k * n + place] = key;
+    nodes_out[(long long)k * n + place] = node;
+}
+
+// ---- the observer / subject tables after a cut, PATCHED instead of rebuilt ---------------------------------------------------
+// ringAdd / ringDelete change the successor and the predecessor of the changed node's ring neighbours and nothing else
+// (R/MembershipView.java:123-201).  So only these rows change: on every ring, the old predecessor and the old successor of a node
+// that left (read off the OLD tables: a row of a node that left is not written here), the joiner's own row and the rows of its
+// new neighbours.  Every one of them is recomputed from the NEW ring -- the node's position found by a binary search over the
+// ring's sorted (key, node) pairs -- so that chains of changes (the neighbour left too, two joiners side by side) need no case
+// analysis: whoever writes a row writes what the final ring says.  changed[0 .. n_gone) = the nodes that left, changed[n_gone ..
+// n_gone + n_join) = the joiners; member = the NEW flags; ring / skeys = the NEW rings [K][m]; m >= 2.  One thread per (changed
+// node, ring): 150,000 threads instead of two passes over 10^7 table entries with scattered reads (0.38 ms at 10^6 members).
+__device__ inline void ring_patch_row(const int* rk, const unsigned long long* sk, int m, const long long* keys, int n_nodes, int k, int K, int node,
+                                      int* obs, int* subj) {
+    const unsigned long long key = (unsigned long long)keys[(long long)k * n_nodes + node] ^ 0x8000000000000000ull;
+    const int q = lower_bound_key_node(sk, rk, m, key, node);  // the node's own position: (key, node) is in the ring
+    obs[(long long)node * K + k] = rk[q + 1 == m ? 0 : q + 1];
+    subj[(long long)node * K + k] = rk[q == 0 ? m - 1 : q - 1];
+}
+__global__ void ring_patch_kernel(const int* changed, int n_gone, int n_join, const int* ring, const unsigned long long* ring_skeys, int m,
+                                  const long long* keys, const unsigned char* member, int n_nodes, int K, int* obs, int* subj) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)(n_gone + n_join) * K) return;
+    const int i = (int)(t / K), k = (int)(t - (long long)i * K);
+    const int node = changed[i];
+    const int* const rk = ring + (long long)k * m;
+    const unsigned long long* const sk = ring_skeys + (long long)k * m;
+    if (i < n_gone) {  // (its row still holds the old view's neighbours)
+        const int pred = subj[(long long)node * K + k], succ = obs[(long long)node * K + k];
+        if (pred >= 0 && pred < n_nodes && member[pred] != 0) ring_patch_row(rk, sk, m, keys, n_nodes, k, K, pred, obs, subj);
+        if (succ >= 0 && succ < n_nodes && member[succ] != 0) ring_patch_row(rk, sk, m, keys, n_nodes, k, K, succ, obs, subj);
+    } else {
+        const unsigned long long key = (unsigned long long)keys[(long long)k * n_nodes + node] ^ 0x8000000000000000ull;
+        const int q = lower_bound_key_node(sk, rk, m, key, node);
+        const int succ = rk[q + 1 == m ? 0 : q + 1], pred = rk[q == 0 ? m - 1 : q - 1];
+        obs[(long long)node * K + k] = succ;
+        subj[(long long)node * K + k] = pred;
+        obs[(long long)pred * K + k] = node;   // (what the final ring says about them, whoever else writes these rows)
+        subj[(long long)succ * K + k] = node;
+    }
+}
+// ... and the rows of the NON-members -- their expected observers, R/MembershipView.java:292-322: the ring predecessors of their
+// keys; subjects: none -- after the members' rows are final (a node that left reads its old row in ring_patch_kernel).  Every
+// registered non-member is recomputed: which of them have a changed neighbourhood is not worth finding out.
+// Two launches: the registered non-members gathered into a list (one pass over the member flags: a wave's ballot, one atomic per
+// wave; list[0] = their number, in no particular order), then one thread per (non-member, ring) in a grid-stride loop over that
+// number -- the host never learns it.  (One thread per (node, ring) of the whole registry, 10^7 of them at 10^6 nodes to find 30,000
+// non-members, was 77 us.)
+// (ONE atomic per workgroup of 1,024 nodes: with one per wave, the ~7,000 waves that hold one of a cut's 10,000 leavers queued up
+// behind each other on list[0] for 126 us)
+__global__ __launch_bounds__(1024) void nonmember_list_kernel(const unsigned char* member, int n_nodes, int* list) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const int n = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const bool is = n < n_nodes && member[n] == 0;
+    const unsigned long long b = __ballot(is);
+    const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6), nw = (int)(blockDim.x >> 6);
+    if (lane == 0) s_wave[wv] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int i = 0; i < nw; ++i) total += s_wave[i];
+        s_base = total > 0 ? atomicAdd(&list[0], total) : 0;
+    }
+    __syncthreads();
+    int before = s_base;
+    for (int i = 0; i < wv; ++i) before += s_wave[i];
+    if (is) list[1 + before + __popcll(b & ((1ull << lane) - 1ull))] = n;
+}
+__global__ void ring_nonmember_rows_kernel(const int* ring, const unsigned long long* ring_skeys, int m, const long long* keys, const int* list, int n_nodes,
+                                           int K, int* obs, int* subj) {
+    const long long total = (long long)list[0] * K;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int n = list[1 + (int)(t / K)], k = (int)(t % K);
+    int o = -1;
+    if (m > 0) {
+        const unsigned long long key = (unsigned long long)keys[(long long)k * n_nodes + n] ^ 0x8000000000000000ull;
+        const unsigned long long* sk = ring_skeys + (long long)k * m;
+        int lo = 0, hi = m;  // lower_bound by key alone, as ring_tables_kernel does for a non-member
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sk[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        o = ring[(long long)k * m + (lo == 0 ? m - 1 : lo - 1)];
+    }
+    obs[(long long)n * K + k] = o;
+    subj[(long long)n * K + k] = -1;
     }
 }
 
@@ -294,6 +494,38 @@ __global__ void ids_contains_kernel(const long long* old_hi, const long long* ol
         if (id_less(old_hi[mid], old_lo[mid], h, l)) lo = mid + 1; else hi = mid;
     }
     if (lo < n_old && old_hi[lo] == h && old_lo[lo] == l) atomicOr(flag, 1u);
+}
+
+// The same question for the few thousand NodeIds of one cut, answered into the host-mapped page the host polls (ONE word: the call's
+// sequence number doubled, + 1 if any of them was seen before): one workgroup; no copy, no stream synchronisation on a view change's path.
+// One thread per NodeId (twenty-one dependent steps through two million sorted ids each: spread over the GPU they take what one of
+// them takes; one workgroup walking all 5,000 took 96 us); acc[0] collects the answer, acc[1] counts finished workgroups, and the
+// last one publishes and leaves both words zero for the next call.
+__global__ __launch_bounds__(256) void ids_contains_publish_kernel(const long long* old_hi, const long long* old_lo, int n_old, const long long* new_hi,
+                                                                   const long long* new_lo, int n_new, unsigned int* acc, volatile unsigned int* mail, int word,
+                                                                   unsigned int seq) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    bool any = false;
+    if (t < n_new) {
+        const long long h = new_hi[t], l = new_lo[t];
+        int lo = 0, hi = n_old;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (id_less(old_hi[mid], old_lo[mid], h, l)) lo = mid + 1; else hi = mid;
+        }
+        any = lo < n_old && old_hi[lo] == h && old_lo[lo] == l;
+    }
+    if (__syncthreads_or(any ? 1 : 0) != 0 && threadIdx.x == 0) atomicOr(&acc[0], 1u);
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&acc[1], 1u) == gridDim.x - 1u) {
+            __threadfence();
+            const unsigned int a = atomicOr(&acc[0], 0u);
+            acc[0] = 0u;
+            acc[1] = 0u;
+            mail[word] = 2u * seq + (a != 0u ? 1u : 0u);
+        }
+    }
 }
 
 __global__ void ids_merge_kernel(const long long* old_hi, const long long* old_lo, int n_old, const long long* new_hi, const long long* new_lo,
@@ -331,28 +563,30 @@ __global__ void gather_rows_kernel(const int* table, const int* nodes, int n, in
 
 // preds[i][k] = the ring-k predecessor of nodes[i] WITHOUT wrap-around (TreeSet.lower: -1 for the ring minimum) -- the node
 // whose memoised observers ringAdd / ringDelete of nodes[i] drop (R/MembershipView.java:143-152, 181-195)
-__global__ void gather_lower_kernel(const int* subj, const int* pos, const int* nodes, int n, int n_nodes, int K, int* preds) {
+__global__ void gather_lower_kernel(const int* subj, const int* ring, int n_members, const int* nodes, int n, int n_nodes, int K, int* preds) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)n * K) return;
     const int i = (int)(t / K), k = (int)(t - (long long)i * K);
     const int node = nodes[i];
-    preds[t] = pos[(long long)k * n_nodes + node] > 0 ? subj[(long long)node * K + k] : -1;
+    preds[t] = (n_members > 0 && ring[(long long)k * n_members] != node) ? subj[(long long)node * K + k] : -1;
 }
 
 // The memoised observers of the reference (Q4; index_kernels.h reads them for hot members): valid[node] = 0 for what
 // ringAdd / ringDelete of nodes[i] drop -- the node's ring predecessors WITHOUT wrap-around (TreeSet.lower) and, self != 0, the
-// node's own entry (R/MembershipView.java:143-152, 181-195).  subj / pos: the tables of the view the predecessors are taken from.
+// node's own entry (R/MembershipView.java:143-152, 181-195).  subj / ring ([K][n_members]): the tables of the view the predecessors
+// are taken from -- "has a predecessor without wrap-around" = "is not the ring's first element" (the per-node ring positions this
+// used to read are not kept any more: a view change patches the tables instead of walking every position).
 // member_clear != nullptr: nodes[] are the nodes that leave in this view change, and their member flags on the device are cleared
 // on the way (what member_patch_kernel would do in a launch of its own).
-__global__ void q4_invalidate_kernel(const int* subj, const int* pos, const int* nodes, int n, int n_nodes, int K, unsigned char* valid, int self,
-                                     unsigned char* member_clear = nullptr) {
+__global__ void q4_invalidate_kernel(const int* subj, const int* ring, int n_members, const int* nodes, int n, int n_nodes, int K, unsigned char* valid,
+                                     int self, unsigned char* member_clear = nullptr) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)n * K) return;
     const int i = (int)(t / K), k = (int)(t - (long long)i * K);
     const int node = nodes[i];
     if (member_clear != nullptr && k == 0) member_clear[node] = 0;
     if (self != 0 && k == 0) valid[node] = 0;
-    if (pos[(long long)k * n_nodes + node] > 0) {
+    if (n_members > 0 && ring[(long long)k * n_members] != node) {
         const int pred = subj[(long long)node * K + k];
         if (pred >= 0 && pred < n_nodes) valid[pred] = 0;
     }
@@ -448,16 +682,37 @@ __global__ void config_id_kernel(const long long* ids_hi, const long long* ids_l
     }
 }
 
-// the workgroups' (v, m) pairs, in order, applied to h = 1 (one wavefront; a few hundred pairs)
-__global__ void config_id_final_kernel(const unsigned long long* partial, int n_pairs, long long* out, volatile unsigned int* seq_out = nullptr,
-                                       unsigned int seq = 0u) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    unsigned long long h = 1ull;
-    for (int i = 0; i < n_pairs; ++i) h = h * partial[2 * i + 1] + partial[2 * i];
-    out[0] = (long long)h;
-    if (seq_out != nullptr) {  // (see config_id_kernel)
-        __threadfence_system();
-        *seq_out = seq;
+// the workgroups' (v, m) pairs, in order, applied to h = 1: one workgroup of 512 threads, the same ordered tree as inside
+// config_id_kernel (one thread folding 512 pairs out of memory one after the other took 53 us, a third of the configuration id's time)
+__global__ __launch_bounds__(512) void config_id_final_kernel(const unsigned long long* partial, int n_pairs, long long* out, volatile unsigned int* seq_out = nullptr,
+                                                              unsigned int seq = 0u) {
+    __shared__ unsigned long long sv[512], sm[512];
+    const int t = (int)threadIdx.x, T = (int)blockDim.x;
+    // thread t folds a contiguous run of pairs (n_pairs <= 512 in the engine: one each), then the tree
+    const int per = (n_pairs + T - 1) / T, beg = min(n_pairs, t * per), end = min(n_pairs, beg + per);
+    unsigned long long v = 0ull, m = 1ull;
+    for (int i = beg; i < end; ++i) {
+        v = v * partial[2 * i + 1] + partial[2 * i];
+        m *= partial[2 * i + 1];
+    }
+    sv[t] = v;
+    sm[t] = m;
+    __syncthreads();
+    for (int stride = 1; stride < T; stride <<= 1) {
+        const int i = 2 * stride * t;
+        if (i + stride < T) {
+            const unsigned long long lv = sv[i], lm = sm[i], rv = sv[i + stride], rm = sm[i + stride];
+            sv[i] = lv * rm + rv;
+            sm[i] = lm * rm;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        out[0] = (long long)(1ull * sm[0] + sv[0]);
+        if (seq_out != nullptr) {  // (see config_id_kernel)
+            __threadfence_system();
+            *seq_out = seq;
+        }
     }
 }
 

@@ -29,6 +29,19 @@ for section in "$@"; do
       RAPID_AB_ONLY=${C5_ONLY:-default,pnolook,pnoor,pstream} timeout 600 python scripts/c5_probe.py 1000000 1024 5 2> gpurun_out/c5_probe.err | tee gpurun_out/c5_probe.txt; tail -2 gpurun_out/c5_probe.err ;;
     c5phase)      # event counters and phase timers of the C5 tally (needs rapid_amd/librapid_mi355x_timers.so)
       timeout 600 python scripts/c5_phase.py 1000000 1024 2> gpurun_out/c5_phase.err | tee gpurun_out/c5_phase.txt; tail -2 gpurun_out/c5_phase.err ;;
+    apply1m)      # where a view change at 10^6 members spends its time (phases with a stream synchronisation each), then untimed-phase totals
+      RAPID_TIME_VIEW=1 timeout 300 python scripts/time_apply.py 1000000 > gpurun_out/time_apply_1m_phases.txt 2>&1; tail -14 gpurun_out/time_apply_1m_phases.txt
+      timeout 300 python scripts/time_apply.py 1000000 2>&1 | tee gpurun_out/time_apply_1m.txt | tail -4 ;;
+    apply1m_kstats)  # the kernels of a view change at 10^6 members (rocprofv3 kernel statistics of scripts/time_apply.py)
+      cd /tmp; rm -rf "$R/gpurun_out/prof_apply"
+      timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_apply" -o apply -- python "$R/scripts/time_apply.py" 1000000 > "$R/gpurun_out/apply_traced.txt" 2> "$R/gpurun_out/prof_apply.log"
+      cd "$R"; python - <<'PY'
+import csv, glob
+f = glob.glob("gpurun_out/prof_apply/**/*kernel_stats.csv", recursive=True)
+for row in list(csv.DictReader(open(f[0])))[:22]:
+    print("%-60s calls %5s avg %10.1f us" % (row["Name"][:60], row["Calls"], float(row["AverageNs"]) / 1e3))
+PY
+      ;;
     ab_c3b)       # the C3b tally kernel in every prepared build, interleaved
       RAPID_AB_ONLY=${AB_ONLY:-default,lanedummy,skipdummy} timeout 600 python scripts/ab_variants.py C3b 3 20 2> gpurun_out/ab_c3b.err | tee gpurun_out/ab_c3b.txt | tail -12; tail -2 gpurun_out/ab_c3b.err ;;
     kstats)       # rocprofv3 kernel statistics of the bench command (driver form)

@@ -417,8 +417,8 @@ extern "C" int emu_hash_build(const int* node_of_slot, const unsigned short* sma
                                  entries, dict, mail, 777);
     }, seed);
     if (mail[11] != 777) return -2;
-    answer[0] = mail[12];
-    answer[1] = mail[13];
+    answer[0] = mail[12] >= 1 ? 1 : 0;
+    answer[1] = mail[12] - 1;
     return 0;
 }
 
@@ -509,19 +509,20 @@ int emu_vote_merge(const unsigned long long* gathered, int n_ranks, int seg_word
 // sign-flipped keys); here std::stable_sort plays that part.
 // ---------------------------------------------------------------------------------------------------------------
 #include "view_kernels.h"
+#include "node_id_sort.h"
 
 #include <algorithm>
 #include <numeric>
 
 // The two small kernels of a view change that touch per-node flags (view_kernels.h): q4_invalidate_kernel -- the memo entries that
 // ringAdd / ringDelete of nodes[] drop, with the member flags of nodes that leave cleared on the way -- and member_patch_kernel.
-extern "C" int emu_view_flags(const int* subj, const int* pos, const int* nodes, int n, int n_nodes, int K, unsigned char* valid, int self,
+extern "C" int emu_view_flags(const int* subj, const int* ring, int n_members, const int* nodes, int n, int n_nodes, int K, unsigned char* valid, int self,
                               unsigned char* member_clear, unsigned char* member, const int* gone, int n_gone, const int* joined, int n_joined,
                               unsigned long long seed) {
     if (n > 0) {
         const unsigned grid = (unsigned)(((long long)n * K + 255) / 256);
         for (unsigned b = 0; b < grid; ++b)
-            emu::run_block(b, grid, 256u, [&] { rapid::q4_invalidate_kernel(subj, pos, nodes, n, n_nodes, K, valid, self, member_clear); }, seed + b);
+            emu::run_block(b, grid, 256u, [&] { rapid::q4_invalidate_kernel(subj, ring, n_members, nodes, n, n_nodes, K, valid, self, member_clear); }, seed + b);
     }
     const int m = n_gone > n_joined ? n_gone : n_joined;
     if (m > 0) {
@@ -536,7 +537,7 @@ extern "C" int emu_view_build(const unsigned char* blob, const int* host_off, co
                               int n_members, const long long* ids_hi_sorted, const long long* ids_lo_sorted, int n_ids,
                               const unsigned char* keep /* nullable: members kept by a removal-only change */, long long* keys_out,
                               int* ring_out, int* obs_out, int* subj_out, long long* cfg_out, int* ring2_out, int* n_members2_out,
-                              unsigned long long seed) {
+                              unsigned long long seed, int* obs2_out, int* subj2_out) {
     const size_t KN = (size_t)K * (size_t)n_nodes, KM = (size_t)K * (size_t)std::max(n_members, 1);
     std::vector<unsigned long long> hx_host(n_nodes + 1), hx_port(n_nodes + 1), skeys(KM), sk2(KM);
     std::vector<int> vals(KM), pos(KN + 1, -1);
@@ -574,7 +575,7 @@ extern "C" int emu_view_build(const unsigned char* blob, const int* host_off, co
             emu::run_block(b, 3u, 256u, [&] {
                 rapid::config_id_kernel(ids_hi_sorted, ids_lo_sorted, n_ids, ring_out, n_members, hx_host.data(), hx_port.data(), &cfg3, partial.data());
             }, seed + 4100 + b);
-        emu::run_block(0u, 1u, 64u, [&] { rapid::config_id_final_kernel(partial.data(), 3, &cfg3); }, seed + 4200);
+        emu::run_block(0u, 1u, 512u, [&] { rapid::config_id_final_kernel(partial.data(), 3, &cfg3); }, seed + 4200);
         if (cfg3 != cfg_out[0]) return -11;
     }
     if (keep != nullptr) {
@@ -598,30 +599,57 @@ extern "C" int emu_view_build(const unsigned char* blob, const int* host_off, co
                 rapid::ring_count_kernel(ring_out, n_members, n_chunks, keep, chunk_kept.data());
             }, seed + 5000 + (unsigned)b);
         if (J > 0) {
-            launch((long long)K * J, 256u, [&] { rapid::ring_gather_kernel(keys_out, joiners.data(), J, n_nodes, K, jkeys.data(), jvals.data()); }, seed + 5500);
-            for (int k = 0; k < K; ++k) {
-                std::vector<int> order(J);
-                std::iota(order.begin(), order.end(), 0);
-                const unsigned long long* sk = jkeys.data() + (size_t)k * J;
-                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sk[a] < sk[b]; });
-                for (int i = 0; i < J; ++i) {
-                    jnodes[(size_t)k * J + i] = jvals[(size_t)k * J + order[i]];
-                    jskeys[(size_t)k * J + i] = sk[order[i]];
-                }
-            }
+            // the joiners in DESCENDING node order on purpose: the sort network orders by (key, node) whatever it is handed
+            std::vector<int> jrev(joiners.rbegin(), joiners.rend());
+            launch((long long)K * J, 256u, [&] { rapid::ring_gather_kernel(keys_out, jrev.data(), J, n_nodes, K, jkeys.data(), jvals.data()); }, seed + 5500);
+            const unsigned gs = (unsigned)(K * ((J + rapid::kJoinRun - 1) / rapid::kJoinRun));
+            for (unsigned b = 0; b < gs; ++b)
+                emu::run_block(b, gs, (unsigned)rapid::kJoinRun / 2u, [&] { rapid::ring_sort_runs_kernel(jkeys.data(), jvals.data(), J); }, seed + 5600 + b);
+            launch((long long)K * J, 256u, [&] { rapid::ring_merge_runs_kernel(jkeys.data(), jvals.data(), J, K, jskeys.data(), jnodes.data()); }, seed + 5700);
+            for (int k = 0; k < K; ++k)
+                for (int i = 1; i < J; ++i)
+                    if (jskeys[(size_t)k * J + i - 1] > jskeys[(size_t)k * J + i]) return -13;
         }
+        std::vector<int> chunk_base((size_t)K * (n_chunks + 1), -7), chunk_lb((size_t)K * (n_chunks + 1), -7);
+        for (int k = 0; k < K; ++k)
+            emu::run_block((unsigned)k, (unsigned)K, 1024u, [&] {
+                rapid::ring_chunk_prep_kernel(ring_out, sk2.data(), n_members, n_chunks, chunk_kept.data(), jskeys.data(), jnodes.data(), J, chunk_base.data(), chunk_lb.data());
+            }, seed + 5900 + (unsigned)k);
         for (int b = 0; b < K * n_chunks; ++b)
             emu::run_block((unsigned)b, (unsigned)(K * n_chunks), (unsigned)rapid::kRingChunk, [&] {
-                rapid::ring_scatter_kernel(ring_out, sk2.data(), n_members, n_chunks, keep, chunk_kept.data(), jskeys.data(), jnodes.data(), J, ring2_out, sk3.data(), m_new);
+                rapid::ring_scatter_kernel(ring_out, sk2.data(), n_members, n_chunks, keep, chunk_base.data(), chunk_lb.data(), jskeys.data(), jnodes.data(), J, ring2_out,
+                                           sk3.data(), m_new);
             }, seed + 6000 + (unsigned)b);
         if (J > 0)
             launch((long long)K * J * 64, 256u, [&] {
-                rapid::ring_join_kernel(ring_out, sk2.data(), n_members, n_chunks, keep, chunk_kept.data(), jskeys.data(), jnodes.data(), J, K, ring2_out,
+                rapid::ring_join_kernel(ring_out, sk2.data(), n_members, n_chunks, keep, chunk_base.data(), jskeys.data(), jnodes.data(), J, K, ring2_out,
                                         sk3.data(), m_new);
             }, seed + 7000);
         for (int k = 0; k < K; ++k)  // the new rings are sorted by key
             for (int i = 1; i < m_new; ++i)
                 if (sk3[(size_t)k * m_new + i - 1] >= sk3[(size_t)k * m_new + i]) return -12;
+        // the tables of the new view, PATCHED (ring_patch_kernel + ring_nonmember_rows_kernel) from the old view's: obs_out / subj_out
+        // are updated in place; obs2_out / subj2_out (nullable) receive them
+        if (obs2_out != nullptr && m_new >= 2 && n_members >= 2) {
+            std::vector<int> changed;
+            for (int n = 0; n < n_nodes; ++n)
+                if (was[n] && !keep[n]) changed.push_back(n);
+            const int n_gone = (int)changed.size();
+            for (int j : joiners) changed.push_back(j);
+            std::vector<int> o2(obs_out, obs_out + (size_t)n_nodes * K), s2(subj_out, subj_out + (size_t)n_nodes * K);
+            if (!changed.empty())
+                launch((long long)changed.size() * K, 256u, [&] {
+                    rapid::ring_patch_kernel(changed.data(), n_gone, J, ring2_out, sk3.data(), m_new, keys_out, keep, n_nodes, K, o2.data(), s2.data());
+                }, seed + 8000);
+            std::vector<int> nonmembers((size_t)n_nodes + 1, 0);
+            launch((long long)n_nodes, 1024u, [&] { rapid::nonmember_list_kernel(keep, n_nodes, nonmembers.data()); }, seed + 8500);
+            for (unsigned b = 0; b < 3u; ++b)  // (a grid smaller than the work: the kernel strides)
+                emu::run_block(b, 3u, 64u, [&] {
+                    rapid::ring_nonmember_rows_kernel(ring2_out, sk3.data(), m_new, keys_out, nonmembers.data(), n_nodes, K, o2.data(), s2.data());
+                }, seed + 9000 + b);
+            std::copy(o2.begin(), o2.end(), obs2_out);
+            std::copy(s2.begin(), s2.end(), subj2_out);
+        }
     }
     return 0;
 }
@@ -638,16 +666,43 @@ extern "C" int emu_ring_merge(const int* ring_in, const unsigned long long* skey
         emu::run_block((unsigned)b, (unsigned)n_chunks, (unsigned)rapid::kRingChunk, [&] {
             rapid::ring_count_kernel(ring_in, m_old, n_chunks, member, chunk_kept.data());
         }, seed + (unsigned)b);
+    std::vector<int> chunk_base((size_t)n_chunks + 1, -7), chunk_lb((size_t)n_chunks + 1, -7);
+    emu::run_block(0u, 1u, 1024u, [&] {
+        rapid::ring_chunk_prep_kernel(ring_in, skeys_in, m_old, n_chunks, chunk_kept.data(), join_skeys, join_nodes, n_join, chunk_base.data(), chunk_lb.data());
+    }, seed + 50);
     for (int b = 0; b < n_chunks; ++b)
         emu::run_block((unsigned)b, (unsigned)n_chunks, (unsigned)rapid::kRingChunk, [&] {
-            rapid::ring_scatter_kernel(ring_in, skeys_in, m_old, n_chunks, member, chunk_kept.data(), join_skeys, join_nodes, n_join, ring_out, skeys_out, m_new);
+            rapid::ring_scatter_kernel(ring_in, skeys_in, m_old, n_chunks, member, chunk_base.data(), chunk_lb.data(), join_skeys, join_nodes, n_join, ring_out, skeys_out, m_new);
         }, seed + 100 + (unsigned)b);
     if (n_join > 0) {
         const unsigned grid = (unsigned)(((long long)n_join * 64 + 255) / 256);
         for (unsigned b = 0; b < grid; ++b)
             emu::run_block(b, grid, 256u, [&] {
-                rapid::ring_join_kernel(ring_in, skeys_in, m_old, n_chunks, member, chunk_kept.data(), join_skeys, join_nodes, n_join, 1, ring_out, skeys_out, m_new);
+                rapid::ring_join_kernel(ring_in, skeys_in, m_old, n_chunks, member, chunk_base.data(), join_skeys, join_nodes, n_join, 1, ring_out, skeys_out, m_new);
             }, seed + 200 + b);
+    }
+    return 0;
+}
+
+// A cut's joiners sorted per ring (ring_sort_runs_kernel + ring_merge_runs_kernel): [K][n] pairs in any order -> sorted by (key, node)
+extern "C" int emu_join_sort(unsigned long long* keys, int* nodes, int n, int K, unsigned long long* keys_out, int* nodes_out, unsigned long long seed) {
+    const unsigned gs = (unsigned)(K * ((n + rapid::kJoinRun - 1) / rapid::kJoinRun));
+    for (unsigned b = 0; b < gs; ++b)
+        emu::run_block(b, gs, (unsigned)rapid::kJoinRun / 2u, [&] { rapid::ring_sort_runs_kernel(keys, nodes, n); }, seed + b);
+    const unsigned gm = (unsigned)(((long long)K * n + 255) / 256);
+    for (unsigned b = 0; b < gm; ++b)
+        emu::run_block(b, gm, 256u, [&] { rapid::ring_merge_runs_kernel(keys, nodes, n, K, keys_out, nodes_out); }, seed + 1000 + b);
+    return 0;
+}
+
+// a cut's joiner NodeIds in order (host code of the view change: node_id_sort.h)
+extern "C" int emu_sort_node_ids(long long* hi, long long* lo, int n) {
+    std::vector<std::pair<int64_t, int64_t>> ids((size_t)n);
+    for (int i = 0; i < n; ++i) ids[(size_t)i] = {hi[i], lo[i]};
+    rapid::sort_node_ids(ids);
+    for (int i = 0; i < n; ++i) {
+        hi[i] = ids[(size_t)i].first;
+        lo[i] = ids[(size_t)i].second;
     }
     return 0;
 }

@@ -350,12 +350,14 @@ def view_build(hostnames, ports, id_hi, id_lo, K, members, keep=None, seed=1):
     lo = np.array([b for _, b in ids] + [0], dtype=np.int64)
     out = dict(keys=np.zeros(K * n + 1, dtype=np.int64), ring=np.full(K * max(M, 1), -1, dtype=np.int32),
                obs=np.full(n * K + 1, -9, dtype=np.int32), subj=np.full(n * K + 1, -9, dtype=np.int32), cfg=np.zeros(1, dtype=np.int64),
-               ring2=np.full(K * max(n, 1), -1, dtype=np.int32), m2=np.zeros(1, dtype=np.int32))
+               ring2=np.full(K * max(n, 1), -1, dtype=np.int32), m2=np.zeros(1, dtype=np.int32),
+               obs2=np.full(n * K + 1, -9, dtype=np.int32), subj2=np.full(n * K + 1, -9, dtype=np.int32))
     keep_a = None if keep is None else np.ascontiguousarray(np.concatenate([np.asarray(keep, dtype=np.uint8), np.zeros(1, dtype=np.uint8)]))
     p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
     L_.emu_view_build.restype = C.c_int
     rc = L_.emu_view_build(p(blob), p(off), p(ports), n, K, p(members), M, p(hi), p(lo), M, p(keep_a), p(out["keys"]), p(out["ring"]),
-                           p(out["obs"]), p(out["subj"]), p(out["cfg"]), p(out["ring2"]), p(out["m2"]), C.c_ulonglong(seed))
+                           p(out["obs"]), p(out["subj"]), p(out["cfg"]), p(out["ring2"]), p(out["m2"]), C.c_ulonglong(seed),
+                           p(out["obs2"]) if keep is not None else None, p(out["subj2"]) if keep is not None else None)
     assert rc == 0, rc
     out["keys"] = out["keys"][: K * n].reshape(K, n)
     out["ring"] = out["ring"][: K * M].reshape(K, M) if M else np.zeros((K, 0), dtype=np.int32)
@@ -363,6 +365,7 @@ def view_build(hostnames, ports, id_hi, id_lo, K, members, keep=None, seed=1):
     if keep is not None:
         m2 = int(out["m2"][0])
         out["ring2"] = out["ring2"][: K * m2].reshape(K, m2)
+        out["obs2"], out["subj2"] = out["obs2"][: n * K].reshape(n, K), out["subj2"][: n * K].reshape(n, K)
     return out
 
 

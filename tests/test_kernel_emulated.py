@@ -477,6 +477,12 @@ def test_view_kernels_match_the_oracle(n, K, n_members):
     assert got["ring2"].shape[1] == n_members - len(gone) + len(come)
     for k in range(K):
         assert np.array_equal(got["ring2"][k], oview.getRing(k)), ("view change", k)
+    if n_members >= 2 and got["ring2"].shape[1] >= 2:  # the tables of the new view, patched from the old ones where the cut touched them
+        # (against a view built afresh over the new membership: the changed one's tables() go through its observer memo, which may
+        # hold stale rows by now -- quirk Q4, tested where it belongs)
+        _, fresh = oracle_view(pop, K, sorted(np.flatnonzero(keep).tolist()))
+        oobs2, osubj2, _ = fresh.tables(n)
+        assert np.array_equal(got["obs2"], oobs2) and np.array_equal(got["subj2"], osubj2)
 
 
 def test_identifiers_merged_on_the_device():
@@ -731,7 +737,7 @@ def test_view_change_flag_kernels(seed):
     rng = np.random.default_rng(5100 + seed)
     n_nodes, K = int(rng.integers(5, 400)), int(rng.integers(3, 11))
     subj = rng.integers(-1, n_nodes, size=(n_nodes, K)).astype(np.int32)   # ring predecessors (-1: none)
-    pos = rng.integers(0, 3, size=(K, n_nodes)).astype(np.int32)          # position in ring k (0: the ring minimum, no predecessor below it)
+    ring = rng.integers(0, n_nodes, size=(K, 3)).astype(np.int32)          # ring[k][0] = the ring minimum: no predecessor below it
     nodes = rng.choice(n_nodes, size=int(rng.integers(0, n_nodes // 2 + 1)), replace=False).astype(np.int32)
     valid0 = rng.integers(0, 2, size=n_nodes).astype(np.uint8)
     member0 = rng.integers(0, 2, size=n_nodes).astype(np.uint8)
@@ -742,7 +748,7 @@ def test_view_change_flag_kernels(seed):
     for self_flag, clear in ((1, True), (0, False), (1, False)):
         valid, member = valid0.copy(), member0.copy()
         gone = np.zeros(0, np.int32) if clear else nodes  # (cleared by the memo kernel, or by the patch kernel)
-        rc = L_.emu_view_flags(p(subj), p(pos), p(nodes) if len(nodes) else None, len(nodes), n_nodes, K, p(valid), self_flag,
+        rc = L_.emu_view_flags(p(subj), p(ring), 3, p(nodes) if len(nodes) else None, len(nodes), n_nodes, K, p(valid), self_flag,
                                p(member) if clear else None, p(member), p(gone) if len(gone) else None, len(gone),
                                p(joined) if len(joined) else None, len(joined), C.c_ulonglong(seed))
         assert rc == 0
@@ -751,8 +757,56 @@ def test_view_change_flag_kernels(seed):
             if self_flag:
                 want_valid[node] = 0
             for k in range(K):
-                if pos[k, node] > 0 and 0 <= subj[node, k] < n_nodes:
+                if ring[k, 0] != node and 0 <= subj[node, k] < n_nodes:
                     want_valid[subj[node, k]] = 0
         want_member[nodes] = 0
         want_member[joined] = 1
         assert np.array_equal(valid, want_valid) and np.array_equal(member, want_member), (self_flag, clear)
+
+
+@pytest.mark.parametrize("n,K", [(1, 3), (700, 2), (1024, 1), (1025, 2), (2600, 3)])
+def test_joiners_sorted_per_ring_in_runs(n, K):
+    """ring_sort_runs_kernel + ring_merge_runs_kernel (a cut's joiners, ring by ring, by (ring key, node index)): runs of 1,024 pairs
+    sorted in LDS, every pair placed among the other runs by binary search -- against numpy, with EQUAL keys among the pairs (which the
+    64-bit hashes of real endpoints never produce; the node index decides) and run boundaries that do not divide n."""
+    import ctypes as C
+    rng = np.random.default_rng(900 + n)
+    keys = rng.integers(0, 2**63, size=(K, n), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(K, n)).astype(np.uint64)
+    keys[:, ::5] = keys[:, 0:1]  # every fifth pair of a ring shares one key
+    nodes = np.stack([rng.permutation(n + 50)[:n] for _ in range(K)]).astype(np.int32)
+    want_k, want_n = np.empty_like(keys), np.empty_like(nodes)
+    for k in range(K):
+        order = np.lexsort((nodes[k], keys[k]))
+        want_k[k], want_n[k] = keys[k][order], nodes[k][order]
+    kk, nn = keys.copy(), nodes.copy()
+    out_k, out_n = np.zeros_like(keys), np.full_like(nodes, -1)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L_ = pyemu.lib()
+    L_.emu_join_sort.restype = C.c_int
+    assert L_.emu_join_sort(p(kk), p(nn), n, K, p(out_k), p(out_n), C.c_ulonglong(n)) == 0
+    assert np.array_equal(out_k, want_k) and np.array_equal(out_n, want_n)
+
+
+def test_joiner_identifiers_put_in_order_on_the_host():
+    """node_id_sort.h (the host's ordering of a cut's joiner NodeIds, in front of the identifiersSeen check and the merge): the order
+    of std::sort over (high, low) signed pairs -- for spread UUIDs (the counting pass), for identifiers that share their top bits
+    (full buckets), with duplicates and ties in the high word, below and above the size where the counting pass starts."""
+    import ctypes as C
+    L_ = pyemu.lib()
+    rng = np.random.default_rng(17)
+    cases = []
+    for n in (1, 2, 255, 256, 257, 5000, 70000):
+        cases.append(rng.integers(-2**63, 2**63 - 1, size=(n, 2), dtype=np.int64))                  # UUIDs
+    seq = np.stack([np.full(3000, 7, dtype=np.int64), np.arange(3000, 0, -1, dtype=np.int64)], axis=1)  # one high word
+    cases.append(seq)
+    few = np.stack([rng.integers(-3, 3, size=4000), rng.integers(-5, 5, size=4000)], axis=1).astype(np.int64)  # ties and duplicates
+    cases.append(few)
+    edge = np.array([[2**63 - 1, -1], [-2**63, 0], [0, 0], [-1, 2**63 - 1], [-1, -2**63]] * 80, dtype=np.int64)
+    cases.append(edge)
+    for ids in cases:
+        hi = np.ascontiguousarray(ids[:, 0]); lo = np.ascontiguousarray(ids[:, 1])
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        L_.emu_sort_node_ids.restype = C.c_int
+        assert L_.emu_sort_node_ids(p(hi), p(lo), len(ids)) == 0
+        want = sorted(map(tuple, ids.tolist()))
+        assert list(zip(hi.tolist(), lo.tolist())) == want
