@@ -467,7 +467,9 @@ int rapid_sim_pass_times(rapid_engine* h, float out[4]);
  * voters' node lists instead of their slot bitmaps, 8192 = the packed detector state (two slots per LDS word: the form of rounds with
  * more than 4,096 hot subjects) whatever the size, 1048576 = packed rounds over boundary records keep their dictionary in LDS as hashed
  * buckets of one-byte remainders (exact; slots renumbered in hash order) instead of looking subjects up in memory, where the round
- * is eligible (every named subject hot, at most 2^21 nodes), 32 = measurement only: stream the records through
+ * is eligible (every named subject hot, at most 2^21 nodes), 2097152 = a tiled round (rapid_sim_round_tiled) makes and tallies its
+ * tiles strictly one after the other on one stream (by default the next tile's deliveries are made on a second stream while this
+ * tile is tallied), 32 = measurement only: stream the records through
  * the registers without tallying them (results are meaningless).  Every bit selects another PRODUCT path or instantiation
  * (all of them parity-tested); none adds code that the default does not ship. */
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);

@@ -178,6 +178,8 @@ struct rapid_engine {
     size_t alert_stage_bytes = 0;
     bool vstage_busy = false;  // asynchronous copies out of h_vstage may still be in flight (cleared when a view change's last kernel has answered)
     hipEvent_t ev_alert = nullptr;
+    hipStream_t stream_gen = nullptr;  // tiled rounds: the next tile's deliveries are made here while this tile is tallied
+    hipEvent_t ev_gen_ready[2] = {nullptr, nullptr}, ev_gen_free[2] = {nullptr, nullptr}, ev_gen_inputs = nullptr;
     bool alert_copy_pending = false;
     long long n_alert_set = -1;
     bool trusted = false, all_down = false;
@@ -1263,6 +1265,9 @@ void rapid_engine_destroy(rapid_engine* h) {
     if (h->h_alert_stage) quiet(hipHostFree(h->h_alert_stage), "hipHostFree(alert staging)");
     if (h->h_vstage) quiet(hipHostFree(h->h_vstage), "hipHostFree(view staging)");
     if (h->ev_alert) quiet(hipEventDestroy(h->ev_alert), "hipEventDestroy");
+    for (hipEvent_t e : {h->ev_gen_ready[0], h->ev_gen_ready[1], h->ev_gen_free[0], h->ev_gen_free[1], h->ev_gen_inputs})
+        if (e) quiet(hipEventDestroy(e), "hipEventDestroy");
+    if (h->stream_gen) quiet(hipStreamDestroy(h->stream_gen), "hipStreamDestroy");
     if (h->stream) quiet(hipStreamDestroy(h->stream), "hipStreamDestroy");
     h->d_blob.release(); h->d_host_off.release(); h->d_ports.release(); h->d_keys.release();
     h->d_hx_host0.release(); h->d_hx_port0.release(); h->d_member.release(); h->d_members.release();
@@ -2376,6 +2381,16 @@ int rapid_debug_vote_merge(rapid_engine* h, const void* segments, int32_t n_rank
 #endif  // RAPID_TEST_BUILD
 
 // ---- a round over a population that does not fit one launch ------------------------------------------------------------------
+// (inside rapid_sim_round_tiled's tile loop: a failing call does not leave the generator running into buffers the caller may free)
+#define HIPCHK_SYNC_GEN(expr)                                                                   \
+    do {                                                                                        \
+        const hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                                 \
+            if (h->stream_gen) (void)hipStreamSynchronize(h->stream_gen);                       \
+            HIPCHK(h, e_);                                                                      \
+        }                                                                                       \
+    } while (0)
+
 int rapid_sim_round_tiled(rapid_engine* h, const rapid_alert_record* alerts, const int64_t* batch_off, int32_t n_batches,
                           const uint32_t* batch_keep, const int32_t* receivers, int32_t n_receivers, int32_t tile_receivers,
                           uint64_t seed, int32_t format, rapid_round_result* out) {
@@ -2417,8 +2432,22 @@ int rapid_sim_round_tiled(rapid_engine* h, const rapid_alert_record* alerts, con
     if (R) HIPCHK(h, hipMemcpyAsync(h->d_gen_rx.p, receivers, sizeof(int) * (size_t)R, hipMemcpyHostToDevice, st));
     if (batch_keep && n_batches) HIPCHK(h, hipMemcpyAsync(h->d_gen_keep.p, batch_keep, sizeof(unsigned int) * (size_t)n_batches, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipStreamSynchronize(st));  // (borrowed inputs)
-    HIPCHK(h, h->d_records_own.ensure((size_t)T * (size_t)A * stride + 64));
+    // TWO stream buffers: the deliveries of tile t + 1 are made (on a stream of their own) while tile t is tallied.  The two kernels
+    // want different things of a CU -- the generator is arithmetic (the permutation, the scan over the batch lengths) and holds no
+    // LDS, the tally of a packed round sits on its LDS with one wave per SIMD -- so they share the CUs instead of taking turns.
+    // (Testing knob bit 21: one buffer, one stream, as before.)
+    const bool overlap = (h->force_exact & 2097152) == 0 && R > T;
+    const size_t buf_bytes = (((size_t)T * (size_t)A * stride + 64) + 255) & ~(size_t)255;
+    HIPCHK(h, h->d_records_own.ensure(buf_bytes * (overlap ? 2 : 1)));
     HIPCHK(h, h->d_rec_off_own.ensure((size_t)T + 1));
+    if (overlap && !h->stream_gen) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->stream_gen, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_gen_ready[i], hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_gen_free[i], hipEventDisableTiming));
+        }
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_gen_inputs, hipEventDisableTiming));
+    }
     hipLaunchKernelGGL(rapid::gen_offsets_kernel, dim3(grid_for(T + 1, 256)), dim3(256), 0, st, h->d_rec_off_own.p, (int)T, A);  // (the same for every tile)
     h->d_records = h->d_records_own.p;
     h->records_bytes = (unsigned long long)T * (unsigned long long)A * stride;
@@ -2480,15 +2509,41 @@ int rapid_sim_round_tiled(rapid_engine* h, const rapid_alert_record* alerts, con
         ++passes;
         HIPCHK(h, hipMemsetAsync(acc, 0, acc_words * 8, st));
         if (target != 0ull) HIPCHK(h, hipMemcpyAsync(acc + 6, &target, 8, hipMemcpyHostToDevice, st));  // (pageable, 8 bytes: staged by the runtime)
-        for (long long base = 0; base < R; base += T) {
+        // deliveries of the tile at `base` into stream buffer `buf`, on stream `gs`
+        auto generate = [&](long long base, int buf, hipStream_t gs) {
+            const int n = (int)std::min<long long>(T, R - base);
+            hipLaunchKernelGGL(rapid::gen_streams_kernel, dim3(grid_for(n, rapid::kGenWavesPerBlock)), dim3(rapid::kGenWavesPerBlock * 64), 0, gs, h->d_gen_res.p,
+                               h->d_alert_set.p, h->d_gen_bat.p, n_batches, batch_keep ? h->d_gen_keep.p : (const unsigned int*)nullptr, h->d_gen_rx.p + base,
+                               n, A, (unsigned long long)seed, h->d_records_own.p + (size_t)buf * buf_bytes, boundary ? 1 : 0);
+        };
+        int buf = 0;
+        if (overlap) {  // (the generator's inputs were written on the round's stream)
+            HIPCHK_SYNC_GEN(hipEventRecord(h->ev_gen_inputs, st));
+            HIPCHK_SYNC_GEN(hipStreamWaitEvent(h->stream_gen, h->ev_gen_inputs, 0));
+            generate(0, 0, h->stream_gen);
+            HIPCHK_SYNC_GEN(hipEventRecord(h->ev_gen_ready[0], h->stream_gen));
+        }
+        for (long long base = 0; base < R; base += T, buf ^= overlap ? 1 : 0) {
             const int n = (int)std::min<long long>(T, R - base);
             ++tiles;
-            hipLaunchKernelGGL(rapid::gen_streams_kernel, dim3(grid_for(n, rapid::kGenWavesPerBlock)), dim3(rapid::kGenWavesPerBlock * 64), 0, st, h->d_gen_res.p,
-                               h->d_alert_set.p, h->d_gen_bat.p, n_batches, batch_keep ? h->d_gen_keep.p : (const unsigned int*)nullptr, h->d_gen_rx.p + base,
-                               n, A, (unsigned long long)seed, h->d_records_own.p, boundary ? 1 : 0);
+            if (overlap) {
+                if (base + T < R) {  // the next tile's deliveries, into the buffer the tile before this one was tallied from
+                    if (base > 0) HIPCHK_SYNC_GEN(hipStreamWaitEvent(h->stream_gen, h->ev_gen_free[buf ^ 1], 0));
+                    generate(base + T, buf ^ 1, h->stream_gen);
+                    HIPCHK_SYNC_GEN(hipEventRecord(h->ev_gen_ready[buf ^ 1], h->stream_gen));
+                }
+                HIPCHK_SYNC_GEN(hipStreamWaitEvent(st, h->ev_gen_ready[buf], 0));
+            } else {
+                generate(base, 0, st);
+            }
+            h->d_records = h->d_records_own.p + (size_t)buf * buf_bytes;
             h->n_receivers = n;
             h->out_base = base;
-            if ((rc = launch_tally(h))) return rc;
+            if ((rc = launch_tally(h))) {
+                if (overlap) (void)hipStreamSynchronize(h->stream_gen);
+                return rc;
+            }
+            if (overlap) HIPCHK_SYNC_GEN(hipEventRecord(h->ev_gen_free[buf], st));
             hipLaunchKernelGGL(rapid::vote_acc_pick_kernel, dim3(1), dim3(1024), 0, st, d_res, h->d_fp.p + base, h->d_pcount.p + base, h->d_props.p, h->max_cut,
                                h->d_bitmaps.p, words, n, h->d_errflags.p, acc, acc_bits, acc_list);
             hipLaunchKernelGGL(rapid::vote_acc_count_kernel, dim3(std::max(1u, grid_for((long long)n * 64, 1024))), dim3(1024), 0, st, h->d_fp.p + base,

@@ -1773,8 +1773,13 @@ def test_round_taken_tile_by_tile_accumulates_the_votes(E, test_build):
             rr1 = sim.count_votes()
             cut1 = sim.decided_cut()
             assert rr1.decided == 1 and sorted(cut1) == sc.faulty.tolist()
-            for tile in (0, 256, 1000, 97):
+            for tile in (0, 256, 1000, 97, -97):
+                # (a tile's deliveries are made on a second stream while the tile before it is tallied; -97: knob bit 21, one
+                # stream and one buffer, the tiles strictly one after the other)
+                sim.set_force_exact(2097152 if tile < 0 else 0)
+                tile = abs(tile)
                 rr = sim.round_tiled(batches, rx, seed, tile_receivers=tile, boundary=boundary)
+                sim.set_force_exact(0)
                 got = sim.results()
                 assert all(np.array_equal(a, b) for a, b in zip(want, got)), (boundary, tile)
                 assert (rr.decided, rr.votes_winner, rr.votes_total, rr.cut_size, rr.quorum) == (1, rr1.votes_winner, rr1.votes_total, rr1.cut_size, rr1.quorum)
