@@ -1074,8 +1074,9 @@ def test_c4_full_shard_against_fast_oracle(E):
     """BASELINE configs[3] exactly as `bench.py --config C4 --gpus 1` runs it: shard 0 of the eight (all 12,375 receivers
     of P.shard_range(99,000, 0, 8), ~122 M delivered records), the round's alerts declared and the per-delivery
     configuration-id check waived on the load pass's verdict.  Every receiver against the optimised CPU formulation
-    (announcing batch, getNumProposals, proposal size, proposal contents through the fingerprints); the same streams
-    through the per-delivery filter give the same results; a shard alone has no quorum."""
+    (announcing batch, getNumProposals, proposal size, proposal contents through the fingerprints), 64 of them also against
+    the faithful restatement of the Java; the same streams through the per-delivery filter give the same results; a shard alone
+    has no quorum."""
     from rapid_amd import parallel as P
     n, K, H, L = 100000, 10, 9, 4
     pop = S.Population.make(n)
@@ -1097,6 +1098,21 @@ def test_c4_full_shard_against_fast_oracle(E):
     assert np.all(fe >= 0) and np.all(pcount == len(sc0.faulty))
     for r in (0, 6000, len(rx) - 1):
         assert sorted(sim.proposal(r)) == sc0.faulty.tolist()
+    # ... and the faithful restatement of the Java at this size, on the same streams: 64 receivers spread over the shard (the
+    # faithful detector walks every subject in flux at every batch end, R/MultiNodeCutDetector.java:137-164 -- ~6 s per receiver
+    # here, which is why the other 12,311 are held against the optimised formulation only)
+    sample = np.linspace(0, len(rx) - 1, 64).astype(np.int64)
+    sub_off = np.zeros(len(sample) + 1, dtype=np.int64)
+    parts = []
+    for i, r in enumerate(sample):
+        parts.append(records[rec_off[r]:rec_off[r + 1]])
+        sub_off[i + 1] = sub_off[i] + len(parts[-1])
+    reg, oview = oracle_view(pop, K)
+    assert oview.getCurrentConfigurationId() == cfg
+    oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, np.concatenate(parts), sub_off, nthreads=32)
+    assert np.array_equal(emit[sample], oe) and np.array_equal(nprop[sample], on) and np.array_equal(pcount[sample], np.diff(oo))
+    assert np.array_equal(fp[sample], proposal_fingerprints(oo, op, oe >= 0))
+    del reg, oview
     rr = sim.count_votes()
     assert rr.votes_winner == len(rx) and rr.decided == 0 and rr.quorum == n - (n - 1) // 4
     sim, res_f = run_population(E, eng, records, rec_off, alert_set=sc0.batches.recs, trust=False)
@@ -1373,7 +1389,8 @@ def test_q4_stale_observer_cache_is_reproduced_and_reported(E):
 
 def test_streaming_rounds_at_100k_nodes(E):
     """The same stream at N = 100,000 (a single-GPU-sized slice of BASELINE configs[4]): three rounds, 1,000 crashes + 500 joins
-    each, against the optimised oracle on every simulated receiver; configuration ids against the oracle's view."""
+    each, against the optimised oracle on every simulated receiver -- and, in the second round (late deliveries, a view change
+    behind it), three receivers against the faithful restatement of the Java; configuration ids against the oracle's view."""
     K, H, L = 10, 9, 4
     n_mem, spare, rounds = 100000, 2000, 3
     pop = S.Population.make(n_mem + spare)
@@ -1399,6 +1416,16 @@ def test_streaming_rounds_at_100k_nodes(E):
         assert (fe >= 0).all()
         for r_ in np.flatnonzero(fe >= 0)[:5]:
             assert sorted(fpp[fo[r_]:fo[r_ + 1]].tolist()) == sc.faulty.tolist()
+        if rnd == 1:
+            # the second round -- late deliveries among the records, a view change behind it -- also through the FAITHFUL
+            # restatement of the Java, on the oracle's own view (its observer cache as the first view change left it): three
+            # receivers, ~50 s each (the faithful detector walks the ~1,500 subjects in flux at each of ~14,000 batch ends; at
+            # 10^6 nodes that is ~1.5 h per receiver, which is why the rounds at 10^6 are held against the optimised one only)
+            m = 3
+            oe, on, oo, op = O.sim_run(oview, K, H, L, pop.id_hi, pop.id_lo, sc.records[: sc.rec_off[m]], sc.rec_off[: m + 1],
+                                       prewarm_observers=False)
+            assert np.array_equal(emit[:m], oe) and np.array_equal(nprop[:m], on) and np.array_equal(pcount[:m], np.diff(oo))
+            assert np.array_equal(fp[:m], proposal_fingerprints(oo, op, oe >= 0))
         cut = sc.faulty.tolist()
         new_cfg = sim.apply_cut(cut)
         _oracle_decide(oview, K, H, L, pop, sc, cut)
