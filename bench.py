@@ -243,8 +243,9 @@ def main():
     achieved = rec_b * consumed / (kern_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "tally_population_kernel<%s, %s, kFmtBoundary>" % ({0: "kDictMemory", 1: "kDictDirect", 2: "kDictCompressed"}.get(index["dict_mode"], "?"),
-                                                                               "trusted" if index["alerts_prevalidated"] else "filter"),
+                "kernel": "tally_population_kernel<%s, %s, kFmtBoundary%s>" % ({0: "kDictMemory", 1: "kDictDirect", 2: "kDictCompressed"}.get(index["dict_mode"], "?"),
+                                                                                 "trusted" if index["alerts_prevalidated"] else "filter",
+                                                                                 ", ids known current" if index.get("configuration_ids_known_current") else ""),
                 "kernel_ms": round(kern_ms, 4),
                 "bytes_per_launch": int(rec_b * consumed), "bytes_per_record": 20, "records_consumed_per_launch": int(consumed),
                 "records_delivered_per_launch": my_records,

@@ -449,7 +449,8 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg);
  * slot (boundary records: 1 = direct tables in LDS, 2 = compressed tables in LDS, 0 = tables in memory, read through L2 --
  * chosen by what fits the LDS next to the receivers' detector state; 3 = nowhere: generated resolved records carry their
  * subjects' entries), bit 0: alert set declared, bit 1: a hot member's memoised observers are stale in this round (Q4 is
- * live)}; index_ms = device time of the last index build that was timed: a call that asks (index_ms != NULL) has the
+ * live), bit 2: the records are pre-validated boundary records of the engine's own configuration -- the tally leaves their
+ * configuration ids in the cache lines (one load per record)}; index_ms = device time of the last index build that was timed: a call that asks (index_ms != NULL) has the
  * NEXT build bracketed by timing events -- this call's own if the index is stale; 0 before the
  * first timed build.  Rounds nobody asks about carry no timing events. */
 int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms);
@@ -469,7 +470,9 @@ int rapid_sim_pass_times(rapid_engine* h, float out[4]);
  * buckets of one-byte remainders (exact; slots renumbered in hash order) instead of looking subjects up in memory, where the round
  * is eligible (every named subject hot, at most 2^21 nodes), 2097152 = a tiled round (rapid_sim_round_tiled) makes and tallies its
  * tiles strictly one after the other on one stream (by default the next tile's deliveries are made on a second stream while this
- * tile is tallied), 32 = measurement only: stream the records through
+ * tile is tallied), 4194304 = pre-validated boundary records of the engine's own configuration still have their configuration
+ * ids loaded and compared per delivery (by default they stay in the cache lines: one load per record instead of two),
+ * 32 = measurement only: stream the records through
  * the registers without tallying them (results are meaningless).  Every bit selects another PRODUCT path or instantiation
  * (all of them parity-tested); none adds code that the default does not ship. */
 int rapid_sim_set_force_exact(rapid_engine* h, int32_t on);

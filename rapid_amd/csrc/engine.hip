@@ -183,6 +183,7 @@ struct rapid_engine {
     bool alert_copy_pending = false;
     long long n_alert_set = -1;
     bool trusted = false, all_down = false;
+    bool all_current = false;  // every alert the round index saw carries the engine's configuration id
     bool trust_copies = false;  // the caller vouches that the deliveries are copies of the declared alerts (rapid_sim_trust_alert_copies)
     DevBuf<unsigned int> d_loadflags;
     DevBuf<unsigned int> d_adj;
@@ -930,6 +931,7 @@ int build_round_index(rapid_engine* h) {
         return fail(h, RAPID_ECAPACITY, "hot adjacency has %d entries; at most 65535 are supported", info[3]);
     h->trusted = (info[4] & 1) == 0;
     h->all_down = (info[4] & 2) == 0;
+    h->all_current = (info[4] & 4) == 0;
     h->n_slots = info[0];
     h->n_hot = info[1];
     h->n_adj = h->n_hot > 0 ? info[3] : 0;
@@ -1139,6 +1141,26 @@ int launch_tally(rapid_engine* h) {
     const bool trusted = tally_is_trusted(h);
     const size_t lds = (size_t)h->lds_bytes;
     using namespace rapid;
+    // pre-validated boundary records of ONE configuration -- the engine's: their configuration ids stay in the cache lines
+    // (tally_kernel.h: kCurrent; testing knob bit 22: compared per delivery all the same)
+    if (trusted && h->all_current && h->rec_fmt == kFmtBoundary && (h->force_exact & 4194304) == 0) {
+        if (h->packed && h->dict_mode == kDictMemory) {
+            hipLaunchKernelGGL((tally_population_kernel<kDictMemory, true, kFmtBoundary, true, true>), grid, block, lds, h->stream, p);
+            return RAPID_OK;
+        }
+        if (!h->packed && h->dict_mode == kDictMemory) {
+            hipLaunchKernelGGL((tally_population_kernel<kDictMemory, true, kFmtBoundary, false, true>), grid, block, lds, h->stream, p);
+            return RAPID_OK;
+        }
+        if (!h->packed && h->dict_mode == kDictDirect) {
+            hipLaunchKernelGGL((tally_population_kernel<kDictDirect, true, kFmtBoundary, false, true>), grid, block, lds, h->stream, p);
+            return RAPID_OK;
+        }
+        if (!h->packed && h->dict_mode == kDictCompressed) {
+            hipLaunchKernelGGL((tally_population_kernel<kDictCompressed, true, kFmtBoundary, false, true>), grid, block, lds, h->stream, p);
+            return RAPID_OK;
+        }
+    }
     switch ((h->packed ? 16 : 0) + (h->rec_fmt == kFmtBoundary ? 0 : 8) + h->dict_mode * 2 + (trusted ? 1 : 0)) {
         case 24: hipLaunchKernelGGL((tally_population_kernel<kDictHashed, false, kFmtBoundary, true>), grid, block, lds, h->stream, p); break;
         case 25: hipLaunchKernelGGL((tally_population_kernel<kDictHashed, true, kFmtBoundary, true>), grid, block, lds, h->stream, p); break;
@@ -1187,7 +1209,11 @@ int prepare_tally(rapid_engine* h) {
 int ensure_tally_attrs(rapid_engine* h) {
     if (!h->lds_attr_set) {  // once per engine: every instantiation may use the whole 160 KiB of LDS
         using namespace rapid;
-        const void* kernels[14] = {reinterpret_cast<const void*>(tally_population_kernel<kDictHashed, false, kFmtBoundary, true>),
+        const void* kernels[18] = {reinterpret_cast<const void*>(tally_population_kernel<kDictMemory, true, kFmtBoundary, true, true>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictMemory, true, kFmtBoundary, false, true>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictDirect, true, kFmtBoundary, false, true>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictCompressed, true, kFmtBoundary, false, true>),
+                                  reinterpret_cast<const void*>(tally_population_kernel<kDictHashed, false, kFmtBoundary, true>),
                                   reinterpret_cast<const void*>(tally_population_kernel<kDictHashed, true, kFmtBoundary, true>),
                                   reinterpret_cast<const void*>(tally_population_kernel<kDictResolved, false, kFmtResident, true>),
                                   reinterpret_cast<const void*>(tally_population_kernel<kDictResolved, true, kFmtResident, true>),
@@ -2868,7 +2894,10 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
     info[4] = h->lds_bytes;
     info[5] = tally_is_trusted(h) ? 1 : 0;
     info[6] = h->dict_mode;  // 3 = resolved records (no lookup in the tally); 0 / 1 / 2 = tables in memory / direct in LDS / compressed in LDS
-    info[7] = (h->n_alert_set >= 0 ? 1 : 0) | (h->q4_live ? 2 : 0);
+    // (bit 2: the tally runs the instantiation that leaves the records' configuration ids in their cache lines -- launch_tally)
+    const bool ids_skipped = tally_is_trusted(h) && h->all_current && h->rec_fmt == rapid::kFmtBoundary && (h->force_exact & 4194304) == 0 &&
+                             (h->dict_mode == rapid::kDictMemory || (!h->packed && (h->dict_mode == rapid::kDictDirect || h->dict_mode == rapid::kDictCompressed)));
+    info[7] = (h->n_alert_set >= 0 ? 1 : 0) | (h->q4_live ? 2 : 0) | (ids_skipped ? 4 : 0);
     if (h->index_ms_pending && h->ev_idx0 && h->ev_idx1) {
         h->index_ms_pending = false;
         if (hipEventSynchronize(h->ev_idx1) == hipSuccess) (void)hipEventElapsedTime(&h->index_ms, h->ev_idx0, h->ev_idx1);

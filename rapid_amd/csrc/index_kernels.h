@@ -36,7 +36,7 @@ __global__ void index_touch_kernel(const unsigned char* records, long long n_rec
         // whole by the tally's configuration-id compare, R/MembershipService.java:653-657 -- late deliveries among a round's
         // batches do not cost the round its pre-validated instantiation)
         const bool ok = !current || (dst < (unsigned)n_nodes && bits != 0u && ((member[dst < (unsigned)n_nodes ? dst : 0u] != 0) == down));
-        f |= (ok ? 0u : 1u) | (down ? 0u : 2u);
+        f |= (ok ? 0u : 1u) | (down ? 0u : 2u) | (current ? 0u : 4u);  // (bit 2: an alert of another configuration is among them)
     }
     if (f) atomicOr(vflags, f);
 }
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(1024) void index_fused_kernel(const unsigned char* 
             const bool down = (cw & kCoreDown) != 0u;
             if (inr && bits != 0u) atomicOr(&l_decl32[dst >> 1], bits << ((dst & 1u) * 16u));  // (whatever the filter says: a superset, as in index_touch_kernel)
             const bool ok = !current || (inr && bits != 0u && ((l_mem[inr ? dst : 0u] != 0) == down));  // (see index_touch_kernel)
-            f |= (ok ? 0u : 1u) | (down ? 0u : 2u);
+            f |= (ok ? 0u : 1u) | (down ? 0u : 2u) | (current ? 0u : 4u);
         }
     }
     if (f) atomicOr(&s_flags, f);

@@ -624,6 +624,9 @@ enum { kApplied = 0, kWitnessFails = 1, kNotFastable = 2 };  // outcome of a fas
 #ifndef RAPID_SETS_PACKED
 #define RAPID_SETS_PACKED 4
 #endif
+#ifndef RAPID_SETS_CURRENT
+#define RAPID_SETS_CURRENT 3  // boundary records of which {dst, word} only is loaded (kCurrent): a window is as small as a resident one
+#endif
 // cache policy of the two loads of a boundary record (0 = default, 2 = nt).  Both touch the same cache lines: with nt the second
 // one fetches them from L2 again (measured, scripts/micro/boundary_shapes.hip: 5.4 TB/s against 6.1 TB/s for this shape;
 // the kernel: 0.436 -> 0.383 ms on C3b), whereas a resident 8-byte record is loaded once and streams best with nt
@@ -652,8 +655,15 @@ __host__ __device__ constexpr int tally_max_waves(int dict_mode, bool trusted, i
 #else
 #define RAPID_TALLY_OCCUPANCY
 #endif
-template <int kDictMode, bool kTrusted, int kFmt = kFmtResident, bool kPacked = false>
+// kCurrent (pre-validated boundary records only): every alert the round index saw carries the engine's configuration id, and the
+// deliveries are vouched-for copies of them -- so does every delivered record, and its configuration id need not travel from the
+// cache line to the registers at all: ONE buffer_load_dwordx2 per record ({dst, word}, non-temporal: nothing asks for the line
+// again) instead of two, no 64-bit compare, eight registers fewer per window in flight.  The bytes that cross the HBM interface
+// are the same 20 per record (the lines are the same); what is saved is the second request per line between L2 and the CU
+// (scripts/micro/boundary_shapes.hip, shape 2 against shape 0: 6.6 against 6.1 TB/s with nothing else going on).
+template <int kDictMode, bool kTrusted, int kFmt = kFmtResident, bool kPacked = false, bool kCurrent = false>
 __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked) * 64) RAPID_TALLY_OCCUPANCY void tally_population_kernel(TallyParams p) {
+    static_assert(!kCurrent || (kTrusted && kFmt == kFmtBoundary), "only vouched-for boundary records can be known to be current");
     static_assert(!kPacked || kDictMode == kDictMemory || kDictMode == kDictResolved || kDictMode == kDictHashed,
                   "packed detector state: dictionary in memory, hashed in LDS, or none");
     static_assert(kDictMode != kDictHashed || kFmt == kFmtBoundary, "the hashed dictionary maps the subjects of boundary records");
@@ -845,7 +855,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
     int n_applied = 0;
     unsigned int sink = 0u;  // stream-only mode: keeps the loads alive
 
-    typedef WindowT<kFmt> Win;
+    typedef WindowT<kCurrent ? kFmtResident : kFmt> Win;  // (kCurrent: {dst, word} is all that is loaded of a boundary record)
     struct Rec {  // a window as the paths below see it, whatever the format it arrived in
         unsigned int w3[kQ], w4[kQ];  // subject (resident: its dict_entry, or the subject | kCoreStale); core word (core_word)
     };
@@ -864,8 +874,12 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
 #pragma unroll
         for (int q = 0; q < kQ; ++q) {
             if constexpr (kFmt == kFmtBoundary) {
-                stream_load2<RAPID_BOUNDARY_AUX_A>(rsrc, voff, (unsigned int)q * kQuarterB, W.c0[q], W.c1[q]);
-                stream_load2<RAPID_BOUNDARY_AUX_B>(rsrc, voff, (unsigned int)q * kQuarterB + 12u, W.w3[q], W.w4[q]);
+                if constexpr (kCurrent) {
+                    stream_load2<2>(rsrc, voff, (unsigned int)q * kQuarterB + 12u, W.w3[q], W.w4[q]);
+                } else {
+                    stream_load2<RAPID_BOUNDARY_AUX_A>(rsrc, voff, (unsigned int)q * kQuarterB, W.c0[q], W.c1[q]);
+                    stream_load2<RAPID_BOUNDARY_AUX_B>(rsrc, voff, (unsigned int)q * kQuarterB + 12u, W.w3[q], W.w4[q]);
+                }
             } else {
                 stream_load2(rsrc, voff, (unsigned int)q * kQuarterB, W.w3[q], W.w4[q]);
             }
@@ -884,7 +898,8 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
         for (int q = 0; q < kQ; ++q) {
             if constexpr (kFmt == kFmtBoundary) {
                 // (one 64-bit compare instead of two exclusive-ors, an or and a 32-bit compare)
-                const bool current = (((unsigned long long)c.c1[q] << 32) | (unsigned long long)c.c0[q]) == cfg64;
+                bool current = true;
+                if constexpr (!kCurrent) current = (((unsigned long long)c.c1[q] << 32) | (unsigned long long)c.c0[q]) == cfg64;
                 const unsigned int raw = c.w4[q];
                 const unsigned int rings = raw & kCoreRings;
                 const unsigned int live = current ? rings : 0u;
@@ -1041,7 +1056,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
     // whole memory latency per window as soon as a window's tally is shorter than that, which it is since the fast window
     // shrank to ~100 instructions: 15 waves x 2 KiB per CU are not enough bytes in flight for 8 TB/s).  Three sets of 8 registers.
     // (boundary records: two sets of 16 registers -- 10 KiB of stream in flight per wave against 6 KiB of the resident format)
-    constexpr int kSets = kPacked ? RAPID_SETS_PACKED : kFmt == kFmtBoundary ? RAPID_SETS_BOUNDARY : RAPID_SETS;
+    constexpr int kSets = kPacked ? RAPID_SETS_PACKED : kCurrent ? RAPID_SETS_CURRENT : kFmt == kFmtBoundary ? RAPID_SETS_BOUNDARY : RAPID_SETS;
     static_assert(kSets >= 2 && kSets <= 6, "window sets");
     constexpr unsigned int kWinBytes = (unsigned int)(kWin * kStride);
     Win S[kSets];
@@ -1259,7 +1274,8 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
                 for (int q = 0; q < kQ; ++q) {
                     const Look k = lookup(cw.w3[q]);
                     const unsigned int raw = cw.w4[q];
-                    const bool current = (((unsigned long long)cw.c1[q] << 32) | (unsigned long long)cw.c0[q]) == cfg64;
+                    bool current = true;
+                    if constexpr (!kCurrent) current = (((unsigned long long)cw.c1[q] << 32) | (unsigned long long)cw.c0[q]) == cfg64;
                     const unsigned int full = (raw & kCoreRings) | ((raw & 0x00FF0000u) != 0u ? kCoreDown : kCoreUp);
                     w[q] = current ? full : 0u;
                     uncovered |= w[q] & k.entry;
@@ -1678,7 +1694,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
 #pragma unroll
                     for (int q = 0; q < kQ; ++q) {
                         sink ^= cur.w3[q] ^ cur.w4[q];
-                        if constexpr (kFmt == kFmtBoundary) sink ^= cur.c0[q] ^ cur.c1[q];
+                        if constexpr (kFmt == kFmtBoundary && !kCurrent) sink ^= cur.c0[q] ^ cur.c1[q];
                     }
                     next_general();
                     continue;

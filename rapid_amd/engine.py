@@ -478,6 +478,7 @@ class ClusterSimulation:
                 "alerts_prevalidated", "dict_mode", "alert_set_declared")
         out = {k: int(v) for k, v in zip(keys, info)}
         out["q4_live"] = (out["alert_set_declared"] >> 1) & 1  # a hot member's memoised observers are stale in this round (quirk Q4)
+        out["configuration_ids_known_current"] = (out["alert_set_declared"] >> 2) & 1  # the tally loads {dst, word} only (kCurrent)
         out["alert_set_declared"] &= 1
         # dict_mode -- where the tally maps a boundary record's subject to its slot: 1 = direct tables in LDS, 2 = compressed
         # tables in LDS, 0 = tables in memory (through L2); 3 = nowhere: generated records carry their subjects' entries

@@ -245,6 +245,16 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
         std::memset(smem, 0xCD, sizeof(smem));  // poison: the kernel must initialise what it reads
         const bool trusted = (flags & 256) != 0;  // emulator-only selector of the kTrusted instantiation
         auto run = [&](auto kern) { emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { kern(p); }, seed + (unsigned)b); };
+        const bool current = (flags & 16384) != 0;  // emulator-only: ... and of kCurrent (boundary records of the engine's configuration only)
+        if (current) {
+            if (!trusted || fmt != 1) return -9;
+            if (packed && tables_in_lds == 0) run(rapid::tally_population_kernel<rapid::kDictMemory, true, rapid::kFmtBoundary, true, true>);
+            else if (!packed && tables_in_lds == 0) run(rapid::tally_population_kernel<rapid::kDictMemory, true, rapid::kFmtBoundary, false, true>);
+            else if (!packed && tables_in_lds == 1) run(rapid::tally_population_kernel<rapid::kDictDirect, true, rapid::kFmtBoundary, false, true>);
+            else if (!packed && tables_in_lds == 2) run(rapid::tally_population_kernel<rapid::kDictCompressed, true, rapid::kFmtBoundary, false, true>);
+            else return -9;
+            continue;
+        }
         if (packed) {
             if (tables_in_lds == 4) {
                 if (trusted) run(rapid::tally_population_kernel<rapid::kDictHashed, true, rapid::kFmtBoundary, true>);

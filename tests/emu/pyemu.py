@@ -125,6 +125,9 @@ def validate_alerts(records, n_nodes, K, cfg_id, member):
     return bool(ok.all()), bool(down.all())
 
 
+CURRENT_RUNS = 0  # runs of a kCurrent instantiation so far (tally() below)
+
+
 def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_cap=None, force_exact=0, seed=1, waves=3,
           grid=2, tables_in_lds=1, trusted=False, declared=None, pool=False, fmt=None, packed=False):
     """`declared`: build the round index from these records (the round's distinct alert set) instead of the delivered
@@ -160,6 +163,17 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
         assert packed and ix["n_touched"] == ix["n_hot"], "kDictHashed: packed rounds whose every named subject is hot"
         hashed = hash_build(ix, n_nodes, member, seed=seed)
         ix = dict(ix, node_of_slot=hashed["node_of_slot"], adj_off=hashed["smask"], adj=hashed["pairs"])
+    # pre-validated boundary records that all carry the engine's configuration id: the product runs the instantiation that leaves
+    # the ids in their cache lines (kCurrent) -- run here too, first, and held against the run that compares them
+    if trusted and fmt == 1 and tables_in_lds in (0, 1, 2) and not (force_exact & 16384) and len(recs) and bool(np.all(recs["cfg_id"] == cfg_id)):
+        want = tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_cap=prop_cap, force_exact=(force_exact & ~256) | 16384 | 32768,
+                     seed=seed, waves=waves, grid=grid, tables_in_lds=tables_in_lds, trusted=True, declared=declared, pool=False, fmt=fmt, packed=packed)
+    else:
+        want = None
+    if force_exact & 32768:  # (this call IS that run)
+        global CURRENT_RUNS
+        CURRENT_RUNS += 1
+    force_exact &= ~32768
     rc = L_.emu_tally_run(p(raw), C.c_ulonglong(recs.nbytes), p(rec_off), R, n_nodes, K, H, L, C.c_longlong(cfg_id),
                           p(ix["dict"]), p(ix["decl"]), p(ix["node_of_slot"]), p(ix["adj_off"]), p(ix["adj"]),
                           ix["n_hot"], ix["n_adj"], p(emit), p(nprop), p(pcount), p(fp), p(props), prop_cap, p(stats),
@@ -176,6 +190,11 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     assert int(vote_res[2]) == len(voters), (vote_res, len(voters))
     assert int(vote_res[0]) == (int(voters[0]) if len(voters) else 0xFFFFFFFF), vote_res
     assert not vote_res[[1, 3, 4, 5, 6, 7, 9]].any(), vote_res
+    if want is not None:  # (statistics aside: the two instantiations take the same windows the same way, but that is not a promise)
+        for a, b in zip(want[:5], (emit, nprop, pcount, fp, props)):
+            assert np.array_equal(a, b), "kCurrent differs from the instantiation that compares the configuration ids"
+        if declared is not None:
+            assert want[6] == (rc == 0)
     if declared is not None:
         assert rc in (0, -1), rc
         return emit, nprop, pcount, fp, props, stats.sum(axis=0), rc == 0

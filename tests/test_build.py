@@ -22,7 +22,8 @@ def test_tally_kernels_fit_the_register_file_without_scratch():
     # {20-byte boundary records looked up in memory / direct tables / compressed tables, resolved 8-byte records of the generator}
     # x {filter per delivery, trusted copies} + {in memory, resolved} x {filter, trusted} with two slots per LDS word
     # ... + the hashed dictionary in LDS (mode 4) x {filter, trusted}, packed
-    assert len(tally) == 14, sorted(tally)
+    # ... + trusted boundary records known to carry the engine's configuration id (kCurrent): memory / direct / compressed, memory packed
+    assert len(tally) == 18, sorted(tally)
     for name, r in tally.items():
         assert r["ScratchSize [bytes/lane]"] == 0, (name, r)
         # 16 waves per CU = 4 per SIMD = 128 VGPRs; the per-delivery filter over compressed tables on boundary records is
@@ -45,7 +46,9 @@ def test_every_other_kernel_of_the_path_is_scratch_free_too():
 # (dictionary mode, trusted, record format, packed): 0 / 1 / 2 = tables in memory / direct in LDS / compressed in LDS over 20-byte
 # boundary records (format 1); 3 = resolved 8-byte records (format 0); packed = two slots per LDS word
 # 4 = hashed buckets in LDS (packed rounds, opt-in).  The packed instantiations keep four windows of the stream in flight (round 5).
-EXPECTED_VGPRS = {(0, False, 1, False): 123, (0, False, 1, True): 166, (0, True, 1, False): 104, (0, True, 1, True): 159, (1, False, 1, False): 119, (1, True, 1, False): 103, (2, False, 1, False): 133, (2, True, 1, False): 114, (3, False, 0, False): 91, (3, False, 0, True): 125, (3, True, 0, False): 87, (3, True, 0, True): 118, (4, False, 1, True): 174, (4, True, 1, True): 167}
+# fifth parameter (kCurrent): trusted boundary records whose configuration ids are never loaded -- 16 registers fewer
+EXPECTED_VGPRS = {(0, True, 1, False, True): 97, (0, True, 1, True, True): 127, (1, True, 1, False, True): 96, (2, True, 1, False, True): 107,
+                  (0, False, 1, False): 123, (0, False, 1, True): 166, (0, True, 1, False): 104, (0, True, 1, True): 159, (1, False, 1, False): 119, (1, True, 1, False): 103, (2, False, 1, False): 133, (2, True, 1, False): 114, (3, False, 0, False): 91, (3, False, 0, True): 125, (3, True, 0, False): 87, (3, True, 0, True): 118, (4, False, 1, True): 174, (4, True, 1, True): 167}
 
 
 def test_register_allocation_of_the_tally_kernel_is_the_measured_one():
@@ -59,7 +62,8 @@ def test_register_allocation_of_the_tally_kernel_is_the_measured_one():
     for name, r in res.items():
         if "tally_population_kernel" in name:
             t = name.split("tally_population_kernelILi")[1]  # <dictionary mode>ELb<trusted>ELi<record format>ELb<packed>EEEv...
-            got[(int(t[0]), t[4] == "1", int(t[8]), t[12] == "1")] = r["VGPRs"]
+            key = (int(t[0]), t[4] == "1", int(t[8]), t[12] == "1")
+            got[key + (True,) if t[16] == "1" else key] = r["VGPRs"]
     assert got == EXPECTED_VGPRS, got
 
 

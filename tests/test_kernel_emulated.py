@@ -53,7 +53,11 @@ def test_random_valid_streams_trusted_variant(seed):
         off.append(off[-1] + n_rec)
     records = np.concatenate(recs)
     assert pyemu.validate_alerts(records, n_nodes, K, cfg, member)[0]
+    before = pyemu.CURRENT_RUNS
     _check(records, np.array(off), n_nodes, K, H, L, cfg, obs, subj, member, seed=seed)
+    # every record carries the view's configuration id: the trusted run was taken twice -- comparing the ids per delivery, and by the
+    # instantiation that never loads them (kCurrent, what the product launches for such a round) -- with equal results
+    assert pyemu.CURRENT_RUNS == before + 1
 
 
 @pytest.mark.parametrize("seed", range(10))
