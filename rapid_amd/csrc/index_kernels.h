@@ -927,20 +927,18 @@ __host__ __device__ inline unsigned int gen_mix32(unsigned int x) {  // murmur3'
     return x ^ (x >> 16);
 }
 struct GenPerm {
-    unsigned int rk[4];        // round keys
+    unsigned int rk[2];        // round keys
     unsigned long long keepk;  // key of the per-batch delivery draw
     unsigned int n;            // batches
     unsigned int s;            // the right half has s bits: a = 1 << s
     unsigned int mask_r;       // a - 1
-    unsigned int b;            // radix of the left half: ceil(n / a)
+    unsigned int b;            // radix of the left half: ceil(n / a) <= 2^16
 };
 __host__ __device__ inline GenPerm gen_perm_make(unsigned long long seed, unsigned int receiver_node, unsigned int n_batches) {
     GenPerm g;
     const unsigned long long key = gen_mix64(seed + (unsigned long long)receiver_node);
     g.rk[0] = (unsigned int)(gen_mix64(key + 1ull) >> 32);  // (spelled out: a loop over rk[] left the round keys in scratch memory)
     g.rk[1] = (unsigned int)(gen_mix64(key + 2ull) >> 32);
-    g.rk[2] = (unsigned int)(gen_mix64(key + 3ull) >> 32);
-    g.rk[3] = (unsigned int)(gen_mix64(key + 4ull) >> 32);
     g.keepk = gen_mix64(key ^ 0xD1B54A32D192ED03ull);
     g.n = n_batches;
     unsigned int s = 1;
@@ -951,20 +949,27 @@ __host__ __device__ inline GenPerm gen_perm_make(unsigned long long seed, unsign
     if (g.b == 0u) g.b = 1u;
     return g;
 }
-__host__ __device__ inline unsigned int gen_scale(unsigned int x, unsigned int b) {  // x in [0, 2^32) -> [0, b)
-    return (unsigned int)(((unsigned long long)x * (unsigned long long)b) >> 32);
+// The round function: sixteen pseudo-random bits of a half position x < 2^16 under a round key.  Both multiplies take 24-bit
+// operands -- one full-rate v_mul_u32_u24 each where a 32-bit multiply costs four issue slots; the generator is arithmetic-bound
+// (round 5: ~1,100 cycles per 64 deliveries, a third of them the permutation's eight 32-bit multiplies and two 64-bit scalings).
+__host__ __device__ inline unsigned int gen_f16(unsigned int x, unsigned int k) {
+    unsigned int h = ((x ^ k) & 0xFFFFFFu) * 0x9E3779u;
+    h ^= h >> 15;
+    h = (h & 0xFFFFFFu) * 0x85EBCBu;
+    return h >> 16;
 }
-__host__ __device__ inline unsigned int gen_perm_at(const GenPerm& g, unsigned int j) {  // j < n -> the batch delivered j-th
+// j < n -> the batch delivered j-th: a two-round alternating Feistel network on [0, b) x [0, a) -- the left half moved by a function
+// of the right one, then the right half by a function of the new left one; each step is a bijection whatever the function, so the
+// whole is, and consecutive positions (one left half, consecutive right halves) land on unrelated batches -- walked until it lands
+// below n (the domain a * b exceeds n by less than a: one position in hundreds takes a second step).
+__host__ __device__ inline unsigned int gen_perm_at(const GenPerm& g, unsigned int j) {
     if (g.n <= 1u) return 0u;
     unsigned int x = j;
     do {
         unsigned int r = x & g.mask_r, l = x >> g.s;
-        l += gen_scale(gen_mix32(r + g.rk[0]), g.b);
+        l += (gen_f16(r, g.rk[0]) * (g.b & 0xFFFFFFu)) >> 16;  // (16 bits x at most 16 bits) -> [0, b); the mask says so to the compiler: v_mul_u32_u24
         l -= l >= g.b ? g.b : 0u;
-        r = (r + gen_mix32(l + g.rk[1])) & g.mask_r;
-        l += gen_scale(gen_mix32(r + g.rk[2]), g.b);
-        l -= l >= g.b ? g.b : 0u;
-        r = (r + gen_mix32(l + g.rk[3])) & g.mask_r;
+        r = (r + gen_f16(l, g.rk[1])) & g.mask_r;
         x = (l << g.s) | r;
     } while (x >= g.n);
     return x;
@@ -1069,11 +1074,7 @@ __global__ __launch_bounds__(kGenWavesPerBlock * 64) void gen_streams_kernel(con
 #pragma unroll
         for (int u = 0; u < kGenChunks; ++u) {
             if (j0 + 64 * u >= n_batches) continue;  // (wave-uniform; `continue`, so that the loop unrolls and first[] / len[] stay in registers)
-            int incl = (int)len[u];
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += o;
-            }
+            const int incl = wave_inclusive_sum((int)len[u]);  // (seven adds on the DPP paths: stream_load.h)
             const int start = incl - (int)len[u];
             const int total = __shfl(incl, 63, 64);
             const bool any_long = __ballot(len[u] > (unsigned int)kGenLaneLoop) != 0ull;

@@ -49,6 +49,21 @@ __device__ __forceinline__ void stream_load2(stream_rsrc_t rsrc, unsigned int la
     b = v.y;
 }
 
+// Inclusive prefix sum over the wave's 64 lanes: seven adds whose second operand arrives over the data-parallel-primitive paths
+// (shifts inside the rows of 16 lanes, then the row totals broadcast) -- no trip through the LDS crossbar, where the six
+// ds_bpermute steps of a shuffle scan each cost a round trip the adds behind them wait for.
+__device__ __forceinline__ int wave_inclusive_sum(int x) {
+    int s = x;
+    s += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  // row_shr:1
+    s += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);  // row_shr:2
+    s += __builtin_amdgcn_update_dpp(0, x, 0x113, 0xf, 0xf, true);  // row_shr:3: s = x[i-3 .. i] within the row
+    s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xe, true);  // row_shr:4 into lanes 4 .. 15 of every row
+    s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xc, true);  // row_shr:8 into lanes 8 .. 15: every row holds its own prefix sums
+    s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1 and 3: the total of the row before
+    s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2 and 3: the total of the first two rows
+    return s;
+}
+
 // Four dwords / one dword, same addressing (measurement variants of the boundary-record loads).
 typedef unsigned int stream_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void stream_load4(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int imm, unsigned int& a, unsigned int& b,

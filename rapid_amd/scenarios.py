@@ -253,14 +253,23 @@ def mix32(x):
 def _perm_keys(seed, receiver):
     with np.errstate(over="ignore"):
         key = mix64(np.uint64(int(seed) & _M64) + np.uint64(int(receiver) & 0xFFFFFFFF))
-        rk = [np.uint32(int(mix64(key + np.uint64(i + 1))) >> 32) for i in range(4)]
+        rk = [np.uint32(int(mix64(key + np.uint64(i + 1))) >> 32) for i in range(2)]
         keepk = mix64(key ^ np.uint64(0xD1B54A32D192ED03))
     return rk, keepk
 
 
+def _f16(x, k):
+    """csrc/index_kernels.h: gen_f16 -- sixteen pseudo-random bits of a half position under a round key (24-bit multiplies)."""
+    m24 = np.uint32(0xFFFFFF)
+    h = ((x ^ k) & m24) * np.uint32(0x9E3779)
+    h = h ^ (h >> np.uint32(15))
+    h = (h & m24) * np.uint32(0x85EBCB)
+    return h >> np.uint32(16)
+
+
 def hashed_order(seed, receiver, n_batches):
     """The order in which rapid_sim_generate delivers the round's batches to `receiver` (its node index): position j holds
-    batch perm(j), a four-round alternating Feistel network on [0, b) x [0, a) -- a = the power of two at or above
+    batch perm(j), a two-round alternating Feistel network on [0, b) x [0, a) -- a = the power of two at or above
     sqrt(n_batches), b = ceil(n_batches / a) --, keyed by mix64(seed + receiver), walked until it lands below n_batches
     (csrc/index_kernels.h: gen_perm_at)."""
     n = int(n_batches)
@@ -272,22 +281,15 @@ def hashed_order(seed, receiver, n_batches):
         s += 1
     mask_r = np.uint32((1 << s) - 1)
     b = np.uint32(max(1, (n + (1 << s) - 1) >> s))
-
-    def scale(x):  # [0, 2^32) -> [0, b)
-        return ((x.astype(np.uint64) * np.uint64(b)) >> np.uint64(32)).astype(np.uint32)
-
     x = np.arange(n, dtype=np.uint32)
     out = np.zeros(n, dtype=np.int64)
     todo = np.arange(n)
     with np.errstate(over="ignore"):
         while len(todo):
             r, l = x & mask_r, x >> np.uint32(s)
-            l = l + scale(mix32(r + rk[0]))
+            l = l + ((_f16(r, rk[0]) * b) >> np.uint32(16))
             l = np.where(l >= b, l - b, l)
-            r = (r + mix32(l + rk[1])) & mask_r
-            l = l + scale(mix32(r + rk[2]))
-            l = np.where(l >= b, l - b, l)
-            r = (r + mix32(l + rk[3])) & mask_r
+            r = (r + _f16(l, rk[1])) & mask_r
             x = (l << np.uint32(s)) | r
             done = x < n
             out[todo[done]] = x[done]

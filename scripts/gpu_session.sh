@@ -48,6 +48,17 @@ PY
       cd /tmp; rm -rf "$R/gpurun_out/prof_bench"
       timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_bench" -o bench -- python "$R/bench.py" --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > "$R/gpurun_out/bench_traced.json" 2> "$R/gpurun_out/prof_bench.log"
       cd "$R"; head -12 gpurun_out/prof_bench/bench_kernel_stats.csv | cut -c1-200 ;;
+    kstats:*)     # kstats:<config>[:extra flags] -- kernel statistics of another configuration's bench run
+      IFS=: read -r _ cfg extra <<< "$section"
+      cd /tmp; rm -rf "$R/gpurun_out/prof_bench_$cfg"
+      timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_bench_$cfg" -o bench -- python "$R/bench.py" --gpus 1 --config "$cfg" $extra --no-cpu-baseline --no-pmc > "$R/gpurun_out/bench_traced_$cfg.json" 2> "$R/gpurun_out/prof_bench_$cfg.log"
+      cd "$R"; python - "$cfg" <<'PY'
+import csv, glob, sys
+f = glob.glob("gpurun_out/prof_bench_%s/**/*kernel_stats.csv" % sys.argv[1], recursive=True)
+for row in list(csv.DictReader(open(f[0])))[:12]:
+    print("%-72s calls %6s avg %10.1f us  total %8.1f ms" % (row["Name"][:72], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["TotalDurationNs"]) / 1e6))
+PY
+      ;;
     c5stream)     # BASELINE configs[4] rounds on a receiver sample (scripts/c5_stream.py)
       timeout 600 python scripts/c5_stream.py 1000000 3 1024 > gpurun_out/c5_1m.jsonl 2> gpurun_out/c5.err; cut -c1-420 gpurun_out/c5_1m.jsonl; tail -2 gpurun_out/c5.err ;;
     *) echo "unknown section $section" ;;

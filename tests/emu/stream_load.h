@@ -37,6 +37,30 @@ inline void stream_load4(stream_rsrc_t rsrc, unsigned int lane_off, unsigned int
     stream_load1(rsrc, lane_off, imm + 12u, d);
 }
 
+// One data-parallel-primitive move as the hardware defines it (the controls wave_inclusive_sum uses: row_shr:n, row_bcast:15,
+// row_bcast:31): a disabled lane (its row / bank not in the masks) keeps `old`, a lane whose source lies outside gets 0 (bound_ctrl).
+inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask) {
+    const int lane = (int)(threadIdx.x & 63u), row = lane >> 4, in_row = lane & 15, bank = in_row >> 2;
+    int from = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11f) from = in_row >= (ctrl & 15) ? lane - (ctrl & 15) : -1;
+    else if (ctrl == 0x142) from = row >= 1 ? row * 16 - 1 : -1;
+    else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;
+    const int v = __shfl(src, from < 0 ? lane : from, 64);  // (every lane takes part in the exchange)
+    const bool enabled = ((row_mask >> row) & 1) != 0 && ((bank_mask >> bank) & 1) != 0;
+    return !enabled ? old : from < 0 ? 0 : v;
+}
+inline int wave_inclusive_sum(int x) {  // the same seven steps as csrc/stream_load.h
+    int s = x;
+    s += emu_update_dpp(0, x, 0x111, 0xf, 0xf);
+    s += emu_update_dpp(0, x, 0x112, 0xf, 0xf);
+    s += emu_update_dpp(0, x, 0x113, 0xf, 0xf);
+    s += emu_update_dpp(0, s, 0x114, 0xf, 0xe);
+    s += emu_update_dpp(0, s, 0x118, 0xf, 0xc);
+    s += emu_update_dpp(0, s, 0x142, 0xa, 0xf);
+    s += emu_update_dpp(0, s, 0x143, 0xc, 0xf);
+    return s;
+}
+
 inline long long stream_scalar_load(const long long* p) { return *p; }
 inline unsigned int stream_scalar_load32(const unsigned int* p) { return *p; }
 inline void stream_store(int* p, int v) { *p = v; }
