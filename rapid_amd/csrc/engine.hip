@@ -230,6 +230,7 @@ struct rapid_engine {
     // ---- a round taken tile by tile (rapid_sim_round_tiled) ----
     long long out_base = 0;      // receiver offset of the running tile in the per-receiver result arrays (0 outside a tiled round)
     int tiled_total = 0;         // receivers of the last tiled round (its per-receiver results cover all of them), 0: none
+    const unsigned long long* tiled_block = nullptr;  // ... and the answer block its last pass left for the all-gather (d_gather)
     int tiled_last_base = 0, tiled_last_n = 0;  // the tile whose proposals are still resident (rapid_sim_proposal)
     DevBuf<unsigned long long> d_vacc;  // vote accumulator: acc[8] | candidate bitmap | candidate list (vote_kernels.h)
     double tiled_ms[4] = {0, 0, 0, 0};  // the last tiled round: total wall, tiles, passes, records delivered / 1e6
@@ -1773,6 +1774,7 @@ int rapid_cd_clear(rapid_cd* cd) {
 static void streams_replaced(rapid_engine* h, int n_receivers, long long n_rec) {
     h->out_base = 0;
     h->tiled_total = 0;
+    h->tiled_block = nullptr;
     h->n_receivers = n_receivers;
     h->n_records_total = n_rec;
     h->n_alert_set = -1;
@@ -2366,6 +2368,12 @@ int rapid_debug_vote_segment(rapid_engine* h, void* out, int64_t cap_bytes, int6
     *seg_bytes = (int64_t)(seg_words * 8);
     if (!out) return RAPID_OK;
     if (cap_bytes < *seg_bytes) return fail(h, RAPID_ECAPACITY, "segment needs %lld bytes", (long long)*seg_bytes);
+    if (h->tiled_total > 0 || h->tiled_block != nullptr) {  // a tiled round: the block its last pass left for the all-gather
+        if (h->tiled_block == nullptr) return fail(h, RAPID_ESTATE, "the tiled round left no answer block");
+        HIPCHK(h, hipMemcpyAsync(out, h->tiled_block, seg_words * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return RAPID_OK;
+    }
     HIPCHK(h, h->d_voteback.ensure(seg_words));
     h->tally_votes_valid = false;
     unsigned long long* const d_res = h->d_voteback.p;
@@ -2448,6 +2456,7 @@ int rapid_sim_round_tiled(rapid_engine* h, const rapid_alert_record* alerts, con
     h->tallied = false;
     h->have_decision = false;
     h->tiled_total = 0;
+    h->tiled_block = nullptr;
     h->out_base = 0;
     HIPCHK(h, h->d_alert_set.ensure((size_t)std::max<long long>(A, 1) * 20 + 16));
     HIPCHK(h, h->d_gen_boff.ensure((size_t)n_batches + 1));
@@ -2637,6 +2646,7 @@ int rapid_sim_round_tiled(rapid_engine* h, const rapid_alert_record* alerts, con
     h->out_base = 0;
     h->n_receivers = R;
     h->tiled_total = R;
+    h->tiled_block = d_block;
     h->tallied = true;
     h->tiled_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     h->tiled_ms[1] = tiles;

@@ -1823,6 +1823,30 @@ def test_round_taken_tile_by_tile_accumulates_the_votes(E, test_build):
                     sim.tally()
                 with pytest.raises(E.RapidError):
                     sim.count_votes()
+    # ---- the round sharded over three ranks: every rank takes ITS receivers tile by tile and contributes the block its last pass
+    # left for the all-gather; the merge every rank then runs (vote_merge_kernel) must decide what the whole population decides ----
+    sim.generate(sc.batches, rx, seed, trust_copies=True)
+    sim.tally()
+    rr1 = sim.count_votes()
+    cut1 = sim.decided_cut()
+    cuts = [0, len(rx) // 3, len(rx) // 3 + 500, len(rx)]
+    segs = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        rr = sim.round_tiled(sc.batches, rx[a:b], seed, tile_receivers=200)
+        assert rr.decided == 0 and rr.votes_winner == rr.votes_total == b - a  # (a shard alone: unanimous, no quorum)
+        segs.append(sim.vote_segment())
+    status, rr = sim.merge_vote_segments(segs)
+    assert status == 1 and (rr.decided, rr.cut_size, rr.votes_total, rr.votes_winner, rr.quorum) == (1, rr1.cut_size, len(rx), len(rx), rr1.quorum)
+    assert sim.decided_cut() == cut1
+    # ... and through a real (one-rank) RCCL communicator: the all-gather + merge of the tiled round, and -- for the round below, in
+    # which the first candidate has no quorum -- the histogram all-reduce and the max-reduce of the exact plurality
+    eng_c, _ = make_engine(E, pop, K, H, L, members=list(range(n)))
+    eng_c.comm_init(E.comm_unique_id(), 0, 1)
+    sim_c = E.ClusterSimulation(eng_c)
+    rr = sim_c.round_tiled(sc.batches, rx, seed, tile_receivers=256)
+    assert (rr.decided, rr.votes_winner, rr.votes_total, rr.cut_size, rr.quorum) == (1, rr1.votes_winner, rr1.votes_total, rr1.cut_size, rr1.quorum)
+    assert sim_c.decided_cut() == cut1 and sim_c.round_tiled_info()["passes"] == 1
+
     # ---- the lowest voter dissents, a quorum agrees ----
     # one more "batch": a single alert naming a healthy member on all K rings (a legal AlertMessage with K ring numbers), which
     # reaches nine receivers in ten; the others propose the cut without it.  The seed is chosen so that receiver 0 is one of them.
@@ -1850,6 +1874,11 @@ def test_round_taken_tile_by_tile_accumulates_the_votes(E, test_build):
             assert all(np.array_equal(a, b) for a, b in zip(want, sim.results()))
             assert (rr.decided, rr.votes_winner, rr.votes_total, rr.cut_size) == (1, rr1.votes_winner, rr1.votes_total, len(cut1)) and sim.decided_cut() == cut1
             assert sim.round_tiled_info()["passes"] == 2
+        rr = sim_c.round_tiled(bs, rx, s2, tile_receivers=300, keep=keep, boundary=boundary)  # (the one-rank communicator)
+        assert all(np.array_equal(a, b) for a, b in zip(want, sim_c.results()))
+        assert (rr.decided, rr.votes_winner, rr.votes_total, rr.cut_size) == (1, rr1.votes_winner, rr1.votes_total, len(cut1)) and sim_c.decided_cut() == cut1
+        assert sim_c.round_tiled_info()["passes"] == 2
+    eng_c.close()
     # ... and nobody has a quorum when four receivers in ten dissent: undecided, after ONE pass over the population
     keep[-1] = int(0.5 * 0xFFFFFFFF)
     rr = sim.round_tiled(bs, rx, s2, tile_receivers=300, keep=keep)
