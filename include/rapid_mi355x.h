@@ -225,7 +225,13 @@ int rapid_sim_set_alert_set_device(rapid_engine* h, const void* d_alerts, uint64
  * silently runs the per-delivery filter instead and drops those records as the reference does (:653-657).  Checked per
  * delivery either way: UP / DOWN against the membership, rings covered by the index -> RAPID_EINVAL as above.  A delivered
  * record that passes these checks passes the reference's filter, so the results are the reference's for ANY stream that is
- * accepted, not only for byte copies of the declared alerts. */
+ * accepted, not only for byte copies of the declared alerts.
+ * on == 2 adds the ONE thing on this path that rests on the caller's word: no delivered record carries another configuration id
+ * (no late deliveries among them).  If, in addition, every declared alert is of the engine's configuration, the tally then does
+ * not read the records' configuration ids at all -- one 8-byte load per record ({dst, word}) instead of two, the ids stay in the
+ * cache lines (~3 % of the kernel at N = 10^4) -- and a late delivery that is there all the same is tallied as if it were current.
+ * The library takes that path by itself, on its own knowledge, for the boundary records it lays down (rapid_sim_generate,
+ * rapid_sim_round_tiled with RAPID_GEN_BOUNDARY).  Anything but 0, 1, 2: RAPID_EINVAL. */
 int rapid_sim_trust_alert_copies(rapid_engine* h, int32_t on);
 /* Starts another round over the streams (and the declared alert set) that are loaded: the per-round index is built again
  * by the next tally, as it is after a load.  What a round costs = index + tally + vote count; bench.py times exactly that. */
@@ -449,8 +455,9 @@ int rapid_sim_time_tally(rapid_engine* h, int32_t reps, float* ms_avg);
  * slot (boundary records: 1 = direct tables in LDS, 2 = compressed tables in LDS, 0 = tables in memory, read through L2 --
  * chosen by what fits the LDS next to the receivers' detector state; 3 = nowhere: generated resolved records carry their
  * subjects' entries), bit 0: alert set declared, bit 1: a hot member's memoised observers are stale in this round (Q4 is
- * live), bit 2: the records are pre-validated boundary records of the engine's own configuration -- the tally leaves their
- * configuration ids in the cache lines (one load per record)}; index_ms = device time of the last index build that was timed: a call that asks (index_ms != NULL) has the
+ * live), bit 2: the records are pre-validated boundary records known to be of the engine's own configuration (laid down by the
+ * library, or vouched for at level 2 of rapid_sim_trust_alert_copies) -- the tally leaves their configuration ids in the cache
+ * lines (one load per record)}; index_ms = device time of the last index build that was timed: a call that asks (index_ms != NULL) has the
  * NEXT build bracketed by timing events -- this call's own if the index is stale; 0 before the
  * first timed build.  Rounds nobody asks about carry no timing events. */
 int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms);
@@ -470,8 +477,8 @@ int rapid_sim_pass_times(rapid_engine* h, float out[4]);
  * buckets of one-byte remainders (exact; slots renumbered in hash order) instead of looking subjects up in memory, where the round
  * is eligible (every named subject hot, at most 2^21 nodes), 2097152 = a tiled round (rapid_sim_round_tiled) makes and tallies its
  * tiles strictly one after the other on one stream (by default the next tile's deliveries are made on a second stream while this
- * tile is tallied), 4194304 = pre-validated boundary records of the engine's own configuration still have their configuration
- * ids loaded and compared per delivery (by default they stay in the cache lines: one load per record instead of two),
+ * tile is tallied), 4194304 = boundary records known to be of the engine's own configuration still have their configuration
+ * ids loaded and compared per delivery (see rapid_sim_trust_alert_copies, level 2),
  * 32 = measurement only: stream the records through
  * the registers without tallying them (results are meaningless).  Every bit selects another PRODUCT path or instantiation
  * (all of them parity-tested); none adds code that the default does not ship. */

@@ -185,6 +185,8 @@ struct rapid_engine {
     bool trusted = false, all_down = false;
     bool all_current = false;  // every alert the round index saw carries the engine's configuration id
     bool trust_copies = false;  // the caller vouches that the deliveries are copies of the declared alerts (rapid_sim_trust_alert_copies)
+    bool no_late_copies = false;     // ... and (level 2) that none of them carries another configuration id: no late deliveries among them
+    bool streams_generated = false;  // the delivered records were laid down by the library itself, from the declared alerts
     DevBuf<unsigned int> d_loadflags;
     DevBuf<unsigned int> d_adj;
     hipEvent_t ev_idx0 = nullptr, ev_idx1 = nullptr;  // around the round-index kernels; read lazily (rapid_sim_index_info)
@@ -1071,6 +1073,16 @@ bool tally_is_trusted(const rapid_engine* h) {
     return h->trust_copies;
 }
 
+// Boundary records whose configuration ids need not be read (tally_kernel.h: kCurrent): pre-validated, every alert of the round
+// index of the engine's configuration, and every delivered record KNOWN to be a copy of one of them -- because the library laid the
+// records down itself (rapid_sim_generate / rapid_sim_round_tiled), or because the caller says so at level 2 of
+// rapid_sim_trust_alert_copies (the one thing on this path that rests on the caller's word: level 1 compares the ids per delivery
+// and drops late deliveries of an earlier configuration, R/MembershipService.java:653-657).  Testing knob bit 22: never.
+bool records_known_current(const rapid_engine* h) {
+    return tally_is_trusted(h) && h->all_current && h->n_alert_set >= 0 && h->rec_fmt == rapid::kFmtBoundary && (h->force_exact & 4194304) == 0 &&
+           (h->streams_generated || h->no_late_copies);
+}
+
 int launch_tally(rapid_engine* h) {
     rapid::TallyParams p;
     p.core = h->d_records;
@@ -1144,7 +1156,7 @@ int launch_tally(rapid_engine* h) {
     using namespace rapid;
     // pre-validated boundary records of ONE configuration -- the engine's: their configuration ids stay in the cache lines
     // (tally_kernel.h: kCurrent; testing knob bit 22: compared per delivery all the same)
-    if (trusted && h->all_current && h->rec_fmt == kFmtBoundary && (h->force_exact & 4194304) == 0) {
+    if (records_known_current(h)) {
         if (h->packed && h->dict_mode == kDictMemory) {
             hipLaunchKernelGGL((tally_population_kernel<kDictMemory, true, kFmtBoundary, true, true>), grid, block, lds, h->stream, p);
             return RAPID_OK;
@@ -1775,6 +1787,7 @@ static void streams_replaced(rapid_engine* h, int n_receivers, long long n_rec) 
     h->out_base = 0;
     h->tiled_total = 0;
     h->tiled_block = nullptr;
+    h->streams_generated = false;
     h->n_receivers = n_receivers;
     h->n_records_total = n_rec;
     h->n_alert_set = -1;
@@ -1968,6 +1981,7 @@ int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const 
     streams_replaced(h, n_receivers, total);
     h->n_alert_set = A;  // (streams_replaced forgets a declared set: this one is the streams' own)
     h->d_alerts = h->d_alert_set.p;
+    h->streams_generated = true;
     h->index_valid = index_valid;  // (resolved: the index the entries come from; rapid_sim_new_round builds it again -- same numbering)
     return RAPID_OK;
 }
@@ -2053,8 +2067,10 @@ int rapid_sim_set_alert_set_device(rapid_engine* h, const void* d_alerts, uint64
 
 int rapid_sim_trust_alert_copies(rapid_engine* h, int32_t on) {
     if (!h) return RAPID_EINVAL;
+    if (on < 0 || on > 2) return RAPID_EINVAL;
     if (h->trust_copies != (on != 0)) h->index_valid = false;  // (another instantiation, maybe another launch geometry)
     h->trust_copies = on != 0;
+    h->no_late_copies = on == 2;
     return RAPID_OK;
 }
 
@@ -2497,6 +2513,7 @@ int rapid_sim_round_tiled(rapid_engine* h, const rapid_alert_record* alerts, con
     h->gen_clean = clean && batch_keep == nullptr;
     // the deliveries are made here, by the library, from the declared alerts: it can vouch for them being copies itself
     h->trust_copies = true;
+    h->streams_generated = true;
     HIPCHK(h, h->d_errflags.ensure(2));
     HIPCHK(h, h->d_stats.ensure(stats_words(h)));
     const size_t res_words = 10, ref_len = (size_t)h->max_cut + 1;
@@ -2905,7 +2922,7 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
     info[5] = tally_is_trusted(h) ? 1 : 0;
     info[6] = h->dict_mode;  // 3 = resolved records (no lookup in the tally); 0 / 1 / 2 = tables in memory / direct in LDS / compressed in LDS
     // (bit 2: the tally runs the instantiation that leaves the records' configuration ids in their cache lines -- launch_tally)
-    const bool ids_skipped = tally_is_trusted(h) && h->all_current && h->rec_fmt == rapid::kFmtBoundary && (h->force_exact & 4194304) == 0 &&
+    const bool ids_skipped = records_known_current(h) &&
                              (h->dict_mode == rapid::kDictMemory || (!h->packed && (h->dict_mode == rapid::kDictDirect || h->dict_mode == rapid::kDictCompressed)));
     info[7] = (h->n_alert_set >= 0 ? 1 : 0) | (h->q4_live ? 2 : 0) | (ids_skipped ? 4 : 0);
     if (h->index_ms_pending && h->ev_idx0 && h->ev_idx1) {

@@ -656,8 +656,9 @@ __host__ __device__ constexpr int tally_max_waves(int dict_mode, bool trusted, i
 #define RAPID_TALLY_OCCUPANCY
 #endif
 // kCurrent (pre-validated boundary records only): every alert the round index saw carries the engine's configuration id, and the
-// deliveries are vouched-for copies of them -- so does every delivered record, and its configuration id need not travel from the
-// cache line to the registers at all: ONE buffer_load_dwordx2 per record ({dst, word}, non-temporal: nothing asks for the line
+// deliveries are KNOWN to be copies of them -- the library laid them down itself, or the caller vouches for it at level 2 of
+// rapid_sim_trust_alert_copies (engine.hip: records_known_current; the plain trusted instantiation compares the ids and drops late
+// deliveries) -- so does every delivered record, and its configuration id need not travel from the cache line to the registers at all: ONE buffer_load_dwordx2 per record ({dst, word}, non-temporal: nothing asks for the line
 // again) instead of two, no 64-bit compare, eight registers fewer per window in flight.  The bytes that cross the HBM interface
 // are the same 20 per record (the lines are the same); what is saved is the second request per line between L2 and the CU
 // (scripts/micro/boundary_shapes.hip, shape 2 against shape 0: 6.6 against 6.1 TB/s with nothing else going on).

@@ -368,11 +368,13 @@ class ClusterSimulation:
         return subj[:n], words[:n]
 
     def set_alert_set(self, alerts, trust_copies=False):
-        """Declares the round's distinct alerts (see rapid_sim_set_alert_set).  trust_copies: the caller vouches that every
-        delivered record is a byte copy of one of them, configuration id included (rapid_sim_trust_alert_copies)."""
+        """Declares the round's distinct alerts (see rapid_sim_set_alert_set).  trust_copies (rapid_sim_trust_alert_copies): True / 1 =
+        asks for the pre-validated instantiation (granted on verified facts; late deliveries of another configuration are still
+        dropped per delivery); 2 = the caller also vouches that NO delivered record carries another configuration id -- the records'
+        configuration ids are then not read at all (this one rests on the caller's word)."""
         alerts = np.ascontiguousarray(alerts, dtype=ALERT_DTYPE)
         self.e._check(self.e._lib.rapid_sim_set_alert_set(self.e._h, _addr(alerts) if len(alerts) else None, len(alerts)))
-        self.e._check(self.e._lib.rapid_sim_trust_alert_copies(self.e._h, 1 if trust_copies else 0))
+        self.e._check(self.e._lib.rapid_sim_trust_alert_copies(self.e._h, int(trust_copies)))
 
     def set_alert_set_device(self, d_alerts_ptr, n_alerts, trust_copies=False, keepalive=None, alerts_bytes=None):
         """The round's distinct alerts, already in device memory (rapid_sim_set_alert_set_device): read in place.
@@ -380,7 +382,7 @@ class ClusterSimulation:
         self._keep_alerts = keepalive
         nbytes = 20 * int(n_alerts) if alerts_bytes is None else int(alerts_bytes)
         self.e._check(self.e._lib.rapid_sim_set_alert_set_device(self.e._h, d_alerts_ptr, nbytes, n_alerts))
-        self.e._check(self.e._lib.rapid_sim_trust_alert_copies(self.e._h, 1 if trust_copies else 0))
+        self.e._check(self.e._lib.rapid_sim_trust_alert_copies(self.e._h, int(trust_copies)))
 
     def tally(self):
         self.e._check(self.e._lib.rapid_sim_tally(self.e._h))

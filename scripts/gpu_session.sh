@@ -59,6 +59,26 @@ for row in list(csv.DictReader(open(f[0])))[:12]:
     print("%-72s calls %6s avg %10.1f us  total %8.1f ms" % (row["Name"][:72], row["Calls"], float(row["AverageNs"]) / 1e3, float(row["TotalDurationNs"]) / 1e6))
 PY
       ;;
+    gaps)         # the launch chain of a round (start / duration / gap of each kernel), from the kstats trace
+      python scripts/trace_gaps.py gpurun_out/prof_bench > gpurun_out/trace_gaps.txt 2>&1; tail -15 gpurun_out/trace_gaps.txt ;;
+    pmc_sq)       # SQ counters of the tally kernel, one group per pass (scripts/pmc_sq.sh) -> gpurun_out/sq_summary.txt
+      bash scripts/pmc_sq.sh > gpurun_out/sq_summary.txt 2>&1; tail -24 gpurun_out/sq_summary.txt ;;
+    pmc_traffic)  # FETCH_SIZE / WRITE_SIZE of the tally kernel, calibrated on the streaming probe (scripts/pmc_traffic.py)
+      cd /tmp
+      for c in FETCH_SIZE WRITE_SIZE; do
+        rm -rf "$R/gpurun_out/pmc_$c"
+        timeout 300 rocprofv3 --pmc $c --output-format csv -d "$R/gpurun_out/pmc_$c" -o pmc -- python "$R/scripts/prof_tally.py" C3b 3 > "$R/gpurun_out/pmc_$c.log" 2>&1
+      done
+      cd "$R"
+      sb=$(grep -h "^workload" gpurun_out/pmc_FETCH_SIZE.log | tail -1 | sed 's/.*stream_bytes \([0-9]*\).*/\1/')
+      python scripts/pmc_traffic.py "$(find gpurun_out/pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$sb" gpurun_out/pmc_traffic.json | tail -12
+      python - <<'PY'
+import csv, glob
+for f in glob.glob("gpurun_out/pmc_WRITE_SIZE/**/*counter_collection.csv", recursive=True):
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "tally_population" in r["Kernel_Name"]]
+    if v: print("tally WRITE_SIZE avg (KiB)", sum(v) / len(v), "launches", len(v))
+PY
+      ;;
     c5stream)     # BASELINE configs[4] rounds on a receiver sample (scripts/c5_stream.py)
       timeout 600 python scripts/c5_stream.py 1000000 3 1024 > gpurun_out/c5_1m.jsonl 2> gpurun_out/c5.err; cut -c1-420 gpurun_out/c5_1m.jsonl; tail -2 gpurun_out/c5.err ;;
     *) echo "unknown section $section" ;;

@@ -1121,6 +1121,73 @@ def test_c4_full_shard_against_fast_oracle(E):
     eng.close()
 
 
+def test_configuration_ids_left_in_the_cache_lines_only_when_known_current(E, test_build):
+    """Level 2 of rapid_sim_trust_alert_copies and the instantiation behind it (kCurrent: one load per boundary record, its
+    configuration id never read).  Over the four dictionary forms (direct / compressed tables in LDS, tables in memory, packed
+    state): level 2 gives level 1's results and the oracle's on streams of one configuration, and reports itself in the index
+    info; deliveries the library lays down itself take that path without anybody's word; a declared alert of another configuration
+    switches it off; and level 1 -- verified facts only -- drops a late delivery of the previous configuration per delivery
+    (R/MembershipService.java:653-657), where level 2 would have been the caller's mistake."""
+    K, H, L = 10, 9, 4
+    n = 3000
+    pop = S.Population.make(n)
+    eng, view = make_engine(E, pop, K, H, L)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_churn_scenario(obs, member, cfg, 30, 0, H, L, materialise=False)
+    rx = sc.receivers[:600]
+    records, rec_off, _ = S.deliver(sc.batches, rx, 5)
+    fe, fn, fo, fpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, records, rec_off, nthreads=8)
+    want = (fe, fn, np.diff(fo), proposal_fingerprints(fo, fpp, fe >= 0))
+    sim = E.ClusterSimulation(eng)
+    for knob, mode in ((0, 1), (128, 2), (256, 0), (8192, 0)):  # direct tables, compressed tables, tables in memory, packed state
+        for level in (1, 2):
+            sim.set_force_exact(knob)
+            sim.load_streams(records, rec_off)
+            sim.set_alert_set(sc.batches.recs, trust_copies=level)
+            sim.tally()
+            info = sim.index_info()
+            assert (info["alerts_prevalidated"], info["dict_mode"], info["configuration_ids_known_current"]) == (1, mode, int(level == 2)), (knob, level, info)
+            assert all(np.array_equal(a, b) for a, b in zip(want, sim.results())), (knob, level)
+    sim.set_force_exact(4194304)  # (knob: level 2 asked for, ids compared all the same)
+    sim.load_streams(records, rec_off)
+    sim.set_alert_set(sc.batches.recs, trust_copies=2)
+    sim.tally()
+    assert sim.index_info()["configuration_ids_known_current"] == 0 and all(np.array_equal(a, b) for a, b in zip(want, sim.results()))
+    sim.set_force_exact(0)
+    # the library's own deliveries (boundary records): known current without anybody saying so
+    sim.generate(sc.batches, rx, 11, boundary=True, trust_copies=True)
+    sim.tally()
+    assert sim.index_info()["configuration_ids_known_current"] == 1
+    got = [a.copy() for a in sim.results()]
+    recs_g, off_g, _ = S.deliver_hashed(sc.batches, rx, 11)
+    ge, gn, go, gpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, recs_g, off_g, nthreads=8)
+    assert np.array_equal(got[0], ge) and np.array_equal(got[1], gn) and np.array_equal(got[2], np.diff(go))
+    # ... unless the set it copies from holds alerts of another configuration (late batches): ids compared, copies dropped
+    both = S.with_late_batches(sc.batches, cfg - 1, 0.2, 5)
+    sim.generate(both, rx, 11, boundary=True, trust_copies=True)
+    sim.tally()
+    assert sim.index_info()["configuration_ids_known_current"] == 0
+    recs_l, off_l, _ = S.deliver_hashed(both, rx, 11)
+    le, ln, lo, lpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, recs_l, off_l, nthreads=8)
+    res = sim.results()
+    assert np.array_equal(res[0], le) and np.array_equal(res[1], ln) and np.array_equal(res[2], np.diff(lo))
+    # a late delivery among host-delivered records: level 1 drops it, as the oracle (and the reference) does
+    late = records.copy()
+    first = int(rec_off[3])  # the first record of receiver 3: a DOWN report, now of the previous configuration
+    late["cfg_id"][first] = cfg - 1
+    oe, on, oo, opp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, late, rec_off, nthreads=8)
+    sim.load_streams(late, rec_off)
+    sim.set_alert_set(sc.batches.recs, trust_copies=1)
+    sim.tally()
+    res = sim.results()
+    assert sim.index_info()["alerts_prevalidated"] == 1 and sim.index_info()["configuration_ids_known_current"] == 0
+    assert np.array_equal(res[0], oe) and np.array_equal(res[1], on) and np.array_equal(res[2], np.diff(oo))
+    with pytest.raises(E.IllegalArgumentException):
+        eng._check(eng._lib.rapid_sim_trust_alert_copies(eng._h, 3))
+    eng.close()
+
+
 # ------------------------------------------------------------------ C5: streaming rounds, stale records, quirk Q4
 def _oracle_decide(oview, K, H, L, pop, sc, cut):
     """decideViewChange on the oracle: it learns the joiners' NodeIds from the UP alerts (only the batches that carry one
