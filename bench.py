@@ -241,7 +241,8 @@ def main():
         fresh_round(0)
     traffic, traffic_source = (None, "not measured at %d ranks" % world)
     if world == 1 and rank == 0 and not args.no_pmc:
-        traffic, traffic_source = measure_traffic(cfgname)
+        per_byte, traffic_source = measure_traffic(cfgname)
+        traffic = int(per_byte * 20.0 * my_records) if per_byte else None
     # Accounting: SURVEY 8(d)'s unit -- 20 B per delivered record, the record as it crosses the boundary; every one of those
     # bytes is in a cache line the kernel pulls from HBM (src, 4 of the 20, is never loaded into a register), cross-checked by
     # the PMC traffic of the same launch.
@@ -714,7 +715,7 @@ def measure_traffic(cfgname):
     no tracing domains) over scripts/prof_tally.py, which replays the same workload and also runs the stream probe -- same
     access pattern, known byte count -- that calibrates the counter (MI355X_MICROARCH.md, HBM section: FETCH_SIZE is in
     KiB and under-reports wide coalesced reads on gfx950 by ~2x; calibrate on a known byte count of your own pattern).
-    -> (bytes or None, how it was obtained)."""
+    -> (HBM bytes per delivered byte of the profiled launch, or None; how it was obtained)."""
     import csv
     import glob
     import shutil
@@ -747,7 +748,9 @@ def measure_traffic(cfgname):
             if not tally or not probe or not stream_bytes or sum(probe) == 0:
                 return None, "counter file without tally / probe rows"
             factor = stream_bytes / (1024.0 * sum(probe) / len(probe))
-            return int(1024.0 * sum(tally) / len(tally) * factor), \
+            # (per delivered byte of the profiled launch: scripts/prof_tally.py holds the configuration's WHOLE population, a rank
+            # of a sharded configuration one shard of it -- the caller scales by its own launch)
+            return 1024.0 * sum(tally) / len(tally) * factor / stream_bytes, \
                 "rocprofv3 --pmc FETCH_SIZE in this run, calibrated x%.3f on the stream probe (known byte count)" % factor
     except Exception as e:  # a measurement aid must not take the bench line down
         return None, "PMC pass failed: %s" % str(e)[:120]

@@ -79,8 +79,6 @@ for f in glob.glob("gpurun_out/pmc_WRITE_SIZE/**/*counter_collection.csv", recur
     if v: print("tally WRITE_SIZE avg (KiB)", sum(v) / len(v), "launches", len(v))
 PY
       ;;
-    c5stream)     # BASELINE configs[4] rounds on a receiver sample (scripts/c5_stream.py)
-      timeout 600 python scripts/c5_stream.py 1000000 3 1024 > gpurun_out/c5_1m.jsonl 2> gpurun_out/c5.err; cut -c1-420 gpurun_out/c5_1m.jsonl; tail -2 gpurun_out/c5.err ;;
     *) echo "unknown section $section" ;;
   esac
 done
