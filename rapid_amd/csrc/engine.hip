@@ -2414,6 +2414,7 @@ int rapid_debug_vote_merge(rapid_engine* h, const void* segments, int32_t n_rank
     begin_round_result(h, out);
     const size_t res_words = 10, ref_len = (size_t)h->max_cut + 1;
     const size_t seg_words = (res_words * 8 + ref_len * sizeof(int) + 7) / 8;
+    h->tiled_block = nullptr;  // (it lives in d_gather, which is about to be overwritten -- and maybe moved)
     HIPCHK(h, h->d_gather.ensure(seg_words * (size_t)n_ranks));
     hipStream_t st = h->stream;
     HIPCHK(h, hipMemcpyAsync(h->d_gather.p, segments, seg_words * 8 * (size_t)n_ranks, hipMemcpyHostToDevice, st));
