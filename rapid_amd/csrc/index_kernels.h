@@ -926,51 +926,75 @@ __host__ __device__ inline unsigned int gen_mix32(unsigned int x) {  // murmur3'
     x *= 0xC2B2AE35u;
     return x ^ (x >> 16);
 }
+// The delivery order of a receiver is a permutation with TWO levels: the batch list is cut into lines of kGenLine consecutive
+// batches (their table entries fill one 128-byte cache line), the LINES are delivered in a receiver-specific pseudo-random order,
+// the batches of a line one after the other in a line-and-receiver-specific order.  Why: lane l of a step fetches its batch's table
+// entry; with every position on a line of its own that is one cache-line fill per delivery -- 4 x 10^8 per 4,096 receivers at
+// N = 10^6, 1.9 of the generator's 3.1 ms, at the rate the GPU turns scattered addresses into lines (2.65 x 10^11 per second,
+// profiles/r05_gather_rate.txt; probe builds without the gather: profiles/r05_generator_probes.txt) -- and with eight positions per
+// line it is one fill per eight deliveries.  A receiver still gets every batch exactly once in an order of its own; what the two
+// levels give up is entropy nobody uses: which eight list neighbours arrive back to back (their subjects are unrelated: the list
+// is in sender order).
+constexpr unsigned int kGenLineBits = 3, kGenLine = 1u << kGenLineBits;
 struct GenPerm {
-    unsigned int rk[2];        // round keys
+    unsigned int rk[3];        // round keys: two for the order of the lines, one for the order inside a line
     unsigned long long keepk;  // key of the per-batch delivery draw
     unsigned int n;            // batches
-    unsigned int s;            // the right half has s bits: a = 1 << s
+    unsigned int lines;        // ceil(n / kGenLine)
+    unsigned int s;            // the right half of a line number has s bits: a = 1 << s
     unsigned int mask_r;       // a - 1
-    unsigned int b;            // radix of the left half: ceil(n / a) <= 2^16
+    unsigned int b;            // radix of the left half: ceil(lines / a) <= 2^16
 };
 __host__ __device__ inline GenPerm gen_perm_make(unsigned long long seed, unsigned int receiver_node, unsigned int n_batches) {
     GenPerm g;
     const unsigned long long key = gen_mix64(seed + (unsigned long long)receiver_node);
     g.rk[0] = (unsigned int)(gen_mix64(key + 1ull) >> 32);  // (spelled out: a loop over rk[] left the round keys in scratch memory)
     g.rk[1] = (unsigned int)(gen_mix64(key + 2ull) >> 32);
+    g.rk[2] = (unsigned int)(gen_mix64(key + 3ull) >> 32);
     g.keepk = gen_mix64(key ^ 0xD1B54A32D192ED03ull);
     g.n = n_batches;
+    g.lines = (n_batches + kGenLine - 1u) >> kGenLineBits;
     unsigned int s = 1;
-    while (s < 16u && (1ull << (2 * s)) < (unsigned long long)n_batches) ++s;  // a * a >= n
+    while (s < 16u && (1ull << (2 * s)) < (unsigned long long)g.lines) ++s;  // a * a >= lines
     g.s = s;
     g.mask_r = (1u << s) - 1u;
-    g.b = (unsigned int)(((unsigned long long)n_batches + g.mask_r) >> s);
+    g.b = (unsigned int)(((unsigned long long)g.lines + g.mask_r) >> s);
     if (g.b == 0u) g.b = 1u;
     return g;
 }
-// The round function: sixteen pseudo-random bits of a half position x < 2^16 under a round key.  Both multiplies take 24-bit
-// operands -- one full-rate v_mul_u32_u24 each where a 32-bit multiply costs four issue slots; the generator is arithmetic-bound
-// (round 5: ~1,100 cycles per 64 deliveries, a third of them the permutation's eight 32-bit multiplies and two 64-bit scalings).
+// The round function: sixteen pseudo-random bits of a half line number x < 2^16 under a round key.  Both multiplies take 24-bit
+// operands -- one full-rate v_mul_u32_u24 each where a 32-bit multiply costs four issue slots.
 __host__ __device__ inline unsigned int gen_f16(unsigned int x, unsigned int k) {
     unsigned int h = ((x ^ k) & 0xFFFFFFu) * 0x9E3779u;
     h ^= h >> 15;
     h = (h & 0xFFFFFFu) * 0x85EBCBu;
     return h >> 16;
 }
-// j < n -> the batch delivered j-th: a two-round alternating Feistel network on [0, b) x [0, a) -- the left half moved by a function
-// of the right one, then the right half by a function of the new left one; each step is a bijection whatever the function, so the
-// whole is, and consecutive positions (one left half, consecutive right halves) land on unrelated batches -- walked until it lands
-// below n (the domain a * b exceeds n by less than a: one position in hundreds takes a second step).
-__host__ __device__ inline unsigned int gen_perm_at(const GenPerm& g, unsigned int j) {
-    if (g.n <= 1u) return 0u;
-    unsigned int x = j;
+// q < lines -> the line delivered q-th: a two-round alternating Feistel network on [0, b) x [0, a) -- the left half moved by a
+// function of the right one, then the right half by a function of the new left one; each step is a bijection whatever the function
+// -- walked until it lands below `lines` (the domain a * b exceeds it by less than a).
+__host__ __device__ inline unsigned int gen_line_at(const GenPerm& g, unsigned int q) {
+    unsigned int x = q;
     do {
         unsigned int r = x & g.mask_r, l = x >> g.s;
         l += (gen_f16(r, g.rk[0]) * (g.b & 0xFFFFFFu)) >> 16;  // (16 bits x at most 16 bits) -> [0, b); the mask says so to the compiler: v_mul_u32_u24
         l -= l >= g.b ? g.b : 0u;
         r = (r + gen_f16(l, g.rk[1])) & g.mask_r;
         x = (l << g.s) | r;
+    } while (x >= g.lines);
+    return x;
+}
+// j < n -> the batch delivered j-th: position (q, t) = (j / 8, j % 8) holds batch 8 Q + T, Q = gen_line_at(q) and T = t under an
+// affine map of the line's eight places (an odd multiplier, an offset and a mask, all drawn from the line and the receiver); the map
+// (q, t) -> (Q, T) is a bijection of [0, 8 lines), walked until it lands below n (only places of the last line can lie beyond it).
+__host__ __device__ inline unsigned int gen_perm_at(const GenPerm& g, unsigned int j) {
+    if (g.n <= 1u) return 0u;
+    unsigned int x = j;
+    do {
+        const unsigned int Q = gen_line_at(g, x >> kGenLineBits);
+        const unsigned int h = gen_f16(Q & 0xFFFFu, g.rk[2] ^ (Q >> 16));
+        const unsigned int T = ((((x & (kGenLine - 1u)) ^ (h >> 8)) * ((h & 6u) | 1u)) + (h >> 3)) & (kGenLine - 1u);
+        x = (Q << kGenLineBits) | T;
     } while (x >= g.n);
     return x;
 }

@@ -253,13 +253,13 @@ def mix32(x):
 def _perm_keys(seed, receiver):
     with np.errstate(over="ignore"):
         key = mix64(np.uint64(int(seed) & _M64) + np.uint64(int(receiver) & 0xFFFFFFFF))
-        rk = [np.uint32(int(mix64(key + np.uint64(i + 1))) >> 32) for i in range(2)]
+        rk = [np.uint32(int(mix64(key + np.uint64(i + 1))) >> 32) for i in range(3)]
         keepk = mix64(key ^ np.uint64(0xD1B54A32D192ED03))
     return rk, keepk
 
 
 def _f16(x, k):
-    """csrc/index_kernels.h: gen_f16 -- sixteen pseudo-random bits of a half position under a round key (24-bit multiplies)."""
+    """csrc/index_kernels.h: gen_f16 -- sixteen pseudo-random bits of a half line number under a round key (24-bit multiplies)."""
     m24 = np.uint32(0xFFFFFF)
     h = ((x ^ k) & m24) * np.uint32(0x9E3779)
     h = h ^ (h >> np.uint32(15))
@@ -267,30 +267,53 @@ def _f16(x, k):
     return h >> np.uint32(16)
 
 
+GEN_LINE_BITS = 3  # (csrc/index_kernels.h: kGenLineBits -- eight batches per line of the delivery order)
+
+
 def hashed_order(seed, receiver, n_batches):
-    """The order in which rapid_sim_generate delivers the round's batches to `receiver` (its node index): position j holds
-    batch perm(j), a two-round alternating Feistel network on [0, b) x [0, a) -- a = the power of two at or above
-    sqrt(n_batches), b = ceil(n_batches / a) --, keyed by mix64(seed + receiver), walked until it lands below n_batches
-    (csrc/index_kernels.h: gen_perm_at)."""
+    """The order in which rapid_sim_generate delivers the round's batches to `receiver` (its node index), csrc/index_kernels.h:
+    gen_perm_at -- a permutation with two levels: the batch list in lines of eight consecutive batches, the LINES in a
+    receiver-specific pseudo-random order (a two-round alternating Feistel network on [0, b) x [0, a), a = the power of two at or
+    above sqrt(lines), b = ceil(lines / a), keyed by mix64(seed + receiver), walked until it lands below `lines`), the eight batches
+    of a line one after the other under an affine map of their places drawn from the line and the receiver; the whole walked until
+    it lands below n_batches."""
     n = int(n_batches)
     if n <= 1:
         return np.zeros(n, dtype=np.int64)
     rk, _ = _perm_keys(seed, receiver)
+    lb = np.uint32(GEN_LINE_BITS)
+    lm = np.uint32((1 << GEN_LINE_BITS) - 1)
+    lines = (n + (1 << GEN_LINE_BITS) - 1) >> GEN_LINE_BITS
     s = 1
-    while s < 16 and (1 << (2 * s)) < n:
+    while s < 16 and (1 << (2 * s)) < lines:
         s += 1
     mask_r = np.uint32((1 << s) - 1)
-    b = np.uint32(max(1, (n + (1 << s) - 1) >> s))
-    x = np.arange(n, dtype=np.uint32)
-    out = np.zeros(n, dtype=np.int64)
-    todo = np.arange(n)
-    with np.errstate(over="ignore"):
+    b = np.uint32(max(1, (lines + (1 << s) - 1) >> s))
+
+    def line_at(q):
+        out = np.zeros(len(q), dtype=np.uint32)
+        todo = np.arange(len(q))
+        x = q.copy()
         while len(todo):
             r, l = x & mask_r, x >> np.uint32(s)
             l = l + ((_f16(r, rk[0]) * b) >> np.uint32(16))
             l = np.where(l >= b, l - b, l)
             r = (r + _f16(l, rk[1])) & mask_r
             x = (l << np.uint32(s)) | r
+            done = x < lines
+            out[todo[done]] = x[done]
+            todo, x = todo[~done], x[~done]
+        return out
+
+    x = np.arange(n, dtype=np.uint32)
+    out = np.zeros(n, dtype=np.int64)
+    todo = np.arange(n)
+    with np.errstate(over="ignore"):
+        while len(todo):
+            Q = line_at(x >> lb)
+            h = _f16(Q & np.uint32(0xFFFF), rk[2] ^ (Q >> np.uint32(16)))
+            T = ((((x & lm) ^ (h >> np.uint32(8))) * ((h & np.uint32(6)) | np.uint32(1))) + (h >> np.uint32(3))) & lm
+            x = (Q << lb) | T
             done = x < n
             out[todo[done]] = x[done]
             todo, x = todo[~done], x[~done]
