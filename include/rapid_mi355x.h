@@ -180,10 +180,12 @@ int rapid_sim_attach_streams_device(rapid_engine* h, const void* d_records, uint
 /* The delivered streams made ON THE DEVICE instead of loaded (rapid_sim_generate): alerts = the round's distinct
  * alerts in batch order, batch b = alerts[batch_off[b] .. batch_off[b + 1]) = one BatchedAlertMessage (never empty:
  * RAPID_EINVAL); every receiver gets every batch exactly once (the fan-out of R/UnicastToAllBroadcaster.java:46-63), receiver
- * r in an order of its own: position j holds batch perm(j), a seeded permutation of [0, n_batches) evaluated in place (a
- * four-round Feistel network on a mixed-radix domain that covers n_batches with less than its square root to spare, keyed by
- * mix64(seed + receivers[r]), cycle-walked into range; csrc/index_kernels.h: gen_perm_at;
- * rapid_amd/scenarios.py: hashed_order / deliver_hashed are the same statement on the host).  No keys, no sort, no bound on
+ * r in an order of its own: position j holds batch perm(j), a seeded permutation of [0, n_batches) evaluated in place, in two
+ * levels -- the batch list in lines of eight consecutive batches; the lines in a pseudo-random order (a two-round Feistel network
+ * on a mixed-radix domain that covers the line count with less than its square root to spare, keyed by mix64(seed +
+ * receivers[r]), cycle-walked into range), the eight batches of a line under an affine map of their places drawn from the line and
+ * the receiver (csrc/index_kernels.h: gen_perm_at; rapid_amd/scenarios.py: hashed_order / deliver_hashed are the same statement
+ * on the host).  No keys, no sort, no bound on
  * receivers x batches.  `alerts` IS the declared alert set of the round (rapid_sim_set_alert_set is implied and refused).
  * batch_keep (optional, [n_batches]): batch b reaches receiver r only if a per-(r, b) 32-bit draw is <= batch_keep[b]
  * (0xFFFFFFFF: every receiver) -- late deliveries of an earlier configuration (alerts of the set that carry another
