@@ -497,7 +497,7 @@ __global__ void ids_contains_kernel(const long long* old_hi, const long long* ol
 }
 
 // The same question for the few thousand NodeIds of one cut, answered into the host-mapped page the host polls (ONE word: the call's
-// sequence number doubled, + 1 if any of them was seen before): one workgroup; no copy, no stream synchronisation on a view change's path.
+// sequence number doubled, + 1 if any of them was seen before): no copy, no stream synchronisation on a view change's path.
 // One thread per NodeId (twenty-one dependent steps through two million sorted ids each: spread over the GPU they take what one of
 // them takes; one workgroup walking all 5,000 took 96 us); acc[0] collects the answer, acc[1] counts finished workgroups, and the
 // last one publishes and leaves both words zero for the next call.

@@ -505,6 +505,42 @@ int emu_vote_settle(const unsigned long long* fp, const int* prop_count, const i
     return 0;
 }
 
+// The fast-round votes of a TILED round, accumulated across the tiles' launches (vote_acc_pick_kernel / vote_acc_count_kernel per
+// tile of `tile` receivers, vote_acc_finish_kernel at the end; engine.hip: rapid_sim_round_tiled).  The per-tile statistics the tally
+// kernel gathers (lowest voter, voters) are worked out here.  target: 0 = the first voter's proposal is the candidate, else the
+// proposal with this fingerprint.  block[] = res[10] followed by ref[1 + prop_cap], the layout of the all-gather.
+int emu_vote_acc(const unsigned long long* fp, const int* prop_count, const int* props, int prop_cap, const unsigned long long* bits, int bits_words,
+                 int n_receivers, int tile, unsigned long long target, unsigned int tally_error, unsigned long long* block, unsigned long long seed) {
+    std::vector<unsigned long long> acc((size_t)rapid::kVoteAccWords + (size_t)bits_words + ((size_t)prop_cap + 1) / 2 + 1, 0ull);
+    unsigned long long* const acc_bits = acc.data() + rapid::kVoteAccWords;
+    int* const acc_list = reinterpret_cast<int*>(acc_bits + bits_words);
+    acc[6] = target;
+    unsigned int errs[2] = {tally_error, 0u};
+    for (int base = 0, t = 0; base < n_receivers; base += tile, ++t) {
+        const int n = std::min(tile, n_receivers - base);
+        unsigned long long tile_res[10] = {0xFFFFFFFFull, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = n - 1; r >= 0; --r)
+            if (prop_count[base + r] != 0) {
+                ++tile_res[2];
+                tile_res[0] = (unsigned long long)r;
+            }
+        // (a tile's node lists and bitmaps are tile-local in the product: the pointers start at the tile)
+        emu::run_block(0u, 1u, 1024u, [&] {
+            rapid::vote_acc_pick_kernel(tile_res, fp + base, prop_count + base, props + (size_t)base * prop_cap, prop_cap, bits + (size_t)base * bits_words,
+                                        bits_words, n, errs, acc.data(), acc_bits, acc_list);
+        }, seed + 100u * (unsigned)t);
+        const unsigned grid = (unsigned)std::max(1, (n * 64 + 1023) / 1024);
+        for (unsigned b = 0; b < grid; ++b)
+            emu::run_block(b, grid, 1024u, [&] {
+                rapid::vote_acc_count_kernel(fp + base, prop_count + base, bits + (size_t)base * bits_words, bits_words, n, acc.data(), acc_bits);
+            }, seed + 100u * (unsigned)t + 1u + b);
+    }
+    int* ref = reinterpret_cast<int*>(block + 10);
+    for (unsigned b = 0; b < 8u; ++b)
+        emu::run_block(b, 8u, 256u, [&] { rapid::vote_acc_finish_kernel(acc.data(), acc_list, prop_cap, block, ref); }, seed + 7u + b);
+    return 0;
+}
+
 int emu_vote_merge(const unsigned long long* gathered, int n_ranks, int seg_words, int prop_cap, long long quorum,
                    unsigned long long* block, unsigned long long seed) {
     unsigned int seq_word = 0u;
@@ -714,6 +750,19 @@ extern "C" int emu_sort_node_ids(long long* hi, long long* lo, int n) {
         hi[i] = ids[(size_t)i].first;
         lo[i] = ids[(size_t)i].second;
     }
+    return 0;
+}
+
+// "was any of these NodeIds seen before?" answered into the mailbox word (ids_contains_publish_kernel): -> the published word
+extern "C" int emu_ids_contains_publish(const long long* old_hi, const long long* old_lo, int n_old, const long long* new_hi, const long long* new_lo,
+                                        int n_new, unsigned int seq, unsigned int* word_out, unsigned long long seed) {
+    unsigned int acc[2] = {0u, 0u};
+    unsigned int mail[16] = {0};
+    const unsigned grid = (unsigned)std::max(1, (n_new + 255) / 256);
+    for (unsigned b = 0; b < grid; ++b)
+        emu::run_block(b, grid, 256u, [&] { rapid::ids_contains_publish_kernel(old_hi, old_lo, n_old, new_hi, new_lo, n_new, acc, mail, 13, seq); }, seed + b);
+    if (acc[0] != 0u || acc[1] != 0u) return -2;  // the last workgroup leaves both words zero for the next call
+    *word_out = mail[13];
     return 0;
 }
 

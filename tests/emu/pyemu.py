@@ -323,6 +323,41 @@ def vote_settle(fp, prop_count, props, mode, salt=0, seed=1, bits=None):
     return block[:RES_WORDS].copy(), (ref[1: 1 + n].tolist() if n >= 0 else None)
 
 
+def vote_acc(fp, prop_count, props, bits, tile, target=0, tally_error=0, seed=1):
+    """The accumulated vote count of a round taken tile by tile (vote_acc_pick / _count / _finish kernels).  -> (res[10], the
+    candidate's list or None): the block a rank contributes to the all-gather."""
+    L_ = lib()
+    fp = np.ascontiguousarray(fp, dtype=np.uint64)
+    prop_count = np.ascontiguousarray(prop_count, dtype=np.int32)
+    props = np.ascontiguousarray(props, dtype=np.int32)
+    bits = np.ascontiguousarray(bits, dtype=np.uint64)
+    R, cap = props.shape
+    block = np.zeros(RES_WORDS + (cap + 2) // 2 + 1, dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L_.emu_vote_acc.restype = C.c_int
+    rc = L_.emu_vote_acc(p(fp), p(prop_count), p(props), cap, p(bits), int(bits.shape[1]), R, int(tile), C.c_ulonglong(int(target)),
+                         C.c_uint(tally_error), p(block), C.c_ulonglong(seed))
+    assert rc == 0, rc
+    ref = block[RES_WORDS:].view(np.int32)
+    n = int(ref[0])
+    return block[:RES_WORDS].copy(), (ref[1: 1 + n].tolist() if n >= 0 else None), block.copy()
+
+
+def ids_contains_publish(old, new, seq, seed=1):
+    """ids_contains_publish_kernel: is any of `new` (NodeIds as (high, low)) in the sorted list `old`?  -> the published word."""
+    L_ = lib()
+    oh = np.array([h for h, _ in old], dtype=np.int64)
+    ol = np.array([l for _, l in old], dtype=np.int64)
+    nh = np.array([h for h, _ in new], dtype=np.int64)
+    nl = np.array([l for _, l in new], dtype=np.int64)
+    word = C.c_uint(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L_.emu_ids_contains_publish.restype = C.c_int
+    rc = L_.emu_ids_contains_publish(p(oh), p(ol), len(old), p(nh), p(nl), len(new), C.c_uint(seq), C.byref(word), C.c_ulonglong(seed))
+    assert rc == 0, rc
+    return int(word.value)
+
+
 def vote_block(votes, voters, fp, cut, prop_cap, bad=0, err=0):
     """A rank's answer block as rapid_sim_count_votes all-gathers it: res[10] + ref[1 + prop_cap], padded to 8 bytes."""
     seg_words = RES_WORDS + (prop_cap + 2) // 2 + 1

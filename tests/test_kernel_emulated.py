@@ -814,3 +814,85 @@ def test_joiner_identifiers_put_in_order_on_the_host():
         assert L_.emu_sort_node_ids(p(hi), p(lo), len(ids)) == 0
         want = sorted(map(tuple, ids.tolist()))
         assert list(zip(hi.tolist(), lo.tolist())) == want
+
+
+def test_votes_accumulated_across_the_tiles_of_a_round():
+    """vote_acc_pick / _count / _finish (csrc/vote_kernels.h; rapid_sim_round_tiled runs them once per tile): the candidate is the
+    round's FIRST voter's proposal (or, in a counting pass, the first voter holding a given fingerprint), every voter holding its
+    fingerprint is compared with it bit for bit -- a voter with the fingerprint and another bitmap is an offender, not a vote --,
+    votes and voters add up over the tiles whatever the tiling, and the block left for the all-gather merges like the block of a
+    population counted in one launch (R/FastPaxos.java:141-150: a count per proposal is all that is kept)."""
+    rng = np.random.default_rng(5)
+    R, cap, words = 300, 40, 3
+    A = sorted(rng.choice(150, size=12, replace=False).tolist())
+    B = sorted(rng.choice(150, size=9, replace=False).tolist())
+
+    def bitmap(cut):
+        w = np.zeros(words, dtype=np.uint64)
+        for x in cut:
+            w[x // 64] |= np.uint64(1) << np.uint64(x % 64)
+        return w
+
+    fpA, fpB = np.uint64(0x1111222233334444), np.uint64(0x9999AAAABBBBCCCC)
+    kind = rng.choice(3, size=R, p=[0.2, 0.65, 0.15])  # 0: does not vote, 1: proposes A, 2: proposes B
+    for first_kind in (1, 2):
+        kind[:5] = 0
+        kind[5] = first_kind
+        fp = np.where(kind == 1, fpA, np.where(kind == 2, fpB, np.uint64(0))).astype(np.uint64)
+        pc = np.where(kind == 1, len(A), np.where(kind == 2, len(B), 0)).astype(np.int32)
+        props = np.zeros((R, cap), dtype=np.int32)
+        bits = np.zeros((R, words), dtype=np.uint64)
+        for r in range(R):
+            cut = A if kind[r] == 1 else B if kind[r] == 2 else []
+            props[r, : len(cut)] = cut
+            bits[r] = bitmap(cut)
+        liar = int(np.flatnonzero(kind == first_kind)[3])  # holds the candidate's fingerprint over another proposal
+        bits[liar, 0] ^= np.uint64(1) << np.uint64(63)
+        cand, other = (A, B) if first_kind == 1 else (B, A)
+        n_cand, n_voters = int((kind == first_kind).sum()), int((kind != 0).sum())
+        blocks = {}
+        for tile in (R, 128, 97, 33):
+            res, ref, block = pyemu.vote_acc(fp, pc, props, bits, tile, seed=tile)
+            assert ref == cand and int(res[1]) == int(res[7]) == n_cand - 1 and int(res[2]) == n_voters and int(res[6]) == 1, (tile, res)
+            assert int(res[3]) == 2 and res[4] == (fpA if first_kind == 1 else fpB) and res[5] == ~res[4] and int(res[8]) == 0
+            blocks[tile] = block
+        assert all(np.array_equal(blocks[R], b) for b in blocks.values())  # the tiling does not show in the answer
+        # a counting pass for the OTHER proposal (what the exact plurality asks for when the first candidate has no quorum)
+        res, ref, _ = pyemu.vote_acc(fp, pc, props, bits, 100, target=int(fpB if first_kind == 1 else fpA))
+        assert ref == other and int(res[1]) == int((kind == (3 - first_kind)).sum()) and int(res[2]) == n_voters and int(res[6]) == 0
+        # two "ranks" (the receivers cut in two, each taken tile by tile) merged = the whole population's answer; a rank that holds an
+        # offender -- or another candidate -- is not merged: the general count would run
+        half = R // 2
+        _, _, b0 = pyemu.vote_acc(fp[:half], pc[:half], props[:half], bits[:half], 64)
+        _, _, b1 = pyemu.vote_acc(fp[half:], pc[half:], props[half:], bits[half:], 64)
+        assert pyemu.vote_merge([b0, b1], cap, quorum=n_cand - 1)[0] == 2
+        bits[liar] = bitmap(cand)
+        _, _, b0 = pyemu.vote_acc(fp[:half], pc[:half], props[:half], bits[:half], 64)
+        _, _, b1 = pyemu.vote_acc(fp[half:], pc[half:], props[half:], bits[half:], 64)
+        status, votes, voters, cut, _ = pyemu.vote_merge([b0, b1], cap, quorum=n_cand)
+        if kind[half:][np.flatnonzero(kind[half:] != 0)[0]] == first_kind:  # both ranks' first voters hold the same proposal
+            assert (status, votes, voters, cut) == (1, n_cand, n_voters, cand)
+        else:
+            assert status == 2
+    # nobody votes; a tally error flag of a tile travels with the block
+    res, ref, _ = pyemu.vote_acc(np.zeros(50, dtype=np.uint64), np.zeros(50, dtype=np.int32), np.zeros((50, cap), dtype=np.int32),
+                                 np.zeros((50, words), dtype=np.uint64), 16, tally_error=1)
+    assert ref == [] and int(res[1]) == int(res[2]) == int(res[3]) == 0 and int(res[8]) == 1
+
+
+def test_identifier_check_answered_into_the_mailbox():
+    """ids_contains_publish_kernel (the check in front of every view change that admits joiners): one thread per joiner NodeId, a
+    binary search in the sorted identifiersSeen, the answer -- 2 x the call's sequence number, + 1 if any was seen before
+    (R/MembershipView.java:127-129) -- published by the last workgroup, which leaves the accumulators zero."""
+    rng = np.random.default_rng(9)
+    old = sorted({(int(h), int(l)) for h, l in rng.integers(-2**62, 2**62, size=(3000, 2))})
+    fresh = [(int(h), int(l)) for h, l in rng.integers(-2**62, 2**62, size=(700, 2))]
+    fresh = [x for x in fresh if x not in set(old)]
+    assert pyemu.ids_contains_publish(old, fresh, seq=21) == 42
+    assert pyemu.ids_contains_publish(old, fresh[:1], seq=5) == 10
+    for where in (0, 299, len(fresh) - 1):  # one seen identifier, in the first / a middle / the last workgroup's share
+        new = list(fresh)
+        new[where] = old[(where * 7) % len(old)]
+        assert pyemu.ids_contains_publish(old, new, seq=33) == 67
+    assert pyemu.ids_contains_publish(old, [old[0]], seq=1) == 3 and pyemu.ids_contains_publish(old, [old[-1]], seq=1) == 3
+    assert pyemu.ids_contains_publish(old, [(old[0][0], old[0][1] + 1)], seq=1) in (2, 3)  # (+ 1 only if that id happens to exist)
