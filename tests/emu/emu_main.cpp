@@ -525,7 +525,7 @@ int emu_vote_acc(const unsigned long long* fp, const int* prop_count, const int*
                 tile_res[0] = (unsigned long long)r;
             }
         // (a tile's node lists and bitmaps are tile-local in the product: the pointers start at the tile)
-        emu::run_block(0u, 1u, 1024u, [&] {
+        emu::run_block(0u, 1u, 256u, [&] {
             rapid::vote_acc_pick_kernel(tile_res, fp + base, prop_count + base, props + (size_t)base * prop_cap, prop_cap, bits + (size_t)base * bits_words,
                                         bits_words, n, errs, acc.data(), acc_bits, acc_list);
         }, seed + 100u * (unsigned)t);

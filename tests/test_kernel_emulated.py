@@ -823,7 +823,7 @@ def test_votes_accumulated_across_the_tiles_of_a_round():
     votes and voters add up over the tiles whatever the tiling, and the block left for the all-gather merges like the block of a
     population counted in one launch (R/FastPaxos.java:141-150: a count per proposal is all that is kept)."""
     rng = np.random.default_rng(5)
-    R, cap, words = 300, 40, 3
+    R, cap, words = 120, 40, 3  # (64 emulated lanes per receiver and pass: kept small)
     A = sorted(rng.choice(150, size=12, replace=False).tolist())
     B = sorted(rng.choice(150, size=9, replace=False).tolist())
 
@@ -851,24 +851,24 @@ def test_votes_accumulated_across_the_tiles_of_a_round():
         cand, other = (A, B) if first_kind == 1 else (B, A)
         n_cand, n_voters = int((kind == first_kind).sum()), int((kind != 0).sum())
         blocks = {}
-        for tile in (R, 128, 97, 33):
+        for tile in (R, 50, 33):
             res, ref, block = pyemu.vote_acc(fp, pc, props, bits, tile, seed=tile)
             assert ref == cand and int(res[1]) == int(res[7]) == n_cand - 1 and int(res[2]) == n_voters and int(res[6]) == 1, (tile, res)
             assert int(res[3]) == 2 and res[4] == (fpA if first_kind == 1 else fpB) and res[5] == ~res[4] and int(res[8]) == 0
             blocks[tile] = block
         assert all(np.array_equal(blocks[R], b) for b in blocks.values())  # the tiling does not show in the answer
         # a counting pass for the OTHER proposal (what the exact plurality asks for when the first candidate has no quorum)
-        res, ref, _ = pyemu.vote_acc(fp, pc, props, bits, 100, target=int(fpB if first_kind == 1 else fpA))
+        res, ref, _ = pyemu.vote_acc(fp, pc, props, bits, 70, target=int(fpB if first_kind == 1 else fpA))
         assert ref == other and int(res[1]) == int((kind == (3 - first_kind)).sum()) and int(res[2]) == n_voters and int(res[6]) == 0
         # two "ranks" (the receivers cut in two, each taken tile by tile) merged = the whole population's answer; a rank that holds an
         # offender -- or another candidate -- is not merged: the general count would run
         half = R // 2
-        _, _, b0 = pyemu.vote_acc(fp[:half], pc[:half], props[:half], bits[:half], 64)
-        _, _, b1 = pyemu.vote_acc(fp[half:], pc[half:], props[half:], bits[half:], 64)
+        _, _, b0 = pyemu.vote_acc(fp[:half], pc[:half], props[:half], bits[:half], 40)
+        _, _, b1 = pyemu.vote_acc(fp[half:], pc[half:], props[half:], bits[half:], 40)
         assert pyemu.vote_merge([b0, b1], cap, quorum=n_cand - 1)[0] == 2
         bits[liar] = bitmap(cand)
-        _, _, b0 = pyemu.vote_acc(fp[:half], pc[:half], props[:half], bits[:half], 64)
-        _, _, b1 = pyemu.vote_acc(fp[half:], pc[half:], props[half:], bits[half:], 64)
+        _, _, b0 = pyemu.vote_acc(fp[:half], pc[:half], props[:half], bits[:half], 40)
+        _, _, b1 = pyemu.vote_acc(fp[half:], pc[half:], props[half:], bits[half:], 40)
         status, votes, voters, cut, _ = pyemu.vote_merge([b0, b1], cap, quorum=n_cand)
         if kind[half:][np.flatnonzero(kind[half:] != 0)[0]] == first_kind:  # both ranks' first voters hold the same proposal
             assert (status, votes, voters, cut) == (1, n_cand, n_voters, cand)
