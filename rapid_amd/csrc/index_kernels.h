@@ -899,16 +899,13 @@ __global__ __launch_bounds__(1024) void index_fused_kernel(const unsigned char* 
 // ---- rapid_sim_generate: the delivered streams made on the device ----------------------------------------------------
 // Every receiver gets every BatchedAlertMessage of the round exactly once, in a receiver-specific seeded order (the
 // reference's fan-out: UnicastToAllBroadcaster.java:46-63 sends each batch to all members; arrival order differs per
-// receiver -- paper Fig.11 methodology).  The order is a seeded PERMUTATION evaluated in place, not a sort: position j of
-// receiver r holds batch perm_r(j), a four-round alternating Feistel network on the mixed-radix domain [0, b) x [0, a) -- a = the
-// power of two at or above sqrt(n_batches), b = ceil(n_batches / a): the smallest such domain covers n_batches with less than a
-// positions to spare, so that "walk until it lands inside [0, n_batches)" (cycle walking: a bijection of a domain restricted to a
-// subset is a bijection of the subset) takes a second step for one position in several hundred.  (Round 4 ran the network on the
-// next power of two: up to half of the positions walked, and a wave walks as long as its unluckiest lane -- five to six network
-// evaluations per delivery at 1.4 x 10^5 batches, most of the generator's instructions.)  Keyed by mix64(seed + node index of r).
-// Any position is computed in O(1) by itself, so one WAVE per receiver lays the stream down 64 deliveries at a time with nothing
-// but a prefix sum of the batch lengths over its lanes in between -- no keys in memory, no sort, no barrier, no LDS, no limit on
-// receivers x batches.  (rapid_amd/scenarios.py: hashed_order / deliver_hashed state the same on the host.)
+// receiver -- paper Fig.11 methodology).  The order is a seeded PERMUTATION evaluated in place, not a sort (gen_perm_at below: two
+// levels, Feistel networks on mixed-radix domains, cycle walking -- a bijection of a domain restricted to a subset is a bijection of
+// the subset), keyed by mix64(seed + node index of r).  Any position is computed in O(1) by itself, so one WAVE per receiver lays
+// the stream down 64 deliveries at a time with nothing but a prefix sum of the batch lengths over its lanes in between -- no keys
+// in memory, no sort, no barrier, no LDS, no limit on receivers x batches.  (Round 4 ran a four-round network on the next power of
+// two above n_batches: up to half of the positions walked, and a wave walks as long as its unluckiest lane -- five to six network
+// evaluations per delivery at 1.4 x 10^5 batches.)  rapid_amd/scenarios.py: hashed_order / deliver_hashed state the same on the host.
 // keep != nullptr: batch b reaches receiver r only if (uint32)(mix64(keepk_r + b) >> 32) <= keep[b] -- late deliveries of an
 // earlier configuration (R/MembershipService.java:653-657 drops them) and lossy links reach SOME receivers; the places of an
 // undelivered batch hold empty records (no ring, no batch end: what the zeros behind a stream's end are), so that every
@@ -918,13 +915,6 @@ __host__ __device__ inline unsigned long long gen_mix64(unsigned long long x) { 
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
-}
-__host__ __device__ inline unsigned int gen_mix32(unsigned int x) {  // murmur3's 32-bit finaliser
-    x ^= x >> 16;
-    x *= 0x85EBCA6Bu;
-    x ^= x >> 13;
-    x *= 0xC2B2AE35u;
-    return x ^ (x >> 16);
 }
 // The delivery order of a receiver is a permutation with TWO levels: the batch list is cut into lines of kGenLine consecutive
 // batches (their table entries fill one 128-byte cache line), the LINES are delivered in a receiver-specific pseudo-random order,

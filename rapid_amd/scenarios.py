@@ -239,17 +239,6 @@ def mix64(x):
     return x ^ (x >> np.uint64(31))
 
 
-def mix32(x):
-    """murmur3's 32-bit finaliser on uint32 arrays (== gen_mix32 on the device)."""
-    x = np.asarray(x, dtype=np.uint32)
-    with np.errstate(over="ignore"):
-        x = x ^ (x >> np.uint32(16))
-        x = x * np.uint32(0x85EBCA6B)
-        x = x ^ (x >> np.uint32(13))
-        x = x * np.uint32(0xC2B2AE35)
-    return x ^ (x >> np.uint32(16))
-
-
 def _perm_keys(seed, receiver):
     with np.errstate(over="ignore"):
         key = mix64(np.uint64(int(seed) & _M64) + np.uint64(int(receiver) & 0xFFFFFFFF))

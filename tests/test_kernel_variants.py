@@ -19,7 +19,7 @@ def test_emulated_kernel_tests_on_variant(variant):
     env = {**os.environ, "RAPID_EMU_VARIANT": variant}
     # (the window-size variants change the tally kernel only: the index / vote / view kernel tests of that file run once, in
     # the default build -- except under the sanitizer, where everything runs)
-    only = [] if variant == "ubsan" else ["-k", "not (round_index or vote_ or view_kernels or view_change)"]
+    only = [] if variant == "ubsan" else ["-k", "not (round_index or vote_ or votes_ or view_kernels or view_change or identifier or joiner)"]
     # (the child run spreads over a few workers where pytest-xdist is there: the variants are most of the CPU suite's wall time)
     try:
         import xdist  # noqa: F401
