@@ -87,6 +87,14 @@ int rapid_engine_create(const rapid_engine_config* cfg, rapid_engine** out);
 void rapid_engine_destroy(rapid_engine* h);
 const char* rapid_last_error(const rapid_engine* h);
 int rapid_device_count(void); /* number of usable gfx950 devices (0 on a CPU-only host) */
+/* Known-answer test of the whole path on h's device, on a private engine (h's view and streams are untouched): a 5-node view whose
+ * configuration id and ring 0 are compared with constants (the CPU oracle's values, recomputed by tests/test_abi.py), one round in
+ * which the four other receivers hear node 4 reported DOWN on every ring, the decided cut {4} and the configuration id after it.
+ * RAPID_OK, or RAPID_EDEVICE with the first difference in rapid_last_error(h).  What a host calls once after rapid_engine_create,
+ * where the reference would simply trust `new MembershipView(K, ids, endpoints)` (R/MembershipView.java:74-89) and
+ * `new MultiNodeCutDetector(K, H, L)` (R/MultiNodeCutDetector.java:51-60) not to fail: a runtime that cannot run the kernels is
+ * then an error code at start-up, not a wrong cut later (a device FAULT still ends the process: INTEGRATION.md section 6). */
+int rapid_engine_self_test(rapid_engine* h);
 
 /* ---- MembershipView (R/MembershipView.java) -----------------------------------------------------------
  * rapid_view_build <- MembershipView(int K, Collection<NodeId>, Collection<Endpoint>) (:74-89).  Registers

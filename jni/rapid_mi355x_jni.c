@@ -68,6 +68,12 @@ JNIEXPORT jlong JNICALL Java_com_vrg_rapid_NativeCutEngine_create(JNIEnv* env, j
     return (jlong)(intptr_t)h;
 }
 
+/* once after create: a known-answer view + round on h's device; RAPID_EDEVICE -> IllegalStateException with the first difference */
+JNIEXPORT void JNICALL Java_com_vrg_rapid_NativeCutEngine_selfTest(JNIEnv* env, jobject self, jlong h) {
+    (void)self;
+    CHECK(h, rapid_engine_self_test(ENGINE(h)));
+}
+
 JNIEXPORT void JNICALL Java_com_vrg_rapid_NativeCutEngine_close(JNIEnv* env, jobject self, jlong h) {
     (void)env; (void)self;
     rapid_engine_destroy(ENGINE(h));

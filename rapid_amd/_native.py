@@ -157,6 +157,7 @@ def _signatures():
         "rapid_engine_destroy": (None, [vp]),
         "rapid_last_error": (C.c_char_p, [vp]),
         "rapid_device_count": (i32, []),
+        "rapid_engine_self_test": (i32, [vp]),
         "rapid_engine_comm_info": (i32, [vp, pi32, pi32]),
         "rapid_sim_new_round": (i32, [vp]),
         "rapid_sim_trust_alert_copies": (i32, [vp, i32]),

@@ -5,6 +5,7 @@
 // device work is enqueued on the engine's own HIP stream.  There is NO CPU fallback: every entry point
 // that needs the device returns RAPID_EDEVICE when it is not a usable gfx950.
 #include <hip/hip_runtime.h>
+#include <pthread.h>
 
 #include <algorithm>
 #include <atomic>
@@ -12,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <set>
@@ -57,6 +59,15 @@ struct DevBuf {
         const size_t want = n + n / 8 + 64;
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
         if (e == hipSuccess) cap = want;
+#ifdef RAPID_TEST_BUILD
+        // RAPID_POISON=<byte>: every fresh device buffer is filled with that byte, so that a kernel reading scratch nobody wrote
+        // misbehaves on every box, not only on one whose memory a previous tenant left dirty (the round-5 fault hunt)
+        if (e == hipSuccess)
+            if (const char* v = getenv("RAPID_POISON")) {
+                e = hipMemset(p, (int)strtol(v, nullptr, 0) & 255, want * sizeof(T));
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+            }
+#endif
         return e;
     }
     void release() {
@@ -246,6 +257,8 @@ struct rapid_engine {
     // host-mapped mailbox the kernels write their small answers into (no copy enqueued, the host reads it after a
     // synchronisation): [0, 64) the round index's info[8], [64, ...) the vote count's res[] + representative list
     bool idx_lds_attr_set = false;
+    unsigned char* h_arena = nullptr;  // the engine's one pinned, host-mapped block (ensure_arena): mailbox | view staging
+    size_t arena_bytes = 0;
     unsigned char* h_mail = nullptr;
     unsigned int mail_seq = 0;  // sequence numbers of the answers polled from the mailbox
     unsigned char* d_mail = nullptr;
@@ -293,6 +306,17 @@ int fail(rapid_engine* h, int code, const char* fmt, ...) {
                         __FILE__, __LINE__);                                                      \
     } while (0)
 
+// After every kernel launch of the view path: a launch the runtime refused (bad geometry, LDS request over the limit) is reported
+// by the kernel's name, not by whatever call comes across the sticky error later.  Test build with RAPID_SYNC_LAUNCHES set: the stream
+// is synchronised as well, so a kernel that FAULTS is named too (the product never synchronises here).
+#define LAUNCHCHK(h, name)                                                                                           \
+    do {                                                                                                             \
+        hipError_t e_ = hipGetLastError();                                                                           \
+        if (e_ == hipSuccess && env_knob("RAPID_SYNC_LAUNCHES")) e_ = hipStreamSynchronize((h)->stream);             \
+        if (e_ != hipSuccess)                                                                                        \
+            return fail((h), RAPID_EDEVICE, "kernel %s: %s (%s:%d)", name, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
 bool valid_khl(int K, int H, int L) {
     // R/MultiNodeCutDetector.java:52 -- if (H > K || L > H || K < K_MIN || L <= 0 || H <= 0) throw
     return !(H > K || L > H || K < 3 || L <= 0 || H <= 0);
@@ -308,6 +332,39 @@ int use_device(rapid_engine* h) {
 }
 
 int ensure_mailbox(rapid_engine* h);
+int ensure_arena(rapid_engine* h);
+
+// A BORROWED device buffer (rapid_sim_attach_streams_device, rapid_sim_load_streams_device, rapid_sim_set_alert_set_device) is read
+// by kernels long after the call that handed it over: a host pointer, a pointer into another device's memory or a length that runs
+// past the allocation would surface as a GPU memory fault -- which ends the process (in a deployment: the JVM) -- instead of as an
+// error code.  So the runtime is asked what the pointer is: memory this engine's device can read (its own allocations, or
+// host-mapped / managed memory), with [p, p + bytes) inside ONE allocation.  ~1 us per pointer, host side only; no launch, no wait.
+int check_borrowed(rapid_engine* h, const void* p, unsigned long long bytes, const char* what) {
+    if (p == nullptr) return bytes == 0 ? RAPID_OK : fail(h, RAPID_EINVAL, "%s: null pointer with %llu bytes", what, bytes);
+    hipPointerAttribute_t at;
+    std::memset(&at, 0, sizeof at);
+    const hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(h, RAPID_EINVAL, "%s: %p is not memory the HIP runtime knows (%s): a device pointer is required", what, p, hipGetErrorString(e));
+    }
+    if (at.type == hipMemoryTypeUnregistered)
+        return fail(h, RAPID_EINVAL, "%s: %p is ordinary host memory: a device pointer is required", what, p);
+    if (at.type == hipMemoryTypeDevice && at.device != h->cfg.device_id)
+        return fail(h, RAPID_EINVAL, "%s: %p lives on device %d, the engine runs on device %d", what, p, at.device, h->cfg.device_id);
+    if (bytes) {
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, const_cast<void*>(p)) == hipSuccess) {
+            const unsigned long long off = (unsigned long long)(reinterpret_cast<uintptr_t>(p) - reinterpret_cast<uintptr_t>(base));
+            if (off > size || bytes > size - off)
+                return fail(h, RAPID_EINVAL, "%s: %llu bytes at %p run past the end of their allocation (%zu bytes from %p)", what, bytes, p, size, (void*)base);
+        } else {
+            (void)hipGetLastError();  // (a kind of memory without a range record, e.g. registered host memory: the type check above stands)
+        }
+    }
+    return RAPID_OK;
+}
 
 // Rebuilds rings, tables, state template and configuration id from the host member flags.
 // Is any of `ids` (sorted, distinct) among the identifiers seen so far?  A binary search per id in the device's sorted copy.
@@ -363,20 +420,38 @@ static int ids_seen_any(rapid_engine* h, const std::vector<std::pair<int64_t, in
     return RAPID_OK;
 }
 
-// all K rings of `count` (key, node) pairs per ring in ONE segmented sort (ring k = segment [k count, (k + 1) count))
+// All K rings of `count` (sortable key, node) pairs per ring (ring k = [k count, (k + 1) count)), sorted by (key, node) -- the order a
+// stable sort by key gives members handed over in ascending node order.
+//   count <= kJoinSortMax (8,192: every small view, BASELINE configs[0] and [1]): the engine's own two kernels -- runs sorted in LDS,
+//   then every pair finds its place among the other runs (view_kernels.h) -- no library, no temporary storage, no scratch memory;
+//   beyond: the library's segmented radix sort with a configuration whose kernels keep their items in registers (RingSortConfig).
+// Until round 5 every build went through the library's default configuration, whose gfx950 kernels spill 148 bytes per lane into
+// scratch memory -- the only kernels of the product that needed the runtime to set up a scratch arena on the queue, and they ran inside
+// the first call every user makes; tests/test_build.py now pins "no kernel of the product uses scratch".
+using RingSortConfig = rocprim::segmented_radix_sort_config<8, rocprim::kernel_config<256, 8>, rocprim::DisabledWarpSortConfig, false>;
+
 static int sort_rings(rapid_engine* h, unsigned long long* keys_in, unsigned long long* keys_out, int* vals_in, int* vals_out, int count) {
     const int K = h->cfg.K;
     hipStream_t st = h->stream;
+    if (count <= rapid::kJoinSortMax) {
+        const long long kc = (long long)K * count;
+        hipLaunchKernelGGL(rapid::ring_sort_runs_kernel, dim3((unsigned)(K * ((count + rapid::kJoinRun - 1) / rapid::kJoinRun))), dim3(rapid::kJoinRun / 2), 0, st,
+                           keys_in, vals_in, count);
+        LAUNCHCHK(h, "ring_sort_runs_kernel");
+        hipLaunchKernelGGL(rapid::ring_merge_runs_kernel, dim3(grid_for(kc, 256)), dim3(256), 0, st, keys_in, vals_in, count, K, keys_out, vals_out);
+        LAUNCHCHK(h, "ring_merge_runs_kernel");
+        return RAPID_OK;
+    }
     h->seg_host.resize((size_t)K + 1);
     for (int k = 0; k <= K; ++k) h->seg_host[(size_t)k] = k * count;
     HIPCHK(h, h->d_seg_off.ensure((size_t)K + 1));
     HIPCHK(h, hipMemcpyAsync(h->d_seg_off.p, h->seg_host.data(), sizeof(int) * ((size_t)K + 1), hipMemcpyHostToDevice, st));
     size_t tmp_bytes = 0;
-    HIPCHK(h, rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (unsigned int)((size_t)K * count),
-                                                  (unsigned int)K, h->d_seg_off.p, h->d_seg_off.p + 1, 0, 64, st));
+    HIPCHK(h, rocprim::segmented_radix_sort_pairs<RingSortConfig>(nullptr, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (unsigned int)((size_t)K * count),
+                                                                  (unsigned int)K, h->d_seg_off.p, h->d_seg_off.p + 1, 0, 64, st));
     HIPCHK(h, h->d_sort_tmp.ensure(tmp_bytes + 16));
-    HIPCHK(h, rocprim::segmented_radix_sort_pairs(h->d_sort_tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
-                                                  (unsigned int)((size_t)K * count), (unsigned int)K, h->d_seg_off.p, h->d_seg_off.p + 1, 0, 64, st));
+    HIPCHK(h, rocprim::segmented_radix_sort_pairs<RingSortConfig>(h->d_sort_tmp.p, tmp_bytes, keys_in, keys_out, vals_in, vals_out,
+                                                                  (unsigned int)((size_t)K * count), (unsigned int)K, h->d_seg_off.p, h->d_seg_off.p + 1, 0, 64, st));
     return RAPID_OK;
 }
 
@@ -421,29 +496,34 @@ int presize_view(rapid_engine* h) {
     HIPCHK(h, h->d_q4_valid.ensure(N));
     HIPCHK(h, h->d_q4_nodes.ensure(N));
     HIPCHK(h, h->d_gone.ensure(N));
-    {
-        // member flags (N) | nodes that left (4 N) | nodes that came (4 N) | members, for a sort from scratch (4 N) | new NodeIds (16 N)
-        const size_t need = ((size_t)29 * N + 256 + 4095) & ~(size_t)4095;  // (+ 256: each part starts on a 16-byte boundary)
-        if (h->vstage_bytes < need) {
-            if (h->h_vstage) {
-                HIPCHK(h, hipStreamSynchronize(h->stream));
-                (void)hipHostFree(h->h_vstage);
-                h->h_vstage = nullptr;
-                h->vstage_bytes = 0;
-            }
-            HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_vstage), need, hipHostMallocDefault));
-            h->vstage_bytes = need;
-        }
-    }
     // the library sort's scratch: for all K rings at full size, and for the joiners of one change
     size_t tmp_full = 0, tmp_join = 0;
-    HIPCHK(h, rocprim::segmented_radix_sort_pairs(nullptr, tmp_full, h->d_sort_keys.p, h->d_ring_skeys.p, h->d_sort_vals.p, h->d_ring.p, (unsigned int)km,
+    HIPCHK(h, rocprim::segmented_radix_sort_pairs<RingSortConfig>(nullptr, tmp_full, h->d_sort_keys.p, h->d_ring_skeys.p, h->d_sort_vals.p, h->d_ring.p, (unsigned int)km,
                                                   (unsigned int)K, h->d_seg_off.p, h->d_seg_off.p + 1, 0, 64, h->stream));
-    HIPCHK(h, rocprim::segmented_radix_sort_pairs(nullptr, tmp_join, h->d_join_keys.p, h->d_join_skeys.p, h->d_join_vals.p, h->d_join_nodes.p, (unsigned int)kj,
+    HIPCHK(h, rocprim::segmented_radix_sort_pairs<RingSortConfig>(nullptr, tmp_join, h->d_join_keys.p, h->d_join_skeys.p, h->d_join_vals.p, h->d_join_nodes.p, (unsigned int)kj,
                                                   (unsigned int)K, h->d_seg_off.p, h->d_seg_off.p + 1, 0, 64, h->stream));
     HIPCHK(h, h->d_sort_tmp.ensure(std::max(tmp_full, tmp_join) + 16));
     return RAPID_OK;
 }
+
+#ifdef RAPID_TEST_BUILD
+// RAPID_DEBUG_ADDR: where every buffer of the engine lives, against pthread_self() (the round-5 fault report names one address and the
+// main thread's: with the same binaries the distances between mappings repeat from box to box)
+void dump_addresses(rapid_engine* h) {
+    const unsigned long long self = (unsigned long long)pthread_self();
+    fprintf(stderr, "ADDR pthread_self %llx\n", self);
+#define RAPID_DUMP(b) fprintf(stderr, "ADDR %-14s %14llx bytes %10zu self-minus %llx\n", #b, (unsigned long long)(uintptr_t)h->b.p, h->b.cap * sizeof(*h->b.p), self - (unsigned long long)(uintptr_t)h->b.p)
+    RAPID_DUMP(d_blob); RAPID_DUMP(d_host_off); RAPID_DUMP(d_ports); RAPID_DUMP(d_keys); RAPID_DUMP(d_hx_host0); RAPID_DUMP(d_hx_port0);
+    RAPID_DUMP(d_member); RAPID_DUMP(d_members); RAPID_DUMP(d_sort_keys); RAPID_DUMP(d_sort_vals); RAPID_DUMP(d_ring_skeys); RAPID_DUMP(d_ring);
+    RAPID_DUMP(d_pos); RAPID_DUMP(d_obs); RAPID_DUMP(d_subj); RAPID_DUMP(d_ids_hi); RAPID_DUMP(d_ids_lo); RAPID_DUMP(d_ids_hi2); RAPID_DUMP(d_ids_lo2);
+    RAPID_DUMP(d_ids_new); RAPID_DUMP(d_cfg_out); RAPID_DUMP(d_cfg_partial); RAPID_DUMP(d_chunk_kept); RAPID_DUMP(d_chunk_base); RAPID_DUMP(d_chunk_lb);
+    RAPID_DUMP(d_nonmembers); RAPID_DUMP(d_joiners); RAPID_DUMP(d_join_keys); RAPID_DUMP(d_join_skeys); RAPID_DUMP(d_join_vals); RAPID_DUMP(d_join_nodes);
+    RAPID_DUMP(d_seg_off); RAPID_DUMP(d_sort_tmp); RAPID_DUMP(d_loadflags); RAPID_DUMP(d_q4_rows); RAPID_DUMP(d_q4_valid); RAPID_DUMP(d_q4_nodes); RAPID_DUMP(d_gone);
+#undef RAPID_DUMP
+    fprintf(stderr, "ADDR %-14s %14llx bytes %10zu self-minus %llx\n", "h_mail", (unsigned long long)(uintptr_t)h->h_mail, h->mail_bytes, self - (unsigned long long)(uintptr_t)h->h_mail);
+    fprintf(stderr, "ADDR %-14s %14llx bytes %10zu self-minus %llx\n", "h_vstage", (unsigned long long)(uintptr_t)h->h_vstage, h->vstage_bytes, self - (unsigned long long)(uintptr_t)h->h_vstage);
+}
+#endif
 
 int rebuild_view(rapid_engine* h) {
     const int K = h->cfg.K, N = h->n_nodes;
@@ -529,6 +609,7 @@ int rebuild_view(rapid_engine* h) {
         if (m == 0 || !h->d_subj.p || !ring_now || !h->d_q4_valid.p) return RAPID_OK;
         hipLaunchKernelGGL(rapid::q4_invalidate_kernel, dim3(grid_for((long long)m * K, 256)), dim3(256), 0, st, h->d_subj.p, ring_now, m_now, d_nodes,
                            (int)m, N, K, h->d_q4_valid.p, self, clear_members ? h->d_member.p : (unsigned char*)nullptr);
+        LAUNCHCHK(h, "q4_invalidate_kernel");
         gone_cleared = gone_cleared || clear_members;
         return RAPID_OK;
     };
@@ -549,9 +630,11 @@ int rebuild_view(rapid_engine* h) {
     HIPCHK(h, h->d_member.ensure((size_t)N));
     if (by_list) {  // the flags on the device are patched where they changed
         const int n_clear = gone_cleared ? 0 : removed;
-        if (n_clear > 0 || J > 0)
+        if (n_clear > 0 || J > 0) {
             hipLaunchKernelGGL(rapid::member_patch_kernel, dim3(grid_for((long long)std::max(n_clear, J), 256)), dim3(256), 0, st, h->d_member.p,
                                n_clear > 0 ? h->d_gone.p : (const int*)nullptr, n_clear, J > 0 ? d_joined : (const int*)nullptr, J);
+            LAUNCHCHK(h, "member_patch_kernel");
+        }
     } else {
         std::memcpy(stage_member, h->member.data(), (size_t)N);
         HIPCHK(h, hipMemcpyAsync(h->d_member.p, stage_member, (size_t)N, hipMemcpyHostToDevice, st));
@@ -576,6 +659,7 @@ int rebuild_view(rapid_engine* h) {
         HIPCHK(h, h->d_chunk_kept.ensure((size_t)K * n_chunks));
         hipLaunchKernelGGL(rapid::ring_count_kernel, dim3((unsigned)(K * n_chunks)), dim3(rapid::kRingChunk), 0, st, h->d_ring.p, m_old, n_chunks,
                            h->d_member.p, h->d_chunk_kept.p);
+        LAUNCHCHK(h, "ring_count_kernel");
         if (J > 0) {
             const size_t kj = (size_t)K * J;
             HIPCHK(h, h->d_join_keys.ensure(kj));
@@ -584,27 +668,26 @@ int rebuild_view(rapid_engine* h) {
             HIPCHK(h, h->d_join_nodes.ensure(kj));
             hipLaunchKernelGGL(rapid::ring_gather_kernel, dim3(grid_for((long long)kj, 256)), dim3(256), 0, st, h->d_keys.p, d_joined, J, N, K,
                                h->d_join_keys.p, h->d_join_vals.p);
-            if (J <= rapid::kJoinSortMax) {  // a cut's joiners: runs sorted in LDS, then every pair finds its place among the other runs (the library's sort: 0.27 ms of fixed cost)
-                hipLaunchKernelGGL(rapid::ring_sort_runs_kernel, dim3((unsigned)(K * ((J + rapid::kJoinRun - 1) / rapid::kJoinRun))), dim3(rapid::kJoinRun / 2), 0, st,
-                                   h->d_join_keys.p, h->d_join_vals.p, J);
-                hipLaunchKernelGGL(rapid::ring_merge_runs_kernel, dim3(grid_for((long long)kj, 256)), dim3(256), 0, st, h->d_join_keys.p, h->d_join_vals.p, J, K,
-                                   h->d_join_skeys.p, h->d_join_nodes.p);
-            } else {
-                int rc = sort_rings(h, h->d_join_keys.p, h->d_join_skeys.p, h->d_join_vals.p, h->d_join_nodes.p, J);
-                if (rc) return rc;
-            }
+            LAUNCHCHK(h, "ring_gather_kernel");
+            // (a cut's joiners, up to 8,192 of them: the engine's own two sort kernels -- the library's sort has 0.27 ms of fixed cost)
+            int rc = sort_rings(h, h->d_join_keys.p, h->d_join_skeys.p, h->d_join_vals.p, h->d_join_nodes.p, J);
+            if (rc) return rc;
         }
         HIPCHK(h, h->d_chunk_base.ensure((size_t)K * ((size_t)n_chunks + 1)));
         HIPCHK(h, h->d_chunk_lb.ensure((size_t)K * ((size_t)n_chunks + 1)));
         hipLaunchKernelGGL(rapid::ring_chunk_prep_kernel, dim3((unsigned)K), dim3(1024), 0, st, h->d_ring.p, h->d_ring_skeys.p, m_old, n_chunks, h->d_chunk_kept.p,
                            h->d_join_skeys.p, h->d_join_nodes.p, J, h->d_chunk_base.p, h->d_chunk_lb.p);
+        LAUNCHCHK(h, "ring_chunk_prep_kernel");
         hipLaunchKernelGGL(rapid::ring_scatter_kernel, dim3((unsigned)(K * n_chunks)), dim3(rapid::kRingChunk), 0, st, h->d_ring.p, h->d_ring_skeys.p,
                            m_old, n_chunks, h->d_member.p, h->d_chunk_base.p, h->d_chunk_lb.p, h->d_join_skeys.p, h->d_join_nodes.p, J, h->d_sort_vals.p,
                            h->d_sort_keys.p, M);
-        if (J > 0)
+        LAUNCHCHK(h, "ring_scatter_kernel");
+        if (J > 0) {
             hipLaunchKernelGGL(rapid::ring_join_kernel, dim3(grid_for((long long)K * J * 64, 256)), dim3(256), 0, st, h->d_ring.p, h->d_ring_skeys.p,
                                m_old, n_chunks, h->d_member.p, h->d_chunk_base.p, h->d_join_skeys.p, h->d_join_nodes.p, J, K, h->d_sort_vals.p,
                                h->d_sort_keys.p, M);
+            LAUNCHCHK(h, "ring_join_kernel");
+        }
         std::swap(h->d_ring, h->d_sort_vals);
         std::swap(h->d_ring_skeys, h->d_sort_keys);
         lap("rings: compact + merge");
@@ -614,11 +697,14 @@ int rebuild_view(rapid_engine* h) {
         if (by_list && M >= 2 && m_old >= 2) {
             hipLaunchKernelGGL(rapid::ring_patch_kernel, dim3(grid_for((long long)(removed + J) * K, 256)), dim3(256), 0, st, h->d_gone.p, removed, J, h->d_ring.p,
                                h->d_ring_skeys.p, M, h->d_keys.p, h->d_member.p, N, K, h->d_obs.p, h->d_subj.p);
+            LAUNCHCHK(h, "ring_patch_kernel");
             HIPCHK(h, h->d_nonmembers.ensure((size_t)N + 1));
             HIPCHK(h, hipMemsetAsync(h->d_nonmembers.p, 0, 4, st));
             hipLaunchKernelGGL(rapid::nonmember_list_kernel, dim3(grid_for((long long)N, 1024)), dim3(1024), 0, st, h->d_member.p, N, h->d_nonmembers.p);
+            LAUNCHCHK(h, "nonmember_list_kernel");
             hipLaunchKernelGGL(rapid::ring_nonmember_rows_kernel, dim3((unsigned)std::min<long long>(4096, std::max<long long>(1, grid_for((long long)K * (N - M), 256)))),
                                dim3(256), 0, st, h->d_ring.p, h->d_ring_skeys.p, M, h->d_keys.p, h->d_nonmembers.p, N, K, h->d_obs.p, h->d_subj.p);
+            LAUNCHCHK(h, "ring_nonmember_rows_kernel");
             tables_patched = true;
         }
     } else if (M && !(incremental && removed == 0 && J == 0)) {
@@ -631,15 +717,19 @@ int rebuild_view(rapid_engine* h) {
         HIPCHK(h, hipMemcpyAsync(h->d_members.p, stage_members, sizeof(int) * M, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(rapid::ring_gather_kernel, dim3(grid_for((long long)K * M, 256)), dim3(256), 0, st, h->d_keys.p,
                            h->d_members.p, M, N, K, h->d_sort_keys.p, h->d_sort_vals.p);
+        LAUNCHCHK(h, "ring_gather_kernel");
         int rc = sort_rings(h, h->d_sort_keys.p, h->d_ring_skeys.p, h->d_sort_vals.p, h->d_ring.p, M);
         if (rc) return rc;
     }
     if (!tables_patched) {  // (a build, a change that sorted the rings afresh: every row from the rings; d_pos is this pass's scratch)
-        if (M)
+        if (M) {
             hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * M, 256)), dim3(256), 0, st, h->d_ring.p,
                                h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 0);
+            LAUNCHCHK(h, "ring_tables_kernel");
+        }
         hipLaunchKernelGGL(rapid::ring_tables_kernel, dim3(grid_for((long long)K * N, 256)), dim3(256), 0, st, h->d_ring.p,
                            h->d_ring_skeys.p, h->d_keys.p, h->d_member.p, N, M, K, h->d_pos.p, h->d_obs.p, h->d_subj.p, 1);
+        LAUNCHCHK(h, "ring_tables_kernel");
     }
 
     lap("tables");
@@ -668,6 +758,7 @@ int rebuild_view(rapid_engine* h) {
         HIPCHK(h, hipMemcpyAsync(h->d_ids_new.p, flat, 16 * nn, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(rapid::ids_merge_kernel, dim3(grid_for((long long)ni, 256)), dim3(256), 0, st, h->d_ids_hi.p, h->d_ids_lo.p, h->n_ids_dev,
                            h->d_ids_new.p, h->d_ids_new.p + nn, (int)nn, h->d_ids_hi2.p, h->d_ids_lo2.p);
+        LAUNCHCHK(h, "ids_merge_kernel");
         if (!overflow.empty()) HIPCHK(h, hipStreamSynchronize(st));  // (`overflow` goes out of scope)
         std::swap(h->d_ids_hi, h->d_ids_hi2);
         std::swap(h->d_ids_lo, h->d_ids_lo2);
@@ -691,8 +782,11 @@ int rebuild_view(rapid_engine* h) {
         const unsigned int seq = ++h->mail_seq;
         hipLaunchKernelGGL(rapid::config_id_kernel, dim3((unsigned)G), dim3(T), (size_t)T * 16, st, h->d_ids_hi.p, h->d_ids_lo.p,
                            h->n_ids_dev, h->d_ring.p, M, h->d_hx_host0.p, h->d_hx_port0.p, d_cfg, h->d_cfg_partial.p, d_seq, seq);
-        if (G > 1) hipLaunchKernelGGL(rapid::config_id_final_kernel, dim3(1), dim3(512), 0, st, h->d_cfg_partial.p, G, d_cfg, d_seq, seq);
-        HIPCHK(h, hipGetLastError());
+        LAUNCHCHK(h, "config_id_kernel");
+        if (G > 1) {
+            hipLaunchKernelGGL(rapid::config_id_final_kernel, dim3(1), dim3(512), 0, st, h->d_cfg_partial.p, G, d_cfg, d_seq, seq);
+            LAUNCHCHK(h, "config_id_final_kernel");
+        }
         if ((rc_mail = await_mail(h, 10, seq))) return rc_mail;
     }
     h->vstage_busy = false;  // (the kernel that answered runs behind every copy of this change on the stream)
@@ -713,6 +807,9 @@ int rebuild_view(rapid_engine* h) {
     h->tallied = false;
     h->have_decision = false;
     h->index_valid = false;
+#ifdef RAPID_TEST_BUILD
+    if (env_knob("RAPID_DEBUG_ADDR")) dump_addresses(h);
+#endif
     return RAPID_OK;
 }
 
@@ -720,6 +817,7 @@ int rebuild_view(rapid_engine* h) {
 // swapped the rings while ring_member / ring_m still describe the old ones: nothing incremental may be built on that.  The next
 // change sorts the rings afresh from the host's member flags; if the identifiers of the change were already merged on the device
 // the view has to be built again (rapid_view_build) -- the set cannot be un-merged.
+int rebuild_view(rapid_engine* h);
 void view_change_failed(rapid_engine* h, int n_ids_before) {
     h->changed.clear();
     h->changed_valid = false;
@@ -732,6 +830,20 @@ void view_change_failed(rapid_engine* h, int n_ids_before) {
     if (h->n_ids_dev != n_ids_before) {
         h->view_built = false;
         h->err += " (the identifiers of the failed change are merged already: build the view again)";
+        return;
+    }
+    // The device's rings may be swapped and its tables patched for the cut that failed, under the old configuration id: nothing may
+    // be answered from them.  The rolled-back membership is built afresh right away (a full sort, the !have_rings path); if the
+    // device cannot do that either, there is no view until rapid_view_build.
+    const std::string first = h->err;
+    if (rebuild_view(h) != RAPID_OK) {
+        h->view_built = false;
+        h->ring_member.clear();
+        h->ring_m = 0;
+        h->changed_valid = false;
+        h->err = first + " (and the view could not be rebuilt from the rolled-back membership: " + h->err + "; build the view again)";
+    } else {
+        h->err = first + " (the view was rebuilt from the rolled-back membership)";
     }
 }
 
@@ -779,22 +891,37 @@ int copy_list(rapid_engine* h, const int* src, int n, int32_t* out, int32_t cap,
     return RAPID_OK;
 }
 
-int ensure_mailbox(rapid_engine* h) {
-    // [0, 64) index info | [64, 64 + A) vote answer written by the kernels | [.., + A) staging of the copied answer (sharded
-    // populations); ONE page-granular allocation: two small hipHostMalloc blocks of one engine were observed to share
-    // their fate (freeing the first made hipHostFree of the second fail with "invalid argument")
+// ONE pinned, host-mapped block per engine, allocated by rapid_engine_create and freed by rapid_engine_destroy, never in between:
+//   [0, mail_bytes)   the mailbox the kernels write their small answers into -- [0, 64) the round index's info[8] and the sequence
+//                     words, [64, 64 + A) the vote answer, [.., + A) the staging of the copied answer (sharded populations);
+//   [mail_bytes, ..)  the staging block of a view change's uploads: member flags (N) | nodes that left (4 N) | nodes that came (4 N)
+//                     | members, for a sort from scratch (4 N) | new NodeIds (16 N), N = n_max (+ 256: each part starts on a
+//                     16-byte boundary).
+// At least 64 KiB and a multiple of it, with explicit flags (mapped, coherent).  Rounds 2-5 kept the mailbox and the staging
+// blocks as separate small hipHostMalloc allocations (4 KiB each for a small engine), allocated lazily and re-allocated on
+// growth; DESIGN.md section 8 has the history of the fault report that ended that.
+int ensure_arena(rapid_engine* h) {
+    if (h->h_arena) return RAPID_OK;
     const size_t answer = (10 * 8 + ((size_t)h->max_cut + 1) * sizeof(int) + 63) & ~(size_t)63;
-    const size_t need = (64 + 2 * answer + 4095) & ~(size_t)4095;
-    if (h->h_mail && h->mail_bytes >= need) return RAPID_OK;
-    if (h->h_mail) (void)hipHostFree(h->h_mail);
-    h->h_mail = nullptr;
-    h->h_pinned = nullptr;
-    HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_mail), need, hipHostMallocMapped | hipHostMallocCoherent));
-    HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_mail), h->h_mail, 0));
-    std::memset(h->h_mail, 0, need);
-    h->mail_bytes = need;
+    const size_t mail = (64 + 2 * answer + 4095) & ~(size_t)4095;
+    const size_t stage = ((size_t)29 * (size_t)h->cfg.n_max + 256 + 4095) & ~(size_t)4095;
+    const size_t need = (mail + stage + 65535) & ~(size_t)65535;
+    HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_arena), need, hipHostMallocMapped | hipHostMallocCoherent));
+    unsigned char* dev = nullptr;
+    HIPCHK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), h->h_arena, 0));
+    std::memset(h->h_arena, 0, need);
+    h->arena_bytes = need;
+    h->h_mail = h->h_arena;
+    h->d_mail = dev;
+    h->mail_bytes = mail;
     h->h_pinned = reinterpret_cast<unsigned long long*>(h->h_mail + 64 + answer);
+    h->h_vstage = h->h_arena + mail;
+    h->vstage_bytes = need - mail;
     return RAPID_OK;
+}
+
+int ensure_mailbox(rapid_engine* h) {
+    return h->h_mail ? RAPID_OK : fail(h, RAPID_ESTATE, "the engine has no mailbox (rapid_engine_create allocates it)");
 }
 
 // Waits for a kernel's answer in the host-mapped mailbox: the kernel's last act is a system-scope fence and the write of
@@ -1279,6 +1406,12 @@ int rapid_engine_create(const rapid_engine_config* cfg, rapid_engine** out) {
         delete h;
         return RAPID_EDEVICE;
     }
+    if (ensure_arena(h) != RAPID_OK) {
+        (void)hipStreamDestroy(h->stream);
+        (void)hipGetLastError();
+        delete h;
+        return RAPID_EDEVICE;
+    }
     *out = h;
     return RAPID_OK;
 }
@@ -1300,9 +1433,8 @@ void rapid_engine_destroy(rapid_engine* h) {
     if (h->ev_idx1) quiet(hipEventDestroy(h->ev_idx1), "hipEventDestroy");
     if (h->ev0) quiet(hipEventDestroy(h->ev0), "hipEventDestroy");
     if (h->ev1) quiet(hipEventDestroy(h->ev1), "hipEventDestroy");
-    if (h->h_mail) quiet(hipHostFree(h->h_mail), "hipHostFree(mailbox)");
+    if (h->h_arena) quiet(hipHostFree(h->h_arena), "hipHostFree(mailbox + view staging)");
     if (h->h_alert_stage) quiet(hipHostFree(h->h_alert_stage), "hipHostFree(alert staging)");
-    if (h->h_vstage) quiet(hipHostFree(h->h_vstage), "hipHostFree(view staging)");
     if (h->ev_alert) quiet(hipEventDestroy(h->ev_alert), "hipEventDestroy");
     for (hipEvent_t e : {h->ev_gen_ready[0], h->ev_gen_ready[1], h->ev_gen_free[0], h->ev_gen_free[1], h->ev_gen_inputs})
         if (e) quiet(hipEventDestroy(e), "hipEventDestroy");
@@ -1333,6 +1465,97 @@ void rapid_engine_destroy(rapid_engine* h) {
 }
 
 const char* rapid_last_error(const rapid_engine* h) { return h ? h->err.c_str() : "null engine"; }
+
+// A known-answer test of the whole path on h's device, through the public entry points, on a PRIVATE engine (h's view, streams and
+// results are not touched): five endpoints 10.0.0.0 .. 10.0.0.4 : 5000 with NodeIds (i + 1, i + 101), K = H = 3, L = 1 -- the
+// view's configuration id and ring 0 must be the constants below (the CPU oracle's, restated by tests/test_abi.py so that they cannot
+// drift); node 4 is then reported DOWN on every ring to the four other receivers, the fast round must decide the cut {4} with four of
+// four votes, and the configuration id after the cut must be the second constant.  RAPID_OK, or RAPID_EDEVICE with the first
+// difference in rapid_last_error(h).  A host calls it once after rapid_engine_create: a runtime or a device that cannot do this is
+// found out by an error code, before the first real view is built (INTEGRATION.md section 6 -- a device FAULT still ends the process;
+// nothing in a process can catch that).
+int rapid_engine_self_test(rapid_engine* h) {
+    if (!h) return RAPID_EINVAL;
+    static const int64_t kCfg = 886890972789580738ll, kCfgAfter = -3371242312397245251ll;
+    static const int32_t kRing0[5] = {4, 1, 2, 0, 3}, kRing0After[4] = {1, 2, 0, 3};
+    rapid_engine_config cfg = h->cfg;
+    cfg.n_max = 8;
+    cfg.K = 3;
+    cfg.H = 3;
+    cfg.L = 1;
+    cfg.max_cut = 0;
+    rapid_engine* t = nullptr;
+    int rc = rapid_engine_create(&cfg, &t);
+    if (rc != RAPID_OK || !t) return fail(h, RAPID_EDEVICE, "self test: a second engine could not be created on device %d (%d)", h->cfg.device_id, rc);
+    std::string why;
+    auto bad = [&](const char* fmt, ...) {
+        char buf[400];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        why = buf;
+        return RAPID_EDEVICE;
+    };
+    auto run = [&]() -> int {
+        uint8_t blob[5 * 8];
+        int32_t off[6] = {0, 0, 0, 0, 0, 0}, ports[5], members[5];
+        int64_t hi[5], lo[5];
+        for (int i = 0; i < 5; ++i) {
+            const int len = snprintf(reinterpret_cast<char*>(blob) + off[i], 9, "10.0.0.%d", i);
+            off[i + 1] = off[i] + len;
+            ports[i] = 5000;
+            members[i] = i;
+            hi[i] = i + 1;
+            lo[i] = i + 101;
+        }
+        int r = rapid_view_build(t, blob, off, ports, hi, lo, 5, members, 5, nullptr, nullptr, 0);
+        if (r) return bad("rapid_view_build: %d (%s)", r, rapid_last_error(t));
+        int64_t id = 0;
+        if ((r = rapid_view_config_id(t, &id))) return bad("rapid_view_config_id: %d (%s)", r, rapid_last_error(t));
+        if (id != kCfg) return bad("configuration id of the 5-node view is %lld, expected %lld", (long long)id, (long long)kCfg);
+        int32_t ring[8], n = 0;
+        if ((r = rapid_view_ring(t, 0, ring, 8, &n))) return bad("rapid_view_ring: %d (%s)", r, rapid_last_error(t));
+        if (n != 5 || std::memcmp(ring, kRing0, sizeof kRing0) != 0) return bad("ring 0 of the 5-node view differs from the known answer");
+        int32_t obs[4];
+        if ((r = rapid_view_observers(t, 4, obs, 4, &n)) || n != 3) return bad("rapid_view_observers(4): %d, %d observers (%s)", r, n, rapid_last_error(t));
+        rapid_alert_record recs[4 * 3];
+        int64_t rec_off[5];
+        for (int rx = 0; rx < 4; ++rx) {
+            rec_off[rx] = 3 * rx;
+            for (int k = 0; k < 3; ++k) {
+                rapid_alert_record& a = recs[3 * rx + k];
+                std::memset(&a, 0, sizeof a);
+                a.cfg_id = kCfg;
+                a.src = (uint32_t)obs[k];
+                a.dst = 4u;
+                a.ring_mask = (uint16_t)(1u << k);
+                a.status = RAPID_EDGE_DOWN;
+                a.flags = k == 2 ? RAPID_ALERT_LAST_IN_BATCH : 0u;
+            }
+        }
+        rec_off[4] = 12;
+        if ((r = rapid_sim_load_streams(t, recs, rec_off, 4))) return bad("rapid_sim_load_streams: %d (%s)", r, rapid_last_error(t));
+        rapid_round_result rr;
+        std::memset(&rr, 0, sizeof rr);
+        int64_t after = 0;
+        if ((r = rapid_sim_round(t, 1, &rr, &after))) return bad("rapid_sim_round: %d (%s)", r, rapid_last_error(t));
+        if (rr.decided != 1 || rr.cut_size != 1 || rr.votes_winner != 4 || rr.quorum != 4)
+            return bad("the round decided %d, cut of %d, %lld votes, quorum %d; expected a decided cut of 1 with 4 of 4", rr.decided, rr.cut_size,
+                       (long long)rr.votes_winner, rr.quorum);
+        int32_t cut[4];
+        if ((r = rapid_sim_decided_cut(t, cut, 4, &n)) || n != 1 || cut[0] != 4) return bad("decided cut is not {4} (%d, n=%d)", r, n);
+        if (after != kCfgAfter) return bad("configuration id after the cut is %lld, expected %lld", (long long)after, (long long)kCfgAfter);
+        if ((r = rapid_view_ring(t, 0, ring, 8, &n)) || n != 4 || std::memcmp(ring, kRing0After, sizeof kRing0After) != 0)
+            return bad("ring 0 after the cut differs from the known answer");
+        return RAPID_OK;
+    };
+    rc = run();
+    rapid_engine_destroy(t);
+    (void)hipSetDevice(h->cfg.device_id);
+    if (rc != RAPID_OK) return fail(h, RAPID_EDEVICE, "self test failed: %s", why.c_str());
+    return RAPID_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ view
 int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* host_off, const int32_t* ports,
@@ -1401,6 +1624,7 @@ int rapid_view_build(rapid_engine* h, const uint8_t* hostnames, const int32_t* h
     HIPCHK(h, hipMemcpyAsync(h->d_ports.p, ports, sizeof(int) * (size_t)n_nodes, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(rapid::ring_keys_kernel, dim3(grid_for((long long)K * n_nodes, 256)), dim3(256), 0, h->stream,
                        h->d_blob.p, h->d_host_off.p, h->d_ports.p, n_nodes, K, h->d_keys.p, h->d_hx_host0.p, h->d_hx_port0.p);
+    LAUNCHCHK(h, "ring_keys_kernel");
     h->host_keys0_valid = false;
     HIPCHK(h, hipStreamSynchronize(h->stream));  // borrowed inputs may go away after the call
     h->streams_loaded = false;
@@ -1854,6 +2078,9 @@ int rapid_sim_load_streams_device(rapid_engine* h, const void* d_records, uint64
     if (!h || !d_rec_off || n_receivers < 0 || (!d_records && records_bytes)) return RAPID_EINVAL;
     int rc = use_device(h);
     if (rc) return rc;
+    if ((rc = check_borrowed(h, d_records, records_bytes, "rapid_sim_load_streams_device: records")) ||
+        (rc = check_borrowed(h, d_rec_off, 8ull * ((unsigned long long)n_receivers + 1ull), "rapid_sim_load_streams_device: offsets")))
+        return rc;
     long long n_rec = 0;
     if ((rc = check_device_offsets(h, d_rec_off, n_receivers, records_bytes, &n_rec))) return rc;
     h->streams_loaded = false;
@@ -1869,6 +2096,9 @@ int rapid_sim_attach_streams_device(rapid_engine* h, const void* d_records, uint
     if ((reinterpret_cast<uintptr_t>(d_records) & 3u) != 0u) return fail(h, RAPID_EINVAL, "records must be 4-byte aligned");
     int rc = use_device(h);
     if (rc) return rc;
+    if ((rc = check_borrowed(h, d_records, records_bytes, "rapid_sim_attach_streams_device: records")) ||
+        (rc = check_borrowed(h, d_rec_off, 8ull * ((unsigned long long)n_receivers + 1ull), "rapid_sim_attach_streams_device: offsets")))
+        return rc;
     // On the round's path: nothing is copied, nothing is launched, nothing is waited for.  The offsets are checked where they are,
     // by the wave of the tally kernel that is about to follow them (tally_kernel.h: TallyParams::stream_bytes): offsets that do
     // not lie inside the records are not followed, and the round's results come back as RAPID_EINVAL (rapid_sim_results /
@@ -2033,8 +2263,8 @@ int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, i
             h->h_alert_stage = nullptr;
             h->alert_stage_bytes = 0;
         }
-        const size_t want = bytes + bytes / 4 + 4096;
-        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_alert_stage), want, hipHostMallocDefault));
+        const size_t want = (std::max<size_t>(bytes + bytes / 4, 65536) + 65535) & ~(size_t)65535;  // (64 KiB granules, like the arena)
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_alert_stage), want, hipHostMallocMapped | hipHostMallocCoherent));
         h->alert_stage_bytes = want;
     }
     if (!h->ev_alert) HIPCHK(h, hipEventCreateWithFlags(&h->ev_alert, hipEventDisableTiming));
@@ -2048,6 +2278,9 @@ int rapid_sim_set_alert_set(rapid_engine* h, const rapid_alert_record* alerts, i
     h->n_alert_set = n_alerts;
     h->d_alerts = h->d_alert_set.p;
     h->index_valid = false;
+    // the delivered records were generated from ANOTHER set: what the library could vouch for ("every record is a copy of a declared
+    // alert of the current configuration") it can vouch for no longer -- records_known_current() must look at the records again
+    h->streams_generated = false;
     return RAPID_OK;
 }
 
@@ -2059,9 +2292,15 @@ int rapid_sim_set_alert_set_device(rapid_engine* h, const void* d_alerts, uint64
     if (!h->streams_loaded) return fail(h, RAPID_ESTATE, "load the streams first");
     if (h->rec_fmt == rapid::kFmtResident)
         return fail(h, RAPID_ESTATE, "generated deliveries are copies of the alert set they were generated from (rapid_sim_generate declares it)");
+    {
+        int rc = use_device(h);
+        if (rc) return rc;
+        if ((rc = check_borrowed(h, d_alerts, (unsigned long long)n_alerts * 20ull, "rapid_sim_set_alert_set_device: alerts"))) return rc;
+    }
     h->d_alerts = static_cast<const unsigned char*>(d_alerts);  // read in place by the round index; nothing is copied or waited for
     h->n_alert_set = n_alerts;
     h->index_valid = false;
+    h->streams_generated = false;  // (as in rapid_sim_set_alert_set)
     return RAPID_OK;
 }
 
@@ -2442,9 +2681,44 @@ int rapid_debug_vote_merge(rapid_engine* h, const void* segments, int32_t n_rank
         }                                                                                       \
     } while (0)
 
+static int round_tiled_impl(rapid_engine* h, const rapid_alert_record* alerts, const int64_t* batch_off, int32_t n_batches,
+                            const uint32_t* batch_keep, const int32_t* receivers, int32_t n_receivers, int32_t tile_receivers,
+                            uint64_t seed, int32_t format, rapid_round_result* out);
+
+// A tiled round that fails on the way -- a device error, a collective that returns an error, an impure vote bucket -- leaves NOTHING of
+// its tile state behind: both streams are drained, the per-receiver results are invalid, no streams are loaded, and the caller's
+// trust setting is what it was.  (Sharded: a rank that fails before the all-gather leaves its peers waiting in it -- the caller
+// aborts the communicator, as after any rank failure)
 int rapid_sim_round_tiled(rapid_engine* h, const rapid_alert_record* alerts, const int64_t* batch_off, int32_t n_batches,
                           const uint32_t* batch_keep, const int32_t* receivers, int32_t n_receivers, int32_t tile_receivers,
                           uint64_t seed, int32_t format, rapid_round_result* out) {
+    const bool trust_before = h ? h->trust_copies : false, late_before = h ? h->no_late_copies : false;
+    const int rc = round_tiled_impl(h, alerts, batch_off, n_batches, batch_keep, receivers, n_receivers, tile_receivers, seed, format, out);
+    if (h) {
+        h->trust_copies = trust_before;  // (the round vouches for its own deliveries while it runs: see launch_tally)
+        h->no_late_copies = late_before;
+        h->out_base = 0;
+        if (rc != RAPID_OK && rc != RAPID_EINVAL && rc != RAPID_ESTATE) {
+            if (h->stream_gen) (void)hipStreamSynchronize(h->stream_gen);
+            if (h->stream) (void)hipStreamSynchronize(h->stream);
+            (void)hipGetLastError();
+            h->n_receivers = 0;
+            h->tiled_total = 0;
+            h->tiled_block = nullptr;
+            h->tiled_last_base = h->tiled_last_n = 0;
+            h->tallied = false;
+            h->have_decision = false;
+            h->streams_loaded = false;
+            h->streams_generated = false;
+            h->index_valid = false;
+        }
+    }
+    return rc;
+}
+
+static int round_tiled_impl(rapid_engine* h, const rapid_alert_record* alerts, const int64_t* batch_off, int32_t n_batches,
+                            const uint32_t* batch_keep, const int32_t* receivers, int32_t n_receivers, int32_t tile_receivers,
+                            uint64_t seed, int32_t format, rapid_round_result* out) {
     if (!h || !out || !batch_off || n_batches < 0 || n_receivers < 0 || (n_receivers > 0 && !receivers) || tile_receivers < 0) return RAPID_EINVAL;
     if (format != RAPID_GEN_RESOLVED && format != RAPID_GEN_BOUNDARY) return fail(h, RAPID_EINVAL, "unknown record format %d", format);
     if (!h->view_built) return fail(h, RAPID_ESTATE, "view not built");

@@ -67,6 +67,10 @@ class Engine:
     def sync(self):
         self._check(self._lib.rapid_engine_sync(self._h))
 
+    def self_test(self):
+        """rapid_engine_self_test: a known-answer view + round on a private engine on this device; raises RapidError(EDEVICE)."""
+        self._check(self._lib.rapid_engine_self_test(self._h))
+
     @property
     def stream(self):
         return self._lib.rapid_engine_stream(self._h)

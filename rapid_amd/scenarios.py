@@ -441,7 +441,7 @@ class StreamingChurn:
         self.ever_member = None  # identifiers are never pruned (quirk Q5): a node joins once
 
     def next_round_batches(self, obs, member, cfg_id):
-        """The round WITHOUT materialised deliveries -- what rapid_sim_generate / rapid_sim_round_population take: the scenario
+        """The round WITHOUT materialised deliveries -- what rapid_sim_generate / rapid_sim_round_tiled take: the scenario
         (receivers = every surviving member, batches = the round's own alerts) and the batch set to deliver (+ the late
         deliveries of the previous configuration as additional batches).  -> (scenario, batch set to deliver)."""
         is_member = np.asarray(member) != 0

@@ -119,3 +119,24 @@ def test_fast_round_filters():
     for s, p in enumerate(([1, 2], [2, 1], [1, 2])):
         assert not fp.handleFastRoundProposal(s, 1, p)
     assert fp.handleFastRoundProposal(3, 1, [1, 2]) is False  # 3 votes for [1,2] < N - F = 4
+
+
+def test_self_test_constants_are_the_oracles():
+    """rapid_engine_self_test (csrc/engine.hip) compares the device's answers for a fixed 5-node cluster with constants compiled into
+    the library; they are the CPU oracle's values for the same endpoints -- recomputed here, so they cannot drift unnoticed.  (The
+    product never calls the oracle: the constants are how it knows the answers.)"""
+    from oracle import pyoracle as O
+    src = open(os.path.join(ROOT, "rapid_amd", "csrc", "engine.hip")).read()
+    body = src[src.index("int rapid_engine_self_test(rapid_engine* h) {"):]
+    body = body[:body.index("\n}\n")]
+    cfg, after = [int(x) for x in re.search(r"kCfg = (-?\d+)ll, kCfgAfter = (-?\d+)ll", body).groups()]
+    ring0 = [int(x) for x in re.search(r"kRing0\[5\] = \{([^}]*)\}", body).group(1).split(",")]
+    ring0_after = [int(x) for x in re.search(r"kRing0After\[4\] = \{([^}]*)\}", body).group(1).split(",")]
+    reg = O.Registry()
+    for i in range(5):
+        assert reg.intern(b"10.0.0.%d" % i, 5000) == i
+    view = O.MembershipView(reg, 3, [(i + 1, i + 101) for i in range(5)], list(range(5)))
+    assert view.getCurrentConfigurationId() == cfg and view.getRing(0).tolist() == ring0
+    assert len(view.getObserversOf(4)) == 3
+    view.ringDelete(4)
+    assert view.getCurrentConfigurationId() == after and view.getRing(0).tolist() == ring0_after

@@ -35,11 +35,14 @@ def test_tally_kernels_fit_the_register_file_without_scratch():
         assert r["Occupancy [waves/SIMD]"] >= (2 if packed else 3 if twelve else 4), (name, r)
 
 
-def test_every_other_kernel_of_the_path_is_scratch_free_too():
+def test_no_kernel_of_the_product_uses_scratch_memory():
+    """EVERY kernel in librapid_mi355x.so, the library sort's included (round 6: the default configuration of rocPRIM's segmented
+    radix sort spilled 148 bytes per lane on gfx950 -- the only kernels of the product that made the runtime set up a scratch arena
+    on the queue, inside the first call every user makes; csrc/engine.hip: RingSortConfig)."""
     res = resources()
     ours = {k: v for k, v in res.items() if k.startswith("_ZN5rapid")}
-    assert len(ours) >= 20
-    spilling = {k: v["ScratchSize [bytes/lane]"] for k, v in ours.items() if v.get("ScratchSize [bytes/lane]", 0) != 0}
+    assert len(ours) >= 20 and len(res) > len(ours)  # (the report covers the library's kernels, too)
+    spilling = {k[:160]: v["ScratchSize [bytes/lane]"] for k, v in res.items() if v.get("ScratchSize [bytes/lane]", 0) != 0}
     assert not spilling, spilling
 
 
