@@ -1,0 +1,129 @@
+"""The error contract at the drop-in boundary, on the device (-m gpu): what a host must get back as an error CODE where a
+kernel reading the argument would otherwise fault -- and a device fault ends the process, in a deployment the JVM
+(INTEGRATION.md section 6).  The reference's own contract here is exceptions, never a crash: R/MembershipView.java:502-519,
+R/MultiNodeCutDetector.java:52-55."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from rapid_amd import scenarios as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    from rapid_amd import engine
+    if engine.device_count() < 1:
+        pytest.fail("no gfx950 device visible: the product has no CPU fallback")
+    return engine
+
+
+@pytest.fixture(scope="module")
+def hip():
+    h = C.CDLL("libamdhip64.so")
+    h.hipMalloc.argtypes, h.hipMemcpy.argtypes, h.hipFree.argtypes = [C.POINTER(C.c_void_p), C.c_size_t], [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int], [C.c_void_p]
+    h.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    h.hipHostFree.argtypes = [C.c_void_p]
+    return h
+
+
+def to_device(hip, a, slack=0):
+    a = np.ascontiguousarray(a)
+    ptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(ptr), max(a.nbytes + slack, 16)) == 0
+    assert hip.hipMemcpy(ptr, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0
+    return ptr
+
+
+def test_borrowed_device_buffers_are_checked_before_a_kernel_reads_them(E, hip):
+    n, K, H, L = 300, 10, 9, 4
+    pop = S.Population.make(n)
+    eng = E.Engine(n_max=n, K=K, H=H, L=L)
+    view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
+    obs, subj, member = view.tables()
+    sc = S.build_scenario("C2", subj, view.getCurrentConfigurationId(), n=n, f=5, H=H, L=L)
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(sc.records, sc.rec_off)
+    sim.tally()
+    want = [a.copy() for a in sim.results()]
+    raw = np.ascontiguousarray(sc.records).view(np.uint8).reshape(-1)
+    off = np.ascontiguousarray(sc.rec_off, dtype=np.int64)
+    R = len(off) - 1
+    d_rec, d_off = to_device(hip, raw), to_device(hip, off)
+    # ordinary host memory where a device pointer is required: an error code, not a fault in the tally kernel
+    for fn in (sim.attach_streams_device, sim.load_streams_device):
+        with pytest.raises(E.IllegalArgumentException, match="host memory|not memory"):
+            fn(raw.ctypes.data, raw.nbytes, d_off.value, R)
+        with pytest.raises(E.IllegalArgumentException, match="host memory|not memory"):
+            fn(d_rec.value, raw.nbytes, off.ctypes.data, R)
+        # a length that runs past the allocation (the tally would read the neighbour's memory, or an unmapped page)
+        with pytest.raises(E.IllegalArgumentException, match="run past the end"):
+            fn(d_rec.value, raw.nbytes + (64 << 20), d_off.value, R)
+        # fewer offsets in the buffer than receivers + 1
+        with pytest.raises(E.IllegalArgumentException, match="run past the end"):
+            fn(d_rec.value, raw.nbytes, d_off.value, R + (8 << 20))
+    # the refused calls changed nothing: the loaded streams are still the loaded streams
+    sim.new_round()
+    sim.tally()
+    assert all(np.array_equal(a, b) for a, b in zip(want, sim.results()))
+    al = np.ascontiguousarray(sc.batches.recs).view(np.uint8).reshape(-1)
+    d_al = to_device(hip, al)
+    sim.attach_streams_device(d_rec.value, raw.nbytes, d_off.value, R)
+    with pytest.raises(E.IllegalArgumentException, match="host memory|not memory"):
+        sim.set_alert_set_device(al.ctypes.data, len(al) // 20)
+    with pytest.raises(E.IllegalArgumentException):
+        sim.set_alert_set_device(d_al.value, len(al) // 20 + (4 << 20), alerts_bytes=20 * (len(al) // 20 + (4 << 20)))
+    # host-mapped pinned memory IS device-readable: accepted (a producer may leave a small round there)
+    hp = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(hp), max(raw.nbytes, 4096), 0x2 | 0x40000000) == 0  # hipHostMallocMapped | hipHostMallocCoherent
+    C.memmove(hp, raw.ctypes.data, raw.nbytes)
+    sim.attach_streams_device(hp.value, raw.nbytes, d_off.value, R)
+    sim.tally()
+    assert all(np.array_equal(a, b) for a, b in zip(want, sim.results()))
+    sim.attach_streams_device(d_rec.value, raw.nbytes, d_off.value, R)
+    sim.tally()
+    assert all(np.array_equal(a, b) for a, b in zip(want, sim.results()))
+    eng.close()
+    assert hip.hipHostFree(hp) == 0
+    for p in (d_rec, d_off, d_al):
+        assert hip.hipFree(p) == 0
+
+
+def test_self_test_leaves_the_engine_alone(E):
+    """rapid_engine_self_test runs on a private engine: the caller's view, loaded streams and results are what they were."""
+    n, K, H, L = 200, 10, 9, 4
+    pop = S.Population.make(n)
+    eng = E.Engine(n_max=n, K=K, H=H, L=L)
+    eng.self_test()  # before a view exists
+    view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
+    cfg = view.getCurrentConfigurationId()
+    obs, subj, member = view.tables()
+    sc = S.build_scenario("C2", subj, cfg, n=n, f=4, H=H, L=L)
+    sim = E.ClusterSimulation(eng)
+    sim.load_streams(sc.records, sc.rec_off)
+    sim.tally()
+    want = [a.copy() for a in sim.results()]
+    eng.self_test()
+    assert view.getCurrentConfigurationId() == cfg
+    assert all(np.array_equal(a, b) for a, b in zip(want, sim.results()))
+    rr, new_cfg = sim.round(apply=True)
+    assert rr.decided == 1 and sorted(sim.decided_cut()) == sc.faulty.tolist()
+    eng.self_test()
+    assert view.getCurrentConfigurationId() == new_cfg
+
+
+def test_view_errors_name_the_call_and_leave_the_view(E):
+    """RAPID_EINVAL paths of rapid_view_build leave a built view as it was (argument checks come before any device work)."""
+    n, K = 40, 5
+    pop = S.Population.make(n)
+    eng = E.Engine(n_max=n, K=K, H=4, L=2)
+    view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
+    cfg = view.getCurrentConfigurationId()
+    with pytest.raises(E.IllegalArgumentException):
+        E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo, members=[0, 1, n + 3])
+    big = S.Population.make(n + 1)
+    with pytest.raises(E.IllegalArgumentException):
+        E.MembershipView(eng).build(big.hostnames, big.ports, big.id_hi, big.id_lo)  # over n_max
+    assert view.getCurrentConfigurationId() == cfg and view.getMembershipSize() == n
