@@ -192,9 +192,12 @@ def main():
         sim.set_alert_set_device(d_alert_sets[i % n_sets].data_ptr(), len(alert_set), trust_copies=True, keepalive=d_alert_sets)
 
     def step(i):
-        fresh_round(i)
-        sim.tally()
-        return sim.count_votes()  # blocks until the decision is on the host
+        """One fresh round through the library's one-call form (rapid_sim_round_device = attach in place + declare in place +
+        trust level 1 + index + tally + vote count; nothing applied): what fresh_round() + tally() + count_votes() do in five calls."""
+        d_rec, d_off, n_rx = sets[i % n_sets]
+        rr, _ = sim.round_device(d_rec.data_ptr(), d_rec.numel(), d_off.data_ptr(), n_rx, d_alert_sets[i % n_sets].data_ptr(),
+                                 len(alert_set), trust=1, apply=False, keepalive=(sets, d_alert_sets))
+        return rr  # (returned when the decision is on the host)
 
     for i in range(args.warmup):
         rr = step(i)

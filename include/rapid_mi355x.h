@@ -277,6 +277,14 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out);
 int rapid_sim_decided_cut(rapid_engine* h, int32_t* out, int32_t cap, int32_t* n_out); /* ring-0 order */
 /* tally + vote count (+ apply, if decided and apply != 0): one full round; new_config_id may be NULL */
 int rapid_sim_round(rapid_engine* h, int32_t apply, rapid_round_result* out, int64_t* new_config_id);
+/* The same for a round whose deliveries and distinct alerts already lie in device memory, in ONE call: rapid_sim_attach_streams_device
+ * + rapid_sim_set_alert_set_device (skipped if d_alerts is NULL and n_alerts 0: nothing declared) + rapid_sim_trust_alert_copies(trust)
+ * + rapid_sim_round -- same checks, same errors, same state afterwards; one crossing of the host's foreign-function boundary per
+ * round instead of four (the per-round sequence of R/MembershipService.java:300-354 followed by R/FastPaxos.java:94-156 and, when
+ * apply != 0 and the round decides, R/MembershipService.java:385-430). */
+int rapid_sim_round_device(rapid_engine* h, const void* d_records, uint64_t records_bytes, const int64_t* d_rec_off, int32_t n_receivers,
+                           const void* d_alerts, uint64_t alerts_bytes, int64_t n_alerts, int32_t trust, int32_t apply,
+                           rapid_round_result* out, int64_t* new_config_id);
 
 /* ---- one round over a population that does not fit one launch (BASELINE configs[4]: 10^6 receivers x ~1.5 x 10^5 deliveries) ------
  * The receivers are taken TILE BY TILE: a tile's deliveries are made on the device from the round's alert set exactly as
@@ -488,7 +496,10 @@ int rapid_sim_pass_times(rapid_engine* h, float out[4]);
  * is eligible (every named subject hot, at most 2^21 nodes), 2097152 = a tiled round (rapid_sim_round_tiled) makes and tallies its
  * tiles strictly one after the other on one stream (by default the next tile's deliveries are made on a second stream while this
  * tile is tallied), 4194304 = boundary records known to be of the engine's own configuration still have their configuration
- * ids loaded and compared per delivery (see rapid_sim_trust_alert_copies, level 2),
+ * ids loaded and compared per delivery (see rapid_sim_trust_alert_copies, level 2), 8388608 = the fast round is settled INSIDE
+ * the tally launch (the first workgroup to finish publishes its first voter's proposal as the candidate, every workgroup compares its
+ * voters' bitmaps with it at its end, the last one lays down the answer block: no counting or verifying launch follows; measured
+ * at N = 10^4: the round 1 % shorter, the tally kernel 2-3 % longer -- opt-in),
  * 32 = measurement only: stream the records through
  * the registers without tallying them (results are meaningless).  Every bit selects another PRODUCT path or instantiation
  * (all of them parity-tested); none adds code that the default does not ship. */

@@ -198,6 +198,7 @@ def _signatures():
         "rapid_sim_count_votes": (i32, [vp, C.POINTER(RoundResult)]),
         "rapid_sim_decided_cut": (i32, [vp, p, i32, pi32]),
         "rapid_sim_round": (i32, [vp, i32, C.POINTER(RoundResult), pi64]),
+        "rapid_sim_round_device": (i32, [vp, p, u64, p, i32, p, u64, i64, i32, i32, C.POINTER(RoundResult), pi64]),
         "rapid_apply_cut": (i32, [vp, p, i32, pi64]),
         "rapid_fast_round_create": (i32, [i64, i32, C.POINTER(vp)]),
         "rapid_fast_round_destroy": (None, [vp]),

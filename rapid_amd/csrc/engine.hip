@@ -209,6 +209,14 @@ struct rapid_engine {
     int idxwork_clean_n = -1;
     bool tally_bitmaps_valid = false;  // d_bitmaps holds the voters' proposals of the last tally launch as slot bitmaps (TallyParams::bitmaps)
     bool tally_votes_valid = false;  // d_voteback holds the vote statistics of the last tally launch (tally_kernel.h: vote_res)
+    // the fast round settled inside the tally launch (tally_kernel.h: TallyParams::vote_cand): d_voteback holds the COMPLETE answer block
+    // of the last launch -- candidate, its verified votes, voters, its node list -- and, for a population held by one rank, the
+    // host-mapped page received it under sequence number tally_settled_seq; no counting or verifying launch follows
+    bool tally_settled_valid = false;
+    unsigned int tally_settled_seq = 0;
+    bool settle_in_tally = true;  // (false inside a tiled round: its votes are accumulated across the tiles' launches by kernels of their own)
+    DevBuf<unsigned long long> d_vote_cand;   // [4 + 64]
+    DevBuf<unsigned int> d_vote_deferred;     // [1 + kVoteDeferredCap]
     bool stats_fresh = false;  // the statistics were zeroed by the index build of this very call
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // timing events, created once (no create / destroy per call, nothing to leak on an error path)
     DevBuf<unsigned short> d_dict, d_decl, d_adj_off, d_trank;
@@ -1248,6 +1256,7 @@ int launch_tally(rapid_engine* h) {
     p.stats = h->d_stats.p;  // [grid_blocks][8]
     p.waves_per_block = h->waves_per_block;
     p.flags = h->force_exact & (1 | 4 | 8 | 32);
+    if (const char* e = env_knob("RAPID_SETTLE_SKIP")) p.flags |= (atoi(e) & 7) << 10;  // measurement knob (test build): parts of the in-launch vote settlement left out
     p.stagger = 0;
     if (const char* e = env_knob("RAPID_TALLY_STAGGER")) p.stagger = std::max(0, std::min(64, atoi(e)));  // profiling knob
     // The last eighth of the receivers is not dealt to the workgroups but left in a common pool (tally_kernel.h: n_static),
@@ -1264,6 +1273,38 @@ int launch_tally(rapid_engine* h) {
     p.bitmaps = h->d_bitmaps.p;
     h->tally_bitmaps_valid = true;
     h->bitmap_words = p.bitmap_words;
+    // The fast round settled by the launch itself -- OPT-IN (knob bit 23 of rapid_sim_set_force_exact).  Measured at C3b on two boxes
+    // (profiles/r06_ab_settle_in_tally.txt): the verification launch (12 us) disappears from the round's path, the tally launch grows
+    // by 6-11 us (its last workgroup's chain of round trips: candidate, comparison, totals, answer), the round gets 3-5 us shorter
+    // (1 %) and the dominant kernel 2-3 % longer -- not a trade the default should make.
+    p.vote_cand = nullptr;
+    p.vote_deferred = nullptr;
+    p.vote_deferred_cap = 0;
+    p.vote_publish = nullptr;
+    p.vote_seq_out = nullptr;
+    p.vote_seq = 0u;
+    h->tally_settled_valid = false;
+    if (h->settle_in_tally && h->out_base == 0 && p.bitmap_words <= 64 && h->n_receivers <= 262144 && (h->force_exact & 8388608) != 0 &&
+        (h->force_exact & (2048 | 262144 | 512)) == 0) {
+        constexpr int kVoteDeferredCap = 4096;
+        if (!h->d_vote_cand.p) {
+            HIPCHK(h, h->d_vote_cand.ensure(4 + 64));
+            HIPCHK(h, h->d_vote_deferred.ensure(1 + kVoteDeferredCap));
+            HIPCHK(h, hipMemsetAsync(h->d_vote_cand.p, 0, (4 + 64) * 8, h->stream));  // (once: every launch leaves them zeroed)
+            HIPCHK(h, hipMemsetAsync(h->d_vote_deferred.p, 0, (1 + kVoteDeferredCap) * 4, h->stream));
+        }
+        p.vote_cand = h->d_vote_cand.p;
+        p.vote_deferred = h->d_vote_deferred.p;
+        p.vote_deferred_cap = kVoteDeferredCap;
+        if (!h->comm) {  // one rank holds the population: the answer goes straight to the page the host polls
+            if (int rc = ensure_mailbox(h)) return rc;
+            p.vote_publish = reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64);
+            p.vote_seq_out = reinterpret_cast<volatile unsigned int*>(h->d_mail) + 14;
+            p.vote_seq = ++h->mail_seq;
+            h->tally_settled_seq = p.vote_seq;
+        }
+        h->tally_settled_valid = true;
+    }
     {
         const long long slots = (long long)h->grid_blocks * h->waves_per_block;
         const char* e = env_knob("RAPID_POOL_EIGHTHS");  // measurement knob: size of the pool in eighths of the population
@@ -1449,6 +1490,7 @@ void rapid_engine_destroy(rapid_engine* h) {
     h->d_gen_res.release(); h->d_gen_keep.release(); h->d_gen_boff.release(); h->d_gen_rx.release(); h->d_gen_bat.release();
     h->d_ids_hi2.release(); h->d_ids_lo2.release(); h->d_ids_new.release(); h->d_cfg_partial.release(); h->d_chunk_kept.release();
     h->d_bitmaps.release();
+    h->d_vote_cand.release(); h->d_vote_deferred.release();
     h->d_vacc.release();
     h->d_idacc.release(); h->d_chunk_base.release(); h->d_chunk_lb.release(); h->d_nonmembers.release();
     h->d_hoff.release(); h->d_hnew.release(); h->d_smask2.release(); h->d_hrem.release(); h->d_hmem.release(); h->d_adj2.release(); h->d_nos2.release();
@@ -2021,6 +2063,7 @@ static void streams_replaced(rapid_engine* h, int n_receivers, long long n_rec) 
     h->tallied = false;
     h->have_decision = false;
     h->tally_votes_valid = false;
+    h->tally_settled_valid = false;
 }
 
 static int own_records(rapid_engine* h, const unsigned char* src, hipMemcpyKind kind, long long n_rec) {
@@ -2320,6 +2363,7 @@ int rapid_sim_new_round(rapid_engine* h) {
     h->tallied = false;
     h->have_decision = false;
     h->tally_votes_valid = false;
+    h->tally_settled_valid = false;
     return RAPID_OK;
 }
 
@@ -2329,6 +2373,7 @@ int rapid_sim_tally(rapid_engine* h) {
     if (rc) return rc;
     if (h->tiled_total) return fail(h, RAPID_ESTATE, "the last round was taken tile by tile: load, attach or generate streams first");
     h->tally_votes_valid = false;  // (set again by the launch below; a call that launches nothing must not leave an older launch's statistics valid)
+    h->tally_settled_valid = false;
     if ((rc = prepare_tally(h))) return rc;
     if (!h->stats_fresh) HIPCHK(h, hipMemsetAsync(h->d_stats.p, 0, (size_t)64 * ((size_t)std::max(h->grid_blocks, 1) + 1), h->stream));
     if (h->n_receivers > 0) {
@@ -2505,24 +2550,28 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
     // histogram -> (all-reduce) -> winner -> min/max of the winning bucket -> (all-reduce) -> representative list
     // -> (all-reduce) -> element-wise verification -> (all-reduce).
     bool from_tally_used = false;
+    unsigned int settled_seq = 0u;  // the sequence number the single-rank answer arrives under
     for (unsigned long long salt = 0; salt < 4; ++salt) {
         from_tally_used = false;
         if (merged) {
             // this rank's answer block: candidate, its verified votes, the rank's voters, the candidate's list -- from the
             // statistics the tally kernel gathered when they are fresh (no counting pass), else from the counting kernel
             const bool from_tally = h->tally_votes_valid && salt == 0 && (h->force_exact & 2048) == 0;
+            const bool settled_by_tally = from_tally && h->tally_settled_valid;  // this rank's answer block is complete already (TallyParams::vote_cand)
             h->tally_votes_valid = false;
+            h->tally_settled_valid = false;
             if (!from_tally)
                 hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st,
                                    h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
             // (published "to" the block itself: the last workgroup completes res[] and, from_tally, copies the list into ref[])
             const bool by_bits = from_tally && h->tally_bitmaps_valid && (h->force_exact & 262144) == 0;  // (the voters' bitmaps of the same launch: 64 bytes per receiver instead of a list)
             const int bits_wave = by_bits && h->bitmap_words > 16 ? 1 : 0;  // (bitmaps of more than 128 bytes: a wave per receiver)
-            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * (by_bits && !bits_wave ? 1 : 64), 1024))), dim3(1024), 0, st,
-                               h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, d_res,
-                               (int)res_words, reinterpret_cast<unsigned int*>(d_res + 9), reinterpret_cast<volatile unsigned long long*>(d_res),
-                               nullptr, 0u, from_tally ? 1 : 0, h->d_errflags.p, by_bits ? h->d_bitmaps.p : (const unsigned long long*)nullptr,
-                               h->bitmap_words, bits_wave);
+            if (!settled_by_tally)
+                hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * (by_bits && !bits_wave ? 1 : 64), 1024))), dim3(1024), 0, st,
+                                   h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, d_res,
+                                   (int)res_words, reinterpret_cast<unsigned int*>(d_res + 9), reinterpret_cast<volatile unsigned long long*>(d_res),
+                                   nullptr, 0u, from_tally ? 1 : 0, h->d_errflags.p, by_bits ? h->d_bitmaps.p : (const unsigned long long*)nullptr,
+                                   h->bitmap_words, bits_wave);
             NCCLCHK(h, ncclAllGather(d_res, h->d_gather.p, seg_words, ncclUint64, h->comm, st));  // the round's one collective
             hipLaunchKernelGGL(rapid::vote_merge_kernel, dim3(1), dim3(256), 0, st, h->d_gather.p, h->n_ranks, (int)seg_words,
                                (int)res_words, h->max_cut, (long long)out->quorum, reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
@@ -2538,19 +2587,26 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
             // the tally kernel gathered the voters' statistics itself (tally_kernel.h: vote_acc): if they are unanimous -- the
             // common round -- no counting pass runs at all; the verification below reads the representative's list in place
             const bool from_tally = h->tally_votes_valid && salt == 0 && (h->force_exact & 2048) == 0;
+            // ... or the launch settled the round by itself (TallyParams::vote_cand): its last workgroup wrote the answer into the
+            // host-mapped page under tally_settled_seq -- NOTHING is launched here, the host only waits for that word
+            const bool settled_by_tally = from_tally && h->tally_settled_valid;
             h->tally_votes_valid = false;  // consumed: the verification below adds its counters to them
+            h->tally_settled_valid = false;
             if (!from_tally)
                 hipLaunchKernelGGL(rapid::vote_count_local_kernel, dim3(1), dim3(1024), (size_t)rapid::kVoteBuckets * 4 + 1024, st,
                                    h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, salt, h->d_errflags.p, d_res, d_ref);
             from_tally_used = from_tally;
             const bool by_bits = from_tally && h->tally_bitmaps_valid && (h->force_exact & 262144) == 0;  // (the voters' bitmaps of the same launch: 64 bytes per receiver instead of a list)
             const int bits_wave = by_bits && h->bitmap_words > 16 ? 1 : 0;  // (bitmaps of more than 128 bytes: a wave per receiver)
-            hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * (by_bits && !bits_wave ? 1 : 64), 1024))), dim3(1024), 0, st,
-                               h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, d_res,
-                               (int)res_words, reinterpret_cast<unsigned int*>(d_res + 9),
-                               reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
-                               reinterpret_cast<volatile unsigned int*>(h->d_mail) + 14, ++h->mail_seq, from_tally ? 1 : 0,
-                               h->d_errflags.p, by_bits ? h->d_bitmaps.p : (const unsigned long long*)nullptr, h->bitmap_words, bits_wave);
+            if (settled_by_tally)
+                settled_seq = h->tally_settled_seq;
+            else
+                hipLaunchKernelGGL(rapid::vote_verify_kernel, dim3(std::max(1u, grid_for((long long)R * (by_bits && !bits_wave ? 1 : 64), 1024))), dim3(1024), 0, st,
+                                   h->d_fp.p, h->d_pcount.p, h->d_props.p, h->max_cut, R, d_res + 4, d_ref, d_mismatch, d_res,
+                                   (int)res_words, reinterpret_cast<unsigned int*>(d_res + 9),
+                                   reinterpret_cast<volatile unsigned long long*>(h->d_mail + 64),
+                                   reinterpret_cast<volatile unsigned int*>(h->d_mail) + 14, (settled_seq = ++h->mail_seq), from_tally ? 1 : 0,
+                                   h->d_errflags.p, by_bits ? h->d_bitmaps.p : (const unsigned long long*)nullptr, h->bitmap_words, bits_wave);
         } else {
             HIPCHK(h, hipMemsetAsync(h->d_hist.p, 0, HB * 8, st));
             HIPCHK(h, hipMemsetAsync(h->d_mm.p, 0, 64, st));
@@ -2581,7 +2637,7 @@ int rapid_sim_count_votes(rapid_engine* h, rapid_round_result* out) {
         if (!local && !merged) HIPCHK(h, hipMemcpyAsync(hres, d_res, back_bytes, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipGetLastError());
         if (local) {
-            if ((rc = await_mail(h, 14, h->mail_seq))) return rc;
+            if ((rc = await_mail(h, 14, settled_seq))) return rc;
             if (from_tally_used) {
                 // settled iff the candidate (the lowest voter's proposal) has a quorum, or every voter holds it, or nobody
                 // voted; otherwise the exact plurality count is owed: histogram pass, same salt again
@@ -2631,6 +2687,7 @@ int rapid_debug_vote_segment(rapid_engine* h, void* out, int64_t cap_bytes, int6
     }
     HIPCHK(h, h->d_voteback.ensure(seg_words));
     h->tally_votes_valid = false;
+    h->tally_settled_valid = false;
     unsigned long long* const d_res = h->d_voteback.p;
     int* const d_ref = reinterpret_cast<int*>(d_res + res_words);
     const int R = h->n_receivers;
@@ -2693,8 +2750,10 @@ int rapid_sim_round_tiled(rapid_engine* h, const rapid_alert_record* alerts, con
                           const uint32_t* batch_keep, const int32_t* receivers, int32_t n_receivers, int32_t tile_receivers,
                           uint64_t seed, int32_t format, rapid_round_result* out) {
     const bool trust_before = h ? h->trust_copies : false, late_before = h ? h->no_late_copies : false;
+    if (h) h->settle_in_tally = false;  // (the tiles' votes are accumulated across launches: vote_acc_pick / _count / _finish)
     const int rc = round_tiled_impl(h, alerts, batch_off, n_batches, batch_keep, receivers, n_receivers, tile_receivers, seed, format, out);
     if (h) {
+        h->settle_in_tally = true;
         h->trust_copies = trust_before;  // (the round vouches for its own deliveries while it runs: see launch_tally)
         h->no_late_copies = late_before;
         h->out_base = 0;
@@ -2879,6 +2938,7 @@ static int round_tiled_impl(rapid_engine* h, const rapid_alert_record* alerts, c
             h->tiled_last_n = n;
         }
         h->tally_votes_valid = false;
+        h->tally_settled_valid = false;
         hipLaunchKernelGGL(rapid::vote_acc_finish_kernel, dim3(8), dim3(256), 0, st, acc, acc_list, h->max_cut, d_block, reinterpret_cast<int*>(d_block + res_words));
         HIPCHK(h, hipGetLastError());
         const unsigned long long* ans = nullptr;
@@ -3027,6 +3087,25 @@ int rapid_sim_round(rapid_engine* h, int32_t apply, rapid_round_result* out, int
         *new_config_id = h->config_id;
     }
     return RAPID_OK;
+}
+
+// A round whose deliveries and distinct alerts already lie in device memory, in ONE call: attach in place, declare in place, the
+// trust level, index + tally + vote count (+ apply).  What rapid_sim_attach_streams_device + rapid_sim_set_alert_set_device +
+// rapid_sim_trust_alert_copies + rapid_sim_round do one after the other -- the same checks, the same state afterwards -- without a
+// host paying four or five crossings of its foreign-function boundary per round (a JNI crossing with its pinning of arguments
+// costs about what a kernel launch does; from Python it is ~1.5 us per call: 5 us of a 450 us round at N = 10^4).
+int rapid_sim_round_device(rapid_engine* h, const void* d_records, uint64_t records_bytes, const int64_t* d_rec_off, int32_t n_receivers,
+                           const void* d_alerts, uint64_t alerts_bytes, int64_t n_alerts, int32_t trust, int32_t apply,
+                           rapid_round_result* out, int64_t* new_config_id) {
+    if (!h || !out) return RAPID_EINVAL;
+    if (trust < 0 || trust > 2) return fail(h, RAPID_EINVAL, "trust level %d (0, 1 or 2)", trust);
+    int rc = rapid_sim_attach_streams_device(h, d_records, records_bytes, d_rec_off, n_receivers);
+    if (rc) return rc;
+    if (d_alerts != nullptr || n_alerts > 0) {
+        if ((rc = rapid_sim_set_alert_set_device(h, d_alerts, alerts_bytes, n_alerts))) return rc;
+    }
+    if ((rc = rapid_sim_trust_alert_copies(h, trust))) return rc;
+    return rapid_sim_round(h, apply, out, new_config_id);
 }
 
 // ------------------------------------------------------------------------------------------- multi-GPU

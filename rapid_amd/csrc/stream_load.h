@@ -95,6 +95,10 @@ __device__ __forceinline__ void stream_store(unsigned long long* p, unsigned lon
     asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
+// Waits for every memory operation of this wave, the assembly stores above included (the compiler's wait-count pass does not know of
+// them, so a barrier's own s_waitcnt does not cover them): behind a workgroup barrier after this, the workgroup's results have left the CU.
+__device__ __forceinline__ void stream_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Sets bits in a word of global memory (no value returned); rare, issued from assembly like the stores.
 __device__ __forceinline__ void stream_flag_or(unsigned int* p, unsigned int bits) {
     asm volatile("global_atomic_or %0, %1, off" ::"v"(p), "v"(bits) : "memory");

@@ -225,6 +225,26 @@ struct TallyParams {
     // saturated), then everybody tallies the end of a stream and writes results (the memory system idle).
     int stagger;
     int flags;                        // bit0: exact path only, bit3: careful path only (both for tests); bit5: stream only
+    // The fast round SETTLED INSIDE THE LAUNCH (R/FastPaxos.java:125-156 counts identical proposals; a proposal with
+    // N - floor((N-1)/4) > N/2 votes is the only one that can have a quorum).  Every workgroup notes which of its receivers voted; at
+    // its end -- its waves have stopped streaming -- it looks for the round's CANDIDATE: the first workgroup to get there claims
+    // vote_cand[0] by compare-and-swap for its first voter and publishes that proposal's fingerprint, size and bitmap; every other
+    // workgroup compares its voters' bitmaps with the published one, word for word -- nothing is counted on fingerprints alone.  A
+    // workgroup that arrives inside the microsecond between claim and publication hands its voters to vote_deferred, and the launch's
+    // LAST workgroup compares those, then lays the answer down in vote_res[0..9] + the candidate's node list behind it -- exactly the
+    // block vote_verify_kernel (vote_kernels.h) used to complete in a launch of its own (12 us on the round's path at C3b) -- and, for
+    // a population held by one rank, into the host-mapped page the host polls (vote_publish / vote_seq_out).  Which voter's proposal
+    // is the candidate changes no result: a candidate with a quorum is decided; a candidate without one among voters that do not all
+    // hold it sends the round to the exact plurality count, as before.
+    //   vote_cand: [0] = 1 + the candidate's receiver (0: nobody has voted yet), [1] = published, [2] = fingerprint, [3] = its
+    //   prop_count, [4 .. 4 + bitmap_words) = its bitmap; all zero between launches.  vote_acc[0] = voters holding the candidate's
+    //   fingerprint whose bitmap differs, vote_acc[1] = voters holding it.  nullptr (or bitmap_words > 64): not settled here.
+    unsigned long long* vote_cand;
+    unsigned int* vote_deferred;      // [0] = how many, [1 .. 1 + vote_deferred_cap) = receivers; [0] zero between launches
+    int vote_deferred_cap;
+    volatile unsigned long long* vote_publish;
+    volatile unsigned int* vote_seq_out;
+    unsigned int vote_seq;
 };
 
 __host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
@@ -271,7 +291,10 @@ __host__ __device__ inline int tally_shared_bytes(int mode, int n_nodes, int n_t
            (!packed ? align16((n_hot + kDummySlots) * 2) + align16(n_hot * 4) : 0);
 }
 // per-workgroup statistics accumulator at the very end of the dynamic LDS segment
-constexpr int kBlockStatsBytes = 112;  // eight counters, the workgroup's claim counter, four vote accumulators
+// eight counters, the workgroup's claim counter, four vote accumulators (112 bytes); then, for the fast round settled inside the
+// launch (TallyParams::vote_cand): four flag words and the receivers of this workgroup that voted
+constexpr int kBlockVoters = 160;
+constexpr int kBlockStatsBytes = 112 + 16 + kBlockVoters * 4;
 // packed: two slots per LDS word (PackedSlotDetector) -- rounds with thousands of hot subjects, where the detector state decides
 // how many receivers a CU holds (C5: 15,000 hot subjects = 60 KB per receiver as 32-bit words)
 __host__ __device__ inline int tally_state_bytes(int n_slots, bool packed) { return align16((n_slots + kDummySlots) * (packed ? 2 : 4)); }
@@ -662,6 +685,23 @@ __host__ __device__ constexpr int tally_max_waves(int dict_mode, bool trusted, i
 // again) instead of two, no 64-bit compare, eight registers fewer per window in flight.  The bytes that cross the HBM interface
 // are the same 20 per record (the lines are the same); what is saved is the second request per line between L2 and the CU
 // (scripts/micro/boundary_shapes.hip, shape 2 against shape 0: 6.6 against 6.1 TB/s with nothing else going on).
+// Two proposal bitmaps compared word for word, both read with agent-scope atomic loads (another workgroup, maybe on another XCD, wrote
+// them), eight words of each requested together: the comparison is a chain of round trips, not bandwidth.
+__device__ inline bool bitmap_differs(const unsigned long long* a, const unsigned long long* b, int words) {
+    bool differs = false;
+    for (int w0 = 0; w0 < words; w0 += 8) {
+        unsigned long long x[8], y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x[j] = w0 + j < words ? __hip_atomic_load(a + w0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            y[j] = w0 + j < words ? __hip_atomic_load(b + w0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) differs = differs || x[j] != y[j];
+    }
+    return differs;
+}
+
 template <int kDictMode, bool kTrusted, int kFmt = kFmtResident, bool kPacked = false, bool kCurrent = false>
 __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked) * 64) RAPID_TALLY_OCCUPANCY void tally_population_kernel(TallyParams p) {
     static_assert(!kCurrent || (kTrusted && kFmt == kFmtBoundary), "only vouched-for boundary records can be known to be current");
@@ -831,6 +871,11 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
     if (threadIdx.x < 8u) block_stats[threadIdx.x] = 0ull;
     unsigned long long* const block_votes = block_stats + 10;  // [4], see TallyParams::vote_acc
     if (threadIdx.x >= 16u && threadIdx.x < 20u) block_votes[threadIdx.x - 16u] = 0ull;
+    // [0] = what the workgroup found when it looked for the round's candidate (0: nothing yet, 1: published, 2: claimed but not yet
+    // published), [1] = this is the launch's last workgroup, [2] = voters among this workgroup's receivers; then their indices
+    unsigned int* const cand_flags = reinterpret_cast<unsigned int*>(block_stats + 14);
+    unsigned int* const block_voters = reinterpret_cast<unsigned int*>(block_stats + 16);  // [kBlockVoters]
+    if (threadIdx.x >= 20u && threadIdx.x < 24u) cand_flags[threadIdx.x - 20u] = 0u;
     RAPID_HOOK_BLOCK_INIT();
     if (threadIdx.x == 8u) *block_claims = blockDim.x >> 6;  // claims 0 .. waves - 1 are the first deal
     __syncthreads();
@@ -1793,6 +1838,15 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
             if (count != 0 && p.vote_acc != nullptr) {  // this receiver votes (an oversized proposal is still a vote)
                 atomicAdd(&block_votes[2], 1ull);
                 atomicMax(&block_votes[3], ~(unsigned long long)(unsigned int)r);
+                if (p.vote_cand != nullptr && (p.flags & 1024) == 0) {  // noted for the workgroup's own comparison at its end (TallyParams::vote_cand)
+                    const unsigned int at = atomicAdd(&cand_flags[2], 1u);
+                    if (at < (unsigned int)kBlockVoters) {
+                        block_voters[at] = (unsigned int)r;
+                    } else {  // (a workgroup that took far more than its share from the pool: the launch's last workgroup compares)
+                        const unsigned int g = atomicAdd(p.vote_deferred, 1u);
+                        if (g < (unsigned int)p.vote_deferred_cap) p.vote_deferred[1 + g] = (unsigned int)r;
+                    }
+                }
             }
             RAPID_HOOK_RESULTS();
         }
@@ -1819,20 +1873,167 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
             p.pool[1] = 0u;
         }
     }
+    if (p.vote_cand != nullptr) {  // (kernel-uniform) this workgroup's voters against the round's candidate
+        // Here, at the workgroup's end, and not where each receiver finishes: the waves have stopped streaming, so the fences and the
+        // round trips to the candidate's words wait for nothing but themselves (done per receiver, inside the receiver loop, the same
+        // comparison cost the launch 0.04 ms at C3b: every fence drains the next stream's windows in flight and drops the CU's L1).
+        stream_drain();
+        __syncthreads();  // every result this workgroup stored has left the CU
+        // (No fence here: on gfx950 an agent-scope fence writes back and invalidates the XCD's whole L2 -- 3,840 waves doing that at the
+        // end of a launch cost it 0.05 ms.  What other workgroups read of this one's results they read with agent-scope atomic loads,
+        // after this workgroup's ONE release fence further down -- thread 0's, behind the barrier that drained everybody's stores.)
+        const unsigned int nv_all = (p.flags & 2048) != 0 ? 0u : cand_flags[2];
+        const unsigned int nv = nv_all < (unsigned int)kBlockVoters ? nv_all : (unsigned int)kBlockVoters;
+        const int words = p.bitmap_words;
+        if (nv != 0u) {
+            if (threadIdx.x == 0) {
+                const unsigned int r0 = block_voters[0];
+                const unsigned int prev = atomicCAS(reinterpret_cast<unsigned int*>(p.vote_cand), 0u, r0 + 1u);
+                if (prev == 0u) {  // nobody has voted before: this workgroup's first voter holds the round's CANDIDATE
+                    for (int w = 0; w < words; ++w)
+                        __hip_atomic_store(p.vote_cand + 4 + w, __hip_atomic_load(p.bitmaps + (long long)r0 * words + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.vote_cand + 2, __hip_atomic_load(p.fingerprint + r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.vote_cand + 3, (unsigned long long)(unsigned int)__hip_atomic_load(p.prop_count + r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __threadfence();  // (release: the candidate's words before the flag)
+                    __hip_atomic_store(p.vote_cand + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cand_flags[0] = 1u;
+                } else {  // (what is read of the candidate below is read with agent-scope atomic loads: no acquire fence)
+                    const unsigned long long ready = __hip_atomic_load(p.vote_cand + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cand_flags[0] = ready != 0ull ? 1u : 2u;
+                }
+            }
+            __syncthreads();
+            if (cand_flags[0] == 1u) {  // published: one thread per voter, the bitmaps compared word for word
+                const unsigned long long cf = __hip_atomic_load(p.vote_cand + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (unsigned int i = threadIdx.x; i < nv; i += blockDim.x) {
+                    const unsigned int rx = block_voters[i];
+                    if (__hip_atomic_load(p.fingerprint + rx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cf) continue;
+                    const bool differs = bitmap_differs(p.bitmaps + (long long)rx * words, p.vote_cand + 4, words);
+                    atomicAdd(&block_votes[1], 1ull);
+                    if (differs) atomicAdd(&block_votes[0], 1ull);
+                }
+            } else {  // claimed by another workgroup a moment ago, not yet published: the launch's last workgroup compares these
+                for (unsigned int i = threadIdx.x; i < nv; i += blockDim.x) {
+                    const unsigned int g = atomicAdd(p.vote_deferred, 1u);
+                    if (g < (unsigned int)p.vote_deferred_cap) p.vote_deferred[1 + g] = block_voters[i];
+                }
+            }
+            __syncthreads();
+        }
+    }
     if (threadIdx.x == 0 && p.vote_acc != nullptr) {
         if (block_votes[2] != 0ull) {
             atomicAdd(&p.vote_acc[2], block_votes[2]);
             atomicMax(&p.vote_acc[3], block_votes[3]);
+            if (block_votes[1] != 0ull) atomicAdd(&p.vote_acc[1], block_votes[1]);
+            if (block_votes[0] != 0ull) atomicAdd(&p.vote_acc[0], block_votes[0]);
         }
         __threadfence();  // this workgroup's share is visible before its count is (release; once per workgroup)
         if (atomicAdd(&p.vote_acc[4], 1ull) == (unsigned long long)gridDim.x - 1ull) {  // the last workgroup: every other one has added its share
             __threadfence();  // (acquire)
-            const unsigned long long voters = atomicAdd(&p.vote_acc[2], 0ull), repc = atomicAdd(&p.vote_acc[3], 0ull);
-            p.vote_res[0] = voters != 0ull ? (~repc & 0xFFFFFFFFull) : 0xFFFFFFFFull;
-            p.vote_res[1] = 0ull;
-            p.vote_res[2] = voters;
-            for (int i = 3; i < 10; ++i) p.vote_res[i] = 0ull;
-            for (int i = 0; i < 5; ++i) p.vote_acc[i] = 0ull;
+            if (p.vote_cand != nullptr) {
+                cand_flags[1] = 1u;  // (the answer is completed by the whole workgroup, below)
+                block_votes[0] = 0ull;
+                block_votes[1] = 0ull;
+            } else {
+                const unsigned long long voters = atomicAdd(&p.vote_acc[2], 0ull), repc = atomicAdd(&p.vote_acc[3], 0ull);
+                p.vote_res[0] = voters != 0ull ? (~repc & 0xFFFFFFFFull) : 0xFFFFFFFFull;
+                p.vote_res[1] = 0ull;
+                p.vote_res[2] = voters;
+                for (int i = 3; i < 10; ++i) p.vote_res[i] = 0ull;
+                for (int i = 0; i < 5; ++i) p.vote_acc[i] = 0ull;
+            }
+        }
+    }
+    if (p.vote_cand != nullptr) {  // (kernel-uniform)
+        __syncthreads();
+        if (cand_flags[1] != 0u) {  // the launch's last workgroup: every other one has added its share and published what it wrote
+            // the voters that finished between the candidate's claim and its publication (usually none): compared here, one thread
+            // each, against the published candidate -- their bitmaps and fingerprints were written before their workgroups counted
+            const int words = p.bitmap_words;
+            const unsigned int n_def_all = (p.flags & 4096) != 0 ? 0u : __hip_atomic_load(p.vote_deferred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int n_def = n_def_all < (unsigned int)p.vote_deferred_cap ? n_def_all : (unsigned int)p.vote_deferred_cap;
+            const unsigned long long cf = __hip_atomic_load(p.vote_cand + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (everything the answer needs is requested here, together: one round trip instead of four at the very end of the launch)
+            const unsigned long long owner1 = __hip_atomic_load(p.vote_cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFFFFull;
+            const unsigned long long voters = __hip_atomic_load(p.vote_acc + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long acc_seen = __hip_atomic_load(p.vote_acc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long acc_bad = __hip_atomic_load(p.vote_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int cnt = (int)(unsigned int)__hip_atomic_load(p.vote_cand + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int tally_err = __hip_atomic_load(p.error_flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int n_list = (owner1 == 0ull || cnt < 0 || cnt > p.prop_cap) ? 0 : cnt;
+            const int* const src = p.props + (long long)(owner1 == 0ull ? 0ull : owner1 - 1ull) * p.prop_cap;
+            int my_nodes[4];  // (the candidate's node list, up to four nodes per thread in flight: the whole list of a cut of 4,096)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = (int)threadIdx.x + j * (int)blockDim.x;
+                my_nodes[j] = i < n_list ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            }
+            for (unsigned int i = threadIdx.x; i < n_def; i += blockDim.x) {
+                const unsigned int rx = __hip_atomic_load(p.vote_deferred + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__hip_atomic_load(p.fingerprint + rx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != cf) continue;
+                const bool differs = bitmap_differs(p.bitmaps + (long long)rx * words, p.vote_cand + 4, words);
+                atomicAdd(&block_votes[1], 1ull);
+                if (differs) atomicAdd(&block_votes[0], 1ull);
+            }
+            __syncthreads();
+            unsigned long long seen = acc_seen + block_votes[1];
+            const unsigned long long bad = acc_bad + block_votes[0];
+            const bool lost = n_def_all > n_def;  // more deferred voters than the list holds: their votes are unknown -- no quorum is claimed
+            if (lost) seen = 0ull;
+            unsigned long long res[10];
+            res[0] = owner1 != 0ull ? owner1 - 1ull : 0xFFFFFFFFull;
+            res[1] = seen;
+            res[2] = voters;
+            res[3] = voters == 0ull ? 0ull : (seen == voters ? 1ull : 2ull);
+            res[4] = owner1 != 0ull ? cf : 0ull;
+            res[5] = owner1 != 0ull ? ~cf : ~0ull;
+            res[6] = bad;
+            res[7] = seen;
+            res[8] = (unsigned long long)tally_err;
+            res[9] = 0ull;
+            __syncthreads();  // (everybody has read the accumulators: thread 11 zeroes them below)
+            // the answer block: res[0..9], then {size, node list} of the candidate -- in memory (the all-gather of a sharded population
+            // reads it there) and, for a population held by one rank, in the host-mapped page the host polls
+            int* const ref = reinterpret_cast<int*>(p.vote_res + 10);
+            unsigned long long* const pub = const_cast<unsigned long long*>(p.vote_publish);
+            int* const pref = pub != nullptr ? reinterpret_cast<int*>(pub + 10) : nullptr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = (int)threadIdx.x + j * (int)blockDim.x;
+                if (i < n_list) {
+                    ref[1 + i] = my_nodes[j];
+                    if (pref != nullptr) pref[1 + i] = my_nodes[j];
+                }
+            }
+            for (int i = (int)threadIdx.x + 4 * (int)blockDim.x; i < n_list; i += (int)blockDim.x) {
+                const int node = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ref[1 + i] = node;
+                if (pref != nullptr) pref[1 + i] = node;
+            }
+            if (threadIdx.x < 10u) {
+                p.vote_res[threadIdx.x] = res[threadIdx.x];
+                if (pub != nullptr) pub[threadIdx.x] = res[threadIdx.x];
+            }
+            if (threadIdx.x == 10u) {
+                ref[0] = owner1 != 0ull ? cnt : 0;
+                if (pref != nullptr) pref[0] = owner1 != 0ull ? cnt : 0;
+            }
+            if (threadIdx.x == 11u) {  // everything a launch expects zeroed, for the next one
+                for (int i = 0; i < 5; ++i) p.vote_acc[i] = 0ull;
+                for (int i = 0; i < 4; ++i) p.vote_cand[i] = 0ull;
+                p.vote_deferred[0] = 0u;
+            }
+            if (pub != nullptr) {
+                __syncthreads();  // (everybody's stores to the page have left the CU)
+                if (threadIdx.x == 0) {
+                    __threadfence_system();  // ONE system-scope fence (each one writes back the L2), then the word the host polls
+                    if (p.vote_seq_out != nullptr) *p.vote_seq_out = p.vote_seq;
+                }
+            }
         }
     }
     // p.stats = [gridDim.x][8], accumulated over launches; one plain read-modify-write per workgroup and counter

@@ -313,18 +313,18 @@ class ClusterSimulation:
 
     def load_streams_device(self, d_records_ptr, records_bytes, d_rec_off_ptr, n_receivers, keepalive=None):
         """20-byte records already in device memory, copied into the engine's buffer (the offsets stay borrowed)."""
-        self._keep = keepalive
-        self.n_receivers = n_receivers
         self.e._check(self.e._lib.rapid_sim_load_streams_device(self.e._h, d_records_ptr, records_bytes, d_rec_off_ptr,
                                                                 n_receivers))
+        self._keep = keepalive  # (a refused call changes nothing, here either)
+        self.n_receivers = n_receivers
 
     def attach_streams_device(self, d_records_ptr, records_bytes, d_rec_off_ptr, n_receivers, keepalive=None):
         """20-byte records in device memory, tallied IN PLACE (rapid_sim_attach_streams_device): nothing is copied; both
         buffers stay borrowed until the next load / attach / generate -- `keepalive` holds them."""
-        self._keep = keepalive
-        self.n_receivers = n_receivers
         self.e._check(self.e._lib.rapid_sim_attach_streams_device(self.e._h, d_records_ptr, records_bytes, d_rec_off_ptr,
                                                                   n_receivers))
+        self._keep = keepalive
+        self.n_receivers = n_receivers
 
     def generate(self, batches, receivers, seed, trust_copies=False, keep=None, boundary=False):
         """The round's deliveries made on the device (rapid_sim_generate): every receiver gets every batch of `batches`
@@ -438,6 +438,22 @@ class ClusterSimulation:
         rr = RoundResult()
         cfg = C.c_int64(0)
         self.e._check(self.e._lib.rapid_sim_round(self.e._h, 1 if apply else 0, C.byref(rr), C.byref(cfg)))
+        return rr, cfg.value
+
+    def round_device(self, d_records_ptr, records_bytes, d_rec_off_ptr, n_receivers, d_alerts_ptr=None, n_alerts=0, trust=1,
+                     apply=False, keepalive=None, alerts_bytes=None):
+        """A round whose deliveries (and distinct alerts) already lie in device memory, in ONE library call
+        (rapid_sim_round_device): attach in place + declare in place + trust level + index + tally + vote count (+ apply)."""
+        rr = RoundResult()
+        cfg = C.c_int64(0)
+        nbytes = 20 * int(n_alerts) if alerts_bytes is None else int(alerts_bytes)
+        keep_old = self._keep
+        self._keep = (keep_old, keepalive)  # (both sets of buffers stay alive across the call: which one the engine holds depends on how far it gets)
+        rc = self.e._lib.rapid_sim_round_device(self.e._h, d_records_ptr, records_bytes, d_rec_off_ptr, n_receivers, d_alerts_ptr, nbytes,
+                                                n_alerts, int(trust), 1 if apply else 0, C.byref(rr), C.byref(cfg))
+        self.e._check(rc)
+        self._keep = keepalive
+        self.n_receivers = n_receivers
         return rr, cfg.value
 
     def classic_round(self, arrival=None, apply=True):

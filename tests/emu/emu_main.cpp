@@ -227,11 +227,29 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     pool[0] = pool[1] = 0u;
     p.n_static = n_receivers;
     p.pool = nullptr;
-    static unsigned long long vote_acc[5], vote_res[10];
+    static unsigned long long vote_acc[5];
+    std::vector<unsigned long long> vote_res_buf(10 + ((size_t)prop_cap + 1 + 1) / 2 + 1, 0xDEADull);
+    unsigned long long* const vote_res = vote_res_buf.data();
     for (int i = 0; i < 5; ++i) vote_acc[i] = 0ull;
-    for (int i = 0; i < 10; ++i) vote_res[i] = 0xDEADull;
     p.vote_acc = vote_acc;
     p.vote_res = vote_res;
+    // the fast round settled by the launch itself (TallyParams::vote_cand) whenever a proposal's bitmap fits 64 words; emulator-only
+    // selector bit 16: the earlier statistics only (lowest voter + voters, completed by vote_verify_kernel)
+    static unsigned long long vote_cand[4 + 64];
+    static unsigned int vote_deferred[1 + 4096];
+    static unsigned long long vote_pub[10 + 4096];
+    static unsigned int vote_seq_word;
+    for (int i = 0; i < 4 + 64; ++i) vote_cand[i] = 0ull;
+    for (int i = 0; i < 1 + 4096; ++i) vote_deferred[i] = 0u;
+    vote_seq_word = 0u;
+    const bool settle = (flags & 65536) == 0 && (n_hot + 63) / 64 <= 64 && prop_cap <= 8000;
+    p.vote_cand = settle ? vote_cand : nullptr;
+    p.vote_deferred = settle ? vote_deferred : nullptr;
+    // emulator-only selector bit 18: a list of eight entries (its overflow is reachable); bit 17: see the block loop
+    p.vote_deferred_cap = (flags & 262144) != 0 ? 8 : 4096;
+    p.vote_publish = settle ? vote_pub : nullptr;
+    p.vote_seq_out = settle ? &vote_seq_word : nullptr;
+    p.vote_seq = 77u;
     // the voters' proposals as bitmaps over the hot slots (TallyParams::bitmaps), poisoned: a voter's words must all be written
     const int bitmap_words = (n_hot + 63) / 64;
     std::vector<unsigned long long> bitmaps((size_t)std::max(n_receivers, 1) * (size_t)std::max(bitmap_words, 1), 0xA5A5A5A5A5A5A5A5ull);
@@ -242,6 +260,11 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
         p.pool = pool;
     }
     for (int b = 0; b < grid; ++b) {
+        // Workgroups run one after the other here, so the first one with a voter always finds the candidate unclaimed and every later
+        // one finds it published.  Emulator-only selector bit 17 makes the publication LATE: once somebody has claimed the candidate it
+        // reads as "not yet published" for the workgroups in between -- they hand their voters to the deferred list -- and as published
+        // again for the last one, which has to compare them.
+        if (settle && (flags & 131072) != 0 && vote_cand[0] != 0ull) vote_cand[1] = b == grid - 1 ? 1ull : 0ull;
         std::memset(smem, 0xCD, sizeof(smem));  // poison: the kernel must initialise what it reads
         const bool trusted = (flags & 256) != 0;  // emulator-only selector of the kTrusted instantiation
         auto run = [&](auto kern) { emu::run_block((unsigned)b, (unsigned)grid, (unsigned)waves * 64u, [&] { kern(p); }, seed + (unsigned)b); };
@@ -292,8 +315,32 @@ int emu_tally_run(const unsigned char* records, unsigned long long records_bytes
     }
     for (int i = 0; i < 5; ++i)
         if (vote_acc[i] != 0ull) return -8;  // the last workgroup leaves the vote accumulators zeroed, too
-    if (vote_res_out != nullptr)
+    if (settle) {
+        for (int i = 0; i < 4; ++i)
+            if (vote_cand[i] != 0ull) return -11;  // ... and the candidate's words and the deferred count
+        if (vote_deferred[0] != 0u || vote_seq_word != 77u) return -11;
+        // the published copy is the answer block: res[0..9] and the candidate's {size, list}
+        const int* ref = reinterpret_cast<const int*>(vote_res + 10);
+        const int* pref = reinterpret_cast<const int*>(vote_pub + 10);
+        for (int i = 0; i < 10; ++i)
+            if (vote_pub[i] != vote_res[i]) return -12;
+        const int n_list = ref[0] < 0 ? 0 : ref[0];
+        if (pref[0] != ref[0] || n_list > prop_cap) return -12;
+        for (int i = 0; i < n_list; ++i)
+            if (pref[1 + i] != ref[1 + i]) return -12;
+    }
+    if (vote_res_out != nullptr) {
         for (int i = 0; i < 10; ++i) vote_res_out[i] = vote_res[i];
+        // (behind them: 1 = settled by the launch, then the candidate's size and node list as 32-bit words)
+        vote_res_out[10] = settle ? 1ull : 0ull;
+        if (settle) {
+            const int* ref = reinterpret_cast<const int*>(vote_res + 10);
+            const int n_list = ref[0] < 0 ? 0 : ref[0];
+            int* out32 = reinterpret_cast<int*>(vote_res_out + 11);
+            out32[0] = ref[0];
+            for (int i = 0; i < n_list; ++i) out32[1 + i] = ref[1 + i];
+        }
+    }
     if (pool[0] != 0u || pool[1] != 0u) return -7;  // the last workgroup must leave the pool words zeroed for the next launch
     // every voter's bitmap names exactly its proposal: as many bits as the proposal has nodes, and (up to the list's capacity)
     // the same nodes in the same order

@@ -142,6 +142,11 @@ inline unsigned atomicAnd(unsigned* p, unsigned v) {
     *p = o & v;
     return o;
 }
+inline unsigned atomicCAS(unsigned* p, unsigned expected, unsigned desired) {
+    const unsigned o = *p;
+    if (o == expected) *p = desired;
+    return o;
+}
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 inline void __threadfence_system() {}

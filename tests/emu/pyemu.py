@@ -156,7 +156,7 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
     fp = np.zeros(R, dtype=np.uint64)
     props = np.full((R, prop_cap), -1, dtype=np.int32)
     stats = np.zeros((grid, 8), dtype=np.uint64)  # one row per workgroup, as the kernel writes them
-    vote_res = np.zeros(10, dtype=np.uint64)
+    vote_res = np.zeros(11 + (prop_cap + 2) // 2 + 1, dtype=np.uint64)  # res[0..9], "settled by the launch", the candidate's {size, list}
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     hashed = None
     if tables_in_lds == 4:  # the hashed dictionary of packed rounds: built by index_hash_kernel, which renumbers the slots
@@ -187,9 +187,31 @@ def tally(records, rec_off, n_nodes, K, H, L, cfg_id, obs, subj, member, prop_ca
                 props[r, : pcount[r]] = np.sort(props[r, : pcount[r]])
     # the vote statistics the kernel gathers next to the proposals (TallyParams::vote_res) against the results themselves
     voters = np.flatnonzero(pcount != 0)
-    assert int(vote_res[2]) == len(voters), (vote_res, len(voters))
-    assert int(vote_res[0]) == (int(voters[0]) if len(voters) else 0xFFFFFFFF), vote_res
-    assert not vote_res[[1, 3, 4, 5, 6, 7, 9]].any(), vote_res
+    assert int(vote_res[2]) == len(voters), (vote_res[:11], len(voters))
+    if int(vote_res[10]) == 0:  # the earlier statistics: lowest voter + voters, the rest left to vote_verify_kernel
+        assert int(vote_res[0]) == (int(voters[0]) if len(voters) else 0xFFFFFFFF), vote_res[:11]
+        assert not vote_res[[1, 3, 4, 5, 6, 7, 9]].any(), vote_res[:11]
+    else:
+        # settled by the launch (TallyParams::vote_cand): the candidate is SOME voter's proposal (whoever finished first), every voter
+        # holding its fingerprint is counted, none of them differs bit for bit, and the answer carries the candidate's node list
+        ref32 = vote_res[11:].view(np.int32)
+        if len(voters) == 0:
+            assert int(vote_res[0]) == 0xFFFFFFFF and not vote_res[[1, 3, 4, 6, 7, 9]].any() and int(vote_res[5]) == 0xFFFFFFFFFFFFFFFF and ref32[0] == 0, vote_res[:11]
+        else:
+            own = int(vote_res[0])
+            assert own in set(voters.tolist()), (own, voters[:8])
+            same = int(np.count_nonzero((pcount != 0) & (fp == fp[own])))
+            assert int(vote_res[4]) == int(fp[own]) and int(vote_res[5]) == int(fp[own]) ^ 0xFFFFFFFFFFFFFFFF, vote_res[:11]
+            deferred_lost = int(vote_res[1]) == 0 and same > 0  # (more deferred voters than the emulator's short list holds: no quorum is claimed)
+            if not deferred_lost:
+                assert int(vote_res[1]) == same and int(vote_res[7]) == same, (vote_res[:11], same)
+                assert int(vote_res[3]) == (1 if same == len(voters) else 2)
+            assert int(vote_res[6]) == 0 and int(vote_res[9]) == 0, vote_res[:11]
+            assert int(ref32[0]) == int(pcount[own])
+            if pcount[own] > 0:
+                want_list = np.sort(props[own, : pcount[own]]) if hashed else props[own, : pcount[own]]
+                got_list = np.sort(ref32[1: 1 + pcount[own]]) if hashed else ref32[1: 1 + pcount[own]]
+                assert np.array_equal(got_list, want_list), (got_list[:8], want_list[:8])
     if want is not None:  # (statistics aside: the two instantiations take the same windows the same way, but that is not a promise)
         for a, b in zip(want[:5], (emit, nprop, pcount, fp, props)):
             assert np.array_equal(a, b), "kCurrent differs from the instantiation that compares the configuration ids"

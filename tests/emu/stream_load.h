@@ -66,6 +66,7 @@ inline unsigned int stream_scalar_load32(const unsigned int* p) { return *p; }
 inline void stream_store(int* p, int v) { *p = v; }
 inline void stream_store(unsigned long long* p, unsigned long long v) { *p = v; }
 
+inline void stream_drain() {}
 inline void stream_flag_or(unsigned int* p, unsigned int bits) { *p |= bits; }
 inline void stream_settle(unsigned int&, unsigned int&, unsigned int&) {}  // a scheduling fence on the device, nothing here
 

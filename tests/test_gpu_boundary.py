@@ -127,3 +127,41 @@ def test_view_errors_name_the_call_and_leave_the_view(E):
     with pytest.raises(E.IllegalArgumentException):
         E.MembershipView(eng).build(big.hostnames, big.ports, big.id_hi, big.id_lo)  # over n_max
     assert view.getCurrentConfigurationId() == cfg and view.getMembershipSize() == n
+
+
+def test_fast_round_settled_inside_the_tally_equals_the_separate_count(E):
+    """The fast round settled by the tally launch itself (tally_kernel.h: TallyParams::vote_cand; opt-in, knob bit 23) against the
+    default -- vote statistics from the tally, counting / verification in launches of their own -- and against the general
+    count (knob 512), on the three kinds of round: unanimous, dissenters under a quorum, conflicting proposals without one
+    (R/FastPaxos.java:125-156).  Same decision, same cut, same votes; and again on the same engine, round after round (the
+    candidate's words and the deferred list are left zeroed by every launch)."""
+    ns = {}
+    from tests.test_gpu_two_ranks import COMMON
+    exec(COMMON, ns)
+    N_, K, H, L = ns["N"], ns["K"], ns["H"], ns["L"]
+    pop = S.Population.make(N_)
+    eng = E.Engine(n_max=N_, K=K, H=H, L=L)
+    view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
+    obs, subj, member = view.tables()
+    cfg = view.getCurrentConfigurationId()
+    sim = E.ClusterSimulation(eng)
+    for rep in range(2):
+        for name, (records, rec_off, declared) in ns["rounds"](obs, member, cfg).items():
+            got = {}
+            for knob in (8388608, 0, 512):
+                sim.set_force_exact(knob)
+                sim.load_streams(records, rec_off)
+                sim.set_alert_set(declared)
+                sim.tally()
+                rr = sim.count_votes()
+                got[knob] = (int(rr.decided), int(rr.votes_total), int(rr.quorum), int(rr.cut_size) if rr.decided else -1,
+                             int(rr.votes_winner) if rr.decided else -1, sim.decided_cut() if rr.decided else None)
+            sim.set_force_exact(0)
+            assert got[0] == got[8388608] == got[512], (name, got)
+            assert got[0][0] == (0 if name == "conflict" else 1), (name, got[0])
+    # nobody votes: an answer all the same (no candidate), round after round
+    quiet = np.zeros(0, dtype=S.ALERT_DTYPE)
+    sim.load_streams(quiet, np.zeros(11, dtype=np.int64))
+    sim.tally()
+    rr = sim.count_votes()
+    assert rr.decided == 0 and rr.votes_total == 0

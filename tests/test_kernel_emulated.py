@@ -896,3 +896,33 @@ def test_identifier_check_answered_into_the_mailbox():
         assert pyemu.ids_contains_publish(old, new, seq=33) == 67
     assert pyemu.ids_contains_publish(old, [old[0]], seq=1) == 3 and pyemu.ids_contains_publish(old, [old[-1]], seq=1) == 3
     assert pyemu.ids_contains_publish(old, [(old[0][0], old[0][1] + 1)], seq=1) in (2, 3)  # (+ 1 only if that id happens to exist)
+
+
+def test_fast_round_settled_inside_the_tally_launch():
+    """TallyParams::vote_cand: the launch itself names a candidate (the first voter of the first workgroup to finish), compares every
+    voter's bitmap with it and lays down the complete answer block -- pyemu.tally checks that block against the per-receiver results
+    after EVERY run of this file.  Here the paths a sequential emulator does not reach by itself: a candidate that is claimed but
+    published LATE (the workgroups in between hand their voters to the deferred list, the last one compares them: selector bit 17),
+    a deferred list that overflows (bit 18: no quorum may be claimed then), and the round-5 statistics alone (bit 16)."""
+    n, K, H, L = 300, 10, 9, 4
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K)
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_scenario("C3b", subj, cfg, n=n, f=15, H=H, L=L, receivers=np.arange(0, n, 5))
+    fe, fn, fo, fp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off)
+    assert int((np.diff(fo) != 0).sum()) > 30  # many voters, spread over the workgroups below
+    for knob in (0, 131072, 131072 | 262144, 65536):
+        for grid, waves in ((4, 3), (5, 2)):
+            emit, nprop, pcount, fpr, props, stats = pyemu.tally(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, force_exact=knob, trusted=True,
+                                                                 grid=grid, waves=waves)
+            assert np.array_equal(emit, fe) and np.array_equal(pcount, np.diff(fo))
+            assert np.array_equal(fpr, proposal_fingerprints(fo, fp, fe >= 0))
+    # a round in which two proposals are held (a dissenting receiver): the candidate's votes are the voters holding ITS fingerprint
+    recs, off = sc.records.copy(), sc.rec_off
+    r_diss = int(np.flatnonzero(np.diff(fo) != 0)[3])
+    recs["ring_mask"][off[r_diss]: off[r_diss + 1]] &= 1  # this receiver hears of one ring only: it announces later, or something else
+    fe2, fn2, fo2, fp2 = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, recs, off)
+    for knob in (0, 131072):
+        emit, nprop, pcount, fpr, props, stats = pyemu.tally(recs, off, n, K, H, L, cfg, obs, subj, member, force_exact=knob, grid=4, waves=3)
+        assert np.array_equal(emit, fe2) and np.array_equal(fpr, proposal_fingerprints(fo2, fp2, fe2 >= 0))
