@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("RAPID_MI355X_LIB") or os.path.join(_HERE, "librapid_m
 # environment knobs of the measurement scripts.  Only tests/ and scripts/ load it (use_test_build()).
 TEST_LIB_PATH = os.path.join(_HERE, "librapid_mi355x_test.so")
 SRC_DIR = os.path.join(_HERE, "csrc")
-SOURCES = ["engine.hip", "host_abi.cpp", "tally_kernel.h", "stream_load.h", "lds_dma.h", "index_kernels.h", "view_kernels.h", "vote_kernels.h", "wire.h", "consensus.h"]
+SOURCES = ["engine.hip", "host_abi.cpp", "tally_kernel.h", "tally_probes.inc", "stream_probes.inc", "stream_load.h", "lds_dma.h", "index_kernels.h", "view_kernels.h", "vote_kernels.h", "wire.h", "consensus.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "rapid_mi355x.h")
 
 OK, EINVAL, ENODE_EXISTS, ENODE_MISSING, EUUID_SEEN, ECAPACITY, EDEVICE, ESTATE, ECOLLISION = 0, -1, -2, -3, -4, -5, -6, -7, -8

@@ -55,7 +55,7 @@
 #include <type_traits>
 
 #ifdef RAPID_TEST_BUILD
-#include <lds_dma.h>  // (the LDS-DMA stream probe)
+#include <lds_dma.h>  // (what the LDS-DMA stream probe of stream_probes.inc is written with; test build only)
 #endif
 #include <stream_load.h>
 
@@ -678,13 +678,6 @@ __host__ __device__ constexpr int tally_max_waves(int dict_mode, bool trusted, i
 #else
 #define RAPID_TALLY_OCCUPANCY
 #endif
-// kCurrent (pre-validated boundary records only): every alert the round index saw carries the engine's configuration id, and the
-// deliveries are KNOWN to be copies of them -- the library laid them down itself, or the caller vouches for it at level 2 of
-// rapid_sim_trust_alert_copies (engine.hip: records_known_current; the plain trusted instantiation compares the ids and drops late
-// deliveries) -- so does every delivered record, and its configuration id need not travel from the cache line to the registers at all: ONE buffer_load_dwordx2 per record ({dst, word}, non-temporal: nothing asks for the line
-// again) instead of two, no 64-bit compare, eight registers fewer per window in flight.  The bytes that cross the HBM interface
-// are the same 20 per record (the lines are the same); what is saved is the second request per line between L2 and the CU
-// (scripts/micro/boundary_shapes.hip, shape 2 against shape 0: 6.6 against 6.1 TB/s with nothing else going on).
 // Two proposal bitmaps compared word for word, both read with agent-scope atomic loads (another workgroup, maybe on another XCD, wrote
 // them), eight words of each requested together: the comparison is a chain of round trips, not bandwidth.
 __device__ inline bool bitmap_differs(const unsigned long long* a, const unsigned long long* b, int words) {
@@ -702,6 +695,13 @@ __device__ inline bool bitmap_differs(const unsigned long long* a, const unsigne
     return differs;
 }
 
+// kCurrent (pre-validated boundary records only): every alert the round index saw carries the engine's configuration id, and the
+// deliveries are KNOWN to be copies of them -- the library laid them down itself, or the caller vouches for it at level 2 of
+// rapid_sim_trust_alert_copies (engine.hip: records_known_current; the plain trusted instantiation compares the ids and drops late
+// deliveries) -- so does every delivered record, and its configuration id need not travel from the cache line to the registers at all: ONE buffer_load_dwordx2 per record ({dst, word}, non-temporal: nothing asks for the line
+// again) instead of two, no 64-bit compare, eight registers fewer per window in flight.  The bytes that cross the HBM interface
+// are the same 20 per record (the lines are the same); what is saved is the second request per line between L2 and the CU
+// (scripts/micro/boundary_shapes.hip, shape 2 against shape 0: 6.6 against 6.1 TB/s with nothing else going on).
 template <int kDictMode, bool kTrusted, int kFmt = kFmtResident, bool kPacked = false, bool kCurrent = false>
 __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked) * 64) RAPID_TALLY_OCCUPANCY void tally_population_kernel(TallyParams p) {
     static_assert(!kCurrent || (kTrusted && kFmt == kFmtBoundary), "only vouched-for boundary records can be known to be current");
@@ -2107,87 +2107,7 @@ __global__ __launch_bounds__(64) void cd_instance_kernel(CdParams p) {
 }
 
 #ifdef RAPID_TEST_BUILD
-// --------------------------------------------------------------------------------------------------------------
-// Measurement probe (not part of the product path): the same access pattern as the tally kernel -- one wave per
-// receiver stream, TILE-byte tiles of 16 B/lane loads, DEPTH tiles in flight -- with no processing, to separate
-// what the memory system delivers for this pattern from what the detector logic costs.
-// --------------------------------------------------------------------------------------------------------------
-template <int TILE_VEC, int DEPTH>
-__global__ __launch_bounds__(1024) void stream_probe_kernel(const unsigned char* records, unsigned long long records_bytes,
-                                                            const long long* rec_off, int n_receivers,
-                                                            unsigned int* next_receiver, unsigned int* sink, unsigned long long rec_bytes) {
-    const int lane = (int)(threadIdx.x & 63u);
-    unsigned int acc = 0;
-    for (;;) {
-        int r = 0;
-        if (lane == 0) r = (int)atomicAdd(next_receiver, 1u);
-        r = __builtin_amdgcn_readfirstlane(r);
-        if (r >= n_receivers) break;
-        const unsigned long long b0 = (unsigned long long)rec_off[r] * rec_bytes, b1 = (unsigned long long)rec_off[r + 1] * rec_bytes;
-        const unsigned long long a0 = b0 & ~15ull;
-        const int tile_bytes = TILE_VEC * 1024;
-        const int ntiles = (int)((b1 - a0 + tile_bytes - 1) / tile_bytes);
-        const unsigned long long last16 = records_bytes - 16ull;
-        uint4 t[DEPTH][TILE_VEC];
-#pragma unroll
-        for (int q = 0; q < DEPTH; ++q)
-#pragma unroll
-            for (int m = 0; m < TILE_VEC; ++m) {
-                unsigned long long addr = a0 + (unsigned long long)q * tile_bytes + 16ull * (unsigned)(lane + 64 * m);
-                addr = addr < last16 ? addr : last16;
-                t[q][m] = *reinterpret_cast<const uint4*>(records + addr);
-            }
-        for (int jb = 0; jb < ntiles; jb += DEPTH) {
-#pragma unroll
-            for (int q = 0; q < DEPTH; ++q) {
-#pragma unroll
-                for (int m = 0; m < TILE_VEC; ++m) {
-                    acc ^= t[q][m].x ^ t[q][m].y ^ t[q][m].z ^ t[q][m].w;
-                    const int j = jb + q + DEPTH;
-                    unsigned long long addr = a0 + (unsigned long long)(j < ntiles ? j : 0) * tile_bytes + 16ull * (unsigned)(lane + 64 * m);
-                    addr = addr < last16 ? addr : last16;
-                    t[q][m] = *reinterpret_cast<const uint4*>(records + addr);
-                }
-            }
-        }
-    }
-    if (acc == 0x12345678u) sink[0] = acc;
-}
-
-// The same probe through the LDS-DMA path: kD KiB in flight per wave, landing in a private LDS ring of kD slots.
-template <int kD>
-__global__ __launch_bounds__(1024) void dma_probe_kernel(const unsigned char* records, unsigned long long records_bytes,
-                                                         const long long* rec_off, int n_receivers,
-                                                         unsigned int* next_receiver, unsigned int* sink, unsigned long long rec_bytes) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = (int)(threadIdx.x & 63u);
-    const int wave = (int)(threadIdx.x >> 6);
-    // sink[1] = byte offset of the rings inside the workgroup's LDS allocation (measurement knob)
-    const lds_addr_t ring = lds_uniform(lds_address(smem + sink[1] + wave * kD * 1024));
-    const unsigned int lane16 = (unsigned int)lane * 16u;
-    for (;;) {
-        int r = 0;
-        if (lane == 0) r = (int)atomicAdd(next_receiver, 1u);
-        r = __builtin_amdgcn_readfirstlane(r);
-        if (r >= n_receivers) break;
-        const unsigned long long b0 = (unsigned long long)rec_off[r] * rec_bytes, b1 = (unsigned long long)rec_off[r + 1] * rec_bytes;
-        const unsigned long long a0 = b0 & ~15ull;
-        const int nk = (int)((b1 - a0 + 1023ull) / 1024ull);
-        const dma_rsrc_t rsrc = dma_make_rsrc(records + a0, (unsigned int)(((b1 - a0) + 15ull) & ~15ull));
-        wait_dma<0>();
-#pragma unroll
-        for (int k = 0; k < kD; ++k) lds_dma16(rsrc, lane16, (unsigned int)k * 1024u, ring + k * 1024);
-        int slot = 0;
-        for (int k = 0; k < nk; ++k) {
-            wait_dma<kD - 1>();
-            lds_dma16(rsrc, lane16, (unsigned int)(k + kD) * 1024u, ring + slot * 1024);
-            if (++slot == kD) slot = 0;
-        }
-    }
-    wait_dma<0>();
-    if (reinterpret_cast<unsigned int*>(smem)[threadIdx.x] == 0x12345678u) sink[0] = 1u;
-}
-
+#include "stream_probes.inc"  // (stream_probe_kernel, dma_probe_kernel: measurement aids, test build only)
 #endif  // RAPID_TEST_BUILD
 
 }  // namespace rapid

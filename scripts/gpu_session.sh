@@ -79,6 +79,15 @@ for f in glob.glob("gpurun_out/pmc_WRITE_SIZE/**/*counter_collection.csv", recur
     if v: print("tally WRITE_SIZE avg (KiB)", sum(v) / len(v), "launches", len(v))
 PY
       ;;
+    soak)         # random view builds / changes against the oracle on the device (product build, then poisoned test build)
+      timeout 600 python scripts/soak_view.py --chunks 2 100 1000 2>&1 | filter | tee gpurun_out/soak_view_product.txt | tail -3
+      RAPID_POISON=0xFF timeout 600 python scripts/soak_view.py --chunks 2 60 2000 --test-build 2>&1 | filter | tee gpurun_out/soak_view_poisoned.txt | tail -3 ;;
+    tail_probe)   # tally kernel time against the number of receivers: steady rate + per-launch cost
+      timeout 600 python scripts/tail_probe.py 10 2>&1 | filter | tee gpurun_out/tail_probe.txt | tail -12 ;;
+    collective)   # the round's collective floor through a 1-rank communicator; the step at 1/2, 1/4, 1/8 of the receivers
+      timeout 600 python scripts/collective_latency.py 50 2>&1 | filter | tee gpurun_out/collective_latency.txt | tail -8 ;;
+    settle_ab)    # the fast round settled inside the tally launch (opt-in) against the default
+      timeout 600 python scripts/step_ab_settle.py 60 2>&1 | filter | tee gpurun_out/step_ab_settle.txt | tail -4 ;;
     *) echo "unknown section $section" ;;
   esac
 done
