@@ -284,6 +284,29 @@ JNIEXPORT jlongArray JNICALL Java_com_vrg_rapid_NativeCutEngine_simRound(JNIEnv*
     return a;
 }
 
+/* a round whose deliveries and distinct alerts lie in device memory, in ONE crossing (rapid_sim_round_device) */
+JNIEXPORT jlongArray JNICALL Java_com_vrg_rapid_NativeCutEngine_simRoundDevice(JNIEnv* env, jobject self, jlong h, jlong dRecords, jlong recordsBytes,
+                                                                               jlong dRecOff, jint nReceivers, jlong dAlerts, jlong alertsBytes,
+                                                                               jlong nAlerts, jint trust, jboolean apply) {
+    (void)self;
+    if (recordsBytes < 0 || alertsBytes < 0 || nAlerts < 0 || nReceivers < 0) {
+        throw_iae(env, "negative size");
+        return NULL;
+    }
+    rapid_round_result rr;
+    int64_t cfg = 0;
+    const int rc = rapid_sim_round_device(ENGINE(h), (const void*)(intptr_t)dRecords, (uint64_t)recordsBytes, (const int64_t*)(intptr_t)dRecOff,
+                                          nReceivers, (const void*)(intptr_t)dAlerts, (uint64_t)alertsBytes, nAlerts, trust, apply ? 1 : 0, &rr, &cfg);
+    if (rc != RAPID_OK) {
+        throw_for(env, rapid_last_error(ENGINE(h)), rc);
+        return NULL;
+    }
+    const jlong v[5] = {rr.decided, rr.cut_size, rr.votes_winner, rr.quorum, cfg};
+    jlongArray a = (*env)->NewLongArray(env, 5);
+    if (a) (*env)->SetLongArrayRegion(env, a, 0, 5, v);
+    return a;
+}
+
 JNIEXPORT jintArray JNICALL Java_com_vrg_rapid_NativeCutEngine_simDecidedCut(JNIEnv* env, jobject self, jlong h) {
     (void)self;
     int32_t out[MAX_LIST], n = 0;

@@ -1172,6 +1172,15 @@ def test_configuration_ids_left_in_the_cache_lines_only_when_known_current(E, te
     le, ln, lo, lpp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, recs_l, off_l, nthreads=8)
     res = sim.results()
     assert np.array_equal(res[0], le) and np.array_equal(res[1], ln) and np.array_equal(res[2], np.diff(lo))
+    # ... and what the library knew about its own deliveries it knows about the set it made them FROM: declaring another set over the
+    # same generated streams -- the current alerts only -- at level 1 must not let the late copies pass as current (ADVICE round 5:
+    # streams_generated used to survive the declaration, and the ids were then not read at all)
+    sim.set_alert_set(sc.batches.recs, trust_copies=1)
+    sim.new_round()
+    sim.tally()
+    assert sim.index_info()["configuration_ids_known_current"] == 0
+    res = sim.results()
+    assert np.array_equal(res[0], le) and np.array_equal(res[1], ln) and np.array_equal(res[2], np.diff(lo))
     # a late delivery among host-delivered records: level 1 drops it, as the oracle (and the reference) does
     late = records.copy()
     first = int(rec_off[3])  # the first record of receiver 3: a DOWN report, now of the previous configuration
