@@ -88,6 +88,27 @@ PY
       timeout 600 python scripts/collective_latency.py 50 2>&1 | filter | tee gpurun_out/collective_latency.txt | tail -8 ;;
     settle_ab)    # the fast round settled inside the tally launch (opt-in) against the default
       timeout 600 python scripts/step_ab_settle.py 60 2>&1 | filter | tee gpurun_out/step_ab_settle.txt | tail -4 ;;
+    pmc_c5)       # FETCH_SIZE / WRITE_SIZE of the C5 tile kernels (generator, tally on boundary and on resolved records): scripts/c5_probe.py under rocprofv3
+      cd /tmp
+      for c in FETCH_SIZE WRITE_SIZE; do
+        rm -rf "$R/gpurun_out/pmc_c5_$c"
+        RAPID_AB_ONLY=default timeout 600 rocprofv3 --pmc $c --output-format csv -d "$R/gpurun_out/pmc_c5_$c" -o pmc -- python "$R/scripts/c5_probe.py" 1000000 1024 2 > "$R/gpurun_out/pmc_c5_$c.log" 2>&1
+      done
+      cd "$R"; python - <<'PY' | tee gpurun_out/pmc_traffic_c5.txt
+import csv, glob, collections
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    acc = collections.defaultdict(list)
+    for f in glob.glob("gpurun_out/pmc_c5_%s/**/*counter_collection.csv" % c, recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c:
+                acc[r["Kernel_Name"][:90]].append(float(r["Counter_Value"]))
+    for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:8]:
+        print("%-11s %-90s launches %4d  avg %12.0f KiB  max %12.0f KiB" % (c, k, len(v), sum(v) / len(v), max(v)))
+for line in open("gpurun_out/pmc_c5_FETCH_SIZE.log"):
+    if line.startswith("setup") or "records" in line:
+        print(line.rstrip()[:200])
+PY
+      ;;
     *) echo "unknown section $section" ;;
   esac
 done
