@@ -440,6 +440,35 @@ typedef struct rapid_classic_round_result {
 } rapid_classic_round_result;
 int rapid_classic_round_population(int32_t membership_size, int32_t n_acceptors, const uint64_t* vote_key,
                                    const uint8_t* voted, const int32_t* arrival, rapid_classic_round_result* out);
+/* The same recovery with CONCURRENT coordinators and message loss (several startPhase1a in flight, R/Paxos.java:98-111; promises
+ * that belong to another rank ignored, :156-188; acceptors that have promised a higher rank refusing a Phase2a, :195-216): every live
+ * acceptor is a whole consensus instance (the code behind rapid_consensus_*) holding its fast-round vote, behind the reference's
+ * test network -- one FIFO per destination, a broadcast queued at every live node, the sender's included (PaxosTests.java:403-476,
+ * R/UnicastToAllBroadcaster.java:46-53).  starts[j] = {step, acceptor, round}: before delivery step `step` (ascending) that acceptor calls
+ * startPhase1a(round); rank_index[a] stands in for myAddr.hashCode() (NULL: a + 2).  Delivery: step t hands node schedule[t] the
+ * oldest message queued for it, or LOSES it if drop[t] != 0 (schedule == NULL: until nothing is queued -- or n_steps steps, if
+ * n_steps > 0 -- a seeded choice among the nodes with queued messages, each message lost with probability `loss`).  Values are
+ * identified by their 64-bit keys as in rapid_classic_round_population.  decided_vote_of[a] (optional, [n_acceptors]) = an acceptor
+ * whose fast-round vote is what node a decided, -1 if it has not.  Memory is one queue entry per (message, destination): at most
+ * RAPID_CLASSIC_ROUNDS_MAX_ACCEPTORS acceptors; the closed form above serves whole populations. */
+#define RAPID_CLASSIC_ROUNDS_MAX_ACCEPTORS 4096
+typedef struct rapid_classic_start {
+    int32_t step, acceptor, round;
+} rapid_classic_start;
+typedef struct rapid_classic_rounds_result {
+    int32_t decided_nodes;   /* nodes that have decided */
+    int32_t agreed;          /* 1 iff every node that decided decided the same value (the protocol's safety: reported, not assumed) */
+    int32_t chosen_acceptor; /* an acceptor whose fast-round vote is the decided value; -1 if nobody decided */
+    int32_t lost;            /* messages lost */
+    int64_t steps;           /* delivery steps taken */
+    int64_t undelivered;     /* messages still queued at the end */
+    int64_t sent[4];         /* Phase1a, Phase1b, Phase2a, Phase2b messages queued (a broadcast counts once per live destination) */
+    int64_t delivered[4];    /* ... and handled */
+} rapid_classic_rounds_result;
+int rapid_classic_rounds_population(int32_t membership_size, int32_t n_acceptors, const uint64_t* vote_key, const uint8_t* voted,
+                                    const int32_t* rank_index, const rapid_classic_start* starts, int32_t n_starts,
+                                    const int32_t* schedule, const uint8_t* drop, int64_t n_steps, uint64_t seed, double loss,
+                                    rapid_classic_rounds_result* out, int32_t* decided_vote_of);
 /* wire forms of the five consensus messages (rapid.proto:124-169).  decode: the payload of a RapidRequest whose kind
  * rapid_decode_request reported; out->dest is set to RAPID_DEST_BROADCAST.  encode: a complete serialized RapidRequest,
  * byte for byte what protobuf-java emits for the messages R/Paxos.java and R/FastPaxos.java build (fields in number

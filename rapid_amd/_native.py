@@ -142,6 +142,15 @@ class ClassicRoundResult(C.Structure):  # rapid_classic_round_result
                 ("messages", C.c_int64)]
 
 
+class ClassicStart(C.Structure):  # rapid_classic_start
+    _fields_ = [("step", C.c_int32), ("acceptor", C.c_int32), ("round", C.c_int32)]
+
+
+class ClassicRoundsResult(C.Structure):  # rapid_classic_rounds_result
+    _fields_ = [("decided_nodes", C.c_int32), ("agreed", C.c_int32), ("chosen_acceptor", C.c_int32), ("lost", C.c_int32),
+                ("steps", C.c_int64), ("undelivered", C.c_int64), ("sent", C.c_int64 * 4), ("delivered", C.c_int64 * 4)]
+
+
 class EngineConfig(C.Structure):
     _fields_ = [("n_max", C.c_int32), ("K", C.c_int32), ("H", C.c_int32), ("L", C.c_int32), ("device_id", C.c_int32),
                 ("max_cut", C.c_int32)]
@@ -227,6 +236,7 @@ def _signatures():
         "rapid_consensus_fallback_delay_ms": (i32, [i32, i64, C.c_double, pi64]),
         "rapid_paxos_select_proposal": (i32, [i32, p, p, p, i32, pi32]),
         "rapid_classic_round_population": (i32, [i32, i32, p, p, p, C.POINTER(ClassicRoundResult)]),
+        "rapid_classic_rounds_population": (i32, [i32, i32, p, p, p, p, i32, p, p, i64, u64, C.c_double, C.POINTER(ClassicRoundsResult), p]),
         "rapid_decode_consensus_message": (i32, [vp, i32, p, i64, C.POINTER(ConsensusMsg), p, i32]),
         "rapid_encode_consensus_request": (i32, [vp, C.POINTER(ConsensusMsg), p, p, i64, pi64]),
         "rapid_engine_comm_init": (i32, [vp, p, i32, i32]),

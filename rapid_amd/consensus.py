@@ -148,6 +148,37 @@ def classic_round_population(membership_size, vote_key, voted, arrival=None):
             "rule": res.rule, "messages": res.messages}
 
 
+def classic_rounds_population(membership_size, vote_key, voted, starts, rank_index=None, schedule=None, drop=None, n_steps=0, seed=0,
+                              loss=0.0):
+    """The recovery with CONCURRENT coordinators and message loss over a population of whole consensus instances
+    (rapid_classic_rounds_population).  starts: [(step, acceptor, round)] ascending by step; schedule / drop: explicit delivery
+    (node whose oldest queued message is handled at each step / lost instead), or None for a seeded run with loss probability
+    `loss`.  -> dict of the result fields + "decided_vote_of": per acceptor, an acceptor whose vote it decided (-1: undecided)."""
+    vote_key = np.ascontiguousarray(vote_key, dtype=np.uint64)
+    voted = np.ascontiguousarray(voted, dtype=np.uint8)
+    n = len(voted)
+    assert len(vote_key) == n
+    st = (N.ClassicStart * max(len(starts), 1))()
+    for j, (step, a, rnd) in enumerate(starts):
+        st[j].step, st[j].acceptor, st[j].round = int(step), int(a), int(rnd)
+    ri = None if rank_index is None else np.ascontiguousarray(rank_index, dtype=np.int32)
+    sch = None if schedule is None else np.ascontiguousarray(schedule, dtype=np.int32)
+    dr = None if drop is None else np.ascontiguousarray(drop, dtype=np.uint8)
+    if sch is not None:
+        n_steps = len(sch)
+        assert dr is None or len(dr) == n_steps
+    res = N.ClassicRoundsResult()
+    dec = np.full(max(n, 1), -2, dtype=np.int32)
+    rc = N.lib().rapid_classic_rounds_population(membership_size, n, _addr(vote_key) if n else None, _addr(voted) if n else None,
+                                                 None if ri is None else _addr(ri), C.cast(st, C.c_void_p), len(starts),
+                                                 None if sch is None or not len(sch) else _addr(sch), None if dr is None or not len(dr) else _addr(dr),
+                                                 int(n_steps), int(seed), float(loss), C.byref(res), _addr(dec))
+    _check(rc, "rapid_classic_rounds_population")
+    return {"decided_nodes": res.decided_nodes, "agreed": bool(res.agreed), "chosen_acceptor": res.chosen_acceptor, "lost": res.lost,
+            "steps": res.steps, "undelivered": res.undelivered, "sent": list(res.sent), "delivered": list(res.delivered),
+            "decided_vote_of": dec[:n].tolist()}
+
+
 def classic_round_from_results(membership_size, emit_batch, fingerprint, arrival=None):
     """The recovery of a simulated population whose fast round found no quorum, from ClusterSimulation.results():
     receiver i voted iff emit_batch[i] >= 0, for the proposal with fingerprint[i].  -> (result dict, index of a

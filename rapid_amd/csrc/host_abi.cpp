@@ -8,6 +8,7 @@
 #include <set>
 #include <string>
 #include <unordered_map>
+#include <deque>
 #include <vector>
 
 #include "../../include/rapid_mi355x.h"
@@ -411,6 +412,154 @@ int rapid_classic_round_population(int32_t membership_size, int32_t n_acceptors,
     out->rule = rule;
     out->messages += (int64_t)N + (int64_t)n_acceptors * N;
     out->decided = 1;  // n_acceptors >= need > N/2 Phase2b messages for the round reach every live node (R/Paxos.java:231)
+    return RAPID_OK;
+}
+
+// The population form of the recovery with CONCURRENT coordinators and message loss: every live acceptor is a whole rapid_consensus
+// object holding its fast-round vote (values travel as one-element lists {index of the first acceptor that holds the key}), behind
+// the reference's test network -- ONE FIFO per destination, the single-threaded executor per node of PaxosTests.java:403-476: a
+// broadcast is appended to every live node's queue, the sender's included (R/UnicastToAllBroadcaster.java:46-53).  The per-node code is
+// the one rapid_consensus_* runs message by message; what this call adds is the network around n of them.
+int rapid_classic_rounds_population(int32_t membership_size, int32_t n_acceptors, const uint64_t* vote_key, const uint8_t* voted,
+                                    const int32_t* rank_index, const rapid_classic_start* starts, int32_t n_starts,
+                                    const int32_t* schedule, const uint8_t* drop, int64_t n_steps, uint64_t seed, double loss,
+                                    rapid_classic_rounds_result* out, int32_t* decided_vote_of) {
+    const int32_t N = membership_size, n = n_acceptors;
+    if (!out || N < 1 || n < 0 || n > N || n > RAPID_CLASSIC_ROUNDS_MAX_ACCEPTORS || (n > 0 && (!vote_key || !voted)) || n_starts < 0 ||
+        (n_starts > 0 && !starts) || n_steps < 0 || (n_steps > 0 && schedule == nullptr && drop != nullptr) || !(loss >= 0.0 && loss < 1.0))
+        return RAPID_EINVAL;
+    for (int32_t j = 0; j < n_starts; ++j)
+        if (starts[j].acceptor < 0 || starts[j].acceptor >= n || starts[j].step < 0 || (j > 0 && starts[j].step < starts[j - 1].step)) return RAPID_EINVAL;
+    *out = rapid_classic_rounds_result{};
+    out->chosen_acceptor = -1;
+    // values: the first acceptor holding a key stands for it
+    std::unordered_map<uint64_t, int32_t> first_of;
+    std::vector<rapid_consensus> nodes((size_t)n);
+    for (int32_t a = 0; a < n; ++a) {
+        rapid_consensus& c = nodes[(size_t)a];
+        c.me = a;
+        c.rank_index = rank_index ? rank_index[a] : a + 2;
+        c.config_id = 1;
+        c.N = N;
+        if (voted[a]) {  // registerFastRoundVote (R/Paxos.java:246-259); the fast round's own messages are not part of this call
+            const int32_t id = first_of.emplace(vote_key[a], a).first->second;
+            c.rnd = rapid_rank{1, 1};
+            c.vrnd = c.rnd;
+            c.vval = rapid_px::Value{id};
+        }
+    }
+    struct Msg {
+        rapid_consensus_msg head;
+        int32_t value;  // -1: no value
+    };
+    std::vector<Msg> msgs;
+    std::vector<std::deque<int32_t>> queues((size_t)n);
+    std::vector<int32_t> pending;          // nodes with queued messages (seeded mode), with their places
+    std::vector<int32_t> place((size_t)n, -1);
+    auto mark = [&](int32_t d) {
+        if (place[(size_t)d] < 0) {
+            place[(size_t)d] = (int32_t)pending.size();
+            pending.push_back(d);
+        }
+    };
+    auto unmark = [&](int32_t d) {
+        const int32_t at = place[(size_t)d];
+        if (at < 0) return;
+        const int32_t last = pending.back();
+        pending[(size_t)at] = last;
+        place[(size_t)last] = at;
+        pending.pop_back();
+        place[(size_t)d] = -1;
+    };
+    auto drain = [&](int32_t a) {  // what node a wants sent, in its order
+        rapid_consensus& c = nodes[(size_t)a];
+        while (!c.outbox.empty()) {
+            const rapid_px::Outgoing& o = c.outbox.front();
+            const int32_t id = (int32_t)msgs.size();
+            msgs.push_back(Msg{o.head, o.endpoints.empty() ? -1 : o.endpoints[0]});
+            const int k = o.head.kind - RAPID_MSG_PHASE1A;
+            if (o.head.dest == RAPID_DEST_BROADCAST) {
+                for (int32_t d = 0; d < n; ++d) {
+                    queues[(size_t)d].push_back(id);
+                    mark(d);
+                }
+                if (k >= 0 && k < 4) out->sent[k] += n;
+            } else if (o.head.dest >= 0 && o.head.dest < n) {
+                queues[(size_t)o.head.dest].push_back(id);
+                mark(o.head.dest);
+                if (k >= 0 && k < 4) out->sent[k] += 1;
+            }
+            c.outbox.pop_front();
+        }
+    };
+    uint64_t rng = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    auto next = [&]() {  // splitmix64
+        uint64_t z = (rng += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    int32_t next_start = 0;
+    int64_t step = 0;
+    for (;; ++step) {
+        while (next_start < n_starts && starts[next_start].step <= step) {
+            nodes[(size_t)starts[next_start].acceptor].start_phase1a(starts[next_start].round);
+            drain(starts[next_start].acceptor);
+            ++next_start;
+        }
+        int32_t d;
+        bool lose;
+        if (schedule) {
+            if (step >= n_steps) break;
+            d = schedule[step];
+            if (d < 0 || d >= n || queues[(size_t)d].empty()) return RAPID_EINVAL;  // (the schedule names a node with nothing queued)
+            lose = drop != nullptr && drop[step] != 0;
+        } else {
+            if (pending.empty()) {
+                if (next_start >= n_starts) break;
+                step = starts[next_start].step - 1;  // (nothing in flight: on to the next coordinator's start)
+                continue;
+            }
+            if (n_steps > 0 && step >= n_steps) break;
+            d = pending[(size_t)(next() % (uint64_t)pending.size())];
+            lose = loss > 0.0 && (double)(next() >> 11) * (1.0 / 9007199254740992.0) < loss;
+        }
+        const int32_t id = queues[(size_t)d].front();
+        queues[(size_t)d].pop_front();
+        if (queues[(size_t)d].empty()) unmark(d);
+        const Msg m = msgs[(size_t)id];
+        const int k = m.head.kind - RAPID_MSG_PHASE1A;
+        if (lose) {
+            out->lost += 1;
+            continue;
+        }
+        if (k >= 0 && k < 4) out->delivered[k] += 1;
+        const int32_t v = m.value;
+        const rapid_px::Value eps = v < 0 ? rapid_px::Value{} : rapid_px::Value{v};
+        rapid_consensus& c = nodes[(size_t)d];
+        switch (m.head.kind) {
+            case RAPID_MSG_PHASE1A: c.on_phase1a(m.head.sender, m.head.rnd); break;
+            case RAPID_MSG_PHASE1B: c.on_phase1b(m.head.rnd, m.head.vrnd, eps); break;
+            case RAPID_MSG_PHASE2A: c.on_phase2a(m.head.rnd, eps); break;
+            case RAPID_MSG_PHASE2B: c.on_phase2b(m.head.sender, m.head.rnd, eps); break;
+            default: break;
+        }
+        drain(d);
+    }
+    out->steps = step;
+    int32_t agreed = 1;
+    for (int32_t a = 0; a < n; ++a) {
+        const rapid_consensus& c = nodes[(size_t)a];
+        const int32_t v = c.decided && !c.decision.empty() ? c.decision[0] : -1;
+        if (decided_vote_of) decided_vote_of[a] = v;
+        if (c.decided) {
+            out->decided_nodes += 1;
+            if (out->chosen_acceptor < 0) out->chosen_acceptor = v;
+            else if (out->chosen_acceptor != v) agreed = 0;  // (Paxos never lets this happen: reported, not assumed)
+        }
+    }
+    out->agreed = agreed;
+    for (int32_t a = 0; a < n; ++a) out->undelivered += (int64_t)queues[(size_t)a].size();
     return RAPID_OK;
 }
 

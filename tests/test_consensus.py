@@ -327,6 +327,84 @@ def test_population_round_matches_the_message_level_run():
     assert checked > 200 and seen_rules == {1, 2, 3}
 
 
+def test_population_rounds_with_concurrent_coordinators_and_loss_match_the_message_level_run():
+    """rapid_classic_rounds_population against the oracle's network (PaxosTests.java:403-476 restated), SAME schedule: several
+    coordinators start classic rounds (rounds 2, 3, ...; their ranks ordered by round, then by the hash that stands in for the node
+    index, R/Paxos.java:98-111, 333-339) while earlier rounds' messages are still in flight, messages are lost one by one, and
+    every step handles the oldest message queued at a chosen node.  Per node: decided or not, and what; per kind: messages handled."""
+    rng = random.Random(23)
+    palette = [(1, 2), (2, 1), (3,), (4, 5, 6)]
+    saw_concurrent = saw_loss_undecided = saw_decided = 0
+    for trial in range(250):
+        n = rng.randrange(3, 24)
+        n_live = rng.randrange(n // 2 + 1, n + 1)
+        k = rng.randrange(1, len(palette) + 1)
+        votes = [rng.choice(palette[:k]) if rng.random() < rng.choice([0.3, 0.8, 1.0]) else None for _ in range(n_live)]
+        hc = rng.sample(range(5, 5000), n_live)
+        net = PX.Network(n_live, seed=trial, membershipSize=n, hash_codes=hc, drop={PX.FAST_ROUND_PHASE2B})
+        for a in range(n_live):
+            if votes[a] is not None:
+                net.nodes[a].propose(votes[a])  # (the fast round's own messages are swallowed: nobody decides in it)
+        assert not net.decisions and not net.pending()
+        n_coord = rng.randrange(1, 4)
+        p_loss = rng.choice([0.0, 0.0, 0.05, 0.3])
+        starts, schedule, drop = [], [], []
+        to_start = sorted((rng.randrange(0, 6 * n_live), rng.randrange(n_live), 2 + j) for j in range(n_coord))
+        step = 0
+        while True:
+            while to_start and to_start[0][0] <= step:
+                _, a, rnd = to_start.pop(0)
+                starts.append((step, a, rnd))
+                net.nodes[a].paxos.startPhase1a(rnd)
+            pend = net.pending()
+            if not pend:
+                if not to_start:
+                    break
+                # nothing in flight: the next coordinator starts now
+                t, a, rnd = to_start.pop(0)
+                to_start.insert(0, (step, a, rnd))
+                continue
+            d = rng.choice(pend)
+            lose = rng.random() < p_loss
+            schedule.append(d)
+            drop.append(1 if lose else 0)
+            if lose:
+                net.queues[d].pop(0)
+            else:
+                net.deliver_one(d)
+            step += 1
+        decided = dict(net.decisions)
+        key = {v: np.uint64(7000 + i) for i, v in enumerate(palette)}
+        vote_key = [key[v] if v is not None else np.uint64(0) for v in votes]
+        got = CS.classic_rounds_population(n, vote_key, [v is not None for v in votes], starts, rank_index=hc, schedule=schedule, drop=drop)
+        assert got["agreed"] and got["undelivered"] == 0 and got["steps"] == len(schedule) and got["lost"] == sum(drop)
+        assert got["decided_nodes"] == len(decided)
+        for a in range(n_live):
+            w = got["decided_vote_of"][a]
+            assert (w >= 0) == (a in decided), (trial, a)
+            if w >= 0:
+                assert votes[w] == decided[a]
+        handled = {kk: sum(1 for _, m in net.log if m.kind == kk) for kk in (PX.PHASE1A, PX.PHASE1B, PX.PHASE2A, PX.PHASE2B)}
+        assert got["delivered"] == [handled[PX.PHASE1A], handled[PX.PHASE1B], handled[PX.PHASE2A], handled[PX.PHASE2B]], trial
+        assert len(set(decided.values())) <= 1  # (safety, on the oracle's side too)
+        saw_concurrent += n_coord > 1 and len(starts) > 1 and starts[1][0] < len(schedule)
+        saw_decided += bool(decided)
+        saw_loss_undecided += p_loss > 0 and not decided
+    assert saw_concurrent > 40 and saw_decided > 80 and saw_loss_undecided > 3
+    # the seeded form: no schedule, a loss probability -- safety holds, and without loss every live node of a majority decides
+    votes = [palette[i % 3] for i in range(60)]
+    vote_key = [np.uint64(hash(v) & 0xFFFF) for v in votes]
+    for seed in range(20):
+        got = CS.classic_rounds_population(100, vote_key, [True] * 60, [(0, 5, 2), (40, 17, 3), (300, 33, 4)], seed=seed, loss=0.0)
+        assert got["agreed"] and got["decided_nodes"] == 60 and got["undelivered"] == 0 and got["lost"] == 0
+        got = CS.classic_rounds_population(100, vote_key, [True] * 60, [(0, 5, 2), (40, 17, 3), (300, 33, 4)], seed=seed, loss=0.2)
+        assert got["agreed"] and got["lost"] > 0
+    with pytest.raises(N.IllegalArgumentException):
+        CS.classic_rounds_population(10, [1, 2], [True, True], [(3, 0, 2)], schedule=[1], drop=[0])  # nothing is queued at node 1 before step 3
+    with pytest.raises(N.IllegalArgumentException):
+        CS.classic_rounds_population(10, [1, 2], [True, True], [(0, 5, 2)])  # no such acceptor
+
+
 def test_population_round_from_tally_results():
     """The glue ClusterSimulation.classic_round uses: receivers without a proposal (emit_batch -1) did not vote."""
     n = 12
