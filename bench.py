@@ -229,13 +229,23 @@ def main():
     st = sim.stats()
     consumed = st["records_consumed"] // (args.kernel_reps + 1)
     index = sim.index_info(timed=False)
-    kern_filter_ms = kern_nolate_ms = None
+    kern_filter_ms = kern_nolate_ms = step_filter_ms = None
     if not args.no_extras:
         # the same kernel with the per-delivery filter forced on (the instantiation that runs when the round's alerts do not
         # all validate against the view, or deliveries are not vouched for)
         sim.set_force_exact(64)
         kern_filter_ms = sim.time_tally(args.kernel_reps)
+        # ... and whole steps in that form (untimed region of the line: the line's `value` is the vouched-for form's; this is what
+        # it would be with every delivery filtered)
+        for i in range(2):
+            step(i)
+        t_f = time.perf_counter()
+        for i in range(max(5, min(args.steps, 20))):
+            step(i)
+        eng.sync()
+        step_filter_ms = 1e3 * (time.perf_counter() - t_f) / max(5, min(args.steps, 20))
         sim.set_force_exact(0)
+        fresh_round(0)
         # ... and with the caller's word that no late delivery is among the records (rapid_sim_trust_alert_copies level 2: true of
         # these streams): the configuration ids are not read at all.  NOT the line's kernel: level 1 rests on verified facts only.
         sim.set_alert_set_device(d_alert_sets[0].data_ptr(), len(alert_set), trust_copies=2, keepalive=d_alert_sets)
@@ -262,6 +272,8 @@ def main():
                 "traffic_over_bytes": round(traffic / (rec_b * consumed), 3) if traffic else None,
                 "kernel_ms_filter_per_delivery": round(kern_filter_ms, 4) if kern_filter_ms else None,
                 "frac_filter_per_delivery": round(rec_b * consumed / (kern_filter_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern_filter_ms else None,
+                "ms_per_step_filter_per_delivery": round(step_filter_ms, 4) if kern_filter_ms else None,
+                "value_filter_per_delivery": round(my_batches / (step_filter_ms * 1e-3), 1) if kern_filter_ms and world == 1 else None,
                 "kernel_ms_no_late_deliveries_vouched": round(kern_nolate_ms, 4) if kern_nolate_ms else None,
                 "passes_over_a_delivered_record": 1}
 
