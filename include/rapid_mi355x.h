@@ -142,7 +142,7 @@ int rapid_view_tables(rapid_engine* h, int32_t* observers, int32_t* subjects, ui
  * reference would apply (tests provoke the quirk and compare with the oracle's faithful cache).  One memo per engine: the
  * population shares the view object, as the oracle's does; a real deployment has one cache per node, filled when THAT node first
  * had the subject in its preProposal -- a hot subject that no receiver ever had in preProposal at a batch end is memoised here
- * and not there (INTEGRATION.md section 4).
+ * and not there (INTEGRATION.md section 2d).
  * rapid_view_q4_emulation(h, 0) switches the memo off: the index always reads today's observers (the round-3 behaviour).
  * rapid_view_q4_at_risk reports: for hot[0..n) (non-members and duplicates skipped) a member without an entry gets one (what its
  * first getObserversOf does), a member whose memoised observers differ from today's is written to out (capacity cap, *n_out =
