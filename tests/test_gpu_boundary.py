@@ -165,3 +165,46 @@ def test_fast_round_settled_inside_the_tally_equals_the_separate_count(E):
     sim.tally()
     rr = sim.count_votes()
     assert rr.decided == 0 and rr.votes_total == 0
+
+
+def test_a_round_in_one_call_equals_the_five_calls(E, hip):
+    """rapid_sim_round_device = attach + declare + trust + round (include/rapid_mi355x.h): same decision, same cut, same configuration
+    id after applying it as the call sequence it stands for; a refused argument refuses the whole call and leaves the loaded round."""
+    n, K, H, L = 1200, 10, 9, 4
+    pop = S.Population.make(n)
+    cuts, cfgs = [], []
+    for one_call in (False, True):
+        eng = E.Engine(n_max=n, K=K, H=H, L=L)
+        view = E.MembershipView(eng).build(pop.hostnames, pop.ports, pop.id_hi, pop.id_lo)
+        obs, subj, member = view.tables()
+        cfg = view.getCurrentConfigurationId()
+        sc = S.build_scenario("C2", subj, cfg, n=n, f=12, H=H, L=L)
+        raw = np.ascontiguousarray(sc.records).view(np.uint8).reshape(-1)
+        off = np.ascontiguousarray(sc.rec_off, dtype=np.int64)
+        al = np.ascontiguousarray(sc.batches.recs).view(np.uint8).reshape(-1)
+        d_rec, d_off, d_al = to_device(hip, raw), to_device(hip, off), to_device(hip, al)
+        sim = E.ClusterSimulation(eng)
+        R = len(off) - 1
+        if one_call:
+            with pytest.raises(E.IllegalArgumentException):  # host memory for the alerts: nothing of the call happens
+                sim.round_device(d_rec.value, raw.nbytes, d_off.value, R, al.ctypes.data, len(al) // 20, trust=1, apply=True)
+            with pytest.raises(E.IllegalArgumentException):
+                sim.round_device(d_rec.value, raw.nbytes, d_off.value, R, d_al.value, len(al) // 20, trust=3, apply=True)
+            assert view.getCurrentConfigurationId() == cfg
+            rr, new_cfg = sim.round_device(d_rec.value, raw.nbytes, d_off.value, R, d_al.value, len(al) // 20, trust=1, apply=True)
+        else:
+            sim.attach_streams_device(d_rec.value, raw.nbytes, d_off.value, R)
+            sim.set_alert_set_device(d_al.value, len(al) // 20, trust_copies=1)
+            rr, new_cfg = sim.round(apply=True)
+        assert rr.decided == 1 and sorted(sim.decided_cut()) == sc.faulty.tolist()
+        assert view.getCurrentConfigurationId() == new_cfg != cfg
+        cuts.append(sim.decided_cut())
+        cfgs.append((new_cfg, int(rr.votes_winner), int(rr.quorum)))
+        # nothing declared (d_alerts NULL, n_alerts 0): the round scans the delivered records themselves -- in the NEW view these
+        # deliveries are of an earlier configuration: every one dropped, nobody proposes
+        rr2, _ = sim.round_device(d_rec.value, raw.nbytes, d_off.value, R, None, 0, trust=0, apply=False)
+        assert rr2.decided == 0 and rr2.votes_total == 0
+        eng.close()
+        for p in (d_rec, d_off, d_al):
+            assert hip.hipFree(p) == 0
+    assert cuts[0] == cuts[1] and cfgs[0] == cfgs[1]
