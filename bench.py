@@ -549,8 +549,13 @@ def bench_c5(args, rank, world, local_rank, torch, dist, E, P, S):
                        "dict_mode": info["dict_mode"], "waves_per_workgroup": info["waves_per_workgroup"], "workgroups": info["workgroups"],
                        "hot_subjects": info["hot_subjects"], "alerts_prevalidated": info["alerts_prevalidated"]}
     b = forms["boundary"]
-    roofline = {"bound": "hbm", "achieved": b["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b["frac"], "traffic": None,
-                "traffic_source": "not measured for C5 (the C3b line carries the PMC pass)",
+    traffic, traffic_source = (None, "not measured at %d ranks" % world)
+    if world == 1 and rank == 0 and not args.no_pmc:
+        per_byte, traffic_source = measure_traffic_c5()
+        traffic = int(per_byte * 20.0 * b["records_consumed_per_launch"]) if per_byte else None
+    roofline = {"bound": "hbm", "achieved": b["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b["frac"], "traffic": traffic,
+                "traffic_source": traffic_source,
+                "traffic_over_bytes": round(traffic / (20.0 * b["records_consumed_per_launch"]), 3) if traffic else None,
                 "kernel": "tally_population_kernel<%s, %s, kFmtBoundary, packed>" % ({0: "kDictMemory", 4: "kDictHashed"}.get(b["dict_mode"], "?"),
                                                                                        "trusted" if b["alerts_prevalidated"] else "filter"),
                 "kernel_ms": b["kernel_ms"], "bytes_per_launch": int(20 * b["records_consumed_per_launch"]), "bytes_per_record": 20,
@@ -723,6 +728,43 @@ def light_run(E, S, torch, pop, K, H, L, cfgname, n, f, seed_fault, seed_deliver
     del d_rec, d_off, d_al
     torch.cuda.empty_cache()
     return out
+
+
+def measure_traffic_c5():
+    """HBM bytes per delivered byte of the C5 tile tally (20-byte boundary records, packed detector state), measured in this run: a
+    `rocprofv3 --pmc FETCH_SIZE` pass (its own process, counters only) over scripts/c5_probe.py -- one tile of 1,024 receivers at
+    10^6 members.  FETCH_SIZE (KiB) under-reports wide coalesced reads on gfx950; the same pass holds its own calibration: the tally of
+    the RESOLVED records of the same tile reads a known byte count (8 B per record) with the same load instructions.
+    -> (HBM bytes per delivered byte, or None; how it was obtained)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            cmd = [exe, "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+                   os.path.join(ROOT, "scripts", "c5_probe.py"), "1000000", "1024", "2"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", RAPID_AB_ONLY="default"), capture_output=True, text=True, timeout=600)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "rocprofv3 --pmc produced no counter file (rc %d)" % r.returncode
+            boundary, resolved = [], []
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != "FETCH_SIZE" or "tally_population" not in row["Kernel_Name"]:
+                    continue
+                (resolved if "<3," in row["Kernel_Name"] else boundary).append(float(row["Counter_Value"]))
+            if not boundary or not resolved:
+                return None, "counter file without the two tally kernels"
+            # the same tile, the same number n of records: the resolved tally reads 8 n known bytes, the boundary tally 20 n algorithmic
+            # ones -- bytes fetched per delivered byte = (counter ratio) x 8 / 20
+            return (sum(boundary) / len(boundary)) / (sum(resolved) / len(resolved)) * 8.0 / 20.0, \
+                "rocprofv3 --pmc FETCH_SIZE in this run over one C5 tile (scripts/c5_probe.py), calibrated on the tally of the same tile's resolved 8-byte records"
+    except Exception as e:  # a measurement aid must not take the bench line down
+        return None, "PMC pass failed: %s" % str(e)[:120]
 
 
 def measure_traffic(cfgname):
