@@ -222,12 +222,19 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = tot_batches * args.steps / elapsed
 
-    # ---- dominant kernel: the alert tally.  HIP events on the engine's own stream, back-to-back launches over stream set 0 ----
+    # ---- dominant kernel: the alert tally.  HIP events on the engine's own stream, back-to-back launches over EVERY resident stream
+    # set the timed steps alternated between -- the kernel's average launch duration over the timed region's launches.  (The sets hold
+    # the same round in different delivery orders and lie in different allocations: the same kernel measures 0.385 or 0.400 ms by the
+    # allocation the records happen to lie in, profiles/r06_measurements.md section 5 -- one set alone would be a draw of that.)
     sim.index_info()  # (asks for the device time of the NEXT index build: the rounds of the timed loop above carried no timing events)
-    fresh_round(0)
-    kern_ms = sim.time_tally(args.kernel_reps)
-    st = sim.stats()
-    consumed = st["records_consumed"] // (args.kernel_reps + 1)
+    kern_by_set, consumed_by_set = [], []
+    for k in range(n_sets - 1, -1, -1):  # (set 0 last: the measurements beside the line go on with it)
+        fresh_round(k)
+        kern_by_set.insert(0, sim.time_tally(args.kernel_reps))
+        st = sim.stats()  # (the last pass, over set 0, is the one whose event counters the line carries)
+        consumed_by_set.insert(0, st["records_consumed"] // (args.kernel_reps + 1))
+    kern_ms = sum(kern_by_set) / len(kern_by_set)
+    consumed = sum(consumed_by_set) // len(consumed_by_set)
     index = sim.index_info(timed=False)
     kern_filter_ms = kern_nolate_ms = step_filter_ms = None
     if not args.no_extras:
@@ -266,7 +273,7 @@ def main():
                 "kernel": "tally_population_kernel<%s, %s, kFmtBoundary%s>" % ({0: "kDictMemory", 1: "kDictDirect", 2: "kDictCompressed"}.get(index["dict_mode"], "?"),
                                                                                  "trusted" if index["alerts_prevalidated"] else "filter",
                                                                                  ", ids known current" if index.get("configuration_ids_known_current") else ""),
-                "kernel_ms": round(kern_ms, 4),
+                "kernel_ms": round(kern_ms, 4), "kernel_ms_by_stream_set": [round(x, 4) for x in kern_by_set],
                 "bytes_per_launch": int(rec_b * consumed), "bytes_per_record": 20, "records_consumed_per_launch": int(consumed),
                 "records_delivered_per_launch": my_records,
                 "traffic_over_bytes": round(traffic / (rec_b * consumed), 3) if traffic else None,
