@@ -554,6 +554,10 @@ int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, in
  * rapid_sim_count_votes fills it; 2: the voters disagree somewhere and the general (histogram) count would run. */
 int rapid_debug_vote_segment(rapid_engine* h, void* out, int64_t cap_bytes, int64_t* seg_bytes);
 int rapid_debug_vote_merge(rapid_engine* h, const void* segments, int32_t n_ranks, rapid_round_result* out, int32_t* status);
+/* testing aid for the test suite's own fault tolerance (tests/conftest.py): launches a kernel that stores through a wild pointer --
+ * a REAL device memory fault: the runtime aborts the process.  Only called by tests/test_gpu_fault_isolation.py, and only when
+ * RAPID_TEST_REAL_FAULT=1 is set by whoever runs it. */
+int rapid_debug_device_fault(rapid_engine* h);
 
 #endif /* RAPID_TEST_BUILD */
 

@@ -260,6 +260,7 @@ def _test_signatures():
         "rapid_debug_vote_merge": (i32, [vp, p, i32, p, pi32]),
         "rapid_debug_read_records": (i32, [vp, i64, i32, p, p]),
         "rapid_debug_stream_probe": (i32, [vp, i32, i32, i32, C.POINTER(C.c_float)]),
+        "rapid_debug_device_fault": (i32, [vp]),
     }
 
 

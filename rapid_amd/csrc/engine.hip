@@ -3289,6 +3289,19 @@ int rapid_sim_index_info(rapid_engine* h, int32_t info[8], float* index_ms) {
 }
 
 #ifdef RAPID_TEST_BUILD
+namespace rapid {
+__global__ void debug_wild_store_kernel(unsigned long long* p) { p[threadIdx.x] = 0xFA17ull; }
+}  // namespace rapid
+// (see the header: the test suite's fault tolerance, exercised with a real fault when somebody asks for it)
+int rapid_debug_device_fault(rapid_engine* h) {
+    if (!h) return RAPID_EINVAL;
+    int rc = use_device(h);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rapid::debug_wild_store_kernel, dim3(1), dim3(64), 0, h->stream, reinterpret_cast<unsigned long long*>(0x10ull));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RAPID_OK;  // (not reached on a device that faults)
+}
+
 int rapid_debug_block_stats(rapid_engine* h, uint64_t* out, int32_t cap_rows, int32_t* rows_out) {
     if (!h || !rows_out || cap_rows < 0 || (cap_rows > 0 && !out)) return RAPID_EINVAL;
     int rc = use_device(h);

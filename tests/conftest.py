@@ -58,7 +58,9 @@ def pytest_runtest_logreport(report):
 def _run_child(nodeids, report_path):
     env = dict(os.environ)
     env[CHILD_ENV] = report_path
-    cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--no-header"] + nodeids
+    # (-s: the child does not capture -- what the runtime prints when it aborts the process, "Memory access fault by GPU ...", goes to
+    # the child's real stderr and so into `out`; captured, it would die with the child's capture buffers)
+    cmd = [sys.executable, "-m", "pytest", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider", "--no-header"] + nodeids
     t0 = time.time()
     try:
         p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=MODULE_TIMEOUT_S)
@@ -84,8 +86,13 @@ def _replay(item, recs):
 
 def _crash_records(item, rc, out, why):
     sig = " (signal %d)" % -rc if rc < 0 and rc != -999 else ""
-    tail = "\n".join(l for l in out.splitlines() if l.strip())[-3000:]
-    msg = "%s: the child process running this test exited with code %d%s before reporting it.\n---- child output (tail) ----\n%s" % (why, rc, sig, tail)
+    lines = [l for l in out.splitlines() if l.strip()]
+    # what names the cause first (the runtime's fault line, the interpreter's verdict, the frames inside this repository), then the tail
+    key = [l for l in lines if "Memory access fault" in l or "Fatal Python error" in l or "HSA_STATUS" in l or
+           ('File "' in l and os.sep + "site-packages" + os.sep not in l and "dist-packages" not in l and "/usr/lib/python" not in l)][:12]
+    tail = "\n".join(lines)[-2000:]
+    msg = "%s: the child process running this test exited with code %d%s before reporting it.\n%s\n---- child output (tail) ----\n%s" % (
+        why, rc, sig, "\n".join(key), tail)
     return [{"nodeid": item.nodeid, "when": "call", "outcome": "failed", "longrepr": msg, "duration": 0.0}]
 
 
