@@ -981,7 +981,7 @@ int build_round_index(rapid_engine* h) {
     HIPCHK(h, h->d_decl.ensure((size_t)N + 40));  // (the index build reads it 64 bytes at a time)
     HIPCHK(h, h->d_node_of_slot.ensure((size_t)N));
     HIPCHK(h, h->d_entries.ensure((size_t)N + 8));  // (+ 8: staged 16 bytes at a time)
-    HIPCHK(h, h->d_adj_off.ensure((size_t)N + 1));
+    HIPCHK(h, h->d_adj_off.ensure((size_t)N + 1 + 8));
     const int tent_cap = 16384;  // touched nodes the compressed dictionary can hold (64 KiB of LDS)
     HIPCHK(h, h->d_tbits.ensure((size_t)(N + 31) / 32 + 1));
     HIPCHK(h, h->d_trank.ensure((size_t)(N + 31) / 32 + 1));
@@ -1127,7 +1127,7 @@ int build_round_index(rapid_engine* h) {
         HIPCHK(h, h->d_hmem.ensure(((size_t)h->n_hot + 31) / 32 + 1));
         HIPCHK(h, h->d_hnew.ensure((size_t)h->n_hot + 1));
         HIPCHK(h, h->d_nos2.ensure((size_t)N));
-        HIPCHK(h, h->d_smask2.ensure((size_t)N + 1));
+        HIPCHK(h, h->d_smask2.ensure((size_t)N + 1 + 8));
         HIPCHK(h, h->d_adj2.ensure((size_t)adj_cap + 1));
         const size_t hl = (size_t)rapid::index_hash_lds_bytes(N, h->n_hot);
         if (!h->hash_lds_attr_set) {
@@ -2235,7 +2235,7 @@ int rapid_sim_generate(rapid_engine* h, const rapid_alert_record* alerts, const 
         }
         HIPCHK(h, h->d_gen_bat.ensure((size_t)std::max(n_batches, 1)));
         hipLaunchKernelGGL(rapid::gen_pack_batches_kernel, dim3(grid_for(n_batches, 256)), dim3(256), 0, st, h->d_gen_boff.p, n_batches,
-                           boundary ? (const uint2*)nullptr : h->d_gen_res.p, h->d_gen_bat.p);
+                           boundary ? (const uint2*)nullptr : h->d_gen_res.p, batch_keep ? h->d_gen_keep.p : (const unsigned int*)nullptr, h->d_gen_bat.p);
         hipLaunchKernelGGL(rapid::gen_streams_kernel, dim3(grid_for(n_receivers, rapid::kGenWavesPerBlock)), dim3(rapid::kGenWavesPerBlock * 64), 0, st,
                            h->d_gen_res.p, h->d_alert_set.p, h->d_gen_bat.p, n_batches, batch_keep ? h->d_gen_keep.p : (const unsigned int*)nullptr,
                            h->d_gen_rx.p, n_receivers, A, (unsigned long long)seed, h->d_records_own.p, boundary ? 1 : 0);
@@ -2862,7 +2862,7 @@ static int round_tiled_impl(rapid_engine* h, const rapid_alert_record* alerts, c
     }
     HIPCHK(h, h->d_gen_bat.ensure((size_t)std::max(n_batches, 1)));
     hipLaunchKernelGGL(rapid::gen_pack_batches_kernel, dim3(grid_for(n_batches, 256)), dim3(256), 0, st, h->d_gen_boff.p, n_batches,
-                       boundary ? (const uint2*)nullptr : h->d_gen_res.p, h->d_gen_bat.p);
+                       boundary ? (const uint2*)nullptr : h->d_gen_res.p, batch_keep ? h->d_gen_keep.p : (const unsigned int*)nullptr, h->d_gen_bat.p);
     // per-receiver results for the whole population; node lists and bitmaps for one tile
     const size_t Rz = (size_t)std::max(R, 1);
     HIPCHK(h, h->d_emit.ensure(Rz));

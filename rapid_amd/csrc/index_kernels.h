@@ -1010,12 +1010,16 @@ __global__ void gen_resolve_alerts_kernel(const unsigned char* alerts, long long
 // in ONE 16-byte gather -- and, for the nine batches in ten that hold a single alert, the record itself (res == nullptr, boundary
 // records: zeros there).  The generator is bound by the rate at which a CU turns scattered addresses into cache lines (2.65 x 10^11
 // scattered reads per second over the whole GPU, profiles/r05_gather_rate.txt): a second gather per delivery halves it.
-__global__ void gen_pack_batches_kernel(const long long* boff, int n_batches, const uint2* res, uint4* bat) {
+// Bit 31 of the length: the batch reaches EVERY receiver (no per-batch draw, or one that cannot fail) -- true of all but the late
+// batches of a round; the generator then neither evaluates the draw (a 64-bit mix: two quarter-rate multiplies) nor gathers keep[b].
+constexpr unsigned int kGenAlways = 0x80000000u;
+__global__ void gen_pack_batches_kernel(const long long* boff, int n_batches, const uint2* res, const unsigned int* keep, uint4* bat) {
     const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (b >= n_batches) return;
     const unsigned int f = (unsigned int)boff[b];
     const uint2 r0 = res != nullptr ? res[f] : make_uint2(0u, 0u);
-    bat[b] = make_uint4(f, (unsigned int)(boff[b + 1] - boff[b]), r0.x, r0.y);
+    const unsigned int always = (keep == nullptr || keep[b] == 0xFFFFFFFFu) ? kGenAlways : 0u;
+    bat[b] = make_uint4(f, (unsigned int)(boff[b + 1] - boff[b]) | always, r0.x, r0.y);
 }
 
 // ONE WAVE PER RECEIVER (a workgroup = kGenWavesPerBlock receivers; no barrier, no LDS): the wave walks its receiver's delivery
@@ -1065,24 +1069,42 @@ __global__ __launch_bounds__(kGenWavesPerBlock * 64) void gen_streams_kernel(con
             for (int q = 0; q < 5; ++q) dst[q] = w[q];
         }
     };
+    static_assert(64 * kGenChunks / (int)kGenLine <= 64, "the lines of one step are evaluated by the lanes of one wave");
     for (int j0 = 0; j0 < n_batches; j0 += 64 * kGenChunks) {
         unsigned int first[kGenChunks], len[kGenChunks];
         uint2 rec0[kGenChunks];
         bool del[kGenChunks];
+        // The step's 256 positions lie on 32 lines of the order: lane l evaluates line (j0 / 8) + (l mod 32) ONCE -- the Feistel
+        // network and the line's hash, two thirds of gen_perm_at's instructions -- and the eight positions of a line fetch the result
+        // from that lane (gen_perm_at evaluates it in each of the eight lanes).  Same permutation: gen_perm_at's first turn, spelled
+        // out; a position that lands beyond n (the last line only) walks on through gen_perm_at itself.
+        unsigned int Ql = 0u, hl = 0u;
+        if (g.n > 1u) {
+            const unsigned int ql = min(((unsigned int)j0 >> kGenLineBits) + (unsigned int)(lane & 31), g.lines - 1u);
+            Ql = gen_line_at(g, ql);
+            hl = gen_f16(Ql & 0xFFFFu, g.rk[2] ^ (Ql >> 16));
+        }
 #pragma unroll
         for (int u = 0; u < kGenChunks; ++u) {
             const int j = j0 + 64 * u + lane;
+            const int src = u * (64 / (int)kGenLine) + (lane >> kGenLineBits);
+            const unsigned int Q = (unsigned int)__shfl((int)Ql, src, 64), h = (unsigned int)__shfl((int)hl, src, 64);
             first[u] = 0u;
             len[u] = 0u;
             rec0[u] = make_uint2(0u, 0u);
             del[u] = false;
             if (j < n_batches) {
-                const unsigned int b = gen_perm_at(g, (unsigned int)j);
+                unsigned int b = 0u;
+                if (g.n > 1u) {
+                    const unsigned int T = (((((unsigned int)j & (kGenLine - 1u)) ^ (h >> 8)) * ((h & 6u) | 1u)) + (h >> 3)) & (kGenLine - 1u);
+                    b = (Q << kGenLineBits) | T;
+                    if (b >= g.n) b = gen_perm_at(g, b);
+                }
                 const uint4 bt = bat[b];
                 first[u] = bt.x;
-                len[u] = bt.y;
+                len[u] = bt.y & ~kGenAlways;
                 rec0[u] = make_uint2(bt.z, bt.w);
-                del[u] = gen_delivered(g, keep, b);
+                del[u] = (bt.y & kGenAlways) != 0u || gen_delivered(g, keep, b);
             }
         }
 #pragma unroll

@@ -1190,38 +1190,55 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
             wave_lds_fence();
             int run = 0;
             unsigned int best = 0xFFFFFFFFu;  // bound << 16 | slot
-            // Per-slot masks in memory (packed detector state: thousands of hot subjects): the masks of kSweepBatch steps are requested
-            // together and for every slot of the step, whether or not it turns out to be in preProposal -- coalesced 128-byte loads, all
-            // in flight at once.  Asked for slot by slot under the "in preProposal" mask, every step of the sweep waited out a memory
-            // round trip of its own: 118 dependent round trips per sweep at 15,000 hot subjects, ~95,000 cycles, 16 % of a receiver's
-            // time at 10^6 nodes (profiles/r05_c5_phase_before.txt).
-            constexpr int kSweepBatch = slot_tables_in_lds ? 1 : 4;
-            for (int i0 = 0; i0 < n_hot; i0 += 2 * kWave * kSweepBatch) {  // two slots per lane and step: two LDS round trips in flight, half the turns
-                unsigned int pre_a[kSweepBatch], pre_b[kSweepBatch];
-                if constexpr (!slot_tables_in_lds) {
+            // Per-slot masks in memory (packed detector state: thousands of hot subjects).  Asked for slot by slot under the "in preProposal"
+            // mask, every step of the sweep waited out a memory round trip of its own: 118 dependent round trips per sweep at 15,000
+            // hot subjects, ~95,000 cycles (profiles/r05_c5_phase_before.txt); round 5 requested the masks of four steps together.
+            // Round 6: the packed state is swept EIGHT slots per lane and step -- one ds_read_b128 of the state, one 16-byte load of
+            // the masks (the masks of kSweepVec steps requested together), the slots in [L, H) counted per lane and summed once at
+            // the end instead of a ballot and a scalar count per slot: 30 steps instead of 118 at 15,000 hot subjects, and the
+            // scalar pipe left alone (a sweep was 57,000 cycles, five times per receiver: a fifth of a receiver's time at 10^6 nodes,
+            // profiles/r06_c5_phase_resolved.txt).  Which slots a lane sees decides the 2nd to 4th candidate, never what is tallied.
+            if constexpr (!slot_tables_in_lds) {
+                constexpr int kPer = 8, kStepSlots = kPer * kWave, kSweepVec = 5;
+                const uint4* const st128 = reinterpret_cast<const uint4*>(mine);
+                const uint4* const sm128 = reinterpret_cast<const uint4*>(p.idx.smask);  // (engine.hip sizes the table with 16 bytes to spare)
+                unsigned int run_l = 0u;
+                const unsigned int Lu = (unsigned int)d.L, HLu = (unsigned int)(d.H - d.L), Hu = (unsigned int)d.H;
+                for (int i0 = 0; i0 < n_hot; i0 += kStepSlots * kSweepVec) {
+                    uint4 pm[kSweepVec];
 #pragma unroll
-                    for (int u = 0; u < kSweepBatch; ++u) {
-                        const int ia = i0 + u * 2 * kWave + lane, ib = ia + kWave;
-                        pre_a[u] = ia < n_hot ? (unsigned int)p.idx.smask[ia] : 0u;
-                        pre_b[u] = ib < n_hot ? (unsigned int)p.idx.smask[ib] : 0u;
+                    for (int u = 0; u < kSweepVec; ++u) {
+                        const int base = i0 + u * kStepSlots + lane * kPer;
+                        pm[u] = sm128[min(base, n_hot - 1) >> 3];  // (clamped, not skipped: loads under a branch cost the wait-count pass its count)
+                    }
+#pragma unroll
+                    for (int u = 0; u < kSweepVec; ++u) {
+                        if (i0 + u * kStepSlots >= n_hot) continue;  // (wave-uniform)
+                        const int base = i0 + u * kStepSlots + lane * kPer;
+                        const uint4 sv = base < n_hot ? st128[base >> 3] : make_uint4(0u, 0u, 0u, 0u);
+                        const unsigned int sw[4] = {sv.x, sv.y, sv.z, sv.w}, mw[4] = {pm[u].x, pm[u].y, pm[u].z, pm[u].w};
+#pragma unroll
+                        for (int j = 0; j < kPer; ++j) {
+                            const unsigned int m = (sw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu, am = (mw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                            const unsigned int c = (unsigned int)d.count(m);
+                            const bool pre = base + j < n_hot && c - Lu < HLu;  // L <= c < H
+                            run_l += pre ? 1u : 0u;
+                            const unsigned int bound = (unsigned int)d.count(m | am);
+                            const unsigned int key = (pre && bound < Hu) ? (bound << 16) | (unsigned int)(base + j) : 0xFFFFFFFFu;
+                            best = min(best, key);
+                        }
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < kSweepBatch; ++u) {
-                    const int ia = i0 + u * 2 * kWave + lane, ib = ia + kWave;
+                run = (int)uniform((unsigned int)wave_sum64((unsigned long long)run_l));
+            } else {
+                for (int i0 = 0; i0 < n_hot; i0 += 2 * kWave) {  // two slots per lane and step: two LDS round trips in flight, half the turns
+                    const int ia = i0 + lane, ib = ia + kWave;
                     const bool ina = ia < n_hot, inb = ib < n_hot;
                     const unsigned int ma = ina ? d.load(ia) : 0u, mb = inb ? d.load(ib) : 0u;
                     const int ca = d.count(ma), cb = d.count(mb);
                     const bool prea = ina && ca >= d.L && ca < d.H, preb = inb && cb >= d.L && cb < d.H;
                     run += __popcll(wave_ballot(prea)) + __popcll(wave_ballot(preb));
-                    unsigned int ama, amb;
-                    if constexpr (slot_tables_in_lds) {
-                        ama = prea ? smask_of((unsigned int)ia) : 0u;
-                        amb = preb ? smask_of((unsigned int)ib) : 0u;
-                    } else {
-                        ama = prea ? pre_a[u] : 0u;
-                        amb = preb ? pre_b[u] : 0u;
-                    }
+                    const unsigned int ama = prea ? smask_of((unsigned int)ia) : 0u, amb = preb ? smask_of((unsigned int)ib) : 0u;
                     const int bounda = d.count(ma | ama), boundb = d.count(mb | amb);
                     const unsigned int keya = (prea && bounda < d.H) ? ((unsigned int)bounda << 16) | (unsigned int)ia : 0xFFFFFFFFu;
                     const unsigned int keyb = (preb && boundb < d.H) ? ((unsigned int)boundb << 16) | (unsigned int)ib : 0xFFFFFFFFu;
@@ -1810,18 +1827,60 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
             wave_lds_fence();
             int* const out = p.props + (long long)r * p.prop_cap;
             unsigned long long* const bm = p.bitmaps != nullptr ? p.bitmaps + (long long)r * p.bitmap_words : nullptr;
-            for (int i0 = 0; i0 < n_hot; i0 += kWave) {
-                const int i = i0 + lane;
-                const bool take = i < n_hot && (d.load(i) & Det::kFlushed) != 0;
-                const unsigned long long mk = wave_ballot(take);
-                if (bm != nullptr && lane == 0) stream_store(bm + (i0 >> 6), mk);
-                const int idx = count + __popcll(mk & lanes_lt(lane));
-                if (take) {
-                    const int node = nos_in_lds ? l_nos[i] : p.idx.node_of_slot[i];
-                    if (idx < p.prop_cap) stream_store(out + idx, node);
-                    fp += mix64((unsigned long long)node);
+            if constexpr (nos_in_lds) {
+                for (int i0 = 0; i0 < n_hot; i0 += kWave) {
+                    const int i = i0 + lane;
+                    const bool take = i < n_hot && (d.load(i) & Det::kFlushed) != 0;
+                    const unsigned long long mk = wave_ballot(take);
+                    if (bm != nullptr && lane == 0) stream_store(bm + (i0 >> 6), mk);
+                    const int idx = count + __popcll(mk & lanes_lt(lane));
+                    if (take) {
+                        const int node = l_nos[i];
+                        if (idx < p.prop_cap) stream_store(out + idx, node);
+                        fp += mix64((unsigned long long)node);
+                    }
+                    count += __popcll(mk);
                 }
-                count += __popcll(mk);
+            } else {
+                // slot -> node in memory (packed rounds): the nodes of eight steps are requested together, flushed or not -- coalesced
+                // 256-byte loads, all in flight at once -- and the NEXT eight steps' before these eight are written out.  Asked for
+                // under the "flushed" mask, every step waited out a memory round trip of its own: 235 of them per proposal at 15,000
+                // hot subjects (a tenth of a receiver's time at 10^6 nodes, profiles/r06_c5_phase_resolved.txt).
+                constexpr int kOutBatch = 8;
+                auto fetch = [&](int i0, int (&nodes)[kOutBatch]) {
+#pragma unroll
+                    for (int u = 0; u < kOutBatch; ++u) {
+                        // (clamped, not skipped: a load under a branch leaves the compiler's wait-count pass without a count, and it
+                        // then waits with vmcnt(0) -- for the loads just requested and for every store still on its way)
+                        const int i = min(i0 + u * kWave + lane, n_hot - 1);
+                        nodes[u] = p.idx.node_of_slot[i];
+                    }
+                };
+                auto emit = [&](int i0, const int (&nodes)[kOutBatch]) {
+#pragma unroll
+                    for (int u = 0; u < kOutBatch; ++u) {
+                        const int i = i0 + u * kWave + lane;
+                        if (i0 + u * kWave >= n_hot) continue;  // (wave-uniform)
+                        const bool take = i < n_hot && (d.load(i) & Det::kFlushed) != 0;
+                        const unsigned long long mk = wave_ballot(take);
+                        if (bm != nullptr && lane == 0) stream_store(bm + ((i0 + u * kWave) >> 6), mk);
+                        const int idx = count + __popcll(mk & lanes_lt(lane));
+                        if (take) {
+                            if (idx < p.prop_cap) stream_store(out + idx, nodes[u]);
+                            fp += mix64((unsigned long long)nodes[u]);
+                        }
+                        count += __popcll(mk);
+                    }
+                };
+                constexpr int kStep = kWave * kOutBatch;
+                int na[kOutBatch], nb[kOutBatch];
+                fetch(0, na);
+                for (int i0 = 0; i0 < n_hot; i0 += 2 * kStep) {
+                    fetch(i0 + kStep, nb);
+                    emit(i0, na);
+                    fetch(i0 + 2 * kStep, na);
+                    emit(i0 + kStep, nb);
+                }
             }
             fp = wave_sum64(fp) + mix64(0x5EEDull + (unsigned long long)count);
             if (fp == 0) fp = 1;

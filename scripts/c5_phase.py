@@ -1,6 +1,6 @@
 """Where a receiver's cycles go at BASELINE configs[4] (10^6 members, ~15,000 hot subjects): the tally kernel's event counters per
 receiver (test build) and the phase timers of the -DRAPID_PHASE_TIMERS build (scripts/build_variants.sh timers "-DRAPID_PHASE_TIMERS").
-    python scripts/c5_phase.py [members=1000000] [receivers=1024]"""
+    python scripts/c5_phase.py [members=1000000] [receivers=1024] [boundary|resolved]"""
 import os
 import sys
 import time
@@ -15,6 +15,7 @@ from rapid_amd import scenarios as S  # noqa: E402
 
 n_mem = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 n_rx = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+boundary = not (len(sys.argv) > 3 and sys.argv[3] == "resolved")
 K, H, L = 10, 9, 4
 pop = S.Population.make(n_mem + int(0.006 * n_mem) + 64)
 sc = deliver_set = rx = None
@@ -33,7 +34,7 @@ for tag, path in (("counters", N.TEST_LIB_PATH), ("timers", os.path.join(ROOT, "
         sc, deliver_set = st.next_round_batches(obs, member, cfg)
         rx = np.sort(np.random.Generator(np.random.PCG64(11)).permutation(sc.receivers)[:n_rx]).astype(np.int32)
     sim = E.ClusterSimulation(eng)
-    sim.generate(deliver_set, rx, seed=7, trust_copies=True, boundary=True)
+    sim.generate(deliver_set, rx, seed=7, trust_copies=True, boundary=boundary)
     reps = 3
     ms = sim.time_tally(reps)
     s = np.zeros(8, dtype=np.uint64)
@@ -41,7 +42,7 @@ for tag, path in (("counters", N.TEST_LIB_PATH), ("timers", os.path.join(ROOT, "
     runs = reps + 1
     info = sim.index_info(timed=False)
     nwin = (len(deliver_set.recs) + 255) // 256
-    print(tag, "tally_ms", round(ms, 4), "windows per receiver", nwin, info, flush=True)
+    print(tag, "boundary" if boundary else "resolved", "tally_ms", round(ms, 4), "windows per receiver", nwin, info, flush=True)
     if tag == "counters":
         names = ("exact_subchunks", "lean_windows", "full_sweeps", "restarts", "implicit_reports", "records_consumed", "lean_give_ups", "careful_subchunks")
         print({k: round(float(v) / runs / len(rx), 2) for k, v in zip(names, s)}, flush=True)

@@ -495,7 +495,7 @@ extern "C" int emu_generate(const unsigned char* alerts, const long long* boff, 
     std::vector<uint4> bat((size_t)std::max(n_batches, 1));
     {
         const unsigned g = (unsigned)std::max(1, (n_batches + 255) / 256);
-        for (unsigned b = 0; b < g; ++b) emu::run_block(b, g, 256u, [&] { rapid::gen_pack_batches_kernel(boff, n_batches, boundary ? nullptr : res.data(), bat.data()); }, sd + 50 + b);
+        for (unsigned b = 0; b < g; ++b) emu::run_block(b, g, 256u, [&] { rapid::gen_pack_batches_kernel(boff, n_batches, boundary ? nullptr : res.data(), keep, bat.data()); }, sd + 50 + b);
     }
     const unsigned gw = (unsigned)((n_receivers + rapid::kGenWavesPerBlock - 1) / rapid::kGenWavesPerBlock);
     for (unsigned b = 0; b < gw; ++b)

@@ -45,7 +45,7 @@ def build_round_index(records, n_nodes, K, L, obs, member):
     slot_of[node_of_slot] = np.arange(n_hot)
     # the hot adjacency as index_build_block_kernel produces it: one triple (subject slot | observer slot << 14 | ring << 28)
     # per ring on which a hot node observes a hot slot, and the per-slot mask of those rings
-    pairs, smask = [], np.zeros(n_hot + 1, dtype=np.uint16)
+    pairs, smask = [], np.zeros(n_hot + 1 + 8, dtype=np.uint16)  # (+ 8: the packed sweep reads the masks 16 bytes at a time, as engine.hip sizes the table)
     dict_ = slot_of | np.where(np.asarray(member) != 0, 0x8000, 0)
     for e in range(n_hot):
         s_node = int(node_of_slot[e])
@@ -95,7 +95,7 @@ def index_run(records, n_nodes, K, L, cfg_id, obs, member, chunked=False, direct
     n_words = (n_nodes + 31) // 32
     adj_cap, tent_cap = 65536, 16384
     out = dict(dict=np.full(n_nodes + 40, 0xEEEE, dtype=np.uint16), decl=np.full(n_nodes + 40, 0xEEEE, dtype=np.uint16),
-               node_of_slot=np.full(n_nodes + 1, -7, dtype=np.int32), smask=np.full(n_nodes + 1, 0xEEEE, dtype=np.uint16),
+               node_of_slot=np.full(n_nodes + 1, -7, dtype=np.int32), smask=np.full(n_nodes + 1 + 8, 0xEEEE, dtype=np.uint16),
                pairs=np.zeros(adj_cap + 1, dtype=np.uint32), tbits=np.full(n_words + 1, 0xEEEEEEEE, dtype=np.uint32),
                trank=np.full(n_words + 1, 0xEEEE, dtype=np.uint16), tent=np.full(tent_cap, 0xEEEEEEEE, dtype=np.uint32),
                info=np.zeros(8, dtype=np.int32), entries=np.full(n_nodes + 1, 0xEEEEEEEE, dtype=np.uint32))
@@ -246,7 +246,7 @@ def hash_build(ix, n_nodes, member, seed=1):
     entries = dict_entries(ix, n_nodes).copy()
     dict_ = np.ascontiguousarray(ix["dict"], dtype=np.uint16).copy()
     out = dict(hoff=np.full(nb + 4, 0xEEEE, dtype=np.uint16), hrem=np.full(n_hot + 32 + 8, 0xEE, dtype=np.uint8), hmem=np.full((n_hot + 31) // 32 + 1, 0xEEEEEEEE, dtype=np.uint32),
-               node_of_slot=np.full(n_hot + 1, -7, dtype=np.int32), smask=np.full(n_hot + 1, 0xEEEE, dtype=np.uint16),
+               node_of_slot=np.full(n_hot + 1, -7, dtype=np.int32), smask=np.full(n_hot + 1 + 8, 0xEEEE, dtype=np.uint16),
                pairs=np.zeros(max(n_adj, 1) + 1, dtype=np.uint32), new_of_old=np.full(n_hot + 1, 0xEEEE, dtype=np.uint16))
     ans = np.zeros(2, dtype=np.int32)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
