@@ -1033,6 +1033,9 @@ __global__ void gen_pack_batches_kernel(const long long* boff, int n_batches, co
 // {entry, core word} from res[]; else the 20-byte boundary records themselves (flags bit 0 = the batch end).  A batch ends with
 // its last alert, whatever the flags of the set say.  (Round 4: a workgroup per receiver, 1,024 deliveries per step between two
 // barriers, every output record found by a ten-step binary search in LDS: 1.8 - 2.5 ms per 1.5 x 10^8 records at 10^6 nodes.)
+#ifndef RAPID_GEN_PRIO
+#define RAPID_GEN_PRIO 0  // (measurement knob: the issue priority of the generator's waves beside a tally launch, s_setprio)
+#endif
 constexpr int kGenWavesPerBlock = 4;
 constexpr int kGenChunks = 4;
 constexpr int kGenLaneLoop = 4;
@@ -1043,6 +1046,9 @@ __global__ __launch_bounds__(kGenWavesPerBlock * 64) void gen_streams_kernel(con
     const int lane = (int)(threadIdx.x & 63u);
     const int r = (int)blockIdx.x * kGenWavesPerBlock + (int)(threadIdx.x >> 6);
     if (r >= n_receivers) return;
+#if RAPID_GEN_PRIO
+    __builtin_amdgcn_s_setprio(RAPID_GEN_PRIO);
+#endif
     const GenPerm g = gen_perm_make(seed, (unsigned int)receivers[r], (unsigned int)n_batches);
     long long at = (long long)r * n_alerts;  // the stream's next record
     // record k of the batch whose first alert is f, `last`: it closes the batch; delivered == false: an empty record
@@ -1070,14 +1076,17 @@ __global__ __launch_bounds__(kGenWavesPerBlock * 64) void gen_streams_kernel(con
         }
     };
     static_assert(64 * kGenChunks / (int)kGenLine <= 64, "the lines of one step are evaluated by the lanes of one wave");
-    for (int j0 = 0; j0 < n_batches; j0 += 64 * kGenChunks) {
-        unsigned int first[kGenChunks], len[kGenChunks];
-        uint2 rec0[kGenChunks];
-        bool del[kGenChunks];
-        // The step's 256 positions lie on 32 lines of the order: lane l evaluates line (j0 / 8) + (l mod 32) ONCE -- the Feistel
-        // network and the line's hash, two thirds of gen_perm_at's instructions -- and the eight positions of a line fetch the result
-        // from that lane (gen_perm_at evaluates it in each of the eight lanes).  Same permutation: gen_perm_at's first turn, spelled
-        // out; a position that lands beyond n (the last line only) walks on through gen_perm_at itself.
+    // A STEP = 64 kGenChunks positions of the order.  locate(): which batches they hold, and the gathers of those batches' table
+    // entries REQUESTED; lay(): the entries used -- lengths summed over the lanes, records written.  The wave requests step s + 1
+    // before it lays step s down: the gather (a scattered read out of L2, a microsecond or two with a tally launch running beside
+    // it) is the longest wait of a step, and with four or five waves per SIMD -- one receiver per wave, a tile of 4,096 receivers --
+    // nothing else was there to cover it.  The loads are unconditional (positions beyond the order ask for batch 0): a load under a
+    // branch costs the compiler's wait-count pass its count, and it then waits for everything in flight.
+    // The step's 256 positions lie on 32 lines of the order: lane l evaluates line (j0 / 8) + (l mod 32) ONCE -- the Feistel network
+    // and the line's hash, two thirds of gen_perm_at's instructions -- and the eight positions of a line fetch the result from that
+    // lane (gen_perm_at evaluates it in each of the eight lanes).  Same permutation: gen_perm_at's first turn, spelled out; a
+    // position that lands beyond n (the last line only) walks on through gen_perm_at itself.
+    auto locate = [&](int j0, uint4 (&bt)[kGenChunks], unsigned int (&bsel)[kGenChunks]) {
         unsigned int Ql = 0u, hl = 0u;
         if (g.n > 1u) {
             const unsigned int ql = min(((unsigned int)j0 >> kGenLineBits) + (unsigned int)(lane & 31), g.lines - 1u);
@@ -1089,23 +1098,27 @@ __global__ __launch_bounds__(kGenWavesPerBlock * 64) void gen_streams_kernel(con
             const int j = j0 + 64 * u + lane;
             const int src = u * (64 / (int)kGenLine) + (lane >> kGenLineBits);
             const unsigned int Q = (unsigned int)__shfl((int)Ql, src, 64), h = (unsigned int)__shfl((int)hl, src, 64);
-            first[u] = 0u;
-            len[u] = 0u;
-            rec0[u] = make_uint2(0u, 0u);
-            del[u] = false;
-            if (j < n_batches) {
-                unsigned int b = 0u;
-                if (g.n > 1u) {
-                    const unsigned int T = (((((unsigned int)j & (kGenLine - 1u)) ^ (h >> 8)) * ((h & 6u) | 1u)) + (h >> 3)) & (kGenLine - 1u);
-                    b = (Q << kGenLineBits) | T;
-                    if (b >= g.n) b = gen_perm_at(g, b);
-                }
-                const uint4 bt = bat[b];
-                first[u] = bt.x;
-                len[u] = bt.y & ~kGenAlways;
-                rec0[u] = make_uint2(bt.z, bt.w);
-                del[u] = (bt.y & kGenAlways) != 0u || gen_delivered(g, keep, b);
+            unsigned int b = 0u;
+            if (j < n_batches && g.n > 1u) {
+                const unsigned int T = (((((unsigned int)j & (kGenLine - 1u)) ^ (h >> 8)) * ((h & 6u) | 1u)) + (h >> 3)) & (kGenLine - 1u);
+                b = (Q << kGenLineBits) | T;
+                if (b >= g.n) b = gen_perm_at(g, b);
             }
+            bsel[u] = b;
+            bt[u] = bat[b];
+        }
+    };
+    auto lay = [&](int j0, const uint4 (&bt)[kGenChunks], const unsigned int (&bsel)[kGenChunks]) {
+        unsigned int first[kGenChunks], len[kGenChunks];
+        uint2 rec0[kGenChunks];
+        bool del[kGenChunks];
+#pragma unroll
+        for (int u = 0; u < kGenChunks; ++u) {
+            const bool in = j0 + 64 * u + lane < n_batches;
+            first[u] = in ? bt[u].x : 0u;
+            len[u] = in ? bt[u].y & ~kGenAlways : 0u;
+            rec0[u] = in ? make_uint2(bt[u].z, bt[u].w) : make_uint2(0u, 0u);
+            del[u] = in && ((bt[u].y & kGenAlways) != 0u || gen_delivered(g, keep, bsel[u]));
         }
 #pragma unroll
         for (int u = 0; u < kGenChunks; ++u) {
@@ -1140,6 +1153,16 @@ __global__ __launch_bounds__(kGenWavesPerBlock * 64) void gen_streams_kernel(con
             }
             at += total;
         }
+    };
+    constexpr int kStepPos = 64 * kGenChunks;
+    uint4 ta[kGenChunks], tb[kGenChunks];
+    unsigned int ba[kGenChunks], bb[kGenChunks];
+    if (n_batches > 0) locate(0, ta, ba);
+    for (int j0 = 0; j0 < n_batches; j0 += 2 * kStepPos) {
+        locate(j0 + kStepPos, tb, bb);
+        lay(j0, ta, ba);
+        locate(j0 + 2 * kStepPos, ta, ba);
+        if (j0 + kStepPos < n_batches) lay(j0 + kStepPos, tb, bb);
     }
 }
 __global__ void gen_offsets_kernel(long long* rec_off, int n_receivers, long long n_alerts) {
