@@ -73,7 +73,23 @@ constexpr int kCoreBytes = 8;   // what a tally launch reads per delivered recor
 constexpr int kQ = RAPID_QUARTERS;        // quarters (64 records each) per window
 constexpr int kWin = kQ * kWave;          // 256 records = 5 KiB of stream per window
 static_assert(kQ >= 1 && kQ <= 16, "window size");
-constexpr int kScratchWords = (kQ + 1) * kWave;  // carried quarter + window, one decoded word per record
+// The PACKED instantiations (rounds with thousands of hot subjects: one wave per SIMD, its LDS) take windows twice as large: what a
+// window costs beside its records -- the certificate, the scalar bookkeeping, a branch or two -- is latency that one wave per SIMD
+// cannot hide, and it is paid per window (C5: 1.28 -> 1.15 ms per 152 M boundary records with windows of 512 and three sets in
+// flight, profiles/r06_c5_window_quarters.txt).  (A build with another RAPID_QUARTERS -- the emulator's q1 / q2 / q3 variants --
+// uses that for both.)
+#ifndef RAPID_QUARTERS_PACKED
+#define RAPID_QUARTERS_PACKED (RAPID_QUARTERS == 4 ? 8 : RAPID_QUARTERS)
+#endif
+constexpr int kQPacked = RAPID_QUARTERS_PACKED;
+static_assert(kQPacked >= 1 && kQPacked <= 16, "window size (packed)");
+// ... the packed instantiations over BOUNDARY records, that is.  The packed tally of resolved records runs beside the generator that
+// makes them (rapid_sim_round_tiled), and there a SIMD holds four generator waves of 88 registers next to a tally wave of at most
+// 160: with windows of 512 records that tally is faster by a seventh alone (180 registers) and the shard round slower by a
+// seventh (99.5 -> 113.4 ms: the generator, one wave short, is the critical path).  It keeps windows of 256.
+__host__ __device__ constexpr int tally_quarters(bool packed, bool boundary) { return packed && boundary ? kQPacked : kQ; }
+// (one LDS layout for both packed forms: the scratch list is sized for the larger window)
+__host__ __device__ constexpr int tally_scratch_words(bool packed) { return ((packed && kQPacked > kQ ? kQPacked : kQ) + 1) * kWave; }  // carried quarter + window, one decoded word per record
 #ifndef RAPID_UNDO_CAP
 #define RAPID_UNDO_CAP 128
 #endif
@@ -299,7 +315,7 @@ constexpr int kBlockStatsBytes = 112 + 16 + kBlockVoters * 4;
 // how many receivers a CU holds (C5: 15,000 hot subjects = 60 KB per receiver as 32-bit words)
 __host__ __device__ inline int tally_state_bytes(int n_slots, bool packed) { return align16((n_slots + kDummySlots) * (packed ? 2 : 4)); }
 __host__ __device__ inline int tally_wave_bytes(int n_slots, bool packed = false) {
-    return tally_state_bytes(n_slots, packed) + kScratchWords * 4 + kUndoCap * 4;
+    return tally_state_bytes(n_slots, packed) + tally_scratch_words(packed) * 4 + kUndoCap * 4;
 }
 // rounds with more hot subjects than the per-slot tables' LDS limit run packed (and with their dictionary in memory)
 __host__ __device__ inline bool tally_wants_packed(int n_hot) { return n_hot > kSlotNodesInLdsMax; }
@@ -628,12 +644,12 @@ __device__ inline void exact_batch_end(const D& d, RxScalars& s, const unsigned 
 //   kFmtResident -- 8 bytes {the subject's dict_entry, core word}: what rapid_sim_generate writes when the round's deliveries
 //       are made on the device (the subjects are resolved while the records are laid down: kDictResolved, no lookup here).
 enum { kFmtResident = 0, kFmtBoundary = 1 };
-template <int kFmt>
+template <int kFmt, int kQ>
 struct WindowT {  // kQ x 64 records in flight, lane l of quarter q = record 64 q + l
     unsigned int w3[kQ], w4[kQ];  // resident: dict_entry (or subject); core word
 };
-template <>
-struct WindowT<kFmtBoundary> {
+template <int kQ>
+struct WindowT<kFmtBoundary, kQ> {
     unsigned int c0[kQ], c1[kQ], w3[kQ], w4[kQ];  // configuration id (low, high); dst; dword 4 of the boundary record
 };
 enum { kApplied = 0, kWitnessFails = 1, kNotFastable = 2 };  // outcome of a fast-window attempt
@@ -646,6 +662,9 @@ enum { kApplied = 0, kWitnessFails = 1, kNotFastable = 2 };  // outcome of a fas
 #endif
 #ifndef RAPID_SETS_PACKED
 #define RAPID_SETS_PACKED 4
+#endif
+#ifndef RAPID_SETS_PACKED_BOUNDARY
+#define RAPID_SETS_PACKED_BOUNDARY 3  // (of 512 records each: kQPacked)
 #endif
 #ifndef RAPID_SETS_CURRENT
 #define RAPID_SETS_CURRENT 3  // boundary records of which {dst, word} only is loaded (kCurrent): a window is as small as a resident one
@@ -710,6 +729,8 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
     static_assert(kDictMode != kDictHashed || kFmt == kFmtBoundary, "the hashed dictionary maps the subjects of boundary records");
     static_assert(kFmt == kFmtResident || kDictMode != kDictResolved, "a boundary record carries its subject, not an entry");
     constexpr bool kTablesInLds = kDictMode == kDictDirect;
+    // the window of THIS instantiation (everything below says kQ / kWin / kScratchWords and means these)
+    constexpr int kQ = tally_quarters(kPacked, kFmt == kFmtBoundary), kWin = kQ * kWave, kScratchWords = tally_scratch_words(kPacked);
 #ifndef RAPID_LEAN_OPEN
 #define RAPID_LEAN_OPEN 1
 #endif
@@ -901,7 +922,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
     int n_applied = 0;
     unsigned int sink = 0u;  // stream-only mode: keeps the loads alive
 
-    typedef WindowT<kCurrent ? kFmtResident : kFmt> Win;  // (kCurrent: {dst, word} is all that is loaded of a boundary record)
+    typedef WindowT<kCurrent ? kFmtResident : kFmt, kQ> Win;  // (kCurrent: {dst, word} is all that is loaded of a boundary record)
     struct Rec {  // a window as the paths below see it, whatever the format it arrived in
         unsigned int w3[kQ], w4[kQ];  // subject (resident: its dict_entry, or the subject | kCoreStale); core word (core_word)
     };
@@ -1102,7 +1123,7 @@ __global__ __launch_bounds__(tally_max_waves(kDictMode, kTrusted, kFmt, kPacked)
     // whole memory latency per window as soon as a window's tally is shorter than that, which it is since the fast window
     // shrank to ~100 instructions: 15 waves x 2 KiB per CU are not enough bytes in flight for 8 TB/s).  Three sets of 8 registers.
     // (boundary records: two sets of 16 registers -- 10 KiB of stream in flight per wave against 6 KiB of the resident format)
-    constexpr int kSets = kPacked ? RAPID_SETS_PACKED : kCurrent ? RAPID_SETS_CURRENT : kFmt == kFmtBoundary ? RAPID_SETS_BOUNDARY : RAPID_SETS;
+    constexpr int kSets = kPacked ? (kFmt == kFmtBoundary ? RAPID_SETS_PACKED_BOUNDARY : RAPID_SETS_PACKED) : kCurrent ? RAPID_SETS_CURRENT : kFmt == kFmtBoundary ? RAPID_SETS_BOUNDARY : RAPID_SETS;
     static_assert(kSets >= 2 && kSets <= 6, "window sets");
     constexpr unsigned int kWinBytes = (unsigned int)(kWin * kStride);
     Win S[kSets];
