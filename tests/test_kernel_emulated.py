@@ -926,3 +926,26 @@ def test_fast_round_settled_inside_the_tally_launch():
     for knob in (0, 131072):
         emit, nprop, pcount, fpr, props, stats = pyemu.tally(recs, off, n, K, H, L, cfg, obs, subj, member, force_exact=knob, grid=4, waves=3)
         assert np.array_equal(emit, fe2) and np.array_equal(fpr, proposal_fingerprints(fo2, fp2, fe2 >= 0))
+
+
+def test_packed_rounds_with_thousands_of_hot_subjects():
+    """The packed instantiations at the scale they exist for, as far as the emulator can go: 2,760 hot subjects (C3b's kind of round
+    at 54,000 nodes) -- the sweep over the hot slots takes eight slots per lane and step and needs a second turn of its outer loop
+    (more than 2,560 slots), a receiver's proposal is written in six pipelined batches of 512 slots, the last of them incomplete --
+    against the oracle, on boundary records looked up in memory and on resolved records."""
+    n, f, K, H, L = 54000, 2700, 10, 9, 4
+    pop = S.Population.make(n)
+    reg, view = oracle_view(pop, K)
+    obs, subj, member = view.tables(n)
+    cfg = view.getCurrentConfigurationId()
+    sc = S.build_scenario("C3b", subj, cfg, n=n, f=f, H=H, L=L, receivers=np.array([5, n - 99]))
+    fe, fn, fo, fp = O.fast_sim_run(n, K, H, L, cfg, obs, subj, member, sc.records, sc.rec_off)
+    assert (fe >= 0).all() and np.diff(fo).min() > 2560
+    for mode in (0, 3):
+        emit, nprop, pcount, fpr, props, stats = pyemu.tally(sc.records, sc.rec_off, n, K, H, L, cfg, obs, subj, member, tables_in_lds=mode,
+                                                            packed=True, trusted=True)
+        assert np.array_equal(emit, fe) and np.array_equal(nprop, fn) and np.array_equal(pcount, np.diff(fo))
+        for r in range(len(fe)):
+            assert props[r, : pcount[r]].tolist() == fp[fo[r]: fo[r + 1]].tolist(), (mode, r)
+        assert np.array_equal(fpr, proposal_fingerprints(fo, fp, fe >= 0))
+        assert int(stats[2]) > 0  # (sweeps over the hot slots happened)
