@@ -208,3 +208,31 @@ def test_a_round_in_one_call_equals_the_five_calls(E, hip):
         for p in (d_rec, d_off, d_al):
             assert hip.hipFree(p) == 0
     assert cuts[0] == cuts[1] and cfgs[0] == cfgs[1]
+
+
+def test_bench_line_of_a_small_configuration_in_the_driver_s_process_form(E):
+    """`python bench.py` as the driver starts it (a process of its own, one JSON line on stdout), on the smallest configuration: the
+    contract's keys, the roofline and cpu_baseline objects, the receive buffers chosen among the candidates (roofline.placement) --
+    and the same without the choice.  The line checks itself against the oracle (a mismatch is a non-zero exit)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--config", "C2", "--steps", "4", "--warmup", "2", "--no-pmc", "--reps", "1"]
+    for extra, chosen in ((["--placement-candidates", "2"], True), (["--placement-candidates", "0", "--no-cpu-baseline", "--no-extras"], False)):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                    "data", "config", "roofline"):
+            assert key in line, key
+        assert line["metric"] == "alert-batches/sec" and line["n_gpus"] == 1 and line["steps"] == 4 and line["value"] > 0
+        roof = line["roofline"]
+        assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0.0 < roof["frac"] < 1.0 and len(roof["kernel_ms_by_stream_set"]) == 2
+        if chosen:
+            assert len(roof["placement"]["candidates_ms"]) == 4 and len(roof["placement"]["kept"]) == 2
+            assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+            assert line["parity_checked"]["mismatches"] == 0
+        else:
+            assert roof["placement"] is None
